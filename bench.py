@@ -1,0 +1,176 @@
+#!/usr/bin/env python
+"""Headline benchmark: audio-seconds/s of the Wav2Vec2ForCTC forward (BASELINE.json).
+
+Workload (configs[1]): wav2vec2-base, fp32, forward only, batch 32 x 246000 samples of
+synthetic 16 kHz audio per GPU, random-init (seeded) weights.  A "step" is one forward of
+that batch with the input already resident in HBM.  Multi-GPU is pure data parallel: every
+rank runs its own 32-row shard, no collective on the data path (forward needs none); timing
+is bracketed by barrier + synchronize and the MAX over ranks is reported ("weak" scaling).
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline     -- the dominant kernel family (fp32 MFMA GEMM / implicit-GEMM conv): algorithmic
+                  FLOPs / HIP-event time of its launches inside the timed region, against the
+                  157.3 TFLOP/s fp32 matrix peak of gfx950.
+  cpu_baseline -- the CPU oracle (numpy restatement of the reference path; TensorFlow cannot be
+                  run here) timed on this box's host cores on a bounded sample (B=1), rank 0, N=1 only.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "gsoc-wav2vec2_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+SAMPLE_RATE = 16000
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(cfg, weights, L, max_seconds=30.0):
+    """CPU restatement of the reference path (oracle/, numpy+BLAS on all host cores), B=1."""
+    import numpy as np
+    from oracle import w2v2_oracle as O
+    from wav2vec2 import variables as V
+    x = V.hash_normal("bench/cpu", L, 0).reshape(1, L)
+    O.ctc_forward(cfg, weights, x)                     # warm-up (BLAS threads, page-in)
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 5 and (time.perf_counter() - t_start) < max_seconds:
+        t0 = time.perf_counter()
+        O.ctc_forward(cfg, weights, x)
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    return {
+        "value": round(L / SAMPLE_RATE / best, 3),
+        "unit": "audio-seconds/s",
+        "cores": os.cpu_count(),
+        "kind": "port",
+        "sample": f"numpy oracle (CPU restatement of the reference path; TensorFlow not run), wav2vec2-base fp32, "
+                  f"B=1 x {L} samples, best of {len(times)} after 1 warm-up",
+        "median_s": round(float(np.median(times)), 4),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="rows per GPU")
+    ap.add_argument("--samples", type=int, default=246000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import wav2vec2
+    from wav2vec2 import variables as V
+
+    cfg = wav2vec2.Wav2Vec2Config()
+    weights = V.seeded_weights(cfg, seed=0)
+    model = wav2vec2.Wav2Vec2ForCTC(cfg, input_shape=(args.batch, args.samples))
+    model.set_weights(weights)
+    B, L = args.batch, args.samples
+    T = cfg.num_frames(L)
+
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    x = torch.randn((B, L), generator=gen, device=dev, dtype=torch.float32)   # resident in HBM
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = model(x)
+    barrier()
+    if not args.no_profile:
+        model.profile(True)
+        model.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = model(x)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = model.profile_read() if not args.no_profile else {}
+    model.profile(False)
+    assert tuple(out.shape) == (B, T, cfg.vocab_size) and bool(torch.isfinite(out).all())
+
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        audio_s = world * B * L / SAMPLE_RATE * args.steps
+        res = {
+            "metric": "audio-seconds/s (wav2vec2-base forward, 246000-sample pad)",
+            "value": round(audio_s / elapsed, 2),
+            "unit": "audio-seconds/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"wav2vec2-base fp32 forward-only, batch={B}x{L} samples per GPU (BASELINE configs[1])",
+                       "global_batch": world * B, "samples": L, "frames": T, "parallelism": f"dp{world}"},
+        }
+        if prof:
+            gm = prof["gemm_f32"]
+            ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
+            res["roofline"] = {
+                "kernel": "gemm_f32_kernel (fp32 MFMA 32x32x2: conv1-6 implicit GEMM + all Dense layers)",
+                "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "launches_per_step": gm["launches"] // max(1, args.steps),
+                "avg_launch_ms": round(gm["ms"] / max(1, gm["launches"]), 4),
+            }
+            tot = sum(v["ms"] for v in prof.values())
+            res["families"] = {
+                k: {"ms_per_step": round(v["ms"] / args.steps, 3),
+                    "share": round(v["ms"] / tot, 4) if tot > 0 else 0.0,
+                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0,
+                    "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0.0}
+                for k, v in prof.items() if v["launches"] > 0}
+            # whole-forward algorithmic rate: 235.56 GFLOP per 246000-sample utterance scales with T
+            flops_step = sum(v["flops"] for k, v in prof.items() if k in ("gemm_f32", "pos_conv", "attention", "conv0_apply")) / args.steps
+            res["forward_tflops"] = round(flops_step * world / (elapsed / args.steps) / 1e12, 2)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg, weights, L)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

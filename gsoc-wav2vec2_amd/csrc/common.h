@@ -1,0 +1,130 @@
+// Shared host/device helpers for the gfx950 Wav2Vec2 path.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <string>
+
+#include "../../include/w2v2.h"
+
+namespace w2v2 {
+
+// ---- error plumbing (no exceptions across the C ABI) ----------------------
+void set_error(const char* fmt, ...);
+
+#define W2V2_HIP_CHECK(expr)                                                            \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            ::w2v2::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),    \
+                              __FILE__, __LINE__);                                      \
+            return W2V2_EHIP;                                                           \
+        }                                                                               \
+    } while (0)
+
+#define W2V2_REQUIRE(cond, ...)                \
+    do {                                       \
+        if (!(cond)) {                         \
+            ::w2v2::set_error(__VA_ARGS__);    \
+            return W2V2_EINVAL;                \
+        }                                      \
+    } while (0)
+
+// ---- kernel families (one row each in profiles/ and in the roofline) ------
+enum Family {
+    FAM_CONV0_STATS = 0,   // conv0 recompute + per-(sample,channel) sum/sumsq   (HBM: wave read)
+    FAM_CONV0_APPLY,       // conv0 recompute + GroupNorm + GELU + single write  (HBM: 100.76 MB/utt write)
+    FAM_GEMM,              // fp32 MFMA GEMM / implicit-GEMM conv / Dense        (MFMA f32)
+    FAM_LAYERNORM,         // row LayerNorm (+GELU)                              (HBM)
+    FAM_POSCONV,           // grouped positional conv, MFMA 16x16x4 f32          (MFMA f32)
+    FAM_ATTENTION,         // fused QK^T-softmax-PV, MFMA 32x32x2 f32            (MFMA f32)
+    FAM_CTC,               // CTC alpha/beta                                     (latency)
+    FAM_MISC,              // frame lengths, weight-norm regroup, packing
+    FAM_COUNT
+};
+const char* family_name(int f);
+
+// A launch record sink.  When `enabled`, every launch wrapper brackets its
+// kernel with an event pair on the launch stream and logs algorithmic
+// flops/bytes; reading synchronises the events.
+struct Profiler;
+Profiler* profiler_create();
+void profiler_destroy(Profiler*);
+void profiler_enable(Profiler*, bool on);
+bool profiler_enabled(const Profiler*);
+void profiler_reset(Profiler*);
+// returns a token (>=0) to pass to profiler_end, or -1 when disabled
+int profiler_begin(Profiler*, int family, double flops, double bytes, hipStream_t s);
+void profiler_end(Profiler*, int token, hipStream_t s);
+int profiler_read(Profiler*, int family, int64_t* launches, double* ms, double* flops, double* bytes);
+
+struct ProfScope {
+    Profiler* p;
+    int tok;
+    hipStream_t s;
+    ProfScope(Profiler* p_, int family, double flops, double bytes, hipStream_t s_)
+        : p(p_), tok(p_ ? profiler_begin(p_, family, flops, bytes, s_) : -1), s(s_) {}
+    ~ProfScope() {
+        if (tok >= 0) profiler_end(p, tok, s);
+    }
+};
+
+// ---- operator launchers (defined one per .hip file) ------------------------
+// All return 0 / negative W2V2_E*; `prof` may be null.
+int launch_gemm(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const float* B,
+                int64_t ldb, float* C, int64_t ldc, int64_t strideC, const float* bias,
+                const float* residual, int M, int N, int K, int nbatch, int act, hipStream_t s);
+
+int launch_layer_norm(Profiler* prof, const float* x, float* y, const float* gamma,
+                      const float* beta, int64_t rows, int C, float eps, int act, hipStream_t s);
+
+int64_t conv0_ws_floats(int B, int64_t L, int K, int stride, int C);
+int launch_conv0(Profiler* prof, const float* wave, const float* kernel, const float* bias,
+                 const float* gamma, const float* beta, float* out, float* ws, int B, int64_t L,
+                 int K, int stride, int C, float eps, int norm_mode, int act, hipStream_t s);
+
+int launch_weight_norm_regroup(Profiler* prof, const float* wv, const float* wg, float* out, int K,
+                               int cg, int H, int groups, hipStream_t s);
+int launch_pos_conv(Profiler* prof, const float* x, const float* wg, const float* bias,
+                    const int32_t* frame_len, float* y, int B, int T, int H, int K, int groups,
+                    int act, hipStream_t s);
+
+int launch_attention(Profiler* prof, const float* qkv, const int32_t* frame_len, float* ctx, int B,
+                     int T, int H, int heads, hipStream_t s);
+
+int launch_frame_lengths(Profiler* prof, const int32_t* mask, int32_t* frame_len, int B, int64_t L,
+                         const int32_t* ks, const int32_t* ss, int nl, hipStream_t s);
+
+int launch_ctc(Profiler* prof, const float* logits, int B, int T, int V, const int32_t* labels,
+               int U, const int32_t* label_len, const int32_t* logit_len, int blank, float* nll,
+               float* grad, hipStream_t s);
+
+// ---- device helpers ---------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ float gelu_erf(float x) {
+    // tf.nn.gelu(approximate=False): 0.5 x (1 + erf(x / sqrt(2)))
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_tanh(float x) {
+    const float c = 0.79788456080286535588f;  // sqrt(2/pi)
+    return 0.5f * x * (1.0f + tanhf(c * (x + 0.044715f * x * x * x)));
+}
+__device__ __forceinline__ float apply_act(float x, int act) {
+    return act == 1 ? gelu_erf(x) : (act == 2 ? gelu_tanh(x) : x);
+}
+// wave64 all-reduce sum via DPP/shuffles
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+#endif
+
+}  // namespace w2v2

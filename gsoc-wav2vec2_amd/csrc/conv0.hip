@@ -1,0 +1,210 @@
+// Layer 0 of the feature extractor: Conv1D(C_in = 1, K = 10, stride 5, valid) ->
+// GroupNormalization(groups = C) -> exact GELU, fused so the un-normalised conv
+// output (100.8 MB per 246000-sample utterance) is never written.
+//
+// Reference: feature_extractor.py:31-47,54-59 and tensorflow_addons.py:207-231.
+// With groups == channels the "group" norm is a per-(sample, channel) mean /
+// population variance over TIME (tf.nn.moments over axis 1), applied as
+// tf.nn.batch_normalization does:  y * inv + (beta - mean * inv),  inv = rsqrt(var+eps)*gamma.
+//
+// The stage is HBM-bound by its single output write.  Two passes over the raw
+// waveform (0.98 MB / utterance, L2-resident):
+//   pass 1 (stats):  recompute the 10-tap conv in registers, accumulate sum and
+//                    sum-of-squares per channel in fp64, one partial per time chunk;
+//   finalize:        fp64 combine of the chunk partials -> (scale, shift) per (b, c);
+//   pass 2 (apply):  recompute, scale/shift, GELU, write once, coalesced along C.
+// A thread owns channels (the kernel taps live in its registers); the waveform
+// chunk is staged in LDS and read as a wave-uniform broadcast.
+#include "common.h"
+
+namespace w2v2 {
+namespace {
+
+constexpr int TC = 64;          // frames per block
+constexpr int CPT_MAX = 2;      // channels per thread (C <= 512 with 256 threads), looped beyond
+
+struct Conv0Args {
+    const float* wave;
+    const float* kernel;   // (K, 1, C)
+    const float* bias;     // (C) or null
+    const float* gamma;
+    const float* beta;
+    float* out;            // (B, T0, C)
+    double* partial;       // (B, nchunks, 2, C)
+    float* scale_shift;    // (B, 2, C)
+    int64_t L;
+    int T0, K, stride, C, nchunks, norm_mode, act;
+    float eps;
+};
+
+// MODE 0: stats, MODE 1: apply (group norm), MODE 2: plain conv(+bias) write
+template <int MODE, int KT, int ST>
+__global__ __launch_bounds__(256) void conv0_kernel(Conv0Args a) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    const int K = KT > 0 ? KT : a.K;
+    const int S = ST > 0 ? ST : a.stride;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int t0 = chunk * TC;
+    const int nt = min(TC, a.T0 - t0);
+    const int nx = (nt - 1) * S + K;
+    const float* __restrict__ wv = a.wave + (int64_t)b * a.L + (int64_t)t0 * S;
+    for (int i = threadIdx.x; i < nx; i += 256) xs[i] = wv[i];
+    __syncthreads();
+
+    for (int c0 = threadIdx.x; c0 < a.C; c0 += 256 * CPT_MAX) {
+        // taps of up to CPT_MAX channels in registers
+        float w[CPT_MAX][KT > 0 ? KT : 32];
+        float bs[CPT_MAX], sc[CPT_MAX], sh[CPT_MAX];
+        double s1[CPT_MAX], s2[CPT_MAX];
+#pragma unroll
+        for (int j = 0; j < CPT_MAX; ++j) {
+            const int c = c0 + 256 * j;
+            const bool ok = c < a.C;
+#pragma unroll
+            for (int k = 0; k < (KT > 0 ? KT : 32); ++k)
+                w[j][k] = (ok && k < K) ? a.kernel[(int64_t)k * a.C + c] : 0.f;
+            bs[j] = (ok && a.bias) ? a.bias[c] : 0.f;
+            s1[j] = 0.0; s2[j] = 0.0;
+            if (MODE == 1 && ok) {
+                sc[j] = a.scale_shift[((int64_t)b * 2 + 0) * a.C + c];
+                sh[j] = a.scale_shift[((int64_t)b * 2 + 1) * a.C + c];
+            } else {
+                sc[j] = 1.f; sh[j] = 0.f;
+            }
+        }
+        for (int t = 0; t < nt; ++t) {
+            const float* xp = xs + t * S;
+            float y[CPT_MAX];
+#pragma unroll
+            for (int j = 0; j < CPT_MAX; ++j) y[j] = bs[j];
+            if (KT > 0) {
+#pragma unroll
+                for (int k = 0; k < (KT > 0 ? KT : 1); ++k) {
+                    const float xv = xp[k];
+#pragma unroll
+                    for (int j = 0; j < CPT_MAX; ++j) y[j] = fmaf(xv, w[j][k], y[j]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) {
+                    if (k < K) {
+                        const float xv = xp[k];
+#pragma unroll
+                        for (int j = 0; j < CPT_MAX; ++j) y[j] = fmaf(xv, w[j][k], y[j]);
+                    }
+                }
+            }
+            if (MODE == 0) {
+#pragma unroll
+                for (int j = 0; j < CPT_MAX; ++j) {
+                    s1[j] += (double)y[j];
+                    s2[j] += (double)y[j] * (double)y[j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < CPT_MAX; ++j) {
+                    const int c = c0 + 256 * j;
+                    if (c < a.C) {
+                        float v = MODE == 1 ? apply_act(fmaf(y[j], sc[j], sh[j]), a.act) : y[j];
+                        a.out[((int64_t)b * a.T0 + t0 + t) * a.C + c] = v;
+                    }
+                }
+            }
+        }
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < CPT_MAX; ++j) {
+                const int c = c0 + 256 * j;
+                if (c < a.C) {
+                    double* p = a.partial + (((int64_t)b * a.nchunks + chunk) * 2) * a.C;
+                    p[c] = s1[j];
+                    p[a.C + c] = s2[j];
+                }
+            }
+        }
+    }
+}
+
+// (b, c): fp64 combine of chunk partials -> scale = rsqrt(var+eps)*gamma, shift = beta - mean*scale
+__global__ void conv0_finalize_kernel(Conv0Args a, int B) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * a.C) return;
+    const int b = (int)(i / a.C), c = (int)(i % a.C);
+    double s1 = 0.0, s2 = 0.0;
+    for (int ch = 0; ch < a.nchunks; ++ch) {
+        const double* p = a.partial + (((int64_t)b * a.nchunks + ch) * 2) * a.C;
+        s1 += p[c];
+        s2 += p[a.C + c];
+    }
+    const double n = (double)a.T0;
+    const double mean = s1 / n;
+    double var = s2 / n - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const double inv = (double)a.gamma[c] / sqrt(var + (double)a.eps);
+    a.scale_shift[((int64_t)b * 2 + 0) * a.C + c] = (float)inv;
+    a.scale_shift[((int64_t)b * 2 + 1) * a.C + c] = (float)((double)a.beta[c] - mean * inv);
+}
+
+template <int MODE>
+void launch_mode(const Conv0Args& a, int B, hipStream_t s) {
+    dim3 grid(a.nchunks, B), block(256);
+    const size_t lds = ((size_t)(TC - 1) * a.stride + a.K + 4) * sizeof(float);
+    if (a.K == 10 && a.stride == 5)
+        hipLaunchKernelGGL((conv0_kernel<MODE, 10, 5>), grid, block, lds, s, a);
+    else
+        hipLaunchKernelGGL((conv0_kernel<MODE, 0, 0>), grid, block, lds, s, a);
+}
+
+}  // namespace
+
+static inline int conv0_nchunks(int64_t L, int K, int stride) {
+    const int64_t T0 = 1 + (L - K) / stride;
+    return (int)((T0 + TC - 1) / TC);
+}
+
+int64_t conv0_ws_floats(int B, int64_t L, int K, int stride, int C) {
+    if (L < K || stride <= 0) return 0;
+    const int64_t nch = conv0_nchunks(L, K, stride);
+    return 2 * ((int64_t)B * nch * 2 * C) /* fp64 partials */ + (int64_t)B * 2 * C + 8;
+}
+
+int launch_conv0(Profiler* prof, const float* wave, const float* kernel, const float* bias,
+                 const float* gamma, const float* beta, float* out, float* ws, int B, int64_t L,
+                 int K, int stride, int C, float eps, int norm_mode, int act, hipStream_t s) {
+    W2V2_REQUIRE(wave && kernel && out, "conv0: null operand");
+    W2V2_REQUIRE(B > 0 && C > 0 && K > 0 && K <= 32 && stride > 0 && L >= K,
+                 "conv0: unsupported B=%d C=%d K=%d stride=%d L=%lld", B, C, K, stride, (long long)L);
+    W2V2_REQUIRE(norm_mode == 0 || norm_mode == 1, "conv0: bad norm_mode %d", norm_mode);
+    Conv0Args a;
+    a.wave = wave; a.kernel = kernel; a.bias = bias; a.gamma = gamma; a.beta = beta; a.out = out;
+    a.L = L; a.K = K; a.stride = stride; a.C = C; a.eps = eps; a.norm_mode = norm_mode; a.act = act;
+    a.T0 = (int)(1 + (L - K) / stride);
+    a.nchunks = conv0_nchunks(L, K, stride);
+    const double out_bytes = 4.0 * B * (double)a.T0 * C, in_bytes = 4.0 * B * (double)L;
+    const double flops = 2.0 * B * (double)a.T0 * C * K;
+    if (norm_mode == 1) {
+        ProfScope ps(prof, FAM_CONV0_APPLY, flops, in_bytes + out_bytes, s);
+        launch_mode<2>(a, B, s);
+        W2V2_HIP_CHECK(hipGetLastError());
+        return W2V2_OK;
+    }
+    W2V2_REQUIRE(ws && gamma && beta, "conv0: group-norm mode needs workspace, gamma and beta");
+    // workspace: 8-byte aligned fp64 partials first, then fp32 scale/shift
+    uintptr_t p = (reinterpret_cast<uintptr_t>(ws) + 7) & ~(uintptr_t)7;
+    a.partial = reinterpret_cast<double*>(p);
+    a.scale_shift = reinterpret_cast<float*>(a.partial + (int64_t)B * a.nchunks * 2 * C);
+    {
+        ProfScope ps(prof, FAM_CONV0_STATS, flops, in_bytes, s);
+        launch_mode<0>(a, B, s);
+        const int64_t n = (int64_t)B * C;
+        hipLaunchKernelGGL(conv0_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, B);
+    }
+    {
+        ProfScope ps(prof, FAM_CONV0_APPLY, flops, in_bytes + out_bytes, s);
+        launch_mode<1>(a, B, s);
+    }
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
+}  // namespace w2v2

@@ -1,0 +1,243 @@
+// CTC negative log-likelihood and its gradient w.r.t. the logits, fp64 recursions.
+//
+// Reference: CTCLoss.call (losses.py:14-45) -> tf.nn.ctc_loss(labels, logits,
+// label_length, logit_length, logits_time_major=False, blank_index=pad_id).
+// Per sample: log-softmax over the vocabulary, the alpha recursion over the
+// blank-interleaved label string (2U+1 states), nll = -log p(labels | logits).
+// Gradient (what TF's registered gradient returns for the unnormalised logits):
+//   d nll / d logits[t, v] = softmax(logits[t])[v] - sum_{s: ext[s]=v} alpha_t(s) beta_t(s) / (y_t(v) p)
+//
+// One workgroup per sample; the recursion is sequential in t, parallel over the
+// <= 513 states.  The loss sums ~768 log-probabilities of magnitude ~1 into a
+// value of magnitude ~1e3, so the recursions run in fp64 (ulp(1e3) in fp32 is
+// 6e-5 per step); fp64 VALU is plentiful on gfx950 and this stage is latency-
+// bound on the per-frame barrier, not on arithmetic.
+#include "common.h"
+
+namespace w2v2 {
+namespace {
+
+constexpr int CTC_THREADS = 256;
+constexpr double NEG_INF = -1e300;   // finite sentinel: keeps (a - m) well-defined
+
+__device__ __forceinline__ double lse2(double a, double b) {
+    const double m = a > b ? a : b;
+    if (m <= NEG_INF) return NEG_INF;
+    return m + log(exp(a - m) + exp(b - m));
+}
+__device__ __forceinline__ double lse3(double a, double b, double c) {
+    double m = a > b ? a : b;
+    m = m > c ? m : c;
+    if (m <= NEG_INF) return NEG_INF;
+    return m + log(exp(a - m) + exp(b - m) + exp(c - m));
+}
+
+struct CtcArgs {
+    const float* logits;      // (B, T, V)
+    const int32_t* labels;    // (B, U)
+    const int32_t* label_len;
+    const int32_t* logit_len;
+    float* nll;               // (B)
+    float* grad;              // (B, T, V) or null
+    double* alpha_ws;         // (B, T, S_max) when grad != null
+    int B, T, V, U, blank, S_max;
+};
+
+// dynamic LDS: double lse[T]; double ab[2][S_max]; double occ[V]; int ext[S_max]
+__global__ __launch_bounds__(CTC_THREADS) void ctc_kernel(CtcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
+    double* lse = reinterpret_cast<double*>(raw);
+    double* buf0 = lse + a.T;
+    double* buf1 = buf0 + a.S_max;
+    double* occ = buf1 + a.S_max;
+    int* ext = reinterpret_cast<int*>(occ + a.V);
+    __shared__ double nll_sh;
+
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int U = a.label_len[b];
+    U = U < 0 ? 0 : (U > a.U ? a.U : U);
+    int Tb = a.logit_len[b];
+    Tb = Tb < 0 ? 0 : (Tb > a.T ? a.T : Tb);
+    const int S = 2 * U + 1;
+    const float* __restrict__ lg = a.logits + (int64_t)b * a.T * a.V;
+
+    for (int s = tid; s < S; s += CTC_THREADS) ext[s] = (s & 1) ? a.labels[(int64_t)b * a.U + (s >> 1)] : a.blank;
+    // log-sum-exp per frame (fp64)
+    for (int t = tid; t < Tb; t += CTC_THREADS) {
+        const float* r = lg + (int64_t)t * a.V;
+        float m = r[0];
+        for (int v = 1; v < a.V; ++v) m = fmaxf(m, r[v]);
+        double acc = 0.0;
+        for (int v = 0; v < a.V; ++v) acc += exp((double)r[v] - (double)m);
+        lse[t] = (double)m + log(acc);
+    }
+    __syncthreads();
+    if (Tb == 0) {
+        if (tid == 0) a.nll[b] = U == 0 ? 0.0f : INFINITY;
+        if (a.grad)
+            for (int64_t i = tid; i < (int64_t)a.T * a.V; i += CTC_THREADS) a.grad[(int64_t)b * a.T * a.V + i] = 0.f;
+        return;
+    }
+    auto logp = [&](int t, int s) { return (double)lg[(int64_t)t * a.V + ext[s]] - lse[t]; };
+
+    // ---- alpha ----
+    double* prev = buf0;
+    double* cur = buf1;
+    double* aw = a.grad ? a.alpha_ws + (int64_t)b * a.T * a.S_max : nullptr;
+    for (int s = tid; s < S; s += CTC_THREADS) {
+        const double v = s < 2 ? logp(0, s) : NEG_INF;
+        prev[s] = v;
+        if (aw) aw[s] = v;
+    }
+    __syncthreads();
+    for (int t = 1; t < Tb; ++t) {
+        for (int s = tid; s < S; s += CTC_THREADS) {
+            const double a0 = prev[s];
+            const double a1 = s >= 1 ? prev[s - 1] : NEG_INF;
+            const bool skip = s >= 2 && (s & 1) && ext[s] != ext[s - 2];
+            const double a2 = skip ? prev[s - 2] : NEG_INF;
+            double v = lse3(a0, a1, a2);
+            v = v <= NEG_INF ? NEG_INF : v + logp(t, s);
+            cur[s] = v;
+            if (aw) aw[(int64_t)t * a.S_max + s] = v;
+        }
+        __syncthreads();
+        double* tmp = prev; prev = cur; cur = tmp;
+    }
+    if (tid == 0) {
+        const double tot = S >= 2 ? lse2(prev[S - 1], prev[S - 2]) : prev[0];
+        nll_sh = tot <= NEG_INF ? (double)INFINITY : -tot;
+        a.nll[b] = (float)nll_sh;
+    }
+    __syncthreads();
+    if (!a.grad) return;
+
+    // ---- beta + gradient ----
+    const double nll = nll_sh;
+    float* __restrict__ gr = a.grad + (int64_t)b * a.T * a.V;
+    for (int64_t i = (int64_t)Tb * a.V + tid; i < (int64_t)a.T * a.V; i += CTC_THREADS) gr[i] = 0.f;  // frames past logit_length
+    const bool feasible = isfinite(nll);
+    double* bprev = buf0;
+    double* bcur = buf1;
+    for (int t = Tb - 1; t >= 0; --t) {
+        for (int v = tid; v < a.V; v += CTC_THREADS) occ[v] = 0.0;
+        for (int s = tid; s < S; s += CTC_THREADS) {
+            double v;
+            if (t == Tb - 1) {
+                v = (s >= S - 2) ? logp(t, s) : NEG_INF;
+            } else {
+                const double b0 = bprev[s];
+                const double b1 = s + 1 < S ? bprev[s + 1] : NEG_INF;
+                const bool skip = s + 2 < S && (s & 1) && ext[s] != ext[s + 2];
+                const double b2 = skip ? bprev[s + 2] : NEG_INF;
+                v = lse3(b0, b1, b2);
+                v = v <= NEG_INF ? NEG_INF : v + logp(t, s);
+            }
+            bcur[s] = v;
+        }
+        __syncthreads();
+        if (feasible) {
+            for (int s = tid; s < S; s += CTC_THREADS) {
+                const double al = aw[(int64_t)t * a.S_max + s], be = bcur[s];
+                if (al > NEG_INF && be > NEG_INF) {
+                    // alpha_t(s) beta_t(s) / y_t(ext[s]) / p   (both carry the emission at t once)
+                    const double w = exp(al + be - logp(t, s) + nll);
+                    atomicAdd(&occ[ext[s]], w);
+                }
+            }
+        }
+        __syncthreads();
+        for (int v = tid; v < a.V; v += CTC_THREADS) {
+            const double sm = exp((double)lg[(int64_t)t * a.V + v] - lse[t]);
+            gr[(int64_t)t * a.V + v] = feasible ? (float)(sm - occ[v]) : 0.f;
+        }
+        __syncthreads();
+        double* tmp = bprev; bprev = bcur; bcur = tmp;
+    }
+}
+
+struct LenArgs {
+    int32_t ks[W2V2_MAX_CONV_LAYERS], ss[W2V2_MAX_CONV_LAYERS];
+    int nl;
+};
+
+__global__ void frame_len_kernel(const int32_t* __restrict__ mask, int32_t* __restrict__ out,
+                                 int64_t L, LenArgs la) {
+    __shared__ long long red[4];
+    const int b = blockIdx.x;
+    long long acc = 0;
+    for (int64_t i = threadIdx.x; i < L; i += 256) acc += mask[(int64_t)b * L + i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long n = red[0] + red[1] + red[2] + red[3];
+        // 1 + (len - k) // s with floor semantics (modeling.py:202-204)
+        for (int i = 0; i < la.nl; ++i) {
+            const long long d = n - la.ks[i];
+            const long long q = d >= 0 ? d / la.ss[i] : -((-d + la.ss[i] - 1) / la.ss[i]);
+            n = 1 + q;
+        }
+        out[b] = (int32_t)(n < 0 ? 0 : n);
+    }
+}
+
+double* g_alpha_ws = nullptr;
+size_t g_alpha_bytes = 0;
+
+}  // namespace
+
+int launch_ctc(Profiler* prof, const float* logits, int B, int T, int V, const int32_t* labels,
+               int U, const int32_t* label_len, const int32_t* logit_len, int blank, float* nll,
+               float* grad, hipStream_t s) {
+    W2V2_REQUIRE(logits && labels && label_len && logit_len && nll, "ctc: null operand");
+    W2V2_REQUIRE(B > 0 && T > 0 && V > 0 && U >= 0, "ctc: bad sizes");
+    W2V2_REQUIRE(blank >= 0 && blank < V, "ctc: blank index %d outside vocabulary %d", blank, V);
+    CtcArgs a;
+    a.logits = logits; a.labels = labels; a.label_len = label_len; a.logit_len = logit_len;
+    a.nll = nll; a.grad = grad; a.B = B; a.T = T; a.V = V; a.U = U; a.blank = blank;
+    a.S_max = 2 * U + 1;
+    a.alpha_ws = nullptr;
+    if (grad) {
+        const size_t need = (size_t)B * T * a.S_max * sizeof(double);
+        if (need > g_alpha_bytes) {            // grow-only scratch owned by the library
+            if (g_alpha_ws) W2V2_HIP_CHECK(hipFree(g_alpha_ws));
+            g_alpha_ws = nullptr; g_alpha_bytes = 0;
+            W2V2_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g_alpha_ws), need));
+            g_alpha_bytes = need;
+        }
+        a.alpha_ws = g_alpha_ws;
+    }
+    const size_t lds = (size_t)(T + 2 * a.S_max + V) * sizeof(double) + (size_t)a.S_max * sizeof(int) + 16;
+    W2V2_REQUIRE(lds <= 150 * 1024, "ctc: T=%d U=%d needs %zu B of LDS", T, U, lds);
+    static bool attr_set = false;
+    if (!attr_set) {
+        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    ProfScope ps(prof, FAM_CTC, 30.0 * B * (double)T * a.S_max, 4.0 * B * (double)T * V * (grad ? 2 : 1), s);
+    hipLaunchKernelGGL(ctc_kernel, dim3(B), dim3(CTC_THREADS), lds, s, a);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
+int launch_frame_lengths(Profiler* prof, const int32_t* mask, int32_t* frame_len, int B, int64_t L,
+                         const int32_t* ks, const int32_t* ss, int nl, hipStream_t s) {
+    W2V2_REQUIRE(mask && frame_len && ks && ss, "frame_lengths: null operand");
+    W2V2_REQUIRE(B > 0 && L > 0 && nl > 0 && nl <= W2V2_MAX_CONV_LAYERS, "frame_lengths: bad sizes");
+    ProfScope ps(prof, FAM_MISC, 0.0, 4.0 * B * (double)L, s);
+    LenArgs la;
+    la.nl = nl;
+    for (int i = 0; i < nl; ++i) {
+        W2V2_REQUIRE(ss[i] > 0, "frame_lengths: stride must be positive");
+        la.ks[i] = ks[i];
+        la.ss[i] = ss[i];
+    }
+    hipLaunchKernelGGL(frame_len_kernel, dim3(B), dim3(256), 0, s, mask, frame_len, L, la);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
+}  // namespace w2v2

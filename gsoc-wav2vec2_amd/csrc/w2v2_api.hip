@@ -1,0 +1,617 @@
+// C ABI (include/w2v2.h): model lifetime, variable I/O, the forward orchestration,
+// profiling and the single-operator entry points.  Host code only; the kernels
+// live in the sibling .hip files.
+//
+// Forward order follows the reference exactly: Wav2Vec2ForCTC.call
+// (modeling.py:239-255) -> Wav2Vec2Model.call (modeling.py:169-209) ->
+// FeatureExtractorLayer x7 (feature_extractor.py:54-59) -> FeatureProjection
+// (feature_extractor.py:92-95) -> Wav2Vec2Encoder.call (encoder.py:251-276) ->
+// TransformerLayer.call (encoder.py:111-134) -> lm_head.
+#include <stdarg.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+
+namespace w2v2 {
+
+// ---- errors ---------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+const char* family_name(int f) {
+    static const char* names[FAM_COUNT] = {"conv0_stats", "conv0_apply", "gemm_f32", "layer_norm",
+                                           "pos_conv",    "attention",   "ctc",      "misc"};
+    return (f >= 0 && f < FAM_COUNT) ? names[f] : "?";
+}
+
+// ---- profiler ---------------------------------------------------------------
+struct ProfRec {
+    int family;
+    double flops, bytes;
+    hipEvent_t e0, e1;
+};
+struct Profiler {
+    bool enabled = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;   // recycled events
+};
+Profiler* profiler_create() { return new Profiler(); }
+void profiler_reset(Profiler* p) {
+    for (auto& r : p->recs) {
+        p->pool.push_back(r.e0);
+        p->pool.push_back(r.e1);
+    }
+    p->recs.clear();
+}
+void profiler_destroy(Profiler* p) {
+    if (!p) return;
+    profiler_reset(p);
+    for (auto e : p->pool) (void)hipEventDestroy(e);
+    delete p;
+}
+void profiler_enable(Profiler* p, bool on) { p->enabled = on; }
+bool profiler_enabled(const Profiler* p) { return p->enabled; }
+static hipEvent_t prof_event(Profiler* p) {
+    if (!p->pool.empty()) {
+        hipEvent_t e = p->pool.back();
+        p->pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+int profiler_begin(Profiler* p, int family, double flops, double bytes, hipStream_t s) {
+    if (!p || !p->enabled) return -1;
+    ProfRec r{family, flops, bytes, prof_event(p), prof_event(p)};
+    (void)hipEventRecord(r.e0, s);
+    p->recs.push_back(r);
+    return (int)p->recs.size() - 1;
+}
+void profiler_end(Profiler* p, int token, hipStream_t s) {
+    if (!p || token < 0 || token >= (int)p->recs.size()) return;
+    (void)hipEventRecord(p->recs[token].e1, s);
+}
+int profiler_read(Profiler* p, int family, int64_t* launches, double* ms, double* flops, double* bytes) {
+    int64_t n = 0;
+    double t = 0, f = 0, by = 0;
+    for (auto& r : p->recs) {
+        if (r.family != family) continue;
+        W2V2_HIP_CHECK(hipEventSynchronize(r.e1));
+        float dt = 0.f;
+        W2V2_HIP_CHECK(hipEventElapsedTime(&dt, r.e0, r.e1));
+        t += dt; f += r.flops; by += r.bytes; ++n;
+    }
+    *launches = n; *ms = t; *flops = f; *bytes = by;
+    return W2V2_OK;
+}
+
+}  // namespace w2v2
+
+using namespace w2v2;
+
+// ---- model ------------------------------------------------------------------
+struct Param {
+    std::string name;
+    std::vector<int64_t> shape;
+    int64_t numel = 0;
+    float* dev = nullptr;
+    bool set = false;
+};
+struct Act {
+    float* ptr;
+    int64_t shape[3];
+};
+
+struct w2v2_model {
+    w2v2_config cfg;
+    std::vector<Param> params;
+    std::unordered_map<std::string, int> index;
+    // derived tensors (w2v2_finalize)
+    float* pos_wg = nullptr;                 // (groups, K, cg, og)
+    std::vector<float*> qkv_w, qkv_b;        // per layer (H, 3H), (3H)
+    bool finalized = false;
+    // activation workspace
+    int ws_B = 0;
+    int64_t ws_L = 0;
+    std::vector<void*> allocs;
+    std::map<std::string, Act> acts;
+    std::vector<float*> conv;                // conv stack outputs
+    std::vector<int> conv_T;
+    float *conv0_ws = nullptr, *ln512 = nullptr, *proj = nullptr, *posout = nullptr;
+    std::vector<float*> hs;                  // hidden states: encoder_in, layer0..N-1
+    float *qkv = nullptr, *ctx = nullptr, *t0 = nullptr, *t1 = nullptr, *t2 = nullptr, *t3 = nullptr,
+          *ffn = nullptr, *enc_out = nullptr;
+    int32_t* frame_len = nullptr;
+    Profiler* prof = nullptr;
+
+    float* P(const std::string& n) const {
+        auto it = index.find(n);
+        return it == index.end() ? nullptr : params[it->second].dev;
+    }
+};
+
+static void add_param(w2v2_model* m, const std::string& name, std::vector<int64_t> shape) {
+    Param p;
+    p.name = name;
+    p.shape = shape;
+    p.numel = 1;
+    for (auto d : shape) p.numel *= d;
+    m->index[name] = (int)m->params.size();
+    m->params.push_back(p);
+}
+
+// Same inventory and order as gsoc-wav2vec2_amd/wav2vec2/variables.py (the
+// reference's 213 variables for base CTC).
+static void build_inventory(w2v2_model* m) {
+    const w2v2_config& c = m->cfg;
+    const int64_t H = c.hidden_size, F = c.intermediate_size;
+    add_param(m, "masked_spec_embed", {H});
+    int64_t cin = 1;
+    for (int i = 0; i < c.num_conv_layers; ++i) {
+        const std::string b = "feature_extractor/conv_layers/" + std::to_string(i);
+        add_param(m, b + "/conv/kernel", {c.kernal_sizes[i], cin, c.filter_sizes[i]});
+        if (c.conv_bias) add_param(m, b + "/conv/bias", {c.filter_sizes[i]});
+        if (c.feature_extractor_norm_type == 1 || i == 0) {
+            add_param(m, b + "/layer_norm/gamma", {c.filter_sizes[i]});
+            add_param(m, b + "/layer_norm/beta", {c.filter_sizes[i]});
+        }
+        cin = c.filter_sizes[i];
+    }
+    add_param(m, "feature_projection/layer_norm/gamma", {cin});
+    add_param(m, "feature_projection/layer_norm/beta", {cin});
+    add_param(m, "feature_projection/projection/kernel", {cin, H});
+    add_param(m, "feature_projection/projection/bias", {H});
+    const int64_t K = c.num_conv_pos_embeddings, G = c.num_conv_pos_embedding_groups;
+    add_param(m, "encoder/pos_conv_embed/conv/bias", {H});
+    add_param(m, "encoder/pos_conv_embed/conv/weight_g", {K, 1, 1});
+    add_param(m, "encoder/pos_conv_embed/conv/weight_v", {K, H / G, H});
+    add_param(m, "encoder/layer_norm/gamma", {H});
+    add_param(m, "encoder/layer_norm/beta", {H});
+    for (int i = 0; i < c.num_layers; ++i) {
+        const std::string b = "encoder/layers/" + std::to_string(i);
+        for (const char* p : {"q_proj", "k_proj", "v_proj", "out_proj"}) {
+            add_param(m, b + "/attention/" + p + "/kernel", {H, H});
+            add_param(m, b + "/attention/" + p + "/bias", {H});
+        }
+        add_param(m, b + "/layer_norm/gamma", {H});
+        add_param(m, b + "/layer_norm/beta", {H});
+        add_param(m, b + "/feed_forward/intermediate_dense/kernel", {H, F});
+        add_param(m, b + "/feed_forward/intermediate_dense/bias", {F});
+        add_param(m, b + "/feed_forward/output_dense/kernel", {F, H});
+        add_param(m, b + "/feed_forward/output_dense/bias", {H});
+        add_param(m, b + "/final_layer_norm/gamma", {H});
+        add_param(m, b + "/final_layer_norm/beta", {H});
+    }
+    if (c.with_lm_head) {
+        add_param(m, "lm_head/kernel", {H, c.vocab_size});
+        add_param(m, "lm_head/bias", {c.vocab_size});
+    }
+}
+
+static void free_workspace(w2v2_model* m) {
+    for (void* p : m->allocs) (void)hipFree(p);
+    m->allocs.clear();
+    m->acts.clear();
+    m->conv.clear();
+    m->conv_T.clear();
+    m->hs.clear();
+    m->ws_B = 0;
+    m->ws_L = 0;
+}
+
+static int ws_alloc(w2v2_model* m, float** out, int64_t floats) {
+    void* p = nullptr;
+    W2V2_HIP_CHECK(hipMalloc(&p, (size_t)(floats > 0 ? floats : 1) * sizeof(float)));
+    m->allocs.push_back(p);
+    *out = reinterpret_cast<float*>(p);
+    return W2V2_OK;
+}
+
+static int ensure_workspace(w2v2_model* m, int B, int64_t L) {
+    if (m->ws_B == B && m->ws_L == L) return W2V2_OK;
+    free_workspace(m);
+    const w2v2_config& c = m->cfg;
+    const int64_t H = c.hidden_size, F = c.intermediate_size;
+    int64_t T = L;
+    for (int i = 0; i < c.num_conv_layers; ++i) {
+        T = 1 + (T - c.kernal_sizes[i]) / c.strides[i];
+        float* p = nullptr;
+        if (int e = ws_alloc(m, &p, (int64_t)B * T * c.filter_sizes[i])) return e;
+        m->conv.push_back(p);
+        m->conv_T.push_back((int)T);
+        m->acts["conv" + std::to_string(i)] = Act{p, {B, T, c.filter_sizes[i]}};
+    }
+    const int64_t C = c.filter_sizes[c.num_conv_layers - 1];
+    const int64_t BT = (int64_t)B * T;
+    if (int e = ws_alloc(m, &m->conv0_ws, conv0_ws_floats(B, L, c.kernal_sizes[0], c.strides[0], c.filter_sizes[0]))) return e;
+    if (int e = ws_alloc(m, &m->ln512, BT * C)) return e;
+    if (int e = ws_alloc(m, &m->proj, BT * H)) return e;
+    if (int e = ws_alloc(m, &m->posout, BT * H)) return e;
+    m->acts["projection"] = Act{m->proj, {B, T, H}};
+    for (int i = 0; i <= c.num_layers; ++i) {
+        float* p = nullptr;
+        if (c.attention_norm_type == 1 && i == 0) {
+            p = m->posout;           // prenorm: encoder_in IS x + pos_conv(x)
+        } else if (int e = ws_alloc(m, &p, BT * H)) {
+            return e;
+        }
+        m->hs.push_back(p);
+        m->acts[i == 0 ? std::string("encoder_in") : "layer" + std::to_string(i - 1)] = Act{p, {B, T, H}};
+    }
+    if (int e = ws_alloc(m, &m->qkv, BT * 3 * H)) return e;
+    if (int e = ws_alloc(m, &m->ctx, BT * H)) return e;
+    if (int e = ws_alloc(m, &m->t0, BT * H)) return e;
+    if (int e = ws_alloc(m, &m->t1, BT * H)) return e;
+    if (int e = ws_alloc(m, &m->t2, BT * H)) return e;
+    if (int e = ws_alloc(m, &m->t3, BT * H)) return e;
+    if (int e = ws_alloc(m, &m->ffn, BT * F)) return e;
+    if (c.attention_norm_type == 1) {
+        if (int e = ws_alloc(m, &m->enc_out, BT * H)) return e;
+    } else {
+        m->enc_out = m->hs[c.num_layers];
+    }
+    m->acts["encoder_out"] = Act{m->enc_out, {B, T, H}};
+    float* fl = nullptr;
+    if (int e = ws_alloc(m, &fl, B + 4)) return e;
+    m->frame_len = reinterpret_cast<int32_t*>(fl);
+    m->ws_B = B;
+    m->ws_L = L;
+    return W2V2_OK;
+}
+
+extern "C" {
+
+const char* w2v2_last_error(void) { return g_err; }
+const char* w2v2_version(void) { return "w2v2-gfx950 0.1 (fp32 MFMA path)"; }
+
+int w2v2_create(const w2v2_config* cfg, w2v2_model** out) {
+    W2V2_REQUIRE(cfg && out, "create: null argument");
+    const w2v2_config& c = *cfg;
+    W2V2_REQUIRE(c.num_conv_layers > 0 && c.num_conv_layers <= W2V2_MAX_CONV_LAYERS, "create: num_conv_layers=%d", c.num_conv_layers);
+    W2V2_REQUIRE(c.hidden_size > 0 && c.num_heads > 0 && c.hidden_size % c.num_heads == 0,
+                 "create: hidden_size %d is not a multiple of num_heads %d", c.hidden_size, c.num_heads);
+    W2V2_REQUIRE(c.num_conv_pos_embedding_groups > 0 && c.hidden_size % c.num_conv_pos_embedding_groups == 0,
+                 "create: hidden_size %d is not a multiple of the positional conv groups", c.hidden_size);
+    W2V2_REQUIRE(c.feature_extractor_norm_type == 0 || c.feature_extractor_norm_type == 1, "create: bad conv norm type");
+    W2V2_REQUIRE(c.attention_norm_type == 0 || c.attention_norm_type == 1, "create: bad attention norm type");
+    W2V2_REQUIRE(c.num_layers >= 1 && c.intermediate_size > 0 && c.vocab_size > 0, "create: bad transformer sizes");
+    for (int i = 0; i < c.num_conv_layers; ++i) {
+        W2V2_REQUIRE(c.filter_sizes[i] > 0 && c.kernal_sizes[i] > 0 && c.strides[i] > 0, "create: bad conv layer %d", i);
+        W2V2_REQUIRE(c.filter_sizes[i] % 4 == 0, "create: conv filters must be a multiple of 4");
+    }
+    w2v2_model* m = new w2v2_model();
+    m->cfg = c;
+    build_inventory(m);
+    for (auto& p : m->params) {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p.dev), (size_t)p.numel * sizeof(float));
+        if (e == hipSuccess) e = hipMemset(p.dev, 0, (size_t)p.numel * sizeof(float));
+        if (e != hipSuccess) {
+            set_error("create: allocating `%s` failed: %s", p.name.c_str(), hipGetErrorString(e));
+            w2v2_destroy(m);
+            return W2V2_EHIP;
+        }
+    }
+    m->prof = profiler_create();
+    *out = m;
+    return W2V2_OK;
+}
+
+void w2v2_destroy(w2v2_model* m) {
+    if (!m) return;
+    free_workspace(m);
+    for (auto& p : m->params)
+        if (p.dev) (void)hipFree(p.dev);
+    if (m->pos_wg) (void)hipFree(m->pos_wg);
+    for (auto p : m->qkv_w) (void)hipFree(p);
+    for (auto p : m->qkv_b) (void)hipFree(p);
+    profiler_destroy(m->prof);
+    delete m;
+}
+
+int w2v2_num_params(const w2v2_model* m) { return m ? (int)m->params.size() : 0; }
+
+int w2v2_param_info(const w2v2_model* m, int index, const char** name, int64_t shape[4], int* rank) {
+    W2V2_REQUIRE(m && index >= 0 && index < (int)m->params.size(), "param_info: bad index %d", index);
+    const Param& p = m->params[index];
+    if (name) *name = p.name.c_str();
+    if (rank) *rank = (int)p.shape.size();
+    if (shape)
+        for (size_t i = 0; i < 4; ++i) shape[i] = i < p.shape.size() ? p.shape[i] : 1;
+    return W2V2_OK;
+}
+
+int w2v2_set_param(w2v2_model* m, const char* name, const float* host_src, const int64_t* shape, int rank) {
+    W2V2_REQUIRE(m && name && host_src && shape, "set_param: null argument");
+    auto it = m->index.find(name);
+    if (it == m->index.end()) {
+        set_error("set_param: unknown variable `%s`", name);
+        return W2V2_ENOTFOUND;
+    }
+    Param& p = m->params[it->second];
+    bool ok = rank == (int)p.shape.size();
+    for (int i = 0; ok && i < rank; ++i) ok = shape[i] == p.shape[i];
+    W2V2_REQUIRE(ok, "set_param: shape mismatch for `%s`", name);
+    W2V2_HIP_CHECK(hipMemcpy(p.dev, host_src, (size_t)p.numel * sizeof(float), hipMemcpyHostToDevice));
+    p.set = true;
+    m->finalized = false;
+    return W2V2_OK;
+}
+
+int w2v2_get_param(w2v2_model* m, const char* name, float* host_dst, int64_t numel) {
+    W2V2_REQUIRE(m && name && host_dst, "get_param: null argument");
+    auto it = m->index.find(name);
+    if (it == m->index.end()) {
+        set_error("get_param: unknown variable `%s`", name);
+        return W2V2_ENOTFOUND;
+    }
+    Param& p = m->params[it->second];
+    W2V2_REQUIRE(numel == p.numel, "get_param: `%s` has %lld elements, caller asked for %lld", name,
+                 (long long)p.numel, (long long)numel);
+    W2V2_HIP_CHECK(hipDeviceSynchronize());
+    W2V2_HIP_CHECK(hipMemcpy(host_dst, p.dev, (size_t)p.numel * sizeof(float), hipMemcpyDeviceToHost));
+    return W2V2_OK;
+}
+
+int w2v2_finalize(w2v2_model* m, void* stream) {
+    W2V2_REQUIRE(m, "finalize: null model");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const w2v2_config& c = m->cfg;
+    const int64_t H = c.hidden_size;
+    const int K = c.num_conv_pos_embeddings, G = c.num_conv_pos_embedding_groups, cg = (int)(H / G);
+    if (!m->pos_wg) W2V2_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m->pos_wg), (size_t)K * cg * H * sizeof(float)));
+    if (int e = launch_weight_norm_regroup(m->prof, m->P("encoder/pos_conv_embed/conv/weight_v"),
+                                           m->P("encoder/pos_conv_embed/conv/weight_g"), m->pos_wg, K, cg,
+                                           (int)H, G, s))
+        return e;
+    // packed q|k|v projection: one (H, 3H) GEMM per layer instead of three (H, H)
+    if (m->qkv_w.empty()) {
+        m->qkv_w.resize(c.num_layers, nullptr);
+        m->qkv_b.resize(c.num_layers, nullptr);
+        for (int i = 0; i < c.num_layers; ++i) {
+            W2V2_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m->qkv_w[i]), (size_t)H * 3 * H * sizeof(float)));
+            W2V2_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m->qkv_b[i]), (size_t)3 * H * sizeof(float)));
+        }
+    }
+    for (int i = 0; i < c.num_layers; ++i) {
+        const std::string b = "encoder/layers/" + std::to_string(i) + "/attention/";
+        const char* names[3] = {"q_proj", "k_proj", "v_proj"};
+        for (int j = 0; j < 3; ++j) {
+            W2V2_HIP_CHECK(hipMemcpy2DAsync(m->qkv_w[i] + j * H, (size_t)3 * H * sizeof(float),
+                                            m->P(b + names[j] + "/kernel"), (size_t)H * sizeof(float),
+                                            (size_t)H * sizeof(float), (size_t)H, hipMemcpyDeviceToDevice, s));
+            W2V2_HIP_CHECK(hipMemcpyAsync(m->qkv_b[i] + j * H, m->P(b + names[j] + "/bias"),
+                                          (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
+    }
+    m->finalized = true;
+    return W2V2_OK;
+}
+
+int64_t w2v2_num_frames(const w2v2_model* m, int64_t n) {
+    if (!m) return -1;
+    for (int i = 0; i < m->cfg.num_conv_layers; ++i) {
+        if (n < m->cfg.kernal_sizes[i]) return 0;
+        n = 1 + (n - m->cfg.kernal_sizes[i]) / m->cfg.strides[i];
+    }
+    return n;
+}
+
+int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const int32_t* mask,
+                 float* out, void* stream) {
+    W2V2_REQUIRE(m && wave && out, "forward: null argument");
+    W2V2_REQUIRE(B > 0 && L > 0, "forward: bad batch shape (%d, %lld)", B, (long long)L);
+    if (!m->finalized) {
+        set_error("forward: call w2v2_finalize after setting the variables");
+        return W2V2_ESTATE;
+    }
+    const w2v2_config& c = m->cfg;
+    const int64_t Tll = w2v2_num_frames(m, L);
+    W2V2_REQUIRE(Tll >= 1, "forward: %lld samples are shorter than the conv stack's receptive field", (long long)L);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (int e = ensure_workspace(m, B, L)) return e;
+    Profiler* pf = m->prof;
+    const int T = (int)Tll;
+    const int H = c.hidden_size, F = c.intermediate_size;
+    const int64_t BT = (int64_t)B * T;
+    const int act = c.is_gelu_approx ? 2 : 1;
+    const bool layer_mode = c.feature_extractor_norm_type == 1;
+    const bool prenorm = c.attention_norm_type == 1;
+    const float eps = c.layer_norm_eps;
+    auto fe = [&](int i, const char* leaf) { return m->P("feature_extractor/conv_layers/" + std::to_string(i) + leaf); };
+
+    // ---- feature extractor (feature_extractor.py:54-59) ----
+    if (int e = launch_conv0(pf, wave, fe(0, "/conv/kernel"), c.conv_bias ? fe(0, "/conv/bias") : nullptr,
+                             fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"), m->conv[0], m->conv0_ws, B, L,
+                             c.kernal_sizes[0], c.strides[0], c.filter_sizes[0], 1e-5f, layer_mode ? 1 : 0, act, s))
+        return e;
+    if (layer_mode)
+        if (int e = launch_layer_norm(pf, m->conv[0], m->conv[0], fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"),
+                                      (int64_t)B * m->conv_T[0], c.filter_sizes[0], 1e-5f, act, s))
+            return e;
+    for (int i = 1; i < c.num_conv_layers; ++i) {
+        const int cin = c.filter_sizes[i - 1], cout = c.filter_sizes[i];
+        const int Tin = m->conv_T[i - 1], Tout = m->conv_T[i];
+        // strided Conv1D == GEMM over an overlapping window view: lda = stride * C_in < K * C_in
+        if (int e = launch_gemm(pf, m->conv[i - 1], (int64_t)c.strides[i] * cin, (int64_t)Tin * cin,
+                                fe(i, "/conv/kernel"), cout, m->conv[i], cout, (int64_t)Tout * cout,
+                                c.conv_bias ? fe(i, "/conv/bias") : nullptr, nullptr, Tout, cout,
+                                c.kernal_sizes[i] * cin, B, layer_mode ? 0 : act, s))
+            return e;
+        if (layer_mode)
+            if (int e = launch_layer_norm(pf, m->conv[i], m->conv[i], fe(i, "/layer_norm/gamma"), fe(i, "/layer_norm/beta"),
+                                          (int64_t)B * Tout, cout, 1e-5f, act, s))
+                return e;
+    }
+    // ---- feature projection (feature_extractor.py:92-95) ----
+    const int C = c.filter_sizes[c.num_conv_layers - 1];
+    if (int e = launch_layer_norm(pf, m->conv[c.num_conv_layers - 1], m->ln512, m->P("feature_projection/layer_norm/gamma"),
+                                  m->P("feature_projection/layer_norm/beta"), BT, C, eps, 0, s))
+        return e;
+    if (int e = launch_gemm(pf, m->ln512, C, 0, m->P("feature_projection/projection/kernel"), H, m->proj, H, 0,
+                            m->P("feature_projection/projection/bias"), nullptr, (int)BT, H, C, 1, 0, s))
+        return e;
+    // ---- encoder (encoder.py:251-276) ----
+    const int32_t* flen = nullptr;
+    if (mask) {
+        if (int e = launch_frame_lengths(pf, mask, m->frame_len, B, L, c.kernal_sizes, c.strides, c.num_conv_layers, s)) return e;
+        flen = m->frame_len;
+    }
+    if (int e = launch_pos_conv(pf, m->proj, m->pos_wg, m->P("encoder/pos_conv_embed/conv/bias"), flen, m->posout, B, T,
+                                H, c.num_conv_pos_embeddings, c.num_conv_pos_embedding_groups, act, s))
+        return e;
+    if (!prenorm)
+        if (int e = launch_layer_norm(pf, m->posout, m->hs[0], m->P("encoder/layer_norm/gamma"),
+                                      m->P("encoder/layer_norm/beta"), BT, H, eps, 0, s))
+            return e;
+    for (int i = 0; i < c.num_layers; ++i) {
+        const std::string b = "encoder/layers/" + std::to_string(i);
+        const float* x = m->hs[i];
+        const float* attn_in = x;
+        if (prenorm) {
+            if (int e = launch_layer_norm(pf, x, m->t0, m->P(b + "/layer_norm/gamma"), m->P(b + "/layer_norm/beta"), BT, H, eps, 0, s)) return e;
+            attn_in = m->t0;
+        }
+        if (int e = launch_gemm(pf, attn_in, H, 0, m->qkv_w[i], 3 * H, m->qkv, 3 * H, 0, m->qkv_b[i], nullptr, (int)BT, 3 * H, H, 1, 0, s)) return e;
+        if (int e = launch_attention(pf, m->qkv, flen, m->ctx, B, T, H, c.num_heads, s)) return e;
+        // out projection + residual (encoder.py:31,117-119)
+        if (int e = launch_gemm(pf, m->ctx, H, 0, m->P(b + "/attention/out_proj/kernel"), H, m->t1, H, 0,
+                                m->P(b + "/attention/out_proj/bias"), x, (int)BT, H, H, 1, 0, s))
+            return e;
+        const float* ffn_res = m->t1;
+        const float* ffn_in = m->t1;
+        if (!prenorm) {
+            if (int e = launch_layer_norm(pf, m->t1, m->t2, m->P(b + "/layer_norm/gamma"), m->P(b + "/layer_norm/beta"), BT, H, eps, 0, s)) return e;
+            ffn_res = m->t2;
+            ffn_in = m->t2;
+        } else {
+            if (int e = launch_layer_norm(pf, m->t1, m->t2, m->P(b + "/final_layer_norm/gamma"), m->P(b + "/final_layer_norm/beta"), BT, H, eps, 0, s)) return e;
+            ffn_in = m->t2;
+        }
+        if (int e = launch_gemm(pf, ffn_in, H, 0, m->P(b + "/feed_forward/intermediate_dense/kernel"), F, m->ffn, F, 0,
+                                m->P(b + "/feed_forward/intermediate_dense/bias"), nullptr, (int)BT, F, H, 1, act, s))
+            return e;
+        // output dense + residual; StochasticDepth at inference is a plain add (tensorflow_addons.py:386-390)
+        float* dst = prenorm ? m->hs[i + 1] : m->t3;
+        if (int e = launch_gemm(pf, m->ffn, F, 0, m->P(b + "/feed_forward/output_dense/kernel"), H, dst, H, 0,
+                                m->P(b + "/feed_forward/output_dense/bias"), ffn_res, (int)BT, H, F, 1, 0, s))
+            return e;
+        if (!prenorm)
+            if (int e = launch_layer_norm(pf, m->t3, m->hs[i + 1], m->P(b + "/final_layer_norm/gamma"),
+                                          m->P(b + "/final_layer_norm/beta"), BT, H, eps, 0, s))
+                return e;
+    }
+    if (prenorm)
+        if (int e = launch_layer_norm(pf, m->hs[c.num_layers], m->enc_out, m->P("encoder/layer_norm/gamma"),
+                                      m->P("encoder/layer_norm/beta"), BT, H, eps, 0, s))
+            return e;
+    // ---- head (modeling.py:253-254) ----
+    if (c.with_lm_head) {
+        if (int e = launch_gemm(pf, m->enc_out, H, 0, m->P("lm_head/kernel"), c.vocab_size, out, c.vocab_size, 0,
+                                m->P("lm_head/bias"), nullptr, (int)BT, c.vocab_size, H, 1, 0, s))
+            return e;
+    } else {
+        W2V2_HIP_CHECK(hipMemcpyAsync(out, m->enc_out, (size_t)BT * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    return W2V2_OK;
+}
+
+int w2v2_ctc_loss(const float* logits, int32_t B, int32_t T, int32_t V, const int32_t* labels, int32_t U,
+                  const int32_t* label_length, const int32_t* logit_length, int32_t blank, float* nll,
+                  float* grad, void* stream) {
+    return launch_ctc(nullptr, logits, B, T, V, labels, U, label_length, logit_length, blank, nll, grad,
+                      reinterpret_cast<hipStream_t>(stream));
+}
+
+int w2v2_activation_info(const w2v2_model* m, const char* name, int64_t shape[3]) {
+    W2V2_REQUIRE(m && name && shape, "activation_info: null argument");
+    auto it = m->acts.find(name);
+    if (it == m->acts.end()) {
+        set_error("activation `%s` does not exist (run a forward first)", name);
+        return W2V2_ENOTFOUND;
+    }
+    for (int i = 0; i < 3; ++i) shape[i] = it->second.shape[i];
+    return W2V2_OK;
+}
+
+int w2v2_copy_activation(w2v2_model* m, const char* name, float* host_dst, int64_t numel, void* stream) {
+    W2V2_REQUIRE(m && name && host_dst, "copy_activation: null argument");
+    auto it = m->acts.find(name);
+    if (it == m->acts.end()) {
+        set_error("activation `%s` does not exist (run a forward first)", name);
+        return W2V2_ENOTFOUND;
+    }
+    const Act& a = it->second;
+    W2V2_REQUIRE(numel == a.shape[0] * a.shape[1] * a.shape[2], "copy_activation: `%s` element count mismatch", name);
+    W2V2_HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+    W2V2_HIP_CHECK(hipMemcpy(host_dst, a.ptr, (size_t)numel * sizeof(float), hipMemcpyDeviceToHost));
+    return W2V2_OK;
+}
+
+int w2v2_profile_enable(w2v2_model* m, int enable) {
+    W2V2_REQUIRE(m, "profile_enable: null model");
+    profiler_enable(m->prof, enable != 0);
+    return W2V2_OK;
+}
+int w2v2_profile_num_families(void) { return FAM_COUNT; }
+int w2v2_profile_read(w2v2_model* m, int index, const char** name, int64_t* launches, double* total_ms,
+                      double* flops, double* bytes) {
+    W2V2_REQUIRE(m && index >= 0 && index < FAM_COUNT && launches && total_ms && flops && bytes, "profile_read: bad argument");
+    if (name) *name = family_name(index);
+    return profiler_read(m->prof, index, launches, total_ms, flops, bytes);
+}
+int w2v2_profile_reset(w2v2_model* m) {
+    W2V2_REQUIRE(m, "profile_reset: null model");
+    profiler_reset(m->prof);
+    return W2V2_OK;
+}
+
+// ---- single operators ---------------------------------------------------------
+int w2v2_op_gemm(const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb, float* C,
+                 int64_t ldc, int64_t strideC, const float* bias, const float* residual, int32_t M,
+                 int32_t N, int32_t K, int32_t nbatch, int32_t act, void* stream) {
+    return launch_gemm(nullptr, A, lda, strideA, B, ldb, C, ldc, strideC, bias, residual, M, N, K, nbatch, act,
+                       reinterpret_cast<hipStream_t>(stream));
+}
+int w2v2_op_layer_norm(const float* x, float* y, const float* gamma, const float* beta, int64_t rows,
+                       int32_t C, float eps, int32_t act, void* stream) {
+    return launch_layer_norm(nullptr, x, y, gamma, beta, rows, C, eps, act, reinterpret_cast<hipStream_t>(stream));
+}
+int64_t w2v2_conv0_ws_floats(int32_t B, int64_t L, int32_t K, int32_t stride, int32_t C) {
+    return conv0_ws_floats(B, L, K, stride, C);
+}
+int w2v2_op_conv0(const float* wave, const float* kernel, const float* bias, const float* gamma,
+                  const float* beta, float* out, float* ws, int32_t B, int64_t L, int32_t K, int32_t stride,
+                  int32_t C, float eps, int32_t norm_mode, int32_t act, void* stream) {
+    return launch_conv0(nullptr, wave, kernel, bias, gamma, beta, out, ws, B, L, K, stride, C, eps, norm_mode, act,
+                        reinterpret_cast<hipStream_t>(stream));
+}
+int w2v2_op_weight_norm_regroup(const float* wv, const float* wg, float* out, int32_t K, int32_t cg,
+                                int32_t H, int32_t groups, void* stream) {
+    return launch_weight_norm_regroup(nullptr, wv, wg, out, K, cg, H, groups, reinterpret_cast<hipStream_t>(stream));
+}
+int w2v2_op_pos_conv(const float* x, const float* wg, const float* bias, const int32_t* frame_len, float* y,
+                     int32_t B, int32_t T, int32_t H, int32_t K, int32_t groups, int32_t act, void* stream) {
+    return launch_pos_conv(nullptr, x, wg, bias, frame_len, y, B, T, H, K, groups, act, reinterpret_cast<hipStream_t>(stream));
+}
+int w2v2_op_attention(const float* qkv, const int32_t* frame_len, float* ctx, int32_t B, int32_t T,
+                      int32_t H, int32_t num_heads, void* stream) {
+    return launch_attention(nullptr, qkv, frame_len, ctx, B, T, H, num_heads, reinterpret_cast<hipStream_t>(stream));
+}
+int w2v2_op_frame_lengths(const int32_t* mask, int32_t* frame_len, int32_t B, int64_t L,
+                          const int32_t* kernal_sizes, const int32_t* strides, int32_t num_layers, void* stream) {
+    return launch_frame_lengths(nullptr, mask, frame_len, B, L, kernal_sizes, strides, num_layers,
+                                reinterpret_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,221 @@
+/*
+ * w2v2.h -- C ABI of the MI355X-native Wav2Vec2 forward / CTC path.
+ *
+ * The reference (thevasudevgupta/gsoc-wav2vec2) has NO plugin / operator / FFI
+ * interface: its hot path sits behind a plain Python package surface
+ * (src/wav2vec2/__init__.py:1-4) and every arithmetic op is a TensorFlow call.
+ * This header is therefore the boundary a maintainer of that package would
+ * bind *instead of* TensorFlow: each entry point names the reference call it
+ * replaces.  The Python host side (gsoc-wav2vec2_amd/wav2vec2) binds it with
+ * ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative W2V2_E* code on failure;
+ *     w2v2_last_error() returns a thread-local message.  No exceptions cross
+ *     the ABI.
+ *   - `*_dev` pointers are HIP device pointers (fp32 unless stated), owned by
+ *     the caller; `*_host` pointers are host memory.  The model owns its
+ *     weights and its activation workspace.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  All
+ *     work is enqueued on it; nothing synchronises unless stated.
+ *   - one model per stream at a time; the library is not thread-safe per model.
+ *   - activations are channels-last (batch, time, channels), as in the
+ *     reference; kernels are (K, C_in, C_out) / (in, out) -- the reference's
+ *     TF checkpoint layout (src/convert_torch_to_tf.py:110-117).
+ */
+#ifndef W2V2_H_
+#define W2V2_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define W2V2_MAX_CONV_LAYERS 16
+
+enum {
+    W2V2_OK = 0,
+    W2V2_EINVAL = -1,     /* bad argument / shape / config           */
+    W2V2_ENOTFOUND = -2,  /* unknown parameter or activation name    */
+    W2V2_EHIP = -3,       /* a HIP runtime call failed               */
+    W2V2_ESTATE = -4      /* call order (e.g. forward before all params are set) */
+};
+
+/* Mirrors Wav2Vec2Config (reference src/wav2vec2/config.py:6-60); only the
+ * fields the forward / CTC arithmetic reads.  dropout, survival_prob and the
+ * spec-augment fields are train-time host concerns. */
+typedef struct w2v2_config {
+    int32_t vocab_size;
+    int32_t hidden_size;
+    int32_t num_heads;
+    int32_t num_layers;
+    int32_t intermediate_size;
+    int32_t num_conv_pos_embeddings;
+    int32_t num_conv_pos_embedding_groups;
+    int32_t num_conv_layers;
+    int32_t filter_sizes[W2V2_MAX_CONV_LAYERS];
+    int32_t kernal_sizes[W2V2_MAX_CONV_LAYERS];   /* sic: the reference's spelling is API */
+    int32_t strides[W2V2_MAX_CONV_LAYERS];
+    int32_t conv_bias;                    /* 0 / 1 */
+    int32_t feature_extractor_norm_type;  /* 0 = "group", 1 = "layer"        */
+    int32_t attention_norm_type;          /* 0 = "postnorm", 1 = "prenorm"   */
+    int32_t is_gelu_approx;               /* 0 = exact erf GELU              */
+    int32_t with_lm_head;                 /* 1 = Wav2Vec2ForCTC, 0 = Wav2Vec2Model */
+    int32_t pad_id;                       /* CTC blank index                 */
+    float   layer_norm_eps;
+} w2v2_config;
+
+typedef struct w2v2_model w2v2_model;
+
+const char* w2v2_last_error(void);
+const char* w2v2_version(void);
+
+/* ---- model lifetime ------------------------------------------------------
+ * Replaces Wav2Vec2Model.__init__ / Wav2Vec2ForCTC.__init__
+ * (reference modeling.py:105-167, 217-233): allocates every variable on the
+ * current HIP device (zero-filled). */
+int  w2v2_create(const w2v2_config* cfg, w2v2_model** out);
+void w2v2_destroy(w2v2_model* m);
+
+/* Variable inventory, named as the reference's TF variables without the model
+ * prefix and ":0" (convert_torch_to_tf.py:12-44), e.g.
+ * "encoder/layers/3/attention/q_proj/kernel", "lm_head/bias". */
+int w2v2_num_params(const w2v2_model* m);
+int w2v2_param_info(const w2v2_model* m, int index, const char** name,
+                    int64_t shape[4], int* rank);
+
+/* Replaces model.load_weights / keras batch_set_value
+ * (modeling.py:82, convert_torch_to_tf.py:121): copy one variable host->device.
+ * `shape`/`rank` must match the inventory. */
+int w2v2_set_param(w2v2_model* m, const char* name, const float* host_src,
+                   const int64_t* shape, int rank);
+/* Replaces model.variables[i].numpy() (convert_torch_to_tf.py:81). */
+int w2v2_get_param(w2v2_model* m, const char* name, float* host_dst, int64_t numel);
+
+/* Derives the tensors the kernels consume from the variables: the
+ * weight-normalised positional kernel  l2_normalize(weight_v,[1,2])*weight_g
+ * (tensorflow_addons.py:16-21) regrouped per conv group, and the packed
+ * q|k|v projection.  Must be called after the last w2v2_set_param and before
+ * w2v2_forward; enqueued on `stream`. */
+int w2v2_finalize(w2v2_model* m, void* stream);
+
+/* Frames out of the conv stack for `num_samples` input samples:
+ * 1 + (len - k) // s per layer (modeling.py:202-204, losses.py:47-56). */
+int64_t w2v2_num_frames(const w2v2_model* m, int64_t num_samples);
+
+/* ---- the hot path --------------------------------------------------------
+ * Replaces Wav2Vec2ForCTC.call / Wav2Vec2Model.call at training=False
+ * (modeling.py:169-209, 239-255).
+ *   wave_dev   (B, L) fp32 waveform, already normalised + padded by the caller
+ *   mask_dev   (B, L) int32 0/1 attention mask, or NULL (base checkpoints)
+ *   out_dev    (B, T, vocab) logits if with_lm_head else (B, T, hidden);
+ *              T = w2v2_num_frames(L)
+ * The first call for a new (B, L) allocates the activation workspace
+ * (hipMalloc; not capturable); later calls with B*L no larger reuse it. */
+int w2v2_forward(w2v2_model* m, const float* wave_dev, int32_t B, int64_t L,
+                 const int32_t* mask_dev, float* out_dev, void* stream);
+
+/* Replaces CTCLoss.call (losses.py:14-45) = tf.nn.ctc_loss(
+ * logits_time_major=False, blank_index=pad_id) with the reference's length
+ * convention supplied by the caller:
+ *   logits_dev       (B, T, V) fp32
+ *   labels_dev       (B, U) int32, label_length_dev (B) int32  (count of labels != pad)
+ *   logit_length_dev (B) int32 (the reference passes the full T for every row)
+ *   nll_dev          (B) fp32 per-sample negative log-likelihood (not divided,
+ *                    not reduced: division_factor and the SUM are the caller's)
+ *   grad_logits_dev  (B, T, V) fp32 d(sum_b nll_b)/d logits, or NULL to skip */
+int w2v2_ctc_loss(const float* logits_dev, int32_t B, int32_t T, int32_t V,
+                  const int32_t* labels_dev, int32_t U,
+                  const int32_t* label_length_dev, const int32_t* logit_length_dev,
+                  int32_t blank, float* nll_dev, float* grad_logits_dev, void* stream);
+
+/* ---- introspection (parity tests, profiling) -----------------------------
+ * Stage activations of the LAST forward, by name: "conv0".."conv6",
+ * "projection", "encoder_in", "layer0".."layerN-1", "encoder_out".  Copies
+ * device -> host after synchronising `stream`. */
+int w2v2_activation_info(const w2v2_model* m, const char* name, int64_t shape[3]);
+int w2v2_copy_activation(w2v2_model* m, const char* name, float* host_dst,
+                         int64_t numel, void* stream);
+
+/* Per-kernel-family timing with HIP events on the launch stream.
+ * enable=1 starts recording (every launch is bracketed by an event pair);
+ * w2v2_profile_read synchronises and returns, for family `index`, its name,
+ * launch count, total milliseconds, algorithmic FLOPs and algorithmic bytes
+ * summed over the recorded launches; w2v2_profile_reset clears the record. */
+int w2v2_profile_enable(w2v2_model* m, int enable);
+int w2v2_profile_num_families(void);
+int w2v2_profile_read(w2v2_model* m, int index, const char** name, int64_t* launches,
+                      double* total_ms, double* flops, double* bytes);
+int w2v2_profile_reset(w2v2_model* m);
+
+/* ---- individual operators (each is one hot-path kernel family) -----------
+ * Exposed so every kernel is parity-tested on its own against the oracle. */
+
+/* C[z] = act(A[z] @ Bm + bias) + residual[z]      (tf.keras.layers.Dense /
+ * Conv1D-as-implicit-GEMM; feature_extractor.py:31-37, encoder.py:15-18,99-104)
+ *   A  (M, K) row-major with leading dimension lda (elements) -- an overlapping
+ *      lda < K window view is how strided Conv1D is expressed;
+ *   Bm (K, N) row-major, ldb;  C (M, N), ldc;  bias (N) or NULL;
+ *   residual (M, N) with ldc or NULL (added AFTER the activation);
+ *   act: 0 none, 1 exact GELU, 2 tanh GELU;
+ *   batch z in [0, nbatch): A += z*strideA, C/residual += z*strideC. */
+int w2v2_op_gemm(const float* A_dev, int64_t lda, int64_t strideA,
+                 const float* B_dev, int64_t ldb,
+                 float* C_dev, int64_t ldc, int64_t strideC,
+                 const float* bias_dev, const float* residual_dev,
+                 int32_t M, int32_t N, int32_t K, int32_t nbatch, int32_t act, void* stream);
+
+/* y = LN(x) * gamma + beta over the last axis, optional GELU after
+ * (tf.keras.layers.LayerNormalization(axis=-1); act as above). rows x C. */
+int w2v2_op_layer_norm(const float* x_dev, float* y_dev, const float* gamma_dev,
+                       const float* beta_dev, int64_t rows, int32_t C, float eps,
+                       int32_t act, void* stream);
+
+/* Layer 0 of the feature extractor in "group" mode: Conv1D(C_in=1, K, stride,
+ * valid) -> GroupNormalization(groups=C) = per-(sample, channel) statistics
+ * over time -> GELU, without materialising the un-normalised conv output
+ * (feature_extractor.py:31-47,54-59; tensorflow_addons.py:207-231).
+ *   wave (B, L); kernel (K, 1, C); bias (C) or NULL; out (B, T0, C);
+ *   stats_ws: caller scratch of w2v2_conv0_ws_floats(B, L, K, stride, C) floats.
+ * norm_mode: 0 = group-norm+GELU, 1 = conv(+bias) only ("layer" configs
+ * follow it with w2v2_op_layer_norm). */
+int64_t w2v2_conv0_ws_floats(int32_t B, int64_t L, int32_t K, int32_t stride, int32_t C);
+int w2v2_op_conv0(const float* wave_dev, const float* kernel_dev, const float* bias_dev,
+                  const float* gamma_dev, const float* beta_dev, float* out_dev,
+                  float* stats_ws_dev, int32_t B, int64_t L, int32_t K, int32_t stride,
+                  int32_t C, float eps, int32_t norm_mode, int32_t act, void* stream);
+
+/* Effective positional kernel: l2_normalize(weight_v, axes [1,2]) * weight_g,
+ * regrouped to (groups, K, C_in/groups, C_out/groups)
+ * (tensorflow_addons.py:16-21; encoder.py:168-175). */
+int w2v2_op_weight_norm_regroup(const float* weight_v_dev, const float* weight_g_dev,
+                                float* wg_dev, int32_t K, int32_t cg, int32_t H,
+                                int32_t groups, void* stream);
+
+/* y = xz + GELU(grouped_conv_same(xz) + bias), xz = x with frames >=
+ * frame_len[b] zeroed (encoder.py:253,265; PositionalConvEmbedding
+ * encoder.py:177-181: pad K/2 both sides, drop the last frame for even K).
+ *   x, y (B, T, H); wg from w2v2_op_weight_norm_regroup; frame_len (B) or NULL. */
+int w2v2_op_pos_conv(const float* x_dev, const float* wg_dev, const float* bias_dev,
+                     const int32_t* frame_len_dev, float* y_dev, int32_t B, int32_t T,
+                     int32_t H, int32_t K, int32_t groups, int32_t act, void* stream);
+
+/* Multi-head self-attention context (TransformerAttention.get_context,
+ * encoder.py:34-47, with the q pre-scale of :28): per (batch, head)
+ * softmax((q*scale) k^T + mask) v, mask = -10000 on keys >= frame_len[b].
+ *   qkv (B, T, 3H) packed q|k|v rows;  ctx (B, T, H). Scores are never
+ *   materialised. */
+int w2v2_op_attention(const float* qkv_dev, const int32_t* frame_len_dev, float* ctx_dev,
+                      int32_t B, int32_t T, int32_t H, int32_t num_heads, void* stream);
+
+/* frame_len[b] = conv-stack length arithmetic applied to sum(mask[b, :])
+ * (modeling.py:201-204). */
+int w2v2_op_frame_lengths(const int32_t* mask_dev, int32_t* frame_len_dev, int32_t B,
+                          int64_t L, const int32_t* kernal_sizes, const int32_t* strides,
+                          int32_t num_layers, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* W2V2_H_ */

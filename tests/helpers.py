@@ -1,0 +1,52 @@
+"""Shared test helpers: golden fixtures, seeded configs, tolerances."""
+
+import os
+
+import numpy as np
+
+from wav2vec2 import variables as V
+from wav2vec2.config import RobustWav2Vec2Config, Wav2Vec2Config
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+TINY = dict(hidden_size=64, num_heads=2, num_layers=2, intermediate_size=128,
+            filter_sizes=[32] * 7, num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4)
+
+# fp32 bar: max-abs logit error <= 1e-3 vs the oracle fixture (the reference's own
+# TF-vs-HF bar, tests/test_wav2vec2.py:77-79).  We aim an order of magnitude inside it.
+ATOL_BAR = 1e-3
+ATOL_AIM = 2e-4
+
+
+def golden(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def case_config(name):
+    if name == "tiny_base":
+        return Wav2Vec2Config(**TINY)
+    if name == "tiny_robust":
+        return RobustWav2Vec2Config(**TINY)
+    if name.startswith("base"):
+        return Wav2Vec2Config()
+    if name.startswith("robust"):
+        return RobustWav2Vec2Config()
+    raise KeyError(name)
+
+
+def case_weights(name, with_lm_head=True):
+    return V.seeded_weights(case_config(name), seed=0, with_lm_head=with_lm_head)
+
+
+# time-strides the fixture generator used for the strided stage taps (tests/golden/make_golden.py)
+TAP_STRIDE = {"conv0": 997, "conv1": 499, "conv2": 251, "conv3": 127, "conv4": 61, "conv5": 31,
+              "conv6": 7, "encoder_in": 13, "layer0": 13, "last_hidden": 13}
+
+
+def tap_view(name, arr, full):
+    return arr if full else arr[:, ::TAP_STRIDE[name]]
+
+
+def max_err(a, b):
+    return float(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max())

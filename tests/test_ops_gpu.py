@@ -1,0 +1,296 @@
+"""Per-kernel parity: every HIP kernel family, through the C ABI, against the CPU oracle
+primitive of the same op on the same seeded inputs.  fp32; tolerances written per test."""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers as H
+from oracle import w2v2_oracle as O
+from wav2vec2 import _native as N
+from wav2vec2 import variables as V
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    lib = N.load()
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    return lib, torch, dev
+
+
+def rnd(tag, shape, scale=1.0):
+    n = int(np.prod(shape))
+    return ((V.hash_uniform(tag, n, 11) * 2 - 1) * scale).reshape(shape).astype(np.float32)
+
+
+def dev_t(torch, dev, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def stream():
+    return N.current_stream()
+
+
+# ---------------------------------------------------------------- GEMM ----------
+@pytest.mark.parametrize("M,N_,K,act,use_bias,use_res", [
+    (128, 128, 32, 0, False, False),
+    (300, 200, 96, 1, True, True),       # ragged M and N tiles
+    (257, 32, 768, 0, True, False),      # lm_head-like narrow N
+    (64, 2304, 64, 0, True, False),      # packed qkv-like wide N
+    (130, 100, 50, 2, True, True),       # K not a multiple of 32 -> guarded path
+    (77, 30, 19, 1, True, False),        # nothing aligned
+])
+def test_gemm_matches_numpy(env, M, N_, K, act, use_bias, use_res):
+    lib, torch, dev = env
+    A, B = rnd("A", (M, K)), rnd("B", (K, N_), 0.2)
+    bias = rnd("bias", (N_,)) if use_bias else None
+    res = rnd("res", (M, N_)) if use_res else None
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    if use_bias:
+        ref = ref + bias
+    if act:
+        ref = O.gelu(ref, approximate=(act == 2))
+    if use_res:
+        ref = ref + res
+    tA, tB = dev_t(torch, dev, A), dev_t(torch, dev, B)
+    tb = dev_t(torch, dev, bias) if use_bias else None
+    tr = dev_t(torch, dev, res) if use_res else None
+    out = torch.full((M, N_), float("nan"), device=dev)
+    N.check(lib.w2v2_op_gemm(N.ptr(tA), K, 0, N.ptr(tB), N_, N.ptr(out), N_, 0, N.ptr(tb), N.ptr(tr),
+                             M, N_, K, 1, act, stream()))
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert H.max_err(got, ref) < 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_gemm_transpose_detecting(env):
+    """A = I with an ASYMMETRIC B: a swapped C row/col map cannot pass."""
+    lib, torch, dev = env
+    n = 160
+    A = np.eye(n, dtype=np.float32)
+    B = (np.arange(n)[:, None] * 1000 + np.arange(n)[None, :]).astype(np.float32)
+    out = torch.empty((n, n), device=dev)
+    N.check(lib.w2v2_op_gemm(N.ptr(dev_t(torch, dev, A)), n, 0, N.ptr(dev_t(torch, dev, B)), n, N.ptr(out), n, 0,
+                             None, None, n, n, n, 1, 0, stream()))
+    assert np.array_equal(out.cpu().numpy(), B)
+
+
+@pytest.mark.parametrize("Tin,Cin,Cout,k,s,B", [(203, 64, 96, 3, 2, 3), (101, 32, 32, 2, 2, 2), (49199 // 16, 512, 512, 3, 2, 1)])
+def test_strided_conv_as_overlapping_gemm(env, Tin, Cin, Cout, k, s, B):
+    """Conv1D(valid, stride) == GEMM over a window view with lda = s*Cin < k*Cin
+    (feature_extractor.py:31-37), batched over samples."""
+    lib, torch, dev = env
+    x, w = rnd("x", (B, Tin, Cin)), rnd("w", (k, Cin, Cout), 0.1)
+    bias = rnd("cb", (Cout,))
+    ref = O.gelu(O.conv1d_valid(x.astype(np.float64), w.astype(np.float64), s, bias.astype(np.float64)))
+    Tout = 1 + (Tin - k) // s
+    tx, tw, tb = dev_t(torch, dev, x), dev_t(torch, dev, w), dev_t(torch, dev, bias)
+    out = torch.empty((B, Tout, Cout), device=dev)
+    N.check(lib.w2v2_op_gemm(N.ptr(tx), s * Cin, Tin * Cin, N.ptr(tw), Cout, N.ptr(out), Cout, Tout * Cout,
+                             N.ptr(tb), None, Tout, Cout, k * Cin, B, 1, stream()))
+    assert H.max_err(out.cpu().numpy(), ref) < 3e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_gemm_rejects_bad_arguments(env):
+    lib, torch, dev = env
+    t = torch.zeros((4, 4), device=dev)
+    assert lib.w2v2_op_gemm(N.ptr(t), 4, 0, N.ptr(t), 4, N.ptr(t), 4, 0, None, None, 0, 4, 4, 1, 0, stream()) == -1
+    assert b"gemm" in lib.w2v2_last_error()
+    assert lib.w2v2_op_gemm(None, 4, 0, N.ptr(t), 4, N.ptr(t), 4, 0, None, None, 4, 4, 4, 1, 0, stream()) == -1
+
+
+# ---------------------------------------------------------------- LayerNorm -----
+@pytest.mark.parametrize("rows,Cn,act", [(37, 512, 0), (5, 768, 1), (130, 1024, 0), (9, 64, 0), (3, 50, 0), (4, 1500, 1)])
+def test_layer_norm(env, rows, Cn, act):
+    lib, torch, dev = env
+    x = rnd("lnx", (rows, Cn), 3.0) + 1.5
+    g, b = 1 + rnd("lng", (Cn,), 0.2), rnd("lnb", (Cn,), 0.2)
+    ref = O.layer_norm(x.astype(np.float64), g.astype(np.float64), b.astype(np.float64), 1e-5)
+    if act:
+        ref = O.gelu(ref)
+    out = torch.empty((rows, Cn), device=dev)
+    N.check(lib.w2v2_op_layer_norm(N.ptr(dev_t(torch, dev, x)), N.ptr(out), N.ptr(dev_t(torch, dev, g)),
+                                   N.ptr(dev_t(torch, dev, b)), rows, Cn, 1e-5, act, stream()))
+    assert H.max_err(out.cpu().numpy(), ref) < 1e-5
+
+
+# ---------------------------------------------------------------- conv0 ---------
+@pytest.mark.parametrize("B,L,Cn,K,S,bias", [(2, 4000, 32, 10, 5, False), (1, 46797, 512, 10, 5, False),
+                                             (2, 1003, 48, 7, 3, True), (1, 10, 512, 10, 5, False)])
+def test_conv0_groupnorm_gelu(env, B, L, Cn, K, S, bias):
+    """conv0 -> per-(sample, channel) norm over time -> GELU, fused (feature_extractor.py:31-47;
+    tensorflow_addons.py:207-231)."""
+    lib, torch, dev = env
+    x = V.hash_normal("c0x", B * L, 5).reshape(B, L)
+    if L > 20000:
+        x[:, L // 3:] = 0.0                       # padded tail, as in the 246000 convention
+    w = rnd("c0w", (K, 1, Cn), 0.6)
+    bs = rnd("c0b", (Cn,)) if bias else None
+    g, b = 1 + rnd("c0g", (Cn,), 0.1), rnd("c0be", (Cn,), 0.1)
+    y = O.conv1d_valid(x.astype(np.float64)[:, :, None], w.astype(np.float64), S, None if bs is None else bs.astype(np.float64))
+    ref = O.gelu(O.group_norm_time(y, g.astype(np.float64), b.astype(np.float64), 1e-5))
+    T0 = 1 + (L - K) // S
+    out = torch.full((B, T0, Cn), float("nan"), device=dev)
+    ws = torch.empty((int(lib.w2v2_conv0_ws_floats(B, L, K, S, Cn)),), device=dev)
+    N.check(lib.w2v2_op_conv0(N.ptr(dev_t(torch, dev, x)), N.ptr(dev_t(torch, dev, w)),
+                              N.ptr(dev_t(torch, dev, bs)) if bias else None, N.ptr(dev_t(torch, dev, g)),
+                              N.ptr(dev_t(torch, dev, b)), N.ptr(out), N.ptr(ws), B, L, K, S, Cn, 1e-5, 0, 1, stream()))
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert H.max_err(got, ref) < 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_conv0_plain_mode(env):
+    lib, torch, dev = env
+    B, L, Cn = 2, 3000, 64
+    x, w, bs = rnd("p0x", (B, L)), rnd("p0w", (10, 1, Cn), 0.5), rnd("p0b", (Cn,))
+    ref = O.conv1d_valid(x[:, :, None].astype(np.float64), w.astype(np.float64), 5, bs.astype(np.float64))
+    out = torch.empty((B, ref.shape[1], Cn), device=dev)
+    N.check(lib.w2v2_op_conv0(N.ptr(dev_t(torch, dev, x)), N.ptr(dev_t(torch, dev, w)), N.ptr(dev_t(torch, dev, bs)),
+                              None, None, N.ptr(out), None, B, L, 10, 5, Cn, 1e-5, 1, 0, stream()))
+    assert H.max_err(out.cpu().numpy(), ref) < 1e-5
+
+
+# ---------------------------------------------------------------- pos conv ------
+@pytest.mark.parametrize("B,T,Hh,K,G,flen", [(2, 12, 64, 16, 4, None), (2, 145, 768, 128, 16, None),
+                                              (2, 200, 1024, 128, 16, [200, 130]), (1, 300, 128, 15, 4, [257])])
+def test_pos_conv_weight_norm(env, B, T, Hh, K, G, flen):
+    """weight-norm (per tap) + pad K/2 + grouped conv + drop-last-if-even + GELU + residual
+    (tensorflow_addons.py:16-21,50-53; encoder.py:177-181,253,265)."""
+    lib, torch, dev = env
+    cg = Hh // G
+    x = rnd("pcx", (B, T, Hh))
+    wv, wg, bias = rnd("pcv", (K, cg, Hh), 0.3), 0.5 + rnd("pcg", (K, 1, 1), 0.3) ** 2, rnd("pcb", (Hh,), 0.1)
+    xz = x.astype(np.float64).copy()
+    if flen is not None:
+        for b in range(B):
+            xz[b, flen[b]:] = 0.0
+    kern = O.weight_norm_kernel(wv.astype(np.float64), wg.astype(np.float64))
+    y = O.grouped_conv1d_same(xz, kern, bias.astype(np.float64), G, K // 2)
+    if K % 2 == 0:
+        y = y[:, :-1]
+    ref = xz + O.gelu(y)
+    twg = torch.empty((G, K, cg, cg), device=dev)
+    N.check(lib.w2v2_op_weight_norm_regroup(N.ptr(dev_t(torch, dev, wv)), N.ptr(dev_t(torch, dev, wg)), N.ptr(twg),
+                                            K, cg, Hh, G, stream()))
+    ref_w = np.stack([kern[:, :, g * cg:(g + 1) * cg] for g in range(G)])
+    assert H.max_err(twg.cpu().numpy(), ref_w) < 1e-6
+    tf = dev_t(torch, dev, np.asarray(flen, dtype=np.int32)) if flen is not None else None
+    out = torch.full((B, T, Hh), float("nan"), device=dev)
+    N.check(lib.w2v2_op_pos_conv(N.ptr(dev_t(torch, dev, x)), N.ptr(twg), N.ptr(dev_t(torch, dev, bias)), N.ptr(tf),
+                                 N.ptr(out), B, T, Hh, K, G, 1, stream()))
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert H.max_err(got, ref) < 3e-5
+
+
+# ---------------------------------------------------------------- attention -----
+@pytest.mark.parametrize("B,T,Hh,heads,flen", [(2, 12, 64, 2, None), (1, 145, 768, 12, None), (2, 768, 128, 2, None),
+                                                (2, 200, 128, 2, [200, 61]), (1, 97, 64, 2, [0])])
+def test_attention(env, B, T, Hh, heads, flen):
+    """softmax((q d^-0.5) k^T + key mask) v per head (encoder.py:22-47, 256-263)."""
+    lib, torch, dev = env
+    d = Hh // heads
+    qkv = rnd("qkv", (B, T, 3 * Hh), 2.0)
+    q, k, v = [qkv[:, :, i * Hh:(i + 1) * Hh].astype(np.float64).reshape(B, T, heads, d).transpose(0, 2, 1, 3) for i in range(3)]
+    s = (q * d ** -0.5) @ k.transpose(0, 1, 3, 2)
+    if flen is not None:
+        keep = np.arange(T)[None, :] < np.asarray(flen)[:, None]
+        s = s + ((1.0 - keep) * -10000.0)[:, None, None, :]
+    s = s - s.max(-1, keepdims=True)
+    p = np.exp(s)
+    p /= p.sum(-1, keepdims=True)
+    ref = (p @ v).transpose(0, 2, 1, 3).reshape(B, T, Hh)
+    tf = dev_t(torch, dev, np.asarray(flen, dtype=np.int32)) if flen is not None else None
+    out = torch.full((B, T, Hh), float("nan"), device=dev)
+    N.check(lib.w2v2_op_attention(N.ptr(dev_t(torch, dev, qkv)), N.ptr(tf), N.ptr(out), B, T, Hh, heads, stream()))
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert H.max_err(got, ref) < 2e-5
+
+
+def test_attention_softmax_spike(env):
+    """One key dominating by ~60 nats mid-sequence: forces the online-softmax rescale."""
+    lib, torch, dev = env
+    B, T, Hh, heads = 1, 256, 64, 1
+    qkv = rnd("spk", (B, T, 3 * Hh), 1.0)
+    qkv[0, 5, :Hh] = 6.0            # query 5
+    qkv[0, 150, Hh:2 * Hh] = 10.0   # key 150 aligned with it
+    q, k, v = [qkv[0, :, i * Hh:(i + 1) * Hh].astype(np.float64) for i in range(3)]
+    s = (q * Hh ** -0.5) @ k.T
+    p = np.exp(s - s.max(-1, keepdims=True))
+    ref = (p / p.sum(-1, keepdims=True)) @ v
+    out = torch.empty((B, T, Hh), device=dev)
+    N.check(lib.w2v2_op_attention(N.ptr(dev_t(torch, dev, qkv)), None, N.ptr(out), B, T, Hh, heads, stream()))
+    assert H.max_err(out.cpu().numpy()[0], ref) < 2e-5
+
+
+# ---------------------------------------------------------------- lengths / CTC --
+def test_frame_lengths(env):
+    lib, torch, dev = env
+    cfg = H.case_config("base_sample_padded")
+    L = 246000
+    m = np.ones((4, L), np.int32)
+    m[1, 46797:] = 0
+    m[2, 400:] = 0
+    m[3, :] = 0
+    ks = (C.c_int32 * 7)(*cfg.kernal_sizes)
+    ss = (C.c_int32 * 7)(*cfg.strides)
+    out = torch.empty((4,), device=dev, dtype=torch.int32)
+    N.check(lib.w2v2_op_frame_lengths(N.ptr(dev_t(torch, dev, m)), N.ptr(out), 4, L, ks, ss, 7, stream()))
+    assert out.cpu().tolist() == [768, 145, 1, 0]
+    assert list(O.frame_lengths(cfg, m))[:3] == [768, 145, 1]
+
+
+@pytest.mark.parametrize("B,T,Vv,U", [(3, 50, 32, 8), (2, 768, 32, 256), (4, 20, 7, 12)])
+def test_ctc_loss_and_grad(env, B, T, Vv, U):
+    """tf.nn.ctc_loss semantics (losses.py:35-43): NLL vs the oracle (fp64), gradient vs torch autograd."""
+    lib, torch, dev = env
+    rng = np.random.default_rng(B * 1000 + T)
+    logits = rng.normal(size=(B, T, Vv)).astype(np.float32) * 2
+    labels = rng.integers(1, Vv, size=(B, U)).astype(np.int32)
+    lab_len = rng.integers(0, min(U, T // 2) + 1, size=B).astype(np.int32)
+    lab_len[0] = min(U, T // 2)
+    for b in range(B):
+        labels[b, lab_len[b]:] = 0
+    log_len = np.full(B, T, np.int32)
+    log_len[-1] = max(T - 3, 2 * int(lab_len[-1]) + 1)
+    ref = O.ctc_nll(logits, labels, lab_len, log_len, blank=0)
+    tl = dev_t(torch, dev, logits)
+    nll = torch.empty((B,), device=dev)
+    grad = torch.full((B, T, Vv), float("nan"), device=dev)
+    N.check(lib.w2v2_ctc_loss(N.ptr(tl), B, T, Vv, N.ptr(dev_t(torch, dev, labels)), U, N.ptr(dev_t(torch, dev, lab_len)),
+                              N.ptr(dev_t(torch, dev, log_len)), 0, N.ptr(nll), N.ptr(grad), stream()))
+    got = nll.cpu().numpy()
+    assert np.allclose(got, ref, rtol=2e-6, atol=1e-4), (got, ref)
+    # gradient: torch CPU autograd on the same problem (fp64)
+    lt = torch.from_numpy(logits).double().requires_grad_(True)
+    lp = torch.log_softmax(lt, -1).transpose(0, 1)
+    flat = torch.cat([torch.from_numpy(labels[b, :lab_len[b]].astype(np.int64)) for b in range(B)])
+    loss = torch.nn.functional.ctc_loss(lp, flat, torch.from_numpy(log_len.astype(np.int64)),
+                                        torch.from_numpy(lab_len.astype(np.int64)), blank=0, reduction="sum")
+    loss.backward()
+    g = grad.cpu().numpy()
+    assert np.isfinite(g).all()
+    assert H.max_err(g, lt.grad.numpy()) < 1e-5
+    # nll-only call (grad = NULL) agrees
+    nll2 = torch.empty((B,), device=dev)
+    N.check(lib.w2v2_ctc_loss(N.ptr(tl), B, T, Vv, N.ptr(dev_t(torch, dev, labels)), U, N.ptr(dev_t(torch, dev, lab_len)),
+                              N.ptr(dev_t(torch, dev, log_len)), 0, N.ptr(nll2), None, stream()))
+    assert np.array_equal(nll2.cpu().numpy(), got)
+
+
+def test_ctc_infeasible_is_inf(env):
+    lib, torch, dev = env
+    logits = np.zeros((1, 2, 5), np.float32)
+    labels = np.array([[1, 1]], np.int32)          # "1 1" needs 3 frames
+    nll = torch.empty((1,), device=dev)
+    N.check(lib.w2v2_ctc_loss(N.ptr(dev_t(torch, dev, logits)), 1, 2, 5, N.ptr(dev_t(torch, dev, labels)), 2,
+                              N.ptr(dev_t(torch, dev, np.array([2], np.int32))), N.ptr(dev_t(torch, dev, np.array([2], np.int32))),
+                              0, N.ptr(nll), None, stream()))
+    assert np.isinf(nll.cpu().numpy()[0])

@@ -1,0 +1,104 @@
+"""Pin the CPU oracle: reference known-answer tests and HF-PyTorch golden vectors.
+
+Runs without a GPU.  The oracle is the checker for the HIP path, so it is itself
+checked here against (a) the reference's own self-contained known answers and
+(b) fixtures produced by HuggingFace-PyTorch Wav2Vec2 -- the comparator the
+reference's tests use -- in the build container (tests/golden/make_golden.py).
+"""
+
+import os
+import wave
+
+import numpy as np
+import pytest
+
+import helpers as H
+from oracle import w2v2_oracle as O
+
+
+def _read_wav(path):
+    with wave.open(path) as f:
+        pcm = np.frombuffer(f.readframes(f.getnframes()), dtype=np.int16)
+    return pcm.astype(np.float32) / 32768.0
+
+
+def test_normalize_known_answer():
+    """reference tests/test_dataloader.py:56-63: samples [32:40] of the
+    normalised data/sample.wav."""
+    target = np.array([0.01438822, 0.01776027, 0.01438822, 0.02113231, 0.01438822, 0.00764414,
+                       0.00764414, -0.00921606])
+    x = O.normalize(_read_wav(os.path.join(H.GOLDEN, "sample.wav")))
+    assert x.shape == (46797,)
+    assert np.allclose(x[32:40], target, atol=1e-7)
+    # var is 0.878, not 1: the raw variance (7e-5) is comparable to the reference's eps of 1e-5
+    assert abs(x.mean()) < 1e-6 and abs(x.var() - 0.878) < 1e-3
+
+
+def test_weight_norm_conv_matches_torch_fixture():
+    """reference tests/test_wav2vec2.py:239-282 (atol 1e-4): weight-normalised
+    grouped conv == torch weight_norm(Conv1d(groups), dim=2)."""
+    g = H.golden("weight_norm_conv")
+    kern = O.weight_norm_kernel(g["weight_v"], g["weight_g"])
+    y = O.grouped_conv1d_same(g["x"], kern, g["bias"], groups=2, padding=1)
+    assert y.shape == g["y"].shape
+    assert H.max_err(y, g["y"]) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["tiny_base", "tiny_robust", "base_sample_unpadded", "robust_masked"])
+def test_forward_matches_hf(name):
+    g = H.golden(name)
+    cfg, w = H.case_config(name), H.case_weights(name)
+    mask = g.get("attention_mask")
+    taps = {}
+    logits = O.ctc_forward(cfg, w, g["wave"], mask, taps)
+    full = name.startswith("tiny")
+    assert logits.shape == g["logits_f64"].shape
+    err = H.max_err(logits, g["logits_f64"])
+    assert err < H.ATOL_AIM, f"{name}: oracle vs HF fp64 logits {err:.2e}"
+    for tap in ("conv0", "conv3", "conv6", "encoder_in", "layer0"):
+        assert H.max_err(H.tap_view(tap, taps[tap], full), g[tap]) < H.ATOL_AIM, tap
+
+
+def test_padded_246000_matches_hf():
+    """BASELINE config-1 input convention: sample.wav normalised, THEN right-padded with
+    zeros to 246000 (T = 768); row 1 is seeded noise."""
+    g = H.golden("base_sample_padded")
+    cfg, w = H.case_config("base_sample_padded"), H.case_weights("base_sample_padded")
+    logits = O.ctc_forward(cfg, w, g["wave"][:1], None)
+    assert logits.shape == (1, 768, 32)
+    err = H.max_err(logits, g["logits_f64"][:1])
+    assert err < H.ATOL_AIM, f"oracle vs HF fp64 {err:.2e}"
+    # the fp32 HF run itself sits this far from fp64 HF: the noise floor of a correct fp32 path
+    assert H.max_err(g["logits_f32"], g["logits_f64"]) < H.ATOL_AIM
+
+
+@pytest.mark.parametrize("name", ["tiny_base", "base_sample_unpadded", "base_sample_padded"])
+def test_ctc_loss_matches_torch(name):
+    """reference tests/test_wav2vec2.py:217-237 compares the CTC loss with HF at 1e-3."""
+    g = H.golden(name)
+    cfg = H.case_config(name)
+    labels = g["labels"]
+    total, nll = O.ctc_loss(cfg, labels, g["logits_f64"], g["wave"].shape, division_factor=1)
+    assert np.allclose(nll, g["ctc_nll_f64"], atol=1e-3, rtol=0)
+    assert abs(total - g["ctc_nll_f64"].sum()) < 1e-3
+
+
+def test_ctc_edge_cases():
+    rng = np.random.default_rng(0)
+    logits = rng.normal(size=(3, 6, 5))
+    labels = np.array([[1, 1, 2, 0], [0, 0, 0, 0], [3, 4, 3, 4]])
+    nll = O.ctc_nll(logits, labels, [3, 0, 4], [6, 6, 6], blank=0)
+    assert np.all(np.isfinite(nll))
+    # empty label string: only the all-blank path
+    logp = logits[1] - np.log(np.exp(logits[1]).sum(-1, keepdims=True))
+    assert abs(nll[1] + logp[:, 0].sum()) < 1e-9
+    # repeated label "1 1" needs a blank between: infeasible in 2 frames
+    assert np.isinf(O.ctc_nll(logits[:1, :2], labels[:1, :2], [2], [2], blank=0)[0])
+
+
+def test_frame_lengths():
+    cfg = H.case_config("base_sample_padded")
+    m = np.ones((2, 246000), np.int32)
+    m[1, 46797:] = 0
+    assert list(O.frame_lengths(cfg, m)) == [768, 145]
+    assert cfg.num_frames(246000) == 768 and cfg.num_frames(480000) == 1499
