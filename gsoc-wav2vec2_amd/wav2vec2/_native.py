@@ -87,6 +87,10 @@ def load(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
+    # torch-ROCm bundles its own HIP runtime (soname libamdhip64.so.7).  It must be the one already
+    # mapped when libw2v2.so is loaded, so that both sides share ONE runtime (device pointers,
+    # streams); loading libw2v2.so first would pull in /opt/rocm's copy as a second runtime.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH) and build_if_missing:
         try:
             import importlib.util

@@ -12,6 +12,21 @@ from wav2vec2 import variables as V
 
 pytestmark = pytest.mark.gpu
 
+REPORT = {}
+
+
+def report(key, value):
+    """Collect measured parity numbers; written to gpurun_out/parity_report.json when possible."""
+    import json
+    REPORT[key] = value
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_report.json"), "w") as f:
+            json.dump(REPORT, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
 
 @pytest.fixture(scope="module")
 def torch_mod():
@@ -41,12 +56,15 @@ def test_logits_match_golden(torch_mod, name):
     assert np.isfinite(logits).all()
     err = H.max_err(logits, g["logits_f64"])
     print(f"{name}: max|logits - HF fp64| = {err:.3e}  (HF fp32 vs fp64 = {H.max_err(g['logits_f32'], g['logits_f64']):.3e})")
+    report(f"{name}/logits_vs_hf_f64", err)
+    report(f"{name}/hf_f32_vs_hf_f64", H.max_err(g["logits_f32"], g["logits_f64"]))
     assert err < H.ATOL_AIM
     full = name.startswith("tiny")
     taps = ["conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "encoder_in", "layer0"]
     for tap in taps:
         e = H.max_err(H.tap_view(tap, m.activation(tap), full), g[tap])
         scale = max(1.0, float(np.abs(g[tap]).max()))
+        report(f"{name}/{tap}", e)
         assert e < H.ATOL_AIM * scale, f"{name}/{tap}: {e:.3e}"
     last = m.activation("encoder_out")
     assert H.max_err(H.tap_view("last_hidden", last, full), g["last_hidden"]) < H.ATOL_AIM
@@ -86,15 +104,21 @@ def test_batch_rows_are_independent(torch_mod):
 def test_ctc_loss_matches_golden(torch_mod):
     """reference tests/test_wav2vec2.py:217-237: loss within 1e-3 of HF."""
     import wav2vec2
-    for name in ("tiny_base", "base_sample_padded"):
+    # atol 1e-3 is the reference's bar at ITS test size (2 x 46797 samples, T = 145) = base_sample_unpadded.
+    # At 246000 samples the loss sums 768 frames and is 3-5x larger; the HF fp32 run itself sits 1.4e-3
+    # from HF fp64 there, so that case is held to rtol 1e-5 instead.
+    for name, atol, rtol in (("tiny_base", 1e-3, 0.0), ("base_sample_unpadded", 1e-3, 0.0),
+                             ("base_sample_padded", 1e-3, 1e-5)):
         g = H.golden(name)
         m, cfg = build(name)
         logits = m(g["wave"])
         loss_fn = wav2vec2.CTCLoss(cfg, g["wave"].shape, division_factor=1)
         nll = loss_fn.per_sample(g["labels"], logits).cpu().numpy()
-        assert np.allclose(nll, g["ctc_nll_f64"], atol=2e-3, rtol=0), (nll, g["ctc_nll_f64"])
+        report(f"{name}/ctc_nll_abs_err", float(np.abs(nll - g["ctc_nll_f64"]).max()))
+        report(f"{name}/ctc_hf_f32_abs_err", float(np.abs(g["ctc_nll_f32"] - g["ctc_nll_f64"]).max()))
+        assert np.allclose(nll, g["ctc_nll_f64"], atol=atol, rtol=rtol), (nll, g["ctc_nll_f64"])
         total = float(loss_fn(g["labels"], logits))
-        assert abs(total - g["ctc_nll_f64"].sum()) < 4e-3
+        assert abs(total - g["ctc_nll_f64"].sum()) < 2 * atol + rtol * g["ctc_nll_f64"].sum()
         # division_factor = global batch, SUM reduction (losses.py:45, main.py:198-200)
         assert abs(float(wav2vec2.CTCLoss(cfg, g["wave"].shape, division_factor=2)(g["labels"], logits)) - total / 2) < 1e-3
 

@@ -28,8 +28,22 @@ def rnd(tag, shape, scale=1.0):
     return ((V.hash_uniform(tag, n, 11) * 2 - 1) * scale).reshape(shape).astype(np.float32)
 
 
+_KEEP = []
+
+
+@pytest.fixture(autouse=True)
+def _keepalive():
+    """Raw pointers are handed to the C ABI: every device tensor made by dev_t must outlive the call
+    (a temporary would be freed, and its block reused, before the kernel runs)."""
+    _KEEP.clear()
+    yield
+    _KEEP.clear()
+
+
 def dev_t(torch, dev, a):
-    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    _KEEP.append(t)
+    return t
 
 
 def stream():
@@ -142,7 +156,10 @@ def test_conv0_groupnorm_gelu(env, B, L, Cn, K, S, bias):
                               N.ptr(dev_t(torch, dev, b)), N.ptr(out), N.ptr(ws), B, L, K, S, Cn, 1e-5, 0, 1, stream()))
     got = out.cpu().numpy()
     assert np.isfinite(got).all()
-    assert H.max_err(got, ref) < 2e-5 * max(1.0, np.abs(ref).max())
+    # T0 == 1 is degenerate: var = 0, so rsqrt(eps) = 316 multiplies the fp32 rounding of the
+    # scale/shift form  y*inv + (beta - mean*inv)  that tf.nn.batch_normalization (and this kernel) use
+    tol = 1e-4 if T0 == 1 else 2e-5 * max(1.0, np.abs(ref).max())
+    assert H.max_err(got, ref) < tol
 
 
 def test_conv0_plain_mode(env):
@@ -201,7 +218,9 @@ def test_attention(env, B, T, Hh, heads, flen):
     s = (q * d ** -0.5) @ k.transpose(0, 1, 3, 2)
     if flen is not None:
         keep = np.arange(T)[None, :] < np.asarray(flen)[:, None]
-        s = s + ((1.0 - keep) * -10000.0)[:, None, None, :]
+        # the reference adds the -10000 mask in fp32 (encoder.py:256-257): ulp(1e4) = 1e-3 quantises the
+        # masked scores; emulate that rounding so fully-masked rows compare like with like
+        s = (s.astype(np.float32) + ((1.0 - keep) * -10000.0)[:, None, None, :].astype(np.float32)).astype(np.float64)
     s = s - s.max(-1, keepdims=True)
     p = np.exp(s)
     p /= p.sum(-1, keepdims=True)
@@ -259,7 +278,7 @@ def test_ctc_loss_and_grad(env, B, T, Vv, U):
     for b in range(B):
         labels[b, lab_len[b]:] = 0
     log_len = np.full(B, T, np.int32)
-    log_len[-1] = max(T - 3, 2 * int(lab_len[-1]) + 1)
+    log_len[-1] = min(T, max(T - 3, 2 * int(lab_len[-1]) + 1))
     ref = O.ctc_nll(logits, labels, lab_len, log_len, blank=0)
     tl = dev_t(torch, dev, logits)
     nll = torch.empty((B,), device=dev)
