@@ -1,6 +1,6 @@
 // fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32).
 //
-// One kernel serves every dense contraction of the path:
+// One kernel template serves every dense contraction of the path:
 //   * Dense layers (q|k|v, out, FFN, projection, lm_head)      -- encoder.py:15-18,99-104
 //   * strided Conv1D layers 1..6 as an implicit GEMM           -- feature_extractor.py:31-37
 // In channels-last layout the conv window of output frame t is the CONTIGUOUS run
@@ -8,29 +8,31 @@
 // matrix has leading dimension lda = stride*C < K*C (overlapping rows) and whose
 // B matrix is the (K*C_in, C_out) reshape of the TF kernel.  No im2col copy exists.
 //
-// Tiling: 128x128x32 block tile, 256 threads = 4 waves as 2x2, each wave a 64x64
-// sub-tile = 2x2 MFMA 32x32 accumulators (64 acc VGPRs).  fp32 MFMA issues at
-// 64 cycles per SIMD, so LDS traffic (2 b128 + 8 b32 reads per 16 MFMAs) is far
-// from the limit; the design goal is simply to keep the matrix pipe issuing
-// back-to-back: register-prefetched global loads, double-buffered LDS, one
-// barrier per K tile, 2 blocks per CU.
+// Tiling: BM x BN x 32 block tile, WM x WN waves, each wave a (BM/WM) x (BN/WN)
+// sub-tile of 32x32 MFMA accumulators.  fp32 MFMA issues at 64 cycles per SIMD, so
+// LDS traffic is far from the limit; what matters is (a) keeping the matrix pipe
+// issuing back-to-back (register-prefetched global loads, double-buffered LDS, one
+// barrier per K tile) and (b) the L2->CU operand traffic, which scales with
+// 1/BM + 1/BN: the 128x128 tile asks ~4.9 TB/s of L2 at the fp32 peak, the
+// 128x256 / 256x128 tiles ~3.7 TB/s.
 //
 // The k-pairing inside an MFMA (which two k-indices one 32x32x2 step consumes)
 // is free as long as A and B agree, so each lane fetches its A fragment as ONE
 // 16-byte LDS read (4 consecutive k) and the k-steps are taken as
 // {k, k+4}, {k+1, k+5}, ... within an 8-wide k block.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace w2v2 {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;   // native vector: arrays of HIP's float4 struct land in scratch
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int BK = 32;
 constexpr int LDA_S = BK + 4;   // +16 B row pad: conflict-free ds_read_b128 of a column slice
-constexpr int LDB_S = BN;       // B fragments are row-contiguous b32 reads: no pad needed
-constexpr int STAGE_FLOATS = BM * LDA_S + BK * LDB_S;
 
 struct GemmArgs {
     const float* A;
@@ -50,17 +52,31 @@ __device__ __forceinline__ float ld_b(const float* B, const GemmArgs& g, int k, 
     return (k < g.K && col < g.N) ? B[(int64_t)k * g.ldb + col] : 0.0f;
 }
 
-template <bool FAST>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
+
+template <int BM, int BN, int WM, int WN>
+struct Cfg {
+    static constexpr int NT = WM * WN * 64;             // threads
+    static constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
+    static constexpr int MT = WTM / 32, NTL = WTN / 32; // 32x32 accumulators per wave
+    static constexpr int NA = BM * (BK / 4) / NT;       // float4 per thread per A tile
+    static constexpr int NB = BK * (BN / 4) / NT;       // float4 per thread per B tile
+    static constexpr int STAGE = BM * LDA_S + BK * BN;  // floats per LDS stage
+    static constexpr size_t LDS = 2 * STAGE * sizeof(float);
+};
+
+template <bool FAST, int BM, int BN, int WM, int WN, int MINW>
+__global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_f32_kernel(GemmArgs g) {
+    using C_ = Cfg<BM, BN, WM, WN>;
+    constexpr int NT = C_::NT, MT = C_::MT, NTL = C_::NTL, NA = C_::NA, NB = C_::NB, STAGE = C_::STAGE;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
 
     // XCD-aware tile order: the dispatcher places block b on XCD b % 8; give each
-    // XCD a contiguous run of tiles (N fastest) so a 128-row A panel is re-read
+    // XCD a contiguous run of tiles (N fastest) so a BM-row A panel is re-read
     // from that XCD's L2 by the column tiles next to it.  Bijective for any count.
     const int nwg = g.tiles_m * g.tiles_n;
     int bid = blockIdx.x;
@@ -74,60 +90,193 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     const float* __restrict__ A = g.A + (int64_t)z * g.strideA;
     const float* __restrict__ Bm = g.B;
 
-    // ---- global -> register staging of one K tile ---------------------------
-    // A tile 128x32: thread -> rows (tid>>3)+32i, float4 column (tid&7)
-    // B tile 32x128: thread -> rows (tid>>5)+8i,  float4 column (tid&31)
-    // Named registers (not arrays): hipcc keeps small float4 arrays that are
-    // written under a loop-carried condition in scratch memory.
-    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-    const int a_r = tid >> 3, a_c = (tid & 7) * 4;
-    const int b_r = tid >> 5, b_c = (tid & 31) * 4;
-    int64_t a_off[4], b_off[4];   // FAST path: per-thread element offsets of the 8 staged float4s
-    if constexpr (FAST) {
+    // ---- global -> register staging of one K tile (float4 per thread) ---------
+    f32x4 ra[NA], rb[NB];
+    int64_t a_off[NA], b_off[NB];
+    int a_lds[NA], b_lds[NB];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int row = m0 + a_r + 32 * i;
-            row = row < g.M ? row : g.M - 1;           // clamp: loads stay in bounds, stores are guarded
-            a_off[i] = (int64_t)row * g.lda + a_c;
-            int col = n0 + b_c;
-            col = col < g.N ? col : g.N - 4;           // clamped columns feed accumulators that are never stored
-            b_off[i] = (int64_t)(b_r + 8 * i) * g.ldb + col;
-        }
+    for (int i = 0; i < NA; ++i) {
+        const int idx = tid + i * NT;
+        const int r = idx / (BK / 4), c = (idx % (BK / 4)) * 4;
+        int row = m0 + r;
+        row = row < g.M ? row : g.M - 1;               // clamp: loads stay in bounds, stores are guarded
+        a_off[i] = (int64_t)row * g.lda + c;
+        a_lds[i] = r * LDA_S + c;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int idx = tid + i * NT;
+        const int r = idx / (BN / 4), c = (idx % (BN / 4)) * 4;
+        int col = n0 + c;
+        col = col < g.N ? col : (g.N >= 4 ? g.N - 4 : 0);   // clamped columns feed accumulators never stored
+        b_off[i] = (int64_t)r * g.ldb + col;
+        b_lds[i] = BM * LDA_S + r * BN + c;
     }
 
-#define W2V2_LD_A(i_, k0_)                                                                         \
-    (FAST ? *reinterpret_cast<const float4*>(A + a_off[i_] + (k0_))                                \
-          : make_float4(ld_a(A, g, m0 + a_r + 32 * (i_), (k0_) + a_c),                             \
-                        ld_a(A, g, m0 + a_r + 32 * (i_), (k0_) + a_c + 1),                         \
-                        ld_a(A, g, m0 + a_r + 32 * (i_), (k0_) + a_c + 2),                         \
-                        ld_a(A, g, m0 + a_r + 32 * (i_), (k0_) + a_c + 3)))
-#define W2V2_LD_B(i_, k0_)                                                                         \
-    (FAST ? *reinterpret_cast<const float4*>(Bm + b_off[i_] + (int64_t)(k0_) * g.ldb)              \
-          : make_float4(ld_b(Bm, g, (k0_) + b_r + 8 * (i_), n0 + b_c),                             \
-                        ld_b(Bm, g, (k0_) + b_r + 8 * (i_), n0 + b_c + 1),                         \
-                        ld_b(Bm, g, (k0_) + b_r + 8 * (i_), n0 + b_c + 2),                         \
-                        ld_b(Bm, g, (k0_) + b_r + 8 * (i_), n0 + b_c + 3)))
-#define W2V2_LOAD_TILE(kt_)                                                                        \
-    do {                                                                                           \
-        const int k0__ = (kt_) * BK;                                                               \
-        ra0 = W2V2_LD_A(0, k0__); ra1 = W2V2_LD_A(1, k0__);                                        \
-        ra2 = W2V2_LD_A(2, k0__); ra3 = W2V2_LD_A(3, k0__);                                        \
-        rb0 = W2V2_LD_B(0, k0__); rb1 = W2V2_LD_B(1, k0__);                                        \
-        rb2 = W2V2_LD_B(2, k0__); rb3 = W2V2_LD_B(3, k0__);                                        \
-    } while (0)
-#define W2V2_STORE_TILE(buf_)                                                                      \
-    do {                                                                                           \
-        float* As_ = smem + (buf_) * STAGE_FLOATS + a_r * LDA_S + a_c;                             \
-        float* Bs_ = smem + (buf_) * STAGE_FLOATS + BM * LDA_S + b_r * LDB_S + b_c;                \
-        *reinterpret_cast<float4*>(As_) = ra0;                                                     \
-        *reinterpret_cast<float4*>(As_ + 32 * LDA_S) = ra1;                                        \
-        *reinterpret_cast<float4*>(As_ + 64 * LDA_S) = ra2;                                        \
-        *reinterpret_cast<float4*>(As_ + 96 * LDA_S) = ra3;                                        \
-        *reinterpret_cast<float4*>(Bs_) = rb0;                                                     \
-        *reinterpret_cast<float4*>(Bs_ + 8 * LDB_S) = rb1;                                         \
-        *reinterpret_cast<float4*>(Bs_ + 16 * LDB_S) = rb2;                                        \
-        *reinterpret_cast<float4*>(Bs_ + 24 * LDB_S) = rb3;                                        \
-    } while (0)
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if constexpr (FAST) {
+                ra[i] = *reinterpret_cast<const f32x4*>(A + a_off[i] + k0);
+            } else {
+                const int idx = tid + i * NT;
+                const int row = m0 + idx / (BK / 4), k = k0 + (idx % (BK / 4)) * 4;
+                ra[i] = f32x4{ld_a(A, g, row, k), ld_a(A, g, row, k + 1), ld_a(A, g, row, k + 2), ld_a(A, g, row, k + 3)};
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if constexpr (FAST) {
+                rb[i] = *reinterpret_cast<const f32x4*>(Bm + b_off[i] + (int64_t)k0 * g.ldb);
+            } else {
+                const int idx = tid + i * NT;
+                const int k = k0 + idx / (BN / 4), col = n0 + (idx % (BN / 4)) * 4;
+                rb[i] = f32x4{ld_b(Bm, g, k, col), ld_b(Bm, g, k, col + 1), ld_b(Bm, g, k, col + 2), ld_b(Bm, g, k, col + 3)};
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* S = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(S + a_lds[i]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(S + b_lds[i]) = rb[i];
+    };
+
+    f32x16 acc[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // Fragment reads are left to hipcc's own just-in-time placement (ds_read2_b32 + counted lgkmcnt in
+    // front of each group of 4 MFMAs): with two waves per SIMD the partner wave covers those waits.
+    // An explicitly software-pipelined variant (reads one k block ahead, pinned with sched_barrier)
+    // measured 1 % SLOWER at 128x128 and 25 % slower at 256x256 (VGPR 246).
+    auto compute = [&](int buf) {
+        const float* As = smem + buf * STAGE + (wm * C_::WTM + li) * LDA_S + 4 * lh;
+        const float* Bs = smem + buf * STAGE + BM * LDA_S + (4 * lh) * BN + wn * C_::WTN + li;
+#pragma unroll
+        for (int kb = 0; kb < BK / 8; ++kb) {
+            f32x4 a[MT];
+            float b[NTL][4];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(As + mt * 32 * LDA_S + kb * 8);
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b[nt][e] = Bs[(kb * 8 + e) * BN + nt * 32];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NTL; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][e], b[nt][e], acc[mt][nt], 0, 0, 0);
+        }
+    };
+
+    const int nk = (g.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    // steady state: the prefetch is unconditional (last iteration peeled) so the staging
+    // registers are plain SSA values -- a conditional prefetch makes hipcc spill them to scratch
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        const int cur = kt & 1;
+        load_tile(kt + 1);              // in flight under the MFMAs below
+        // hipcc otherwise sinks the prefetch below the MFMA block (to save 32 VGPRs) and then waits
+        // for it at once: the whole L2/HBM latency exposed every K tile.  Pin the order.
+        __builtin_amdgcn_sched_barrier(0);
+        compute(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tile(cur ^ 1);
+        __syncthreads();
+    }
+    compute((nk - 1) & 1);
+
+    // ---- epilogue: bias -> activation -> + residual -> store -------------------
+    // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    float* __restrict__ C = g.C + (int64_t)z * g.strideC;
+    const float* __restrict__ R = g.residual ? g.residual + (int64_t)z * g.strideC : nullptr;
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt) {
+        const int col = n0 + wn * C_::WTN + nt * 32 + li;
+        if (col >= g.N) continue;
+        const float bv = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * C_::WTM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < g.M) {
+                    float v = apply_act(acc[mt][nt][r] + bv, g.act);
+                    if (R) v += R[(int64_t)row * g.ldc + col];
+                    C[(int64_t)row * g.ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---- LDS-DMA variant (FAST shapes only) ---------------------------------------
+// Same 128x128x32 tile and MFMA loop, but the K tiles go HBM/L2 -> LDS directly with
+// global_load_lds_dwordx4 (no VGPR staging, no ds_write pass, 32 fewer VGPRs).  The DMA writes
+// LDS lane-linearly (wave-uniform base + lane * 16 B), so the A image cannot be row-padded; the
+// bank-conflict fix is an XOR swizzle applied on the per-lane GLOBAL source address and again on
+// the fragment read:  k-slot' = k-slot ^ ((row >> 1) & 7)   (16-B slots, 8 per 128-B row).
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef const __attribute__((address_space(1))) float glb_f32;
+
+__device__ __forceinline__ void dma16(const float* g, float* l) {
+    __builtin_amdgcn_global_load_lds((glb_f32*)g, (lds_f32*)l, 16, 0, 0);
+}
+
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void gemm_f32_dma_kernel(GemmArgs g) {
+    constexpr int BM = 128, BN = 128, STAGE = BM * BK + BK * BN;   // 8192 floats = 32 KiB
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int nwg = g.tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.z;
+    const float* __restrict__ A = g.A + (int64_t)z * g.strideA;
+    const float* __restrict__ Bm = g.B;
+
+    // per-lane global sources of this wave's 4 A pieces and 4 B pieces (1 KiB each)
+    const float* a_src[4];
+    const float* b_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int piece = wave * 4 + i;                     // 16 pieces of 8 rows (A) / 2 rows (B)
+        const int r = piece * 8 + (lane >> 3);              // A row inside the tile
+        int row = m0 + r;
+        row = row < g.M ? row : g.M - 1;
+        const int slot = (lane & 7) ^ ((r >> 1) & 7);       // swizzled 16-B k-slot this lane fetches
+        a_src[i] = A + (int64_t)row * g.lda + slot * 4;
+        const int br = piece * 2 + (lane >> 5);
+        int col = n0 + (lane & 31) * 4;
+        col = col < g.N ? col : (g.N >= 4 ? g.N - 4 : 0);
+        b_src[i] = Bm + (int64_t)br * g.ldb + col;
+    }
+    auto issue_tile = [&](int kt, int buf) {
+        float* S = smem + buf * STAGE;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma16(a_src[i] + k0, S + (wave * 4 + i) * 256);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma16(b_src[i] + (int64_t)k0 * g.ldb, S + BM * BK + (wave * 4 + i) * 256);
+    };
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -137,45 +286,51 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int nk = (g.K + BK - 1) / BK;
-    W2V2_LOAD_TILE(0);
-    W2V2_STORE_TILE(0);
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) W2V2_LOAD_TILE(kt + 1);     // in flight under the MFMAs below
-
-        const float* As = smem + cur * STAGE_FLOATS + (wm * 64 + li) * LDA_S + 4 * lh;
-        const float* Bs = smem + cur * STAGE_FLOATS + BM * LDA_S + (4 * lh) * LDB_S + wn * 64 + li;
+    // fragment read offsets: row i = wm*64 + mt*32 + li, k-slot j = 2 kb + lh, slot' = j ^ ((i >> 1) & 7)
+    int a_row[2], a_swz[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int i = wm * 64 + mt * 32 + li;
+        a_row[mt] = i * BK;
+        a_swz[mt] = (i >> 1) & 7;
+    }
+    auto compute = [&](int buf) {
+        const float* As = smem + buf * STAGE;
+        const float* Bs = smem + buf * STAGE + BM * BK + (4 * lh) * BN + wn * 64 + li;
 #pragma unroll
         for (int kb = 0; kb < BK / 8; ++kb) {
-            float4 a[2];
+            f32x4 a[2];
             float b[2][4];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
-                a[mt] = *reinterpret_cast<const float4*>(As + mt * 32 * LDA_S + kb * 8);
+                a[mt] = *reinterpret_cast<const f32x4*>(As + a_row[mt] + (((2 * kb + lh) ^ a_swz[mt]) << 2));
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) b[nt][e] = Bs[(kb * 8 + e) * LDB_S + nt * 32];
+                for (int e = 0; e < 4; ++e) b[nt][e] = Bs[(kb * 8 + e) * BN + nt * 32];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const float av = e == 0 ? a[mt].x : e == 1 ? a[mt].y : e == 2 ? a[mt].z : a[mt].w;
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[nt][e], acc[mt][nt], 0, 0, 0);
-                }
-            }
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][e], b[nt][e], acc[mt][nt], 0, 0, 0);
         }
-        if (kt + 1 < nk) W2V2_STORE_TILE(cur ^ 1);
+    };
+
+    const int nk = g.K / BK;
+    issue_tile(0, 0);
+    __syncthreads();                    // carries the vmcnt(0) that retires the DMA
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        const int cur = kt & 1;
+        issue_tile(kt + 1, cur ^ 1);    // DMA into the other buffer, in flight under the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        compute(cur);
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
     }
+    compute((nk - 1) & 1);
 
-    // ---- epilogue: bias -> activation -> + residual -> store -------------------
-    // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     float* __restrict__ C = g.C + (int64_t)z * g.strideC;
     const float* __restrict__ R = g.residual ? g.residual + (int64_t)z * g.strideC : nullptr;
 #pragma unroll
@@ -198,6 +353,47 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     }
 }
 
+template <int MINW>
+int launch_dma(GemmArgs& g, int nbatch, hipStream_t s) {
+    g.tiles_m = (g.M + 127) / 128;
+    g.tiles_n = (g.N + 127) / 128;
+    dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch), block(256);
+    hipLaunchKernelGGL(gemm_f32_dma_kernel<MINW>, grid, block, 2 * (128 * BK + BK * 128) * sizeof(float), s, g);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int MINW>
+int launch_cfg(GemmArgs& g, bool fast, int nbatch, hipStream_t s) {
+    using C_ = Cfg<BM, BN, WM, WN>;
+    g.tiles_m = (g.M + BM - 1) / BM;
+    g.tiles_n = (g.N + BN - 1) / BN;
+    static bool attr_set = false;
+    if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in
+        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<true, BM, BN, WM, WN, MINW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C_::LDS));
+        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<false, BM, BN, WM, WN, MINW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)C_::LDS));
+        attr_set = true;
+    }
+    dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch), block(C_::NT);
+    if (fast)
+        hipLaunchKernelGGL((gemm_f32_kernel<true, BM, BN, WM, WN, MINW>), grid, block, C_::LDS, s, g);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<false, BM, BN, WM, WN, MINW>), grid, block, C_::LDS, s, g);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
+int forced_cfg() {
+    static int v = -2;
+    if (v == -2) {
+        const char* e = getenv("W2V2_GEMM_CFG");   // tuning knob, not part of the ABI
+        v = e ? atoi(e) : -1;
+    }
+    return v;
+}
+
 }  // namespace
 
 int launch_gemm(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const float* B,
@@ -211,29 +407,24 @@ int launch_gemm(Profiler* prof, const float* A, int64_t lda, int64_t strideA, co
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.residual = residual;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.strideA = strideA; g.strideC = strideC;
     g.M = M; g.N = N; g.K = K; g.act = act;
-    g.tiles_m = (M + BM - 1) / BM;
-    g.tiles_n = (N + BN - 1) / BN;
     const bool fast = (K % BK == 0) && (N % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) &&
                       (strideA % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
-    dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch), block(256);
-    const size_t lds = 2 * STAGE_FLOATS * sizeof(float);   // 68 KiB: above the 64 KiB default cap
-    static bool attr_set = false;
-    if (!attr_set) {
-        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
     ProfScope ps(prof, FAM_GEMM, 2.0 * M * (double)N * K * nbatch,
                  4.0 * nbatch * ((double)M * K + (double)M * N) + 4.0 * (double)K * N, s);
-    if (fast)
-        hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, block, lds, s, g);
-    else
-        hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, block, lds, s, g);
-    W2V2_HIP_CHECK(hipGetLastError());
-    return W2V2_OK;
+    int cfg = forced_cfg();
+    // default: the LDS-DMA 128x128 kernel whenever the shape allows 16-byte global accesses (every
+    // GEMM of the model does); measured on MI355X, B=32 base shapes: DMA 112-123 TF, register-staged
+    // 128x128 107-120, 128x256 / 256x128 (1 wave per SIMD) 75-100, 256x256 8-wave 67-115.
+    if (cfg < 0) cfg = 4;
+    switch (cfg) {
+        case 1: return launch_cfg<128, 256, 2, 2, 1>(g, fast, nbatch, s);
+        case 2: return launch_cfg<256, 128, 2, 2, 1>(g, fast, nbatch, s);
+        case 3: return launch_cfg<256, 256, 4, 2, 2>(g, fast, nbatch, s);
+        case 4: if (fast) return launch_dma<2>(g, nbatch, s); return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
+        case 5: if (fast) return launch_dma<3>(g, nbatch, s); return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
+        default: return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
+    }
 }
 
 }  // namespace w2v2
