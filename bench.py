@@ -60,6 +60,21 @@ def cpu_baseline(cfg, weights, L, max_seconds=30.0):
     }
 
 
+def measured_traffic():
+    """HBM bytes per GEMM launch from the committed rocprofv3 --pmc summary of this same command
+    (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction; tools/prof_summary.py)."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
+    try:
+        with open(path) as f:
+            js = json.load(f)
+        for k, v in js.items():
+            if "gemm_f32" in k:
+                return round(v["fetch_corrected_bytes"] + v["write_bytes"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,24 +86,20 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     args = ap.parse_args()
 
-    import numpy as np
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import wav2vec2
+    from wav2vec2 import dist as D
+    from wav2vec2 import variables as V
+
+    world, rank, local_rank = D.env_world()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
-
-    import wav2vec2
-    from wav2vec2 import variables as V
+    D.init(backend="nccl", device=dev)        # RCCL; no-op for a single process
 
     cfg = wav2vec2.Wav2Vec2Config()
     weights = V.seeded_weights(cfg, seed=0)
@@ -102,10 +113,7 @@ def main():
     x = torch.randn((B, L), generator=gen, device=dev, dtype=torch.float32)   # resident in HBM
 
     def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        D.barrier(sync_device=torch.cuda.synchronize)
 
     for _ in range(args.warmup):
         out = model(x)
@@ -122,10 +130,7 @@ def main():
     model.profile(False)
     assert tuple(out.shape) == (B, T, cfg.vocab_size) and bool(torch.isfinite(out).all())
 
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = D.max_over_ranks(elapsed, device=dev)      # the slowest rank defines the step
 
     if rank == 0:
         audio_s = world * B * L / SAMPLE_RATE * args.steps
@@ -151,7 +156,8 @@ def main():
             res["roofline"] = {
                 "kernel": "gemm_f32_kernel (fp32 MFMA 32x32x2: conv1-6 implicit GEMM + all Dense layers)",
                 "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(),
+                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
                 "launches_per_step": gm["launches"] // max(1, args.steps),
                 "avg_launch_ms": round(gm["ms"] / max(1, gm["launches"]), 4),
             }
