@@ -235,12 +235,20 @@ __device__ __forceinline__ void dma16(const float* g, float* l) {
     __builtin_amdgcn_global_load_lds((glb_f32*)g, (lds_f32*)l, 16, 0, 0);
 }
 
-template <int MINW>
-__global__ __launch_bounds__(256, MINW) void gemm_f32_dma_kernel(GemmArgs g) {
-    constexpr int BM = 128, BN = 128, STAGE = BM * BK + BK * BN;   // 8192 floats = 32 KiB
+template <int WM, int WN, int MINW, int BKT>
+__global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_f32_dma_kernel(GemmArgs g) {
+    constexpr int BM = 128, BN = 128, STAGE = BM * BKT + BKT * BN;   // 32 KiB at BKT = 32
+    constexpr int RPP = 256 / BKT;              // A rows per 1-KiB DMA piece (8 | 16)
+    constexpr int SPR = BKT / 4;                // 16-B k-slots per A row (8 | 4)
+    constexpr int SW = BKT == 32 ? 1 : 2;       // swizzle: slot ^= (row >> SW) & (SPR - 1)
+    constexpr int NPIECE = BM * BKT / 256;      // pieces per operand per K tile (16 | 8)
+    constexpr int NW = WM * WN;                 // waves per block
+    constexpr int PPW = NPIECE / NW;            // 1-KiB DMA pieces per wave per operand per K tile
+    constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 32, NTL = WTN / 32;
+    static_assert(PPW >= 1 && MT >= 1 && NTL >= 1, "bad wave grid");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN, li = lane & 31, lh = lane >> 5;
     const int nwg = g.tiles_m * g.tiles_n;
     int bid = blockIdx.x;
     {
@@ -253,16 +261,16 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_dma_kernel(GemmArgs g) {
     const float* __restrict__ A = g.A + (int64_t)z * g.strideA;
     const float* __restrict__ Bm = g.B;
 
-    // per-lane global sources of this wave's 4 A pieces and 4 B pieces (1 KiB each)
-    const float* a_src[4];
-    const float* b_src[4];
+    // per-lane global sources of this wave's A pieces and B pieces (1 KiB each)
+    const float* a_src[PPW];
+    const float* b_src[PPW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int piece = wave * 4 + i;                     // 16 pieces of 8 rows (A) / 2 rows (B)
-        const int r = piece * 8 + (lane >> 3);              // A row inside the tile
+    for (int i = 0; i < PPW; ++i) {
+        const int piece = wave * PPW + i;                   // pieces of RPP rows (A) / 2 rows (B)
+        const int r = piece * RPP + lane / SPR;             // A row inside the tile
         int row = m0 + r;
         row = row < g.M ? row : g.M - 1;
-        const int slot = (lane & 7) ^ ((r >> 1) & 7);       // swizzled 16-B k-slot this lane fetches
+        const int slot = (lane % SPR) ^ ((r >> SW) & (SPR - 1));   // swizzled 16-B k-slot this lane fetches
         a_src[i] = A + (int64_t)row * g.lda + slot * 4;
         const int br = piece * 2 + (lane >> 5);
         int col = n0 + (lane & 31) * 4;
@@ -271,54 +279,54 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_dma_kernel(GemmArgs g) {
     }
     auto issue_tile = [&](int kt, int buf) {
         float* S = smem + buf * STAGE;
-        const int k0 = kt * BK;
+        const int k0 = kt * BKT;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dma16(a_src[i] + k0, S + (wave * 4 + i) * 256);
+        for (int i = 0; i < PPW; ++i) dma16(a_src[i] + k0, S + (wave * PPW + i) * 256);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dma16(b_src[i] + (int64_t)k0 * g.ldb, S + BM * BK + (wave * 4 + i) * 256);
+        for (int i = 0; i < PPW; ++i) dma16(b_src[i] + (int64_t)k0 * g.ldb, S + BM * BKT + (wave * PPW + i) * 256);
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MT][NTL];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NTL; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    // fragment read offsets: row i = wm*64 + mt*32 + li, k-slot j = 2 kb + lh, slot' = j ^ ((i >> 1) & 7)
-    int a_row[2], a_swz[2];
+    // fragment read offsets: row i = wm*WTM + mt*32 + li, k-slot j = 2 kb + lh, slot' = j ^ ((i >> 1) & 7)
+    int a_row[MT], a_swz[MT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int i = wm * 64 + mt * 32 + li;
-        a_row[mt] = i * BK;
-        a_swz[mt] = (i >> 1) & 7;
+    for (int mt = 0; mt < MT; ++mt) {
+        const int i = wm * WTM + mt * 32 + li;
+        a_row[mt] = i * BKT;
+        a_swz[mt] = (i >> SW) & (SPR - 1);
     }
     auto compute = [&](int buf) {
         const float* As = smem + buf * STAGE;
-        const float* Bs = smem + buf * STAGE + BM * BK + (4 * lh) * BN + wn * 64 + li;
+        const float* Bs = smem + buf * STAGE + BM * BKT + (4 * lh) * BN + wn * WTN + li;
 #pragma unroll
-        for (int kb = 0; kb < BK / 8; ++kb) {
-            f32x4 a[2];
-            float b[2][4];
+        for (int kb = 0; kb < BKT / 8; ++kb) {
+            f32x4 a[MT];
+            float b[NTL][4];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
                 a[mt] = *reinterpret_cast<const f32x4*>(As + a_row[mt] + (((2 * kb + lh) ^ a_swz[mt]) << 2));
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) b[nt][e] = Bs[(kb * 8 + e) * BN + nt * 32];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
+                    for (int nt = 0; nt < NTL; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][e], b[nt][e], acc[mt][nt], 0, 0, 0);
         }
     };
 
-    const int nk = g.K / BK;
+    const int nk = g.K / BKT;
     issue_tile(0, 0);
     __syncthreads();                    // carries the vmcnt(0) that retires the DMA
     for (int kt = 0; kt + 1 < nk; ++kt) {
@@ -334,15 +342,15 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_dma_kernel(GemmArgs g) {
     float* __restrict__ C = g.C + (int64_t)z * g.strideC;
     const float* __restrict__ R = g.residual ? g.residual + (int64_t)z * g.strideC : nullptr;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int col = n0 + wn * 64 + nt * 32 + li;
+    for (int nt = 0; nt < NTL; ++nt) {
+        const int col = n0 + wn * WTN + nt * 32 + li;
         if (col >= g.N) continue;
         const float bv = g.bias ? g.bias[col] : 0.0f;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int row = m0 + wm * WTM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row < g.M) {
                     float v = apply_act(acc[mt][nt][r] + bv, g.act);
                     if (R) v += R[(int64_t)row * g.ldc + col];
@@ -353,12 +361,12 @@ __global__ __launch_bounds__(256, MINW) void gemm_f32_dma_kernel(GemmArgs g) {
     }
 }
 
-template <int MINW>
+template <int WM, int WN, int MINW, int BKT = 32>
 int launch_dma(GemmArgs& g, int nbatch, hipStream_t s) {
     g.tiles_m = (g.M + 127) / 128;
     g.tiles_n = (g.N + 127) / 128;
-    dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch), block(256);
-    hipLaunchKernelGGL(gemm_f32_dma_kernel<MINW>, grid, block, 2 * (128 * BK + BK * 128) * sizeof(float), s, g);
+    dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch), block(WM * WN * 64);
+    hipLaunchKernelGGL((gemm_f32_dma_kernel<WM, WN, MINW, BKT>), grid, block, 2 * (128 * BKT + BKT * 128) * sizeof(float), s, g);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -413,16 +421,23 @@ int launch_gemm(Profiler* prof, const float* A, int64_t lda, int64_t strideA, co
     ProfScope ps(prof, FAM_GEMM, 2.0 * M * (double)N * K * nbatch,
                  4.0 * nbatch * ((double)M * K + (double)M * N) + 4.0 * (double)K * N, s);
     int cfg = forced_cfg();
-    // default: the LDS-DMA 128x128 kernel whenever the shape allows 16-byte global accesses (every
-    // GEMM of the model does); measured on MI355X, B=32 base shapes: DMA 112-123 TF, register-staged
-    // 128x128 107-120, 128x256 / 256x128 (1 wave per SIMD) 75-100, 256x256 8-wave 67-115.
-    if (cfg < 0) cfg = 4;
+    // default: the LDS-DMA 128x128 kernel with 8 waves (2x4, each wave 64x32), 2 blocks per CU = 4 waves
+    // per SIMD, whenever the shape allows 16-byte global accesses (every GEMM of the model does).
+    // Measured on MI355X, B=32 base shapes (profiles/r01_gemm_tile_study.md): this 118-129 TF; the same
+    // with 4 waves 112-123; register-staged 128x128 107-120; 128x256 / 256x128 at 1 wave per SIMD 75-100;
+    // 256x256 8-wave 67-115; BK=16 variants with 3-4 blocks per CU 114-125.
+    if (cfg < 0) cfg = 7;
     switch (cfg) {
         case 1: return launch_cfg<128, 256, 2, 2, 1>(g, fast, nbatch, s);
         case 2: return launch_cfg<256, 128, 2, 2, 1>(g, fast, nbatch, s);
         case 3: return launch_cfg<256, 256, 4, 2, 2>(g, fast, nbatch, s);
-        case 4: if (fast) return launch_dma<2>(g, nbatch, s); return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
-        case 5: if (fast) return launch_dma<3>(g, nbatch, s); return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
+        case 4: if (fast) return launch_dma<2, 2, 2>(g, nbatch, s); return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
+        case 6: if (fast) return launch_dma<4, 2, 2>(g, nbatch, s); return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
+        case 7: if (fast) return launch_dma<2, 4, 2>(g, nbatch, s); return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
+        case 9: if (fast) return launch_dma<2, 4, 3, 16>(g, nbatch, s); return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
+        case 10: if (fast) return launch_dma<2, 4, 4, 16>(g, nbatch, s); return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
+        case 11: if (fast) return launch_dma<2, 2, 4, 16>(g, nbatch, s); return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
+        case 8: if (fast) return launch_dma<4, 4, 1>(g, nbatch, s); return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
         default: return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
     }
 }

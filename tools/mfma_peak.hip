@@ -6,10 +6,13 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void k(float* out, int iters) {
+__global__ __launch_bounds__(256, 2) void k(float* out, int iters, int rnd) {
     __shared__ __attribute__((aligned(16))) float lds[128 * 36 + 32 * 128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-    for (int i = tid; i < 128 * 36 + 32 * 128; i += 256) lds[i] = (float)(i % 7) * 0.01f;
+    for (int i = tid; i < 128 * 36 + 32 * 128; i += 256) {
+        unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        lds[i] = rnd ? ((float)(h & 0xFFFFFF) / 8388608.0f - 1.0f) : (float)(i % 7) * 0.01f;   // full-entropy mantissas vs low-entropy
+    }
     __syncthreads();
     f32x16 acc[2][2];
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
@@ -51,26 +54,26 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int iters) {
 }
 
 template <int MODE>
-void run(const char* name, int blocks) {
+void run(const char* name, int blocks, int rnd, int iters) {
     float* out; hipMalloc(&out, blocks * 256 * 4);
-    const int iters = 2000;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, 10);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, 10, rnd);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, iters);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, iters, rnd);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     double flops = (double)blocks * 4 * iters * 64 * 4096.0;
-    printf("%-28s blocks=%4d  %.3f ms  %.1f TFLOP/s\n", name, blocks, ms, flops / ms / 1e9);
+    printf("%-28s rnd=%d blocks=%4d  %8.3f ms  %.1f TFLOP/s\n", name, rnd, blocks, ms, flops / ms / 1e9);
     hipFree(out);
 }
 int main() {
     for (int rep = 0; rep < 2; ++rep) {
-        run<0>("registers only, 2 blk/CU", 512);
-        run<0>("registers only, 1 blk/CU", 256);
-        run<1>("LDS fragment reads, 2 blk/CU", 512);
-        run<1>("LDS fragment reads, 1 blk/CU", 256);
+        run<0>("registers only, 2 blk/CU", 512, 0, 2000);
+        run<1>("LDS fragment reads, 2 blk/CU", 512, 0, 2000);
+        run<1>("LDS fragment reads, 2 blk/CU", 512, 1, 2000);
+        run<1>("LDS fragment reads, 2 blk/CU", 512, 1, 20000);   // ~70 ms: long enough for DVFS to settle
+        run<1>("LDS fragment reads, 2 blk/CU", 512, 0, 20000);
     }
     return 0;
 }
