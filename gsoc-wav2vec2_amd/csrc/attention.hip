@@ -17,8 +17,12 @@
 // key assignment.  No LDS round trip, no transposes, no cross-lane traffic
 // beyond the one max/sum exchange.
 //
-// Block = 4 waves x 32 queries of one (batch, head); K and V tiles of 64 keys
-// are staged in LDS (register-prefetched one tile ahead) and shared by the waves.
+// Block = NW waves x 32 queries of one (batch, head) (NW in {4, 6, 8, 12}, picked per launch to fill
+// the 256 CUs in whole rounds); K and V tiles of 64 keys reach LDS by LDS-DMA, double-buffered, one
+// barrier per tile, and are shared by the waves.
+#include <limits.h>
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace w2v2 {
@@ -27,7 +31,6 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 namespace {
 
-constexpr int QB = 128;   // queries per block
 constexpr int KT = 64;    // keys per tile
 
 struct AttnArgs {
@@ -42,21 +45,33 @@ __device__ __forceinline__ float f4get(const float4& v, int e) {
     return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w;
 }
 
-template <int DH>
-__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
-    constexpr int JD = DH / 8;          // 8-wide d blocks for the QK^T contraction
-    constexpr int DT = DH / 32;         // 32-wide d tiles of the output
-    constexpr int KS = DH + 4;          // K tile row stride: conflict-free ds_read_b128 column slices
-    constexpr int F4 = DH / 4;          // float4 per row
-    constexpr int NLD = KT * F4 / 256;  // float4 per thread per tile (K and V each)
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef const __attribute__((address_space(1))) float glb_f32;
+__device__ __forceinline__ void dma16(const float* g, float* l) {
+    __builtin_amdgcn_global_load_lds((glb_f32*)g, (lds_f32*)l, 16, 0, 0);
+}
+
+// DH = head size, NW = waves per block (32 queries each).
+// K/V tiles go HBM/L2 -> LDS by LDS-DMA (1 KiB per wave instruction), double-buffered, one barrier per
+// tile.  The DMA writes LDS lane-linearly, so the K image (read as 16-byte column slices by 16 rows at a
+// time) is XOR-swizzled on the global SOURCE address and again on the read; V is read row-contiguously
+// and needs no swizzle.
+template <int DH, int NW>
+__global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a) {
+    constexpr int JD = DH / 8;            // 8-wide d blocks for the QK^T contraction
+    constexpr int DT = DH / 32;           // 32-wide d tiles of the output
+    constexpr int SPR = DH / 4;           // 16-B slots per row
+    constexpr int RPP = 256 / DH;         // rows per 1-KiB DMA piece
+    constexpr int NP = KT * DH / 256;     // pieces per operand per tile
+    constexpr int SH = DH == 32 ? 1 : 0;  // swizzle: slot ^= (row >> SH) & SWM
+    constexpr int SWM = (SPR < 16 ? SPR : 16) - 1;
+    constexpr int STAGE = 2 * KT * DH;    // floats per buffer (K then V)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ks = smem;                   // KT x KS
-    float* Vs = smem + KT * KS;         // KT x DH
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * QB + wave * 32;
+    const int q0 = (blockIdx.x * NW + wave) * 32;
     const int64_t ld = 3 * (int64_t)a.H;
     const float* __restrict__ base = a.qkv + (int64_t)b * a.T * ld + head * DH;
     const int flen = a.frame_len ? a.frame_len[b] : a.T;
@@ -73,28 +88,18 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
         }
     }
 
-    // ---- K/V tile staging: thread -> rows (tid / F4) + (256 / F4) i, float4 column tid % F4 ----
-    float4 kr[NLD], vr[NLD];
-    const int s_row = tid / F4, s_c4 = (tid % F4) * 4;
-    auto tile_load = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int key = k0 + s_row + (256 / F4) * i;
-            const bool ok = key < a.T;
-            const float* p = base + (int64_t)(ok ? key : a.T - 1) * ld + s_c4;
-            const float4 kv = *reinterpret_cast<const float4*>(p + a.H);
-            const float4 vv = *reinterpret_cast<const float4*>(p + 2 * a.H);
-            const float z = ok ? 1.0f : 0.0f;     // rows past T contribute exact zeros (never NaN * 0)
-            kr[i] = make_float4(kv.x * z, kv.y * z, kv.z * z, kv.w * z);
-            vr[i] = make_float4(vv.x * z, vv.y * z, vv.z * z, vv.w * z);
-        }
-    };
-    auto tile_store = [&]() {
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int r = s_row + (256 / F4) * i;
-            *reinterpret_cast<float4*>(Ks + r * KS + s_c4) = kr[i];
-            *reinterpret_cast<float4*>(Vs + r * DH + s_c4) = vr[i];
+    // ---- tile DMA: piece p (wave-uniform) covers rows p*RPP .. of K (p < NP) or V (p >= NP) ----
+    const int p_row = lane / SPR, p_slot = lane % SPR;
+    auto issue_tile = [&](int tile, int buf) {
+        float* S = smem + buf * STAGE;
+        const int k0 = tile * KT;
+        for (int p = wave; p < 2 * NP; p += NW) {
+            const bool isv = p >= NP;
+            const int pp = isv ? p - NP : p;
+            const int r = pp * RPP + p_row;                       // row inside the tile
+            const int key = min(k0 + r, a.T - 1);                 // clamp: tail rows are masked / weighted 0
+            const int slot = isv ? p_slot : (p_slot ^ ((r >> SH) & SWM));
+            dma16(base + (int64_t)key * ld + (isv ? 2 : 1) * a.H + slot * 4, S + p * 256);
         }
     };
 
@@ -106,13 +111,15 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     float m_run = -INFINITY, l_run = 0.f;
 
     const int ntiles = (a.T + KT - 1) / KT;
-    tile_load(0);
-    tile_store();
-    __syncthreads();
+    issue_tile(0, 0);
+    __syncthreads();                       // carries the vmcnt(0) that retires the DMA
 
     for (int tile = 0; tile < ntiles; ++tile) {
-        const int k0 = tile * KT;
-        tile_load(min(tile + 1, ntiles - 1) * KT);        // unconditional prefetch (last one redundant)
+        const int k0 = tile * KT, buf = tile & 1;
+        if (tile + 1 < ntiles) issue_tile(tile + 1, buf ^ 1);     // wave-uniform branch; no registers involved
+        __builtin_amdgcn_sched_barrier(0);
+        const float* Ks = smem + buf * STAGE;
+        const float* Vs = Ks + KT * DH;
 
         // ---- S^T = K Q^T for two 32-key sub-tiles ----
         f32x16 s[2];
@@ -120,10 +127,12 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-            const float* kp = Ks + (kt * 32 + li) * KS + 4 * lh;
+            const int row = kt * 32 + li;
+            const float* kp = Ks + row * DH;
+            const int sw = (row >> SH) & SWM;
 #pragma unroll
             for (int j = 0; j < JD; ++j) {
-                const float4 kf = *reinterpret_cast<const float4*>(kp + 8 * j);
+                const float4 kf = *reinterpret_cast<const float4*>(kp + (((2 * j + lh) ^ sw) << 2));
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(kf, e), f4get(qf[j], e), s[kt], 0, 0, 0);
@@ -144,7 +153,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
             }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = expf(m_run - m_new);        // exp(-inf) = 0 on the first tile
+        const float alpha = expf(m_run - m_new);          // exp(-inf) = 0 on the first tile
         float rs = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
@@ -172,10 +181,8 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
                 for (int d = 0; d < DT; ++d)
                     o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * d], s[kt][r], o[d], 0, 0, 0);
             }
-
-        __syncthreads();            // every wave is done reading this tile
-        tile_store();
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();            // next tile landed (vmcnt 0) and every wave is done with this one
     }
 
     // ---- normalise and store: O^T rows are d = 32 dt + (r&3) + 8 (r>>2) + 4 lh, column = query ----
@@ -193,13 +200,55 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     }
 }
 
-template <int DH>
-int launch_attn(const AttnArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)(KT * (DH + 4) + KT * DH) * sizeof(float);
-    dim3 grid((a.T + QB - 1) / QB, a.heads, a.B), block(256);
-    hipLaunchKernelGGL(attention_kernel<DH>, grid, block, lds, s, a);
+template <int DH, int NW>
+int launch_attn_nw(const AttnArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)2 * 2 * KT * DH * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<DH, NW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int qb = NW * 32;
+    dim3 grid((a.T + qb - 1) / qb, a.heads, a.B), block(NW * 64);
+    hipLaunchKernelGGL((attention_kernel<DH, NW>), grid, block, lds, s, a);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
+}
+
+// Pick the queries-per-block that fills 256 CUs in the fewest rounds.  Waves per block stay a multiple
+// of 4 (one per SIMD; 6 waves measured 77 TF vs 95-105: two SIMDs carry double load).  Measured at
+// T=768, B=32, 12 heads: 4 waves (2 blocks/CU) 95 TF, 8 waves 93, 12 waves (3 per SIMD) 105.
+template <int DH>
+int launch_attn(const AttnArgs& a, hipStream_t s) {
+    static int forced = -2;
+    if (forced == -2) {
+        const char* e = getenv("W2V2_ATTN_NW");     // tuning knob, not part of the ABI
+        forced = e ? atoi(e) : -1;
+    }
+    const int cand[3] = {12, 8, 4};
+    int best = 4;
+    int64_t best_cost = INT64_MAX;
+    for (int i = 0; i < 3; ++i) {
+        const int nw = cand[i];
+        if (DH == 128 && nw == 12) continue;                  // 241 VGPRs: 3 waves per SIMD would spill
+        const int bpc = (DH != 128 && nw == 4) ? 2 : 1;       // blocks per CU the VGPR / LDS budget admits
+        const int64_t nblk = (int64_t)((a.T + nw * 32 - 1) / (nw * 32)) * a.heads * a.B;
+        const int64_t rounds = (nblk + 256 * bpc - 1) / (256 * bpc);
+        const int64_t cost = rounds * nw * bpc * (nw == 12 ? 9 : 10);   // 3 waves per SIMD run ~10 % better
+        if (cost < best_cost) { best_cost = cost; best = nw; }
+    }
+    if (forced > 0) best = forced;
+    if constexpr (DH == 128) {
+        return best == 8 ? launch_attn_nw<DH, 8>(a, s) : launch_attn_nw<DH, 4>(a, s);
+    } else {
+        switch (best) {
+            case 6: return launch_attn_nw<DH, 6>(a, s);
+            case 8: return launch_attn_nw<DH, 8>(a, s);
+            case 12: return launch_attn_nw<DH, 12>(a, s);
+            default: return launch_attn_nw<DH, 4>(a, s);
+        }
+    }
 }
 
 }  // namespace
