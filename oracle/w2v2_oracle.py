@@ -32,6 +32,8 @@ tests and could not be executed here.
 """
 
 import math
+import os
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -44,12 +46,41 @@ except Exception:  # pragma: no cover
 # --------------------------------------------------------------------------
 # elementwise / normalisation primitives
 # --------------------------------------------------------------------------
+_POOL = None
+
+
+def _chunked(fn, x, min_elems=1 << 20):
+    """Apply an elementwise `fn` over row chunks of `x` on a thread pool (numpy / scipy ufuncs release
+    the GIL).  Same arithmetic per element; only there so that the CPU baseline is not dominated by
+    single-threaded ufunc loops while BLAS uses every core."""
+    global _POOL
+    if x.size < min_elems:
+        return fn(x)
+    flat = x.reshape(-1, x.shape[-1])
+    n = min(64, os.cpu_count() or 1, max(1, x.size // min_elems))
+    if n <= 1:
+        return fn(x)
+    if _POOL is None:
+        _POOL = ThreadPoolExecutor(max_workers=min(64, os.cpu_count() or 1))
+    out = np.empty_like(flat)
+    bounds = np.linspace(0, flat.shape[0], n + 1).astype(int)
+
+    def work(i):
+        out[bounds[i]:bounds[i + 1]] = fn(flat[bounds[i]:bounds[i + 1]])
+    list(_POOL.map(work, range(n)))
+    return out.reshape(x.shape)
+
+
+def _gelu_exact(x):
+    return (0.5 * x * (1.0 + _erf(x * x.dtype.type(1.0 / math.sqrt(2.0))))).astype(x.dtype, copy=False)
+
+
 def gelu(x, approximate=False):
     """tf.nn.gelu as called at feature_extractor.py:58, encoder.py:127,181."""
     if approximate:
         c = x.dtype.type(math.sqrt(2.0 / math.pi))
-        return (0.5 * x * (1.0 + np.tanh(c * (x + 0.044715 * x ** 3)))).astype(x.dtype)
-    return (0.5 * x * (1.0 + _erf(x * x.dtype.type(1.0 / math.sqrt(2.0))))).astype(x.dtype)
+        return (0.5 * x * (1.0 + np.tanh(c * (x + 0.044715 * x ** 3)))).astype(x.dtype, copy=False)
+    return _chunked(_gelu_exact, x)
 
 
 def layer_norm(x, gamma, beta, eps):
@@ -67,9 +98,12 @@ def group_norm_time(x, gamma, beta, eps=1e-5):
     axis 1, population variance, then tf.nn.batch_normalization with
     gamma/beta broadcast as (1, 1, C)); called at feature_extractor.py:40-47."""
     mean = x.mean(axis=1, keepdims=True, dtype=np.float64)
-    var = ((x.astype(np.float64) - mean) ** 2).mean(axis=1, keepdims=True)
-    y = (x - mean) / np.sqrt(var + eps) * gamma + beta
-    return y.astype(x.dtype)
+    # E[(x - mean)^2] accumulated in fp64 without materialising an fp64 copy of x
+    xc = x - mean.astype(x.dtype)
+    var = np.einsum("btc,btc->bc", xc, xc, dtype=np.float64)[:, None, :] / x.shape[1]
+    scale = (gamma / np.sqrt(var + eps)).astype(x.dtype)
+    shift = (beta - (mean - mean.astype(x.dtype)) * scale).astype(x.dtype)   # residual of the fp32 centring
+    return (xc * scale + shift).astype(x.dtype, copy=False)
 
 
 def normalize(x):

@@ -189,3 +189,38 @@ def test_linearity_of_lm_head_at_full_size(torch_mod):
     b = m(x[perm]).numpy()
     assert a.shape == (B, 768, 32) and np.isfinite(a).all()
     assert np.array_equal(a[perm], b)
+
+
+def test_large_robust_full_length_vs_oracle(torch_mod):
+    """BASELINE config 4 shape: wav2vec2-large-robust (24L / 1024d, prenorm, LayerNorm convs, conv bias)
+    at 246000 samples with an attention mask (one full row, one row with 100000 padded samples)."""
+    import wav2vec2
+    from wav2vec2.config import RobustWav2Vec2Config
+    cfg = RobustWav2Vec2Config()
+    w = V.seeded_weights(cfg, seed=5)
+    L = 246000
+    x = V.hash_normal("robust/full", 2 * L, 6).reshape(2, L)
+    mask = np.ones((2, L), np.int32)
+    mask[1, 146000:] = 0
+    x = (x * mask).astype(np.float32)
+    m = wav2vec2.Wav2Vec2ForCTC(cfg, input_shape=(2, L))
+    m.set_weights(w)
+    got = m(x, attention_mask=mask).numpy()
+    ref = O.ctc_forward(cfg, w, x, mask)
+    assert got.shape == (2, 768, 32)
+    err = H.max_err(got, ref)
+    report("robust_full_246000/logits_vs_oracle_f32", err)
+    assert err < H.ATOL_AIM
+
+
+def test_long_form_480000_vs_oracle(torch_mod):
+    """BASELINE config 5 input length: 480000 samples -> T = 1499 frames (not a multiple of any tile)."""
+    m, cfg = build("base_sample_padded")
+    L = 480000
+    x = V.hash_normal("long/wave", L, 7).reshape(1, L)
+    got = m(x).numpy()
+    ref = O.ctc_forward(cfg, H.case_weights("base_sample_padded"), x)
+    assert got.shape == (1, 1499, 32)
+    err = H.max_err(got, ref)
+    report("base_480000/logits_vs_oracle_f32", err)
+    assert err < H.ATOL_AIM
