@@ -24,6 +24,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "train.h"
 
 namespace w2v2 {
 
@@ -56,8 +57,8 @@ __device__ __forceinline__ void dma16(const float* g, float* l) {
 // tile.  The DMA writes LDS lane-linearly, so the K image (read as 16-byte column slices by 16 rows at a
 // time) is XOR-swizzled on the global SOURCE address and again on the read; V is read row-contiguously
 // and needs no swizzle.
-template <int DH, int NW>
-__global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a) {
+template <int DH, int NW, bool TRAIN = false>
+__global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a, AttnTrain tr) {
     constexpr int JD = DH / 8;            // 8-wide d blocks for the QK^T contraction
     constexpr int DT = DH / 32;           // 32-wide d tiles of the output
     constexpr int SPR = DH / 4;           // 16-B slots per row
@@ -166,6 +167,18 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a) {
         rs += __shfl_xor(rs, 32, 64);
         l_run = l_run * alpha + rs;
         m_run = m_new;
+        if (TRAIN && tr.p > 0.f) {
+            // attention-probability dropout (encoder.py:42-44): the row sum above uses the un-dropped p
+            const float inv = 1.0f / (1.0f - tr.p);
+            const uint64_t rowbase = (((uint64_t)b * a.heads + head) * a.T + (uint64_t)min(q0 + li, a.T - 1)) * a.T;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    s[kt][r] = dropout_keep(tr.seed, tr.stream, rowbase + key, tr.p) ? s[kt][r] * inv : 0.f;
+                }
+        }
 #pragma unroll
         for (int d = 0; d < DT; ++d)
 #pragma unroll
@@ -187,6 +200,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a) {
 
     // ---- normalise and store: O^T rows are d = 32 dt + (r&3) + 8 (r>>2) + 4 lh, column = query ----
     const int q = q0 + li;
+    if (TRAIN && q < a.T && lh == 0) tr.lse[((int64_t)b * a.heads + head) * a.T + q] = m_run + logf(l_run);
     if (q < a.T) {
         const float inv = 1.0f / l_run;
         float* op = a.ctx + ((int64_t)b * a.T + q) * a.H + head * DH + 4 * lh;
@@ -211,7 +225,7 @@ int launch_attn_nw(const AttnArgs& a, hipStream_t s) {
     }
     const int qb = NW * 32;
     dim3 grid((a.T + qb - 1) / qb, a.heads, a.B), block(NW * 64);
-    hipLaunchKernelGGL((attention_kernel<DH, NW>), grid, block, lds, s, a);
+    hipLaunchKernelGGL((attention_kernel<DH, NW>), grid, block, lds, s, a, AttnTrain{0.f, 0, 0, nullptr});
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -251,6 +265,323 @@ int launch_attn(const AttnArgs& a, hipStream_t s) {
     }
 }
 
+
+// ======================================================================================
+// Training: forward with attention-probability dropout + saved log-sum-exp, and backward.
+// The backward recomputes P from q, k and the saved lse (nothing T x T is ever stored):
+//   dP = (dO V^T) * keep/(1-p);   dS = P * (dP - D),  D[q] = sum_d dO[q,d] O[q,d];
+//   dQ = scale * dS K;   dK = scale * dS^T Q;   dV = Pd^T dO,  Pd = P * keep/(1-p).
+// Both kernels reuse the forward's layout trick: the wave that owns a COLUMN (a query for dQ, a key
+// for dK/dV) holds that column's [col][d] fragments in registers as MFMA B operands, the other side
+// streams through LDS tiles, and every T x T quantity (S, P, dP, dS) lives only in the MFMA C/D
+// registers of the lane that owns the column -- which is exactly the B-operand position of the next
+// contraction.
+// ======================================================================================
+template <int DH>
+struct Swz {
+    static constexpr int SPR = DH / 4, RPP = 256 / DH, NP = KT * DH / 256;
+    static constexpr int SH = DH == 32 ? 1 : 0, SWM = (SPR < 16 ? SPR : 16) - 1;
+    __device__ static __forceinline__ int f(int row) { return (row >> SH) & SWM; }
+};
+
+// DMA one KT x DH tile of rows [r0, r0 + KT) (clamped to T - 1) at column offset `col` of the packed
+// (B, T, ld) buffer into LDS at `dst`, XOR-swizzled; pieces striped over the block's NW waves.
+template <int DH, int NW>
+__device__ __forceinline__ void dma_tile_swz(const float* base, int64_t ld, int col, int r0, int T,
+                                              float* dst, int wave, int lane, int piece0) {
+    using Z = Swz<DH>;
+    const int p_row = lane / Z::SPR, p_slot = lane % Z::SPR;
+    for (int p = wave; p < Z::NP; p += NW) {
+        const int r = p * Z::RPP + p_row;
+        const int row = min(r0 + r, T - 1);
+        dma16(base + (int64_t)row * ld + col + ((p_slot ^ Z::f(r)) << 2), dst + (piece0 + p) * 256);
+    }
+}
+
+// D[b, h, t] = sum_d dO[b, t, h, d] * O[b, t, h, d]
+template <int DH>
+__global__ void attn_dvec_kernel(const float* __restrict__ o, const float* __restrict__ d_o, float* __restrict__ dvec,
+                                 int B, int T, int H, int heads) {
+    const int64_t row = blockIdx.x;            // (b, t)
+    const int b = (int)(row / T), t = (int)(row % T);
+    for (int h = threadIdx.x >> 6; h < heads; h += blockDim.x >> 6) {
+        const int lane = threadIdx.x & 63;
+        float acc = 0.f;
+        for (int d = lane; d < DH; d += 64) {
+            const int64_t i = row * H + h * DH + d;
+            acc += o[i] * d_o[i];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) dvec[((int64_t)b * heads + h) * T + t] = acc;
+    }
+}
+
+struct AttnBwdArgs {
+    const float* qkv;
+    const int32_t* frame_len;
+    const float* d_o;       // (B, T, H)
+    const float* dvec;      // (B, heads, T)
+    float* dqkv;            // (B, T, 3H)
+    int B, T, H, heads;
+    float scale;
+};
+
+// ---- dQ: block = 4 waves x 32 queries; loop over 64-key tiles of K and V ----
+template <int DH>
+__global__ __launch_bounds__(256) void attention_bwd_dq_kernel(AttnBwdArgs a, AttnTrain tr) {
+    using Z = Swz<DH>;
+    constexpr int NW = 4, JD = DH / 8, DT = DH / 32, STAGE = 2 * KT * DH;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int q0 = (blockIdx.x * NW + wave) * 32;
+    const int64_t ld = 3 * (int64_t)a.H;
+    const float* __restrict__ base = a.qkv + (int64_t)b * a.T * ld + head * DH;
+    const int flen = a.frame_len ? a.frame_len[b] : a.T;
+    const int qr = min(q0 + li, a.T - 1);
+    const bool qok = q0 + li < a.T;
+
+    float4 qf[JD], dof[JD];
+    {
+        const float* qp = base + (int64_t)qr * ld + 4 * lh;
+        const float* dp = a.d_o + ((int64_t)b * a.T + qr) * a.H + head * DH + 4 * lh;
+#pragma unroll
+        for (int j = 0; j < JD; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(qp + 8 * j);
+            qf[j] = make_float4(v.x * a.scale, v.y * a.scale, v.z * a.scale, v.w * a.scale);
+            dof[j] = *reinterpret_cast<const float4*>(dp + 8 * j);
+        }
+    }
+    const int64_t sidx = ((int64_t)b * a.heads + head) * a.T + qr;
+    const float lse = tr.lse[sidx], dv = a.dvec[sidx];
+    const float inv = tr.p > 0.f ? 1.0f / (1.0f - tr.p) : 1.0f;
+    const uint64_t rowbase = (uint64_t)sidx * a.T;
+
+    f32x16 dq[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
+
+    auto issue = [&](int tile, int buf) {
+        float* S = smem + buf * STAGE;
+        dma_tile_swz<DH, NW>(base, ld, a.H, tile * KT, a.T, S, wave, lane, 0);              // K
+        dma_tile_swz<DH, NW>(base, ld, 2 * a.H, tile * KT, a.T, S, wave, lane, Z::NP);      // V
+    };
+    const int ntiles = (a.T + KT - 1) / KT;
+    issue(0, 0);
+    __syncthreads();
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int k0 = tile * KT, buf = tile & 1;
+        if (tile + 1 < ntiles) issue(tile + 1, buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const float* Ks = smem + buf * STAGE;
+        const float* Vs = Ks + KT * DH;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+            const int row = kt * 32 + li, sw = Z::f(row);
+#pragma unroll
+            for (int j = 0; j < JD; ++j) {
+                const float4 kf = *reinterpret_cast<const float4*>(Ks + row * DH + (((2 * j + lh) ^ sw) << 2));
+                const float4 vf = *reinterpret_cast<const float4*>(Vs + row * DH + (((2 * j + lh) ^ sw) << 2));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(kf, e), f4get(qf[j], e), s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(vf, e), f4get(dof[j], e), dp, 0, 0, 0);
+                }
+            }
+            // dS^T = P^T * (dP^T * keep/(1-p) - D)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float sv = s[r];
+                sv = key >= flen ? sv - 10000.0f : sv;
+                const float pv = (key < a.T && qok) ? expf(sv - lse) : 0.f;
+                float g = dp[r];
+                if (tr.p > 0.f) g = dropout_keep(tr.seed, tr.stream, rowbase + key, tr.p) ? g * inv : 0.f;
+                s[r] = pv * (g - dv);
+            }
+            // dQ^T[d][q] += sum_key K[key][d] dS^T[key][q]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int krow = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int ksw = Z::f(krow);
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    const int dd = 32 * d + li;
+                    const float kv = Ks[krow * DH + ((((dd >> 2) ^ ksw)) << 2) + (dd & 3)];
+                    dq[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv, s[r], dq[d], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+    if (qok) {
+        float* op = a.dqkv + ((int64_t)b * a.T + q0 + li) * ld + head * DH + 4 * lh;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(op + 32 * d + 8 * g) =
+                    make_float4(dq[d][4 * g] * a.scale, dq[d][4 * g + 1] * a.scale, dq[d][4 * g + 2] * a.scale,
+                                dq[d][4 * g + 3] * a.scale);
+    }
+}
+
+// ---- dK, dV: block = 4 waves x 32 keys; loop over 64-query tiles of Q and dO (+ their lse, D) ----
+template <int DH>
+__global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(AttnBwdArgs a, AttnTrain tr) {
+    using Z = Swz<DH>;
+    constexpr int NW = 4, JD = DH / 8, DT = DH / 32, STAGE = 2 * KT * DH + 2 * KT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int c0 = (blockIdx.x * NW + wave) * 32;          // this wave's 32 keys
+    const int64_t ld = 3 * (int64_t)a.H;
+    const float* __restrict__ base = a.qkv + (int64_t)b * a.T * ld + head * DH;
+    const float* __restrict__ dobase = a.d_o + (int64_t)b * a.T * a.H + head * DH;
+    const int flen = a.frame_len ? a.frame_len[b] : a.T;
+    const int key = c0 + li;
+    const int kr = min(key, a.T - 1);
+    const bool kok = key < a.T;
+    const float kmask = key >= flen ? -10000.0f : 0.0f;
+
+    float4 kf[JD], vf[JD];
+    {
+        const float* kp = base + (int64_t)kr * ld + a.H + 4 * lh;
+        const float* vp = base + (int64_t)kr * ld + 2 * a.H + 4 * lh;
+#pragma unroll
+        for (int j = 0; j < JD; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(kp + 8 * j);
+            kf[j] = make_float4(v.x * a.scale, v.y * a.scale, v.z * a.scale, v.w * a.scale);   // S = scale q.k
+            vf[j] = *reinterpret_cast<const float4*>(vp + 8 * j);
+        }
+    }
+    const float inv = tr.p > 0.f ? 1.0f / (1.0f - tr.p) : 1.0f;
+    const int64_t bh = (int64_t)b * a.heads + head;
+
+    f32x16 dk[DT], dvv[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dk[d][r] = dvv[d][r] = 0.f;
+
+    auto issue = [&](int tile, int buf) {
+        float* S = smem + buf * STAGE;
+        dma_tile_swz<DH, NW>(base, ld, 0, tile * KT, a.T, S, wave, lane, 0);                    // Q
+        dma_tile_swz<DH, NW>(dobase, a.H, 0, tile * KT, a.T, S, wave, lane, Z::NP);             // dO
+        if (tid < 2 * KT) {      // lse and D of the tile's queries (plain stores: visible after the barrier)
+            const int qq = min(tile * KT + (tid & (KT - 1)), a.T - 1);
+            S[2 * KT * DH + tid] = tid < KT ? tr.lse[bh * a.T + qq] : a.dvec[bh * a.T + qq];
+        }
+    };
+    const int ntiles = (a.T + KT - 1) / KT;
+    issue(0, 0);
+    __syncthreads();
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int t0 = tile * KT, buf = tile & 1;
+        if (tile + 1 < ntiles) issue(tile + 1, buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const float* Qs = smem + buf * STAGE;
+        const float* Os = Qs + KT * DH;
+        const float* Ls = Os + KT * DH;      // [0, KT): lse, [KT, 2KT): D
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+            const int row = qt * 32 + li, sw = Z::f(row);
+#pragma unroll
+            for (int j = 0; j < JD; ++j) {
+                const float4 qv = *reinterpret_cast<const float4*>(Qs + row * DH + (((2 * j + lh) ^ sw) << 2));
+                const float4 ov = *reinterpret_cast<const float4*>(Os + row * DH + (((2 * j + lh) ^ sw) << 2));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(qv, e), f4get(kf[j], e), s, 0, 0, 0);     // S[q][key]
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(ov, e), f4get(vf[j], e), dp, 0, 0, 0);   // dP[q][key]
+                }
+            }
+            // lane owns key column `key`; register r is query row qt*32 + (r&3) + 8 (r>>2) + 4 lh
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ql = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int q = t0 + ql;
+                const float pv = (kok && q < a.T) ? expf(s[r] + kmask - Ls[ql]) : 0.f;
+                float g = dp[r], pd = pv;
+                if (tr.p > 0.f) {
+                    const bool keep = dropout_keep(tr.seed, tr.stream, ((uint64_t)bh * a.T + (uint64_t)min(q, a.T - 1)) * a.T + kr, tr.p);
+                    g = keep ? g * inv : 0.f;
+                    pd = keep ? pv * inv : 0.f;
+                }
+                dp[r] = pd;                          // Pd[q][key]
+                s[r] = pv * (g - Ls[KT + ql]);       // dS[q][key]
+            }
+            // dV^T[d][key] += sum_q dO[q][d] Pd[q][key];   dK^T[d][key] += sum_q Q[q][d] dS[q][key]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qrow = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int qsw = Z::f(qrow);
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    const int dd = 32 * d + li;
+                    const int off = qrow * DH + (((dd >> 2) ^ qsw) << 2) + (dd & 3);
+                    dvv[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(Os[off], dp[r], dvv[d], 0, 0, 0);
+                    dk[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[off], s[r], dk[d], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+    if (kok) {
+        float* kp = a.dqkv + ((int64_t)b * a.T + key) * ld + a.H + head * DH + 4 * lh;
+        float* vp = kp + a.H;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                // kf was pre-scaled for S, so dS is the gradient of the SCALED score: dK = scale * dS^T Q
+                *reinterpret_cast<float4*>(kp + 32 * d + 8 * g) =
+                    make_float4(dk[d][4 * g] * a.scale, dk[d][4 * g + 1] * a.scale, dk[d][4 * g + 2] * a.scale, dk[d][4 * g + 3] * a.scale);
+                *reinterpret_cast<float4*>(vp + 32 * d + 8 * g) =
+                    make_float4(dvv[d][4 * g], dvv[d][4 * g + 1], dvv[d][4 * g + 2], dvv[d][4 * g + 3]);
+            }
+    }
+}
+
+template <int DH>
+int launch_attn_train(const AttnArgs& a, const AttnTrain& tr, hipStream_t s) {
+    constexpr int NW = 4;
+    const size_t lds = (size_t)2 * 2 * KT * DH * sizeof(float);
+    W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<DH, NW, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((a.T + NW * 32 - 1) / (NW * 32), a.heads, a.B), block(NW * 64);
+    hipLaunchKernelGGL((attention_kernel<DH, NW, true>), grid, block, lds, s, a, tr);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
+template <int DH>
+int launch_attn_bwd(const AttnBwdArgs& a, const AttnTrain& tr, const float* ctx, float* dvec, hipStream_t s) {
+    hipLaunchKernelGGL(attn_dvec_kernel<DH>, dim3((unsigned)((int64_t)a.B * a.T)), dim3(256), 0, s, ctx, a.d_o, dvec,
+                       a.B, a.T, a.H, a.heads);
+    const size_t lds_q = (size_t)2 * 2 * KT * DH * sizeof(float);
+    const size_t lds_kv = (size_t)2 * (2 * KT * DH + 2 * KT) * sizeof(float);
+    W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_dq_kernel<DH>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q));
+    W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_dkv_kernel<DH>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv));
+    dim3 grid((a.T + 127) / 128, a.heads, a.B), block(256);
+    hipLaunchKernelGGL(attention_bwd_dq_kernel<DH>, grid, block, lds_q, s, a, tr);
+    hipLaunchKernelGGL(attention_bwd_dkv_kernel<DH>, grid, block, lds_kv, s, a, tr);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
 }  // namespace
 
 int launch_attention(Profiler* prof, const float* qkv, const int32_t* frame_len, float* ctx, int B,
@@ -267,6 +598,43 @@ int launch_attention(Profiler* prof, const float* qkv, const int32_t* frame_len,
         case 128: return launch_attn<128>(a, s);
         default:
             set_error("attention: head size %d unsupported (32, 64, 128)", dh);
+            return W2V2_EINVAL;
+    }
+}
+
+}  // namespace w2v2
+
+namespace w2v2 {
+
+int launch_attention_train(Profiler* prof, const float* qkv, const int32_t* frame_len, float* ctx, int B, int T,
+                           int H, int heads, const AttnTrain& tr, hipStream_t s) {
+    W2V2_REQUIRE(qkv && ctx && tr.lse, "attention_train: null operand");
+    W2V2_REQUIRE(B > 0 && T > 0 && heads > 0 && H % heads == 0 && tr.p >= 0.f && tr.p < 1.f, "attention_train: bad sizes");
+    const int dh = H / heads;
+    AttnArgs a{qkv, frame_len, ctx, B, T, H, heads, 1.0f / sqrtf((float)dh)};
+    ProfScope ps(prof, FAM_ATTENTION, 4.0 * B * (double)heads * T * (double)T * dh, 4.0 * B * (double)T * 4.0 * H, s);
+    switch (dh) {
+        case 32: return launch_attn_train<32>(a, tr, s);
+        case 64: return launch_attn_train<64>(a, tr, s);
+        default:
+            set_error("attention_train: head size %d unsupported (32, 64)", dh);
+            return W2V2_EINVAL;
+    }
+}
+
+int launch_attention_bwd(Profiler* prof, const float* qkv, const int32_t* frame_len, const float* ctx,
+                         const float* dctx, float* dqkv, float* dvec_ws, int B, int T, int H, int heads,
+                         const AttnTrain& tr, hipStream_t s) {
+    W2V2_REQUIRE(qkv && ctx && dctx && dqkv && dvec_ws && tr.lse, "attention_bwd: null operand");
+    W2V2_REQUIRE(B > 0 && T > 0 && heads > 0 && H % heads == 0, "attention_bwd: bad sizes");
+    const int dh = H / heads;
+    AttnBwdArgs a{qkv, frame_len, dctx, dvec_ws, dqkv, B, T, H, heads, 1.0f / sqrtf((float)dh)};
+    ProfScope ps(prof, FAM_ATTENTION, 10.0 * B * (double)heads * T * (double)T * dh, 4.0 * B * (double)T * 8.0 * H, s);
+    switch (dh) {
+        case 32: return launch_attn_bwd<32>(a, tr, ctx, dvec_ws, s);
+        case 64: return launch_attn_bwd<64>(a, tr, ctx, dvec_ws, s);
+        default:
+            set_error("attention_bwd: head size %d unsupported (32, 64)", dh);
             return W2V2_EINVAL;
     }
 }

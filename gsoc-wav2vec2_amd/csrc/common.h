@@ -77,6 +77,10 @@ int launch_gemm(Profiler* prof, const float* A, int64_t lda, int64_t strideA, co
                 int64_t ldb, float* C, int64_t ldc, int64_t strideC, const float* bias,
                 const float* residual, int M, int N, int K, int nbatch, int act, hipStream_t s);
 
+int launch_gemm_ex(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const float* B,
+                   int64_t ldb, int64_t strideB, float* C, int64_t ldc, int64_t strideC, const float* bias,
+                   const float* residual, int M, int N, int K, int nbatch, int act, hipStream_t s);
+
 int launch_layer_norm(Profiler* prof, const float* x, float* y, const float* gamma,
                       const float* beta, int64_t rows, int C, float eps, int act, hipStream_t s);
 

@@ -40,7 +40,7 @@ struct GemmArgs {
     float* C;
     const float* bias;
     const float* residual;
-    int64_t lda, ldb, ldc, strideA, strideC;
+    int64_t lda, ldb, ldc, strideA, strideB, strideC;
     int M, N, K, act;
     int tiles_m, tiles_n;
 };
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_f32_kernel(GemmArgs g)
     const int m0 = tm * BM, n0 = tn * BN;
     const int z = blockIdx.z;
     const float* __restrict__ A = g.A + (int64_t)z * g.strideA;
-    const float* __restrict__ Bm = g.B;
+    const float* __restrict__ Bm = g.B + (int64_t)z * g.strideB;
 
     // ---- global -> register staging of one K tile (float4 per thread) ---------
     f32x4 ra[NA], rb[NB];
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_f32_dma_kernel(GemmArg
     const int m0 = tm * BM, n0 = tn * BN;
     const int z = blockIdx.z;
     const float* __restrict__ A = g.A + (int64_t)z * g.strideA;
-    const float* __restrict__ Bm = g.B;
+    const float* __restrict__ Bm = g.B + (int64_t)z * g.strideB;
 
     // per-lane global sources of this wave's A pieces and B pieces (1 KiB each)
     const float* a_src[PPW];
@@ -407,16 +407,23 @@ int forced_cfg() {
 int launch_gemm(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const float* B,
                 int64_t ldb, float* C, int64_t ldc, int64_t strideC, const float* bias,
                 const float* residual, int M, int N, int K, int nbatch, int act, hipStream_t s) {
+    return launch_gemm_ex(prof, A, lda, strideA, B, ldb, 0, C, ldc, strideC, bias, residual, M, N, K, nbatch, act, s);
+}
+
+// strideB != 0: every batch has its own B (split-K weight gradients: A, B advance along K, C is a slab)
+int launch_gemm_ex(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const float* B,
+                   int64_t ldb, int64_t strideB, float* C, int64_t ldc, int64_t strideC, const float* bias,
+                   const float* residual, int M, int N, int K, int nbatch, int act, hipStream_t s) {
     W2V2_REQUIRE(A && B && C, "gemm: null operand");
     W2V2_REQUIRE(M > 0 && N > 0 && K > 0 && nbatch > 0, "gemm: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, nbatch);
     W2V2_REQUIRE(lda >= 1 && ldb >= N && ldc >= N, "gemm: bad leading dimensions");
     W2V2_REQUIRE(act >= 0 && act <= 2, "gemm: bad activation %d", act);
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.residual = residual;
-    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.strideA = strideA; g.strideC = strideC;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.strideA = strideA; g.strideB = strideB; g.strideC = strideC;
     g.M = M; g.N = N; g.K = K; g.act = act;
     const bool fast = (K % BK == 0) && (N % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) &&
-                      (strideA % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
+                      (strideA % 4 == 0) && (strideB % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
     ProfScope ps(prof, FAM_GEMM, 2.0 * M * (double)N * K * nbatch,
                  4.0 * nbatch * ((double)M * K + (double)M * N) + 4.0 * (double)K * N, s);

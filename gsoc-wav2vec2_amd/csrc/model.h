@@ -1,0 +1,56 @@
+// Model state shared by the forward (w2v2_api.hip) and training (w2v2_train.hip) translation units.
+#pragma once
+
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+
+struct Param {
+    std::string name;
+    std::vector<int64_t> shape;
+    int64_t numel = 0;
+    float* dev = nullptr;
+    bool set = false;
+};
+struct Act {
+    float* ptr;
+    int64_t shape[3];
+};
+
+struct w2v2_model {
+    w2v2_config cfg;
+    std::vector<Param> params;
+    std::unordered_map<std::string, int> index;
+    // derived tensors (w2v2_finalize)
+    float* pos_wg = nullptr;                 // (groups, K, cg, og)
+    std::vector<float*> qkv_w, qkv_b;        // per layer (H, 3H), (3H)
+    bool finalized = false;
+    // activation workspace
+    int ws_B = 0;
+    int64_t ws_L = 0;
+    std::vector<void*> allocs;
+    std::map<std::string, Act> acts;
+    std::vector<float*> conv;                // conv stack outputs
+    std::vector<int> conv_T;
+    float *conv0_ws = nullptr, *ln512 = nullptr, *proj = nullptr, *posout = nullptr;
+    std::vector<float*> hs;                  // hidden states: encoder_in, layer0..N-1
+    float *qkv = nullptr, *ctx = nullptr, *t0 = nullptr, *t1 = nullptr, *t2 = nullptr, *t3 = nullptr,
+          *ffn = nullptr, *enc_out = nullptr;
+    int32_t* frame_len = nullptr;
+    w2v2::Profiler* prof = nullptr;
+    struct TrainState* train = nullptr;      // owned by w2v2_train.hip (null until the first training call)
+
+    float* P(const std::string& n) const {
+        auto it = index.find(n);
+        return it == index.end() ? nullptr : params[it->second].dev;
+    }
+};
+
+
+// implemented in w2v2_api.hip
+int w2v2_ensure_workspace(w2v2_model* m, int B, int64_t L);
+// implemented in w2v2_train.hip
+void w2v2_train_destroy(w2v2_model* m);

@@ -18,6 +18,7 @@
 // shifted row -- the Toeplitz structure means no im2col and no re-fetch; the
 // per-tap weight tile (C_in/g x C_out/g) is double-buffered through LDS.
 #include "common.h"
+#include "train.h"
 
 namespace w2v2 {
 
@@ -57,10 +58,13 @@ __global__ __launch_bounds__(256) void weight_norm_regroup_kernel(const float* _
 struct PosArgs {
     const float* x;
     const float* wg;
-    const float* bias;
+    const float* bias;          // may be null (backward data pass)
     const int32_t* frame_len;
     float* y;
+    float* pre_act;             // optional: conv + bias before the activation (saved for backward)
     int B, T, H, K, groups, act;
+    int pad_left;               // K / 2 forward; K - 1 - K / 2 for the transposed (data-gradient) pass
+    int add_residual;           // 1: y = xz + act(conv + bias) (forward); 0: y = act(conv + bias)
 };
 
 // CG = channels per group (input == output), a multiple of 16, <= 64
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(256) void pos_conv_kernel(PosArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ln = lane & 15, lk = lane >> 4;
     const int t0 = blockIdx.x * PBM, g = blockIdx.y, b = blockIdx.z;
-    const int pad = a.K / 2;
+    const int pad = a.pad_left;
     const int rows = PBM + a.K - 1;
     float* Xs = smem;                           // rows x XS
     float* Ws = smem + ((rows * XS + 3) & ~3);  // 2 x CG x WS
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(256) void pos_conv_kernel(PosArgs a) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int co = n * 16 + ln;
-        const float bv = a.bias[g * CG + co];
+        const float bv = a.bias ? a.bias[g * CG + co] : 0.0f;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -157,8 +161,10 @@ __global__ __launch_bounds__(256) void pos_conv_kernel(PosArgs a) {
                 const int lr = wave * 32 + m * 16 + lk * 4 + r;
                 const int t = t0 + lr;
                 if (t < a.T) {
-                    const float res = Xs[(lr + pad) * XS + co];
-                    yb[(int64_t)t * a.H + co] = res + apply_act(acc[m][n][r] + bv, a.act);
+                    const float res = a.add_residual ? Xs[(lr + pad) * XS + co] : 0.0f;
+                    const float c = acc[m][n][r] + bv;
+                    if (a.pre_act) a.pre_act[((int64_t)b * a.T + t) * a.H + g * CG + co] = c;
+                    yb[(int64_t)t * a.H + co] = res + apply_act(c, a.act);
                 }
             }
         }
@@ -184,6 +190,163 @@ int launch_pos(const PosArgs& a, hipStream_t s) {
     return W2V2_OK;
 }
 
+
+// ---- training: transposed weights for the data-gradient pass ---------------------------------
+// wg (g, k, ci, co) -> wg_t (g, K-1-k, co, ci):  dxz = conv(dc, wg_t) with pad_left = K - 1 - K/2
+__global__ void flip_regroup_kernel(const float* __restrict__ wg, float* __restrict__ wt, int K, int cg, int groups) {
+    const int64_t n = (int64_t)groups * K * cg * cg;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int co = (int)(i % cg), ci = (int)((i / cg) % cg), k = (int)((i / ((int64_t)cg * cg)) % K), g = (int)(i / ((int64_t)cg * cg * K));
+        wt[(((int64_t)g * K + (K - 1 - k)) * cg + co) * cg + ci] = wg[i];
+    }
+}
+
+// ---- training: weight gradient  dWg[g][k][ci][co] = sum_{b,t} xz[b][t + k - P][g cg + ci] dc[b][t][g cg + co]
+// One block per (8-tap group, conv group): it walks the whole batch and all frames, so the reduction
+// over (b, t) stays in MFMA accumulators (no partial slabs, no atomics).  v_mfma_f32_16x16x4_f32 with
+// M = ci, N = co and the contraction over time: A[i = ci][k = t] and B[k = t][j = co] are both read
+// from LDS tiles of the input slab / the upstream gradient.
+constexpr int DW_TT = 128;     // frames per staged tile
+constexpr int DW_TAPS = 8;     // taps per block (2 per wave)
+
+struct PosDwArgs {
+    const float* xz;   // (B, T, H) input of the conv (already masked)
+    const float* dc;   // (B, T, H) gradient w.r.t. conv + bias
+    float* dwg;        // (groups, K, cg, cg)
+    int B, T, H, K, groups, pad;
+};
+
+template <int CG>
+__global__ __launch_bounds__(256) void pos_conv_dw_kernel(PosDwArgs a) {
+    constexpr int NT = CG / 16;
+    constexpr int XS = CG + 2;
+    constexpr int XROWS = DW_TT + DW_TAPS - 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;                               // XROWS x XS
+    float* Ds = smem + ((XROWS * XS + 3) & ~3);     // DW_TT x XS
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ln = lane & 15, lk = lane >> 4;
+    const int k0 = blockIdx.x * DW_TAPS, g = blockIdx.y;
+
+    f32x4 acc[2][NT][NT];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int m = 0; m < NT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[j][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int b = 0; b < a.B; ++b) {
+        const float* __restrict__ xb = a.xz + (int64_t)b * a.T * a.H + g * CG;
+        const float* __restrict__ db = a.dc + (int64_t)b * a.T * a.H + g * CG;
+        for (int t0 = 0; t0 < a.T; t0 += DW_TT) {
+            __syncthreads();
+            // x rows t0 + k0 - P ... (XROWS of them), zero outside [0, T); dc rows t0 .. t0 + TT, zero past T
+            for (int i = tid; i < XROWS * (CG / 4); i += 256) {
+                const int r = i / (CG / 4), c4 = (i % (CG / 4)) * 4;
+                const int t = t0 + k0 - a.pad + r;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t >= 0 && t < a.T) v = *reinterpret_cast<const float4*>(xb + (int64_t)t * a.H + c4);
+                float* d = Xs + r * XS + c4;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+            for (int i = tid; i < DW_TT * (CG / 4); i += 256) {
+                const int r = i / (CG / 4), c4 = (i % (CG / 4)) * 4;
+                const int t = t0 + r;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t < a.T) v = *reinterpret_cast<const float4*>(db + (int64_t)t * a.H + c4);
+                float* d = Ds + r * XS + c4;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int st = 0; st < DW_TT / 4; ++st) {
+                float bfr[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bfr[n] = Ds[(st * 4 + lk) * XS + n * 16 + ln];      // B[k = t][j = co]
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int tap = wave * 2 + j;                                              // local tap
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) {
+                        const float afr = Xs[(st * 4 + lk + tap) * XS + m * 16 + ln];          // A[i = ci][k = t]
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc[j][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr, bfr[n], acc[j][m][n], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // C/D: col = lane & 15 (co), row = 4 (lane >> 4) + reg (ci)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = k0 + wave * 2 + j;
+        if (k >= a.K) continue;
+        float* out = a.dwg + ((int64_t)g * a.K + k) * CG * CG;
+#pragma unroll
+        for (int m = 0; m < NT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[(m * 16 + lk * 4 + r) * CG + n * 16 + ln] = acc[j][m][n][r];
+    }
+}
+
+// ---- training: weight-norm backward, one block per tap ----------------------------------------
+// W_eff[k] = g[k] v[k] / ||v[k]||:  dg = <dW, v> / n;  dv = (g / n) (dW - <dW, v> v / n^2)
+__global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __restrict__ wv, const float* __restrict__ wgain,
+                                                             const float* __restrict__ dwg, float* __restrict__ dwv,
+                                                             float* __restrict__ dwgain, int K, int cg, int H, int groups) {
+    __shared__ double red[8];
+    const int k = blockIdx.x;
+    const int n = cg * H, og = H / groups;
+    const float* v = wv + (int64_t)k * n;
+    double ss = 0.0, dot = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int ci = i / H, c = i % H, g = c / og, co = c % og;
+        const double vv = v[i];
+        ss += vv * vv;
+        dot += vv * (double)dwg[(((int64_t)g * K + k) * cg + ci) * og + co];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        ss += __shfl_xor(ss, off, 64);
+        dot += __shfl_xor(dot, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = ss;
+        red[4 + (threadIdx.x >> 6)] = dot;
+    }
+    __syncthreads();
+    ss = red[0] + red[1] + red[2] + red[3];
+    dot = red[4] + red[5] + red[6] + red[7];
+    const double nrm = sqrt(ss > 1e-12 ? ss : 1e-12);
+    const double gk = wgain[k];
+    if (threadIdx.x == 0) dwgain[k] = (float)(dot / nrm);
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int ci = i / H, c = i % H, g = c / og, co = c % og;
+        const double dw = dwg[(((int64_t)g * K + k) * cg + ci) * og + co];
+        dwv[(int64_t)k * n + i] = (float)(gk / nrm * (dw - dot * (double)v[i] / (nrm * nrm)));
+    }
+}
+
+template <int CG>
+int launch_dw(const PosDwArgs& a, hipStream_t s) {
+    constexpr int XS = CG + 2, XROWS = DW_TT + DW_TAPS - 1;
+    const size_t lds = (size_t)(((XROWS * XS + 3) & ~3) + DW_TT * XS) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pos_conv_dw_kernel<CG>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    dim3 grid((a.K + DW_TAPS - 1) / DW_TAPS, a.groups), block(256);
+    hipLaunchKernelGGL(pos_conv_dw_kernel<CG>, grid, block, lds, s, a);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
 }  // namespace
 
 int launch_weight_norm_regroup(Profiler* prof, const float* wv, const float* wg, float* out, int K,
@@ -200,11 +363,19 @@ int launch_weight_norm_regroup(Profiler* prof, const float* wv, const float* wg,
 int launch_pos_conv(Profiler* prof, const float* x, const float* wg, const float* bias,
                     const int32_t* frame_len, float* y, int B, int T, int H, int K, int groups,
                     int act, hipStream_t s) {
-    W2V2_REQUIRE(x && wg && bias && y, "pos_conv: null operand");
+    W2V2_REQUIRE(bias, "pos_conv: null bias");
+    return launch_pos_conv_ex(prof, x, wg, bias, frame_len, y, nullptr, B, T, H, K, groups, act, K / 2, 1, s);
+}
+
+int launch_pos_conv_ex(Profiler* prof, const float* x, const float* wg, const float* bias,
+                       const int32_t* frame_len, float* y, float* pre_act, int B, int T, int H, int K,
+                       int groups, int act, int pad_left, int add_residual, hipStream_t s) {
+    W2V2_REQUIRE(x && wg && y, "pos_conv: null operand");
+    W2V2_REQUIRE(pad_left >= 0 && pad_left < K, "pos_conv: bad left pad %d", pad_left);
     W2V2_REQUIRE(B > 0 && T > 0 && K > 0 && groups > 0 && H % groups == 0, "pos_conv: bad sizes");
     const int cg = H / groups;
     W2V2_REQUIRE(H % 4 == 0, "pos_conv: hidden size must be a multiple of 4");
-    PosArgs a{x, wg, bias, frame_len, y, B, T, H, K, groups, act};
+    PosArgs a{x, wg, bias, frame_len, y, pre_act, B, T, H, K, groups, act, pad_left, add_residual};
     ProfScope ps(prof, FAM_POSCONV, 2.0 * B * (double)T * H * cg * K, 8.0 * B * (double)T * H + 4.0 * K * cg * H, s);
     switch (cg) {
         case 16: return launch_pos<16>(a, s);
@@ -215,6 +386,45 @@ int launch_pos_conv(Profiler* prof, const float* x, const float* wg, const float
             set_error("pos_conv: channels per group = %d unsupported (16, 32, 48, 64)", cg);
             return W2V2_EINVAL;
     }
+}
+
+}  // namespace w2v2
+
+namespace w2v2 {
+
+int launch_pos_conv_flip_regroup(const float* wg, float* wg_t, int K, int cg, int groups, hipStream_t s) {
+    W2V2_REQUIRE(wg && wg_t && K > 0 && cg > 0 && groups > 0, "pos_conv_flip: bad argument");
+    hipLaunchKernelGGL(flip_regroup_kernel, dim3(1024), dim3(256), 0, s, wg, wg_t, K, cg, groups);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
+int64_t pos_conv_dw_ws_floats(int, int, int, int, int) { return 8; }   // the reduction stays in registers
+
+int launch_pos_conv_dw(Profiler* prof, const float* xz, const float* dc, float* dwg, float* ws, int B, int T,
+                       int H, int K, int groups, hipStream_t s) {
+    (void)ws;
+    W2V2_REQUIRE(xz && dc && dwg && B > 0 && T > 0 && K > 0 && groups > 0 && H % groups == 0, "pos_conv_dw: bad argument");
+    const int cg = H / groups;
+    PosDwArgs a{xz, dc, dwg, B, T, H, K, groups, K / 2};
+    ProfScope ps(prof, FAM_POSCONV, 2.0 * B * (double)T * H * cg * K, 8.0 * B * (double)T * H * (K / DW_TAPS), s);
+    switch (cg) {
+        case 16: return launch_dw<16>(a, s);
+        case 32: return launch_dw<32>(a, s);
+        case 48: return launch_dw<48>(a, s);
+        case 64: return launch_dw<64>(a, s);
+        default:
+            set_error("pos_conv_dw: channels per group = %d unsupported (16, 32, 48, 64)", cg);
+            return W2V2_EINVAL;
+    }
+}
+
+int launch_weight_norm_bwd(const float* wv, const float* wgain, const float* dwg, float* dwv, float* dwgain,
+                           int K, int cg, int H, int groups, hipStream_t s) {
+    W2V2_REQUIRE(wv && wgain && dwg && dwv && dwgain && K > 0 && cg == H / groups, "weight_norm_bwd: bad argument");
+    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(K), dim3(256), 0, s, wv, wgain, dwg, dwv, dwgain, K, cg, H, groups);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
 }
 
 }  // namespace w2v2

@@ -1,0 +1,75 @@
+// Declarations for the training-step kernels (train_kernels.hip, attention_bwd in attention.hip,
+// posconv.hip) and the shared counter-based dropout hash.
+#pragma once
+
+#include "common.h"
+
+namespace w2v2 {
+
+// Dropout sites ("streams") of the training forward; the hash key is (seed, stream, element index).
+enum DropStream : uint32_t {
+    DS_FEATURE_PROJECTION = 1,   // feature_extractor.py:95
+    DS_ENCODER_IN = 2,           // encoder.py:270
+    DS_HEAD = 3,                 // modeling.py:253
+    DS_LAYER_BASE = 16,          // + 4 * layer + {0: attention probs, 1: attention output, 2: FFN intermediate}
+};
+
+#ifdef __HIPCC__
+// uniform [0, 1) with 24-bit resolution from (seed, stream, idx): splitmix64 finaliser.  The same
+// integer function as wav2vec2/variables.py::dropout_uniform.
+__device__ __forceinline__ float dropout_u01(uint64_t seed, uint32_t stream, uint64_t idx) {
+    uint64_t z = idx * 0x2545F4914F6CDD1DULL + (seed ^ ((uint64_t)stream * 0x9E3779B97F4A7C15ULL));
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t stream, uint64_t idx, float p) {
+    return dropout_u01(seed, stream, idx) >= p;
+}
+#endif
+
+int launch_dropout_fwd(const float* x, const float* res, float* y, int64_t n, int act, float p,
+                       uint64_t seed, uint32_t stream_id, hipStream_t s);
+int launch_dropout_bwd(const float* u, const float* dy, float* dx, int64_t n, int act, float p,
+                       uint64_t seed, uint32_t stream_id, hipStream_t s);
+int launch_transpose(const float* x, float* y, int rows, int cols, int nbatch, hipStream_t s);
+int64_t colsum_ws_floats(int64_t rows, int cols);
+int launch_colsum(const float* x, float* out, int64_t rows, int cols, float* ws, int accumulate, hipStream_t s);
+int64_t ln_bwd_ws_floats(int64_t rows, int C);
+int launch_ln_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma,
+                  float* dbeta, int64_t rows, int C, float eps, float* ws, hipStream_t s);
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1, float b2,
+                float eps, hipStream_t s);
+int launch_spec_aug_fwd(const float* x, const uint8_t* mask, const float* embed, float* y, int64_t rows, int H, hipStream_t s);
+int launch_spec_aug_bwd(const float* dy, const uint8_t* mask, float* dx, float* dmasked, int64_t rows, int H, hipStream_t s);
+int launch_axpby(const float* a, const float* b, float* y, int64_t n, float alpha, float beta, hipStream_t s);
+int launch_mask_rows(const float* x, const int32_t* frame_len, float* y, int B, int T, int H, hipStream_t s);
+
+// attention, training variants (attention.hip)
+struct AttnTrain {
+    float p;           // attention-probability dropout (encoder.py:42-44)
+    uint64_t seed;
+    uint32_t stream;
+    float* lse;        // (B, heads, T) log-sum-exp of the (masked) scores, written by forward, read by backward
+};
+int launch_attention_train(Profiler* prof, const float* qkv, const int32_t* frame_len, float* ctx, int B, int T,
+                           int H, int heads, const AttnTrain& tr, hipStream_t s);
+// dqkv (B, T, 3H) = gradient of the packed q|k|v given dctx (B, T, H); ctx is the forward output
+int launch_attention_bwd(Profiler* prof, const float* qkv, const int32_t* frame_len, const float* ctx,
+                         const float* dctx, float* dqkv, float* dvec_ws, int B, int T, int H, int heads,
+                         const AttnTrain& tr, hipStream_t s);
+
+// positional conv, training variants (posconv.hip)
+int launch_pos_conv_ex(Profiler* prof, const float* x, const float* wg, const float* bias,
+                       const int32_t* frame_len, float* y, float* pre_act, int B, int T, int H, int K,
+                       int groups, int act, int pad_left, int add_residual, hipStream_t s);
+int launch_pos_conv_flip_regroup(const float* wg, float* wg_t, int K, int cg, int groups, hipStream_t s);
+int launch_pos_conv_dw(Profiler* prof, const float* xz, const float* dc, float* dwg, float* ws, int B, int T,
+                       int H, int K, int groups, hipStream_t s);
+int64_t pos_conv_dw_ws_floats(int B, int T, int H, int K, int groups);
+int launch_weight_norm_bwd(const float* wv, const float* wgain, const float* dwg, float* dwv, float* dwgain,
+                           int K, int cg, int H, int groups, hipStream_t s);
+
+}  // namespace w2v2

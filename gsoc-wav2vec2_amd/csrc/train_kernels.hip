@@ -1,0 +1,333 @@
+// Training-step support kernels (HBM-bound element-wise / reduction work around the MFMA kernels).
+//
+// Reference semantics: tf.keras.layers.Dropout (feature_extractor.py:90,95; encoder.py:20,42-44,94,118,
+// 128,235,270; modeling.py:230,253): keep with probability 1-p, scale kept values by 1/(1-p).
+// LayerNormalization / exact GELU backward are the analytic derivatives of the forward kernels.
+// Keras Adam (main.py:211-216 -> tf.keras.optimizers.Adam defaults):
+//   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps)
+//
+// Dropout masks are NOT stored: keep(seed, stream, index) is a counter-based hash (splitmix64), the same
+// integer function as wav2vec2/variables.py::dropout_keep, regenerated wherever the mask is needed
+// (forward, backward, and inside the attention kernels).
+#include "common.h"
+#include "train.h"
+
+namespace w2v2 {
+namespace {
+
+constexpr int EW_THREADS = 256;
+
+inline unsigned ew_grid(int64_t n_vec) {
+    int64_t g = (n_vec + EW_THREADS - 1) / EW_THREADS;
+    return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));   // grid-stride beyond 4096 blocks
+}
+
+__device__ __forceinline__ float gelu_grad(float u, int act) {
+    if (act == 1) {   // d/du [0.5 u (1 + erf(u / sqrt 2))]
+        const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
+        return cdf + u * 0.39894228040143267794f * expf(-0.5f * u * u);
+    }
+    if (act == 2) {
+        const float c = 0.79788456080286535588f, k = 0.044715f;
+        const float t = tanhf(c * (u + k * u * u * u));
+        return 0.5f * (1.0f + t) + 0.5f * u * (1.0f - t * t) * c * (1.0f + 3.0f * k * u * u);
+    }
+    return 1.0f;
+}
+
+// y = dropout(act(x)) [+ res]           (act may be 0)
+__global__ void dropout_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                   float* __restrict__ y, int64_t n, int act, float p, uint64_t seed,
+                                   uint32_t stream) {
+    const float inv = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS) {
+        float v = apply_act(x[i], act);
+        if (p > 0.f) v = dropout_keep(seed, stream, (uint64_t)i, p) ? v * inv : 0.0f;
+        y[i] = res ? v + res[i] : v;
+    }
+}
+
+// dx = dy * keep/(1-p) * act'(u)
+__global__ void dropout_bwd_kernel(const float* __restrict__ u, const float* __restrict__ dy,
+                                   float* __restrict__ dx, int64_t n, int act, float p, uint64_t seed,
+                                   uint32_t stream) {
+    const float inv = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS) {
+        float g = dy[i];
+        if (p > 0.f) g = dropout_keep(seed, stream, (uint64_t)i, p) ? g * inv : 0.0f;
+        if (act) g *= gelu_grad(u[i], act);
+        dx[i] = g;
+    }
+}
+
+// batched transpose: y[b][c][r] = x[b][r][c]
+__global__ void transpose_kernel(const float* __restrict__ x, float* __restrict__ y, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int64_t boff = (int64_t)blockIdx.z * rows * cols;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        const int r = r0 + ty + j, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + j][tx] = x[boff + (int64_t)r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        const int c = c0 + ty + j, r = r0 + tx;
+        if (r < rows && c < cols) y[boff + (int64_t)c * rows + r] = tile[tx][ty + j];
+    }
+}
+
+// stage 1: partial[chunk][c] = sum over the chunk's rows of x[r][c]   (fp32, <= 256 rows per chunk)
+__global__ void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                      int64_t rows, int cols, int rows_per_chunk) {
+    const int c = blockIdx.x * EW_THREADS + threadIdx.x;
+    if (c >= cols) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
+    float acc = 0.f;
+    for (int64_t r = r0; r < r1; ++r) acc += x[r * cols + c];
+    partial[(int64_t)blockIdx.y * cols + c] = acc;
+}
+// stage 2: out[c] (+)= sum over chunks, fp64 accumulate
+__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                    int nchunks, int cols, int64_t ld, int accumulate) {
+    const int c = blockIdx.x * EW_THREADS + threadIdx.x;
+    if (c >= cols) return;
+    double acc = 0.0;
+    for (int k = 0; k < nchunks; ++k) acc += (double)partial[(int64_t)k * ld + c];
+    out[c] = accumulate ? out[c] + (float)acc : (float)acc;
+}
+
+// LayerNorm backward.  One wave per row (grid-stride); per-lane dgamma / dbeta partials live in
+// registers across the rows a wave visits, are combined across the block's 4 waves through LDS and
+// written as partial[block][2][C]; colsum_final reduces them.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ dy, float* __restrict__ dx,
+                                                     float* __restrict__ partial, int64_t rows, int C, float eps) {
+    extern __shared__ float red[];   // 4 waves x 2 x C
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float dg[NV][4], db[NV][4];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dg[i][e] = db[i][e] = 0.f;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const float* xr = x + row * C;
+        const float* dr = dy + row * C;
+        float xv[NV][4], gv[NV][4];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = (i * 64 + lane) * 4 + e;
+                xv[i][e] = c < C ? xr[c] : 0.f;
+                sum += xv[i][e];
+            }
+        const float mean = wave_sum(sum) / (float)C;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = (i * 64 + lane) * 4 + e;
+                xv[i][e] = c < C ? xv[i][e] - mean : 0.f;
+                sq += xv[i][e] * xv[i][e];
+            }
+        const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)C + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = (i * 64 + lane) * 4 + e;
+                const float d = c < C ? dr[c] : 0.f;
+                const float xh = xv[i][e] * rstd;
+                xv[i][e] = xh;
+                gv[i][e] = c < C ? d * gamma[c] : 0.f;
+                dg[i][e] += d * xh;
+                db[i][e] += d;
+                s1 += gv[i][e];
+                s2 += gv[i][e] * xh;
+            }
+        s1 = wave_sum(s1) / (float)C;
+        s2 = wave_sum(s2) / (float)C;
+        float* dxr = dx + row * C;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = (i * 64 + lane) * 4 + e;
+                if (c < C) dxr[c] = rstd * (gv[i][e] - s1 - xv[i][e] * s2);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = (i * 64 + lane) * 4 + e;
+            if (c < C) {
+                red[(wave * 2 + 0) * C + c] = dg[i][e];
+                red[(wave * 2 + 1) * C + c] = db[i][e];
+            }
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * C; c += 256) {
+        const int which = c / C, cc = c % C;
+        partial[(int64_t)blockIdx.x * 2 * C + c] =
+            red[(0 * 2 + which) * C + cc] + red[(1 * 2 + which) * C + cc] + red[(2 * 2 + which) * C + cc] + red[(3 * 2 + which) * C + cc];
+    }
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, int64_t n, float lr_t, float b1, float b2, float eps) {
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+// y[row] = mask[row] ? embed : x[row]      (spec_augment.py:127, tf.where(mask, spec_embed, x))
+__global__ void spec_aug_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask,
+                                    const float* __restrict__ embed, float* __restrict__ y, int64_t rows, int H) {
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < rows * H; i += (int64_t)gridDim.x * EW_THREADS) {
+        const int64_t r = i / H;
+        y[i] = mask[r] ? embed[i % H] : x[i];
+    }
+}
+// dx[row] = mask[row] ? 0 : dy[row];   masked rows' dy are kept in dmasked (then column-summed into d embed)
+__global__ void spec_aug_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ mask,
+                                    float* __restrict__ dx, float* __restrict__ dmasked, int64_t rows, int H) {
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < rows * H; i += (int64_t)gridDim.x * EW_THREADS) {
+        const bool mk = mask[i / H] != 0;
+        const float g = dy[i];
+        dx[i] = mk ? 0.f : g;
+        dmasked[i] = mk ? g : 0.f;
+    }
+}
+
+__global__ void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                             int64_t n, float alpha, float beta) {
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS)
+        y[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
+}
+
+// zero rows t >= frame_len[b] of a (B, T, H) tensor (encoder.py:253 and its gradient)
+__global__ void mask_rows_kernel(const float* __restrict__ x, const int32_t* __restrict__ frame_len,
+                                 float* __restrict__ y, int B, int T, int H) {
+    const int64_t n = (int64_t)B * T * H;
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS) {
+        const int64_t row = i / H;
+        const int b = (int)(row / T), t = (int)(row % T);
+        y[i] = t < frame_len[b] ? x[i] : 0.f;
+    }
+}
+
+}  // namespace
+
+int launch_dropout_fwd(const float* x, const float* res, float* y, int64_t n, int act, float p,
+                       uint64_t seed, uint32_t stream_id, hipStream_t s) {
+    W2V2_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, "dropout_fwd: bad argument");
+    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, s, x, res, y, n, act, p, seed, stream_id);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
+int launch_dropout_bwd(const float* u, const float* dy, float* dx, int64_t n, int act, float p,
+                       uint64_t seed, uint32_t stream_id, hipStream_t s) {
+    W2V2_REQUIRE(dy && dx && n > 0 && p >= 0.f && p < 1.f && (act == 0 || u), "dropout_bwd: bad argument");
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, s, u, dy, dx, n, act, p, seed, stream_id);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
+int launch_transpose(const float* x, float* y, int rows, int cols, int nbatch, hipStream_t s) {
+    W2V2_REQUIRE(x && y && rows > 0 && cols > 0 && nbatch > 0, "transpose: bad argument");
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32, nbatch);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, x, y, rows, cols);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
+int64_t colsum_ws_floats(int64_t rows, int cols) { return ((rows + 255) / 256) * (int64_t)cols + 8; }
+
+int launch_colsum(const float* x, float* out, int64_t rows, int cols, float* ws, int accumulate, hipStream_t s) {
+    W2V2_REQUIRE(x && out && ws && rows > 0 && cols > 0, "colsum: bad argument");
+    const int nchunks = (int)((rows + 255) / 256);
+    dim3 grid((cols + EW_THREADS - 1) / EW_THREADS, nchunks);
+    hipLaunchKernelGGL(colsum_partial_kernel, grid, dim3(EW_THREADS), 0, s, x, ws, rows, cols, 256);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(grid.x), dim3(EW_THREADS), 0, s, ws, out, nchunks, cols, (int64_t)cols, accumulate);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
+static int ln_bwd_blocks(int64_t rows) {
+    int64_t b = (rows + 3) / 4;
+    return (int)(b > 1024 ? 1024 : b);
+}
+int64_t ln_bwd_ws_floats(int64_t rows, int C) { return (int64_t)ln_bwd_blocks(rows) * 2 * C + 8; }
+
+int launch_ln_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma,
+                  float* dbeta, int64_t rows, int C, float eps, float* ws, hipStream_t s) {
+    W2V2_REQUIRE(x && gamma && dy && dx && dgamma && dbeta && ws, "ln_bwd: null operand");
+    W2V2_REQUIRE(rows > 0 && C > 0 && C <= 1024, "ln_bwd: rows=%lld C=%d unsupported (C <= 1024)", (long long)rows, C);
+    const int nb = ln_bwd_blocks(rows);
+    const size_t lds = (size_t)4 * 2 * C * sizeof(float);
+    if (C <= 256)
+        hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, ws, rows, C, eps);
+    else if (C <= 512)
+        hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, ws, rows, C, eps);
+    else
+        hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, ws, rows, C, eps);
+    // partial is (nb, 2C): dgamma = column sums of its first C columns, dbeta of its last C
+    const dim3 g2((C + EW_THREADS - 1) / EW_THREADS);
+    hipLaunchKernelGGL(colsum_final_kernel, g2, dim3(EW_THREADS), 0, s, ws, dgamma, nb, C, (int64_t)2 * C, 0);
+    hipLaunchKernelGGL(colsum_final_kernel, g2, dim3(EW_THREADS), 0, s, ws + C, dbeta, nb, C, (int64_t)2 * C, 0);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1, float b2,
+                float eps, hipStream_t s) {
+    W2V2_REQUIRE(p && g && m && v && n > 0, "adam: bad argument");
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, s, p, g, m, v, n, lr_t, b1, b2, eps);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
+int launch_spec_aug_fwd(const float* x, const uint8_t* mask, const float* embed, float* y, int64_t rows, int H, hipStream_t s) {
+    W2V2_REQUIRE(x && mask && embed && y && rows > 0 && H > 0, "spec_aug_fwd: bad argument");
+    hipLaunchKernelGGL(spec_aug_fwd_kernel, dim3(ew_grid(rows * H)), dim3(EW_THREADS), 0, s, x, mask, embed, y, rows, H);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
+int launch_spec_aug_bwd(const float* dy, const uint8_t* mask, float* dx, float* dmasked, int64_t rows, int H, hipStream_t s) {
+    W2V2_REQUIRE(dy && mask && dx && dmasked && rows > 0 && H > 0, "spec_aug_bwd: bad argument");
+    hipLaunchKernelGGL(spec_aug_bwd_kernel, dim3(ew_grid(rows * H)), dim3(EW_THREADS), 0, s, dy, mask, dx, dmasked, rows, H);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
+int launch_axpby(const float* a, const float* b, float* y, int64_t n, float alpha, float beta, hipStream_t s) {
+    W2V2_REQUIRE(a && y && n > 0, "axpby: bad argument");
+    hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, s, a, b, y, n, alpha, beta);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
+int launch_mask_rows(const float* x, const int32_t* frame_len, float* y, int B, int T, int H, hipStream_t s) {
+    W2V2_REQUIRE(x && frame_len && y && B > 0 && T > 0 && H > 0, "mask_rows: bad argument");
+    hipLaunchKernelGGL(mask_rows_kernel, dim3(ew_grid((int64_t)B * T * H)), dim3(EW_THREADS), 0, s, x, frame_len, y, B, T, H);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
+}  // namespace w2v2

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "common.h"
+#include "model.h"
 
 namespace w2v2 {
 
@@ -100,47 +101,6 @@ int profiler_read(Profiler* p, int family, int64_t* launches, double* ms, double
 
 using namespace w2v2;
 
-// ---- model ------------------------------------------------------------------
-struct Param {
-    std::string name;
-    std::vector<int64_t> shape;
-    int64_t numel = 0;
-    float* dev = nullptr;
-    bool set = false;
-};
-struct Act {
-    float* ptr;
-    int64_t shape[3];
-};
-
-struct w2v2_model {
-    w2v2_config cfg;
-    std::vector<Param> params;
-    std::unordered_map<std::string, int> index;
-    // derived tensors (w2v2_finalize)
-    float* pos_wg = nullptr;                 // (groups, K, cg, og)
-    std::vector<float*> qkv_w, qkv_b;        // per layer (H, 3H), (3H)
-    bool finalized = false;
-    // activation workspace
-    int ws_B = 0;
-    int64_t ws_L = 0;
-    std::vector<void*> allocs;
-    std::map<std::string, Act> acts;
-    std::vector<float*> conv;                // conv stack outputs
-    std::vector<int> conv_T;
-    float *conv0_ws = nullptr, *ln512 = nullptr, *proj = nullptr, *posout = nullptr;
-    std::vector<float*> hs;                  // hidden states: encoder_in, layer0..N-1
-    float *qkv = nullptr, *ctx = nullptr, *t0 = nullptr, *t1 = nullptr, *t2 = nullptr, *t3 = nullptr,
-          *ffn = nullptr, *enc_out = nullptr;
-    int32_t* frame_len = nullptr;
-    Profiler* prof = nullptr;
-
-    float* P(const std::string& n) const {
-        auto it = index.find(n);
-        return it == index.end() ? nullptr : params[it->second].dev;
-    }
-};
-
 static void add_param(w2v2_model* m, const std::string& name, std::vector<int64_t> shape) {
     Param p;
     p.name = name;
@@ -218,7 +178,7 @@ static int ws_alloc(w2v2_model* m, float** out, int64_t floats) {
     return W2V2_OK;
 }
 
-static int ensure_workspace(w2v2_model* m, int B, int64_t L) {
+int w2v2_ensure_workspace(w2v2_model* m, int B, int64_t L) {
     if (m->ws_B == B && m->ws_L == L) return W2V2_OK;
     free_workspace(m);
     const w2v2_config& c = m->cfg;
@@ -309,6 +269,7 @@ int w2v2_create(const w2v2_config* cfg, w2v2_model** out) {
 
 void w2v2_destroy(w2v2_model* m) {
     if (!m) return;
+    w2v2_train_destroy(m);
     free_workspace(m);
     for (auto& p : m->params)
         if (p.dev) (void)hipFree(p.dev);
@@ -419,7 +380,7 @@ int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const i
     const int64_t Tll = w2v2_num_frames(m, L);
     W2V2_REQUIRE(Tll >= 1, "forward: %lld samples are shorter than the conv stack's receptive field", (long long)L);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (int e = ensure_workspace(m, B, L)) return e;
+    if (int e = w2v2_ensure_workspace(m, B, L)) return e;
     Profiler* pf = m->prof;
     const int T = (int)Tll;
     const int H = c.hidden_size, F = c.intermediate_size;

@@ -1,0 +1,604 @@
+// Training step of the CTC fine-tuning path: training-mode forward, backward, Adam.
+//
+// What the reference does inside Keras' train_step (src/main.py:136-259):
+//   forward with training=True  -- dropout at every Dropout layer, spec-augment on the projected
+//     features (modeling.py:193-199), StochasticDepth on the FFN branch (encoder.py:130);
+//   CTC loss / global batch (losses.py:45, main.py:198-200);
+//   gradients of every trainable variable -- stage 2 freezes the 7 conv layers (main.py:234-237),
+//     stage 1 trains lm_head only (main.py:210);
+//   Adam (Keras defaults) and, under MirroredStrategy, a SUM all-reduce of the gradients.
+// Here: w2v2_train_forward -> (caller: w2v2_ctc_loss gives d nll / d logits) -> w2v2_train_backward
+// fills one flat gradient buffer (the all-reduce payload) -> w2v2_adam_step.
+//
+// Heavy contractions reuse the forward's fp32 MFMA GEMM:
+//   dX = dY W^T   uses transposed copies of the kernels kept next to the variables;
+//   dW = X^T dY   transposes the activation once and runs a split-K batched GEMM into slabs that a
+//                 reduction kernel sums (deterministic: no atomics anywhere in the backward).
+// The conv feature extractor has no backward: the reference never trains it in this path.
+#include <string.h>
+
+#include "model.h"
+#include "train.h"
+
+using namespace w2v2;
+
+struct LayerSave {
+    float *qkv, *ctx, *lse, *t1, *t2, *u, *gd, *t3;
+    float *WqkvT, *WoT, *W1T, *W2T;     // transposed kernels for the data-gradient GEMMs
+    float keep;                         // stochastic-depth draw of the last forward
+};
+
+struct TrainState {
+    int B = 0, T = 0;
+    int64_t L = 0;
+    std::vector<void*> allocs;
+    std::vector<LayerSave> layers;
+    float *hd = nullptr, *hm = nullptr, *pos_c = nullptr, *hdf = nullptr;
+    float *WpT = nullptr, *WlmT = nullptr, *pos_wg_t = nullptr, *dwg = nullptr;
+    uint8_t* spec_mask = nullptr;       // (B*T) device copy, or null when not applied
+    bool have_spec = false, have_mask = false;
+    float p = 0.f;
+    uint64_t seed = 0;
+    // gradient / optimizer state: flat, inventory order
+    float *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+    std::vector<int64_t> goff;
+    int64_t gtotal = 0;
+    std::vector<char> trainable;
+    bool transposes_fresh = false;
+    // scratch
+    float *gh[4] = {nullptr, nullptr, nullptr, nullptr}, *gf = nullptr, *g3h = nullptr, *at = nullptr,
+          *slabs = nullptr, *red_ws = nullptr, *dvec = nullptr, *dummy = nullptr, *dwqkv = nullptr, *dwv_scratch = nullptr;
+    int64_t slab_floats = 0;
+    bool forward_done = false;
+};
+
+static int t_alloc(TrainState* t, float** out, int64_t floats) {
+    void* p = nullptr;
+    W2V2_HIP_CHECK(hipMalloc(&p, (size_t)(floats > 0 ? floats : 1) * sizeof(float)));
+    t->allocs.push_back(p);
+    *out = reinterpret_cast<float*>(p);
+    return W2V2_OK;
+}
+
+static void t_free(TrainState* t) {
+    for (void* p : t->allocs) (void)hipFree(p);
+    t->allocs.clear();
+}
+
+void w2v2_train_destroy(w2v2_model* m) {
+    if (!m || !m->train) return;
+    t_free(m->train);
+    delete m->train;
+    m->train = nullptr;
+}
+
+static TrainState* get_state(w2v2_model* m) {
+    if (!m->train) {
+        TrainState* t = new TrainState();
+        t->trainable.assign(m->params.size(), 1);
+        // flat gradient layout = inventory order
+        t->goff.resize(m->params.size());
+        int64_t off = 0;
+        for (size_t i = 0; i < m->params.size(); ++i) {
+            t->goff[i] = off;
+            off += (m->params[i].numel + 3) & ~(int64_t)3;     // 16-byte aligned slots
+        }
+        t->gtotal = off;
+        m->train = t;
+    }
+    return m->train;
+}
+
+static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
+    TrainState* t = get_state(m);
+    if (t->B == B && t->L == L && !t->layers.empty()) return W2V2_OK;
+    // keep gradient/optimizer buffers across a shape change, rebuild the rest
+    std::vector<void*> keep;
+    for (void* p : t->allocs)
+        if (p == t->grads || p == t->adam_m || p == t->adam_v) keep.push_back(p);
+        else (void)hipFree(p);
+    t->allocs = keep;
+    t->layers.clear();
+    const w2v2_config& c = m->cfg;
+    const int64_t H = c.hidden_size, F = c.intermediate_size, BT = (int64_t)B * T;
+    const int64_t C = c.filter_sizes[c.num_conv_layers - 1];
+    if (!t->grads) {
+        if (int e = t_alloc(t, &t->grads, t->gtotal)) return e;
+        if (int e = t_alloc(t, &t->adam_m, t->gtotal)) return e;
+        if (int e = t_alloc(t, &t->adam_v, t->gtotal)) return e;
+        W2V2_HIP_CHECK(hipMemset(t->grads, 0, (size_t)t->gtotal * 4));
+        W2V2_HIP_CHECK(hipMemset(t->adam_m, 0, (size_t)t->gtotal * 4));
+        W2V2_HIP_CHECK(hipMemset(t->adam_v, 0, (size_t)t->gtotal * 4));
+    }
+    if (int e = t_alloc(t, &t->hd, BT * H)) return e;
+    if (int e = t_alloc(t, &t->hm, BT * H)) return e;
+    if (int e = t_alloc(t, &t->pos_c, BT * H)) return e;
+    if (int e = t_alloc(t, &t->hdf, BT * H)) return e;
+    if (int e = t_alloc(t, &t->WpT, H * C)) return e;
+    if (int e = t_alloc(t, &t->WlmT, H * (int64_t)c.vocab_size)) return e;
+    const int64_t K = c.num_conv_pos_embeddings, cg = H / c.num_conv_pos_embedding_groups;
+    if (int e = t_alloc(t, &t->pos_wg_t, K * cg * H)) return e;
+    if (int e = t_alloc(t, &t->dwg, K * cg * H)) return e;
+    float* sm = nullptr;
+    if (int e = t_alloc(t, &sm, (BT + 15) / 4 + 4)) return e;
+    t->spec_mask = reinterpret_cast<uint8_t*>(sm);
+    t->layers.resize(c.num_layers);
+    for (auto& l : t->layers) {
+        if (int e = t_alloc(t, &l.qkv, BT * 3 * H)) return e;
+        if (int e = t_alloc(t, &l.ctx, BT * H)) return e;
+        if (int e = t_alloc(t, &l.lse, (int64_t)B * c.num_heads * T)) return e;
+        if (int e = t_alloc(t, &l.t1, BT * H)) return e;
+        if (int e = t_alloc(t, &l.t2, BT * H)) return e;
+        if (int e = t_alloc(t, &l.u, BT * F)) return e;
+        if (int e = t_alloc(t, &l.gd, BT * F)) return e;
+        if (int e = t_alloc(t, &l.t3, BT * H)) return e;
+        if (int e = t_alloc(t, &l.WqkvT, 3 * H * H)) return e;
+        if (int e = t_alloc(t, &l.WoT, H * H)) return e;
+        if (int e = t_alloc(t, &l.W1T, F * H)) return e;
+        if (int e = t_alloc(t, &l.W2T, H * F)) return e;
+        l.keep = 1.f;
+    }
+    for (int i = 0; i < 4; ++i)
+        if (int e = t_alloc(t, &t->gh[i], BT * H)) return e;
+    if (int e = t_alloc(t, &t->gf, BT * F)) return e;
+    if (int e = t_alloc(t, &t->g3h, BT * 3 * H)) return e;
+    const int64_t widest = F > 3 * H ? F : 3 * H;
+    if (int e = t_alloc(t, &t->at, widest * BT)) return e;
+    t->slab_floats = 33 * (F * H > 3 * H * H ? F * H : 3 * H * H);      // 32 split-K slabs + the reduction scratch
+    if (int e = t_alloc(t, &t->slabs, t->slab_floats)) return e;
+    if (int e = t_alloc(t, &t->dwqkv, 3 * H * H + 3 * H)) return e;
+    if (int e = t_alloc(t, &t->dummy, 2 * (H + C + F))) return e;       // sink for gradients of frozen LN params
+    if (int e = t_alloc(t, &t->dwv_scratch, K * cg * H)) return e;
+    int64_t rw = colsum_ws_floats(BT, (int)widest);
+    const int64_t lw = ln_bwd_ws_floats(BT, (int)(H > C ? H : C));
+    if (lw > rw) rw = lw;
+    if (int e = t_alloc(t, &t->red_ws, rw + 16)) return e;
+    if (int e = t_alloc(t, &t->dvec, (int64_t)B * c.num_heads * T)) return e;
+    t->B = B;
+    t->L = L;
+    t->T = T;
+    t->transposes_fresh = false;
+    return W2V2_OK;
+}
+
+static int refresh_transposes(w2v2_model* m, hipStream_t s) {
+    TrainState* t = m->train;
+    if (t->transposes_fresh) return W2V2_OK;
+    const w2v2_config& c = m->cfg;
+    const int H = c.hidden_size, F = c.intermediate_size;
+    const int C = c.filter_sizes[c.num_conv_layers - 1];
+    if (int e = launch_transpose(m->P("feature_projection/projection/kernel"), t->WpT, C, H, 1, s)) return e;
+    if (c.with_lm_head)
+        if (int e = launch_transpose(m->P("lm_head/kernel"), t->WlmT, H, c.vocab_size, 1, s)) return e;
+    for (int i = 0; i < c.num_layers; ++i) {
+        const std::string b = "encoder/layers/" + std::to_string(i);
+        LayerSave& l = t->layers[i];
+        if (int e = launch_transpose(m->qkv_w[i], l.WqkvT, H, 3 * H, 1, s)) return e;
+        if (int e = launch_transpose(m->P(b + "/attention/out_proj/kernel"), l.WoT, H, H, 1, s)) return e;
+        if (int e = launch_transpose(m->P(b + "/feed_forward/intermediate_dense/kernel"), l.W1T, H, F, 1, s)) return e;
+        if (int e = launch_transpose(m->P(b + "/feed_forward/output_dense/kernel"), l.W2T, F, H, 1, s)) return e;
+    }
+    const int K = c.num_conv_pos_embeddings, G = c.num_conv_pos_embedding_groups;
+    if (int e = launch_pos_conv_flip_regroup(m->pos_wg, t->pos_wg_t, K, H / G, G, s)) return e;
+    t->transposes_fresh = true;
+    return W2V2_OK;
+}
+
+static inline uint32_t layer_stream(int layer, int site) { return DS_LAYER_BASE + 4u * (uint32_t)layer + (uint32_t)site; }
+
+static float* grad_of(w2v2_model* m, const std::string& name) {
+    auto it = m->index.find(name);
+    return it == m->index.end() ? nullptr : m->train->grads + m->train->goff[it->second];
+}
+static bool is_trainable(w2v2_model* m, const std::string& name) {
+    auto it = m->index.find(name);
+    return it != m->index.end() && m->train->trainable[it->second];
+}
+
+// dW (Kin x Nout) = A^T (Kin x M) dY (M x Nout), db = column sums of dY.  A is (M x Kin) row-major.
+static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, int Kin, int Nout, float* dW,
+                       float* db, hipStream_t s) {
+    TrainState* t = m->train;
+    if (dW) {
+        if (int e = launch_transpose(A, t->at, M, Kin, 1, s)) return e;
+        int S = 1;
+        const int64_t tiles = (int64_t)((Kin + 127) / 128) * ((Nout + 127) / 128);
+        for (int cand = 32; cand >= 2; cand >>= 1)
+            if (M % (cand * 32) == 0 && tiles * cand <= 2048 && (int64_t)(cand + 1) * Kin * Nout <= t->slab_floats) {
+                S = cand;
+                break;
+            }
+        const int Kp = M / S;
+        if (S == 1) {
+            if (int e = launch_gemm_ex(m->prof, t->at, M, 0, dY, Nout, 0, dW, Nout, 0, nullptr, nullptr, Kin, Nout, M, 1, 0, s)) return e;
+        } else {
+            if (int e = launch_gemm_ex(m->prof, t->at, M, Kp, dY, Nout, (int64_t)Kp * Nout, t->slabs, Nout,
+                                       (int64_t)Kin * Nout, nullptr, nullptr, Kin, Nout, Kp, S, 0, s))
+                return e;
+            // sum the S slabs (rows = S, cols = Kin*Nout); the one-chunk partial scratch lives behind the slabs
+            if (int e = launch_colsum(t->slabs, dW, S, Kin * Nout, t->slabs + (int64_t)S * Kin * Nout, 0, s)) return e;
+        }
+    }
+    if (db)
+        if (int e = launch_colsum(dY, db, M, Nout, t->red_ws, 0, s)) return e;
+    return W2V2_OK;
+}
+
+extern "C" {
+
+int w2v2_set_trainable(w2v2_model* m, const char* prefix, int trainable) {
+    W2V2_REQUIRE(m && prefix, "set_trainable: null argument");
+    TrainState* t = get_state(m);
+    int hits = 0;
+    for (size_t i = 0; i < m->params.size(); ++i)
+        if (m->params[i].name.compare(0, strlen(prefix), prefix) == 0) {
+            t->trainable[i] = trainable ? 1 : 0;
+            ++hits;
+        }
+    if (!hits) {
+        set_error("set_trainable: no variable starts with `%s`", prefix);
+        return W2V2_ENOTFOUND;
+    }
+    return W2V2_OK;
+}
+
+int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const int32_t* mask,
+                       const uint8_t* spec_mask_host, const float* sd_keep_host, float dropout_p,
+                       uint64_t seed, float* logits_out, void* stream) {
+    W2V2_REQUIRE(m && wave && logits_out, "train_forward: null argument");
+    W2V2_REQUIRE(m->cfg.with_lm_head, "train_forward: the training step needs the CTC head (Wav2Vec2ForCTC)");
+    W2V2_REQUIRE(m->cfg.attention_norm_type == 0, "train_forward: only the postnorm (base) transformer is built for training");
+    W2V2_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "train_forward: dropout %f outside [0, 1)", dropout_p);
+    if (!m->finalized) {
+        set_error("train_forward: call w2v2_finalize after setting the variables");
+        return W2V2_ESTATE;
+    }
+    const w2v2_config& c = m->cfg;
+    const int64_t Tll = w2v2_num_frames(m, L);
+    W2V2_REQUIRE(Tll >= 1, "train_forward: input too short");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (int e = w2v2_ensure_workspace(m, B, L)) return e;
+    const int T = (int)Tll;
+    if (int e = ensure_train_ws(m, B, L, T)) return e;
+    TrainState* t = m->train;
+    Profiler* pf = m->prof;
+    const int H = c.hidden_size, F = c.intermediate_size;
+    const int64_t BT = (int64_t)B * T;
+    const int act = c.is_gelu_approx ? 2 : 1;
+    const bool layer_mode = c.feature_extractor_norm_type == 1;
+    const float eps = c.layer_norm_eps, p = dropout_p;
+    t->p = p;
+    t->seed = seed;
+    auto fe = [&](int i, const char* leaf) { return m->P("feature_extractor/conv_layers/" + std::to_string(i) + leaf); };
+
+    // ---- frozen feature extractor: identical to inference (no dropout inside, feature_extractor.py:54-59) ----
+    if (int e = launch_conv0(pf, wave, fe(0, "/conv/kernel"), c.conv_bias ? fe(0, "/conv/bias") : nullptr,
+                             fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"), m->conv[0], m->conv0_ws, B, L,
+                             c.kernal_sizes[0], c.strides[0], c.filter_sizes[0], 1e-5f, layer_mode ? 1 : 0, act, s))
+        return e;
+    if (layer_mode)
+        if (int e = launch_layer_norm(pf, m->conv[0], m->conv[0], fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"),
+                                      (int64_t)B * m->conv_T[0], c.filter_sizes[0], 1e-5f, act, s))
+            return e;
+    for (int i = 1; i < c.num_conv_layers; ++i) {
+        const int cin = c.filter_sizes[i - 1], cout = c.filter_sizes[i];
+        const int Tin = m->conv_T[i - 1], Tout = m->conv_T[i];
+        if (int e = launch_gemm(pf, m->conv[i - 1], (int64_t)c.strides[i] * cin, (int64_t)Tin * cin, fe(i, "/conv/kernel"),
+                                cout, m->conv[i], cout, (int64_t)Tout * cout, c.conv_bias ? fe(i, "/conv/bias") : nullptr,
+                                nullptr, Tout, cout, c.kernal_sizes[i] * cin, B, layer_mode ? 0 : act, s))
+            return e;
+        if (layer_mode)
+            if (int e = launch_layer_norm(pf, m->conv[i], m->conv[i], fe(i, "/layer_norm/gamma"), fe(i, "/layer_norm/beta"),
+                                          (int64_t)B * Tout, cout, 1e-5f, act, s))
+                return e;
+    }
+    // ---- feature projection: LN -> Dense -> Dropout (feature_extractor.py:92-95) ----
+    const int C = c.filter_sizes[c.num_conv_layers - 1];
+    const float* conv_out = m->conv[c.num_conv_layers - 1];
+    if (int e = launch_layer_norm(pf, conv_out, m->ln512, m->P("feature_projection/layer_norm/gamma"),
+                                  m->P("feature_projection/layer_norm/beta"), BT, C, eps, 0, s))
+        return e;
+    if (int e = launch_gemm(pf, m->ln512, C, 0, m->P("feature_projection/projection/kernel"), H, m->proj, H, 0,
+                            m->P("feature_projection/projection/bias"), nullptr, (int)BT, H, C, 1, 0, s))
+        return e;
+    if (int e = launch_dropout_fwd(m->proj, nullptr, t->hd, BT * H, 0, p, seed, DS_FEATURE_PROJECTION, s)) return e;
+    // ---- spec-augment: masked frames <- masked_spec_embed (modeling.py:193-199, spec_augment.py:119-127) ----
+    t->have_spec = spec_mask_host != nullptr;
+    const float* enc_x = t->hd;
+    if (t->have_spec) {
+        W2V2_HIP_CHECK(hipMemcpyAsync(t->spec_mask, spec_mask_host, (size_t)BT, hipMemcpyHostToDevice, s));
+        if (int e = launch_spec_aug_fwd(t->hd, t->spec_mask, m->P("masked_spec_embed"), t->hm, BT, H, s)) return e;
+        enc_x = t->hm;
+    }
+    // ---- encoder (encoder.py:251-276) ----
+    const int32_t* flen = nullptr;
+    t->have_mask = mask != nullptr;
+    if (mask) {
+        if (int e = launch_frame_lengths(pf, mask, m->frame_len, B, L, c.kernal_sizes, c.strides, c.num_conv_layers, s)) return e;
+        flen = m->frame_len;
+    }
+    // posout = xz + GELU(c), c saved for backward
+    if (int e = launch_pos_conv_ex(pf, enc_x, m->pos_wg, m->P("encoder/pos_conv_embed/conv/bias"), flen, m->posout, t->pos_c,
+                                   B, T, H, c.num_conv_pos_embeddings, c.num_conv_pos_embedding_groups, act,
+                                   c.num_conv_pos_embeddings / 2, 1, s))
+        return e;
+    if (int e = launch_layer_norm(pf, m->posout, m->t0, m->P("encoder/layer_norm/gamma"), m->P("encoder/layer_norm/beta"), BT, H, eps, 0, s)) return e;
+    if (int e = launch_dropout_fwd(m->t0, nullptr, m->hs[0], BT * H, 0, p, seed, DS_ENCODER_IN, s)) return e;
+    for (int i = 0; i < c.num_layers; ++i) {
+        const std::string b = "encoder/layers/" + std::to_string(i);
+        LayerSave& l = t->layers[i];
+        const float* x = m->hs[i];
+        l.keep = sd_keep_host ? sd_keep_host[i] : 1.0f;
+        if (int e = launch_gemm(pf, x, H, 0, m->qkv_w[i], 3 * H, l.qkv, 3 * H, 0, m->qkv_b[i], nullptr, (int)BT, 3 * H, H, 1, 0, s)) return e;
+        AttnTrain tr{p, seed, layer_stream(i, 0), l.lse};
+        if (int e = launch_attention_train(pf, l.qkv, flen, l.ctx, B, T, H, c.num_heads, tr, s)) return e;
+        // o = ctx Wo + bo;  t1 = dropout(o) + x   (encoder.py:116-119)
+        if (int e = launch_gemm(pf, l.ctx, H, 0, m->P(b + "/attention/out_proj/kernel"), H, m->t0, H, 0,
+                                m->P(b + "/attention/out_proj/bias"), nullptr, (int)BT, H, H, 1, 0, s))
+            return e;
+        if (int e = launch_dropout_fwd(m->t0, x, l.t1, BT * H, 0, p, seed, layer_stream(i, 1), s)) return e;
+        if (int e = launch_layer_norm(pf, l.t1, l.t2, m->P(b + "/layer_norm/gamma"), m->P(b + "/layer_norm/beta"), BT, H, eps, 0, s)) return e;
+        if (l.keep != 0.f) {
+            // u = t2 W1 + b1;  gd = dropout(GELU(u));  t3 = t2 + keep * (gd W2 + b2)   (encoder.py:127-130)
+            if (int e = launch_gemm(pf, l.t2, H, 0, m->P(b + "/feed_forward/intermediate_dense/kernel"), F, l.u, F, 0,
+                                    m->P(b + "/feed_forward/intermediate_dense/bias"), nullptr, (int)BT, F, H, 1, 0, s))
+                return e;
+            if (int e = launch_dropout_fwd(l.u, nullptr, l.gd, BT * F, act, p, seed, layer_stream(i, 2), s)) return e;
+            if (int e = launch_gemm(pf, l.gd, F, 0, m->P(b + "/feed_forward/output_dense/kernel"), H, l.t3, H, 0,
+                                    m->P(b + "/feed_forward/output_dense/bias"), l.t2, (int)BT, H, F, 1, 0, s))
+                return e;
+        } else {
+            W2V2_HIP_CHECK(hipMemcpyAsync(l.t3, l.t2, (size_t)BT * H * 4, hipMemcpyDeviceToDevice, s));
+        }
+        if (int e = launch_layer_norm(pf, l.t3, m->hs[i + 1], m->P(b + "/final_layer_norm/gamma"),
+                                      m->P(b + "/final_layer_norm/beta"), BT, H, eps, 0, s))
+            return e;
+    }
+    // ---- head: Dropout -> lm_head (modeling.py:253-254) ----
+    if (int e = launch_dropout_fwd(m->hs[c.num_layers], nullptr, t->hdf, BT * H, 0, p, seed, DS_HEAD, s)) return e;
+    if (int e = launch_gemm(pf, t->hdf, H, 0, m->P("lm_head/kernel"), c.vocab_size, logits_out, c.vocab_size, 0,
+                            m->P("lm_head/bias"), nullptr, (int)BT, c.vocab_size, H, 1, 0, s))
+        return e;
+    t->forward_done = true;
+    return W2V2_OK;
+}
+
+int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
+    W2V2_REQUIRE(m && dlogits, "train_backward: null argument");
+    TrainState* t = m->train;
+    if (!t || !t->forward_done) {
+        set_error("train_backward: no training forward to differentiate");
+        return W2V2_ESTATE;
+    }
+    const w2v2_config& c = m->cfg;
+    for (size_t i = 0; i < m->params.size(); ++i)
+        if (t->trainable[i] && m->params[i].name.compare(0, 18, "feature_extractor/") == 0) {
+            set_error("train_backward: `%s` is trainable, but the conv feature extractor has no backward "
+                      "(the reference freezes it, main.py:234-237); call freeze_feature_extractor()", m->params[i].name.c_str());
+            return W2V2_ESTATE;
+        }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    Profiler* pf = m->prof;
+    const int B = t->B, T = t->T, H = c.hidden_size, F = c.intermediate_size, V = c.vocab_size;
+    const int64_t BT = (int64_t)B * T;
+    const int act = c.is_gelu_approx ? 2 : 1;
+    const float eps = c.layer_norm_eps, p = t->p;
+    const uint64_t seed = t->seed;
+    const int32_t* flen = t->have_mask ? m->frame_len : nullptr;
+    W2V2_HIP_CHECK(hipMemsetAsync(t->grads, 0, (size_t)t->gtotal * 4, s));
+    if (int e = refresh_transposes(m, s)) return e;
+    auto G = [&](const std::string& n) { return is_trainable(m, n) ? grad_of(m, n) : nullptr; };
+    // does anything below the head train?
+    bool below_head = false;
+    for (size_t i = 0; i < m->params.size(); ++i)
+        if (t->trainable[i] && m->params[i].name.compare(0, 8, "lm_head/") != 0) below_head = true;
+
+    // ---- head ----
+    if (int e = weight_grad(m, t->hdf, dlogits, (int)BT, H, V, G("lm_head/kernel"), G("lm_head/bias"), s)) return e;
+    if (!below_head) return W2V2_OK;            // stage 1 of the reference: only lm_head trains (main.py:210)
+    float *dh = t->gh[0], *tmp = t->gh[1], *tmp2 = t->gh[2], *tmp3 = t->gh[3];
+    if (int e = launch_gemm(pf, dlogits, V, 0, t->WlmT, H, tmp, H, 0, nullptr, nullptr, (int)BT, H, V, 1, 0, s)) return e;
+    if (int e = launch_dropout_bwd(nullptr, tmp, dh, BT * H, 0, p, seed, DS_HEAD, s)) return e;
+
+    for (int i = c.num_layers - 1; i >= 0; --i) {
+        const std::string b = "encoder/layers/" + std::to_string(i);
+        LayerSave& l = t->layers[i];
+        // hs[i+1] = LN(t3)
+        float* dt3 = tmp;
+        float* dg2 = G(b + "/final_layer_norm/gamma");
+        float* db2 = G(b + "/final_layer_norm/beta");
+        if (int e = launch_ln_bwd(l.t3, m->P(b + "/final_layer_norm/gamma"), dh, dt3, dg2 ? dg2 : t->dummy, db2 ? db2 : t->dummy + H,
+                                  BT, H, eps, t->red_ws, s))
+            return e;
+        float* dt2 = tmp2;
+        if (l.keep != 0.f) {
+            // t3 = t2 + f,  f = gd W2 + b2
+            if (int e = weight_grad(m, l.gd, dt3, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
+                                    G(b + "/feed_forward/output_dense/bias"), s))
+                return e;
+            if (int e = launch_gemm(pf, dt3, H, 0, l.W2T, F, t->gf, F, 0, nullptr, nullptr, (int)BT, F, H, 1, 0, s)) return e;
+            // du = dgd * keep/(1-p) * GELU'(u)
+            if (int e = launch_dropout_bwd(l.u, t->gf, t->gf, BT * F, act, p, seed, layer_stream(i, 2), s)) return e;
+            if (int e = weight_grad(m, l.t2, t->gf, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
+                                    G(b + "/feed_forward/intermediate_dense/bias"), s))
+                return e;
+            // dt2 = du W1^T + dt3 (the residual branch)
+            if (int e = launch_gemm(pf, t->gf, F, 0, l.W1T, H, dt2, H, 0, nullptr, dt3, (int)BT, H, F, 1, 0, s)) return e;
+        } else {
+            W2V2_HIP_CHECK(hipMemcpyAsync(dt2, dt3, (size_t)BT * H * 4, hipMemcpyDeviceToDevice, s));
+        }
+        // t2 = LN(t1)
+        float* dt1 = tmp3;
+        float* dg1 = G(b + "/layer_norm/gamma");
+        float* db1 = G(b + "/layer_norm/beta");
+        if (int e = launch_ln_bwd(l.t1, m->P(b + "/layer_norm/gamma"), dt2, dt1, dg1 ? dg1 : t->dummy, db1 ? db1 : t->dummy + H, BT, H,
+                                  eps, t->red_ws, s))
+            return e;
+        // t1 = dropout(o) + x,  o = ctx Wo + bo
+        float* d_o = tmp;     // dt3 is dead
+        if (int e = launch_dropout_bwd(nullptr, dt1, d_o, BT * H, 0, p, seed, layer_stream(i, 1), s)) return e;
+        if (int e = weight_grad(m, l.ctx, d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), G(b + "/attention/out_proj/bias"), s)) return e;
+        float* dctx = tmp2;   // dt2 is dead
+        if (int e = launch_gemm(pf, d_o, H, 0, l.WoT, H, dctx, H, 0, nullptr, nullptr, (int)BT, H, H, 1, 0, s)) return e;
+        AttnTrain tr{p, seed, layer_stream(i, 0), l.lse};
+        if (int e = launch_attention_bwd(pf, l.qkv, flen, l.ctx, dctx, t->g3h, t->dvec, B, T, H, c.num_heads, tr, s)) return e;
+        // packed q|k|v projection: dW (H, 3H) -> the three (H, H) kernels, db (3H) -> the three biases
+        {
+            float* dWqkv = t->dwqkv;
+            float* dbqkv = dWqkv + (int64_t)3 * H * H;
+            if (int e = weight_grad(m, m->hs[i], t->g3h, (int)BT, H, 3 * H, dWqkv, dbqkv, s)) return e;
+            const char* names[3] = {"q_proj", "k_proj", "v_proj"};
+            for (int j = 0; j < 3; ++j) {
+                float* gw = G(b + "/attention/" + names[j] + "/kernel");
+                float* gb = G(b + "/attention/" + names[j] + "/bias");
+                if (gw)
+                    W2V2_HIP_CHECK(hipMemcpy2DAsync(gw, (size_t)H * 4, dWqkv + j * H, (size_t)3 * H * 4, (size_t)H * 4, (size_t)H,
+                                                    hipMemcpyDeviceToDevice, s));
+                if (gb) W2V2_HIP_CHECK(hipMemcpyAsync(gb, dbqkv + j * H, (size_t)H * 4, hipMemcpyDeviceToDevice, s));
+            }
+        }
+        // dx = dqkv Wqkv^T + dt1 (residual)
+        if (int e = launch_gemm(pf, t->g3h, 3 * H, 0, l.WqkvT, H, dh, H, 0, nullptr, dt1, (int)BT, H, 3 * H, 1, 0, s)) return e;
+    }
+    // ---- encoder input: hs[0] = dropout(LN(posout)) ----
+    if (int e = launch_dropout_bwd(nullptr, dh, tmp, BT * H, 0, p, seed, DS_ENCODER_IN, s)) return e;
+    float* dpos = tmp2;
+    {
+        float* dg = G("encoder/layer_norm/gamma");
+        float* db = G("encoder/layer_norm/beta");
+        if (int e = launch_ln_bwd(m->posout, m->P("encoder/layer_norm/gamma"), tmp, dpos, dg ? dg : t->dummy, db ? db : t->dummy + H, BT, H,
+                                  eps, t->red_ws, s))
+            return e;
+    }
+    // ---- positional conv: posout = xz + GELU(c),  c = conv(xz; W_eff) + bias ----
+    const int K = c.num_conv_pos_embeddings, Gr = c.num_conv_pos_embedding_groups, cg = H / Gr;
+    float* dc = tmp;
+    if (int e = launch_dropout_bwd(t->pos_c, dpos, dc, BT * H, act, 0.f, 0, 0, s)) return e;       // dc = dpos * GELU'(c)
+    if (float* gb = G("encoder/pos_conv_embed/conv/bias"))
+        if (int e = launch_colsum(dc, gb, BT, H, t->red_ws, 0, s)) return e;
+    const float* enc_x = t->have_spec ? t->hm : t->hd;
+    const float* xz = enc_x;
+    if (flen) {
+        if (int e = launch_mask_rows(enc_x, flen, tmp3, B, T, H, s)) return e;
+        xz = tmp3;
+    }
+    float* gv = G("encoder/pos_conv_embed/conv/weight_v");
+    float* gg = G("encoder/pos_conv_embed/conv/weight_g");
+    if (gv || gg) {
+        if (int e = launch_pos_conv_dw(pf, xz, dc, t->dwg, nullptr, B, T, H, K, Gr, s)) return e;
+        float* gvd = gv ? gv : t->dwv_scratch;   // scratch targets when only one of the pair trains
+        float* ggd = gg ? gg : t->dummy;
+        if (int e = launch_weight_norm_bwd(m->P("encoder/pos_conv_embed/conv/weight_v"), m->P("encoder/pos_conv_embed/conv/weight_g"),
+                                           t->dwg, gvd, ggd, K, cg, H, Gr, s))
+            return e;
+    }
+    // dxz = dpos + conv^T(dc)   (transposed kernel, pad_left = K - 1 - K/2), then the frame mask
+    float* dxz = dh;
+    if (int e = launch_pos_conv_ex(pf, dc, t->pos_wg_t, nullptr, nullptr, dxz, nullptr, B, T, H, K, Gr, 0, K - 1 - K / 2, 0, s)) return e;
+    if (int e = launch_axpby(dxz, dpos, dxz, BT * H, 1.f, 1.f, s)) return e;
+    if (flen)
+        if (int e = launch_mask_rows(dxz, flen, dxz, B, T, H, s)) return e;
+    // ---- spec-augment ----
+    float* dhd = dxz;
+    if (t->have_spec) {
+        if (int e = launch_spec_aug_bwd(dxz, t->spec_mask, tmp, tmp2, BT, H, s)) return e;
+        if (float* ge = G("masked_spec_embed"))
+            if (int e = launch_colsum(tmp2, ge, BT, H, t->red_ws, 0, s)) return e;
+        dhd = tmp;
+    }
+    // ---- feature projection: hd = dropout(ln512 Wp + bp),  ln512 = LN(conv_out) ----
+    float* dproj = tmp3;
+    if (int e = launch_dropout_bwd(nullptr, dhd, dproj, BT * H, 0, p, seed, DS_FEATURE_PROJECTION, s)) return e;
+    const int C = c.filter_sizes[c.num_conv_layers - 1];
+    if (int e = weight_grad(m, m->ln512, dproj, (int)BT, C, H, G("feature_projection/projection/kernel"),
+                            G("feature_projection/projection/bias"), s))
+        return e;
+    float* dgp = G("feature_projection/layer_norm/gamma");
+    float* dbp = G("feature_projection/layer_norm/beta");
+    if (dgp || dbp) {
+        float* dln = tmp2;       // (BT, C) fits a (BT, H) buffer when C <= H; otherwise use the FFN scratch
+        if (C > H) dln = t->gf;
+        if (int e = launch_gemm(pf, dproj, H, 0, t->WpT, C, dln, C, 0, nullptr, nullptr, (int)BT, C, H, 1, 0, s)) return e;
+        float* dxc = C > H ? t->g3h : tmp;    // gradient w.r.t. the frozen conv output: computed and dropped
+        if (int e = launch_ln_bwd(m->conv[c.num_conv_layers - 1], m->P("feature_projection/layer_norm/gamma"), dln, dxc,
+                                  dgp ? dgp : t->dummy, dbp ? dbp : t->dummy + C, BT, C, eps, t->red_ws, s))
+            return e;
+    }
+    return W2V2_OK;
+}
+
+int w2v2_grad_buffer(w2v2_model* m, float** dev_ptr, int64_t* numel) {
+    W2V2_REQUIRE(m && dev_ptr && numel, "grad_buffer: null argument");
+    TrainState* t = m->train;
+    if (!t || !t->grads) {
+        set_error("grad_buffer: run a training forward first");
+        return W2V2_ESTATE;
+    }
+    *dev_ptr = t->grads;
+    *numel = t->gtotal;
+    return W2V2_OK;
+}
+
+int w2v2_get_grad(w2v2_model* m, const char* name, float* host_dst, int64_t numel, void* stream) {
+    W2V2_REQUIRE(m && name && host_dst, "get_grad: null argument");
+    TrainState* t = m->train;
+    if (!t || !t->grads) {
+        set_error("get_grad: run a training forward/backward first");
+        return W2V2_ESTATE;
+    }
+    auto it = m->index.find(name);
+    if (it == m->index.end()) {
+        set_error("get_grad: unknown variable `%s`", name);
+        return W2V2_ENOTFOUND;
+    }
+    W2V2_REQUIRE(numel == m->params[it->second].numel, "get_grad: element count mismatch for `%s`", name);
+    W2V2_HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+    W2V2_HIP_CHECK(hipMemcpy(host_dst, t->grads + t->goff[it->second], (size_t)numel * 4, hipMemcpyDeviceToHost));
+    return W2V2_OK;
+}
+
+int w2v2_adam_step(w2v2_model* m, float lr, float beta1, float beta2, float eps, int64_t step, void* stream) {
+    W2V2_REQUIRE(m && step >= 1, "adam_step: bad argument");
+    TrainState* t = m->train;
+    if (!t || !t->grads) {
+        set_error("adam_step: no gradients");
+        return W2V2_ESTATE;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // Keras: lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t);  p -= lr_t * m / (sqrt(v) + eps)
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
+    for (size_t i = 0; i < m->params.size(); ++i) {
+        if (!t->trainable[i]) continue;
+        Param& p = m->params[i];
+        const int64_t off = t->goff[i];
+        if (int e = launch_adam(p.dev, t->grads + off, t->adam_m + off, t->adam_v + off, p.numel, (float)lr_t, beta1, beta2, eps, s))
+            return e;
+    }
+    t->transposes_fresh = false;
+    m->finalized = false;
+    return w2v2_finalize(m, stream);     // re-derive the effective positional kernel and the packed q|k|v
+}
+
+int64_t w2v2_ln_bwd_ws_floats(int64_t rows, int32_t C) { return ln_bwd_ws_floats(rows, C); }
+int w2v2_op_layer_norm_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma,
+                           float* dbeta, int64_t rows, int32_t C, float eps, float* ws, void* stream) {
+    return launch_ln_bwd(x, gamma, dy, dx, dgamma, dbeta, rows, C, eps, ws, reinterpret_cast<hipStream_t>(stream));
+}
+int w2v2_op_attention_train(const float* qkv, const int32_t* frame_len, float* ctx, float* lse, int32_t B, int32_t T,
+                            int32_t H, int32_t heads, float p, uint64_t seed, uint32_t stream_id, void* stream) {
+    AttnTrain tr{p, seed, stream_id, lse};
+    return launch_attention_train(nullptr, qkv, frame_len, ctx, B, T, H, heads, tr, reinterpret_cast<hipStream_t>(stream));
+}
+int w2v2_op_attention_bwd(const float* qkv, const int32_t* frame_len, const float* ctx, const float* lse,
+                          const float* dctx, float* dqkv, float* dvec_ws, int32_t B, int32_t T, int32_t H,
+                          int32_t heads, float p, uint64_t seed, uint32_t stream_id, void* stream) {
+    AttnTrain tr{p, seed, stream_id, const_cast<float*>(lse)};
+    return launch_attention_bwd(nullptr, qkv, frame_len, ctx, dctx, dqkv, dvec_ws, B, T, H, heads, tr,
+                                reinterpret_cast<hipStream_t>(stream));
+}
+int w2v2_op_dropout(const float* x, const float* residual, float* y, int64_t n, int32_t act, float p,
+                    uint64_t seed, uint32_t stream_id, void* stream) {
+    return launch_dropout_fwd(x, residual, y, n, act, p, seed, stream_id, reinterpret_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -57,6 +57,17 @@ PROTOTYPES = {
     "w2v2_num_frames": (_I64, [_P, _I64]),
     "w2v2_forward": (C.c_int, [_P, _P, _I32, _I64, _P, _P, _P]),
     "w2v2_ctc_loss": (C.c_int, [_P, _I32, _I32, _I32, _P, _I32, _P, _P, _I32, _P, _P, _P]),
+    "w2v2_set_trainable": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "w2v2_train_forward": (C.c_int, [_P, _P, _I32, _I64, _P, _P, _P, C.c_float, C.c_uint64, _P, _P]),
+    "w2v2_train_backward": (C.c_int, [_P, _P, _P]),
+    "w2v2_grad_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I64)]),
+    "w2v2_get_grad": (C.c_int, [_P, C.c_char_p, _P, _I64, _P]),
+    "w2v2_adam_step": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, _I64, _P]),
+    "w2v2_ln_bwd_ws_floats": (_I64, [_I64, _I32]),
+    "w2v2_op_layer_norm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I32, C.c_float, _P, _P]),
+    "w2v2_op_attention_train": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, C.c_float, C.c_uint64, C.c_uint32, _P]),
+    "w2v2_op_attention_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, C.c_float, C.c_uint64, C.c_uint32, _P]),
+    "w2v2_op_dropout": (C.c_int, [_P, _P, _P, _I64, _I32, C.c_float, C.c_uint64, C.c_uint32, _P]),
     "w2v2_activation_info": (C.c_int, [_P, C.c_char_p, C.POINTER(_I64)]),
     "w2v2_copy_activation": (C.c_int, [_P, C.c_char_p, _P, _I64, _P]),
     "w2v2_profile_enable": (C.c_int, [_P, C.c_int]),

@@ -151,6 +151,14 @@ class TFKerasModel:
             N.check(self._lib.w2v2_finalize(self._handle, N.current_stream()), "w2v2_finalize")
             self._dirty = False
 
+    def set_trainable(self, name_prefix, trainable):
+        """Keras `.trainable` for every variable whose local name starts with `name_prefix`
+        (main.py:210,234-237 toggle whole sub-layers this way)."""
+        for v in self._variables:
+            if v.local_name.startswith(name_prefix):
+                v.trainable = bool(trainable)
+        N.check(self._lib.w2v2_set_trainable(self._handle, name_prefix.encode(), int(bool(trainable))), "w2v2_set_trainable")
+
     # ---- persistence (reference modeling.py:22-27, 41-84) -------------------
     def save_weights(self, path):
         arrays = {V.tf_variable_name(n, self._prefix_with_head): a for n, a in self.get_weights().items()}
@@ -308,9 +316,7 @@ class Wav2Vec2Model(TFKerasModel):
 
     def freeze_feature_extractor(self):
         """Marks the 7 conv layers non-trainable (reference modeling.py:211-214)."""
-        for v in self._variables:
-            if v.local_name.startswith("feature_extractor/"):
-                v.trainable = False
+        self.set_trainable("feature_extractor/", False)
 
 
 class Wav2Vec2ForCTC(TFKerasModel):
@@ -335,6 +341,4 @@ class Wav2Vec2ForCTC(TFKerasModel):
     call = __call__
 
     def freeze_feature_extractor(self):
-        for v in self._variables:
-            if v.local_name.startswith("feature_extractor/"):
-                v.trainable = False
+        self.set_trainable("feature_extractor/", False)

@@ -232,3 +232,28 @@ def seeded_weights(config, seed=0, with_lm_head=True):
             raise ValueError(kind)
         out[name] = a.astype(np.float32).reshape(shape)
     return out
+
+
+# --------------------------------------------------------------------------
+# Dropout mask hash -- the host-side twin of csrc/train.h::dropout_u01.
+# --------------------------------------------------------------------------
+DS_FEATURE_PROJECTION, DS_ENCODER_IN, DS_HEAD, DS_LAYER_BASE = 1, 2, 3, 16
+
+
+def layer_stream(layer, site):
+    """site: 0 attention probabilities, 1 attention output, 2 FFN intermediate."""
+    return DS_LAYER_BASE + 4 * layer + site
+
+
+def dropout_uniform(seed, stream, n, start=0):
+    """uniform [0, 1) per element index, identical to the device function (integer arithmetic only)."""
+    key = np.uint64((int(seed) ^ ((int(stream) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        idx = np.arange(start, start + n, dtype=np.uint64) * np.uint64(0x2545F4914F6CDD1D) + key
+    z = _splitmix64(idx)
+    return ((z >> np.uint64(40)).astype(np.float32)) * np.float32(1.0 / (1 << 24))
+
+
+def dropout_keep(seed, stream, n, p):
+    """Boolean keep mask: element kept iff u >= p (then scaled by 1 / (1 - p))."""
+    return dropout_uniform(seed, stream, n) >= np.float32(p)

@@ -130,6 +130,31 @@ int w2v2_ctc_loss(const float* logits_dev, int32_t B, int32_t T, int32_t V,
                   const int32_t* label_length_dev, const int32_t* logit_length_dev,
                   int32_t blank, float* nll_dev, float* grad_logits_dev, void* stream);
 
+/* ---- the training step (reference src/main.py:136-259) --------
+ * Replaces what Keras' train_step does around the forward: training-mode forward, backward of every
+ * trainable variable, Adam.  Postnorm (base) transformer only for now; the conv feature extractor
+ * has no backward (the reference freezes it, main.py:234-237) -- mark it non-trainable first.
+ *
+ * w2v2_train_forward: Wav2Vec2ForCTC.call(training=True): Dropout(p) at every Dropout layer
+ *   (feature_extractor.py:95; encoder.py:42-44,118,128,270; modeling.py:253) with masks from a
+ *   counter-based hash of (seed, site, element) -- never stored, regenerated in the backward;
+ *   spec_mask_host (B*T bytes, or NULL): frames replaced by masked_spec_embed (spec_augment.py:119-127;
+ *   the span sampling itself is host-side numpy in the reference and stays on the host here);
+ *   sd_keep_host (num_layers floats of 0/1, or NULL): StochasticDepth's one Bernoulli draw per layer
+ *   call (tensorflow_addons.py:381).  Saves what the backward needs.
+ * w2v2_train_backward: given d loss / d logits (B, T, V) fills the flat gradient buffer (zero for
+ *   frozen variables).  w2v2_grad_buffer exposes that buffer for the data-parallel all-reduce (SUM).
+ * w2v2_adam_step: Keras Adam, p -= lr sqrt(1-b2^t)/(1-b1^t) m / (sqrt(v) + eps), then re-derives the
+ *   tensors w2v2_finalize builds. */
+int w2v2_set_trainable(w2v2_model* m, const char* name_prefix, int trainable);
+int w2v2_train_forward(w2v2_model* m, const float* wave_dev, int32_t B, int64_t L, const int32_t* mask_dev,
+                       const uint8_t* spec_mask_host, const float* sd_keep_host, float dropout_p,
+                       uint64_t seed, float* logits_dev, void* stream);
+int w2v2_train_backward(w2v2_model* m, const float* grad_logits_dev, void* stream);
+int w2v2_grad_buffer(w2v2_model* m, float** dev_ptr, int64_t* numel);
+int w2v2_get_grad(w2v2_model* m, const char* name, float* host_dst, int64_t numel, void* stream);
+int w2v2_adam_step(w2v2_model* m, float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
+
 /* ---- introspection (parity tests, profiling) -----------------------------
  * Stage activations of the LAST forward, by name: "conv0".."conv6",
  * "projection", "encoder_in", "layer0".."layerN-1", "encoder_out".  Copies
@@ -214,6 +239,29 @@ int w2v2_op_attention(const float* qkv_dev, const int32_t* frame_len_dev, float*
 int w2v2_op_frame_lengths(const int32_t* mask_dev, int32_t* frame_len_dev, int32_t B,
                           int64_t L, const int32_t* kernal_sizes, const int32_t* strides,
                           int32_t num_layers, void* stream);
+
+/* ---- training operators (parity-tested on their own) ----------------------------------------- */
+
+/* LayerNormalization backward: dx, dgamma, dbeta from x (pre-norm input), gamma and dy.
+ * ws: scratch of w2v2_ln_bwd_ws_floats(rows, C) floats. */
+int64_t w2v2_ln_bwd_ws_floats(int64_t rows, int32_t C);
+int w2v2_op_layer_norm_bwd(const float* x_dev, const float* gamma_dev, const float* dy_dev, float* dx_dev,
+                           float* dgamma_dev, float* dbeta_dev, int64_t rows, int32_t C, float eps,
+                           float* ws_dev, void* stream);
+
+/* Attention with dropout on the probabilities (encoder.py:42-44) + saved log-sum-exp (B, heads, T),
+ * and its backward: dqkv (B, T, 3H) from dctx (B, T, H).  dvec_ws: (B, heads, T) scratch. */
+int w2v2_op_attention_train(const float* qkv_dev, const int32_t* frame_len_dev, float* ctx_dev, float* lse_dev,
+                            int32_t B, int32_t T, int32_t H, int32_t num_heads, float dropout_p,
+                            uint64_t seed, uint32_t stream_id, void* stream);
+int w2v2_op_attention_bwd(const float* qkv_dev, const int32_t* frame_len_dev, const float* ctx_dev,
+                          const float* lse_dev, const float* dctx_dev, float* dqkv_dev, float* dvec_ws_dev,
+                          int32_t B, int32_t T, int32_t H, int32_t num_heads, float dropout_p,
+                          uint64_t seed, uint32_t stream_id, void* stream);
+
+/* y = dropout(act(x)) [+ residual]: keep iff hash(seed, stream_id, index) >= p, kept values / (1 - p). */
+int w2v2_op_dropout(const float* x_dev, const float* residual_dev, float* y_dev, int64_t n, int32_t act,
+                    float p, uint64_t seed, uint32_t stream_id, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,258 @@
+"""Training step parity: the HIP training forward / backward / Adam against
+the torch-autograd oracle (oracle/w2v2_torch_train.py, fp64 CPU) on the same seeded weights and the SAME
+dropout masks (the build's counter-based hash is evaluated by both sides)."""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers as H
+from oracle import w2v2_torch_train as TT
+from wav2vec2 import _native as N
+from wav2vec2 import variables as V
+from wav2vec2.spec_augment import compute_mask_indices
+
+pytestmark = pytest.mark.gpu
+
+_KEEP = []
+
+
+@pytest.fixture(autouse=True)
+def _keepalive():
+    _KEEP.clear()
+    yield
+    _KEEP.clear()
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    torch.cuda.set_device(0)
+    return N.load(), torch, torch.device("cuda:0")
+
+
+def dev_t(torch, dev, a):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    _KEEP.append(t)
+    return t
+
+
+def rnd(tag, shape, scale=1.0):
+    n = int(np.prod(shape))
+    return ((V.hash_uniform(tag, n, 21) * 2 - 1) * scale).reshape(shape).astype(np.float32)
+
+
+# ------------------------------------------------------------------ operators --------------
+@pytest.mark.parametrize("n,p,stream", [(1000, 0.1, 3), (70001, 0.5, 17), (256, 0.0, 1)])
+def test_dropout_hash_matches_host(env, n, p, stream):
+    lib, torch, dev = env
+    x = rnd("dx", (n,))
+    res = rnd("dr", (n,))
+    y = torch.empty((n,), device=dev)
+    N.check(lib.w2v2_op_dropout(N.ptr(dev_t(torch, dev, x)), N.ptr(dev_t(torch, dev, res)), N.ptr(y), n, 0, p,
+                                C.c_uint64(0xDEADBEEF12345), stream, N.current_stream()))
+    keep = V.dropout_keep(0xDEADBEEF12345, stream, n, p)
+    ref = np.where(keep, x / np.float32(1 - p), 0).astype(np.float32) + res
+    assert np.allclose(y.cpu().numpy(), ref, atol=1e-6)
+    if p > 0:
+        assert abs(keep.mean() - (1 - p)) < 0.02
+
+
+@pytest.mark.parametrize("rows,Cn", [(37, 512), (130, 768), (9, 64), (5, 50), (3000, 768)])
+def test_layer_norm_backward(env, rows, Cn):
+    lib, torch, dev = env
+    x, dy = rnd("lx", (rows, Cn), 2.0) + 0.5, rnd("ldy", (rows, Cn))
+    g = 1 + rnd("lg", (Cn,), 0.3)
+    xt = torch.from_numpy(x.astype(np.float64)).requires_grad_(True)
+    gt = torch.from_numpy(g.astype(np.float64)).requires_grad_(True)
+    bt = torch.zeros(Cn, dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.layer_norm(xt, (Cn,), gt, bt, 1e-5)
+    y.backward(torch.from_numpy(dy.astype(np.float64)))
+    dx = torch.empty((rows, Cn), device=dev)
+    dg = torch.empty((Cn,), device=dev)
+    db = torch.empty((Cn,), device=dev)
+    ws = torch.empty((int(lib.w2v2_ln_bwd_ws_floats(rows, Cn)),), device=dev)
+    N.check(lib.w2v2_op_layer_norm_bwd(N.ptr(dev_t(torch, dev, x)), N.ptr(dev_t(torch, dev, g)), N.ptr(dev_t(torch, dev, dy)),
+                                       N.ptr(dx), N.ptr(dg), N.ptr(db), rows, Cn, 1e-5, N.ptr(ws), N.current_stream()))
+    assert H.max_err(dx.cpu().numpy(), xt.grad.numpy()) < 2e-5
+    assert H.max_err(dg.cpu().numpy(), gt.grad.numpy()) < 2e-4 * max(1.0, rows / 100)
+    assert H.max_err(db.cpu().numpy(), bt.grad.numpy()) < 2e-4 * max(1.0, rows / 100)
+
+
+@pytest.mark.parametrize("B,T,Hh,heads,p,flen", [(2, 12, 64, 2, 0.0, None), (2, 150, 128, 2, 0.1, None),
+                                                  (1, 200, 768, 12, 0.1, None), (2, 97, 128, 2, 0.2, [97, 40])])
+def test_attention_train_forward_backward(env, B, T, Hh, heads, p, flen):
+    """softmax-dropout attention and its gradient w.r.t. the packed q|k|v vs torch autograd."""
+    lib, torch, dev = env
+    d = Hh // heads
+    seed, stream = 991, 16
+    qkv = rnd("aq", (B, T, 3 * Hh), 1.5)
+    dctx = rnd("ad", (B, T, Hh))
+    qt = torch.from_numpy(qkv.astype(np.float64)).requires_grad_(True)
+    q, k, v = [qt[:, :, i * Hh:(i + 1) * Hh].reshape(B, T, heads, d).transpose(1, 2) for i in range(3)]
+    s = (q * d ** -0.5) @ k.transpose(-1, -2)
+    if flen is not None:
+        keepk = torch.from_numpy(np.arange(T)[None, :] < np.asarray(flen)[:, None])
+        s = s + ((~keepk).double() * -10000.0)[:, None, None, :]
+    pr = torch.softmax(s, -1)
+    lse_ref = torch.logsumexp(s, -1).detach().numpy()
+    if p > 0:
+        keep = torch.from_numpy(V.dropout_keep(seed, stream, B * heads * T * T, p).reshape(B, heads, T, T))
+        pr = torch.where(keep, pr / (1 - p), torch.zeros_like(pr))
+    ctx_ref = (pr @ v).transpose(1, 2).reshape(B, T, Hh)
+    ctx_ref.backward(torch.from_numpy(dctx.astype(np.float64)))
+
+    tq = dev_t(torch, dev, qkv)
+    tf = dev_t(torch, dev, np.asarray(flen, dtype=np.int32)) if flen is not None else None
+    ctx = torch.full((B, T, Hh), float("nan"), device=dev)
+    lse = torch.full((B, heads, T), float("nan"), device=dev)
+    N.check(lib.w2v2_op_attention_train(N.ptr(tq), N.ptr(tf), N.ptr(ctx), N.ptr(lse), B, T, Hh, heads, p,
+                                        C.c_uint64(seed), stream, N.current_stream()))
+    assert H.max_err(ctx.cpu().numpy(), ctx_ref.detach().numpy()) < 3e-5
+    assert H.max_err(lse.cpu().numpy(), lse_ref) < 3e-5
+    dqkv = torch.full((B, T, 3 * Hh), float("nan"), device=dev)
+    ws = torch.empty((B, heads, T), device=dev)
+    N.check(lib.w2v2_op_attention_bwd(N.ptr(tq), N.ptr(tf), N.ptr(ctx), N.ptr(lse), N.ptr(dev_t(torch, dev, dctx)), N.ptr(dqkv),
+                                      N.ptr(ws), B, T, Hh, heads, p, C.c_uint64(seed), stream, N.current_stream()))
+    got, ref = dqkv.cpu().numpy(), qt.grad.numpy()
+    assert np.isfinite(got).all()
+    for name, sl in (("dq", slice(0, Hh)), ("dk", slice(Hh, 2 * Hh)), ("dv", slice(2 * Hh, 3 * Hh))):
+        e = H.max_err(got[:, :, sl], ref[:, :, sl])
+        assert e < 5e-5 * max(1.0, np.abs(ref[:, :, sl]).max()), f"{name}: {e:.3e}"
+
+
+# ------------------------------------------------------------------ whole step ---------------
+def build(name, L):
+    import wav2vec2
+    cfg = H.case_config(name)
+    m = wav2vec2.Wav2Vec2ForCTC(cfg, input_shape=(2, L))
+    w = H.case_weights(name)
+    m.set_weights(w)
+    m.freeze_feature_extractor()
+    return m, cfg, w
+
+
+def grads_close(trainer, ref_grads, rtol=2e-4):
+    worst = ("", 0.0)
+    for name, g in ref_grads.items():
+        got = trainer.gradient(name)
+        if g is None:                      # variable unused in this forward (e.g. masked_spec_embed without a mask)
+            assert not np.any(got), name
+            continue
+        scale = max(1e-3, float(np.abs(g).max()))
+        e = H.max_err(got, g) / scale
+        if e > worst[1]:
+            worst = (name, e)
+        assert e < rtol, f"{name}: relative gradient error {e:.3e} (max |g| = {scale:.3e})"
+    return worst
+
+
+def test_training_forward_without_randomness_equals_inference(env):
+    import wav2vec2
+    g = H.golden("tiny_base")
+    m, cfg, w = build("tiny_base", 4000)
+    tr = wav2vec2.Trainer(m, wav2vec2.CTCLoss(cfg, g["wave"].shape), dropout=0.0, apply_spec_augment=False)
+    a = tr.forward(g["wave"]).cpu().numpy()
+    b = m(g["wave"]).numpy()
+    assert np.allclose(a, b, atol=2e-6)
+
+
+@pytest.mark.parametrize("p,use_spec,use_sd", [(0.0, False, False), (0.1, True, True)])
+def test_gradients_match_autograd_tiny(env, p, use_spec, use_sd):
+    import wav2vec2
+    g = H.golden("tiny_base")
+    m, cfg, w = build("tiny_base", 4000)
+    loss_fn = wav2vec2.CTCLoss(cfg, g["wave"].shape, division_factor=2)
+    tr = wav2vec2.Trainer(m, loss_fn, dropout=p, apply_spec_augment=False, seed=3)
+    spec = compute_mask_indices((2, 12), 0.3, 2, rng=np.random.RandomState(1)) if use_spec else None
+    sd = np.array([1.0, 0.0], np.float32) if use_sd else None
+    logits = tr.forward(g["wave"], spec_mask=spec, sd_keep=sd, step_seed=777)
+    nll, dlog = loss_fn.per_sample(g["labels"], logits, with_grad=True)
+    tr.backward(dlog)
+    loss, ref_nll, ref_logits, ref_grads = TT.loss_and_grads(cfg, w, g["wave"], g["labels"], p=p, seed=777, spec_mask=spec,
+                                                             sd_keep=sd, division_factor=2)
+    assert H.max_err(logits.cpu().numpy(), ref_logits) < 2e-5
+    assert np.allclose(nll.cpu().numpy(), ref_nll, atol=1e-3)
+    assert len(ref_grads) == len(V.variable_specs(cfg)) - 9
+    worst = grads_close(tr, ref_grads)
+    print("worst relative gradient error", worst)
+    # frozen conv stack: gradient slots stay zero
+    assert not np.any(tr.gradient("feature_extractor/conv_layers/3/conv/kernel"))
+
+
+def test_gradients_match_autograd_base_dims(env):
+    """Real base dimensions (768 / 12 heads / 3072 / 16 x 48-channel groups / 128 taps) on a short input."""
+    import wav2vec2
+    L = 12000
+    m, cfg, w = build("base_sample_padded", L)
+    x = V.hash_normal("train/wave", 2 * L, 8).reshape(2, L)
+    labels = np.array([[5, 9, 9, 11, 0, 0], [7, 6, 0, 0, 0, 0]], np.int32)
+    loss_fn = wav2vec2.CTCLoss(cfg, x.shape, division_factor=2)
+    tr = wav2vec2.Trainer(m, loss_fn, dropout=0.1, apply_spec_augment=False, seed=1)
+    T = cfg.num_frames(L)
+    spec = compute_mask_indices((2, T), 0.05, 10, rng=np.random.RandomState(4))
+    logits = tr.forward(x, spec_mask=spec, step_seed=42)
+    nll, dlog = loss_fn.per_sample(labels, logits, with_grad=True)
+    tr.backward(dlog)
+    loss, ref_nll, ref_logits, ref_grads = TT.loss_and_grads(cfg, w, x, labels, p=0.1, seed=42, spec_mask=spec, division_factor=2)
+    assert H.max_err(logits.cpu().numpy(), ref_logits) < 1e-4
+    worst = grads_close(tr, ref_grads, rtol=5e-4)
+    print("worst relative gradient error (base dims)", worst)
+
+
+def test_stage1_only_lm_head_trains(env):
+    import wav2vec2
+    g = H.golden("tiny_base")
+    m, cfg, w = build("tiny_base", 4000)
+    m.set_trainable("", False)
+    m.set_trainable("lm_head/", True)              # main.py:210: model.layers[0].trainable = False
+    loss_fn = wav2vec2.CTCLoss(cfg, g["wave"].shape)
+    tr = wav2vec2.Trainer(m, loss_fn, dropout=0.0, apply_spec_augment=False)
+    logits = tr.forward(g["wave"], step_seed=1)
+    _, dlog = loss_fn.per_sample(g["labels"], logits, with_grad=True)
+    tr.backward(dlog)
+    _, _, _, ref = TT.loss_and_grads(cfg, w, g["wave"], g["labels"], trainable=lambda k: k.startswith("lm_head/"))
+    assert set(ref) == {"lm_head/kernel", "lm_head/bias"}
+    grads_close(tr, ref)
+    assert not np.any(tr.gradient("encoder/layers/0/attention/q_proj/kernel"))
+
+
+def test_adam_step_and_loss_decreases(env):
+    import wav2vec2
+    g = H.golden("tiny_base")
+    m, cfg, w = build("tiny_base", 4000)
+    loss_fn = wav2vec2.CTCLoss(cfg, g["wave"].shape, division_factor=2)
+    tr = wav2vec2.Trainer(m, loss_fn, learning_rate=1e-3, dropout=0.0, apply_spec_augment=False)
+    # one step: parameters move exactly as Keras Adam moves them
+    logits = tr.forward(g["wave"], step_seed=1)
+    _, dlog = loss_fn.per_sample(g["labels"], logits, with_grad=True)
+    tr.backward(dlog)
+    name = "encoder/layers/1/feed_forward/output_dense/kernel"
+    gr = tr.gradient(name)
+    tr.apply_gradients()
+    want, _, _ = TT.adam_reference(w[name].astype(np.float64), gr.astype(np.float64), 0.0, 0.0, 1e-3, 0.9, 0.999, 1e-7, 1)
+    got = [v for v in m.variables if v.local_name == name][0].numpy()
+    assert H.max_err(got, want) < 1e-6
+    frozen = "feature_extractor/conv_layers/2/conv/kernel"
+    assert np.array_equal([v for v in m.variables if v.local_name == frozen][0].numpy(), w[frozen])
+    # a few more steps on the same batch: the loss must go down
+    losses = [float(tr.step(g["wave"], g["labels"])) for _ in range(8)]
+    assert losses[-1] < losses[0] * 0.9, losses
+    # and the inference path sees the updated weights (packed q|k|v / positional kernel re-derived)
+    assert np.isfinite(m(g["wave"]).numpy()).all()
+
+
+def test_trainer_defaults_run_with_dropout_and_spec_augment(env):
+    import wav2vec2
+    L = 24000
+    m, cfg, w = build("base_sample_padded", L)
+    x = V.hash_normal("train/wave2", 2 * L, 9).reshape(2, L)
+    labels = np.array([[5, 9, 9, 11, 0, 0], [7, 6, 8, 0, 0, 0]], np.int32)
+    tr = wav2vec2.Trainer(m, wav2vec2.CTCLoss(cfg, x.shape, division_factor=2), learning_rate=1e-4)
+    l0 = float(tr.step(x, labels))
+    l1 = float(tr.step(x, labels))
+    assert np.isfinite([l0, l1]).all()
+    assert tr.last["spec_mask"].shape == (2, cfg.num_frames(L)) and tr.last["spec_mask"].sum() > 0
+    buf = tr.grad_buffer()
+    assert buf.numel() >= 94_396_320 and bool(buf.isfinite().all())
