@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--samples", type=int, default=246000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--mode", choices=["forward", "train"], default="forward",
+                    help="forward = BASELINE configs[1] (the headline metric); train = one CTC fine-tune step "
+                         "(BASELINE configs[2] shape, fp32: forward + CTC + backward + gradient all-reduce + Adam)")
     args = ap.parse_args()
 
     import torch
@@ -115,27 +118,49 @@ def main():
     def barrier():
         D.barrier(sync_device=torch.cuda.synchronize)
 
+    if args.mode == "train":
+        # labels (B, 256) int32, first 24..200 entries uniform in [1, 31], rest 0
+        import numpy as np
+        rs = np.random.RandomState(7 + rank)
+        labels = np.zeros((B, 256), np.int32)
+        for b in range(B):
+            n = rs.randint(24, 201)
+            labels[b, :n] = rs.randint(1, 32, size=n)
+        labels_dev = torch.from_numpy(labels).to(dev)
+        model.freeze_feature_extractor()                      # stage 2 of the reference (main.py:234-237)
+        trainer = wav2vec2.Trainer(model, wav2vec2.CTCLoss(cfg, (B, L), division_factor=world * B), learning_rate=1e-4, seed=rank)
+
+        def step():
+            return trainer.step(x, labels_dev)
+    else:
+        def step():
+            return model(x)
+
     for _ in range(args.warmup):
-        out = model(x)
+        out = step()
     barrier()
     if not args.no_profile:
         model.profile(True)
         model.profile_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = model(x)
+        out = step()
     barrier()
     elapsed = time.perf_counter() - t0
     prof = model.profile_read() if not args.no_profile else {}
     model.profile(False)
-    assert tuple(out.shape) == (B, T, cfg.vocab_size) and bool(torch.isfinite(out).all())
+    if args.mode == "train":
+        assert bool(torch.isfinite(out).all()), "training loss is not finite"
+    else:
+        assert tuple(out.shape) == (B, T, cfg.vocab_size) and bool(torch.isfinite(out).all())
 
     elapsed = D.max_over_ranks(elapsed, device=dev)      # the slowest rank defines the step
 
     if rank == 0:
         audio_s = world * B * L / SAMPLE_RATE * args.steps
         res = {
-            "metric": "audio-seconds/s (wav2vec2-base forward, 246000-sample pad)",
+            "metric": "audio-seconds/s (wav2vec2-base forward, 246000-sample pad)" if args.mode == "forward"
+                      else "audio-seconds/s (wav2vec2-base CTC fine-tune step, 246000-sample pad)",
             "value": round(audio_s / elapsed, 2),
             "unit": "audio-seconds/s",
             "n_gpus": world,
@@ -147,7 +172,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"wav2vec2-base fp32 forward-only, batch={B}x{L} samples per GPU (BASELINE configs[1])",
+            "config": {"workload": (f"wav2vec2-base fp32 forward-only, batch={B}x{L} samples per GPU (BASELINE configs[1])"
+                                    if args.mode == "forward" else
+                                    f"wav2vec2-base CTC fine-tune step in fp32 (conv stack frozen, dropout 0.1, spec-augment, "
+                                    f"Adam), batch={B}x{L} per GPU (BASELINE configs[2] shape; fp32, not bf16)"),
                        "global_batch": world * B, "samples": L, "frames": T, "parallelism": f"dp{world}"},
         }
         if prof:
@@ -171,7 +199,9 @@ def main():
             # whole-forward algorithmic rate: 235.56 GFLOP per 246000-sample utterance scales with T
             flops_step = sum(v["flops"] for k, v in prof.items() if k in ("gemm_f32", "pos_conv", "attention", "conv0_apply")) / args.steps
             res["forward_tflops"] = round(flops_step * world / (elapsed / args.steps) / 1e12, 2)
-        if world == 1 and not args.no_cpu_baseline:
+        if args.mode == "train":
+            res["final_loss"] = round(float(out), 4)
+        if world == 1 and not args.no_cpu_baseline and args.mode == "forward":
             res["cpu_baseline"] = cpu_baseline(cfg, weights, L)
         print(json.dumps(res), flush=True)
     if world > 1:

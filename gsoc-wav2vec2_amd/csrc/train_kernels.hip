@@ -79,7 +79,7 @@ __global__ void transpose_kernel(const float* __restrict__ x, float* __restrict_
     }
 }
 
-// stage 1: partial[chunk][c] = sum over the chunk's rows of x[r][c]   (fp32, <= 256 rows per chunk)
+// stage 1: partial[chunk][c] = sum over the chunk's rows of x[r][c]   (fp32 within a chunk)
 __global__ void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
                                       int64_t rows, int cols, int rows_per_chunk) {
     const int c = blockIdx.x * EW_THREADS + threadIdx.x;
@@ -98,6 +98,24 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, float* __
     double acc = 0.0;
     for (int k = 0; k < nchunks; ++k) acc += (double)partial[(int64_t)k * ld + c];
     out[c] = accumulate ? out[c] + (float)acc : (float)acc;
+}
+// stage 2 for many chunks x few columns: 32 columns per block, the chunk loop split over 8 thread rows
+__global__ __launch_bounds__(256) void colsum_final_wide_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                                int nchunks, int cols, int64_t ld, int accumulate) {
+    __shared__ double red[8][33];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    double acc = 0.0;
+    if (c < cols)
+        for (int k = ry; k < nchunks; k += 8) acc += (double)partial[(int64_t)k * ld + c];
+    red[ry][cx] = acc;
+    __syncthreads();
+    if (ry == 0 && c < cols) {
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += red[j][cx];
+        out[c] = accumulate ? out[c] + (float)t : (float)t;
+    }
 }
 
 // LayerNorm backward.  One wave per row (grid-stride); per-lane dgamma / dbeta partials live in
@@ -256,14 +274,23 @@ int launch_transpose(const float* x, float* y, int rows, int cols, int nbatch, h
     return W2V2_OK;
 }
 
-int64_t colsum_ws_floats(int64_t rows, int cols) { return ((rows + 255) / 256) * (int64_t)cols + 8; }
+constexpr int COLSUM_CHUNK = 128;    // rows per stage-1 block
+
+int64_t colsum_ws_floats(int64_t rows, int cols) { return ((rows + COLSUM_CHUNK - 1) / COLSUM_CHUNK) * (int64_t)cols + 8; }
 
 int launch_colsum(const float* x, float* out, int64_t rows, int cols, float* ws, int accumulate, hipStream_t s) {
-    W2V2_REQUIRE(x && out && ws && rows > 0 && cols > 0, "colsum: bad argument");
-    const int nchunks = (int)((rows + 255) / 256);
+    W2V2_REQUIRE(x && out && rows > 0 && cols > 0, "colsum: bad argument");
+    if (rows <= 64) {   // few rows (split-K slabs): one pass, fp64 accumulate, no scratch
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + EW_THREADS - 1) / EW_THREADS), dim3(EW_THREADS), 0, s, x, out,
+                           (int)rows, cols, (int64_t)cols, accumulate);
+        W2V2_HIP_CHECK(hipGetLastError());
+        return W2V2_OK;
+    }
+    W2V2_REQUIRE(ws, "colsum: null workspace");
+    const int nchunks = (int)((rows + COLSUM_CHUNK - 1) / COLSUM_CHUNK);
     dim3 grid((cols + EW_THREADS - 1) / EW_THREADS, nchunks);
-    hipLaunchKernelGGL(colsum_partial_kernel, grid, dim3(EW_THREADS), 0, s, x, ws, rows, cols, 256);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(grid.x), dim3(EW_THREADS), 0, s, ws, out, nchunks, cols, (int64_t)cols, accumulate);
+    hipLaunchKernelGGL(colsum_partial_kernel, grid, dim3(EW_THREADS), 0, s, x, ws, rows, cols, COLSUM_CHUNK);
+    hipLaunchKernelGGL(colsum_final_wide_kernel, dim3((cols + 31) / 32), dim3(256), 0, s, ws, out, nchunks, cols, (int64_t)cols, accumulate);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -288,8 +315,9 @@ int launch_ln_bwd(const float* x, const float* gamma, const float* dy, float* dx
         hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, ws, rows, C, eps);
     // partial is (nb, 2C): dgamma = column sums of its first C columns, dbeta of its last C
     const dim3 g2((C + EW_THREADS - 1) / EW_THREADS);
-    hipLaunchKernelGGL(colsum_final_kernel, g2, dim3(EW_THREADS), 0, s, ws, dgamma, nb, C, (int64_t)2 * C, 0);
-    hipLaunchKernelGGL(colsum_final_kernel, g2, dim3(EW_THREADS), 0, s, ws + C, dbeta, nb, C, (int64_t)2 * C, 0);
+    (void)g2;
+    hipLaunchKernelGGL(colsum_final_wide_kernel, dim3((C + 31) / 32), dim3(256), 0, s, ws, dgamma, nb, C, (int64_t)2 * C, 0);
+    hipLaunchKernelGGL(colsum_final_wide_kernel, dim3((C + 31) / 32), dim3(256), 0, s, ws + C, dbeta, nb, C, (int64_t)2 * C, 0);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
