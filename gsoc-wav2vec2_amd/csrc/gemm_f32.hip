@@ -235,17 +235,18 @@ __device__ __forceinline__ void dma16(const float* g, float* l) {
     __builtin_amdgcn_global_load_lds((glb_f32*)g, (lds_f32*)l, 16, 0, 0);
 }
 
-template <int WM, int WN, int MINW, int BKT>
+template <int WM, int WN, int MINW, int BKT, int BM = 128, int BN = 128>
 __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_f32_dma_kernel(GemmArgs g) {
-    constexpr int BM = 128, BN = 128, STAGE = BM * BKT + BKT * BN;   // 32 KiB at BKT = 32
+    constexpr int STAGE = BM * BKT + BKT * BN;   // 32 KiB at 128x128x32, 64 KiB at 256x256x32
     constexpr int RPP = 256 / BKT;              // A rows per 1-KiB DMA piece (8 | 16)
     constexpr int SPR = BKT / 4;                // 16-B k-slots per A row (8 | 4)
     constexpr int SW = BKT == 32 ? 1 : 2;       // swizzle: slot ^= (row >> SW) & (SPR - 1)
-    constexpr int NPIECE = BM * BKT / 256;      // pieces per operand per K tile (16 | 8)
+    constexpr int NPA = BM * BKT / 256;         // 1-KiB pieces of the A tile
+    constexpr int NPB = BKT * BN / 256;         // 1-KiB pieces of the B tile
     constexpr int NW = WM * WN;                 // waves per block
-    constexpr int PPW = NPIECE / NW;            // 1-KiB DMA pieces per wave per operand per K tile
+    constexpr int PPA = NPA / NW, PPB = NPB / NW;   // pieces per wave per K tile
     constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 32, NTL = WTN / 32;
-    static_assert(PPW >= 1 && MT >= 1 && NTL >= 1, "bad wave grid");
+    static_assert(PPA >= 1 && PPB >= 1 && MT >= 1 && NTL >= 1, "bad wave grid");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN, li = lane & 31, lh = lane >> 5;
@@ -262,18 +263,22 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_f32_dma_kernel(GemmArg
     const float* __restrict__ Bm = g.B + (int64_t)z * g.strideB;
 
     // per-lane global sources of this wave's A pieces and B pieces (1 KiB each)
-    const float* a_src[PPW];
-    const float* b_src[PPW];
+    const float* a_src[PPA];
+    const float* b_src[PPB];
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        const int piece = wave * PPW + i;                   // pieces of RPP rows (A) / 2 rows (B)
+    for (int i = 0; i < PPA; ++i) {
+        const int piece = wave * PPA + i;                   // pieces of RPP rows
         const int r = piece * RPP + lane / SPR;             // A row inside the tile
         int row = m0 + r;
         row = row < g.M ? row : g.M - 1;
         const int slot = (lane % SPR) ^ ((r >> SW) & (SPR - 1));   // swizzled 16-B k-slot this lane fetches
         a_src[i] = A + (int64_t)row * g.lda + slot * 4;
-        const int br = piece * 2 + (lane >> 5);
-        int col = n0 + (lane & 31) * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < PPB; ++i) {
+        const int flat = (wave * PPB + i) * 256 + lane * 4;  // lane-linear position inside the (BKT, BN) tile
+        const int br = flat / BN;
+        int col = n0 + flat % BN;
         col = col < g.N ? col : (g.N >= 4 ? g.N - 4 : 0);
         b_src[i] = Bm + (int64_t)br * g.ldb + col;
     }
@@ -281,9 +286,9 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_f32_dma_kernel(GemmArg
         float* S = smem + buf * STAGE;
         const int k0 = kt * BKT;
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) dma16(a_src[i] + k0, S + (wave * PPW + i) * 256);
+        for (int i = 0; i < PPA; ++i) dma16(a_src[i] + k0, S + (wave * PPA + i) * 256);
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) dma16(b_src[i] + (int64_t)k0 * g.ldb, S + BM * BKT + (wave * PPW + i) * 256);
+        for (int i = 0; i < PPB; ++i) dma16(b_src[i] + (int64_t)k0 * g.ldb, S + BM * BKT + (wave * PPB + i) * 256);
     };
 
     f32x16 acc[MT][NTL];
@@ -361,12 +366,19 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_f32_dma_kernel(GemmArg
     }
 }
 
-template <int WM, int WN, int MINW, int BKT = 32>
+template <int WM, int WN, int MINW, int BKT = 32, int BM = 128, int BN = 128>
 int launch_dma(GemmArgs& g, int nbatch, hipStream_t s) {
-    g.tiles_m = (g.M + 127) / 128;
-    g.tiles_n = (g.N + 127) / 128;
+    g.tiles_m = (g.M + BM - 1) / BM;
+    g.tiles_n = (g.N + BN - 1) / BN;
     dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch), block(WM * WN * 64);
-    hipLaunchKernelGGL((gemm_f32_dma_kernel<WM, WN, MINW, BKT>), grid, block, 2 * (128 * BKT + BKT * 128) * sizeof(float), s, g);
+    const size_t lds = 2 * (BM * BKT + BKT * BN) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_dma_kernel<WM, WN, MINW, BKT, BM, BN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_f32_dma_kernel<WM, WN, MINW, BKT, BM, BN>), grid, block, lds, s, g);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -444,6 +456,8 @@ int launch_gemm_ex(Profiler* prof, const float* A, int64_t lda, int64_t strideA,
         case 9: if (fast) return launch_dma<2, 4, 3, 16>(g, nbatch, s); return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
         case 10: if (fast) return launch_dma<2, 4, 4, 16>(g, nbatch, s); return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
         case 11: if (fast) return launch_dma<2, 2, 4, 16>(g, nbatch, s); return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
+        case 12: if (fast && g.N >= 256) return launch_dma<4, 4, 1, 32, 256, 256>(g, nbatch, s); return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
+        case 13: if (fast && g.N >= 128) return launch_dma<4, 2, 1, 32, 256, 128>(g, nbatch, s); return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
         case 8: if (fast) return launch_dma<4, 4, 1>(g, nbatch, s); return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
         default: return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
     }

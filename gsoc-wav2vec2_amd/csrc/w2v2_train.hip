@@ -24,6 +24,7 @@ using namespace w2v2;
 
 struct LayerSave {
     float *qkv, *ctx, *lse, *t1, *t2, *u, *gd, *t3;
+    float* a;                           // prenorm only: LN(x), the attention input
     float *WqkvT, *WoT, *W1T, *W2T;     // transposed kernels for the data-gradient GEMMs
     float keep;                         // stochastic-depth draw of the last forward
 };
@@ -33,7 +34,7 @@ struct TrainState {
     int64_t L = 0;
     std::vector<void*> allocs;
     std::vector<LayerSave> layers;
-    float *hd = nullptr, *hm = nullptr, *pos_c = nullptr, *hdf = nullptr;
+    float *hd = nullptr, *hm = nullptr, *pos_c = nullptr, *hdf = nullptr, *hs0 = nullptr;
     float *WpT = nullptr, *WlmT = nullptr, *pos_wg_t = nullptr, *dwg = nullptr;
     uint8_t* spec_mask = nullptr;       // (B*T) device copy, or null when not applied
     bool have_spec = false, have_mask = false;
@@ -114,6 +115,8 @@ static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
     if (int e = t_alloc(t, &t->hm, BT * H)) return e;
     if (int e = t_alloc(t, &t->pos_c, BT * H)) return e;
     if (int e = t_alloc(t, &t->hdf, BT * H)) return e;
+    if (c.attention_norm_type == 1)
+        if (int e = t_alloc(t, &t->hs0, BT * H)) return e;
     if (int e = t_alloc(t, &t->WpT, H * C)) return e;
     if (int e = t_alloc(t, &t->WlmT, H * (int64_t)c.vocab_size)) return e;
     const int64_t K = c.num_conv_pos_embeddings, cg = H / c.num_conv_pos_embedding_groups;
@@ -132,6 +135,9 @@ static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
         if (int e = t_alloc(t, &l.u, BT * F)) return e;
         if (int e = t_alloc(t, &l.gd, BT * F)) return e;
         if (int e = t_alloc(t, &l.t3, BT * H)) return e;
+        l.a = nullptr;
+        if (c.attention_norm_type == 1)
+            if (int e = t_alloc(t, &l.a, BT * H)) return e;
         if (int e = t_alloc(t, &l.WqkvT, 3 * H * H)) return e;
         if (int e = t_alloc(t, &l.WoT, H * H)) return e;
         if (int e = t_alloc(t, &l.W1T, F * H)) return e;
@@ -247,7 +253,6 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
                        uint64_t seed, float* logits_out, void* stream) {
     W2V2_REQUIRE(m && wave && logits_out, "train_forward: null argument");
     W2V2_REQUIRE(m->cfg.with_lm_head, "train_forward: the training step needs the CTC head (Wav2Vec2ForCTC)");
-    W2V2_REQUIRE(m->cfg.attention_norm_type == 0, "train_forward: only the postnorm (base) transformer is built for training");
     W2V2_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "train_forward: dropout %f outside [0, 1)", dropout_p);
     if (!m->finalized) {
         set_error("train_forward: call w2v2_finalize after setting the variables");
@@ -322,14 +327,28 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
                                    B, T, H, c.num_conv_pos_embeddings, c.num_conv_pos_embedding_groups, act,
                                    c.num_conv_pos_embeddings / 2, 1, s))
         return e;
-    if (int e = launch_layer_norm(pf, m->posout, m->t0, m->P("encoder/layer_norm/gamma"), m->P("encoder/layer_norm/beta"), BT, H, eps, 0, s)) return e;
-    if (int e = launch_dropout_fwd(m->t0, nullptr, m->hs[0], BT * H, 0, p, seed, DS_ENCODER_IN, s)) return e;
+    const bool prenorm = c.attention_norm_type == 1;
+    // postnorm: hs[0] = dropout(LN(posout));  prenorm: hs[0] = dropout(posout)   (encoder.py:267-270)
+    {
+        const float* pre = m->posout;
+        if (!prenorm) {
+            if (int e = launch_layer_norm(pf, m->posout, m->t0, m->P("encoder/layer_norm/gamma"), m->P("encoder/layer_norm/beta"), BT, H, eps, 0, s)) return e;
+            pre = m->t0;
+        }
+        float* h0 = prenorm ? t->hs0 : m->hs[0];      // prenorm: m->hs[0] aliases posout, keep the dropped copy apart
+        if (int e = launch_dropout_fwd(pre, nullptr, h0, BT * H, 0, p, seed, DS_ENCODER_IN, s)) return e;
+    }
     for (int i = 0; i < c.num_layers; ++i) {
         const std::string b = "encoder/layers/" + std::to_string(i);
         LayerSave& l = t->layers[i];
-        const float* x = m->hs[i];
+        const float* x = (prenorm && i == 0) ? t->hs0 : m->hs[i];
         l.keep = sd_keep_host ? sd_keep_host[i] : 1.0f;
-        if (int e = launch_gemm(pf, x, H, 0, m->qkv_w[i], 3 * H, l.qkv, 3 * H, 0, m->qkv_b[i], nullptr, (int)BT, 3 * H, H, 1, 0, s)) return e;
+        const float* attn_in = x;
+        if (prenorm) {     // x + drop(attn(LN(x)))   (encoder.py:114-119)
+            if (int e = launch_layer_norm(pf, x, l.a, m->P(b + "/layer_norm/gamma"), m->P(b + "/layer_norm/beta"), BT, H, eps, 0, s)) return e;
+            attn_in = l.a;
+        }
+        if (int e = launch_gemm(pf, attn_in, H, 0, m->qkv_w[i], 3 * H, l.qkv, 3 * H, 0, m->qkv_b[i], nullptr, (int)BT, 3 * H, H, 1, 0, s)) return e;
         AttnTrain tr{p, seed, layer_stream(i, 0), l.lse};
         if (int e = launch_attention_train(pf, l.qkv, flen, l.ctx, B, T, H, c.num_heads, tr, s)) return e;
         // o = ctx Wo + bo;  t1 = dropout(o) + x   (encoder.py:116-119)
@@ -337,25 +356,37 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
                                 m->P(b + "/attention/out_proj/bias"), nullptr, (int)BT, H, H, 1, 0, s))
             return e;
         if (int e = launch_dropout_fwd(m->t0, x, l.t1, BT * H, 0, p, seed, layer_stream(i, 1), s)) return e;
-        if (int e = launch_layer_norm(pf, l.t1, l.t2, m->P(b + "/layer_norm/gamma"), m->P(b + "/layer_norm/beta"), BT, H, eps, 0, s)) return e;
+        // postnorm: t2 = LN1(t1) feeds the FFN and is its residual; prenorm: t2 = LN2(t1) feeds the FFN, t1 is the residual
+        const char* ln_a = prenorm ? "/final_layer_norm" : "/layer_norm";
+        if (int e = launch_layer_norm(pf, l.t1, l.t2, m->P(b + ln_a + "/gamma"), m->P(b + ln_a + "/beta"), BT, H, eps, 0, s)) return e;
+        const float* ffn_res = prenorm ? l.t1 : l.t2;
+        float* ffn_out = prenorm ? m->hs[i + 1] : l.t3;
         if (l.keep != 0.f) {
-            // u = t2 W1 + b1;  gd = dropout(GELU(u));  t3 = t2 + keep * (gd W2 + b2)   (encoder.py:127-130)
+            // u = t2 W1 + b1;  gd = dropout(GELU(u));  out = res + keep * (gd W2 + b2)   (encoder.py:127-130)
             if (int e = launch_gemm(pf, l.t2, H, 0, m->P(b + "/feed_forward/intermediate_dense/kernel"), F, l.u, F, 0,
                                     m->P(b + "/feed_forward/intermediate_dense/bias"), nullptr, (int)BT, F, H, 1, 0, s))
                 return e;
             if (int e = launch_dropout_fwd(l.u, nullptr, l.gd, BT * F, act, p, seed, layer_stream(i, 2), s)) return e;
-            if (int e = launch_gemm(pf, l.gd, F, 0, m->P(b + "/feed_forward/output_dense/kernel"), H, l.t3, H, 0,
-                                    m->P(b + "/feed_forward/output_dense/bias"), l.t2, (int)BT, H, F, 1, 0, s))
+            if (int e = launch_gemm(pf, l.gd, F, 0, m->P(b + "/feed_forward/output_dense/kernel"), H, ffn_out, H, 0,
+                                    m->P(b + "/feed_forward/output_dense/bias"), ffn_res, (int)BT, H, F, 1, 0, s))
                 return e;
         } else {
-            W2V2_HIP_CHECK(hipMemcpyAsync(l.t3, l.t2, (size_t)BT * H * 4, hipMemcpyDeviceToDevice, s));
+            W2V2_HIP_CHECK(hipMemcpyAsync(ffn_out, ffn_res, (size_t)BT * H * 4, hipMemcpyDeviceToDevice, s));
         }
-        if (int e = launch_layer_norm(pf, l.t3, m->hs[i + 1], m->P(b + "/final_layer_norm/gamma"),
-                                      m->P(b + "/final_layer_norm/beta"), BT, H, eps, 0, s))
-            return e;
+        if (!prenorm)
+            if (int e = launch_layer_norm(pf, l.t3, m->hs[i + 1], m->P(b + "/final_layer_norm/gamma"),
+                                          m->P(b + "/final_layer_norm/beta"), BT, H, eps, 0, s))
+                return e;
     }
-    // ---- head: Dropout -> lm_head (modeling.py:253-254) ----
-    if (int e = launch_dropout_fwd(m->hs[c.num_layers], nullptr, t->hdf, BT * H, 0, p, seed, DS_HEAD, s)) return e;
+    // ---- [prenorm: final encoder LN] -> Dropout -> lm_head (encoder.py:274-275, modeling.py:253-254) ----
+    const float* head_in = m->hs[c.num_layers];
+    if (prenorm) {
+        if (int e = launch_layer_norm(pf, m->hs[c.num_layers], m->enc_out, m->P("encoder/layer_norm/gamma"),
+                                      m->P("encoder/layer_norm/beta"), BT, H, eps, 0, s))
+            return e;
+        head_in = m->enc_out;
+    }
+    if (int e = launch_dropout_fwd(head_in, nullptr, t->hdf, BT * H, 0, p, seed, DS_HEAD, s)) return e;
     if (int e = launch_gemm(pf, t->hdf, H, 0, m->P("lm_head/kernel"), c.vocab_size, logits_out, c.vocab_size, 0,
                             m->P("lm_head/bias"), nullptr, (int)BT, c.vocab_size, H, 1, 0, s))
         return e;
@@ -397,10 +428,79 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     if (int e = weight_grad(m, t->hdf, dlogits, (int)BT, H, V, G("lm_head/kernel"), G("lm_head/bias"), s)) return e;
     if (!below_head) return W2V2_OK;            // stage 1 of the reference: only lm_head trains (main.py:210)
     float *dh = t->gh[0], *tmp = t->gh[1], *tmp2 = t->gh[2], *tmp3 = t->gh[3];
+    const bool prenorm = c.attention_norm_type == 1;
     if (int e = launch_gemm(pf, dlogits, V, 0, t->WlmT, H, tmp, H, 0, nullptr, nullptr, (int)BT, H, V, 1, 0, s)) return e;
-    if (int e = launch_dropout_bwd(nullptr, tmp, dh, BT * H, 0, p, seed, DS_HEAD, s)) return e;
+    if (!prenorm) {
+        if (int e = launch_dropout_bwd(nullptr, tmp, dh, BT * H, 0, p, seed, DS_HEAD, s)) return e;
+    } else {   // hdf = dropout(LN_enc(hs[N]))   (encoder.py:274-275)
+        if (int e = launch_dropout_bwd(nullptr, tmp, tmp2, BT * H, 0, p, seed, DS_HEAD, s)) return e;
+        float* dg = G("encoder/layer_norm/gamma");
+        float* db = G("encoder/layer_norm/beta");
+        if (int e = launch_ln_bwd(m->hs[c.num_layers], m->P("encoder/layer_norm/gamma"), tmp2, dh, dg ? dg : t->dummy,
+                                  db ? db : t->dummy + H, BT, H, eps, t->red_ws, s))
+            return e;
+    }
 
-    for (int i = c.num_layers - 1; i >= 0; --i) {
+    auto qkv_weight_grad = [&](const std::string& b, const float* attn_in) -> int {
+        // packed q|k|v projection: dW (H, 3H) -> the three (H, H) kernels, db (3H) -> the three biases
+        float* dWqkv = t->dwqkv;
+        float* dbqkv = dWqkv + (int64_t)3 * H * H;
+        if (int e = weight_grad(m, attn_in, t->g3h, (int)BT, H, 3 * H, dWqkv, dbqkv, s)) return e;
+        const char* names[3] = {"q_proj", "k_proj", "v_proj"};
+        for (int j = 0; j < 3; ++j) {
+            float* gw = G(b + "/attention/" + names[j] + "/kernel");
+            float* gb = G(b + "/attention/" + names[j] + "/bias");
+            if (gw)
+                W2V2_HIP_CHECK(hipMemcpy2DAsync(gw, (size_t)H * 4, dWqkv + j * H, (size_t)3 * H * 4, (size_t)H * 4, (size_t)H,
+                                                hipMemcpyDeviceToDevice, s));
+            if (gb) W2V2_HIP_CHECK(hipMemcpyAsync(gb, dbqkv + j * H, (size_t)H * 4, hipMemcpyDeviceToDevice, s));
+        }
+        return W2V2_OK;
+    };
+
+    for (int i = c.num_layers - 1; i >= 0 && prenorm; --i) {
+        // prenorm layer (encoder.py:111-134):  t1 = x + drop(attn(LN1(x)));  out = t1 + keep * FFN(LN2(t1))
+        const std::string b = "encoder/layers/" + std::to_string(i);
+        LayerSave& l = t->layers[i];
+        const float* x = i == 0 ? t->hs0 : m->hs[i];
+        float* dt1 = tmp3;
+        if (l.keep != 0.f) {
+            if (int e = weight_grad(m, l.gd, dh, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
+                                    G(b + "/feed_forward/output_dense/bias"), s))
+                return e;
+            if (int e = launch_gemm(pf, dh, H, 0, l.W2T, F, t->gf, F, 0, nullptr, nullptr, (int)BT, F, H, 1, 0, s)) return e;
+            if (int e = launch_dropout_bwd(l.u, t->gf, t->gf, BT * F, act, p, seed, layer_stream(i, 2), s)) return e;
+            if (int e = weight_grad(m, l.t2, t->gf, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
+                                    G(b + "/feed_forward/intermediate_dense/bias"), s))
+                return e;
+            if (int e = launch_gemm(pf, t->gf, F, 0, l.W1T, H, tmp, H, 0, nullptr, nullptr, (int)BT, H, F, 1, 0, s)) return e;
+            float* dg2 = G(b + "/final_layer_norm/gamma");
+            float* db2 = G(b + "/final_layer_norm/beta");
+            if (int e = launch_ln_bwd(l.t1, m->P(b + "/final_layer_norm/gamma"), tmp, tmp2, dg2 ? dg2 : t->dummy,
+                                      db2 ? db2 : t->dummy + H, BT, H, eps, t->red_ws, s))
+                return e;
+            if (int e = launch_axpby(dh, tmp2, dt1, BT * H, 1.f, 1.f, s)) return e;      // residual + LN2 branch
+        } else {
+            W2V2_HIP_CHECK(hipMemcpyAsync(dt1, dh, (size_t)BT * H * 4, hipMemcpyDeviceToDevice, s));
+        }
+        float* d_o = tmp;
+        if (int e = launch_dropout_bwd(nullptr, dt1, d_o, BT * H, 0, p, seed, layer_stream(i, 1), s)) return e;
+        if (int e = weight_grad(m, l.ctx, d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), G(b + "/attention/out_proj/bias"), s)) return e;
+        float* dctx = tmp2;
+        if (int e = launch_gemm(pf, d_o, H, 0, l.WoT, H, dctx, H, 0, nullptr, nullptr, (int)BT, H, H, 1, 0, s)) return e;
+        AttnTrain tr{p, seed, layer_stream(i, 0), l.lse};
+        if (int e = launch_attention_bwd(pf, l.qkv, flen, l.ctx, dctx, t->g3h, t->dvec, B, T, H, c.num_heads, tr, s)) return e;
+        if (int e = qkv_weight_grad(b, l.a)) return e;
+        if (int e = launch_gemm(pf, t->g3h, 3 * H, 0, l.WqkvT, H, tmp, H, 0, nullptr, nullptr, (int)BT, H, 3 * H, 1, 0, s)) return e;
+        float* dg1 = G(b + "/layer_norm/gamma");
+        float* db1 = G(b + "/layer_norm/beta");
+        if (int e = launch_ln_bwd(x, m->P(b + "/layer_norm/gamma"), tmp, tmp2, dg1 ? dg1 : t->dummy, db1 ? db1 : t->dummy + H, BT, H,
+                                  eps, t->red_ws, s))
+            return e;
+        if (int e = launch_axpby(dt1, tmp2, dh, BT * H, 1.f, 1.f, s)) return e;          // residual + LN1 branch
+    }
+
+    for (int i = c.num_layers - 1; i >= 0 && !prenorm; --i) {
         const std::string b = "encoder/layers/" + std::to_string(i);
         LayerSave& l = t->layers[i];
         // hs[i+1] = LN(t3)
@@ -442,28 +542,16 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         if (int e = launch_gemm(pf, d_o, H, 0, l.WoT, H, dctx, H, 0, nullptr, nullptr, (int)BT, H, H, 1, 0, s)) return e;
         AttnTrain tr{p, seed, layer_stream(i, 0), l.lse};
         if (int e = launch_attention_bwd(pf, l.qkv, flen, l.ctx, dctx, t->g3h, t->dvec, B, T, H, c.num_heads, tr, s)) return e;
-        // packed q|k|v projection: dW (H, 3H) -> the three (H, H) kernels, db (3H) -> the three biases
-        {
-            float* dWqkv = t->dwqkv;
-            float* dbqkv = dWqkv + (int64_t)3 * H * H;
-            if (int e = weight_grad(m, m->hs[i], t->g3h, (int)BT, H, 3 * H, dWqkv, dbqkv, s)) return e;
-            const char* names[3] = {"q_proj", "k_proj", "v_proj"};
-            for (int j = 0; j < 3; ++j) {
-                float* gw = G(b + "/attention/" + names[j] + "/kernel");
-                float* gb = G(b + "/attention/" + names[j] + "/bias");
-                if (gw)
-                    W2V2_HIP_CHECK(hipMemcpy2DAsync(gw, (size_t)H * 4, dWqkv + j * H, (size_t)3 * H * 4, (size_t)H * 4, (size_t)H,
-                                                    hipMemcpyDeviceToDevice, s));
-                if (gb) W2V2_HIP_CHECK(hipMemcpyAsync(gb, dbqkv + j * H, (size_t)H * 4, hipMemcpyDeviceToDevice, s));
-            }
-        }
+        if (int e = qkv_weight_grad(b, m->hs[i])) return e;
         // dx = dqkv Wqkv^T + dt1 (residual)
         if (int e = launch_gemm(pf, t->g3h, 3 * H, 0, l.WqkvT, H, dh, H, 0, nullptr, dt1, (int)BT, H, 3 * H, 1, 0, s)) return e;
     }
-    // ---- encoder input: hs[0] = dropout(LN(posout)) ----
-    if (int e = launch_dropout_bwd(nullptr, dh, tmp, BT * H, 0, p, seed, DS_ENCODER_IN, s)) return e;
+    // ---- encoder input: postnorm hs[0] = dropout(LN(posout));  prenorm hs0 = dropout(posout) ----
     float* dpos = tmp2;
-    {
+    if (prenorm) {
+        if (int e = launch_dropout_bwd(nullptr, dh, dpos, BT * H, 0, p, seed, DS_ENCODER_IN, s)) return e;
+    } else {
+        if (int e = launch_dropout_bwd(nullptr, dh, tmp, BT * H, 0, p, seed, DS_ENCODER_IN, s)) return e;
         float* dg = G("encoder/layer_norm/gamma");
         float* db = G("encoder/layer_norm/beta");
         if (int e = launch_ln_bwd(m->posout, m->P("encoder/layer_norm/gamma"), tmp, dpos, dg ? dg : t->dummy, db ? db : t->dummy + H, BT, H,

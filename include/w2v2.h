@@ -132,8 +132,8 @@ int w2v2_ctc_loss(const float* logits_dev, int32_t B, int32_t T, int32_t V,
 
 /* ---- the training step (reference src/main.py:136-259) --------
  * Replaces what Keras' train_step does around the forward: training-mode forward, backward of every
- * trainable variable, Adam.  Postnorm (base) transformer only for now; the conv feature extractor
- * has no backward (the reference freezes it, main.py:234-237) -- mark it non-trainable first.
+ * trainable variable, Adam.  Postnorm (base) and prenorm (robust / xlsr) transformers; the conv feature
+ * extractor has no backward (the reference freezes it, main.py:234-237) -- mark it non-trainable first.
  *
  * w2v2_train_forward: Wav2Vec2ForCTC.call(training=True): Dropout(p) at every Dropout layer
  *   (feature_extractor.py:95; encoder.py:42-44,118,128,270; modeling.py:253) with masks from a

@@ -45,7 +45,7 @@ def conv_stack(config, w, wave):
 
 def train_forward(config, w, wave, attention_mask=None, p=0.0, seed=0, spec_mask=None, sd_keep=None):
     """w: {local_name: torch.float64 tensor (requires_grad for trainables)}.  Returns logits (B, T, V)."""
-    assert config.attention_norm_type == "postnorm"
+    pre = config.attention_norm_type == "prenorm"
     c = config
     eps = c.layer_norm_eps
     x0 = conv_stack(c, w, wave)
@@ -74,7 +74,8 @@ def train_forward(config, w, wave, attention_mask=None, p=0.0, seed=0, spec_mask
     if K % 2 == 0:
         y = y[:, :-1]
     x = x + _gelu(y)
-    x = _ln(x, w["encoder/layer_norm/gamma"], w["encoder/layer_norm/beta"], eps)
+    if not pre:                                                      # encoder.py:267-268
+        x = _ln(x, w["encoder/layer_norm/gamma"], w["encoder/layer_norm/beta"], eps)
     x = _drop(x, p, seed, V.DS_ENCODER_IN)
     for i in range(c.num_layers):
         b = f"encoder/layers/{i}"
@@ -82,8 +83,10 @@ def train_forward(config, w, wave, attention_mask=None, p=0.0, seed=0, spec_mask
         def proj(name, t):
             return (t @ w[f"{b}/attention/{name}/kernel"] + w[f"{b}/attention/{name}/bias"]).reshape(B, T, h, d).transpose(1, 2)
 
-        q = proj("q_proj", x) * d ** -0.5
-        k, v = proj("k_proj", x), proj("v_proj", x)
+        res = x
+        a_in = _ln(x, w[f"{b}/layer_norm/gamma"], w[f"{b}/layer_norm/beta"], eps) if pre else x   # encoder.py:114-115
+        q = proj("q_proj", a_in) * d ** -0.5
+        k, v = proj("k_proj", a_in), proj("v_proj", a_in)
         s = q @ k.transpose(-1, -2)
         if add_mask is not None:
             s = s + add_mask
@@ -91,15 +94,20 @@ def train_forward(config, w, wave, attention_mask=None, p=0.0, seed=0, spec_mask
         pr = _drop(pr, p, seed, V.layer_stream(i, 0))
         ctx = (pr @ v).transpose(1, 2).reshape(B, T, H)
         o = ctx @ w[f"{b}/attention/out_proj/kernel"] + w[f"{b}/attention/out_proj/bias"]
-        x = _drop(o, p, seed, V.layer_stream(i, 1)) + x
-        x = _ln(x, w[f"{b}/layer_norm/gamma"], w[f"{b}/layer_norm/beta"], eps)
+        x = _drop(o, p, seed, V.layer_stream(i, 1)) + res
+        if not pre:
+            x = _ln(x, w[f"{b}/layer_norm/gamma"], w[f"{b}/layer_norm/beta"], eps)
         keep_l = 1.0 if sd_keep is None else float(sd_keep[i])
         if keep_l != 0.0:
-            u = x @ w[f"{b}/feed_forward/intermediate_dense/kernel"] + w[f"{b}/feed_forward/intermediate_dense/bias"]
+            f_in = _ln(x, w[f"{b}/final_layer_norm/gamma"], w[f"{b}/final_layer_norm/beta"], eps) if pre else x
+            u = f_in @ w[f"{b}/feed_forward/intermediate_dense/kernel"] + w[f"{b}/feed_forward/intermediate_dense/bias"]
             g = _drop(_gelu(u), p, seed, V.layer_stream(i, 2))
             f = g @ w[f"{b}/feed_forward/output_dense/kernel"] + w[f"{b}/feed_forward/output_dense/bias"]
             x = x + keep_l * f
-        x = _ln(x, w[f"{b}/final_layer_norm/gamma"], w[f"{b}/final_layer_norm/beta"], eps)
+        if not pre:
+            x = _ln(x, w[f"{b}/final_layer_norm/gamma"], w[f"{b}/final_layer_norm/beta"], eps)
+    if pre:                                                          # encoder.py:274-275
+        x = _ln(x, w["encoder/layer_norm/gamma"], w["encoder/layer_norm/beta"], eps)
     x = _drop(x, p, seed, V.DS_HEAD)
     return x @ w["lm_head/kernel"] + w["lm_head/bias"]
 

@@ -150,3 +150,41 @@ def test_model_fails_loudly_without_gpu():
         wav2vec2.Wav2Vec2ForCTC(Wav2Vec2Config(**H.TINY))
     with pytest.raises(ValueError):
         wav2vec2.Wav2Vec2ForCTC({"hidden_size": 768})
+
+
+# ---- input pipeline contract (reference data_utils.py:52-78) -------------------------------------
+def test_batchify_normalises_then_pads():
+    from wav2vec2.data_utils import attention_mask_for, batchify
+    rng = np.random.default_rng(0)
+    a, b = rng.normal(3, 2, 1000).astype(np.float32), rng.normal(-1, 0.5, 5000).astype(np.float32)
+    tok = Wav2Vec2Processor(is_tokenizer=True, vocab_path=os.path.join(H.GOLDEN, "vocab.json"))
+    speech, labels = batchify([a, b], ["hello world", "a-b"], audio_maxlen=3000, labels_maxlen=8, tokenizer=tok)
+    assert speech.shape == (2, 3000) and labels.shape == (2, 8) and labels.dtype == np.int32
+    # normalised BEFORE padding: the valid part has zero mean / unit variance, the pad is exact zeros
+    assert abs(speech[0, :1000].mean()) < 1e-5 and abs(speech[0, :1000].var() - 1) < 1e-3
+    assert not speech[0, 1000:].any()
+    # truncation keeps the first audio_maxlen samples of the normalised long clip
+    full = Wav2Vec2Processor(is_tokenizer=False)(b)
+    assert np.allclose(speech[1], full[:3000])
+    assert labels[0].tolist() == [11, 5, 15, 15, 8, 4, 18, 8] and labels[1].tolist() == [7, 4, 24, 0, 0, 0, 0, 0]
+    m = attention_mask_for([1000, 5000], 3000)
+    assert m.sum(1).tolist() == [1000, 3000]
+
+
+def test_spec_augment_mask_recipe():
+    from wav2vec2.spec_augment import compute_mask_indices
+    m = compute_mask_indices((8, 768), 0.05, 10, rng=np.random.RandomState(0))
+    assert m.shape == (8, 768) and m.dtype == np.uint8
+    # 0.05 * 768 / 10 = 3.84 -> 3 or 4 spans of 10 frames per row (may overlap), same count for every row
+    assert all(10 <= r <= 40 for r in m.sum(1))
+    m2 = compute_mask_indices((2, 12), 0.0, 2, rng=np.random.RandomState(0))    # min_masks = 2 always applies
+    assert all(2 <= r <= 4 for r in m2.sum(1))
+    with pytest.raises(ValueError):
+        compute_mask_indices((2, 5), 0.5, 10)
+
+
+def test_dropout_hash_statistics():
+    keep = V.dropout_keep(seed=12345, stream=V.layer_stream(3, 0), n=200000, p=0.1)
+    assert abs(keep.mean() - 0.9) < 0.005
+    assert not np.array_equal(keep, V.dropout_keep(12345, V.layer_stream(3, 1), 200000, 0.1))
+    assert np.array_equal(keep, V.dropout_keep(12345, V.layer_stream(3, 0), 200000, 0.1))

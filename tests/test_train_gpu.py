@@ -181,6 +181,28 @@ def test_gradients_match_autograd_tiny(env, p, use_spec, use_sd):
     assert not np.any(tr.gradient("feature_extractor/conv_layers/3/conv/kernel"))
 
 
+def test_gradients_match_autograd_prenorm_with_mask(env):
+    """Robust / xlsr flavour: prenorm transformer, LayerNorm conv stack with bias, attention mask
+    (padded frames zeroed before the positional conv, key-padding mask in attention)."""
+    import wav2vec2
+    g = H.golden("tiny_robust")
+    m, cfg, w = build("tiny_robust", 4000)
+    mask = g["attention_mask"].astype(np.int32)
+    loss_fn = wav2vec2.CTCLoss(cfg, g["wave"].shape, division_factor=2)
+    tr = wav2vec2.Trainer(m, loss_fn, dropout=0.1, apply_spec_augment=False, seed=3)
+    spec = compute_mask_indices((2, 12), 0.3, 2, rng=np.random.RandomState(2))
+    labels = np.array([[3, 4, 0], [5, 0, 0]], np.int32)
+    logits = tr.forward(g["wave"], attention_mask=mask, spec_mask=spec, step_seed=99)
+    nll, dlog = loss_fn.per_sample(labels, logits, with_grad=True)
+    tr.backward(dlog)
+    loss, ref_nll, ref_logits, ref_grads = TT.loss_and_grads(cfg, w, g["wave"], labels, attention_mask=mask, p=0.1, seed=99,
+                                                             spec_mask=spec, division_factor=2)
+    assert H.max_err(logits.cpu().numpy(), ref_logits) < 2e-5
+    assert np.allclose(nll.cpu().numpy(), ref_nll, atol=1e-3)
+    worst = grads_close(tr, ref_grads)
+    print("worst relative gradient error (prenorm + mask)", worst)
+
+
 def test_gradients_match_autograd_base_dims(env):
     """Real base dimensions (768 / 12 heads / 3072 / 16 x 48-channel groups / 128 taps) on a short input."""
     import wav2vec2
