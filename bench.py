@@ -204,7 +204,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.mode == "forward":
             res["cpu_baseline"] = cpu_baseline(cfg, weights, L)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -54,3 +54,4 @@ struct w2v2_model {
 int w2v2_ensure_workspace(w2v2_model* m, int B, int64_t L);
 // implemented in w2v2_train.hip
 void w2v2_train_destroy(w2v2_model* m);
+void w2v2_train_invalidate(w2v2_model* m);

@@ -306,6 +306,7 @@ int w2v2_set_param(w2v2_model* m, const char* name, const float* host_src, const
     W2V2_HIP_CHECK(hipMemcpy(p.dev, host_src, (size_t)p.numel * sizeof(float), hipMemcpyHostToDevice));
     p.set = true;
     m->finalized = false;
+    w2v2_train_invalidate(m);
     return W2V2_OK;
 }
 

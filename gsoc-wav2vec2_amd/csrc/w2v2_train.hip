@@ -73,6 +73,11 @@ void w2v2_train_destroy(w2v2_model* m) {
     m->train = nullptr;
 }
 
+// a variable changed outside the optimizer (w2v2_set_param): the transposed kernel copies are stale
+void w2v2_train_invalidate(w2v2_model* m) {
+    if (m && m->train) m->train->transposes_fresh = false;
+}
+
 static TrainState* get_state(w2v2_model* m) {
     if (!m->train) {
         TrainState* t = new TrainState();

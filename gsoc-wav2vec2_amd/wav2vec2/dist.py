@@ -20,7 +20,8 @@ def init(backend="nccl", device=None):
     """Initialise the default process group from the launcher's env (MASTER_ADDR defaults to 127.0.0.1)."""
     import torch.distributed as dist
     world, rank, _ = env_world()
-    if world == 1 or dist.is_initialized():
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ      # under torch.distributed.run, even with 1 rank
+    if dist.is_initialized() or (world == 1 and not launched):
         return world, rank
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
