@@ -35,28 +35,83 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 PEAK_HBM_GBS = 8000.0
 
 
-def cpu_baseline(cfg, weights, L, max_seconds=30.0):
-    """CPU restatement of the reference path (oracle/, numpy+BLAS on all host cores), B=1."""
-    import numpy as np
+_CPU_WORKER = r"""
+import os, sys, time
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "gsoc-wav2vec2_amd"))
+from threadpoolctl import threadpool_limits
+from oracle import w2v2_oracle as O
+from wav2vec2 import variables as V
+from wav2vec2.config import Wav2Vec2Config
+cfg = Wav2Vec2Config(); w = V.seeded_weights(cfg, seed=0)
+x = V.hash_normal("bench/cpu", {L}, {seed}).reshape(1, {L})
+with threadpool_limits(limits={nt}):
+    O.ctc_forward(cfg, w, x)
+    t0 = time.perf_counter()
+    for _ in range({reps}):
+        O.ctc_forward(cfg, w, x)
+    print("CPU_WORKER_SECONDS", time.perf_counter() - t0, flush=True)
+"""
+
+
+def cpu_baseline(cfg, weights, L):
+    """CPU restatement of the reference path (oracle/: numpy + OpenBLAS + threaded ufuncs) on this box's host
+    cores.  OpenBLAS at its default thread count is SLOWER than at 8-16 threads for these shapes, so the BLAS
+    width is probed first; then as many such workers as the physical cores allow (at most 8) run concurrently,
+    one utterance each (utterances are independent), as fresh subprocesses with a hard timeout -- never a
+    fork of this GPU process.  The aggregate is the baseline; the single-worker figure is reported too."""
+    import subprocess
+    from threadpoolctl import threadpool_limits
     from oracle import w2v2_oracle as O
     from wav2vec2 import variables as V
     x = V.hash_normal("bench/cpu", L, 0).reshape(1, L)
-    O.ctc_forward(cfg, weights, x)                     # warm-up (BLAS threads, page-in)
-    times = []
-    t_start = time.perf_counter()
-    while len(times) < 5 and (time.perf_counter() - t_start) < max_seconds:
-        t0 = time.perf_counter()
-        O.ctc_forward(cfg, weights, x)
-        times.append(time.perf_counter() - t0)
-    best = min(times)
+    ncpu = os.cpu_count() or 1
+    best_nt, best_t = 1, float("inf")
+    for nt in (8, 16, 32):
+        if nt > ncpu:
+            continue
+        with threadpool_limits(limits=nt):
+            O.ctc_forward(cfg, weights, x)
+            t0 = time.perf_counter()
+            O.ctc_forward(cfg, weights, x)
+            dt = time.perf_counter() - t0
+        if dt < best_t:
+            best_nt, best_t = nt, dt
+    single = L / SAMPLE_RATE / best_t
+    procs = max(1, min(8, (ncpu // 2) // best_nt))     # physical cores / BLAS width, at most 8 workers
+    reps, agg, used = 2, single, 1
+    if procs > 1:
+        children = []
+        try:
+            for i in range(procs):
+                code = _CPU_WORKER.format(root=ROOT, L=L, seed=i, nt=best_nt, reps=reps)
+                children.append(subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE,
+                                                 stderr=subprocess.DEVNULL, text=True))
+            times = []
+            deadline = time.perf_counter() + 90.0
+            for ch in children:
+                out, _ = ch.communicate(timeout=max(1.0, deadline - time.perf_counter()))
+                for line in out.splitlines():
+                    if line.startswith("CPU_WORKER_SECONDS"):
+                        times.append(float(line.split()[1]))
+            if len(times) == procs:
+                agg, used = procs * reps * L / SAMPLE_RATE / max(times), procs
+        except Exception:  # noqa: BLE001 -- keep the single-worker figure
+            pass
+        finally:
+            for ch in children:
+                if ch.poll() is None:
+                    ch.kill()
+    if agg < single:
+        agg, used = single, 1
     return {
-        "value": round(L / SAMPLE_RATE / best, 3),
+        "value": round(agg, 3),
         "unit": "audio-seconds/s",
-        "cores": os.cpu_count(),
+        "cores": used * best_nt,
         "kind": "port",
         "sample": f"numpy oracle (CPU restatement of the reference path; TensorFlow not run), wav2vec2-base fp32, "
-                  f"B=1 x {L} samples, best of {len(times)} after 1 warm-up",
-        "median_s": round(float(np.median(times)), 4),
+                  f"{used} concurrent worker(s) x {reps if used > 1 else 1} forward(s) of 1 x {L} samples, {best_nt} BLAS threads "
+                  f"each (probed 8/16/32); single worker {single:.1f} audio-s/s",
+        "host_cpus": ncpu,
     }
 
 
@@ -139,8 +194,10 @@ def main():
     for _ in range(args.warmup):
         out = step()
     barrier()
+    # Timed region: HIP events bracket ONLY the dominant kernel family (the roofline object); an event pair
+    # costs ~7 us of stream time, so instrumenting all ~150 launches per step would tax the headline by ~3 %.
     if not args.no_profile:
-        model.profile(True)
+        model.profile(True, families=["gemm_f32"])
         model.profile_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -149,6 +206,16 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = model.profile_read() if not args.no_profile else {}
     model.profile(False)
+    # Per-family breakdown: two extra, untimed steps with every family instrumented.
+    prof_all = {}
+    if not args.no_profile:
+        model.profile(True)
+        model.profile_reset()
+        for _ in range(2):
+            out = step()
+        barrier()
+        prof_all = model.profile_read()
+        model.profile(False)
     if args.mode == "train":
         assert bool(torch.isfinite(out).all()), "training loss is not finite"
     else:
@@ -189,15 +256,16 @@ def main():
                 "launches_per_step": gm["launches"] // max(1, args.steps),
                 "avg_launch_ms": round(gm["ms"] / max(1, gm["launches"]), 4),
             }
-            tot = sum(v["ms"] for v in prof.values())
+            tot = sum(v["ms"] for v in prof_all.values())
             res["families"] = {
-                k: {"ms_per_step": round(v["ms"] / args.steps, 3),
+                k: {"ms_per_step": round(v["ms"] / 2, 3),
                     "share": round(v["ms"] / tot, 4) if tot > 0 else 0.0,
                     "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0,
                     "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0.0}
-                for k, v in prof.items() if v["launches"] > 0}
+                for k, v in prof_all.items() if v["launches"] > 0}
+            res["families_note"] = "per-family breakdown from 2 extra untimed steps with every family instrumented"
             # whole-forward algorithmic rate: 235.56 GFLOP per 246000-sample utterance scales with T
-            flops_step = sum(v["flops"] for k, v in prof.items() if k in ("gemm_f32", "pos_conv", "attention", "conv0_apply")) / args.steps
+            flops_step = sum(v["flops"] for k, v in prof_all.items() if k in ("gemm_f32", "pos_conv", "attention", "conv0_apply")) / 2
             res["forward_tflops"] = round(flops_step * world / (elapsed / args.steps) / 1e12, 2)
         if args.mode == "train":
             res["final_loss"] = round(float(out), 4)

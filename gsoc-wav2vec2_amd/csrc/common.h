@@ -53,6 +53,7 @@ struct Profiler;
 Profiler* profiler_create();
 void profiler_destroy(Profiler*);
 void profiler_enable(Profiler*, bool on);
+void profiler_set_mask(Profiler*, unsigned family_mask);   // bit f = record family f; 0 = all
 bool profiler_enabled(const Profiler*);
 void profiler_reset(Profiler*);
 // returns a token (>=0) to pass to profiler_end, or -1 when disabled

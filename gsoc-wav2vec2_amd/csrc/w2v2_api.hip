@@ -43,6 +43,7 @@ struct ProfRec {
 };
 struct Profiler {
     bool enabled = false;
+    unsigned mask = 0xFFFFFFFFu;    // families that get an event pair
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> pool;   // recycled events
 };
@@ -61,6 +62,7 @@ void profiler_destroy(Profiler* p) {
     delete p;
 }
 void profiler_enable(Profiler* p, bool on) { p->enabled = on; }
+void profiler_set_mask(Profiler* p, unsigned mask) { p->mask = mask ? mask : 0xFFFFFFFFu; }
 bool profiler_enabled(const Profiler* p) { return p->enabled; }
 static hipEvent_t prof_event(Profiler* p) {
     if (!p->pool.empty()) {
@@ -73,7 +75,7 @@ static hipEvent_t prof_event(Profiler* p) {
     return e;
 }
 int profiler_begin(Profiler* p, int family, double flops, double bytes, hipStream_t s) {
-    if (!p || !p->enabled) return -1;
+    if (!p || !p->enabled || !((p->mask >> family) & 1u)) return -1;
     ProfRec r{family, flops, bytes, prof_event(p), prof_event(p)};
     (void)hipEventRecord(r.e0, s);
     p->recs.push_back(r);
@@ -523,6 +525,11 @@ int w2v2_copy_activation(w2v2_model* m, const char* name, float* host_dst, int64
 int w2v2_profile_enable(w2v2_model* m, int enable) {
     W2V2_REQUIRE(m, "profile_enable: null model");
     profiler_enable(m->prof, enable != 0);
+    return W2V2_OK;
+}
+int w2v2_profile_families(w2v2_model* m, uint32_t family_mask) {
+    W2V2_REQUIRE(m, "profile_families: null model");
+    profiler_set_mask(m->prof, family_mask);
     return W2V2_OK;
 }
 int w2v2_profile_num_families(void) { return FAM_COUNT; }

@@ -143,6 +143,12 @@ class TFKerasModel:
         for k, v in weights.items():
             self._set_param(V.local_name_from_tf(k), v)
 
+    def load_hf_state_dict(self, state_dict):
+        """Load a HuggingFace-PyTorch Wav2Vec2 ``state_dict`` through the reference's HF -> TF name / layout
+        map (src/convert_torch_to_tf.py:12-44,110-117) -- the counterpart of ``get_tf_pretrained_model``
+        without TensorFlow.  Keys missing from the dict raise ``KeyError``."""
+        self.set_weights(V.from_hf_state_dict(state_dict, self.config, with_lm_head=self._with_lm_head))
+
     def get_weights(self):
         return {n: self._get_param(n, s) for n, (s, _) in self._specs.items()}
 
@@ -271,7 +277,20 @@ class TFKerasModel:
                                                N.current_stream()), "w2v2_copy_activation")
         return out
 
-    def profile(self, enable=True):
+    def profile(self, enable=True, families=None):
+        """Bracket kernel launches with HIP events; `families` (names as in profile_read) limits the
+        instrumentation to those kernel families, None = all."""
+        mask = 0
+        if families:
+            names = []
+            for i in range(self._lib.w2v2_profile_num_families()):
+                nm = C.c_char_p()
+                n, a, b, c = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+                N.check(self._lib.w2v2_profile_read(self._handle, i, C.byref(nm), C.byref(n), C.byref(a), C.byref(b), C.byref(c)))
+                names.append(nm.value.decode())
+            for f in families:
+                mask |= 1 << names.index(f)
+        N.check(self._lib.w2v2_profile_families(self._handle, mask), "w2v2_profile_families")
         N.check(self._lib.w2v2_profile_enable(self._handle, int(enable)), "w2v2_profile_enable")
 
     def profile_reset(self):

@@ -169,6 +169,10 @@ int w2v2_copy_activation(w2v2_model* m, const char* name, float* host_dst,
  * launch count, total milliseconds, algorithmic FLOPs and algorithmic bytes
  * summed over the recorded launches; w2v2_profile_reset clears the record. */
 int w2v2_profile_enable(w2v2_model* m, int enable);
+/* Restrict the event pairs to some families (bit i = family index i of w2v2_profile_read; 0 = all):
+ * an event pair costs ~7 us of stream time, so timing ONLY the dominant family keeps the timed region
+ * of a benchmark within 1 % of the un-instrumented run. */
+int w2v2_profile_families(w2v2_model* m, uint32_t family_mask);
 int w2v2_profile_num_families(void);
 int w2v2_profile_read(w2v2_model* m, int index, const char** name, int64_t* launches,
                       double* total_ms, double* flops, double* bytes);

@@ -224,3 +224,15 @@ def test_long_form_480000_vs_oracle(torch_mod):
     err = H.max_err(got, ref)
     report("base_480000/logits_vs_oracle_f32", err)
     assert err < H.ATOL_AIM
+
+
+def test_load_hf_state_dict_roundtrip(torch_mod):
+    """convert_torch_to_tf.py's job without TF: HF-layout tensors in, TF-layout variables out."""
+    g = H.golden("tiny_base")
+    m, cfg = build("tiny_base")
+    ref = m(g["wave"]).numpy()
+    sd = V.to_hf_state_dict(H.case_weights("tiny_base"))          # HF keys / layouts (new weight-norm names)
+    m2, _ = build("tiny_base")
+    m2.set_weights({k: np.zeros_like(v) for k, v in H.case_weights("tiny_base").items()})
+    m2.load_hf_state_dict({k: torch_mod.from_numpy(v) for k, v in sd.items()})
+    assert np.array_equal(m2(g["wave"]).numpy(), ref)
