@@ -139,6 +139,9 @@ def main():
     ap.add_argument("--samples", type=int, default=246000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--model", choices=["base", "large-robust"], default="base",
+                    help="base = wav2vec2-base (the headline); large-robust = 24L/1024d prenorm, LayerNorm convs, conv bias, "
+                         "attention mask (BASELINE configs[3] / [4] shapes, e.g. --batch 16 --samples 480000)")
     ap.add_argument("--mode", choices=["forward", "train"], default="forward",
                     help="forward = BASELINE configs[1] (the headline metric); train = one CTC fine-tune step "
                          "(BASELINE configs[2] shape, fp32: forward + CTC + backward + gradient all-reduce + Adam)")
@@ -159,7 +162,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     D.init(backend="nccl", device=dev)        # RCCL; no-op for a single process
 
-    cfg = wav2vec2.Wav2Vec2Config()
+    cfg = wav2vec2.Wav2Vec2Config() if args.model == "base" else wav2vec2.RobustWav2Vec2Config()
     weights = V.seeded_weights(cfg, seed=0)
     model = wav2vec2.Wav2Vec2ForCTC(cfg, input_shape=(args.batch, args.samples))
     model.set_weights(weights)
@@ -169,6 +172,7 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     x = torch.randn((B, L), generator=gen, device=dev, dtype=torch.float32)   # resident in HBM
+    amask = torch.ones((B, L), device=dev, dtype=torch.int32) if cfg.is_robust else None   # robust models take a mask
 
     def barrier():
         D.barrier(sync_device=torch.cuda.synchronize)
@@ -186,10 +190,10 @@ def main():
         trainer = wav2vec2.Trainer(model, wav2vec2.CTCLoss(cfg, (B, L), division_factor=world * B), learning_rate=1e-4, seed=rank)
 
         def step():
-            return trainer.step(x, labels_dev)
+            return trainer.step(x, labels_dev, attention_mask=amask)
     else:
         def step():
-            return model(x)
+            return model(x, attention_mask=amask)
 
     for _ in range(args.warmup):
         out = step()
@@ -226,8 +230,8 @@ def main():
     if rank == 0:
         audio_s = world * B * L / SAMPLE_RATE * args.steps
         res = {
-            "metric": "audio-seconds/s (wav2vec2-base forward, 246000-sample pad)" if args.mode == "forward"
-                      else "audio-seconds/s (wav2vec2-base CTC fine-tune step, 246000-sample pad)",
+            "metric": f"audio-seconds/s (wav2vec2-{args.model} forward, {L}-sample pad)" if args.mode == "forward"
+                      else f"audio-seconds/s (wav2vec2-{args.model} CTC fine-tune step, {L}-sample pad)",
             "value": round(audio_s / elapsed, 2),
             "unit": "audio-seconds/s",
             "n_gpus": world,
@@ -239,10 +243,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": (f"wav2vec2-base fp32 forward-only, batch={B}x{L} samples per GPU (BASELINE configs[1])"
+            "config": {"workload": (f"wav2vec2-{args.model} fp32 forward-only, batch={B}x{L} samples per GPU"
+                                    + (" (BASELINE configs[1])" if (args.model, B, L) == ("base", 32, 246000) else "")
                                     if args.mode == "forward" else
-                                    f"wav2vec2-base CTC fine-tune step in fp32 (conv stack frozen, dropout 0.1, spec-augment, "
-                                    f"Adam), batch={B}x{L} per GPU (BASELINE configs[2] shape; fp32, not bf16)"),
+                                    f"wav2vec2-{args.model} CTC fine-tune step in fp32 (conv stack frozen, dropout 0.1, spec-augment, "
+                                    f"Adam), batch={B}x{L} per GPU (BASELINE configs[2]/[4] shapes are bf16; this is fp32)"),
                        "global_batch": world * B, "samples": L, "frames": T, "parallelism": f"dp{world}"},
         }
         if prof:
@@ -269,7 +274,7 @@ def main():
             res["forward_tflops"] = round(flops_step * world / (elapsed / args.steps) / 1e12, 2)
         if args.mode == "train":
             res["final_loss"] = round(float(out), 4)
-        if world == 1 and not args.no_cpu_baseline and args.mode == "forward":
+        if world == 1 and not args.no_cpu_baseline and args.mode == "forward" and args.model == "base":
             res["cpu_baseline"] = cpu_baseline(cfg, weights, L)
         print(json.dumps(res), flush=True)
     if dist.is_initialized():

@@ -40,7 +40,8 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "w2v2.h"), __file__]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps = sources() + headers + [os.path.join(INCLUDE, "w2v2.h"), __file__]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -15,18 +15,30 @@ enum DropStream : uint32_t {
 };
 
 #ifdef __HIPCC__
-// uniform [0, 1) with 24-bit resolution from (seed, stream, idx): splitmix64 finaliser.  The same
-// integer function as wav2vec2/variables.py::dropout_uniform.
-__device__ __forceinline__ float dropout_u01(uint64_t seed, uint32_t stream, uint64_t idx) {
-    uint64_t z = idx * 0x2545F4914F6CDD1DULL + (seed ^ ((uint64_t)stream * 0x9E3779B97F4A7C15ULL));
-    z += 0x9E3779B97F4A7C15ULL;
+// keep(seed, stream, idx, p): counter-based hash, 32-bit arithmetic only (one VALU op per step; the earlier
+// 64-bit splitmix cost ~40 VALU ops per element and made the attention kernels VALU-heavy).
+//   (k1, k2) = two 32-bit halves of splitmix64(seed ^ stream * GOLD)        -- loop-invariant
+//   h = lowbias32(lo32(idx) ^ k1);  h = lowbias32(h + hi32(idx) * 0x9E3779B1 + k2);  keep = h >= floor(p * 2^32)
+// The same integer function as wav2vec2/variables.py::dropout_keep.
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint64_t dropout_key(uint64_t seed, uint32_t stream) {
+    uint64_t z = (seed ^ ((uint64_t)stream * 0x9E3779B97F4A7C15ULL)) + 0x9E3779B97F4A7C15ULL;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    z ^= z >> 31;
-    return (float)(z >> 40) * (1.0f / 16777216.0f);
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint32_t dropout_hash(uint64_t key, uint64_t idx) {
+    uint32_t h = lowbias32((uint32_t)idx ^ (uint32_t)key);
+    return lowbias32(h + (uint32_t)(idx >> 32) * 0x9E3779B1u + (uint32_t)(key >> 32));
+}
+__device__ __forceinline__ uint32_t dropout_threshold(float p) {
+    return (uint32_t)((double)p * 4294967296.0);
 }
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t stream, uint64_t idx, float p) {
-    return dropout_u01(seed, stream, idx) >= p;
+    return dropout_hash(dropout_key(seed, stream), idx) >= dropout_threshold(p);
 }
 #endif
 

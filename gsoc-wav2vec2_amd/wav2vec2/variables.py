@@ -235,7 +235,7 @@ def seeded_weights(config, seed=0, with_lm_head=True):
 
 
 # --------------------------------------------------------------------------
-# Dropout mask hash -- the host-side twin of csrc/train.h::dropout_u01.
+# Dropout mask hash -- the host-side twin of csrc/train.h::dropout_hash.
 # --------------------------------------------------------------------------
 DS_FEATURE_PROJECTION, DS_ENCODER_IN, DS_HEAD, DS_LAYER_BASE = 1, 2, 3, 16
 
@@ -245,15 +245,32 @@ def layer_stream(layer, site):
     return DS_LAYER_BASE + 4 * layer + site
 
 
-def dropout_uniform(seed, stream, n, start=0):
-    """uniform [0, 1) per element index, identical to the device function (integer arithmetic only)."""
-    key = np.uint64((int(seed) ^ ((int(stream) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF)
+def _lowbias32(x):
     with np.errstate(over="ignore"):
-        idx = np.arange(start, start + n, dtype=np.uint64) * np.uint64(0x2545F4914F6CDD1D) + key
-    z = _splitmix64(idx)
-    return ((z >> np.uint64(40)).astype(np.float32)) * np.float32(1.0 / (1 << 24))
+        x = x ^ (x >> np.uint32(16))
+        x = x * np.uint32(0x7FEB352D)
+        x = x ^ (x >> np.uint32(15))
+        x = x * np.uint32(0x846CA68B)
+        x = x ^ (x >> np.uint32(16))
+    return x
+
+
+def dropout_hash(seed, stream, n, start=0):
+    """uint32 hash per element index, identical to csrc/train.h::dropout_hash (integer arithmetic only)."""
+    key0 = np.array([(int(seed) ^ ((int(stream) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF],
+                    dtype=np.uint64)
+    key = int(_splitmix64(key0)[0])
+    k1, k2 = np.uint32(key & 0xFFFFFFFF), np.uint32(key >> 32)
+    idx = np.arange(start, start + n, dtype=np.uint64)
+    lo = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    hi = (idx >> np.uint64(32)).astype(np.uint32)
+    h = _lowbias32(lo ^ k1)
+    with np.errstate(over="ignore"):
+        h = h + hi * np.uint32(0x9E3779B1) + k2
+    return _lowbias32(h)
 
 
 def dropout_keep(seed, stream, n, p):
-    """Boolean keep mask: element kept iff u >= p (then scaled by 1 / (1 - p))."""
-    return dropout_uniform(seed, stream, n) >= np.float32(p)
+    """Boolean keep mask: element kept iff hash >= floor(p * 2^32) (then scaled by 1 / (1 - p))."""
+    thr = np.uint32(min(int(float(np.float32(p)) * 4294967296.0), 0xFFFFFFFF))
+    return dropout_hash(seed, stream, n) >= thr

@@ -141,6 +141,10 @@ def grads_close(trainer, ref_grads, rtol=2e-4):
             assert not np.any(got), name
             continue
         scale = max(1e-3, float(np.abs(g).max()))
+        if name.endswith("k_proj/bias"):
+            # exactly zero in exact arithmetic (softmax ignores a per-query constant shift of the scores): what is
+            # left is rounding noise, so measure it against the k_proj kernel gradient it is the column sum of
+            scale = max(scale, float(np.abs(ref_grads[name[:-4] + "kernel"]).max()))
         e = H.max_err(got, g) / scale
         if e > worst[1]:
             worst = (name, e)
