@@ -32,6 +32,7 @@ for p in (ROOT, os.path.join(ROOT, "gsoc-wav2vec2_amd")):
 
 SAMPLE_RATE = 16000
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -142,6 +143,9 @@ def main():
     ap.add_argument("--model", choices=["base", "large-robust"], default="base",
                     help="base = wav2vec2-base (the headline); large-robust = 24L/1024d prenorm, LayerNorm convs, conv bias, "
                          "attention mask (BASELINE configs[3] / [4] shapes, e.g. --batch 16 --samples 480000)")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+                    help="fp32 = the reference's arithmetic and the headline metric; bf16 = Dense / Conv1D operands rounded "
+                         "to bf16 with fp32 accumulation (BASELINE configs[2]/[4] 'bf16 CTC fine-tune'), reported separately")
     ap.add_argument("--mode", choices=["forward", "train"], default="forward",
                     help="forward = BASELINE configs[1] (the headline metric); train = one CTC fine-tune step "
                          "(BASELINE configs[2] shape, fp32: forward + CTC + backward + gradient all-reduce + Adam)")
@@ -166,6 +170,8 @@ def main():
     weights = V.seeded_weights(cfg, seed=0)
     model = wav2vec2.Wav2Vec2ForCTC(cfg, input_shape=(args.batch, args.samples))
     model.set_weights(weights)
+    model.set_precision(args.precision)
+    gemm_family = "gemm_f32" if args.precision == "fp32" else "gemm_bf16"
     B, L = args.batch, args.samples
     T = cfg.num_frames(L)
 
@@ -201,7 +207,7 @@ def main():
     # Timed region: HIP events bracket ONLY the dominant kernel family (the roofline object); an event pair
     # costs ~7 us of stream time, so instrumenting all ~150 launches per step would tax the headline by ~3 %.
     if not args.no_profile:
-        model.profile(True, families=["gemm_f32"])
+        model.profile(True, families=[gemm_family])
         model.profile_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -241,22 +247,26 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.precision == "fp32" else "bf16 operands, f32 accumulate (Dense / Conv1D); f32 elsewhere",
             "data": "synthetic",
-            "config": {"workload": (f"wav2vec2-{args.model} fp32 forward-only, batch={B}x{L} samples per GPU"
-                                    + (" (BASELINE configs[1])" if (args.model, B, L) == ("base", 32, 246000) else "")
+            "config": {"workload": (f"wav2vec2-{args.model} {args.precision} forward-only, batch={B}x{L} samples per GPU"
+                                    + (" (BASELINE configs[1])" if (args.model, B, L, args.precision) == ("base", 32, 246000, "fp32") else "")
                                     if args.mode == "forward" else
-                                    f"wav2vec2-{args.model} CTC fine-tune step in fp32 (conv stack frozen, dropout 0.1, spec-augment, "
-                                    f"Adam), batch={B}x{L} per GPU (BASELINE configs[2]/[4] shapes are bf16; this is fp32)"),
+                                    f"wav2vec2-{args.model} CTC fine-tune step, {args.precision} contractions (conv stack frozen, "
+                                    f"dropout 0.1, spec-augment, Adam, fp32 variables / optimizer state), batch={B}x{L} per GPU"
+                                    + (" (BASELINE configs[2]/[4] name bf16: see --precision bf16)" if args.precision == "fp32" else
+                                       " (BASELINE configs[2]/[4] arithmetic)")),
                        "global_batch": world * B, "samples": L, "frames": T, "parallelism": f"dp{world}"},
         }
         if prof:
-            gm = prof["gemm_f32"]
+            gm = prof[gemm_family]
             ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
+            peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
             res["roofline"] = {
-                "kernel": "gemm_f32_kernel (fp32 MFMA 32x32x2: conv1-6 implicit GEMM + all Dense layers)",
-                "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(),
+                "kernel": ("gemm_f32_kernel (fp32 MFMA 32x32x2: conv1-6 implicit GEMM + all Dense layers)" if args.precision == "fp32"
+                           else "gemm_bf16_kernel (bf16 MFMA 32x32x16, fp32 operands rounded on the way into LDS: conv1-6 + all Dense)"),
+                "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": measured_traffic() if args.precision == "fp32" else None,
                 "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
                 "launches_per_step": gm["launches"] // max(1, args.steps),
                 "avg_launch_ms": round(gm["ms"] / max(1, gm["launches"]), 4),
@@ -270,11 +280,11 @@ def main():
                 for k, v in prof_all.items() if v["launches"] > 0}
             res["families_note"] = "per-family breakdown from 2 extra untimed steps with every family instrumented"
             # whole-forward algorithmic rate: 235.56 GFLOP per 246000-sample utterance scales with T
-            flops_step = sum(v["flops"] for k, v in prof_all.items() if k in ("gemm_f32", "pos_conv", "attention", "conv0_apply")) / 2
+            flops_step = sum(v["flops"] for k, v in prof_all.items() if k in ("gemm_f32", "gemm_bf16", "pos_conv", "attention", "conv0_apply")) / 2
             res["forward_tflops"] = round(flops_step * world / (elapsed / args.steps) / 1e12, 2)
         if args.mode == "train":
             res["final_loss"] = round(float(out), 4)
-        if world == 1 and not args.no_cpu_baseline and args.mode == "forward" and args.model == "base":
+        if world == 1 and not args.no_cpu_baseline and args.mode == "forward" and args.model == "base" and args.precision == "fp32":
             res["cpu_baseline"] = cpu_baseline(cfg, weights, L)
         print(json.dumps(res), flush=True)
     if dist.is_initialized():

@@ -37,6 +37,7 @@ enum Family {
     FAM_CONV0_STATS = 0,   // conv0 recompute + per-(sample,channel) sum/sumsq   (HBM: wave read)
     FAM_CONV0_APPLY,       // conv0 recompute + GroupNorm + GELU + single write  (HBM: 100.76 MB/utt write)
     FAM_GEMM,              // fp32 MFMA GEMM / implicit-GEMM conv / Dense        (MFMA f32)
+    FAM_GEMM_BF16,         // same contractions, bf16 operands / fp32 accumulate (MFMA bf16; precision mode 1)
     FAM_LAYERNORM,         // row LayerNorm (+GELU)                              (HBM)
     FAM_POSCONV,           // grouped positional conv, MFMA 16x16x4 f32          (MFMA f32)
     FAM_ATTENTION,         // fused QK^T-softmax-PV, MFMA 32x32x2 f32            (MFMA f32)
@@ -78,6 +79,19 @@ int launch_gemm(Profiler* prof, const float* A, int64_t lda, int64_t strideA, co
                 int64_t ldb, float* C, int64_t ldc, int64_t strideC, const float* bias,
                 const float* residual, int M, int N, int K, int nbatch, int act, hipStream_t s);
 
+// precision mode 1: operands rounded to bf16 on the way into LDS, fp32 accumulate (gemm_bf16.hip)
+int launch_gemm_bf16(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
+                     int64_t strideB, float* C, int64_t ldc, int64_t strideC, const float* bias,
+                     const float* residual, int M, int N, int K, int nbatch, int act, hipStream_t s);
+// launch_gemm / launch_gemm_ex route to launch_gemm_bf16 while the calling thread's precision is 1.  The
+// API entry points set it from the model for the duration of one call (PrecisionScope).
+void gemm_set_precision(int mode);
+int gemm_get_precision();
+struct PrecisionScope {
+    int prev;
+    explicit PrecisionScope(int mode) : prev(gemm_get_precision()) { gemm_set_precision(mode); }
+    ~PrecisionScope() { gemm_set_precision(prev); }
+};
 int launch_gemm_ex(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const float* B,
                    int64_t ldb, int64_t strideB, float* C, int64_t ldc, int64_t strideC, const float* bias,
                    const float* residual, int M, int N, int K, int nbatch, int act, hipStream_t s);

@@ -1,0 +1,337 @@
+// Mixed-precision GEMM for the bf16 configurations (BASELINE configs[2] and [4]):
+// fp32 operands in HBM, rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) while they are
+// staged into LDS, multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; bias, GELU,
+// residual and the store stay fp32.  Numerically: C = act(bf16(A) . bf16(B) + bias) + residual with
+// exact products and an fp32 running sum -- what a bf16 autocast Dense/Conv1D computes.
+//
+// Same contract as gemm_f32.hip (overlapping-row A for the strided convs, per-batch strides for the
+// split-K weight gradients), so the whole model -- forward and backward -- switches precision by
+// routing launch_gemm here (gemm_set_precision).
+//
+// Tile: BM x 128 x 64, (BM/64) x 2 waves, each wave a 64x64 sub-tile = 2x2 accumulators of
+// 32x32.  One K tile is 16 MFMAs per wave (512 matrix-pipe cycles) against 16 ds_read_b128.
+// LDS image: rows of 64 bf16 = 128 B (A rows = m, B rows = n, both k-contiguous so a fragment is ONE
+// 16-byte read of 8 consecutive k); the 16-B slot index is XOR-swizzled per row (swz) so that the
+// fragment reads, the A stores and the transposing B stores are all bank-conflict free.  B arrives
+// n-contiguous from HBM ([K, N] TF kernel layout); the transpose to k-contiguous happens in registers:
+// a thread owns an 8(k) x 4(n) patch, loads it as eight float4 and writes four 16-byte rows.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace w2v2 {
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+constexpr int BK = 64;          // bf16 elements per K tile = one 128-byte LDS row
+constexpr int ROWB = 128;       // LDS row bytes
+
+struct Gemm16Args {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    const float* residual;
+    int64_t lda, ldb, ldc, strideA, strideB, strideC;
+    int M, N, K, act;
+    int tiles_m, tiles_n;
+};
+
+// two fp32 -> one dword of two bf16, round to nearest even (gfx950 instruction; no builtin in ROCm 7.2)
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+// 16-byte-slot swizzle of an LDS row (8 slots per 128-byte row).  Chosen so that all three access patterns are
+// bank-conflict free: ds_read_b128 fragment reads (16-lane groups {0-3,12-15,20-27}, ... of consecutive rows),
+// the A stores (16 lanes = one row) and the transposing B stores (8 lanes = rows 4 q + j or 2 q + j, q = 8g..8g+7).
+__device__ __forceinline__ int swz(int row) { return ((row >> 1) & 7) ^ ((row >> 4) & 1); }
+
+template <int PN> struct FVec;
+template <> struct FVec<4> { using type = f32x4; };
+template <> struct FVec<2> { using type = f32x2; };
+
+template <bool FAST, int BM, int BN, int WM, int WN, int MINB, int ABL = 0>
+__global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args g) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 32, NTL = WTN / 32;   // wave tile, 32x32 accumulators
+    constexpr int NA = BM * 16 / NT;              // float4 chunks of the A tile per thread
+    constexpr int PN = (2 * BN >= NT) ? 4 : 2;    // B patch = 8(k) x PN(n) per thread, loaded as 8 float4 | float2
+    constexpr int NQ = BN / PN;                   // patches across n
+    constexpr int NB = 8 * NQ / NT;               // patches per thread
+    constexpr int STAGE = (BM + BN) * ROWB;       // bytes per LDS stage
+    static_assert(NA >= 1 && NB >= 1 && MT >= 1 && NTL >= 1, "bad tile / wave grid");
+    using bvec = typename FVec<PN>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN, li = lane & 31, lh = lane >> 5;
+
+    // XCD-aware tile order (see gemm_f32.hip): each XCD walks a contiguous run of tiles, N fastest
+    const int nwg = g.tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.z;
+    const float* __restrict__ A = g.A + (int64_t)z * g.strideA;
+    const float* __restrict__ Bm = g.B + (int64_t)z * g.strideB;
+
+    const int nk = (g.K + BK - 1) / BK;
+
+    // ---- global -> register staging.  Every wave-level load is fully coalesced: A as 16 lanes x 16 B per
+    // 256-byte row, B as NQ lanes x (4 PN) B per k-row.  The vector L1 (64 B/clk/CU) is the resource this kernel
+    // leans on hardest -- 64 KiB of fp32 per 128x128x64 tile step -- so no request may touch a line twice.
+    f32x4 ra[NA];
+    bvec rb[NB][8];
+    int64_t a_off[NA], b_off[NB];
+    int a_lds[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int idx = tid + i * NT, r = idx >> 4, sl = idx & 15;     // sl: 16-byte slot of the fp32 row = 4 k
+        int row = m0 + r;
+        row = row < g.M ? row : g.M - 1;              // clamped rows feed accumulators never stored
+        a_off[i] = (int64_t)row * g.lda + sl * 4;
+        a_lds[i] = r * ROWB + (((sl >> 1) ^ swz(r)) << 4) + (sl & 1) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int idx = tid + i * NT, q = idx % NQ, ks = idx / NQ;
+        int col = n0 + PN * q;
+        col = col < g.N ? col : (g.N >= PN ? g.N - PN : 0);
+        b_off[i] = (int64_t)(ks * 8) * g.ldb + col;
+    }
+
+    auto load_tile = [&](int kt) {
+        if constexpr (ABL == 1) {     // ablation: no global loads
+            if (kt == 0) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) ra[i] = f32x4{1.f, 2.f, 3.f, 4.f};
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                        for (int j = 0; j < PN; ++j) rb[i][kk][j] = 1.f + j;
+            }
+            return;
+        }
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if constexpr (FAST) {
+                ra[i] = *reinterpret_cast<const f32x4*>(A + a_off[i] + k0);
+            } else {
+                const int idx = tid + i * NT;
+                const int row = m0 + (idx >> 4), k = k0 + (idx & 15) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ra[i][e] = (row < g.M && k + e < g.K) ? A[(int64_t)row * g.lda + k + e] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                if constexpr (FAST) {
+                    rb[i][kk] = *reinterpret_cast<const bvec*>(Bm + b_off[i] + (int64_t)(k0 + kk) * g.ldb);
+                } else {
+                    const int idx = tid + i * NT;
+                    const int k = k0 + (idx / NQ) * 8 + kk, col = n0 + PN * (idx % NQ);
+#pragma unroll
+                    for (int j = 0; j < PN; ++j)
+                        rb[i][kk][j] = (k < g.K && col + j < g.N) ? Bm[(int64_t)k * g.ldb + col + j] : 0.0f;
+                }
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        unsigned char* S = smem16 + buf * STAGE;
+        if constexpr (ABL == 2) {     // ablation: loads consumed, no convert / LDS store
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) t += ra[i][0] + ra[i][3];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) t += rb[i][0][0] + rb[i][7][1];
+            if (t == 123.456f) S[tid] = 1;
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            u32x2 p;
+            p[0] = pack_bf16(ra[i][0], ra[i][1]);
+            p[1] = pack_bf16(ra[i][2], ra[i][3]);
+            *reinterpret_cast<u32x2*>(S + a_lds[i]) = p;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int q = (tid + i * NT) % NQ, ks = (tid + i * NT) / NQ;
+#pragma unroll
+            for (int j = 0; j < PN; ++j) {       // register transpose: column j of the patch becomes 8 consecutive k
+                u32x4 p;
+                p[0] = pack_bf16(rb[i][0][j], rb[i][1][j]);
+                p[1] = pack_bf16(rb[i][2][j], rb[i][3][j]);
+                p[2] = pack_bf16(rb[i][4][j], rb[i][5][j]);
+                p[3] = pack_bf16(rb[i][6][j], rb[i][7][j]);
+                const int r = PN * q + j;
+                *reinterpret_cast<u32x4*>(S + BM * ROWB + r * ROWB + ((ks ^ swz(r)) << 4)) = p;
+            }
+        }
+    };
+
+    f32x16 acc[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    int a_row[MT], a_swz[MT], b_row[NTL], b_swz[NTL];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int r = wm * WTM + t * 32 + li;
+        a_row[t] = r * ROWB;
+        a_swz[t] = swz(r);
+    }
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        const int r = wn * WTN + t * 32 + li;
+        b_row[t] = BM * ROWB + r * ROWB;
+        b_swz[t] = swz(r);
+    }
+    // which 8 k of a 16-deep MFMA step a lane supplies is free as long as A and B agree: lane half lh takes
+    // 16-byte slot 2 s + lh of both images
+    auto compute = [&](int buf) {
+        const unsigned char* S = smem16 + buf * STAGE;
+        if constexpr (ABL == 3) return;   // ablation: no fragment reads / MFMA
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            bf16x8 a[MT], b[NTL];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) a[t] = *reinterpret_cast<const bf16x8*>(S + a_row[t] + (((2 * s + lh) ^ a_swz[t]) << 4));
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) b[t] = *reinterpret_cast<const bf16x8*>(S + b_row[t] + (((2 * s + lh) ^ b_swz[t]) << 4));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTL; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        }
+    };
+
+    // One tile of prefetch: measured on MI355X, a second register set (two fp32 tiles = 128 KiB per block in
+    // flight) changed nothing (374 vs 371 TF on conv1) -- the loop is bound by the L2 -> CU operand bandwidth
+    // (~15 TB/s across the chip for this 64-KiB-per-tile-step stream), not by latency.
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt + 1 < nk; ++kt) {       // last iteration peeled: the prefetch stays unconditional
+        const int cur = kt & 1;
+        load_tile(kt + 1);                       // fp32 tile in flight under the MFMAs below
+        __builtin_amdgcn_sched_barrier(0);
+        compute(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tile(cur ^ 1);                     // round + transpose + write the other stage
+        __syncthreads();
+    }
+    compute((nk - 1) & 1);
+
+    // epilogue (fp32): C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    float* __restrict__ C = g.C + (int64_t)z * g.strideC;
+    const float* __restrict__ R = g.residual ? g.residual + (int64_t)z * g.strideC : nullptr;
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt) {
+        const int col = n0 + wn * WTN + nt * 32 + li;
+        if (col >= g.N) continue;
+        const float bv = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WTM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < g.M) {
+                    float v = apply_act(acc[mt][nt][r] + bv, g.act);
+                    if (R) v += R[(int64_t)row * g.ldc + col];
+                    C[(int64_t)row * g.ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int MINB, int ABL = 0>
+int launch_cfg16(Gemm16Args& g, bool fast, int nbatch, hipStream_t s) {
+    constexpr size_t LDS = 2 * (BM + BN) * ROWB;
+    g.tiles_m = (g.M + BM - 1) / BM;
+    g.tiles_n = (g.N + BN - 1) / BN;
+    static bool attr_set = false;
+    if (!attr_set) {
+        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<true, BM, BN, WM, WN, MINB, ABL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<false, BM, BN, WM, WN, MINB, ABL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        attr_set = true;
+    }
+    dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch), block(WM * WN * 64);
+    if (fast)
+        hipLaunchKernelGGL((gemm_bf16_kernel<true, BM, BN, WM, WN, MINB, ABL>), grid, block, LDS, s, g);
+    else
+        hipLaunchKernelGGL((gemm_bf16_kernel<false, BM, BN, WM, WN, MINB, ABL>), grid, block, LDS, s, g);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
+int forced_cfg16() {
+    static int v = -2;
+    if (v == -2) {
+        const char* e = getenv("W2V2_GEMM16_CFG");   // tuning knob, not part of the ABI
+        v = e ? atoi(e) : -1;
+    }
+    return v;
+}
+
+}  // namespace
+
+int launch_gemm_bf16(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
+                     int64_t strideB, float* C, int64_t ldc, int64_t strideC, const float* bias,
+                     const float* residual, int M, int N, int K, int nbatch, int act, hipStream_t s) {
+    W2V2_REQUIRE(A && B && C, "gemm_bf16: null operand");
+    W2V2_REQUIRE(M > 0 && N > 0 && K > 0 && nbatch > 0, "gemm_bf16: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, nbatch);
+    W2V2_REQUIRE(lda >= 1 && ldb >= N && ldc >= N, "gemm_bf16: bad leading dimensions");
+    W2V2_REQUIRE(act >= 0 && act <= 2, "gemm_bf16: bad activation %d", act);
+    Gemm16Args g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.residual = residual;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.strideA = strideA; g.strideB = strideB; g.strideC = strideC;
+    g.M = M; g.N = N; g.K = K; g.act = act;
+    const bool fast = (K % BK == 0) && (N % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && (strideA % 4 == 0) &&
+                      (strideB % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+    ProfScope ps(prof, FAM_GEMM_BF16, 2.0 * M * (double)N * K * nbatch,
+                 4.0 * nbatch * ((double)M * K + (double)M * N) + 4.0 * (double)K * N, s);
+    int cfg = forced_cfg16();
+    if (cfg < 0) cfg = 0;
+    switch (cfg) {
+        case 1: return launch_cfg16<256, 128, 4, 2, 1>(g, fast, nbatch, s);
+        case 2: return launch_cfg16<256, 256, 2, 4, 1>(g, fast, nbatch, s);   // 8 waves of 128x64
+        case 3: return launch_cfg16<256, 256, 4, 2, 1>(g, fast, nbatch, s);   // 8 waves of 64x128
+        case 4: return launch_cfg16<256, 128, 2, 2, 1>(g, fast, nbatch, s);   // 4 waves of 128x64
+        case 5: return launch_cfg16<128, 256, 2, 4, 1>(g, fast, nbatch, s);   // 8 waves of 64x64
+        case 11: return launch_cfg16<128, 128, 2, 2, 2, 1>(g, fast, nbatch, s);
+        case 12: return launch_cfg16<128, 128, 2, 2, 2, 2>(g, fast, nbatch, s);
+        case 13: return launch_cfg16<128, 128, 2, 2, 2, 3>(g, fast, nbatch, s);
+        default: return launch_cfg16<128, 128, 2, 2, 2>(g, fast, nbatch, s);
+    }
+}
+
+}  // namespace w2v2

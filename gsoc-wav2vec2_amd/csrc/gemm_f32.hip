@@ -425,7 +425,12 @@ int forced_cfg() {
     return v;
 }
 
+thread_local int tl_precision = 0;
+
 }  // namespace
+
+void gemm_set_precision(int mode) { tl_precision = mode; }
+int gemm_get_precision() { return tl_precision; }
 
 int launch_gemm(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const float* B,
                 int64_t ldb, float* C, int64_t ldc, int64_t strideC, const float* bias,
@@ -437,6 +442,8 @@ int launch_gemm(Profiler* prof, const float* A, int64_t lda, int64_t strideA, co
 int launch_gemm_ex(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const float* B,
                    int64_t ldb, int64_t strideB, float* C, int64_t ldc, int64_t strideC, const float* bias,
                    const float* residual, int M, int N, int K, int nbatch, int act, hipStream_t s) {
+    if (tl_precision == 1)
+        return launch_gemm_bf16(prof, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, bias, residual, M, N, K, nbatch, act, s);
     W2V2_REQUIRE(A && B && C, "gemm: null operand");
     W2V2_REQUIRE(M > 0 && N > 0 && K > 0 && nbatch > 0, "gemm: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, nbatch);
     W2V2_REQUIRE(lda >= 1 && ldb >= N && ldc >= N, "gemm: bad leading dimensions");

@@ -28,6 +28,7 @@ struct w2v2_model {
     float* pos_wg = nullptr;                 // (groups, K, cg, og)
     std::vector<float*> qkv_w, qkv_b;        // per layer (H, 3H), (3H)
     bool finalized = false;
+    int precision = 0;                       // 0 fp32 MFMA, 1 bf16 operands / fp32 accumulate (w2v2_set_precision)
     // activation workspace
     int ws_B = 0;
     int64_t ws_L = 0;

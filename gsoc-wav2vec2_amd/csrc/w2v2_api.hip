@@ -30,7 +30,7 @@ void set_error(const char* fmt, ...) {
 }
 
 const char* family_name(int f) {
-    static const char* names[FAM_COUNT] = {"conv0_stats", "conv0_apply", "gemm_f32", "layer_norm",
+    static const char* names[FAM_COUNT] = {"conv0_stats", "conv0_apply", "gemm_f32", "gemm_bf16", "layer_norm",
                                            "pos_conv",    "attention",   "ctc",      "misc"};
     return (f >= 0 && f < FAM_COUNT) ? names[f] : "?";
 }
@@ -371,6 +371,14 @@ int64_t w2v2_num_frames(const w2v2_model* m, int64_t n) {
     return n;
 }
 
+int w2v2_set_precision(w2v2_model* m, int32_t mode) {
+    W2V2_REQUIRE(m, "set_precision: null model");
+    W2V2_REQUIRE(mode == W2V2_PRECISION_FP32 || mode == W2V2_PRECISION_BF16, "set_precision: unknown mode %d", mode);
+    m->precision = mode;
+    return W2V2_OK;
+}
+int w2v2_get_precision(const w2v2_model* m) { return m ? m->precision : W2V2_EINVAL; }
+
 int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const int32_t* mask,
                  float* out, void* stream) {
     W2V2_REQUIRE(m && wave && out, "forward: null argument");
@@ -380,6 +388,7 @@ int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const i
         return W2V2_ESTATE;
     }
     const w2v2_config& c = m->cfg;
+    PrecisionScope precision(m->precision);
     const int64_t Tll = w2v2_num_frames(m, L);
     W2V2_REQUIRE(Tll >= 1, "forward: %lld samples are shorter than the conv stack's receptive field", (long long)L);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -551,6 +560,12 @@ int w2v2_op_gemm(const float* A, int64_t lda, int64_t strideA, const float* B, i
                  int32_t N, int32_t K, int32_t nbatch, int32_t act, void* stream) {
     return launch_gemm(nullptr, A, lda, strideA, B, ldb, C, ldc, strideC, bias, residual, M, N, K, nbatch, act,
                        reinterpret_cast<hipStream_t>(stream));
+}
+int w2v2_op_gemm_bf16(const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb, float* C,
+                      int64_t ldc, int64_t strideC, const float* bias, const float* residual, int32_t M,
+                      int32_t N, int32_t K, int32_t nbatch, int32_t act, void* stream) {
+    return launch_gemm_bf16(nullptr, A, lda, strideA, B, ldb, 0, C, ldc, strideC, bias, residual, M, N, K, nbatch, act,
+                            reinterpret_cast<hipStream_t>(stream));
 }
 int w2v2_op_layer_norm(const float* x, float* y, const float* gamma, const float* beta, int64_t rows,
                        int32_t C, float eps, int32_t act, void* stream) {

@@ -264,6 +264,7 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
         return W2V2_ESTATE;
     }
     const w2v2_config& c = m->cfg;
+    PrecisionScope precision(m->precision);
     const int64_t Tll = w2v2_num_frames(m, L);
     W2V2_REQUIRE(Tll >= 1, "train_forward: input too short");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -407,6 +408,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         return W2V2_ESTATE;
     }
     const w2v2_config& c = m->cfg;
+    PrecisionScope precision(m->precision);
     for (size_t i = 0; i < m->params.size(); ++i)
         if (t->trainable[i] && m->params[i].name.compare(0, 18, "feature_extractor/") == 0) {
             set_error("train_backward: `%s` is trainable, but the conv feature extractor has no backward "

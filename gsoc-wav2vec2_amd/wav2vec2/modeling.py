@@ -165,6 +165,21 @@ class TFKerasModel:
                 v.trainable = bool(trainable)
         N.check(self._lib.w2v2_set_trainable(self._handle, name_prefix.encode(), int(bool(trainable))), "w2v2_set_trainable")
 
+    # ---- arithmetic of the dense contractions --------------------------------
+    PRECISIONS = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "mixed_bfloat16": 1}
+
+    def set_precision(self, precision):
+        """"fp32" (default: the reference's arithmetic) or "bf16" (Conv1D layers 1..6 and every Dense take
+        bf16-rounded operands with fp32 accumulation, forward and backward -- the mixed-precision policy the
+        bf16 fine-tune configurations ask for; variables, activations and optimizer state stay fp32)."""
+        if precision not in self.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(set(self.PRECISIONS))}, got {precision!r}")
+        N.check(self._lib.w2v2_set_precision(self._handle, self.PRECISIONS[precision]), "w2v2_set_precision")
+
+    @property
+    def precision(self):
+        return "bf16" if self._lib.w2v2_get_precision(self._handle) == 1 else "fp32"
+
     # ---- persistence (reference modeling.py:22-27, 41-84) -------------------
     def save_weights(self, path):
         arrays = {V.tf_variable_name(n, self._prefix_with_head): a for n, a in self.get_weights().items()}

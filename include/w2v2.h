@@ -104,6 +104,17 @@ int w2v2_finalize(w2v2_model* m, void* stream);
  * 1 + (len - k) // s per layer (modeling.py:202-204, losses.py:47-56). */
 int64_t w2v2_num_frames(const w2v2_model* m, int64_t num_samples);
 
+/* Arithmetic of the dense contractions (Conv1D layers 1..6 and every Dense, forward and backward):
+ *   W2V2_PRECISION_FP32  v_mfma_f32_32x32x2_f32 on fp32 operands -- the reference's arithmetic (default);
+ *   W2V2_PRECISION_BF16  operands rounded to bf16 (nearest-even) on the way into LDS, fp32 accumulation,
+ *                        fp32 bias / GELU / residual / storage: what BASELINE configs "bf16 CTC fine-tune"
+ *                        ask for (mixed precision; variables, optimizer state and activations stay fp32).
+ * Everything else (conv0 + GroupNorm, LayerNorm, positional conv, attention, CTC) is fp32 in both modes. */
+#define W2V2_PRECISION_FP32 0
+#define W2V2_PRECISION_BF16 1
+int w2v2_set_precision(w2v2_model* m, int32_t mode);
+int w2v2_get_precision(const w2v2_model* m);
+
 /* ---- the hot path --------------------------------------------------------
  * Replaces Wav2Vec2ForCTC.call / Wav2Vec2Model.call at training=False
  * (modeling.py:169-209, 239-255).
@@ -194,6 +205,13 @@ int w2v2_op_gemm(const float* A_dev, int64_t lda, int64_t strideA,
                  float* C_dev, int64_t ldc, int64_t strideC,
                  const float* bias_dev, const float* residual_dev,
                  int32_t M, int32_t N, int32_t K, int32_t nbatch, int32_t act, void* stream);
+
+/* Same contract, operands rounded to bf16 / fp32 accumulate (W2V2_PRECISION_BF16's GEMM). */
+int w2v2_op_gemm_bf16(const float* A_dev, int64_t lda, int64_t strideA,
+                      const float* B_dev, int64_t ldb,
+                      float* C_dev, int64_t ldc, int64_t strideC,
+                      const float* bias_dev, const float* residual_dev,
+                      int32_t M, int32_t N, int32_t K, int32_t nbatch, int32_t act, void* stream);
 
 /* y = LN(x) * gamma + beta over the last axis, optional GELU after
  * (tf.keras.layers.LayerNormalization(axis=-1); act as above). rows x C. */

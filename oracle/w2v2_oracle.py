@@ -49,6 +49,28 @@ except Exception:  # pragma: no cover
 _POOL = None
 
 
+# Operand rounding of the dense contractions (Conv1D layers >= 1 and every Dense): None = the reference's
+# fp32 arithmetic; "bf16" = both operands rounded to bfloat16 (nearest-even) before an exact product and a
+# wide sum -- the restatement of W2V2_PRECISION_BF16 (include/w2v2.h), i.e. of a mixed_bfloat16 Keras policy
+# on those layers.  Attention, positional conv, norms and conv0 stay unrounded, as in the build.
+GEMM_OPERANDS = None
+
+
+def round_bf16(x):
+    """fp32 -> nearest-even bfloat16 -> back to the input dtype (values exactly representable in bf16)."""
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    b = a.view(np.uint32).astype(np.uint64)
+    b = (b + np.uint64(0x7FFF) + ((b >> np.uint64(16)) & np.uint64(1))) & np.uint64(0xFFFF0000)
+    return b.astype(np.uint32).view(np.float32).reshape(a.shape).astype(np.asarray(x).dtype)
+
+
+def _mm(a, b):
+    """a @ b of one dense contraction, with the configured operand rounding."""
+    if GEMM_OPERANDS == "bf16":
+        return round_bf16(a) @ round_bf16(b)
+    return a @ b
+
+
 def _chunked(fn, x, min_elems=1 << 20):
     """Apply an elementwise `fn` over row chunks of `x` on a thread pool (numpy / scipy ufuncs release
     the GIL).  Same arithmetic per element; only there so that the CPU baseline is not dominated by
@@ -136,7 +158,8 @@ def conv1d_valid(x, kernel, stride, bias=None):
     step = max(1, (32 << 20) // max(1, K * Cin * it))
     for b in range(B):
         for t0 in range(0, T_out, step):
-            y[b, t0:t0 + step] = np.ascontiguousarray(win[b, t0:t0 + step]) @ w2
+            y[b, t0:t0 + step] = (_mm(np.ascontiguousarray(win[b, t0:t0 + step]), w2) if x.shape[2] > 1
+                                   else np.ascontiguousarray(win[b, t0:t0 + step]) @ w2)   # layer 0 (C_in = 1) is not a GEMM in the build
     if bias is not None:
         y += bias
     return y
@@ -165,7 +188,7 @@ def feature_projection(config, w, x):
     (feature_extractor.py:92-95)."""
     x = layer_norm(x, w["feature_projection/layer_norm/gamma"],
                    w["feature_projection/layer_norm/beta"], config.layer_norm_eps)
-    return x @ w["feature_projection/projection/kernel"] + w["feature_projection/projection/bias"]
+    return _mm(x, w["feature_projection/projection/kernel"]) + w["feature_projection/projection/bias"]
 
 
 def weight_norm_kernel(weight_v, weight_g):
@@ -225,7 +248,7 @@ def attention(config, w, base, x, add_mask):
     d = H // h
 
     def proj(name):
-        y = x @ w[f"{base}/attention/{name}/kernel"] + w[f"{base}/attention/{name}/bias"]
+        y = _mm(x, w[f"{base}/attention/{name}/kernel"]) + w[f"{base}/attention/{name}/bias"]
         return y.reshape(B, T, h, d).transpose(0, 2, 1, 3)            # (B, h, T, d)
 
     q = proj("q_proj") * x.dtype.type(d ** -0.5)
@@ -238,7 +261,7 @@ def attention(config, w, base, x, add_mask):
     p = np.exp(s)
     p = p / p.sum(axis=-1, keepdims=True)
     ctx = (p @ v).transpose(0, 2, 1, 3).reshape(B, T, H)
-    return ctx @ w[f"{base}/attention/out_proj/kernel"] + w[f"{base}/attention/out_proj/bias"]
+    return _mm(ctx, w[f"{base}/attention/out_proj/kernel"]) + w[f"{base}/attention/out_proj/bias"]
 
 
 def transformer_layer(config, w, i, x, add_mask):
@@ -256,9 +279,9 @@ def transformer_layer(config, w, i, x, add_mask):
     res = x
     if pre:
         x = layer_norm(x, w[f"{base}/final_layer_norm/gamma"], w[f"{base}/final_layer_norm/beta"], eps)
-    x = gelu(x @ w[f"{base}/feed_forward/intermediate_dense/kernel"]
+    x = gelu(_mm(x, w[f"{base}/feed_forward/intermediate_dense/kernel"])
              + w[f"{base}/feed_forward/intermediate_dense/bias"], config.is_gelu_approx)
-    x = x @ w[f"{base}/feed_forward/output_dense/kernel"] + w[f"{base}/feed_forward/output_dense/bias"]
+    x = _mm(x, w[f"{base}/feed_forward/output_dense/kernel"]) + w[f"{base}/feed_forward/output_dense/bias"]
     x = res + x
     if not pre:
         x = layer_norm(x, w[f"{base}/final_layer_norm/gamma"], w[f"{base}/final_layer_norm/beta"], eps)
@@ -315,7 +338,7 @@ def ctc_forward(config, w, wave, attention_mask=None, taps=None, dtype=np.float3
     """Wav2Vec2ForCTC.call at inference (modeling.py:239-255): backbone ->
     (dropout: identity) -> lm_head Dense(H -> vocab).  Returns logits (B,T,V)."""
     h = model_forward(config, w, wave, attention_mask, taps, dtype)
-    return h @ np.asarray(w["lm_head/kernel"], dtype=dtype) + np.asarray(w["lm_head/bias"], dtype=dtype)
+    return _mm(h, np.asarray(w["lm_head/kernel"], dtype=dtype)) + np.asarray(w["lm_head/bias"], dtype=dtype)
 
 
 # --------------------------------------------------------------------------

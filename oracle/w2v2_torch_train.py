@@ -18,6 +18,23 @@ import torch
 from wav2vec2 import variables as V
 
 
+# Operand rounding of the Dense contractions, mirroring oracle/w2v2_oracle.py::GEMM_OPERANDS.  "bf16": both
+# operands of every Dense are rounded to bfloat16 in the forward with a straight-through gradient, so autograd
+# yields dX = dY . bf16(W)^T and dW = bf16(X)^T . dY; the build additionally rounds dY in its backward GEMMs
+# (W2V2_PRECISION_BF16), which is why bf16 gradients are compared at a bf16-sized tolerance.
+GEMM_OPERANDS = None
+
+
+def _r(t):
+    if GEMM_OPERANDS == "bf16":
+        return t + (t.to(torch.float32).to(torch.bfloat16).to(t.dtype) - t).detach()
+    return t
+
+
+def _mm(a, b):
+    return _r(a) @ _r(b)
+
+
 def _drop(x, p, seed, stream):
     if p <= 0.0:
         return x
@@ -40,7 +57,11 @@ def conv_stack(config, w, wave):
     from oracle import w2v2_oracle as O
     wn = {k: v.detach().numpy() for k, v in w.items() if k.startswith("feature_extractor/")}
     x = np.asarray(wave, dtype=np.float64)[:, :, None]
-    return torch.from_numpy(O.feature_extractor(config, wn, x))
+    prev, O.GEMM_OPERANDS = O.GEMM_OPERANDS, GEMM_OPERANDS
+    try:
+        return torch.from_numpy(O.feature_extractor(config, wn, x))
+    finally:
+        O.GEMM_OPERANDS = prev
 
 
 def train_forward(config, w, wave, attention_mask=None, p=0.0, seed=0, spec_mask=None, sd_keep=None):
@@ -53,7 +74,7 @@ def train_forward(config, w, wave, attention_mask=None, p=0.0, seed=0, spec_mask
     H, h = c.hidden_size, c.num_heads
     d = H // h
     x = _ln(x0, w["feature_projection/layer_norm/gamma"], w["feature_projection/layer_norm/beta"], eps)
-    x = x @ w["feature_projection/projection/kernel"] + w["feature_projection/projection/bias"]
+    x = _mm(x, w["feature_projection/projection/kernel"]) + w["feature_projection/projection/bias"]
     x = _drop(x, p, seed, V.DS_FEATURE_PROJECTION)
     if spec_mask is not None:
         m = torch.from_numpy(np.asarray(spec_mask).astype(bool))[:, :, None]
@@ -81,7 +102,7 @@ def train_forward(config, w, wave, attention_mask=None, p=0.0, seed=0, spec_mask
         b = f"encoder/layers/{i}"
 
         def proj(name, t):
-            return (t @ w[f"{b}/attention/{name}/kernel"] + w[f"{b}/attention/{name}/bias"]).reshape(B, T, h, d).transpose(1, 2)
+            return (_mm(t, w[f"{b}/attention/{name}/kernel"]) + w[f"{b}/attention/{name}/bias"]).reshape(B, T, h, d).transpose(1, 2)
 
         res = x
         a_in = _ln(x, w[f"{b}/layer_norm/gamma"], w[f"{b}/layer_norm/beta"], eps) if pre else x   # encoder.py:114-115
@@ -93,23 +114,23 @@ def train_forward(config, w, wave, attention_mask=None, p=0.0, seed=0, spec_mask
         pr = torch.softmax(s, -1)
         pr = _drop(pr, p, seed, V.layer_stream(i, 0))
         ctx = (pr @ v).transpose(1, 2).reshape(B, T, H)
-        o = ctx @ w[f"{b}/attention/out_proj/kernel"] + w[f"{b}/attention/out_proj/bias"]
+        o = _mm(ctx, w[f"{b}/attention/out_proj/kernel"]) + w[f"{b}/attention/out_proj/bias"]
         x = _drop(o, p, seed, V.layer_stream(i, 1)) + res
         if not pre:
             x = _ln(x, w[f"{b}/layer_norm/gamma"], w[f"{b}/layer_norm/beta"], eps)
         keep_l = 1.0 if sd_keep is None else float(sd_keep[i])
         if keep_l != 0.0:
             f_in = _ln(x, w[f"{b}/final_layer_norm/gamma"], w[f"{b}/final_layer_norm/beta"], eps) if pre else x
-            u = f_in @ w[f"{b}/feed_forward/intermediate_dense/kernel"] + w[f"{b}/feed_forward/intermediate_dense/bias"]
+            u = _mm(f_in, w[f"{b}/feed_forward/intermediate_dense/kernel"]) + w[f"{b}/feed_forward/intermediate_dense/bias"]
             g = _drop(_gelu(u), p, seed, V.layer_stream(i, 2))
-            f = g @ w[f"{b}/feed_forward/output_dense/kernel"] + w[f"{b}/feed_forward/output_dense/bias"]
+            f = _mm(g, w[f"{b}/feed_forward/output_dense/kernel"]) + w[f"{b}/feed_forward/output_dense/bias"]
             x = x + keep_l * f
         if not pre:
             x = _ln(x, w[f"{b}/final_layer_norm/gamma"], w[f"{b}/final_layer_norm/beta"], eps)
     if pre:                                                          # encoder.py:274-275
         x = _ln(x, w["encoder/layer_norm/gamma"], w["encoder/layer_norm/beta"], eps)
     x = _drop(x, p, seed, V.DS_HEAD)
-    return x @ w["lm_head/kernel"] + w["lm_head/bias"]
+    return _mm(x, w["lm_head/kernel"]) + w["lm_head/bias"]
 
 
 def ctc_loss_sum(config, logits, labels, division_factor=1.0):

@@ -50,3 +50,22 @@ def tap_view(name, arr, full):
 
 def max_err(a, b):
     return float(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max())
+
+
+class oracle_operands:
+    """with H.oracle_operands("bf16"): run both oracles with bf16-rounded Dense / Conv1D operands."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        from oracle import w2v2_oracle as O
+        from oracle import w2v2_torch_train as TT
+        self.prev = (O.GEMM_OPERANDS, TT.GEMM_OPERANDS)
+        O.GEMM_OPERANDS = TT.GEMM_OPERANDS = self.mode
+
+    def __exit__(self, *exc):
+        from oracle import w2v2_oracle as O
+        from oracle import w2v2_torch_train as TT
+        O.GEMM_OPERANDS, TT.GEMM_OPERANDS = self.prev
+        return False

@@ -70,6 +70,56 @@ def test_logits_match_golden(torch_mod, name):
     assert H.max_err(H.tap_view("last_hidden", last, full), g["last_hidden"]) < H.ATOL_AIM
 
 
+# Tolerance of the bf16 configurations (BASELINE configs[2] / [4]; the reference states none).  HF's own bf16
+# autocast moves these logits by ~4e-2.  End to end a same-rounding oracle cannot be matched
+# tightly: activations that agree to 1e-6 occasionally round to different bf16 neighbours, one such flip moves an
+# output by ulp_bf16(x) * |w| ~ 6e-3, and every later layer re-rounds the difference.  So the model-level bar is
+# bf16-sized, and the bit-level claim is made where inputs are identical: the GEMM itself (test_ops_gpu.py) and
+# each conv layer fed with the build's own previous activation (below).
+ATOL_BF16_LOGITS = 0.15
+
+
+@pytest.mark.parametrize("name", ["tiny_base", "tiny_robust", "base_sample_unpadded", "robust_masked"])
+def test_bf16_precision_logits(torch_mod, name):
+    g = H.golden(name)
+    m, cfg = build(name)
+    w = H.case_weights(name)
+    mask = g.get("attention_mask")
+    mask = None if mask is None else mask.astype(np.int32)
+    fp32 = m(g["wave"], attention_mask=mask).numpy()
+    m.set_precision("bf16")
+    assert m.precision == "bf16"
+    got = m(g["wave"], attention_mask=mask).numpy()
+    with H.oracle_operands("bf16"):
+        ref = O.ctc_forward(cfg, w, g["wave"], mask)
+    err, cost = H.max_err(got, ref), H.max_err(got, g["logits_f64"])
+    print(f"{name}: bf16 path vs bf16-operand oracle {err:.3e}; vs HF fp64 {cost:.3e}; oracle's own bf16 cost {H.max_err(ref, g['logits_f64']):.3e}")
+    report(f"{name}/bf16_logits_vs_rounded_oracle", err)
+    report(f"{name}/bf16_logits_vs_hf_f64", cost)
+    assert np.isfinite(got).all()
+    assert err < ATOL_BF16_LOGITS and cost < ATOL_BF16_LOGITS
+    assert H.max_err(got, fp32) > 1e-5     # the mode really changes the arithmetic
+    # teacher-forced conv stack: same fp32 input => same bf16 operands => only the accumulation order differs
+    acts = [m.activation(f"conv{i}") for i in range(len(cfg.kernal_sizes))]
+    for i in range(1, len(cfg.kernal_sizes)):
+        base = f"feature_extractor/conv_layers/{i}"
+        bias = w.get(f"{base}/conv/bias") if cfg.conv_bias else None
+        y = O.conv1d_valid(O.round_bf16(acts[i - 1]).astype(np.float64), O.round_bf16(w[f"{base}/conv/kernel"]).astype(np.float64),
+                           cfg.strides[i], None if bias is None else bias.astype(np.float64))
+        if cfg.feature_extractor_norm_type == "layer":
+            y = O.layer_norm(y, w[f"{base}/layer_norm/gamma"].astype(np.float64), w[f"{base}/layer_norm/beta"].astype(np.float64), 1e-5)
+        e = H.max_err(acts[i], O.gelu(y))
+        assert e < 3e-5 * max(1.0, np.abs(y).max()), f"conv{i}: {e:.3e}"
+    m.set_precision("fp32")
+    assert np.array_equal(m(g["wave"], attention_mask=mask).numpy(), fp32)
+
+
+def test_set_precision_rejects_unknown(torch_mod):
+    m, cfg = build("tiny_base")
+    with pytest.raises(ValueError):
+        m.set_precision("fp8")
+
+
 def test_backbone_model_output(torch_mod):
     """Wav2Vec2Model returns hidden states (reference test_inference compares these)."""
     g = H.golden("base_sample_unpadded")

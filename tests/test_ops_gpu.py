@@ -118,6 +118,65 @@ def test_gemm_rejects_bad_arguments(env):
     assert lib.w2v2_op_gemm(None, 4, 0, N.ptr(t), 4, N.ptr(t), 4, 0, None, None, 4, 4, 4, 1, 0, stream()) == -1
 
 
+# ---------------------------------------------------------------- bf16-operand GEMM ----
+@pytest.mark.parametrize("M,N_,K,act,use_bias,use_res", [
+    (128, 128, 64, 0, False, False), (300, 130, 128, 1, True, False), (257, 32, 192, 0, True, True),
+    (1000, 770, 100, 2, True, False), (65, 3, 7, 0, False, True), (2048, 768, 3072, 0, True, True),
+    (515, 2304, 768, 0, True, False)])
+def test_gemm_bf16_matches_rounded_operands(env, M, N_, K, act, use_bias, use_res):
+    """W2V2_PRECISION_BF16's GEMM == exact products of nearest-even bf16 operands, wide accumulation, fp32
+    epilogue.  Both the 16-byte fast path and the guarded path (odd K / N) are covered."""
+    lib, torch, dev = env
+    A, B = rnd("A16", (M, K)), rnd("B16", (K, N_), 0.2)
+    bias = rnd("bias16", (N_,)) if use_bias else None
+    res = rnd("res16", (M, N_)) if use_res else None
+    ref = O.round_bf16(A).astype(np.float64) @ O.round_bf16(B).astype(np.float64)
+    if use_bias:
+        ref = ref + bias
+    if act:
+        ref = O.gelu(ref, approximate=(act == 2))
+    if use_res:
+        ref = ref + res
+    tb = dev_t(torch, dev, bias) if use_bias else None
+    tr = dev_t(torch, dev, res) if use_res else None
+    out = torch.full((M, N_), float("nan"), device=dev)
+    N.check(lib.w2v2_op_gemm_bf16(N.ptr(dev_t(torch, dev, A)), K, 0, N.ptr(dev_t(torch, dev, B)), N_, N.ptr(out), N_, 0,
+                                  N.ptr(tb), N.ptr(tr), M, N_, K, 1, act, stream()))
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert H.max_err(got, ref) < 2e-5 * max(1.0, np.abs(ref).max())       # fp32 accumulation order only
+    exact = A.astype(np.float64) @ B.astype(np.float64)
+    assert H.max_err(O.round_bf16(A).astype(np.float64) @ O.round_bf16(B).astype(np.float64), exact) > 1e-4 or K < 16
+
+
+def test_gemm_bf16_transpose_detecting(env):
+    """A = I with an ASYMMETRIC bf16-exact B: a swapped k-pairing or C row/col map cannot pass."""
+    lib, torch, dev = env
+    n = 192
+    A = np.eye(n, dtype=np.float32)
+    B = ((np.arange(n)[:, None] % 16) * 16 + (np.arange(n)[None, :] % 13) + 1).astype(np.float32)   # < 256: exact in bf16
+    B *= np.where(np.arange(n)[:, None] > np.arange(n)[None, :], 1.0, -1.0).astype(np.float32)
+    out = torch.empty((n, n), device=dev)
+    N.check(lib.w2v2_op_gemm_bf16(N.ptr(dev_t(torch, dev, A)), n, 0, N.ptr(dev_t(torch, dev, B)), n, N.ptr(out), n, 0,
+                                  None, None, n, n, n, 1, 0, stream()))
+    assert np.array_equal(out.cpu().numpy(), B)
+
+
+@pytest.mark.parametrize("Tin,Cin,Cout,k,s,B", [(203, 64, 96, 3, 2, 3), (101, 32, 32, 2, 2, 2), (49199 // 16, 512, 512, 3, 2, 1)])
+def test_strided_conv_as_overlapping_gemm_bf16(env, Tin, Cin, Cout, k, s, B):
+    lib, torch, dev = env
+    x, w = rnd("x16", (B, Tin, Cin)), rnd("w16", (k, Cin, Cout), 0.1)
+    bias = rnd("cb16", (Cout,))
+    ref = O.gelu(O.conv1d_valid(O.round_bf16(x).astype(np.float64), O.round_bf16(w).astype(np.float64), s, bias.astype(np.float64)))
+    Tout = 1 + (Tin - k) // s
+    out = torch.empty((B, Tout, Cout), device=dev)
+    N.check(lib.w2v2_op_gemm_bf16(N.ptr(dev_t(torch, dev, x)), s * Cin, Tin * Cin, N.ptr(dev_t(torch, dev, w)), Cout,
+                                  N.ptr(out), Cout, Tout * Cout, N.ptr(dev_t(torch, dev, bias)), None, Tout, Cout, k * Cin,
+                                  B, 1, stream()))
+    assert H.max_err(out.cpu().numpy(), ref) < 3e-5 * max(1.0, np.abs(ref).max())
+
+
+
 # ---------------------------------------------------------------- LayerNorm -----
 @pytest.mark.parametrize("rows,Cn,act", [(37, 512, 0), (5, 768, 1), (130, 1024, 0), (9, 64, 0), (3, 50, 0), (4, 1500, 1)])
 def test_layer_norm(env, rows, Cn, act):

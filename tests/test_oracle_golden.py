@@ -102,3 +102,27 @@ def test_frame_lengths():
     m[1, 46797:] = 0
     assert list(O.frame_lengths(cfg, m)) == [768, 145]
     assert cfg.num_frames(246000) == 768 and cfg.num_frames(480000) == 1499
+
+
+def test_bf16_rounding_emulation_matches_torch_bfloat16():
+    """oracle.round_bf16 (the restatement of v_cvt_pk_bf16_f32's nearest-even rounding) is bit-identical to
+    torch's float32 -> bfloat16 conversion, including ties, denormal-sized and large values."""
+    import torch
+    rng = np.random.RandomState(3)
+    x = np.concatenate([rng.randn(100000).astype(np.float32) * s for s in (1e-30, 1e-3, 1.0, 1e5, 1e30)])
+    ties = (np.arange(1, 4097, dtype=np.uint32) << 16 | 0x8000).view(np.float32)       # exactly half-way cases
+    x = np.concatenate([x, ties, -ties, np.array([0.0, -0.0, 1.0, 3.0e38], np.float32)])
+    want = torch.from_numpy(x).to(torch.bfloat16).to(torch.float32).numpy()
+    got = O.round_bf16(x)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_bf16_operand_mode_is_a_small_perturbation():
+    g = H.golden("tiny_base")
+    cfg, w = H.case_config("tiny_base"), H.case_weights("tiny_base")
+    base = O.ctc_forward(cfg, w, g["wave"])
+    with H.oracle_operands("bf16"):
+        low = O.ctc_forward(cfg, w, g["wave"])
+    assert O.GEMM_OPERANDS is None
+    d = H.max_err(low, base)
+    assert 1e-5 < d < 0.1

@@ -227,6 +227,35 @@ def test_gradients_match_autograd_base_dims(env):
     print("worst relative gradient error (base dims)", worst)
 
 
+def test_bf16_precision_training_step(env):
+    """bf16 fine-tune arithmetic (BASELINE configs 3 / 5): training-mode logits equal the torch oracle with
+    bf16-rounded Dense operands; gradients agree at a bf16-sized tolerance (the build also rounds dY inside its
+    backward GEMMs, autograd's straight-through rounding does not)."""
+    import wav2vec2
+    L = 12000
+    m, cfg, w = build("base_sample_padded", L)
+    m.set_precision("bf16")
+    x = V.hash_normal("train/wave16", 2 * L, 8).reshape(2, L)
+    labels = np.array([[5, 9, 9, 11, 0, 0], [7, 6, 0, 0, 0, 0]], np.int32)
+    loss_fn = wav2vec2.CTCLoss(cfg, x.shape, division_factor=2)
+    tr = wav2vec2.Trainer(m, loss_fn, dropout=0.1, apply_spec_augment=False, seed=1)
+    T = cfg.num_frames(L)
+    spec = compute_mask_indices((2, T), 0.05, 10, rng=np.random.RandomState(4))
+    logits = tr.forward(x, spec_mask=spec, step_seed=42)
+    nll, dlog = loss_fn.per_sample(labels, logits, with_grad=True)
+    tr.backward(dlog)
+    with H.oracle_operands("bf16"):
+        loss, ref_nll, ref_logits, ref_grads = TT.loss_and_grads(cfg, w, x, labels, p=0.1, seed=42, spec_mask=spec, division_factor=2)
+    err = H.max_err(logits.cpu().numpy(), ref_logits)
+    print("bf16 training logits vs rounded-operand oracle", err)
+    assert err < 0.15                      # bf16-sized bar, see tests/test_model_gpu.py::ATOL_BF16_LOGITS
+    assert np.allclose(nll.cpu().numpy(), ref_nll, rtol=2e-2)
+    worst = grads_close(tr, ref_grads, rtol=6e-2)
+    print("worst relative gradient error (bf16 operands)", worst)
+    fp32_loss, _, _, fp32_grads = TT.loss_and_grads(cfg, w, x, labels, p=0.1, seed=42, spec_mask=spec, division_factor=2)
+    assert abs(loss - fp32_loss) / abs(fp32_loss) < 2e-2
+
+
 def test_stage1_only_lm_head_trains(env):
     import wav2vec2
     g = H.golden("tiny_base")

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.join(ROOT, "gsoc-wav2vec2_amd"))
 import torch
 from wav2vec2 import _native as N
 
-ap = argparse.ArgumentParser(); ap.add_argument("--iters", type=int, default=10); ap.add_argument("--batch", type=int, default=32)
+ap = argparse.ArgumentParser(); ap.add_argument("--iters", type=int, default=10); ap.add_argument("--batch", type=int, default=32); ap.add_argument("--bf16", action="store_true")
 args = ap.parse_args()
 lib = N.load(); dev = torch.device("cuda:0"); B = args.batch
 T = [49199, 24599, 12299, 6149, 3074, 1537, 768]
@@ -25,7 +25,7 @@ for name, M, Nn, K, lda, sA, nb, act, ub, ur in shapes:
     C = torch.empty(nb * M * Nn, device=dev); bias = torch.randn(Nn, device=dev); R = torch.randn(nb * M * Nn, device=dev) if ur else None
     st = N.current_stream()
     def run():
-        N.check(lib.w2v2_op_gemm(N.ptr(A), lda, sA, N.ptr(Bm), Nn, N.ptr(C), Nn, M * Nn, N.ptr(bias) if ub else None,
+        N.check((lib.w2v2_op_gemm_bf16 if args.bf16 else lib.w2v2_op_gemm)(N.ptr(A), lda, sA, N.ptr(Bm), Nn, N.ptr(C), Nn, M * Nn, N.ptr(bias) if ub else None,
                                  N.ptr(R), M, Nn, K, nb, act, st))
     run(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
