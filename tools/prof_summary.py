@@ -44,7 +44,7 @@ def stats(src, dst):
     # GEMM launches by launch geometry (one row per distinct shape)
     by = defaultdict(list)
     for t in trace:
-        if "gemm_f32_kernel" in t["Kernel_Name"]:
+        if "gemm_f32" in t["Kernel_Name"] or "gemm_bf16" in t["Kernel_Name"]:
             key = (int(t["Grid_Size_X"]) // int(t["Workgroup_Size_X"]), int(t["Grid_Size_Z"]))
             by[key].append((int(t["End_Timestamp"]) - int(t["Start_Timestamp"])) / 1e3)
     out += ["", "GEMM launches by geometry (tiles x batch):", "", "| tiles | batch | calls | avg us | min us |", "|---|---|---|---|---|"]
