@@ -592,6 +592,8 @@ int launch_attention(Profiler* prof, const float* qkv, const int32_t* frame_len,
     AttnArgs a{qkv, frame_len, ctx, B, T, H, heads, 1.0f / sqrtf((float)dh)};
     ProfScope ps(prof, FAM_ATTENTION, 4.0 * B * (double)heads * T * (double)T * dh,
                  4.0 * B * (double)T * 4.0 * H, s);
+    if (gemm_get_precision() == 1 && attention_bf16_supported(dh))
+        return launch_attention_fwd_bf16(qkv, frame_len, ctx, B, T, H, heads, nullptr, s);
     switch (dh) {
         case 32: return launch_attn<32>(a, s);
         case 64: return launch_attn<64>(a, s);
@@ -613,6 +615,8 @@ int launch_attention_train(Profiler* prof, const float* qkv, const int32_t* fram
     const int dh = H / heads;
     AttnArgs a{qkv, frame_len, ctx, B, T, H, heads, 1.0f / sqrtf((float)dh)};
     ProfScope ps(prof, FAM_ATTENTION, 4.0 * B * (double)heads * T * (double)T * dh, 4.0 * B * (double)T * 4.0 * H, s);
+    if (gemm_get_precision() == 1 && attention_bf16_supported(dh))
+        return launch_attention_fwd_bf16(qkv, frame_len, ctx, B, T, H, heads, &tr, s);
     switch (dh) {
         case 32: return launch_attn_train<32>(a, tr, s);
         case 64: return launch_attn_train<64>(a, tr, s);
@@ -630,6 +634,10 @@ int launch_attention_bwd(Profiler* prof, const float* qkv, const int32_t* frame_
     const int dh = H / heads;
     AttnBwdArgs a{qkv, frame_len, dctx, dvec_ws, dqkv, B, T, H, heads, 1.0f / sqrtf((float)dh)};
     ProfScope ps(prof, FAM_ATTENTION, 10.0 * B * (double)heads * T * (double)T * dh, 4.0 * B * (double)T * 8.0 * H, s);
+    if (gemm_get_precision() == 1 && attention_bf16_supported(dh)) {
+        hipLaunchKernelGGL(attn_dvec_kernel<64>, dim3((unsigned)((int64_t)B * T)), dim3(256), 0, s, ctx, dctx, dvec_ws, B, T, H, heads);
+        return launch_attention_bwd_bf16(qkv, frame_len, dctx, dvec_ws, dqkv, B, T, H, heads, tr, s);
+    }
     switch (dh) {
         case 32: return launch_attn_bwd<32>(a, tr, ctx, dvec_ws, s);
         case 64: return launch_attn_bwd<64>(a, tr, ctx, dvec_ws, s);

@@ -15,30 +15,34 @@ enum DropStream : uint32_t {
 };
 
 #ifdef __HIPCC__
-// keep(seed, stream, idx, p): counter-based hash, 32-bit arithmetic only (one VALU op per step; the earlier
-// 64-bit splitmix cost ~40 VALU ops per element and made the attention kernels VALU-heavy).
-//   (k1, k2) = two 32-bit halves of splitmix64(seed ^ stream * GOLD)        -- loop-invariant
-//   h = lowbias32(lo32(idx) ^ k1);  h = lowbias32(h + hi32(idx) * 0x9E3779B1 + k2);  keep = h >= floor(p * 2^32)
-// The same integer function as wav2vec2/variables.py::dropout_keep.
+// keep(seed, stream, idx, p): counter-based hash, 32-bit arithmetic only (the attention kernels evaluate it
+// once per score; the first version used 64-bit splitmix per element, ~40 VALU ops, this is ~10):
+//   k   = low 32 bits of splitmix64(seed ^ stream * GOLD)                     -- loop-invariant
+//   h   = lowbias32(lo32(idx) * 0x9E3779B1 ^ k)   (Fibonacci pre-multiply spreads the sequential counter, then a
+//                                               bijective multiply-xorshift mixer; lagged mask correlations < 1e-3)
+//   keep = h >= floor(p * 2^32)
+// The element index enters modulo 2^32: a mask pattern repeats after 4.29e9 elements of one tensor (the largest
+// here, the (B, heads, T, T) probabilities at B=16, T=1499, has 5.8e8).  Same integer function as
+// wav2vec2/variables.py::dropout_keep.
 __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
-__device__ __forceinline__ uint64_t dropout_key(uint64_t seed, uint32_t stream) {
+__device__ __forceinline__ uint32_t dropout_key(uint64_t seed, uint32_t stream) {
     uint64_t z = (seed ^ ((uint64_t)stream * 0x9E3779B97F4A7C15ULL)) + 0x9E3779B97F4A7C15ULL;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    return z ^ (z >> 31);
-}
-__device__ __forceinline__ uint32_t dropout_hash(uint64_t key, uint64_t idx) {
-    uint32_t h = lowbias32((uint32_t)idx ^ (uint32_t)key);
-    return lowbias32(h + (uint32_t)(idx >> 32) * 0x9E3779B1u + (uint32_t)(key >> 32));
+    return (uint32_t)(z ^ (z >> 31));
 }
 __device__ __forceinline__ uint32_t dropout_threshold(float p) {
     return (uint32_t)((double)p * 4294967296.0);
 }
+// fast form for inner loops: key and threshold hoisted by the caller, 32-bit index
+__device__ __forceinline__ bool dropout_keep32(uint32_t key, uint32_t idx, uint32_t thr) {
+    return lowbias32(idx * 0x9E3779B1u ^ key) >= thr;
+}
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t stream, uint64_t idx, float p) {
-    return dropout_hash(dropout_key(seed, stream), idx) >= dropout_threshold(p);
+    return dropout_keep32(dropout_key(seed, stream), (uint32_t)idx, dropout_threshold(p));
 }
 #endif
 
@@ -66,6 +70,12 @@ struct AttnTrain {
     uint32_t stream;
     float* lse;        // (B, heads, T) log-sum-exp of the (masked) scores, written by forward, read by backward
 };
+// bf16 matrix-pipe attention (attention_bf16.hip); taken by launch_attention* while the thread's precision is 1
+bool attention_bf16_supported(int head_size);
+int launch_attention_fwd_bf16(const float* qkv, const int32_t* frame_len, float* ctx, int B, int T, int H, int heads,
+                              const AttnTrain* tr, hipStream_t s);
+int launch_attention_bwd_bf16(const float* qkv, const int32_t* frame_len, const float* dctx, const float* dvec,
+                              float* dqkv, int B, int T, int H, int heads, const AttnTrain& tr, hipStream_t s);
 int launch_attention_train(Profiler* prof, const float* qkv, const int32_t* frame_len, float* ctx, int B, int T,
                            int H, int heads, const AttnTrain& tr, hipStream_t s);
 // dqkv (B, T, 3H) = gradient of the packed q|k|v given dctx (B, T, H); ctx is the forward output

@@ -561,6 +561,11 @@ int w2v2_op_gemm(const float* A, int64_t lda, int64_t strideA, const float* B, i
     return launch_gemm(nullptr, A, lda, strideA, B, ldb, C, ldc, strideC, bias, residual, M, N, K, nbatch, act,
                        reinterpret_cast<hipStream_t>(stream));
 }
+int w2v2_op_set_precision(int32_t mode) {
+    W2V2_REQUIRE(mode == W2V2_PRECISION_FP32 || mode == W2V2_PRECISION_BF16, "op_set_precision: unknown mode %d", mode);
+    gemm_set_precision(mode);
+    return W2V2_OK;
+}
 int w2v2_op_gemm_bf16(const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb, float* C,
                       int64_t ldc, int64_t strideC, const float* bias, const float* residual, int32_t M,
                       int32_t N, int32_t K, int32_t nbatch, int32_t act, void* stream) {

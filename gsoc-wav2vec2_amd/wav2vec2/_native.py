@@ -79,6 +79,7 @@ PROTOTYPES = {
                                     C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "w2v2_profile_reset": (C.c_int, [_P]),
     "w2v2_op_gemm": (C.c_int, [_P, _I64, _I64, _P, _I64, _P, _I64, _I64, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
+    "w2v2_op_set_precision": (C.c_int, [_I32]),
     "w2v2_op_gemm_bf16": (C.c_int, [_P, _I64, _I64, _P, _I64, _P, _I64, _I64, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "w2v2_op_layer_norm": (C.c_int, [_P, _P, _P, _P, _I64, _I32, C.c_float, _I32, _P]),
     "w2v2_conv0_ws_floats": (_I64, [_I32, _I64, _I32, _I32, _I32]),

@@ -256,18 +256,15 @@ def _lowbias32(x):
 
 
 def dropout_hash(seed, stream, n, start=0):
-    """uint32 hash per element index, identical to csrc/train.h::dropout_hash (integer arithmetic only)."""
+    """uint32 hash per element index, identical to csrc/train.h (integer arithmetic only): one lowbias32 round
+    over ((index mod 2^32) * 0x9E3779B1) xor a per-(seed, stream) key."""
     key0 = np.array([(int(seed) ^ ((int(stream) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF],
                     dtype=np.uint64)
-    key = int(_splitmix64(key0)[0])
-    k1, k2 = np.uint32(key & 0xFFFFFFFF), np.uint32(key >> 32)
+    key = np.uint32(int(_splitmix64(key0)[0]) & 0xFFFFFFFF)
     idx = np.arange(start, start + n, dtype=np.uint64)
     lo = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-    hi = (idx >> np.uint64(32)).astype(np.uint32)
-    h = _lowbias32(lo ^ k1)
     with np.errstate(over="ignore"):
-        h = h + hi * np.uint32(0x9E3779B1) + k2
-    return _lowbias32(h)
+        return _lowbias32((lo * np.uint32(0x9E3779B1)) ^ key)
 
 
 def dropout_keep(seed, stream, n, p):

@@ -109,7 +109,9 @@ int64_t w2v2_num_frames(const w2v2_model* m, int64_t num_samples);
  *   W2V2_PRECISION_BF16  operands rounded to bf16 (nearest-even) on the way into LDS, fp32 accumulation,
  *                        fp32 bias / GELU / residual / storage: what BASELINE configs "bf16 CTC fine-tune"
  *                        ask for (mixed precision; variables, optimizer state and activations stay fp32).
- * Everything else (conv0 + GroupNorm, LayerNorm, positional conv, attention, CTC) is fp32 in both modes. */
+ *                        Attention (head size 64) takes bf16 q, k, v and probabilities on the same pipe with
+ *                        fp32 scores / softmax / accumulation.
+ * Everything else (conv0 + GroupNorm, LayerNorm, positional conv, CTC) is fp32 in both modes. */
 #define W2V2_PRECISION_FP32 0
 #define W2V2_PRECISION_BF16 1
 int w2v2_set_precision(w2v2_model* m, int32_t mode);
@@ -205,6 +207,10 @@ int w2v2_op_gemm(const float* A_dev, int64_t lda, int64_t strideA,
                  float* C_dev, int64_t ldc, int64_t strideC,
                  const float* bias_dev, const float* residual_dev,
                  int32_t M, int32_t N, int32_t K, int32_t nbatch, int32_t act, void* stream);
+
+/* Precision of the w2v2_op_* calls issued by the calling thread from now on (per-kernel tests of the bf16
+ * mode); model-level calls take the model's own setting (w2v2_set_precision) and restore this one. */
+int w2v2_op_set_precision(int32_t mode);
 
 /* Same contract, operands rounded to bf16 / fp32 accumulate (W2V2_PRECISION_BF16's GEMM). */
 int w2v2_op_gemm_bf16(const float* A_dev, int64_t lda, int64_t strideA,

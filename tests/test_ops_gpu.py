@@ -292,6 +292,47 @@ def test_attention(env, B, T, Hh, heads, flen):
     assert H.max_err(got, ref) < 2e-5
 
 
+@pytest.fixture
+def bf16_ops(env):
+    """Per-kernel calls in W2V2_PRECISION_BF16 for the duration of one test."""
+    lib = env[0]
+    N.check(lib.w2v2_op_set_precision(1))
+    yield
+    N.check(lib.w2v2_op_set_precision(0))
+
+
+@pytest.mark.parametrize("B,T,Hh,heads,flen", [(1, 145, 768, 12, None), (2, 768, 128, 2, None), (2, 200, 128, 2, [200, 61]),
+                                                (1, 97, 64, 1, [0]), (2, 64, 64, 1, None), (1, 33, 128, 2, None)])
+def test_attention_bf16(env, bf16_ops, B, T, Hh, heads, flen):
+    """bf16 matrix-pipe attention (head size 64): q d^-0.5, k, v and the probabilities enter the two contractions
+    rounded to bf16, everything else fp32.  Checked against the fp64 formula on bf16-rounded q, k, v; what is
+    left is the rounding of P (2^-9 relative per term, averaging out over the keys) -- a layout or key-order
+    mistake would show up at O(1)."""
+    lib, torch, dev = env
+    d = Hh // heads
+    assert d == 64
+    qkv = rnd("qkv16", (B, T, 3 * Hh), 2.0)
+    q, k, v = [qkv[:, :, i * Hh:(i + 1) * Hh].reshape(B, T, heads, d).transpose(0, 2, 1, 3) for i in range(3)]
+    q = O.round_bf16(q * np.float32(d ** -0.5)).astype(np.float64)
+    k, v = O.round_bf16(k).astype(np.float64), O.round_bf16(v).astype(np.float64)
+    s = q @ k.transpose(0, 1, 3, 2)
+    if flen is not None:
+        keep = np.arange(T)[None, :] < np.asarray(flen)[:, None]
+        s = (s.astype(np.float32) + ((1.0 - keep) * -10000.0)[:, None, None, :].astype(np.float32)).astype(np.float64)
+    s = s - s.max(-1, keepdims=True)
+    p = np.exp(s)
+    p /= p.sum(-1, keepdims=True)
+    ref = (p @ v).transpose(0, 2, 1, 3).reshape(B, T, Hh)
+    tf = dev_t(torch, dev, np.asarray(flen, dtype=np.int32)) if flen is not None else None
+    out = torch.full((B, T, Hh), float("nan"), device=dev)
+    N.check(lib.w2v2_op_attention(N.ptr(dev_t(torch, dev, qkv)), N.ptr(tf), N.ptr(out), B, T, Hh, heads, stream()))
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    err = np.abs(got - ref)
+    print(f"bf16 attention: max err {err.max():.3e}, mean err {err.mean():.3e}, max|ref| {np.abs(ref).max():.3f}")
+    assert err.max() < 2e-2 and err.mean() < 2e-3
+
+
 def test_attention_softmax_spike(env):
     """One key dominating by ~60 nats mid-sequence: forces the online-softmax rescale."""
     lib, torch, dev = env

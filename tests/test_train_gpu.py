@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import helpers as H
+from oracle import w2v2_oracle as O
 from oracle import w2v2_torch_train as TT
 from wav2vec2 import _native as N
 from wav2vec2 import variables as V
@@ -120,6 +121,63 @@ def test_attention_train_forward_backward(env, B, T, Hh, heads, p, flen):
     for name, sl in (("dq", slice(0, Hh)), ("dk", slice(Hh, 2 * Hh)), ("dv", slice(2 * Hh, 3 * Hh))):
         e = H.max_err(got[:, :, sl], ref[:, :, sl])
         assert e < 5e-5 * max(1.0, np.abs(ref[:, :, sl]).max()), f"{name}: {e:.3e}"
+
+
+@pytest.mark.parametrize("B,T,Hh,heads,p,flen", [(2, 150, 128, 2, 0.1, None), (1, 200, 768, 12, 0.1, None),
+                                                  (2, 97, 128, 2, 0.2, [97, 40]), (1, 64, 64, 1, 0.0, None)])
+def test_attention_train_forward_backward_bf16(env, B, T, Hh, heads, p, flen):
+    """bf16 matrix-pipe attention, training forward + backward (head size 64): torch autograd in fp64 on
+    bf16-rounded q d^-0.5, k, v.  Unrounded in the reference: P, dO, dS -- their 2^-9 relative roundings average
+    out over the contraction, so the bar is 1e-2 of the gradient's magnitude (a layout error shows at O(1))."""
+    lib, torch, dev = env
+    d = Hh // heads
+    assert d == 64
+    seed, stream = 991, 16
+    qkv = rnd("aq16", (B, T, 3 * Hh), 1.5)
+    dctx = rnd("ad16", (B, T, Hh))
+    qkv_r = qkv.copy()
+    qkv_r[:, :, :Hh] = O.round_bf16(qkv[:, :, :Hh] * np.float32(0.125)) * 8.0     # scale is a power of two
+    qkv_r[:, :, Hh:] = O.round_bf16(qkv[:, :, Hh:])
+    qt = torch.from_numpy(qkv_r.astype(np.float64)).requires_grad_(True)
+    q, k, v = [qt[:, :, i * Hh:(i + 1) * Hh].reshape(B, T, heads, d).transpose(1, 2) for i in range(3)]
+    s = (q * d ** -0.5) @ k.transpose(-1, -2)
+    if flen is not None:
+        keepk = torch.from_numpy(np.arange(T)[None, :] < np.asarray(flen)[:, None])
+        s = s + ((~keepk).double() * -10000.0)[:, None, None, :]
+    pr = torch.softmax(s, -1)
+    lse_ref = torch.logsumexp(s, -1).detach().numpy()
+    if p > 0:
+        keep = torch.from_numpy(V.dropout_keep(seed, stream, B * heads * T * T, p).reshape(B, heads, T, T))
+        pr = torch.where(keep, pr / (1 - p), torch.zeros_like(pr))
+    ctx_ref = (pr @ v).transpose(1, 2).reshape(B, T, Hh)
+    ctx_ref.backward(torch.from_numpy(dctx.astype(np.float64)))
+
+    N.check(lib.w2v2_op_set_precision(1))
+    try:
+        tq = dev_t(torch, dev, qkv)
+        tf = dev_t(torch, dev, np.asarray(flen, dtype=np.int32)) if flen is not None else None
+        ctx = torch.full((B, T, Hh), float("nan"), device=dev)
+        lse = torch.full((B, heads, T), float("nan"), device=dev)
+        N.check(lib.w2v2_op_attention_train(N.ptr(tq), N.ptr(tf), N.ptr(ctx), N.ptr(lse), B, T, Hh, heads, p,
+                                            C.c_uint64(seed), stream, N.current_stream()))
+        dqkv = torch.full((B, T, 3 * Hh), float("nan"), device=dev)
+        ws = torch.empty((B, heads, T), device=dev)
+        N.check(lib.w2v2_op_attention_bwd(N.ptr(tq), N.ptr(tf), N.ptr(ctx), N.ptr(lse), N.ptr(dev_t(torch, dev, dctx)), N.ptr(dqkv),
+                                          N.ptr(ws), B, T, Hh, heads, p, C.c_uint64(seed), stream, N.current_stream()))
+        torch.cuda.synchronize()
+    finally:
+        N.check(lib.w2v2_op_set_precision(0))
+    e_ctx = H.max_err(ctx.cpu().numpy(), ctx_ref.detach().numpy())
+    e_lse = H.max_err(lse.cpu().numpy(), lse_ref)
+    print(f"bf16 attention train: ctx err {e_ctx:.3e}, lse err {e_lse:.3e}")
+    assert e_ctx < 1e-2 and e_lse < 1e-4          # scores are fp32 sums of exact products: lse is tight
+    got, ref = dqkv.cpu().numpy(), qt.grad.numpy()
+    assert np.isfinite(got).all()
+    for name, sl in (("dq", slice(0, Hh)), ("dk", slice(Hh, 2 * Hh)), ("dv", slice(2 * Hh, 3 * Hh))):
+        err = np.abs(got[:, :, sl] - ref[:, :, sl])
+        scale = max(1.0, np.abs(ref[:, :, sl]).max())
+        print(f"   {name}: max err {err.max():.3e}, mean err {err.mean():.3e}, max|ref| {scale:.3f}")
+        assert err.max() < 1e-2 * scale and err.mean() < 1e-3 * scale, f"{name}: {err.max():.3e}"
 
 
 # ------------------------------------------------------------------ whole step ---------------
