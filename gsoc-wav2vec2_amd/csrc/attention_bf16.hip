@@ -43,6 +43,7 @@ struct Attn16Args {
     const float* qkv;           // (B, T, 3H): q | k | v
     const int32_t* frame_len;   // (B) or null
     float* ctx;                 // (B, T, H)
+    uint16_t* ctx16;            // optional bf16 shadow of ctx (the out-projection GEMM's A operand)
     int B, T, H, heads;
     float scale;
 };
@@ -255,6 +256,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_bf16_kernel(Attn16Args a
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<f32x4*>(op + 32 * d + 8 * g) =
                     f32x4{o[d][4 * g] * inv, o[d][4 * g + 1] * inv, o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv};
+        if (a.ctx16) {      // bf16 shadow for the out-projection GEMM
+            uint16_t* hp = a.ctx16 + ((int64_t)b * a.T + q) * a.H + head * DH + 4 * lh;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<u32x2*>(hp + 32 * d + 8 * g) =
+                        u32x2{pack_bf16(o[d][4 * g] * inv, o[d][4 * g + 1] * inv), pack_bf16(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv)};
+        }
     }
 }
 
@@ -592,10 +602,10 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
 bool attention_bf16_supported(int head_size) { return head_size == DH; }
 
 // tr == nullptr: inference.  Otherwise the training forward (dropout on P, lse saved).
-int launch_attention_fwd_bf16(const float* qkv, const int32_t* frame_len, float* ctx, int B, int T, int H, int heads,
-                              const AttnTrain* tr, hipStream_t s) {
+int launch_attention_fwd_bf16(const float* qkv, const int32_t* frame_len, float* ctx, uint16_t* ctx16, int B, int T, int H,
+                              int heads, const AttnTrain* tr, hipStream_t s) {
     W2V2_REQUIRE(H / heads == DH, "attention_bf16: head size %d unsupported (64)", H / heads);
-    Attn16Args a{qkv, frame_len, ctx, B, T, H, heads, 1.0f / sqrtf((float)DH)};
+    Attn16Args a{qkv, frame_len, ctx, ctx16, B, T, H, heads, 1.0f / sqrtf((float)DH)};
     const size_t lds = 2 * 2 * KT * ROWB;
     dim3 grid((T + NW * 32 - 1) / (NW * 32), heads, B), block(NW * 64);
     if (tr)

@@ -83,6 +83,20 @@ int launch_gemm(Profiler* prof, const float* A, int64_t lda, int64_t strideA, co
 int launch_gemm_bf16(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
                      int64_t strideB, float* C, int64_t ldc, int64_t strideC, const float* bias,
                      const float* residual, int M, int N, int K, int nbatch, int act, hipStream_t s);
+// Optional bf16 shadows of the operands (precision mode 1).  A shadow holds nearest-even bf16 roundings of the fp32
+// tensor -- exactly what the kernel would round to itself -- so using one changes speed, never results.
+//   A16: same shape / strides (in elements) as A;   B16: B TRANSPOSED, [N][K] with row stride ldb16 (0 = K);
+//   C16: bf16 copy of the output for the consumer GEMM (C itself may then be null: the fp32 store is skipped).
+struct GemmShadows {
+    const uint16_t* A16 = nullptr;
+    const uint16_t* B16 = nullptr;
+    uint16_t* C16 = nullptr;
+    int64_t ldb16 = 0;
+};
+int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
+                       int64_t strideB, float* C, int64_t ldc, int64_t strideC, const float* bias,
+                       const float* residual, int M, int N, int K, int nbatch, int act, const GemmShadows& x,
+                       hipStream_t s);
 // launch_gemm / launch_gemm_ex route to launch_gemm_bf16 while the calling thread's precision is 1.  The
 // API entry points set it from the model for the duration of one call (PrecisionScope).
 void gemm_set_precision(int mode);
@@ -99,10 +113,20 @@ int launch_gemm_ex(Profiler* prof, const float* A, int64_t lda, int64_t strideA,
 int launch_layer_norm(Profiler* prof, const float* x, float* y, const float* gamma,
                       const float* beta, int64_t rows, int C, float eps, int act, hipStream_t s);
 
+int launch_layer_norm_x(Profiler* prof, const float* x, float* y, const float* gamma, const float* beta, int64_t rows,
+                        int C, float eps, int act, uint16_t* y16 /* optional bf16 shadow of y */, hipStream_t s);
+
 int64_t conv0_ws_floats(int B, int64_t L, int K, int stride, int C);
 int launch_conv0(Profiler* prof, const float* wave, const float* kernel, const float* bias,
                  const float* gamma, const float* beta, float* out, float* ws, int B, int64_t L,
                  int K, int stride, int C, float eps, int norm_mode, int act, hipStream_t s);
+
+int launch_conv0_x(Profiler* prof, const float* wave, const float* kernel, const float* bias,
+                   const float* gamma, const float* beta, float* out, uint16_t* out16 /* optional bf16 shadow */, float* ws,
+                   int B, int64_t L, int K, int stride, int C, float eps, int norm_mode, int act, hipStream_t s);
+// fp32 -> bf16 (nearest even): plain copy, and [K][N] -> [N][K] transpose (GEMM weight shadows)
+int launch_to_bf16(const float* x, uint16_t* y, int64_t n, hipStream_t s);
+int launch_transpose_to_bf16(const float* w, uint16_t* wt, int K, int N, hipStream_t s);
 
 int launch_weight_norm_regroup(Profiler* prof, const float* wv, const float* wg, float* out, int K,
                                int cg, int H, int groups, hipStream_t s);
@@ -112,6 +136,10 @@ int launch_pos_conv(Profiler* prof, const float* x, const float* wg, const float
 
 int launch_attention(Profiler* prof, const float* qkv, const int32_t* frame_len, float* ctx, int B,
                      int T, int H, int heads, hipStream_t s);
+
+bool attention_bf16_supported(int head_size);   // attention_bf16.hip: head size 64
+int launch_attention_x(Profiler* prof, const float* qkv, const int32_t* frame_len, float* ctx, int B, int T, int H,
+                       int heads, uint16_t* ctx16 /* optional bf16 shadow of ctx (bf16 kernel only) */, hipStream_t s);
 
 int launch_frame_lengths(Profiler* prof, const int32_t* mask, int32_t* frame_len, int B, int64_t L,
                          const int32_t* ks, const int32_t* ss, int nl, hipStream_t s);
@@ -132,6 +160,12 @@ __device__ __forceinline__ float gelu_tanh(float x) {
 }
 __device__ __forceinline__ float apply_act(float x, int act) {
     return act == 1 ? gelu_erf(x) : (act == 2 ? gelu_tanh(x) : x);
+}
+// two fp32 -> one dword of two bf16, nearest even (gfx950 v_cvt_pk_bf16_f32; no builtin in ROCm 7.2)
+__device__ __forceinline__ unsigned pack_bf16_rne(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
 }
 // wave64 all-reduce sum via DPP/shuffles
 __device__ __forceinline__ float wave_sum(float v) {

@@ -30,6 +30,7 @@ struct Conv0Args {
     const float* gamma;
     const float* beta;
     float* out;            // (B, T0, C)
+    uint16_t* out16;       // optional bf16 shadow of out (precision mode 1: layer 1's GEMM reads it)
     double* partial;       // (B, nchunks, 2, C)
     float* scale_shift;    // (B, 2, C)
     int64_t L;
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(Conv0Args a) {
                     if (c < a.C) {
                         float v = MODE == 1 ? apply_act(fmaf(y[j], sc[j], sh[j]), a.act) : y[j];
                         a.out[((int64_t)b * a.T0 + t0 + t) * a.C + c] = v;
+                        if (a.out16) a.out16[((int64_t)b * a.T0 + t0 + t) * a.C + c] = (uint16_t)pack_bf16_rne(v, 0.f);
                     }
                 }
             }
@@ -171,12 +173,18 @@ int64_t conv0_ws_floats(int B, int64_t L, int K, int stride, int C) {
 int launch_conv0(Profiler* prof, const float* wave, const float* kernel, const float* bias,
                  const float* gamma, const float* beta, float* out, float* ws, int B, int64_t L,
                  int K, int stride, int C, float eps, int norm_mode, int act, hipStream_t s) {
+    return launch_conv0_x(prof, wave, kernel, bias, gamma, beta, out, nullptr, ws, B, L, K, stride, C, eps, norm_mode, act, s);
+}
+
+int launch_conv0_x(Profiler* prof, const float* wave, const float* kernel, const float* bias,
+                   const float* gamma, const float* beta, float* out, uint16_t* out16, float* ws, int B, int64_t L,
+                   int K, int stride, int C, float eps, int norm_mode, int act, hipStream_t s) {
     W2V2_REQUIRE(wave && kernel && out, "conv0: null operand");
     W2V2_REQUIRE(B > 0 && C > 0 && K > 0 && K <= 32 && stride > 0 && L >= K,
                  "conv0: unsupported B=%d C=%d K=%d stride=%d L=%lld", B, C, K, stride, (long long)L);
     W2V2_REQUIRE(norm_mode == 0 || norm_mode == 1, "conv0: bad norm_mode %d", norm_mode);
     Conv0Args a;
-    a.wave = wave; a.kernel = kernel; a.bias = bias; a.gamma = gamma; a.beta = beta; a.out = out;
+    a.wave = wave; a.kernel = kernel; a.bias = bias; a.gamma = gamma; a.beta = beta; a.out = out; a.out16 = out16;
     a.L = L; a.K = K; a.stride = stride; a.C = C; a.eps = eps; a.norm_mode = norm_mode; a.act = act;
     a.T0 = (int)(1 + (L - K) / stride);
     a.nchunks = conv0_nchunks(L, K, stride);

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "gemm_epilogue.h"
 
 namespace w2v2 {
 
@@ -42,6 +43,11 @@ struct Gemm16Args {
     int64_t lda, ldb, ldc, strideA, strideB, strideC;
     int M, N, K, act;
     int tiles_m, tiles_n;
+    // optional bf16 shadows (GemmShadows): A16 has A's shape and strides, B16 is B transposed ([N][K], ld = ldb16)
+    const uint16_t* A16;
+    const uint16_t* B16;
+    uint16_t* C16;
+    int64_t ldb16;
 };
 
 // two fp32 -> one dword of two bf16, round to nearest even (gfx950 instruction; no builtin in ROCm 7.2)
@@ -60,9 +66,15 @@ template <int PN> struct FVec;
 template <> struct FVec<4> { using type = f32x4; };
 template <> struct FVec<2> { using type = f32x2; };
 
-template <bool FAST, int BM, int BN, int WM, int WN, int MINB, int ABL = 0>
+// SRC: where the operands come from.  0 = fp32 with scalar guards (any shape), 1 = fp32, 16-byte loads,
+// 2 = A from its bf16 shadow, 3 = B from its bf16 [N][K] shadow, 4 = both shadows (no conversion at all: the tile
+// step streams 32 KiB instead of 64).  Shadows hold exactly the values the fp32 path would round to, so all five
+// produce bit-identical results.
+template <int SRC, int BM, int BN, int WM, int WN, int MINB, int ABL = 0>
 __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args g) {
+    constexpr bool FAST = SRC >= 1, A16 = SRC == 2 || SRC == 4, B16 = SRC == 3 || SRC == 4;
     constexpr int NT = WM * WN * 64;
+    constexpr int NA16 = BM * 8 / NT, NB16 = BN * 8 / NT;   // 16-byte (8 x bf16) chunks per thread when a shadow is the source
     constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 32, NTL = WTN / 32;   // wave tile, 32x32 accumulators
     constexpr int NA = BM * 16 / NT;              // float4 chunks of the A tile per thread
     constexpr int PN = (2 * BN >= NT) ? 4 : 2;    // B patch = 8(k) x PN(n) per thread, loaded as 8 float4 | float2
@@ -113,6 +125,33 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
         b_off[i] = (int64_t)(ks * 8) * g.ldb + col;
     }
 
+    // shadow sources: 8 lanes x 16 B = one 128-byte tile row, stored to LDS as loaded
+    u32x4 ra16[A16 ? NA16 : 1], rb16[B16 ? NB16 : 1];
+    const uint16_t* a16_src[A16 ? NA16 : 1];
+    const uint16_t* b16_src[B16 ? NB16 : 1];
+    int a16_lds[A16 ? NA16 : 1], b16_lds[B16 ? NB16 : 1];
+    if constexpr (A16) {
+        const uint16_t* A16p = g.A16 + (int64_t)z * g.strideA;
+#pragma unroll
+        for (int i = 0; i < NA16; ++i) {
+            const int idx = tid + i * NT, r = idx >> 3, ks = idx & 7;
+            int row = m0 + r;
+            row = row < g.M ? row : g.M - 1;
+            a16_src[i] = A16p + (int64_t)row * g.lda + ks * 8;
+            a16_lds[i] = r * ROWB + ((ks ^ swz(r)) << 4);
+        }
+    }
+    if constexpr (B16) {
+#pragma unroll
+        for (int i = 0; i < NB16; ++i) {
+            const int idx = tid + i * NT, r = idx >> 3, ks = idx & 7;
+            int col = n0 + r;
+            col = col < g.N ? col : g.N - 1;
+            b16_src[i] = g.B16 + (int64_t)col * g.ldb16 + ks * 8;
+            b16_lds[i] = BM * ROWB + r * ROWB + ((ks ^ swz(r)) << 4);
+        }
+    }
+
     auto load_tile = [&](int kt) {
         if constexpr (ABL == 1) {     // ablation: no global loads
             if (kt == 0) {
@@ -128,8 +167,16 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
             return;
         }
         const int k0 = kt * BK;
+        if constexpr (A16) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
+            for (int i = 0; i < NA16; ++i) ra16[i] = *reinterpret_cast<const u32x4*>(a16_src[i] + k0);
+        }
+        if constexpr (B16) {
+#pragma unroll
+            for (int i = 0; i < NB16; ++i) rb16[i] = *reinterpret_cast<const u32x4*>(b16_src[i] + k0);
+        }
+#pragma unroll
+        for (int i = 0; i < (A16 ? 0 : NA); ++i) {
             if constexpr (FAST) {
                 ra[i] = *reinterpret_cast<const f32x4*>(A + a_off[i] + k0);
             } else {
@@ -140,7 +187,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
             }
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
+        for (int i = 0; i < (B16 ? 0 : NB); ++i) {
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
                 if constexpr (FAST) {
@@ -166,15 +213,23 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
             if (t == 123.456f) S[tid] = 1;
             return;
         }
+        if constexpr (A16) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
+            for (int i = 0; i < NA16; ++i) *reinterpret_cast<u32x4*>(S + a16_lds[i]) = ra16[i];
+        }
+        if constexpr (B16) {
+#pragma unroll
+            for (int i = 0; i < NB16; ++i) *reinterpret_cast<u32x4*>(S + b16_lds[i]) = rb16[i];
+        }
+#pragma unroll
+        for (int i = 0; i < (A16 ? 0 : NA); ++i) {
             u32x2 p;
             p[0] = pack_bf16(ra[i][0], ra[i][1]);
             p[1] = pack_bf16(ra[i][2], ra[i][3]);
             *reinterpret_cast<u32x2*>(S + a_lds[i]) = p;
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
+        for (int i = 0; i < (B16 ? 0 : NB); ++i) {
             const int q = (tid + i * NT) % NQ, ks = (tid + i * NT) / NQ;
 #pragma unroll
             for (int j = 0; j < PN; ++j) {       // register transpose: column j of the patch becomes 8 consecutive k
@@ -215,18 +270,26 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
     auto compute = [&](int buf) {
         const unsigned char* S = smem16 + buf * STAGE;
         if constexpr (ABL == 3) return;   // ablation: no fragment reads / MFMA
+        // Fragment reads run one k-step ahead of the MFMAs that consume them: a 16-deep bf16 MFMA is only 32 cycles, so
+        // an LDS round trip (~100+ cycles) in front of each group of 4 would otherwise be the critical path.
+        bf16x8 a[2][MT], b[2][NTL];
+        auto read_frags = [&](int s, int slot) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) a[slot][t] = *reinterpret_cast<const bf16x8*>(S + a_row[t] + (((2 * s + lh) ^ a_swz[t]) << 4));
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) b[slot][t] = *reinterpret_cast<const bf16x8*>(S + b_row[t] + (((2 * s + lh) ^ b_swz[t]) << 4));
+        };
+        read_frags(0, 0);
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
-            bf16x8 a[MT], b[NTL];
-#pragma unroll
-            for (int t = 0; t < MT; ++t) a[t] = *reinterpret_cast<const bf16x8*>(S + a_row[t] + (((2 * s + lh) ^ a_swz[t]) << 4));
-#pragma unroll
-            for (int t = 0; t < NTL; ++t) b[t] = *reinterpret_cast<const bf16x8*>(S + b_row[t] + (((2 * s + lh) ^ b_swz[t]) << 4));
+            if (s + 1 < BK / 16) read_frags(s + 1, (s + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NTL; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1][mt], b[s & 1][nt], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -247,49 +310,39 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
     }
     compute((nk - 1) & 1);
 
-    // epilogue (fp32): C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    float* __restrict__ C = g.C + (int64_t)z * g.strideC;
-    const float* __restrict__ R = g.residual ? g.residual + (int64_t)z * g.strideC : nullptr;
-#pragma unroll
-    for (int nt = 0; nt < NTL; ++nt) {
-        const int col = n0 + wn * WTN + nt * 32 + li;
-        if (col >= g.N) continue;
-        const float bv = g.bias ? g.bias[col] : 0.0f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * WTM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < g.M) {
-                    float v = apply_act(acc[mt][nt][r] + bv, g.act);
-                    if (R) v += R[(int64_t)row * g.ldc + col];
-                    C[(int64_t)row * g.ldc + col] = v;
-                }
-            }
-        }
-    }
+    // ---- epilogue (gemm_epilogue.h): bias -> act -> + residual -> fp32 store and / or bf16 shadow ----
+    const int64_t tile_off = (int64_t)z * g.strideC + (int64_t)(m0 + wm * WTM) * g.ldc + (n0 + wn * WTN);
+    gemm_epilogue<MT, NTL, true>(acc, g.C ? g.C + tile_off : nullptr, g.C16 ? g.C16 + tile_off : nullptr,
+                                 g.residual ? g.residual + tile_off : nullptr, g.bias ? g.bias + (n0 + wn * WTN) : nullptr,
+                                 (int)g.ldc, g.M - (m0 + wm * WTM), g.N - (n0 + wn * WTN), g.act, li, lh);
 }
 
-template <int BM, int BN, int WM, int WN, int MINB, int ABL = 0>
-int launch_cfg16(Gemm16Args& g, bool fast, int nbatch, hipStream_t s) {
+template <int SRC, int BM, int BN, int WM, int WN, int MINB>
+int launch_src16(Gemm16Args& g, int nbatch, hipStream_t s) {
     constexpr size_t LDS = 2 * (BM + BN) * ROWB;
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
     static bool attr_set = false;
     if (!attr_set) {
-        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<true, BM, BN, WM, WN, MINB, ABL>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<false, BM, BN, WM, WN, MINB, ABL>),
+        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<SRC, BM, BN, WM, WN, MINB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         attr_set = true;
     }
     dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch), block(WM * WN * 64);
-    if (fast)
-        hipLaunchKernelGGL((gemm_bf16_kernel<true, BM, BN, WM, WN, MINB, ABL>), grid, block, LDS, s, g);
-    else
-        hipLaunchKernelGGL((gemm_bf16_kernel<false, BM, BN, WM, WN, MINB, ABL>), grid, block, LDS, s, g);
+    hipLaunchKernelGGL((gemm_bf16_kernel<SRC, BM, BN, WM, WN, MINB>), grid, block, LDS, s, g);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int MINB>
+int launch_cfg16(Gemm16Args& g, int src, int nbatch, hipStream_t s) {
+    switch (src) {
+        case 1: return launch_src16<1, BM, BN, WM, WN, MINB>(g, nbatch, s);
+        case 2: return launch_src16<2, BM, BN, WM, WN, MINB>(g, nbatch, s);
+        case 3: return launch_src16<3, BM, BN, WM, WN, MINB>(g, nbatch, s);
+        case 4: return launch_src16<4, BM, BN, WM, WN, MINB>(g, nbatch, s);
+        default: return launch_src16<0, BM, BN, WM, WN, MINB>(g, nbatch, s);
+    }
 }
 
 int forced_cfg16() {
@@ -306,32 +359,42 @@ int forced_cfg16() {
 int launch_gemm_bf16(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
                      int64_t strideB, float* C, int64_t ldc, int64_t strideC, const float* bias,
                      const float* residual, int M, int N, int K, int nbatch, int act, hipStream_t s) {
-    W2V2_REQUIRE(A && B && C, "gemm_bf16: null operand");
+    return launch_gemm_bf16_x(prof, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, bias, residual, M, N, K, nbatch, act,
+                              GemmShadows{}, s);
+}
+
+int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
+                       int64_t strideB, float* C, int64_t ldc, int64_t strideC, const float* bias,
+                       const float* residual, int M, int N, int K, int nbatch, int act, const GemmShadows& x,
+                       hipStream_t s) {
+    W2V2_REQUIRE((A || x.A16) && (B || x.B16) && (C || x.C16), "gemm_bf16: null operand");
     W2V2_REQUIRE(M > 0 && N > 0 && K > 0 && nbatch > 0, "gemm_bf16: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, nbatch);
-    W2V2_REQUIRE(lda >= 1 && ldb >= N && ldc >= N, "gemm_bf16: bad leading dimensions");
+    W2V2_REQUIRE(lda >= 1 && ldb >= N && ldc >= N && ldc < (1 << 23), "gemm_bf16: bad leading dimensions");
     W2V2_REQUIRE(act >= 0 && act <= 2, "gemm_bf16: bad activation %d", act);
     Gemm16Args g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.residual = residual;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.strideA = strideA; g.strideB = strideB; g.strideC = strideC;
     g.M = M; g.N = N; g.K = K; g.act = act;
-    const bool fast = (K % BK == 0) && (N % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && (strideA % 4 == 0) &&
-                      (strideB % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
-                      ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+    g.A16 = x.A16; g.B16 = x.B16; g.C16 = x.C16; g.ldb16 = x.ldb16 ? x.ldb16 : K;
+    const bool kfast = K % BK == 0;
+    const bool a32 = A && (lda % 4 == 0) && (strideA % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+    const bool b32 = B && (N % 4 == 0) && (ldb % 4 == 0) && (strideB % 4 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+    const bool a16 = x.A16 && kfast && (lda % 8 == 0) && (strideA % 8 == 0) && ((reinterpret_cast<uintptr_t>(x.A16) & 15) == 0);
+    const bool b16 = x.B16 && kfast && strideB == 0 && (g.ldb16 % 8 == 0) && ((reinterpret_cast<uintptr_t>(x.B16) & 15) == 0);
+    int src;
+    if (a16 && b16) src = 4;
+    else if (a16 && b32) src = 2;
+    else if (b16 && a32) src = 3;
+    else if (kfast && a32 && b32) src = 1;
+    else src = 0;
+    W2V2_REQUIRE(src != 0 || (A && B), "gemm_bf16: a shadow-only operand needs K %% 64 == 0 and 16-byte alignment");
+    const double abytes = (src == 2 || src == 4) ? 2.0 : 4.0, bbytes = (src == 3 || src == 4) ? 2.0 : 4.0;
     ProfScope ps(prof, FAM_GEMM_BF16, 2.0 * M * (double)N * K * nbatch,
-                 4.0 * nbatch * ((double)M * K + (double)M * N) + 4.0 * (double)K * N, s);
+                 nbatch * (abytes * (double)M * K + (C ? 4.0 : 0.0) * (double)M * N + (x.C16 ? 2.0 : 0.0) * (double)M * N) +
+                     bbytes * (double)K * N, s);
     int cfg = forced_cfg16();
-    if (cfg < 0) cfg = 0;
-    switch (cfg) {
-        case 1: return launch_cfg16<256, 128, 4, 2, 1>(g, fast, nbatch, s);
-        case 2: return launch_cfg16<256, 256, 2, 4, 1>(g, fast, nbatch, s);   // 8 waves of 128x64
-        case 3: return launch_cfg16<256, 256, 4, 2, 1>(g, fast, nbatch, s);   // 8 waves of 64x128
-        case 4: return launch_cfg16<256, 128, 2, 2, 1>(g, fast, nbatch, s);   // 4 waves of 128x64
-        case 5: return launch_cfg16<128, 256, 2, 4, 1>(g, fast, nbatch, s);   // 8 waves of 64x64
-        case 11: return launch_cfg16<128, 128, 2, 2, 2, 1>(g, fast, nbatch, s);
-        case 12: return launch_cfg16<128, 128, 2, 2, 2, 2>(g, fast, nbatch, s);
-        case 13: return launch_cfg16<128, 128, 2, 2, 2, 3>(g, fast, nbatch, s);
-        default: return launch_cfg16<128, 128, 2, 2, 2>(g, fast, nbatch, s);
-    }
+    if (cfg == 2 && src == 1) return launch_src16<1, 256, 256, 2, 4, 1>(g, nbatch, s);   // tile study: 8 waves of 128x64
+    return launch_cfg16<128, 128, 2, 2, 2>(g, src, nbatch, s);
 }
 
 }  // namespace w2v2

@@ -1,0 +1,87 @@
+// Shared epilogue of the MFMA GEMM kernels: bias -> activation -> + residual -> store (fp32 and / or a bf16 shadow),
+// from 32x32 accumulators in the C/D layout  col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+//
+// A wave owns up to 64 outputs per lane, and with a short K (768 = 24 fp32 K tiles, 12 bf16 K tiles) the epilogue is
+// a first-order cost -- on the bf16 kernel it used to be LONGER than the matrix work.  So: uniform conditions (which
+// outputs exist, whether the sub-tile is interior) are decided once per wave, addresses are 32-bit offsets from a
+// wave-uniform base (no 64-bit multiply-add per element), and exact GELU uses a 5-coefficient erf.
+#pragma once
+
+#include "common.h"
+
+namespace w2v2 {
+
+#ifdef __HIPCC__
+using f32x16_t = __attribute__((ext_vector_type(16))) float;
+
+// exact GELU 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.26: |erf error| < 1.5e-7 absolute, i.e.
+// at the level of fp32 rounding of erf itself; ~14 VALU ops against ~35 for erff.
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+    const float erf_abs = fmaf(-p * t, e, 1.0f);             // erf(|x| / sqrt 2)
+    return 0.5f * x + 0.5f * fabsf(x) * erf_abs;             // 0.5 x (1 + sign(x) erf(|x| / sqrt 2))
+}
+
+// C / C16 / R point at the wave sub-tile's first element (row 0, column 0 of the WTM x WTN block); any may be null.
+// bias points at the sub-tile's first column.  rows_left / cols_left = valid extent of the sub-tile.
+template <int MT, int NTL, bool FAST_GELU>
+__device__ __forceinline__ void gemm_epilogue(const f32x16_t (&acc)[MT][NTL], float* __restrict__ C, uint16_t* __restrict__ C16,
+                                              const float* __restrict__ R, const float* __restrict__ bias, int ldc,
+                                              int rows_left, int cols_left, int act, int li, int lh) {
+    const bool interior = rows_left >= MT * 32 && cols_left >= NTL * 32;
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt) {
+        const int cl = nt * 32 + li;                          // column inside the wave sub-tile
+        const bool col_ok = cl < cols_left;
+        const float bv = (bias && col_ok) ? bias[cl] : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x16_t v = acc[mt][nt];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += bv;
+            if (act == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = FAST_GELU ? gelu_erf_fast(v[r]) : gelu_erf(v[r]);
+            } else if (act == 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = gelu_tanh(v[r]);
+            }
+            const int off0 = (mt * 32 + 4 * lh) * ldc + cl;   // register r adds ((r & 3) + 8 (r >> 2)) * ldc
+            if (interior) {
+                if (R) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] += R[off0 + ((r & 3) + 8 * (r >> 2)) * ldc];
+                }
+                if (C) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) C[off0 + ((r & 3) + 8 * (r >> 2)) * ldc] = v[r];
+                }
+                if (C16) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) C16[off0 + ((r & 3) + 8 * (r >> 2)) * ldc] = (uint16_t)pack_bf16_rne(v[r], 0.0f);
+                }
+            } else if (col_ok) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (rl < rows_left) {
+                        const int off = off0 + ((r & 3) + 8 * (r >> 2)) * ldc;
+                        float o = v[r];
+                        if (R) o += R[off];
+                        if (C) C[off] = o;
+                        if (C16) C16[off] = (uint16_t)pack_bf16_rne(o, 0.0f);
+                    }
+                }
+            }
+        }
+    }
+}
+#endif
+
+}  // namespace w2v2

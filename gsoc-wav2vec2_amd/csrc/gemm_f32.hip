@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "gemm_epilogue.h"
 
 namespace w2v2 {
 
@@ -199,27 +200,12 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_f32_kernel(GemmArgs g)
     }
     compute((nk - 1) & 1);
 
-    // ---- epilogue: bias -> activation -> + residual -> store -------------------
-    // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    float* __restrict__ C = g.C + (int64_t)z * g.strideC;
-    const float* __restrict__ R = g.residual ? g.residual + (int64_t)z * g.strideC : nullptr;
-#pragma unroll
-    for (int nt = 0; nt < NTL; ++nt) {
-        const int col = n0 + wn * C_::WTN + nt * 32 + li;
-        if (col >= g.N) continue;
-        const float bv = g.bias ? g.bias[col] : 0.0f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * C_::WTM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < g.M) {
-                    float v = apply_act(acc[mt][nt][r] + bv, g.act);
-                    if (R) v += R[(int64_t)row * g.ldc + col];
-                    C[(int64_t)row * g.ldc + col] = v;
-                }
-            }
-        }
+    // ---- epilogue: bias -> activation -> + residual -> store (gemm_epilogue.h) ----
+    {
+        const int64_t tile_off = (int64_t)z * g.strideC + (int64_t)(m0 + wm * C_::WTM) * g.ldc + (n0 + wn * C_::WTN);
+        gemm_epilogue<MT, NTL, true>(acc, g.C + tile_off, nullptr, g.residual ? g.residual + tile_off : nullptr,
+                                     g.bias ? g.bias + (n0 + wn * C_::WTN) : nullptr, (int)g.ldc, g.M - (m0 + wm * C_::WTM),
+                                     g.N - (n0 + wn * C_::WTN), g.act, li, lh);
     }
 }
 
@@ -355,25 +341,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_f32_dma_kernel(GemmArg
     }
     compute((nk - 1) & 1);
 
-    float* __restrict__ C = g.C + (int64_t)z * g.strideC;
-    const float* __restrict__ R = g.residual ? g.residual + (int64_t)z * g.strideC : nullptr;
-#pragma unroll
-    for (int nt = 0; nt < NTL; ++nt) {
-        const int col = n0 + wn * WTN + nt * 32 + li;
-        if (col >= g.N) continue;
-        const float bv = g.bias ? g.bias[col] : 0.0f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * WTM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < g.M) {
-                    float v = apply_act(acc[mt][nt][r] + bv, g.act);
-                    if (R) v += R[(int64_t)row * g.ldc + col];
-                    C[(int64_t)row * g.ldc + col] = v;
-                }
-            }
-        }
+    {
+        const int64_t tile_off = (int64_t)z * g.strideC + (int64_t)(m0 + wm * WTM) * g.ldc + (n0 + wn * WTN);
+        gemm_epilogue<MT, NTL, true>(acc, g.C + tile_off, nullptr, g.residual ? g.residual + tile_off : nullptr,
+                                     g.bias ? g.bias + (n0 + wn * WTN) : nullptr, (int)g.ldc, g.M - (m0 + wm * WTM),
+                                     g.N - (n0 + wn * WTN), g.act, li, lh);
     }
 }
 
@@ -446,7 +418,7 @@ int launch_gemm_ex(Profiler* prof, const float* A, int64_t lda, int64_t strideA,
         return launch_gemm_bf16(prof, A, lda, strideA, B, ldb, strideB, C, ldc, strideC, bias, residual, M, N, K, nbatch, act, s);
     W2V2_REQUIRE(A && B && C, "gemm: null operand");
     W2V2_REQUIRE(M > 0 && N > 0 && K > 0 && nbatch > 0, "gemm: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, nbatch);
-    W2V2_REQUIRE(lda >= 1 && ldb >= N && ldc >= N, "gemm: bad leading dimensions");
+    W2V2_REQUIRE(lda >= 1 && ldb >= N && ldc >= N && ldc < (1 << 23), "gemm: bad leading dimensions");
     W2V2_REQUIRE(act >= 0 && act <= 2, "gemm: bad activation %d", act);
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.residual = residual;

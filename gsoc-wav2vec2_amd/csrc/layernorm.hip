@@ -15,6 +15,7 @@ namespace {
 template <int NV>   // NV float4 per lane: covers C <= NV * 256
 __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict__ x,
                                                          float* __restrict__ y,
+                                                         uint16_t* __restrict__ y16,   // optional bf16 shadow of y
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta,
                                                          int64_t rows, int C, float eps, int act) {
@@ -60,6 +61,16 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (c + e < C) o[e] = apply_act(o[e] * rstd * gamma[c + e] + beta[c + e], act);
+        if (y16) {      // nearest-even bf16 copy for the consumer GEMM (precision mode 1)
+            uint16_t* hr = y16 + row * C + c;
+            if (vec) {
+                *reinterpret_cast<uint2*>(hr) = make_uint2(pack_bf16_rne(o[0], o[1]), pack_bf16_rne(o[2], o[3]));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < C) hr[e] = (uint16_t)pack_bf16_rne(o[e], 0.f);
+            }
+        }
         if (vec) {
             *reinterpret_cast<float4*>(yr + c) = make_float4(o[0], o[1], o[2], o[3]);
         } else {
@@ -74,19 +85,24 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict
 
 int launch_layer_norm(Profiler* prof, const float* x, float* y, const float* gamma,
                       const float* beta, int64_t rows, int C, float eps, int act, hipStream_t s) {
+    return launch_layer_norm_x(prof, x, y, gamma, beta, rows, C, eps, act, nullptr, s);
+}
+
+int launch_layer_norm_x(Profiler* prof, const float* x, float* y, const float* gamma, const float* beta, int64_t rows,
+                        int C, float eps, int act, uint16_t* y16, hipStream_t s) {
     W2V2_REQUIRE(x && y && gamma && beta, "layer_norm: null operand");
     W2V2_REQUIRE(rows > 0 && C > 0 && C <= 2048, "layer_norm: rows=%lld C=%d unsupported (C <= 2048)",
                  (long long)rows, C);
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-    ProfScope ps(prof, FAM_LAYERNORM, 8.0 * rows * C, 8.0 * rows * C, s);
+    ProfScope ps(prof, FAM_LAYERNORM, 8.0 * rows * C, (y16 ? 10.0 : 8.0) * rows * C, s);
     if (C <= 256)
-        hipLaunchKernelGGL(layer_norm_kernel<1>, grid, block, 0, s, x, y, gamma, beta, rows, C, eps, act);
+        hipLaunchKernelGGL(layer_norm_kernel<1>, grid, block, 0, s, x, y, y16, gamma, beta, rows, C, eps, act);
     else if (C <= 512)
-        hipLaunchKernelGGL(layer_norm_kernel<2>, grid, block, 0, s, x, y, gamma, beta, rows, C, eps, act);
+        hipLaunchKernelGGL(layer_norm_kernel<2>, grid, block, 0, s, x, y, y16, gamma, beta, rows, C, eps, act);
     else if (C <= 1024)
-        hipLaunchKernelGGL(layer_norm_kernel<4>, grid, block, 0, s, x, y, gamma, beta, rows, C, eps, act);
+        hipLaunchKernelGGL(layer_norm_kernel<4>, grid, block, 0, s, x, y, y16, gamma, beta, rows, C, eps, act);
     else
-        hipLaunchKernelGGL(layer_norm_kernel<8>, grid, block, 0, s, x, y, gamma, beta, rows, C, eps, act);
+        hipLaunchKernelGGL(layer_norm_kernel<8>, grid, block, 0, s, x, y, y16, gamma, beta, rows, C, eps, act);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }

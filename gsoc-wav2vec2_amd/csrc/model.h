@@ -41,6 +41,13 @@ struct w2v2_model {
     float *qkv = nullptr, *ctx = nullptr, *t0 = nullptr, *t1 = nullptr, *t2 = nullptr, *t3 = nullptr,
           *ffn = nullptr, *enc_out = nullptr;
     int32_t* frame_len = nullptr;
+    // bf16 shadows (precision mode 1, inference forward; w2v2_api.hip::ensure_shadows).  Weight shadows are the
+    // GEMM kernels transposed to (N, K); activation shadows are written by the producing kernels.
+    bool sh_ready = false, w16_valid = false;
+    std::unordered_map<const float*, uint16_t*> w16;
+    std::vector<void*> sh_allocs, w16_allocs;
+    std::vector<uint16_t*> conv16, hs16;
+    uint16_t *ln512_16 = nullptr, *ctx16 = nullptr, *t0_16 = nullptr, *t2_16 = nullptr, *ffn16 = nullptr, *enc16 = nullptr;
     w2v2::Profiler* prof = nullptr;
     struct TrainState* train = nullptr;      // owned by w2v2_train.hip (null until the first training call)
 

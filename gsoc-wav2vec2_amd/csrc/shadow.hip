@@ -1,0 +1,53 @@
+// fp32 -> bf16 shadows for precision mode 1 (nearest-even, v_cvt_pk_bf16_f32): what gemm_bf16.hip would round an
+// operand to on its own, materialised once so the GEMM streams 2 bytes per element instead of 4 and skips the
+// conversion.  Activations get their shadow from the producing kernel (GEMM / LayerNorm / conv0 / attention
+// epilogues); the kernels here serve the weights, which change only when variables are set or the optimizer steps.
+#include "common.h"
+
+namespace w2v2 {
+namespace {
+
+__global__ __launch_bounds__(256) void to_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const float4 v = *reinterpret_cast<const float4*>(x + i);
+        *reinterpret_cast<uint2*>(y + i) = make_uint2(pack_bf16_rne(v.x, v.y), pack_bf16_rne(v.z, v.w));
+    } else {
+        for (int64_t j = i; j < n; ++j) y[j] = (uint16_t)pack_bf16_rne(x[j], 0.f);
+    }
+}
+
+// w (K, N) row-major fp32  ->  wt (N, K) row-major bf16, through a 64 x 64 LDS tile (both sides coalesced)
+__global__ __launch_bounds__(256) void transpose_to_bf16_kernel(const float* __restrict__ w, uint16_t* __restrict__ wt, int K, int N) {
+    __shared__ float tile[64][65];
+    const int k0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int k = k0 + r, n = n0 + tx;
+        tile[r][tx] = (k < K && n < N) ? w[(int64_t)k * N + n] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int n = n0 + r, k = k0 + tx;
+        if (n < N && k < K) wt[(int64_t)n * K + k] = (uint16_t)pack_bf16_rne(tile[tx][r], 0.f);
+    }
+}
+
+}  // namespace
+
+int launch_to_bf16(const float* x, uint16_t* y, int64_t n, hipStream_t s) {
+    W2V2_REQUIRE(x && y && n > 0, "to_bf16: bad argument");
+    W2V2_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0, "to_bf16: unaligned buffer");
+    hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, x, y, n);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
+int launch_transpose_to_bf16(const float* w, uint16_t* wt, int K, int N, hipStream_t s) {
+    W2V2_REQUIRE(w && wt && K > 0 && N > 0, "transpose_to_bf16: bad argument");
+    hipLaunchKernelGGL(transpose_to_bf16_kernel, dim3((N + 63) / 64, (K + 63) / 64), dim3(256), 0, s, w, wt, K, N);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
+}  // namespace w2v2

@@ -72,8 +72,8 @@ struct AttnTrain {
 };
 // bf16 matrix-pipe attention (attention_bf16.hip); taken by launch_attention* while the thread's precision is 1
 bool attention_bf16_supported(int head_size);
-int launch_attention_fwd_bf16(const float* qkv, const int32_t* frame_len, float* ctx, int B, int T, int H, int heads,
-                              const AttnTrain* tr, hipStream_t s);
+int launch_attention_fwd_bf16(const float* qkv, const int32_t* frame_len, float* ctx, uint16_t* ctx16, int B, int T, int H,
+                              int heads, const AttnTrain* tr, hipStream_t s);
 int launch_attention_bwd_bf16(const float* qkv, const int32_t* frame_len, const float* dctx, const float* dvec,
                               float* dqkv, int B, int T, int H, int heads, const AttnTrain& tr, hipStream_t s);
 int launch_attention_train(Profiler* prof, const float* qkv, const int32_t* frame_len, float* ctx, int B, int T,

@@ -8,6 +8,7 @@
 // (feature_extractor.py:92-95) -> Wav2Vec2Encoder.call (encoder.py:251-276) ->
 // TransformerLayer.call (encoder.py:111-134) -> lm_head.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -164,6 +165,11 @@ static void build_inventory(w2v2_model* m) {
 static void free_workspace(w2v2_model* m) {
     for (void* p : m->allocs) (void)hipFree(p);
     m->allocs.clear();
+    for (void* p : m->sh_allocs) (void)hipFree(p);
+    m->sh_allocs.clear();
+    m->conv16.clear();
+    m->hs16.clear();
+    m->sh_ready = false;
     m->acts.clear();
     m->conv.clear();
     m->conv_T.clear();
@@ -232,6 +238,70 @@ int w2v2_ensure_workspace(w2v2_model* m, int B, int64_t L) {
     return W2V2_OK;
 }
 
+// ---- bf16 shadows for the inference forward in precision mode 1 ------------------------------------------
+// W2V2_BF16_SHADOWS=0 turns them off (every GEMM then rounds its fp32 operands itself): same results bit for
+// bit, used by the tests to prove exactly that.
+static bool shadows_enabled() {
+    const char* e = getenv("W2V2_BF16_SHADOWS");      // read per call: tests flip it between two forwards
+    return !(e && atoi(e) == 0);
+}
+
+static int sh_alloc(std::vector<void*>& pool, uint16_t** out, int64_t n) {
+    void* p = nullptr;
+    W2V2_HIP_CHECK(hipMalloc(&p, (size_t)(n > 0 ? n : 1) * sizeof(uint16_t)));
+    pool.push_back(p);
+    *out = reinterpret_cast<uint16_t*>(p);
+    return W2V2_OK;
+}
+
+static int ensure_shadows(w2v2_model* m, int B, int T, hipStream_t s) {
+    const w2v2_config& c = m->cfg;
+    const int64_t H = c.hidden_size, F = c.intermediate_size, BT = (int64_t)B * T;
+    if (!m->sh_ready) {
+        for (int i = 0; i + 1 < c.num_conv_layers; ++i) {       // the last conv output feeds a LayerNorm, not a GEMM
+            uint16_t* p = nullptr;
+            if (int e = sh_alloc(m->sh_allocs, &p, (int64_t)B * m->conv_T[i] * c.filter_sizes[i])) return e;
+            m->conv16.push_back(p);
+        }
+        if (int e = sh_alloc(m->sh_allocs, &m->ln512_16, BT * c.filter_sizes[c.num_conv_layers - 1])) return e;
+        for (int i = 0; i <= c.num_layers; ++i) {
+            uint16_t* p = nullptr;
+            if (int e = sh_alloc(m->sh_allocs, &p, BT * H)) return e;
+            m->hs16.push_back(p);
+        }
+        if (int e = sh_alloc(m->sh_allocs, &m->ctx16, BT * H)) return e;
+        if (int e = sh_alloc(m->sh_allocs, &m->t0_16, BT * H)) return e;
+        if (int e = sh_alloc(m->sh_allocs, &m->t2_16, BT * H)) return e;
+        if (int e = sh_alloc(m->sh_allocs, &m->ffn16, BT * F)) return e;
+        if (int e = sh_alloc(m->sh_allocs, &m->enc16, BT * H)) return e;
+        m->sh_ready = true;
+    }
+    if (!m->w16_valid) {
+        auto shadow = [&](const float* w, int K, int N) -> int {
+            uint16_t*& dst = m->w16[w];
+            if (!dst)
+                if (int e = sh_alloc(m->w16_allocs, &dst, (int64_t)K * N)) return e;
+            return launch_transpose_to_bf16(w, dst, K, N, s);
+        };
+        for (int i = 1; i < c.num_conv_layers; ++i)
+            if (int e = shadow(m->P("feature_extractor/conv_layers/" + std::to_string(i) + "/conv/kernel"),
+                               c.kernal_sizes[i] * c.filter_sizes[i - 1], c.filter_sizes[i]))
+                return e;
+        if (int e = shadow(m->P("feature_projection/projection/kernel"), c.filter_sizes[c.num_conv_layers - 1], (int)H)) return e;
+        for (int i = 0; i < c.num_layers; ++i) {
+            const std::string b = "encoder/layers/" + std::to_string(i);
+            if (int e = shadow(m->qkv_w[i], (int)H, 3 * (int)H)) return e;
+            if (int e = shadow(m->P(b + "/attention/out_proj/kernel"), (int)H, (int)H)) return e;
+            if (int e = shadow(m->P(b + "/feed_forward/intermediate_dense/kernel"), (int)H, (int)F)) return e;
+            if (int e = shadow(m->P(b + "/feed_forward/output_dense/kernel"), (int)F, (int)H)) return e;
+        }
+        if (c.with_lm_head)
+            if (int e = shadow(m->P("lm_head/kernel"), (int)H, c.vocab_size)) return e;
+        m->w16_valid = true;
+    }
+    return W2V2_OK;
+}
+
 extern "C" {
 
 const char* w2v2_last_error(void) { return g_err; }
@@ -278,6 +348,7 @@ void w2v2_destroy(w2v2_model* m) {
     if (m->pos_wg) (void)hipFree(m->pos_wg);
     for (auto p : m->qkv_w) (void)hipFree(p);
     for (auto p : m->qkv_b) (void)hipFree(p);
+    for (void* p : m->w16_allocs) (void)hipFree(p);
     profiler_destroy(m->prof);
     delete m;
 }
@@ -359,6 +430,7 @@ int w2v2_finalize(w2v2_model* m, void* stream) {
         }
     }
     m->finalized = true;
+    m->w16_valid = false;      // the bf16 weight shadows (if any) follow the variables
     return W2V2_OK;
 }
 
@@ -403,36 +475,57 @@ int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const i
     const float eps = c.layer_norm_eps;
     auto fe = [&](int i, const char* leaf) { return m->P("feature_extractor/conv_layers/" + std::to_string(i) + leaf); };
 
+    // Precision mode 1 with bf16 shadows: every producer of a GEMM operand also writes its nearest-even bf16 copy, the
+    // GEMMs stream those (2 bytes per element, no conversion) and the weights come from (N, K) bf16 shadows.  `sh`
+    // false = plain pointers everywhere: the GEMMs then round their fp32 operands themselves, with identical results.
+    const bool sh = m->precision == 1 && shadows_enabled();
+    if (sh)
+        if (int e = ensure_shadows(m, B, T, s)) return e;
+    const bool attn16 = sh && attention_bf16_supported(H / c.num_heads);
+    auto W16 = [&](const float* w) -> const uint16_t* { return sh ? m->w16[w] : nullptr; };
+    auto gemm = [&](const float* A, const uint16_t* A16, int64_t lda, int64_t strideA, const float* Bw, int64_t ldb, float* Cc,
+                    uint16_t* C16, int64_t ldc, int64_t strideC, const float* bias, const float* res, int M, int N, int K,
+                    int nbatch, int act_) -> int {
+        if (!sh) return launch_gemm(pf, A, lda, strideA, Bw, ldb, Cc, ldc, strideC, bias, res, M, N, K, nbatch, act_, s);
+        GemmShadows x;
+        x.A16 = A16; x.B16 = W16(Bw); x.C16 = C16; x.ldb16 = K;
+        return launch_gemm_bf16_x(pf, A, lda, strideA, Bw, ldb, 0, Cc, ldc, strideC, bias, res, M, N, K, nbatch, act_, x, s);
+    };
+    const int NC = c.num_conv_layers;
+    const bool ffn_sh_only = sh && F % 64 == 0;      // the output dense can then always take the shadow (K = F)
+
     // ---- feature extractor (feature_extractor.py:54-59) ----
-    if (int e = launch_conv0(pf, wave, fe(0, "/conv/kernel"), c.conv_bias ? fe(0, "/conv/bias") : nullptr,
-                             fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"), m->conv[0], m->conv0_ws, B, L,
-                             c.kernal_sizes[0], c.strides[0], c.filter_sizes[0], 1e-5f, layer_mode ? 1 : 0, act, s))
+    if (int e = launch_conv0_x(pf, wave, fe(0, "/conv/kernel"), c.conv_bias ? fe(0, "/conv/bias") : nullptr,
+                               fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"), m->conv[0],
+                               (sh && !layer_mode) ? m->conv16[0] : nullptr, m->conv0_ws, B, L, c.kernal_sizes[0], c.strides[0],
+                               c.filter_sizes[0], 1e-5f, layer_mode ? 1 : 0, act, s))
         return e;
     if (layer_mode)
-        if (int e = launch_layer_norm(pf, m->conv[0], m->conv[0], fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"),
-                                      (int64_t)B * m->conv_T[0], c.filter_sizes[0], 1e-5f, act, s))
+        if (int e = launch_layer_norm_x(pf, m->conv[0], m->conv[0], fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"),
+                                        (int64_t)B * m->conv_T[0], c.filter_sizes[0], 1e-5f, act, sh ? m->conv16[0] : nullptr, s))
             return e;
-    for (int i = 1; i < c.num_conv_layers; ++i) {
+    for (int i = 1; i < NC; ++i) {
         const int cin = c.filter_sizes[i - 1], cout = c.filter_sizes[i];
         const int Tin = m->conv_T[i - 1], Tout = m->conv_T[i];
+        uint16_t* o16 = (sh && i + 1 < NC) ? m->conv16[i] : nullptr;     // the last conv output feeds a LayerNorm
         // strided Conv1D == GEMM over an overlapping window view: lda = stride * C_in < K * C_in
-        if (int e = launch_gemm(pf, m->conv[i - 1], (int64_t)c.strides[i] * cin, (int64_t)Tin * cin,
-                                fe(i, "/conv/kernel"), cout, m->conv[i], cout, (int64_t)Tout * cout,
-                                c.conv_bias ? fe(i, "/conv/bias") : nullptr, nullptr, Tout, cout,
-                                c.kernal_sizes[i] * cin, B, layer_mode ? 0 : act, s))
+        if (int e = gemm(m->conv[i - 1], sh ? m->conv16[i - 1] : nullptr, (int64_t)c.strides[i] * cin, (int64_t)Tin * cin,
+                         fe(i, "/conv/kernel"), cout, m->conv[i], layer_mode ? nullptr : o16, cout, (int64_t)Tout * cout,
+                         c.conv_bias ? fe(i, "/conv/bias") : nullptr, nullptr, Tout, cout, c.kernal_sizes[i] * cin, B,
+                         layer_mode ? 0 : act))
             return e;
         if (layer_mode)
-            if (int e = launch_layer_norm(pf, m->conv[i], m->conv[i], fe(i, "/layer_norm/gamma"), fe(i, "/layer_norm/beta"),
-                                          (int64_t)B * Tout, cout, 1e-5f, act, s))
+            if (int e = launch_layer_norm_x(pf, m->conv[i], m->conv[i], fe(i, "/layer_norm/gamma"), fe(i, "/layer_norm/beta"),
+                                            (int64_t)B * Tout, cout, 1e-5f, act, o16, s))
                 return e;
     }
     // ---- feature projection (feature_extractor.py:92-95) ----
-    const int C = c.filter_sizes[c.num_conv_layers - 1];
-    if (int e = launch_layer_norm(pf, m->conv[c.num_conv_layers - 1], m->ln512, m->P("feature_projection/layer_norm/gamma"),
-                                  m->P("feature_projection/layer_norm/beta"), BT, C, eps, 0, s))
+    const int C = c.filter_sizes[NC - 1];
+    if (int e = launch_layer_norm_x(pf, m->conv[NC - 1], m->ln512, m->P("feature_projection/layer_norm/gamma"),
+                                    m->P("feature_projection/layer_norm/beta"), BT, C, eps, 0, sh ? m->ln512_16 : nullptr, s))
         return e;
-    if (int e = launch_gemm(pf, m->ln512, C, 0, m->P("feature_projection/projection/kernel"), H, m->proj, H, 0,
-                            m->P("feature_projection/projection/bias"), nullptr, (int)BT, H, C, 1, 0, s))
+    if (int e = gemm(m->ln512, sh ? m->ln512_16 : nullptr, C, 0, m->P("feature_projection/projection/kernel"), H, m->proj, nullptr,
+                     H, 0, m->P("feature_projection/projection/bias"), nullptr, (int)BT, H, C, 1, 0))
         return e;
     // ---- encoder (encoder.py:251-276) ----
     const int32_t* flen = nullptr;
@@ -444,54 +537,64 @@ int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const i
                                 H, c.num_conv_pos_embeddings, c.num_conv_pos_embedding_groups, act, s))
         return e;
     if (!prenorm)
-        if (int e = launch_layer_norm(pf, m->posout, m->hs[0], m->P("encoder/layer_norm/gamma"),
-                                      m->P("encoder/layer_norm/beta"), BT, H, eps, 0, s))
+        if (int e = launch_layer_norm_x(pf, m->posout, m->hs[0], m->P("encoder/layer_norm/gamma"),
+                                        m->P("encoder/layer_norm/beta"), BT, H, eps, 0, sh ? m->hs16[0] : nullptr, s))
             return e;
     for (int i = 0; i < c.num_layers; ++i) {
         const std::string b = "encoder/layers/" + std::to_string(i);
         const float* x = m->hs[i];
         const float* attn_in = x;
+        const uint16_t* attn_in16 = sh ? m->hs16[i] : nullptr;       // postnorm: the previous LayerNorm wrote it
         if (prenorm) {
-            if (int e = launch_layer_norm(pf, x, m->t0, m->P(b + "/layer_norm/gamma"), m->P(b + "/layer_norm/beta"), BT, H, eps, 0, s)) return e;
+            if (int e = launch_layer_norm_x(pf, x, m->t0, m->P(b + "/layer_norm/gamma"), m->P(b + "/layer_norm/beta"), BT, H, eps, 0,
+                                            sh ? m->t0_16 : nullptr, s))
+                return e;
             attn_in = m->t0;
+            attn_in16 = sh ? m->t0_16 : nullptr;
         }
-        if (int e = launch_gemm(pf, attn_in, H, 0, m->qkv_w[i], 3 * H, m->qkv, 3 * H, 0, m->qkv_b[i], nullptr, (int)BT, 3 * H, H, 1, 0, s)) return e;
-        if (int e = launch_attention(pf, m->qkv, flen, m->ctx, B, T, H, c.num_heads, s)) return e;
+        if (int e = gemm(attn_in, attn_in16, H, 0, m->qkv_w[i], 3 * H, m->qkv, nullptr, 3 * H, 0, m->qkv_b[i], nullptr, (int)BT, 3 * H, H, 1, 0)) return e;
+        if (int e = launch_attention_x(pf, m->qkv, flen, m->ctx, B, T, H, c.num_heads, attn16 ? m->ctx16 : nullptr, s)) return e;
         // out projection + residual (encoder.py:31,117-119)
-        if (int e = launch_gemm(pf, m->ctx, H, 0, m->P(b + "/attention/out_proj/kernel"), H, m->t1, H, 0,
-                                m->P(b + "/attention/out_proj/bias"), x, (int)BT, H, H, 1, 0, s))
+        if (int e = gemm(m->ctx, attn16 ? m->ctx16 : nullptr, H, 0, m->P(b + "/attention/out_proj/kernel"), H, m->t1, nullptr, H, 0,
+                         m->P(b + "/attention/out_proj/bias"), x, (int)BT, H, H, 1, 0))
             return e;
         const float* ffn_res = m->t1;
-        const float* ffn_in = m->t1;
         if (!prenorm) {
-            if (int e = launch_layer_norm(pf, m->t1, m->t2, m->P(b + "/layer_norm/gamma"), m->P(b + "/layer_norm/beta"), BT, H, eps, 0, s)) return e;
+            if (int e = launch_layer_norm_x(pf, m->t1, m->t2, m->P(b + "/layer_norm/gamma"), m->P(b + "/layer_norm/beta"), BT, H, eps, 0,
+                                            sh ? m->t2_16 : nullptr, s))
+                return e;
             ffn_res = m->t2;
-            ffn_in = m->t2;
         } else {
-            if (int e = launch_layer_norm(pf, m->t1, m->t2, m->P(b + "/final_layer_norm/gamma"), m->P(b + "/final_layer_norm/beta"), BT, H, eps, 0, s)) return e;
-            ffn_in = m->t2;
+            if (int e = launch_layer_norm_x(pf, m->t1, m->t2, m->P(b + "/final_layer_norm/gamma"), m->P(b + "/final_layer_norm/beta"), BT, H,
+                                            eps, 0, sh ? m->t2_16 : nullptr, s))
+                return e;
         }
-        if (int e = launch_gemm(pf, ffn_in, H, 0, m->P(b + "/feed_forward/intermediate_dense/kernel"), F, m->ffn, F, 0,
-                                m->P(b + "/feed_forward/intermediate_dense/bias"), nullptr, (int)BT, F, H, 1, act, s))
+        // the FFN intermediate has one consumer: with shadows only its bf16 form is written (302 MB of fp32 stores saved)
+        if (int e = gemm(m->t2, sh ? m->t2_16 : nullptr, H, 0, m->P(b + "/feed_forward/intermediate_dense/kernel"), F,
+                         ffn_sh_only ? nullptr : m->ffn, sh ? m->ffn16 : nullptr, F, 0, m->P(b + "/feed_forward/intermediate_dense/bias"),
+                         nullptr, (int)BT, F, H, 1, act))
             return e;
         // output dense + residual; StochasticDepth at inference is a plain add (tensorflow_addons.py:386-390)
         float* dst = prenorm ? m->hs[i + 1] : m->t3;
-        if (int e = launch_gemm(pf, m->ffn, F, 0, m->P(b + "/feed_forward/output_dense/kernel"), H, dst, H, 0,
-                                m->P(b + "/feed_forward/output_dense/bias"), ffn_res, (int)BT, H, F, 1, 0, s))
+        if (int e = gemm(m->ffn, sh ? m->ffn16 : nullptr, F, 0, m->P(b + "/feed_forward/output_dense/kernel"), H, dst, nullptr, H, 0,
+                         m->P(b + "/feed_forward/output_dense/bias"), ffn_res, (int)BT, H, F, 1, 0))
             return e;
         if (!prenorm)
-            if (int e = launch_layer_norm(pf, m->t3, m->hs[i + 1], m->P(b + "/final_layer_norm/gamma"),
-                                          m->P(b + "/final_layer_norm/beta"), BT, H, eps, 0, s))
+            if (int e = launch_layer_norm_x(pf, m->t3, m->hs[i + 1], m->P(b + "/final_layer_norm/gamma"),
+                                            m->P(b + "/final_layer_norm/beta"), BT, H, eps, 0, sh ? m->hs16[i + 1] : nullptr, s))
                 return e;
     }
-    if (prenorm)
-        if (int e = launch_layer_norm(pf, m->hs[c.num_layers], m->enc_out, m->P("encoder/layer_norm/gamma"),
-                                      m->P("encoder/layer_norm/beta"), BT, H, eps, 0, s))
+    const uint16_t* head_in16 = sh && !prenorm ? m->hs16[c.num_layers] : nullptr;
+    if (prenorm) {
+        if (int e = launch_layer_norm_x(pf, m->hs[c.num_layers], m->enc_out, m->P("encoder/layer_norm/gamma"),
+                                        m->P("encoder/layer_norm/beta"), BT, H, eps, 0, sh ? m->enc16 : nullptr, s))
             return e;
+        head_in16 = sh ? m->enc16 : nullptr;
+    }
     // ---- head (modeling.py:253-254) ----
     if (c.with_lm_head) {
-        if (int e = launch_gemm(pf, m->enc_out, H, 0, m->P("lm_head/kernel"), c.vocab_size, out, c.vocab_size, 0,
-                                m->P("lm_head/bias"), nullptr, (int)BT, c.vocab_size, H, 1, 0, s))
+        if (int e = gemm(m->enc_out, head_in16, H, 0, m->P("lm_head/kernel"), c.vocab_size, out, nullptr, c.vocab_size, 0,
+                         m->P("lm_head/bias"), nullptr, (int)BT, c.vocab_size, H, 1, 0))
             return e;
     } else {
         W2V2_HIP_CHECK(hipMemcpyAsync(out, m->enc_out, (size_t)BT * H * sizeof(float), hipMemcpyDeviceToDevice, s));

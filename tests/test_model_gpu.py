@@ -114,6 +114,30 @@ def test_bf16_precision_logits(torch_mod, name):
     assert np.array_equal(m(g["wave"], attention_mask=mask).numpy(), fp32)
 
 
+@pytest.mark.parametrize("name", ["tiny_robust", "base_sample_unpadded", "robust_masked"])
+def test_bf16_shadows_do_not_change_results(torch_mod, name):
+    """The bf16 shadows (activations written by the producing kernels, weights transposed once) hold exactly what
+    the GEMM would round its fp32 operands to, so a forward with W2V2_BF16_SHADOWS=0 gives the same logits and
+    activations bit for bit."""
+    g = H.golden(name)
+    m, cfg = build(name)
+    m.set_precision("bf16")
+    mask = g.get("attention_mask")
+    mask = None if mask is None else mask.astype(np.int32)
+    taps = [f"conv{i}" for i in range(len(cfg.kernal_sizes))] + ["projection", "encoder_in", "layer0", "encoder_out"]
+    res = {}
+    try:
+        for flag in ("0", "1"):
+            os.environ["W2V2_BF16_SHADOWS"] = flag
+            out = m(g["wave"], attention_mask=mask).numpy()
+            res[flag] = {k: m.activation(k) for k in taps}
+            res[flag]["logits"] = out
+    finally:
+        os.environ.pop("W2V2_BF16_SHADOWS", None)
+    for k in taps + ["logits"]:
+        assert np.array_equal(res["0"][k], res["1"][k]), f"{k}: max diff {H.max_err(res['0'][k], res['1'][k]):.3e}"
+
+
 def test_set_precision_rejects_unknown(torch_mod):
     m, cfg = build("tiny_base")
     with pytest.raises(ValueError):
