@@ -191,13 +191,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_bf16_kernel(Attn16Args a
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);   // exp2(-inf) = 0 on the first tile
-        const float mb = -m_new * LOG2E;
         float rs = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], LOG2E, mb));
+                const float p = __builtin_amdgcn_exp2f((s[kt][r] - m_new) * LOG2E);   // subtract first: exact for nearby values even at |m| = 1e4 (masked rows)
                 s[kt][r] = p;
                 rs += p;
             }
@@ -388,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dq_kernel(Attn16Bwd
     load_col_frags(qf, base + (int64_t)qr * ld + 8 * lh, a.scale);
     load_col_frags(dof, a.d_o + ((int64_t)b * a.T + qr) * a.H + head * DH + 8 * lh, 1.0f);
     const int64_t sidx = ((int64_t)b * a.heads + head) * a.T + qr;
-    const float nlse2 = -tr.lse[sidx] * LOG2E, dv = a.dvec[sidx];
+    const float lse = tr.lse[sidx], dv = a.dvec[sidx];
     const float inv = tr.p > 0.f ? 1.0f / (1.0f - tr.p) : 1.0f;
     const uint64_t rowbase = (uint64_t)sidx * a.T;
     const uint32_t drop_key = dropout_key(tr.seed, tr.stream), drop_thr = dropout_threshold(tr.p);
@@ -433,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dq_kernel(Attn16Bwd
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, row, st, lh), as_bf16x8(qf[st]), s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vs, row, st, lh), as_bf16x8(dof[st]), dp, 0, 0, 0);
             }
-            // dS^T = P^T * (dP^T * keep/(1-p) - D);  P = exp(S - lse) = exp2(S log2e - lse log2e)
+            // dS^T = P^T * (dP^T * keep/(1-p) - D);  P = exp(S - lse) = exp2((S - lse) log2e)
             if (k0 + KT > min(flen, a.T)) {         // boundary tiles only (wave-uniform)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -446,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dq_kernel(Attn16Bwd
             const uint32_t cbase = (uint32_t)rowbase + (uint32_t)(k0 + kt * 32 + 4 * lh);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, nlse2));
+                const float pv = __builtin_amdgcn_exp2f((s[r] - lse) * LOG2E);
                 float g = dp[r];
                 if (tr.p > 0.f) g = dropout_keep32(drop_key, cbase + (uint32_t)((r & 3) + 8 * (r >> 2)), drop_thr) ? g : 0.f;
                 s[r] = pv * fmaf(g, inv, -dv);
@@ -489,7 +488,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
     const int key = c0 + li;
     const int kr = min(key, a.T - 1);
     const bool kok = key < a.T;
-    const float kmask2 = key >= flen ? -10000.0f * LOG2E : 0.0f;
+    const float kmask = key >= flen ? -10000.0f : 0.0f;
     const uint32_t drop_key = dropout_key(tr.seed, tr.stream), drop_thr = dropout_threshold(tr.p);
 
     u32x4 kf[4], vf[4];
@@ -512,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
         load_patch(rot, dobase, a.H, tile * KT, a.T, tid);
         if (tid < 2 * KT) {
             const int qq = min(tile * KT + (tid & (KT - 1)), a.T - 1);
-            rl = tid < KT ? tr.lse[bh * a.T + qq] * LOG2E : a.dvec[bh * a.T + qq];
+            rl = tid < KT ? tr.lse[bh * a.T + qq] : a.dvec[bh * a.T + qq];
         }
     };
     auto store_tile = [&](int buf) {
@@ -555,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ql = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float pv = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, kmask2 - Ls[ql]));     // Ls[ql] = lse log2e
+                float pv = __builtin_amdgcn_exp2f((s[r] + kmask - Ls[ql]) * LOG2E);
                 if (qtail) pv = t0 + ql < a.T ? pv : 0.f;
                 float g = dp[r], pd = pv;
                 if (tr.p > 0.f) {

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_f32_kernel(GemmArgs g)
     // ---- epilogue: bias -> activation -> + residual -> store (gemm_epilogue.h) ----
     {
         const int64_t tile_off = (int64_t)z * g.strideC + (int64_t)(m0 + wm * C_::WTM) * g.ldc + (n0 + wn * C_::WTN);
-        gemm_epilogue<MT, NTL, true>(acc, g.C + tile_off, nullptr, g.residual ? g.residual + tile_off : nullptr,
+        gemm_epilogue<MT, NTL, false>(acc, g.C + tile_off, nullptr, g.residual ? g.residual + tile_off : nullptr,
                                      g.bias ? g.bias + (n0 + wn * C_::WTN) : nullptr, (int)g.ldc, g.M - (m0 + wm * C_::WTM),
                                      g.N - (n0 + wn * C_::WTN), g.act, li, lh);
     }
@@ -231,7 +231,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_f32_dma_kernel(GemmArg
     constexpr int NPA = BM * BKT / 256;         // 1-KiB pieces of the A tile
     constexpr int NPB = BKT * BN / 256;         // 1-KiB pieces of the B tile
     constexpr int NW = WM * WN;                 // waves per block
-    constexpr int PPA = NPA / NW, PPB = NPB / NW;   // pieces per wave per K tile
+    constexpr int PPA = (NPA + NW - 1) / NW, PPB = (NPB + NW - 1) / NW;   // pieces per wave per K tile (round-robin; the
+                                                                          // last may be absent when NW does not divide)
     constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 32, NTL = WTN / 32;
     static_assert(PPA >= 1 && PPB >= 1 && MT >= 1 && NTL >= 1, "bad wave grid");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_f32_dma_kernel(GemmArg
     const float* b_src[PPB];
 #pragma unroll
     for (int i = 0; i < PPA; ++i) {
-        const int piece = wave * PPA + i;                   // pieces of RPP rows
+        const int piece = min(wave + i * NW, NPA - 1);      // pieces of RPP rows
         const int r = piece * RPP + lane / SPR;             // A row inside the tile
         int row = m0 + r;
         row = row < g.M ? row : g.M - 1;
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_f32_dma_kernel(GemmArg
     }
 #pragma unroll
     for (int i = 0; i < PPB; ++i) {
-        const int flat = (wave * PPB + i) * 256 + lane * 4;  // lane-linear position inside the (BKT, BN) tile
+        const int flat = min(wave + i * NW, NPB - 1) * 256 + lane * 4;  // lane-linear position inside the (BKT, BN) tile
         const int br = flat / BN;
         int col = n0 + flat % BN;
         col = col < g.N ? col : (g.N >= 4 ? g.N - 4 : 0);
@@ -283,9 +284,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_f32_dma_kernel(GemmArg
         float* S = smem + buf * STAGE;
         const int k0 = kt * BKT;
 #pragma unroll
-        for (int i = 0; i < PPA; ++i) dma16(a_src[i] + k0, S + (wave * PPA + i) * 256);
+        for (int i = 0; i < PPA; ++i)
+            if (NPA % NW == 0 || wave + i * NW < NPA) dma16(a_src[i] + k0, S + (wave + i * NW) * 256);
 #pragma unroll
-        for (int i = 0; i < PPB; ++i) dma16(b_src[i] + (int64_t)k0 * g.ldb, S + BM * BKT + (wave * PPB + i) * 256);
+        for (int i = 0; i < PPB; ++i)
+            if (NPB % NW == 0 || wave + i * NW < NPB) dma16(b_src[i] + (int64_t)k0 * g.ldb, S + BM * BKT + (wave + i * NW) * 256);
     };
 
     f32x16 acc[MT][NTL];
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_f32_dma_kernel(GemmArg
 
     {
         const int64_t tile_off = (int64_t)z * g.strideC + (int64_t)(m0 + wm * WTM) * g.ldc + (n0 + wn * WTN);
-        gemm_epilogue<MT, NTL, true>(acc, g.C + tile_off, nullptr, g.residual ? g.residual + tile_off : nullptr,
+        gemm_epilogue<MT, NTL, false>(acc, g.C + tile_off, nullptr, g.residual ? g.residual + tile_off : nullptr,
                                      g.bias ? g.bias + (n0 + wn * WTN) : nullptr, (int)g.ldc, g.M - (m0 + wm * WTM),
                                      g.N - (n0 + wn * WTN), g.act, li, lh);
     }
@@ -440,8 +443,12 @@ int launch_gemm_ex(Profiler* prof, const float* A, int64_t lda, int64_t strideA,
     // Measured on MI355X, B=32 base shapes (profiles/r01_gemm_tile_study.md): this 118-129 TF; the same
     // with 4 waves 112-123; register-staged 128x128 107-120; 128x256 / 256x128 at 1 wave per SIMD 75-100;
     // 256x256 8-wave 67-115; BK=16 variants with 3-4 blocks per CU 114-125.
+    // (cfg 14 = 128x96 tiles with 6 waves, meant to turn the 2.25 "rounds" of the N = 768 GEMMs into 3.0 exact ones:
+    // measured 100 TF against 114-121 -- blocks are not scheduled in lock-step rounds, so the quantisation it removes
+    // does not exist, and the 6-wave block is simply less efficient.)
     if (cfg < 0) cfg = 7;
     switch (cfg) {
+        case 14: if (fast) return launch_dma<2, 3, 2, 32, 128, 96>(g, nbatch, s); return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
         case 1: return launch_cfg<128, 256, 2, 2, 1>(g, fast, nbatch, s);
         case 2: return launch_cfg<256, 128, 2, 2, 1>(g, fast, nbatch, s);
         case 3: return launch_cfg<256, 256, 4, 2, 2>(g, fast, nbatch, s);
