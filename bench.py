@@ -263,8 +263,8 @@ def main():
             ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
             peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
             res["roofline"] = {
-                "kernel": ("gemm_f32_kernel (fp32 MFMA 32x32x2: conv1-6 implicit GEMM + all Dense layers)" if args.precision == "fp32"
-                           else "gemm_bf16_kernel (bf16 MFMA 32x32x16, fp32 operands rounded on the way into LDS: conv1-6 + all Dense)"),
+                "kernel": ("gemm_f32_dma_kernel (fp32 MFMA 32x32x2, LDS-DMA staged: conv1-6 implicit GEMM + all Dense layers)" if args.precision == "fp32"
+                           else "gemm_bf16_kernel (bf16 MFMA 32x32x16; operands from bf16 shadows or fp32 rounded on the way into LDS: conv1-6 + all Dense)"),
                 "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": measured_traffic() if args.precision == "fp32" else None,
                 "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",

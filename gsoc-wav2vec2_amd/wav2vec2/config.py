@@ -81,6 +81,48 @@ class Wav2Vec2Config:
         return cls(**config_dict)
 
     # ---- helpers that are not part of the reference surface -------------
+    @classmethod
+    def from_hf_config(cls, hf):
+        """Build the config from a HuggingFace ``Wav2Vec2Config`` dict (or the path of its ``config.json``): the
+        field correspondence the reference relies on implicitly when it converts checkpoints
+        (src/convert_torch_to_tf.py:128-153 picks ``Wav2Vec2Config()`` / ``RobustWav2Vec2Config()`` by hand;
+        SURVEY 8c lists the verified field-for-field equality for base).  ``do_stable_layer_norm`` selects the
+        prenorm (robust / xlsr) transformer, ``feat_extract_norm`` the conv-stack norm."""
+        if isinstance(hf, (str, os.PathLike)):
+            with open(hf, "r") as f:
+                hf = json.load(f)
+        act = hf.get("hidden_act", "gelu")
+        if act not in ("gelu", "gelu_new", "gelu_fast", "gelu_pytorch_tanh"):
+            raise NotImplementedError(f"hidden_act `{act}` has no counterpart in the reference (GELU only)")
+        if hf.get("feat_extract_activation", "gelu") != "gelu":
+            raise NotImplementedError("the reference's feature extractor is GELU only")
+        robust = bool(hf.get("do_stable_layer_norm", False))
+        fields = dict(
+            vocab_size=hf.get("vocab_size", 32),
+            dropout=hf.get("hidden_dropout", 0.1),
+            hidden_size=hf["hidden_size"],
+            num_heads=hf["num_attention_heads"],
+            num_layers=hf["num_hidden_layers"],
+            intermediate_size=hf["intermediate_size"],
+            is_gelu_approx=act != "gelu",
+            layer_norm_eps=hf.get("layer_norm_eps", 1e-5),
+            survival_prob=1.0 - hf.get("layerdrop", 0.0) * 0.0,      # the reference never enables stochastic depth (config.py:16)
+            pad_id=hf.get("pad_token_id", 0) or 0,
+            num_conv_pos_embeddings=hf.get("num_conv_pos_embeddings", 128),
+            num_conv_pos_embedding_groups=hf.get("num_conv_pos_embedding_groups", 16),
+            filter_sizes=list(hf.get("conv_dim", _default_filters())),
+            kernal_sizes=list(hf.get("conv_kernel", _default_kernels())),
+            strides=list(hf.get("conv_stride", _default_strides())),
+            conv_bias=bool(hf.get("conv_bias", False)),
+            apply_spec_augment=bool(hf.get("apply_spec_augment", True)),
+            mask_time_prob=hf.get("mask_time_prob", 0.05),
+            mask_time_length=hf.get("mask_time_length", 10),
+            attention_norm_type="prenorm" if robust else "postnorm",
+            feature_extractor_norm_type=hf.get("feat_extract_norm", "group"),
+            is_robust=robust,
+        )
+        return (RobustWav2Vec2Config if robust else Wav2Vec2Config)(**fields)
+
     def num_frames(self, num_samples: int) -> int:
         """Frames out of the conv stack: ``1 + (len - k) // s`` per layer
         (reference modeling.py:202-204, losses.py:47-56)."""

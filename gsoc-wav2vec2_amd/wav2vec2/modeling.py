@@ -84,6 +84,40 @@ class Variable:
         return f"<Variable {self.name} shape={self.shape}>"
 
 
+def hf_checkpoint_file(save_dir):
+    """Path of the HuggingFace weight file in `save_dir` (`model.safetensors` preferred, else `pytorch_model.bin`)."""
+    for f in ("model.safetensors", "pytorch_model.bin"):
+        p = os.path.join(save_dir, f)
+        if os.path.exists(p):
+            return p
+    return None
+
+
+def read_hf_state_dict(save_dir):
+    """{hf_key: numpy array} from a HuggingFace-PyTorch Wav2Vec2 checkpoint directory."""
+    path = hf_checkpoint_file(save_dir)
+    if path is None:
+        raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin in {save_dir}")
+    if path.endswith(".safetensors"):
+        from safetensors.numpy import load_file
+        return dict(load_file(path))
+    import torch
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    return {k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def convert_hf_checkpoint(hf_dir, save_dir, with_lm_head=True):
+    """The job of the reference's src/convert_torch_to_tf.py without TensorFlow and without a GPU: read a
+    HuggingFace-PyTorch checkpoint directory, apply the HF -> TF name / layout map (file:12-44,110-117) and write
+    the package's own checkpoint (`config.json` with the reference's 22 fields + weights keyed by TF variable names).
+    Returns the config."""
+    config = Wav2Vec2Config.from_hf_config(os.path.join(hf_dir, "config.json"))
+    weights = V.from_hf_state_dict(read_hf_state_dict(hf_dir), config, with_lm_head=with_lm_head)
+    config.save_pretrained(save_dir)
+    np.savez(os.path.join(save_dir, "tf_model.npz"), **{V.tf_variable_name(n, with_lm_head): a for n, a in weights.items()})
+    return config
+
+
 class TFKerasModel:
     """Shared plumbing (reference modeling.py:21-102 ``TFKerasModel``)."""
 
@@ -232,6 +266,14 @@ class TFKerasModel:
             raise ValueError(f"Couldn't download model weights from https://huggingface.co/{model_id}")
         print(f"Loading weights locally from `{save_dir}`")
         input_shape = config_kwargs.pop("input_shape", (1, 2048))
+        has_own = any(os.path.exists(os.path.join(save_dir, f)) for f in ("tf_model.h5", "tf_model.npz"))
+        if not has_own and hf_checkpoint_file(save_dir):
+            # a HuggingFace-PyTorch checkpoint directory: what src/convert_torch_to_tf.py converts (file:92-123)
+            config = replace(Wav2Vec2Config.from_hf_config(os.path.join(save_dir, "config.json")), **config_kwargs)
+            model = cls(config, input_shape=input_shape)
+            model.load_hf_state_dict(read_hf_state_dict(save_dir))
+            print("Total number of loaded variables:", len(model.variables))
+            return model
         config = Wav2Vec2Config.from_json(os.path.join(save_dir, "config.json"))
         config = replace(config, **config_kwargs)
         model = cls(config, input_shape=input_shape)

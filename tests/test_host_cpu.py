@@ -188,3 +188,56 @@ def test_dropout_hash_statistics():
     assert abs(keep.mean() - 0.9) < 0.005
     assert not np.array_equal(keep, V.dropout_keep(12345, V.layer_stream(3, 1), 200000, 0.1))
     assert np.array_equal(keep, V.dropout_keep(12345, V.layer_stream(3, 0), 200000, 0.1))
+
+
+# ---- HuggingFace checkpoint directories (what src/convert_torch_to_tf.py converts) ------------
+def _hf_dir(tmp_path, cfg, hf_cfg_dict, weights, fmt="safetensors"):
+    import json
+    d = tmp_path / "hf"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps(hf_cfg_dict))
+    sd = V.to_hf_state_dict(weights)
+    if fmt == "safetensors":
+        from safetensors.numpy import save_file
+        save_file({k: np.ascontiguousarray(v) for k, v in sd.items()}, str(d / "model.safetensors"))
+    else:
+        import torch
+        torch.save({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, str(d / "pytorch_model.bin"))
+    return str(d)
+
+
+def test_config_from_real_hf_config_defaults():
+    """transformers' own Wav2Vec2Config defaults map onto the reference's defaults field for field,
+    and the robust switches (do_stable_layer_norm / feat_extract_norm='layer' / conv_bias) onto RobustWav2Vec2Config."""
+    transformers = pytest.importorskip("transformers")
+    base = Wav2Vec2Config.from_hf_config(transformers.Wav2Vec2Config().to_dict())
+    assert base == Wav2Vec2Config()
+    hf_robust = transformers.Wav2Vec2Config(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096,
+                                            do_stable_layer_norm=True, feat_extract_norm="layer", conv_bias=True)
+    assert Wav2Vec2Config.from_hf_config(hf_robust.to_dict()) == RobustWav2Vec2Config()
+    with pytest.raises(NotImplementedError):
+        Wav2Vec2Config.from_hf_config(dict(transformers.Wav2Vec2Config().to_dict(), hidden_act="relu"))
+
+
+@pytest.mark.parametrize("fmt", ["safetensors", "bin"])
+def test_convert_hf_checkpoint_directory(tmp_path, fmt):
+    """convert_torch_to_tf.py without TF: HF directory in, `config.json` (22 reference fields) + TF-named weights out."""
+    from wav2vec2.modeling import convert_hf_checkpoint, read_hf_state_dict
+    cfg = H.case_config("tiny_robust")
+    w = H.case_weights("tiny_robust")
+    hf_cfg = dict(hidden_size=cfg.hidden_size, num_attention_heads=cfg.num_heads, num_hidden_layers=cfg.num_layers,
+                  intermediate_size=cfg.intermediate_size, conv_dim=cfg.filter_sizes, conv_kernel=cfg.kernal_sizes,
+                  conv_stride=cfg.strides, conv_bias=True, feat_extract_norm="layer", do_stable_layer_norm=True,
+                  num_conv_pos_embeddings=cfg.num_conv_pos_embeddings, num_conv_pos_embedding_groups=cfg.num_conv_pos_embedding_groups,
+                  vocab_size=cfg.vocab_size, hidden_act="gelu", layer_norm_eps=cfg.layer_norm_eps, pad_token_id=0,
+                  hidden_dropout=cfg.dropout, mask_time_prob=cfg.mask_time_prob, mask_time_length=cfg.mask_time_length)
+    src = _hf_dir(tmp_path, cfg, hf_cfg, w, fmt)
+    assert set(read_hf_state_dict(src)) == set(V.to_hf_state_dict(w))
+    out = str(tmp_path / "converted")
+    got_cfg = convert_hf_checkpoint(src, out)
+    assert got_cfg == cfg
+    assert Wav2Vec2Config.from_json(os.path.join(out, "config.json")) == Wav2Vec2Config(**{k: getattr(cfg, k) for k in cfg.__dataclass_fields__})
+    with np.load(os.path.join(out, "tf_model.npz")) as z:
+        assert set(z.files) == {V.tf_variable_name(n) for n in w}
+        for n, a in w.items():
+            assert np.array_equal(z[V.tf_variable_name(n)], a), n

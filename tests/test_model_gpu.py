@@ -310,3 +310,26 @@ def test_load_hf_state_dict_roundtrip(torch_mod):
     m2.set_weights({k: np.zeros_like(v) for k, v in H.case_weights("tiny_base").items()})
     m2.load_hf_state_dict({k: torch_mod.from_numpy(v) for k, v in sd.items()})
     assert np.array_equal(m2(g["wave"]).numpy(), ref)
+
+
+def test_from_pretrained_hf_checkpoint_directory(torch_mod, tmp_path):
+    """`from_pretrained` on a HuggingFace-PyTorch directory (config.json + model.safetensors) = the reference's
+    convert_torch_to_tf.py + from_pretrained in one step; logits equal those of the directly-loaded weights."""
+    import json
+    import wav2vec2
+    from safetensors.numpy import save_file
+    name = "tiny_base"
+    g = H.golden(name)
+    m, cfg = build(name)
+    want = m(g["wave"]).numpy()
+    d = tmp_path / "hf"
+    d.mkdir()
+    hf_cfg = dict(hidden_size=cfg.hidden_size, num_attention_heads=cfg.num_heads, num_hidden_layers=cfg.num_layers,
+                  intermediate_size=cfg.intermediate_size, conv_dim=cfg.filter_sizes, conv_kernel=cfg.kernal_sizes,
+                  conv_stride=cfg.strides, num_conv_pos_embeddings=cfg.num_conv_pos_embeddings,
+                  num_conv_pos_embedding_groups=cfg.num_conv_pos_embedding_groups, vocab_size=cfg.vocab_size)
+    (d / "config.json").write_text(json.dumps(hf_cfg))
+    save_file({k: np.ascontiguousarray(v) for k, v in V.to_hf_state_dict(H.case_weights(name)).items()}, str(d / "model.safetensors"))
+    m2 = wav2vec2.Wav2Vec2ForCTC.from_pretrained(str(d), input_shape=(2, 4000))
+    assert m2.config == cfg
+    assert np.array_equal(m2(g["wave"]).numpy(), want)
