@@ -446,8 +446,15 @@ int launch_gemm_ex(Profiler* prof, const float* A, int64_t lda, int64_t strideA,
     // (cfg 14 = 128x96 tiles with 6 waves, meant to turn the 2.25 "rounds" of the N = 768 GEMMs into 3.0 exact ones:
     // measured 100 TF against 114-121 -- blocks are not scheduled in lock-step rounds, so the quantisation it removes
     // does not exist, and the 6-wave block is simply less efficient.)
-    if (cfg < 0) cfg = 7;
+    if (cfg < 0) {
+        cfg = 7;
+        // small problems (batch 1-4 of the transformer GEMMs: M = 768 rows is 6 row tiles): 128x128 tiles leave most
+        // of the 256 CUs idle and serialise a long K loop per tile, so switch to 64x64 tiles (4x the blocks, 4 waves)
+        const int64_t tiles128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * nbatch;
+        if (fast && tiles128 < 384) cfg = 16;
+    }
     switch (cfg) {
+        case 16: if (fast) return launch_dma<2, 2, 2, 32, 64, 64>(g, nbatch, s); return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
         case 14: if (fast) return launch_dma<2, 3, 2, 32, 128, 96>(g, nbatch, s); return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
         case 1: return launch_cfg<128, 256, 2, 2, 1>(g, fast, nbatch, s);
         case 2: return launch_cfg<256, 128, 2, 2, 1>(g, fast, nbatch, s);

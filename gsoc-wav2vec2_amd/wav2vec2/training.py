@@ -27,6 +27,13 @@ class _DeviceBuffer:
         self.__cuda_array_interface__ = {"shape": (int(numel),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
 
 
+def stage2_learning_rate(epoch, lr1=1e-4, lr2=5e-5, transition_epochs=10):
+    """The reference's stage-2 schedule (training_utils.py:24-31 with main.py:56-58 defaults): `lr1` while
+    `epoch <= transition_epochs` (Keras passes 0-based epochs), `lr2` afterwards.  Assign the result to
+    `Trainer.learning_rate` at the start of each epoch -- what `LearningRateScheduler` does to the optimizer."""
+    return lr1 if epoch <= transition_epochs else lr2
+
+
 class Trainer:
     def __init__(self, model, loss, learning_rate=1e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-7, seed=0,
                  dropout=None, apply_spec_augment=None):

@@ -241,3 +241,10 @@ def test_convert_hf_checkpoint_directory(tmp_path, fmt):
         assert set(z.files) == {V.tf_variable_name(n) for n in w}
         for n, a in w.items():
             assert np.array_equal(z[V.tf_variable_name(n)], a), n
+
+
+def test_stage2_learning_rate_schedule():
+    """training_utils.py:24-31: lr1 for epochs <= transition (0-based), lr2 after."""
+    from wav2vec2.training import stage2_learning_rate
+    assert [stage2_learning_rate(e) for e in (0, 9, 10, 11, 30)] == [1e-4, 1e-4, 1e-4, 5e-5, 5e-5]
+    assert stage2_learning_rate(3, lr1=2e-4, lr2=1e-5, transition_epochs=2) == 1e-5

@@ -9,7 +9,7 @@ from wav2vec2 import variables as V
 from wav2vec2.config import RobustWav2Vec2Config
 torch.cuda.set_device(0)
 out = {}
-for name, cfg, cases in (("base", wav2vec2.Wav2Vec2Config(), [(1, 246000), (4, 246000), (8, 246000), (32, 246000), (64, 246000), (16, 480000)]),
+for name, cfg, cases in (("base", wav2vec2.Wav2Vec2Config(), [(1, 50000), (1, 246000), (4, 246000), (8, 246000), (32, 246000), (64, 246000), (16, 480000)]),
                          ("large-robust", RobustWav2Vec2Config(), [(16, 246000)])):
     m = wav2vec2.Wav2Vec2ForCTC(cfg)
     for B, L in cases:
