@@ -68,11 +68,14 @@ template <> struct FVec<2> { using type = f32x2; };
 
 // SRC: where the operands come from.  0 = fp32 with scalar guards (any shape), 1 = fp32, 16-byte loads,
 // 2 = A from its bf16 shadow, 3 = B from its bf16 [N][K] shadow, 4 = both shadows (no conversion at all: the tile
-// step streams 32 KiB instead of 64).  Shadows hold exactly the values the fp32 path would round to, so all five
+// step streams 32 KiB instead of 64), 5 = both shadows copied HBM/L2 -> LDS by global_load_lds_dwordx4 (the swizzle
+// then goes on the per-lane SOURCE address, as in gemm_f32.hip).  Shadows hold exactly the values the fp32 path would round to, so all five
 // produce bit-identical results.
 template <int SRC, int BM, int BN, int WM, int WN, int MINB, int ABL = 0>
 __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args g) {
-    constexpr bool FAST = SRC >= 1, A16 = SRC == 2 || SRC == 4, B16 = SRC == 3 || SRC == 4;
+    constexpr bool FAST = SRC >= 1, A16 = SRC == 2 || SRC >= 4, B16 = SRC == 3 || SRC >= 4;
+    constexpr bool DMA = SRC >= 5;      // both shadows, LDS-DMA staging (no registers, no ds_write)
+    constexpr int NS = SRC == 6 ? 4 : 2;   // LDS stages; SRC 6 = 4-stage ring, three tiles in flight across raw barriers
     constexpr int NT = WM * WN * 64;
     constexpr int NA16 = BM * 8 / NT, NB16 = BN * 8 / NT;   // 16-byte (8 x bf16) chunks per thread when a shadow is the source
     constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 32, NTL = WTN / 32;   // wave tile, 32x32 accumulators
@@ -296,19 +299,88 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
     // One tile of prefetch: measured on MI355X, a second register set (two fp32 tiles = 128 KiB per block in
     // flight) changed nothing (374 vs 371 TF on conv1) -- the loop is bound by the L2 -> CU operand bandwidth
     // (~15 TB/s across the chip for this 64-KiB-per-tile-step stream), not by latency.
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt + 1 < nk; ++kt) {       // last iteration peeled: the prefetch stays unconditional
-        const int cur = kt & 1;
-        load_tile(kt + 1);                       // fp32 tile in flight under the MFMAs below
-        __builtin_amdgcn_sched_barrier(0);
-        compute(cur);
-        __builtin_amdgcn_sched_barrier(0);
-        store_tile(cur ^ 1);                     // round + transpose + write the other stage
+    if constexpr (DMA) {
+        // 1-KiB pieces: piece p of an image = rows 8p .. 8p+7 (8 lanes x 16 B per row); the lane at physical slot
+        // (lane & 7) fetches logical slot (lane & 7) ^ swz(row).  Pieces are dealt round-robin to the waves.
+        constexpr int NWV = WM * WN, PA = BM / 8, PB = BN / 8, PPA = PA / NWV, PPB = PB / NWV;
+        static_assert(PA % NWV == 0 && PB % NWV == 0, "pieces must divide over the waves");
+        const uint16_t* da[PPA];
+        const uint16_t* db[PPB];
+        const uint16_t* A16p = g.A16 + (int64_t)z * g.strideA;
+#pragma unroll
+        for (int i = 0; i < PPA; ++i) {
+            const int r = (wave * PPA + i) * 8 + (lane >> 3);
+            int row = m0 + r;
+            row = row < g.M ? row : g.M - 1;
+            da[i] = A16p + (int64_t)row * g.lda + (((lane & 7) ^ swz(r)) << 3);
+        }
+#pragma unroll
+        for (int i = 0; i < PPB; ++i) {
+            const int r = (wave * PPB + i) * 8 + (lane >> 3);
+            int col = n0 + r;
+            col = col < g.N ? col : g.N - 1;
+            db[i] = g.B16 + (int64_t)col * g.ldb16 + (((lane & 7) ^ swz(r)) << 3);
+        }
+        auto issue = [&](int kt, int buf) {
+            unsigned char* S = smem16 + buf * STAGE;
+            const int k0 = kt * BK;
+#pragma unroll
+            for (int i = 0; i < PPA; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(da[i] + k0),
+                                                 (__attribute__((address_space(3))) void*)(S + (wave * PPA + i) * 1024), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < PPB; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db[i] + k0),
+                                                 (__attribute__((address_space(3))) void*)(S + BM * ROWB + (wave * PPB + i) * 1024), 16, 0, 0);
+        };
+        if constexpr (NS == 2) {
+            issue(0, 0);
+            __syncthreads();                    // carries the vmcnt(0) that retires the DMA
+            for (int kt = 0; kt + 1 < nk; ++kt) {
+                const int cur = kt & 1;
+                issue(kt + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(cur);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+            }
+            compute((nk - 1) & 1);
+        } else {
+            // Ring of NS stages, NS - 1 tiles in flight.  One MFMA block per tile step is only 512 cycles while an
+            // L2 / HBM round trip under load is several thousand, so a single tile of prefetch leaves the loop
+            // latency-bound.  __syncthreads() would drain every DMA (vmcnt(0)); a counted wait + raw barrier keeps the
+            // younger tiles in flight:  this wave's share of tile kt has landed when at most (NS - 2) tiles' worth of
+            // its own DMA instructions are outstanding, and the barrier extends that to every wave's share.
+            constexpr int PER_TILE = PPA + PPB;
+            static_assert(PER_TILE * (NS - 2) < 64, "vmcnt is a 6-bit counter");
+#pragma unroll
+            for (int t = 0; t < NS - 1; ++t) issue(t < nk ? t : nk - 1, t);      // (re-reads the last tile when K is short)
+            for (int kt = 0; kt < nk; ++kt) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE * (NS - 2)) : "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                const int nxt = kt + NS - 1;
+                issue(nxt < nk ? nxt : nk - 1, nxt % NS);      // into the stage whose MFMAs finished before the barrier
+                __builtin_amdgcn_sched_barrier(0);
+                compute(kt % NS);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {
+        load_tile(0);
+        store_tile(0);
         __syncthreads();
+        for (int kt = 0; kt + 1 < nk; ++kt) {       // last iteration peeled: the prefetch stays unconditional
+            const int cur = kt & 1;
+            load_tile(kt + 1);                       // tile in flight under the MFMAs below
+            __builtin_amdgcn_sched_barrier(0);
+            compute(cur);
+            __builtin_amdgcn_sched_barrier(0);
+            store_tile(cur ^ 1);                     // (round + transpose +) write the other stage
+            __syncthreads();
+        }
+        compute((nk - 1) & 1);
     }
-    compute((nk - 1) & 1);
 
     // ---- epilogue (gemm_epilogue.h): bias -> act -> + residual -> fp32 store and / or bf16 shadow ----
     const int64_t tile_off = (int64_t)z * g.strideC + (int64_t)(m0 + wm * WTM) * g.ldc + (n0 + wn * WTN);
@@ -319,7 +391,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
 
 template <int SRC, int BM, int BN, int WM, int WN, int MINB>
 int launch_src16(Gemm16Args& g, int nbatch, hipStream_t s) {
-    constexpr size_t LDS = 2 * (BM + BN) * ROWB;
+    constexpr size_t LDS = (SRC == 6 ? 4 : 2) * (BM + BN) * ROWB;
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
     static bool attr_set = false;
@@ -341,6 +413,8 @@ int launch_cfg16(Gemm16Args& g, int src, int nbatch, hipStream_t s) {
         case 2: return launch_src16<2, BM, BN, WM, WN, MINB>(g, nbatch, s);
         case 3: return launch_src16<3, BM, BN, WM, WN, MINB>(g, nbatch, s);
         case 4: return launch_src16<4, BM, BN, WM, WN, MINB>(g, nbatch, s);
+        case 5: return launch_src16<5, BM, BN, WM, WN, MINB>(g, nbatch, s);
+        case 6: return launch_src16<6, BM, BN, WM, WN, 1>(g, nbatch, s);
         default: return launch_src16<0, BM, BN, WM, WN, MINB>(g, nbatch, s);
     }
 }
@@ -382,13 +456,17 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
     const bool a16 = x.A16 && kfast && (lda % 8 == 0) && (strideA % 8 == 0) && ((reinterpret_cast<uintptr_t>(x.A16) & 15) == 0);
     const bool b16 = x.B16 && kfast && strideB == 0 && (g.ldb16 % 8 == 0) && ((reinterpret_cast<uintptr_t>(x.B16) & 15) == 0);
     int src;
-    if (a16 && b16) src = 4;
+    static int dma = -1;
+    // tuning knob: 0 = register-staged shadows (595 TF on the forward mix), 1 = LDS-DMA, 2 stages, 2 blocks/CU (617, default),
+    // 2 = LDS-DMA 4-stage ring with three tiles in flight, 1 block/CU (513: deeper prefetch does not pay for half the waves)
+    if (dma < 0) { const char* e = getenv("W2V2_GEMM16_DMA"); dma = e ? atoi(e) : 1; }
+    if (a16 && b16) src = dma == 2 ? 6 : (dma ? 5 : 4);
     else if (a16 && b32) src = 2;
     else if (b16 && a32) src = 3;
     else if (kfast && a32 && b32) src = 1;
     else src = 0;
     W2V2_REQUIRE(src != 0 || (A && B), "gemm_bf16: a shadow-only operand needs K %% 64 == 0 and 16-byte alignment");
-    const double abytes = (src == 2 || src == 4) ? 2.0 : 4.0, bbytes = (src == 3 || src == 4) ? 2.0 : 4.0;
+    const double abytes = (src == 2 || src >= 4) ? 2.0 : 4.0, bbytes = (src >= 3) ? 2.0 : 4.0;
     ProfScope ps(prof, FAM_GEMM_BF16, 2.0 * M * (double)N * K * nbatch,
                  nbatch * (abytes * (double)M * K + (C ? 4.0 : 0.0) * (double)M * N + (x.C16 ? 2.0 : 0.0) * (double)M * N) +
                      bbytes * (double)K * N, s);
