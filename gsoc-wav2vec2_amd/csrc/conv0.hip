@@ -147,6 +147,91 @@ __global__ void conv0_finalize_kernel(Conv0Args a, int B) {
     a.scale_shift[((int64_t)b * 2 + 1) * a.C + c] = (float)((double)a.beta[c] - mean * inv);
 }
 
+// ---- GroupNorm statistics without computing the conv (K = 10) ---------------------------------------------------
+// sum_t y[t,c] and sum_t y[t,c]^2 of  y[t,c] = bias_c + sum_k w[k,c] x[S t + k]  are a linear and a quadratic form in
+//   X1[k] = sum_t x[S t + k]              (K numbers per sample)
+//   R[k,k'] = sum_t x[S t + k] x[S t + k']  (K (K+1) / 2 numbers per sample: the strided autocorrelation of the waveform)
+// so the statistics of all 512 channels cost 65 accumulators per frame instead of 512 x 10 multiply-adds: the pass
+// that recomputed the whole conv (0.27 ms) and the 201 MB of per-chunk fp64 partials it fed to the finalize kernel
+// (0.30 ms) become 2.7 M multiply-adds per sample and 65 doubles per block.  Products are exact in fp64 of fp32 inputs;
+// a thread sums 8 of them in fp32 before everything else is carried in fp64.
+constexpr int GK = 10, GN = GK + GK * (GK + 1) / 2;   // 65
+constexpr int GFR = 2048;                              // frames per block
+
+__global__ __launch_bounds__(256) void conv0_gram_kernel(Conv0Args a, int nblk) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    __shared__ double red[4][GN];
+    const int b = blockIdx.y, blk = blockIdx.x, S = a.stride;
+    const int t0 = blk * GFR, nt = min(GFR, a.T0 - t0), nx = (nt - 1) * S + GK;
+    const float* __restrict__ wv = a.wave + (int64_t)b * a.L + (int64_t)t0 * S;
+    for (int i = threadIdx.x; i < nx; i += 256) xs[i] = wv[i];
+    __syncthreads();
+    float acc[GN];
+#pragma unroll
+    for (int i = 0; i < GN; ++i) acc[i] = 0.f;
+    for (int t = threadIdx.x; t < nt; t += 256) {
+        float xv[GK];
+#pragma unroll
+        for (int k = 0; k < GK; ++k) xv[k] = xs[t * S + k];
+        int n = GK;
+#pragma unroll
+        for (int k = 0; k < GK; ++k) {
+            acc[k] += xv[k];
+#pragma unroll
+            for (int k2 = k; k2 < GK; ++k2) {
+                acc[n] = fmaf(xv[k], xv[k2], acc[n]);
+                ++n;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < GN; ++i) {
+        double v = (double)acc[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < GN)
+        a.partial[((int64_t)b * nblk + blk) * GN + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// one block per sample: combine the Gram partials, then every channel evaluates its two forms in fp64
+__global__ __launch_bounds__(256) void conv0_gram_finalize_kernel(Conv0Args a, int nblk) {
+    __shared__ double g[GN];
+    const int b = blockIdx.x;
+    if (threadIdx.x < GN) {
+        double v = 0.0;
+        for (int i = 0; i < nblk; ++i) v += a.partial[((int64_t)b * nblk + i) * GN + threadIdx.x];
+        g[threadIdx.x] = v;
+    }
+    __syncthreads();
+    const double n = (double)a.T0;
+    for (int c = threadIdx.x; c < a.C; c += 256) {
+        double w[GK];
+#pragma unroll
+        for (int k = 0; k < GK; ++k) w[k] = (double)a.kernel[(int64_t)k * a.C + c];
+        double lin = 0.0, quad = 0.0;
+        int idx = GK;
+#pragma unroll
+        for (int k = 0; k < GK; ++k) {
+            lin += w[k] * g[k];
+#pragma unroll
+            for (int k2 = k; k2 < GK; ++k2) quad += (k2 == k ? 1.0 : 2.0) * w[k] * w[k2] * g[idx++];
+        }
+        const double bias = a.bias ? (double)a.bias[c] : 0.0;
+        const double s1 = lin + n * bias, s2 = quad + 2.0 * bias * lin + n * bias * bias;
+        const double mean = s1 / n;
+        double var = s2 / n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const double inv = (double)a.gamma[c] / sqrt(var + (double)a.eps);
+        a.scale_shift[((int64_t)b * 2 + 0) * a.C + c] = (float)inv;
+        a.scale_shift[((int64_t)b * 2 + 1) * a.C + c] = (float)((double)a.beta[c] - mean * inv);
+    }
+}
+
 template <int MODE>
 void launch_mode(const Conv0Args& a, int B, hipStream_t s) {
     dim3 grid(a.nchunks, B), block(256);
@@ -203,9 +288,22 @@ int launch_conv0_x(Profiler* prof, const float* wave, const float* kernel, const
     a.scale_shift = reinterpret_cast<float*>(a.partial + (int64_t)B * a.nchunks * 2 * C);
     {
         ProfScope ps(prof, FAM_CONV0_STATS, flops, in_bytes, s);
-        launch_mode<0>(a, B, s);
-        const int64_t n = (int64_t)B * C;
-        hipLaunchKernelGGL(conv0_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, B);
+        if (K == GK) {
+            const int nblk = (a.T0 + GFR - 1) / GFR;
+            const size_t lds = ((size_t)(GFR - 1) * stride + GK + 4) * sizeof(float);
+            if (lds <= 60 * 1024) {
+                hipLaunchKernelGGL(conv0_gram_kernel, dim3(nblk, B), dim3(256), lds, s, a, nblk);
+                hipLaunchKernelGGL(conv0_gram_finalize_kernel, dim3(B), dim3(256), 0, s, a, nblk);
+            } else {
+                launch_mode<0>(a, B, s);
+                const int64_t n = (int64_t)B * C;
+                hipLaunchKernelGGL(conv0_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, B);
+            }
+        } else {
+            launch_mode<0>(a, B, s);
+            const int64_t n = (int64_t)B * C;
+            hipLaunchKernelGGL(conv0_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, B);
+        }
     }
     {
         ProfScope ps(prof, FAM_CONV0_APPLY, flops, in_bytes + out_bytes, s);

@@ -12,6 +12,9 @@
 namespace w2v2 {
 namespace {
 
+// One wave walks rows  first, first + stride, ...  with the NEXT row's loads issued before the current row is reduced,
+// so a wave always has a 3-KiB row in flight: a one-row-per-wave launch (24.5 k short-lived waves for a (24576, 768)
+// tensor) spent more time starting waves than moving data (2.85 TB/s); this form is bandwidth-bound.
 template <int NV>   // NV float4 per lane: covers C <= NV * 256
 __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict__ x,
                                                          float* __restrict__ y,
@@ -20,64 +23,89 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict
                                                          const float* __restrict__ beta,
                                                          int64_t rows, int C, float eps, int act) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float* xr = x + row * C;
-    float* yr = y + row * C;
     const bool vec = (C & 3) == 0;
-    float4 v[NV];
-    float sum = 0.f;
+    auto load_row = [&](int64_t r, float4 (&v)[NV]) {
+        const float* xr = x + r * C;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = (i * 64 + lane) * 4;
-        if (vec && c < C) {
-            v[i] = *reinterpret_cast<const float4*>(xr + c);
-        } else {
-            v[i].x = c + 0 < C ? xr[c + 0] : 0.f;
-            v[i].y = c + 1 < C ? xr[c + 1] : 0.f;
-            v[i].z = c + 2 < C ? xr[c + 2] : 0.f;
-            v[i].w = c + 3 < C ? xr[c + 3] : 0.f;
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (vec && c < C) {
+                v[i] = *reinterpret_cast<const float4*>(xr + c);
+            } else {
+                v[i].x = c + 0 < C ? xr[c + 0] : 0.f;
+                v[i].y = c + 1 < C ? xr[c + 1] : 0.f;
+                v[i].z = c + 2 < C ? xr[c + 2] : 0.f;
+                v[i].w = c + 3 < C ? xr[c + 3] : 0.f;
+            }
         }
-        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    }
-    const float mean = wave_sum(sum) / (float)C;
-    float sq = 0.f;
+    };
+    // gamma / beta of this lane's columns stay in registers across rows
+    float4 gv[NV], bv[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
-        const float dx = c + 0 < C ? v[i].x - mean : 0.f;
-        const float dy = c + 1 < C ? v[i].y - mean : 0.f;
-        const float dz = c + 2 < C ? v[i].z - mean : 0.f;
-        const float dw = c + 3 < C ? v[i].w - mean : 0.f;
-        v[i] = make_float4(dx, dy, dz, dw);
-        sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        gv[i] = make_float4(c + 0 < C ? gamma[c + 0] : 0.f, c + 1 < C ? gamma[c + 1] : 0.f, c + 2 < C ? gamma[c + 2] : 0.f,
+                            c + 3 < C ? gamma[c + 3] : 0.f);
+        bv[i] = make_float4(c + 0 < C ? beta[c + 0] : 0.f, c + 1 < C ? beta[c + 1] : 0.f, c + 2 < C ? beta[c + 2] : 0.f,
+                            c + 3 < C ? beta[c + 3] : 0.f);
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)C + eps);
+    float4 v[NV], nx[NV];
+    load_row(row, v);
+    while (true) {
+        const int64_t next = row + stride;
+        const bool more = next < rows;
+        load_row(more ? next : row, nx);          // unconditional prefetch (re-reads the last row once): stays in registers
+        float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = (i * 64 + lane) * 4;
-        if (c >= C) continue;
-        float o[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+        for (int i = 0; i < NV; ++i) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        const float mean = wave_sum(sum) / (float)C;
+        float sq = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (c + e < C) o[e] = apply_act(o[e] * rstd * gamma[c + e] + beta[c + e], act);
-        if (y16) {      // nearest-even bf16 copy for the consumer GEMM (precision mode 1)
-            uint16_t* hr = y16 + row * C + c;
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            const float dx = c + 0 < C ? v[i].x - mean : 0.f;
+            const float dy = c + 1 < C ? v[i].y - mean : 0.f;
+            const float dz = c + 2 < C ? v[i].z - mean : 0.f;
+            const float dw = c + 3 < C ? v[i].w - mean : 0.f;
+            v[i] = make_float4(dx, dy, dz, dw);
+            sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)C + eps);
+        float* yr = y + row * C;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c >= C) continue;
+            float o[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+            const float g4[4] = {gv[i].x, gv[i].y, gv[i].z, gv[i].w}, b4[4] = {bv[i].x, bv[i].y, bv[i].z, bv[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e < C) o[e] = apply_act(o[e] * rstd * g4[e] + b4[e], act);
+            if (y16) {      // nearest-even bf16 copy for the consumer GEMM (precision mode 1)
+                uint16_t* hr = y16 + row * C + c;
+                if (vec) {
+                    *reinterpret_cast<uint2*>(hr) = make_uint2(pack_bf16_rne(o[0], o[1]), pack_bf16_rne(o[2], o[3]));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c + e < C) hr[e] = (uint16_t)pack_bf16_rne(o[e], 0.f);
+                }
+            }
             if (vec) {
-                *reinterpret_cast<uint2*>(hr) = make_uint2(pack_bf16_rne(o[0], o[1]), pack_bf16_rne(o[2], o[3]));
+                *reinterpret_cast<float4*>(yr + c) = make_float4(o[0], o[1], o[2], o[3]);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (c + e < C) hr[e] = (uint16_t)pack_bf16_rne(o[e], 0.f);
+                    if (c + e < C) yr[c + e] = o[e];
             }
         }
-        if (vec) {
-            *reinterpret_cast<float4*>(yr + c) = make_float4(o[0], o[1], o[2], o[3]);
-        } else {
+        if (!more) break;
+        row = next;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (c + e < C) yr[c + e] = o[e];
-        }
+        for (int i = 0; i < NV; ++i) v[i] = nx[i];
     }
 }
 
@@ -93,7 +121,9 @@ int launch_layer_norm_x(Profiler* prof, const float* x, float* y, const float* g
     W2V2_REQUIRE(x && y && gamma && beta, "layer_norm: null operand");
     W2V2_REQUIRE(rows > 0 && C > 0 && C <= 2048, "layer_norm: rows=%lld C=%d unsupported (C <= 2048)",
                  (long long)rows, C);
-    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    // at most 8 blocks per CU resident (32 waves): beyond that each wave loops over rows
+    const int64_t want = (rows + 3) / 4;
+    dim3 grid((unsigned)(want < 256 * 8 ? want : 256 * 8)), block(256);
     ProfScope ps(prof, FAM_LAYERNORM, 8.0 * rows * C, (y16 ? 10.0 : 8.0) * rows * C, s);
     if (C <= 256)
         hipLaunchKernelGGL(layer_norm_kernel<1>, grid, block, 0, s, x, y, y16, gamma, beta, rows, C, eps, act);
