@@ -46,6 +46,15 @@ __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t stream, uin
 }
 #endif
 
+// one 4096-element piece of one variable for the single-launch Adam: p = variable + offset, goff = its offset in the
+// flat gradient / moment buffers
+struct AdamChunk {
+    float* p;
+    int64_t goff;
+    int n;
+};
+int launch_adam_multi(const AdamChunk* chunks_dev, int nchunks, const float* grads, float* m, float* v, float lr_t, float b1,
+                      float b2, float eps, hipStream_t s);
 int launch_dropout_fwd(const float* x, const float* res, float* y, int64_t n, int act, float p,
                        uint64_t seed, uint32_t stream_id, hipStream_t s);
 int launch_dropout_bwd(const float* u, const float* dy, float* dx, int64_t n, int act, float p,

@@ -42,6 +42,9 @@ struct TrainState {
     uint64_t seed = 0;
     // gradient / optimizer state: flat, inventory order
     float *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+    AdamChunk* adam_chunks = nullptr;        // device table for the single-launch Adam; rebuilt when `trainable` changes
+    int adam_nchunks = 0;
+    bool adam_table_fresh = false;
     std::vector<int64_t> goff;
     int64_t gtotal = 0;
     std::vector<char> trainable;
@@ -69,6 +72,7 @@ static void t_free(TrainState* t) {
 void w2v2_train_destroy(w2v2_model* m) {
     if (!m || !m->train) return;
     t_free(m->train);
+    if (m->train->adam_chunks) (void)hipFree(m->train->adam_chunks);
     delete m->train;
     m->train = nullptr;
 }
@@ -244,6 +248,7 @@ int w2v2_set_trainable(w2v2_model* m, const char* prefix, int trainable) {
     for (size_t i = 0; i < m->params.size(); ++i)
         if (m->params[i].name.compare(0, strlen(prefix), prefix) == 0) {
             t->trainable[i] = trainable ? 1 : 0;
+            t->adam_table_fresh = false;
             ++hits;
         }
     if (!hits) {
@@ -662,13 +667,26 @@ int w2v2_adam_step(w2v2_model* m, float lr, float beta1, float beta2, float eps,
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     // Keras: lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t);  p -= lr_t * m / (sqrt(v) + eps)
     const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
-    for (size_t i = 0; i < m->params.size(); ++i) {
-        if (!t->trainable[i]) continue;
-        Param& p = m->params[i];
-        const int64_t off = t->goff[i];
-        if (int e = launch_adam(p.dev, t->grads + off, t->adam_m + off, t->adam_v + off, p.numel, (float)lr_t, beta1, beta2, eps, s))
-            return e;
+    if (!t->adam_table_fresh) {
+        std::vector<AdamChunk> host;
+        for (size_t i = 0; i < m->params.size(); ++i) {
+            if (!t->trainable[i]) continue;
+            const Param& p = m->params[i];
+            for (int64_t o = 0; o < p.numel; o += 4096)
+                host.push_back(AdamChunk{p.dev + o, t->goff[i] + o, (int)(p.numel - o < 4096 ? p.numel - o : 4096)});
+        }
+        if (t->adam_chunks) (void)hipFree(t->adam_chunks);
+        t->adam_chunks = nullptr;
+        t->adam_nchunks = (int)host.size();
+        if (!host.empty()) {
+            W2V2_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&t->adam_chunks), host.size() * sizeof(AdamChunk)));
+            W2V2_HIP_CHECK(hipMemcpy(t->adam_chunks, host.data(), host.size() * sizeof(AdamChunk), hipMemcpyHostToDevice));
+        }
+        t->adam_table_fresh = true;
     }
+    if (t->adam_nchunks > 0)
+        if (int e = launch_adam_multi(t->adam_chunks, t->adam_nchunks, t->grads, t->adam_m, t->adam_v, (float)lr_t, beta1, beta2, eps, s))
+            return e;
     t->transposes_fresh = false;
     m->finalized = false;
     return w2v2_finalize(m, stream);     // re-derive the effective positional kernel and the packed q|k|v
