@@ -117,25 +117,68 @@ __global__ void transpose_kernel(const float* __restrict__ x, float* __restrict_
     }
 }
 
-// stage 1: partial[chunk][c] = sum over the chunk's rows of x[r][c]   (fp32 within a chunk)
+// stage 1: partial[chunk][c] = sum over the chunk's rows of x[r][c]   (fp32 within a chunk).  HBM-bound: a thread owns
+// 4 columns (16-byte loads) and keeps 4 rows in flight.
+template <bool VEC>
 __global__ void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
                                       int64_t rows, int cols, int rows_per_chunk) {
-    const int c = blockIdx.x * EW_THREADS + threadIdx.x;
-    if (c >= cols) return;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
     const int64_t r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
-    float acc = 0.f;
-    for (int64_t r = r0; r < r1; ++r) acc += x[r * cols + c];
-    partial[(int64_t)blockIdx.y * cols + c] = acc;
+    if (VEC) {
+        const int c = (blockIdx.x * EW_THREADS + threadIdx.x) * 4;
+        if (c >= cols) return;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+        int64_t r = r0;
+        for (; r + 3 < r1; r += 4) {
+            const float4 v0 = *reinterpret_cast<const float4*>(x + r * cols + c);
+            const float4 v1 = *reinterpret_cast<const float4*>(x + (r + 1) * cols + c);
+            const float4 v2 = *reinterpret_cast<const float4*>(x + (r + 2) * cols + c);
+            const float4 v3 = *reinterpret_cast<const float4*>(x + (r + 3) * cols + c);
+            a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+            a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+            a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+            a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+        }
+        for (; r < r1; ++r) {
+            const float4 v0 = *reinterpret_cast<const float4*>(x + r * cols + c);
+            a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        }
+        *reinterpret_cast<float4*>(partial + (int64_t)blockIdx.y * cols + c) =
+            make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
+                        (a0.w + a1.w) + (a2.w + a3.w));
+    } else {
+        const int c = blockIdx.x * EW_THREADS + threadIdx.x;
+        if (c >= cols) return;
+        float acc = 0.f;
+        for (int64_t r = r0; r < r1; ++r) acc += x[r * cols + c];
+        partial[(int64_t)blockIdx.y * cols + c] = acc;
+    }
 }
 // stage 2: out[c] (+)= sum over chunks, fp64 accumulate
+template <bool VEC>
 __global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                     int nchunks, int cols, int64_t ld, int accumulate) {
-    const int c = blockIdx.x * EW_THREADS + threadIdx.x;
-    if (c >= cols) return;
-    double acc = 0.0;
-    for (int k = 0; k < nchunks; ++k) acc += (double)partial[(int64_t)k * ld + c];
-    out[c] = accumulate ? out[c] + (float)acc : (float)acc;
+    if (VEC) {
+        const int c = (blockIdx.x * EW_THREADS + threadIdx.x) * 4;
+        if (c >= cols) return;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        for (int k = 0; k < nchunks; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(partial + (int64_t)k * ld + c);
+            a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+        }
+        float4 o = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
+        if (accumulate) {
+            const float4 p = *reinterpret_cast<const float4*>(out + c);
+            o = make_float4(p.x + o.x, p.y + o.y, p.z + o.z, p.w + o.w);
+        }
+        *reinterpret_cast<float4*>(out + c) = o;
+    } else {
+        const int c = blockIdx.x * EW_THREADS + threadIdx.x;
+        if (c >= cols) return;
+        double acc = 0.0;
+        for (int k = 0; k < nchunks; ++k) acc += (double)partial[(int64_t)k * ld + c];
+        out[c] = accumulate ? out[c] + (float)acc : (float)acc;
+    }
 }
 // stage 2 for many chunks x few columns: 32 columns per block, the chunk loop split over 8 thread rows
 __global__ __launch_bounds__(256) void colsum_final_wide_kernel(const float* __restrict__ partial, float* __restrict__ out,
@@ -339,22 +382,31 @@ int launch_transpose(const float* x, float* y, int rows, int cols, int nbatch, h
     return W2V2_OK;
 }
 
-constexpr int COLSUM_CHUNK = 128;    // rows per stage-1 block
+constexpr int COLSUM_CHUNK = 256;    // rows per stage-1 block
 
 int64_t colsum_ws_floats(int64_t rows, int cols) { return ((rows + COLSUM_CHUNK - 1) / COLSUM_CHUNK) * (int64_t)cols + 8; }
 
 int launch_colsum(const float* x, float* out, int64_t rows, int cols, float* ws, int accumulate, hipStream_t s) {
     W2V2_REQUIRE(x && out && rows > 0 && cols > 0, "colsum: bad argument");
+    const bool vec = (cols & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(ws)) & 15) == 0;
+    const int per_block = vec ? 4 * EW_THREADS : EW_THREADS;
     if (rows <= 64) {   // few rows (split-K slabs): one pass, fp64 accumulate, no scratch
-        hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + EW_THREADS - 1) / EW_THREADS), dim3(EW_THREADS), 0, s, x, out,
-                           (int)rows, cols, (int64_t)cols, accumulate);
+        if (vec)
+            hipLaunchKernelGGL(colsum_final_kernel<true>, dim3((cols + per_block - 1) / per_block), dim3(EW_THREADS), 0, s, x, out,
+                               (int)rows, cols, (int64_t)cols, accumulate);
+        else
+            hipLaunchKernelGGL(colsum_final_kernel<false>, dim3((cols + per_block - 1) / per_block), dim3(EW_THREADS), 0, s, x, out,
+                               (int)rows, cols, (int64_t)cols, accumulate);
         W2V2_HIP_CHECK(hipGetLastError());
         return W2V2_OK;
     }
     W2V2_REQUIRE(ws, "colsum: null workspace");
     const int nchunks = (int)((rows + COLSUM_CHUNK - 1) / COLSUM_CHUNK);
-    dim3 grid((cols + EW_THREADS - 1) / EW_THREADS, nchunks);
-    hipLaunchKernelGGL(colsum_partial_kernel, grid, dim3(EW_THREADS), 0, s, x, ws, rows, cols, COLSUM_CHUNK);
+    dim3 grid((cols + per_block - 1) / per_block, nchunks);
+    if (vec)
+        hipLaunchKernelGGL(colsum_partial_kernel<true>, grid, dim3(EW_THREADS), 0, s, x, ws, rows, cols, COLSUM_CHUNK);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel<false>, grid, dim3(EW_THREADS), 0, s, x, ws, rows, cols, COLSUM_CHUNK);
     hipLaunchKernelGGL(colsum_final_wide_kernel, dim3((cols + 31) / 32), dim3(256), 0, s, ws, out, nchunks, cols, (int64_t)cols, accumulate);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
