@@ -213,19 +213,43 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     for (int i = 0; i < NV; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) dg[i][e] = db[i][e] = 0.f;
+    const bool vec = (C & 3) == 0;
+    float gam[NV][4];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = (i * 64 + lane) * 4 + e;
+            gam[i][e] = c < C ? gamma[c] : 0.f;
+        }
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
         const float* xr = x + row * C;
         const float* dr = dy + row * C;
-        float xv[NV][4], gv[NV][4];
+        float xv[NV][4], gv[NV][4], dv[NV][4];
         float sum = 0.f;
+        if (vec) {      // 16-byte loads of x and dy issued together
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                const float4 a = c < C ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 d = c < C ? *reinterpret_cast<const float4*>(dr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                xv[i][0] = a.x; xv[i][1] = a.y; xv[i][2] = a.z; xv[i][3] = a.w;
+                dv[i][0] = d.x; dv[i][1] = d.y; dv[i][2] = d.z; dv[i][3] = d.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = (i * 64 + lane) * 4 + e;
+                    xv[i][e] = c < C ? xr[c] : 0.f;
+                    dv[i][e] = c < C ? dr[c] : 0.f;
+                }
+        }
 #pragma unroll
         for (int i = 0; i < NV; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = (i * 64 + lane) * 4 + e;
-                xv[i][e] = c < C ? xr[c] : 0.f;
-                sum += xv[i][e];
-            }
+            for (int e = 0; e < 4; ++e) sum += xv[i][e];
         const float mean = wave_sum(sum) / (float)C;
         float sq = 0.f;
 #pragma unroll
@@ -243,10 +267,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int c = (i * 64 + lane) * 4 + e;
-                const float d = c < C ? dr[c] : 0.f;
+                const float d = dv[i][e];
                 const float xh = xv[i][e] * rstd;
                 xv[i][e] = xh;
-                gv[i][e] = c < C ? d * gamma[c] : 0.f;
+                gv[i][e] = c < C ? d * gam[i][e] : 0.f;
                 dg[i][e] += d * xh;
                 db[i][e] += d;
                 s1 += gv[i][e];
@@ -255,13 +279,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
         s1 = wave_sum(s1) / (float)C;
         s2 = wave_sum(s2) / (float)C;
         float* dxr = dx + row * C;
+        if (vec) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = (i * 64 + lane) * 4 + e;
-                if (c < C) dxr[c] = rstd * (gv[i][e] - s1 - xv[i][e] * s2);
+            for (int i = 0; i < NV; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                if (c < C)
+                    *reinterpret_cast<float4*>(dxr + c) =
+                        make_float4(rstd * (gv[i][0] - s1 - xv[i][0] * s2), rstd * (gv[i][1] - s1 - xv[i][1] * s2),
+                                    rstd * (gv[i][2] - s1 - xv[i][2] * s2), rstd * (gv[i][3] - s1 - xv[i][3] * s2));
             }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = (i * 64 + lane) * 4 + e;
+                    if (c < C) dxr[c] = rstd * (gv[i][e] - s1 - xv[i][e] * s2);
+                }
+        }
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i)
