@@ -92,6 +92,9 @@ struct GemmShadows {
     const uint16_t* B16 = nullptr;
     uint16_t* C16 = nullptr;
     int64_t ldb16 = 0;
+    // A is stored TRANSPOSED: element (m, k) at A[k * lda + m] (fp32).  The weight-gradient GEMM dW = X^T dY passes the
+    // activation X itself this way, so no transposed copy of X is made in precision mode 1.
+    bool transA = false;
 };
 int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
                        int64_t strideB, float* C, int64_t ldc, int64_t strideC, const float* bias,

@@ -69,12 +69,14 @@ template <> struct FVec<2> { using type = f32x2; };
 // SRC: where the operands come from.  0 = fp32 with scalar guards (any shape), 1 = fp32, 16-byte loads,
 // 2 = A from its bf16 shadow, 3 = B from its bf16 [N][K] shadow, 4 = both shadows (no conversion at all: the tile
 // step streams 32 KiB instead of 64), 5 = both shadows copied HBM/L2 -> LDS by global_load_lds_dwordx4 (the swizzle
-// then goes on the per-lane SOURCE address, as in gemm_f32.hip).  Shadows hold exactly the values the fp32 path would round to, so all five
+// then goes on the per-lane SOURCE address, as in gemm_f32.hip), 7 = fp32 with A TRANSPOSED in memory ((K, M), the
+// activation itself in a weight-gradient GEMM  dW = X^T dY): A takes B's register-transposing path, no transposed copy.  Shadows hold exactly the values the fp32 path would round to, so all five
 // produce bit-identical results.
 template <int SRC, int BM, int BN, int WM, int WN, int MINB, int ABL = 0>
 __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args g) {
-    constexpr bool FAST = SRC >= 1, A16 = SRC == 2 || SRC >= 4, B16 = SRC == 3 || SRC >= 4;
-    constexpr bool DMA = SRC >= 5;      // both shadows, LDS-DMA staging (no registers, no ds_write)
+    constexpr bool FAST = SRC >= 1, A16 = SRC == 2 || (SRC >= 4 && SRC <= 6), B16 = SRC == 3 || (SRC >= 4 && SRC <= 6);
+    constexpr bool DMA = SRC == 5 || SRC == 6;      // both shadows, LDS-DMA staging (no registers, no ds_write)
+    constexpr bool AT = SRC == 7;                   // A given TRANSPOSED ((K, M) fp32, m-contiguous): staged like B
     constexpr int NS = SRC == 6 ? 4 : 2;   // LDS stages; SRC 6 = 4-stage ring, three tiles in flight across raw barriers
     constexpr int NT = WM * WN * 64;
     constexpr int NA16 = BM * 8 / NT, NB16 = BN * 8 / NT;   // 16-byte (8 x bf16) chunks per thread when a shadow is the source
@@ -128,6 +130,20 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
         b_off[i] = (int64_t)(ks * 8) * g.ldb + col;
     }
 
+    // A^T source (SRC 7): 8(k) x 4(m) patches exactly like B; element (m, k) of A lives at A[k * lda + m]
+    constexpr int NQA = BM / 4, NAT = 8 * NQA / NT;
+    f32x4 rat[AT ? NAT : 1][8];
+    int64_t at_off[AT ? NAT : 1];
+    if constexpr (AT) {
+#pragma unroll
+        for (int i = 0; i < NAT; ++i) {
+            const int idx = tid + i * NT, q = idx % NQA, ks = idx / NQA;
+            int row = m0 + 4 * q;
+            row = row < g.M ? row : (g.M >= 4 ? g.M - 4 : 0);
+            at_off[i] = (int64_t)(ks * 8) * g.lda + row;
+        }
+    }
+
     // shadow sources: 8 lanes x 16 B = one 128-byte tile row, stored to LDS as loaded
     u32x4 ra16[A16 ? NA16 : 1], rb16[B16 ? NB16 : 1];
     const uint16_t* a16_src[A16 ? NA16 : 1];
@@ -178,8 +194,14 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
 #pragma unroll
             for (int i = 0; i < NB16; ++i) rb16[i] = *reinterpret_cast<const u32x4*>(b16_src[i] + k0);
         }
+        if constexpr (AT) {
 #pragma unroll
-        for (int i = 0; i < (A16 ? 0 : NA); ++i) {
+            for (int i = 0; i < NAT; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) rat[i][kk] = *reinterpret_cast<const f32x4*>(A + at_off[i] + (int64_t)(k0 + kk) * g.lda);
+        }
+#pragma unroll
+        for (int i = 0; i < ((A16 || AT) ? 0 : NA); ++i) {
             if constexpr (FAST) {
                 ra[i] = *reinterpret_cast<const f32x4*>(A + a_off[i] + k0);
             } else {
@@ -224,8 +246,24 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
 #pragma unroll
             for (int i = 0; i < NB16; ++i) *reinterpret_cast<u32x4*>(S + b16_lds[i]) = rb16[i];
         }
+        if constexpr (AT) {
 #pragma unroll
-        for (int i = 0; i < (A16 ? 0 : NA); ++i) {
+            for (int i = 0; i < NAT; ++i) {
+                const int q = (tid + i * NT) % NQA, ks = (tid + i * NT) / NQA;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    u32x4 p;
+                    p[0] = pack_bf16(rat[i][0][j], rat[i][1][j]);
+                    p[1] = pack_bf16(rat[i][2][j], rat[i][3][j]);
+                    p[2] = pack_bf16(rat[i][4][j], rat[i][5][j]);
+                    p[3] = pack_bf16(rat[i][6][j], rat[i][7][j]);
+                    const int r = 4 * q + j;
+                    *reinterpret_cast<u32x4*>(S + r * ROWB + ((ks ^ swz(r)) << 4)) = p;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < ((A16 || AT) ? 0 : NA); ++i) {
             u32x2 p;
             p[0] = pack_bf16(ra[i][0], ra[i][1]);
             p[1] = pack_bf16(ra[i][2], ra[i][3]);
@@ -415,6 +453,7 @@ int launch_cfg16(Gemm16Args& g, int src, int nbatch, hipStream_t s) {
         case 4: return launch_src16<4, BM, BN, WM, WN, MINB>(g, nbatch, s);
         case 5: return launch_src16<5, BM, BN, WM, WN, MINB>(g, nbatch, s);
         case 6: return launch_src16<6, BM, BN, WM, WN, 1>(g, nbatch, s);
+        case 7: return launch_src16<7, BM, BN, WM, WN, MINB>(g, nbatch, s);
         default: return launch_src16<0, BM, BN, WM, WN, MINB>(g, nbatch, s);
     }
 }
@@ -444,6 +483,7 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
     W2V2_REQUIRE((A || x.A16) && (B || x.B16) && (C || x.C16), "gemm_bf16: null operand");
     W2V2_REQUIRE(M > 0 && N > 0 && K > 0 && nbatch > 0, "gemm_bf16: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, nbatch);
     W2V2_REQUIRE(lda >= 1 && ldb >= N && ldc >= N && ldc < (1 << 23), "gemm_bf16: bad leading dimensions");
+    static int dma = -1;
     W2V2_REQUIRE(act >= 0 && act <= 2, "gemm_bf16: bad activation %d", act);
     Gemm16Args g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.residual = residual;
@@ -456,17 +496,21 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
     const bool a16 = x.A16 && kfast && (lda % 8 == 0) && (strideA % 8 == 0) && ((reinterpret_cast<uintptr_t>(x.A16) & 15) == 0);
     const bool b16 = x.B16 && kfast && strideB == 0 && (g.ldb16 % 8 == 0) && ((reinterpret_cast<uintptr_t>(x.B16) & 15) == 0);
     int src;
-    static int dma = -1;
     // tuning knob: 0 = register-staged shadows (595 TF on the forward mix), 1 = LDS-DMA, 2 stages, 2 blocks/CU (617, default),
     // 2 = LDS-DMA 4-stage ring with three tiles in flight, 1 block/CU (513: deeper prefetch does not pay for half the waves)
     if (dma < 0) { const char* e = getenv("W2V2_GEMM16_DMA"); dma = e ? atoi(e) : 1; }
-    if (a16 && b16) src = dma == 2 ? 6 : (dma ? 5 : 4);
+    if (x.transA) {
+        W2V2_REQUIRE(A && kfast && b32 && (M % 4 == 0) && (lda % 4 == 0) && (strideA % 4 == 0) &&
+                         ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && lda >= M,
+                     "gemm_bf16: transposed A needs fp32 A and B, K %% 64 == 0, M %% 4 == 0 and 16-byte alignment");
+        src = 7;
+    } else if (a16 && b16) src = dma == 2 ? 6 : (dma ? 5 : 4);
     else if (a16 && b32) src = 2;
     else if (b16 && a32) src = 3;
     else if (kfast && a32 && b32) src = 1;
     else src = 0;
     W2V2_REQUIRE(src != 0 || (A && B), "gemm_bf16: a shadow-only operand needs K %% 64 == 0 and 16-byte alignment");
-    const double abytes = (src == 2 || src >= 4) ? 2.0 : 4.0, bbytes = (src >= 3) ? 2.0 : 4.0;
+    const double abytes = (src == 2 || (src >= 4 && src <= 6)) ? 2.0 : 4.0, bbytes = (src >= 3 && src <= 6) ? 2.0 : 4.0;
     ProfScope ps(prof, FAM_GEMM_BF16, 2.0 * M * (double)N * K * nbatch,
                  nbatch * (abytes * (double)M * K + (C ? 4.0 : 0.0) * (double)M * N + (x.C16 ? 2.0 : 0.0) * (double)M * N) +
                      bbytes * (double)K * N, s);

@@ -675,6 +675,13 @@ int w2v2_op_gemm_bf16(const float* A, int64_t lda, int64_t strideA, const float*
     return launch_gemm_bf16(nullptr, A, lda, strideA, B, ldb, 0, C, ldc, strideC, bias, residual, M, N, K, nbatch, act,
                             reinterpret_cast<hipStream_t>(stream));
 }
+int w2v2_op_gemm_bf16_at(const float* At, int64_t lda, int64_t strideA, const float* B, int64_t ldb, int64_t strideB,
+                         float* C, int64_t ldc, int64_t strideC, int32_t M, int32_t N, int32_t K, int32_t nbatch, void* stream) {
+    GemmShadows x;
+    x.transA = true;
+    return launch_gemm_bf16_x(nullptr, At, lda, strideA, B, ldb, strideB, C, ldc, strideC, nullptr, nullptr, M, N, K, nbatch, 0, x,
+                              reinterpret_cast<hipStream_t>(stream));
+}
 int w2v2_op_layer_norm(const float* x, float* y, const float* gamma, const float* beta, int64_t rows,
                        int32_t C, float eps, int32_t act, void* stream) {
     return launch_layer_norm(nullptr, x, y, gamma, beta, rows, C, eps, act, reinterpret_cast<hipStream_t>(stream));

@@ -215,16 +215,36 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
                        float* db, hipStream_t s) {
     TrainState* t = m->train;
     if (dW) {
-        if (int e = launch_transpose(A, t->at, M, Kin, 1, s)) return e;
+        // precision mode 1: the bf16 GEMM stages A^T from X directly (its B path transposes in registers anyway)
+        const bool direct = gemm_get_precision() == 1 && Kin % 4 == 0 && Nout % 4 == 0;
+        if (!direct)
+            if (int e = launch_transpose(A, t->at, M, Kin, 1, s)) return e;
         int S = 1;
         const int64_t tiles = (int64_t)((Kin + 127) / 128) * ((Nout + 127) / 128);
+        const int kq = direct ? 64 : 32;        // K granularity of the kernel that will run
         for (int cand = 32; cand >= 2; cand >>= 1)
-            if (M % (cand * 32) == 0 && tiles * cand <= 2048 && (int64_t)(cand + 1) * Kin * Nout <= t->slab_floats) {
+            if (M % (cand * kq) == 0 && tiles * cand <= 2048 && (int64_t)(cand + 1) * Kin * Nout <= t->slab_floats) {
                 S = cand;
                 break;
             }
         const int Kp = M / S;
-        if (S == 1) {
+        if (direct && Kp % 64 == 0) {
+            GemmShadows x;
+            x.transA = true;
+            float* dst = S == 1 ? dW : t->slabs;
+            if (int e = launch_gemm_bf16_x(m->prof, A, Kin, (int64_t)Kp * Kin, dY, Nout, (int64_t)Kp * Nout, dst, Nout,
+                                           (int64_t)Kin * Nout, nullptr, nullptr, Kin, Nout, Kp, S, 0, x, s))
+                return e;
+            if (S > 1)
+                if (int e = launch_colsum(t->slabs, dW, S, Kin * Nout, t->slabs + (int64_t)S * Kin * Nout, 0, s)) return e;
+        } else if (direct) {
+            if (int e = launch_transpose(A, t->at, M, Kin, 1, s)) return e;
+            if (int e = launch_gemm_ex(m->prof, t->at, M, S == 1 ? 0 : Kp, dY, Nout, S == 1 ? 0 : (int64_t)Kp * Nout, S == 1 ? dW : t->slabs,
+                                       Nout, (int64_t)Kin * Nout, nullptr, nullptr, Kin, Nout, Kp, S, 0, s))
+                return e;
+            if (S > 1)
+                if (int e = launch_colsum(t->slabs, dW, S, Kin * Nout, t->slabs + (int64_t)S * Kin * Nout, 0, s)) return e;
+        } else if (S == 1) {
             if (int e = launch_gemm_ex(m->prof, t->at, M, 0, dY, Nout, 0, dW, Nout, 0, nullptr, nullptr, Kin, Nout, M, 1, 0, s)) return e;
         } else {
             if (int e = launch_gemm_ex(m->prof, t->at, M, Kp, dY, Nout, (int64_t)Kp * Nout, t->slabs, Nout,

@@ -219,6 +219,14 @@ int w2v2_op_gemm_bf16(const float* A_dev, int64_t lda, int64_t strideA,
                       const float* bias_dev, const float* residual_dev,
                       int32_t M, int32_t N, int32_t K, int32_t nbatch, int32_t act, void* stream);
 
+/* The weight-gradient form of the same GEMM: C_z (M, N) = A_z^T B_z with A given TRANSPOSED, (K, M) fp32 row-major with
+ * row stride lda (>= M), and per-batch strides on A, B and C (split-K: batch z covers rows [z K, (z+1) K) of both
+ * operands and writes slab z).  bf16-rounded operands, fp32 accumulation.  K % 64 == 0, M % 4 == 0, N % 4 == 0. */
+int w2v2_op_gemm_bf16_at(const float* At_dev, int64_t lda, int64_t strideA,
+                         const float* B_dev, int64_t ldb, int64_t strideB,
+                         float* C_dev, int64_t ldc, int64_t strideC,
+                         int32_t M, int32_t N, int32_t K, int32_t nbatch, void* stream);
+
 /* y = LN(x) * gamma + beta over the last axis, optional GELU after
  * (tf.keras.layers.LayerNormalization(axis=-1); act as above). rows x C. */
 int w2v2_op_layer_norm(const float* x_dev, float* y_dev, const float* gamma_dev,

@@ -177,6 +177,24 @@ def test_strided_conv_as_overlapping_gemm_bf16(env, Tin, Cin, Cout, k, s, B):
 
 
 
+@pytest.mark.parametrize("rows,Kin,Nout,S", [(256, 128, 132, 1), (512, 768, 64, 4), (1024, 132, 256, 8)])
+def test_gemm_bf16_transposed_a_split_k(env, rows, Kin, Nout, S):
+    """dW = X^T dY as the training step runs it in precision mode 1: X (rows, Kin) is passed as the TRANSPOSED A of the GEMM
+    (no transposed copy), split over S batches along the rows, one (Kin, Nout) slab per batch."""
+    lib, torch, dev = env
+    X, dY = rnd("atX", (rows, Kin)), rnd("atY", (rows, Nout), 0.3)
+    Kp = rows // S
+    out = torch.full((S, Kin, Nout), float("nan"), device=dev)
+    N.check(lib.w2v2_op_gemm_bf16_at(N.ptr(dev_t(torch, dev, X)), Kin, Kp * Kin, N.ptr(dev_t(torch, dev, dY)), Nout, Kp * Nout,
+                                     N.ptr(out), Nout, Kin * Nout, Kin, Nout, Kp, S, stream()))
+    got = out.cpu().numpy()
+    Xr, Yr = O.round_bf16(X).astype(np.float64), O.round_bf16(dY).astype(np.float64)
+    for z in range(S):
+        ref = Xr[z * Kp:(z + 1) * Kp].T @ Yr[z * Kp:(z + 1) * Kp]
+        assert H.max_err(got[z], ref) < 2e-5 * max(1.0, np.abs(ref).max()), z
+    assert H.max_err(got.sum(0), Xr.T @ Yr) < 1e-4 * max(1.0, np.abs(Xr.T @ Yr).max())
+
+
 # ---------------------------------------------------------------- LayerNorm -----
 @pytest.mark.parametrize("rows,Cn,act", [(37, 512, 0), (5, 768, 1), (130, 1024, 0), (9, 64, 0), (3, 50, 0), (4, 1500, 1)])
 def test_layer_norm(env, rows, Cn, act):

@@ -290,8 +290,9 @@ def test_bf16_precision_training_step(env):
     bf16-rounded Dense operands; gradients agree at a bf16-sized tolerance (the build also rounds dY inside its
     backward GEMMs, autograd's straight-through rounding does not)."""
     import wav2vec2
-    L = 12000
+    L = 20560               # T = 64 frames: B T = 128 rows, so the weight-gradient GEMMs take the split-K, transposed-A path
     m, cfg, w = build("base_sample_padded", L)
+    assert cfg.num_frames(L) == 64
     m.set_precision("bf16")
     x = V.hash_normal("train/wave16", 2 * L, 8).reshape(2, L)
     labels = np.array([[5, 9, 9, 11, 0, 0], [7, 6, 0, 0, 0, 0]], np.int32)
