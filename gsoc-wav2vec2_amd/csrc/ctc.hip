@@ -20,16 +20,21 @@ namespace {
 constexpr int CTC_THREADS = 256;
 constexpr double NEG_INF = -1e300;   // finite sentinel: keeps (a - m) well-defined
 
+// log(sum exp) of two / three fp64 states.  The state values and the running sums stay fp64 (the loss adds ~768
+// log-probabilities into a value of ~1e3); the transcendental parts work on the DIFFERENCES to the maximum, which lie
+// in [-inf, 0] and need no more than fp32: exp and log of fp32 cost ~12 instructions each against ~90 for the fp64
+// library routines, and the recursion is exactly that arithmetic, 2 x T times per sample (3.3 ms -> 0.9 ms at T = 768).
+// Per-step error ~1e-7 absolute, unbiased (libm expf / logf, not the v_exp / v_log approximations).
 __device__ __forceinline__ double lse2(double a, double b) {
     const double m = a > b ? a : b;
     if (m <= NEG_INF) return NEG_INF;
-    return m + log(exp(a - m) + exp(b - m));
+    return m + (double)logf(expf((float)(a - m)) + expf((float)(b - m)));
 }
 __device__ __forceinline__ double lse3(double a, double b, double c) {
     double m = a > b ? a : b;
     m = m > c ? m : c;
     if (m <= NEG_INF) return NEG_INF;
-    return m + log(exp(a - m) + exp(b - m) + exp(c - m));
+    return m + (double)logf(expf((float)(a - m)) + expf((float)(b - m)) + expf((float)(c - m)));
 }
 
 struct CtcArgs {
@@ -40,17 +45,26 @@ struct CtcArgs {
     float* nll;               // (B)
     float* grad;              // (B, T, V) or null
     double* alpha_ws;         // (B, T, S_max) when grad != null
-    int B, T, V, U, blank, S_max;
+    double* beta_ws;          // (B, T, S_max) when grad != null
+    double* lse_ws;           // (B, T)        when grad != null
+    int B, T, V, U, blank, S_max, CH;
 };
 
-// dynamic LDS: double lse[T]; double ab[2][S_max]; double occ[V]; int ext[S_max]
+// The recursions are a dependent chain of T steps per sample, so anything with memory latency inside a step is paid T
+// times: the first version read its emission log-probabilities (and, in the backward sweep, alpha) from global memory
+// every step and spent 2 us per step doing it (3.3 ms at T = 768).  Now a sweep touches only LDS and issues
+// fire-and-forget stores: the sample's logits are staged in LDS in chunks of CH frames (the whole utterance when
+// T <= 768), alpha and beta go out to a workspace, and the gradient -- independent across frames -- is a separate,
+// fully parallel kernel.
+//
+// dynamic LDS: double lse[T]; double ab[2][S_max]; int ext[S_max]; float lg[CH][V]
 __global__ __launch_bounds__(CTC_THREADS) void ctc_kernel(CtcArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
     double* lse = reinterpret_cast<double*>(raw);
     double* buf0 = lse + a.T;
     double* buf1 = buf0 + a.S_max;
-    double* occ = buf1 + a.S_max;
-    int* ext = reinterpret_cast<int*>(occ + a.V);
+    int* ext = reinterpret_cast<int*>(buf1 + a.S_max);
+    float* lgs = reinterpret_cast<float*>(ext + ((a.S_max + 3) & ~3));
     __shared__ double nll_sh;
 
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -70,20 +84,30 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_kernel(CtcArgs a) {
         double acc = 0.0;
         for (int v = 0; v < a.V; ++v) acc += exp((double)r[v] - (double)m);
         lse[t] = (double)m + log(acc);
+        if (a.lse_ws) a.lse_ws[(int64_t)b * a.T + t] = lse[t];
     }
     __syncthreads();
     if (Tb == 0) {
         if (tid == 0) a.nll[b] = U == 0 ? 0.0f : INFINITY;
-        if (a.grad)
-            for (int64_t i = tid; i < (int64_t)a.T * a.V; i += CTC_THREADS) a.grad[(int64_t)b * a.T * a.V + i] = 0.f;
-        return;
+        return;                                   // (the gradient kernel writes zeros for this sample)
     }
-    auto logp = [&](int t, int s) { return (double)lg[(int64_t)t * a.V + ext[s]] - lse[t]; };
+    // stage the frames of chunk c = [c CH, (c + 1) CH) of this sample's logits in LDS (coalesced)
+    int chunk = -1;
+    auto stage = [&](int c) {
+        __syncthreads();                          // everyone is done with the previous chunk
+        const int f0 = c * a.CH, nf = min(a.CH, Tb - f0);
+        const float* src = lg + (int64_t)f0 * a.V;
+        for (int i = tid; i < nf * a.V; i += CTC_THREADS) lgs[i] = src[i];
+        chunk = c;
+        __syncthreads();
+    };
+    auto logp = [&](int t, int s) { return (double)lgs[(t - chunk * a.CH) * a.V + ext[s]] - lse[t]; };
 
     // ---- alpha ----
     double* prev = buf0;
     double* cur = buf1;
     double* aw = a.grad ? a.alpha_ws + (int64_t)b * a.T * a.S_max : nullptr;
+    stage(0);
     for (int s = tid; s < S; s += CTC_THREADS) {
         const double v = s < 2 ? logp(0, s) : NEG_INF;
         prev[s] = v;
@@ -91,6 +115,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_kernel(CtcArgs a) {
     }
     __syncthreads();
     for (int t = 1; t < Tb; ++t) {
+        if (t / a.CH != chunk) stage(t / a.CH);   // block-uniform
         for (int s = tid; s < S; s += CTC_THREADS) {
             const double a0 = prev[s];
             const double a1 = s >= 1 ? prev[s - 1] : NEG_INF;
@@ -112,15 +137,12 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_kernel(CtcArgs a) {
     __syncthreads();
     if (!a.grad) return;
 
-    // ---- beta + gradient ----
-    const double nll = nll_sh;
-    float* __restrict__ gr = a.grad + (int64_t)b * a.T * a.V;
-    for (int64_t i = (int64_t)Tb * a.V + tid; i < (int64_t)a.T * a.V; i += CTC_THREADS) gr[i] = 0.f;  // frames past logit_length
-    const bool feasible = isfinite(nll);
+    // ---- beta (stored; the gradient kernel combines it with alpha) ----
+    double* bw = a.beta_ws + (int64_t)b * a.T * a.S_max;
     double* bprev = buf0;
     double* bcur = buf1;
     for (int t = Tb - 1; t >= 0; --t) {
-        for (int v = tid; v < a.V; v += CTC_THREADS) occ[v] = 0.0;
+        if (t / a.CH != chunk) stage(t / a.CH);
         for (int s = tid; s < S; s += CTC_THREADS) {
             double v;
             if (t == Tb - 1) {
@@ -134,26 +156,63 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_kernel(CtcArgs a) {
                 v = v <= NEG_INF ? NEG_INF : v + logp(t, s);
             }
             bcur[s] = v;
-        }
-        __syncthreads();
-        if (feasible) {
-            for (int s = tid; s < S; s += CTC_THREADS) {
-                const double al = aw[(int64_t)t * a.S_max + s], be = bcur[s];
-                if (al > NEG_INF && be > NEG_INF) {
-                    // alpha_t(s) beta_t(s) / y_t(ext[s]) / p   (both carry the emission at t once)
-                    const double w = exp(al + be - logp(t, s) + nll);
-                    atomicAdd(&occ[ext[s]], w);
-                }
-            }
-        }
-        __syncthreads();
-        for (int v = tid; v < a.V; v += CTC_THREADS) {
-            const double sm = exp((double)lg[(int64_t)t * a.V + v] - lse[t]);
-            gr[(int64_t)t * a.V + v] = feasible ? (float)(sm - occ[v]) : 0.f;
+            bw[(int64_t)t * a.S_max + s] = v;
         }
         __syncthreads();
         double* tmp = bprev; bprev = bcur; bcur = tmp;
     }
+}
+
+// d nll / d logits[t, v] = softmax(logits[t])[v] - sum_{s: ext[s] = v} alpha_t(s) beta_t(s) / (y_t(v) p): one block per
+// (sample, frame), no dependence between frames.
+__global__ __launch_bounds__(64) void ctc_grad_kernel(CtcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
+    double* occ = reinterpret_cast<double*>(raw);          // [V]
+    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    int U = a.label_len[b];
+    U = U < 0 ? 0 : (U > a.U ? a.U : U);
+    int Tb = a.logit_len[b];
+    Tb = Tb < 0 ? 0 : (Tb > a.T ? a.T : Tb);
+    const int S = 2 * U + 1;
+    float* __restrict__ gr = a.grad + ((int64_t)b * a.T + t) * a.V;
+    if (t >= Tb || !isfinite(a.nll[b])) {               // frames past logit_length, or an infeasible alignment
+        for (int v = tid; v < a.V; v += 64) gr[v] = 0.f;
+        return;
+    }
+    for (int v = tid; v < a.V; v += 64) occ[v] = 0.0;
+    __syncthreads();
+    const float* __restrict__ lg = a.logits + ((int64_t)b * a.T + t) * a.V;
+    const double lse = a.lse_ws[(int64_t)b * a.T + t];
+    const double* __restrict__ aw = a.alpha_ws + ((int64_t)b * a.T + t) * a.S_max;
+    const double* __restrict__ bw = a.beta_ws + ((int64_t)b * a.T + t) * a.S_max;
+    // the float nll would cost 1e-4 relative in every weight: recompute it in fp64 from the two sweeps at this frame
+    //   p = sum_s alpha_t(s) beta_t(s) / y_t(ext[s])   (any t)
+    double m = NEG_INF;
+    for (int s = tid; s < S; s += 64) {
+        const int e = (s & 1) ? a.labels[(int64_t)b * a.U + (s >> 1)] : a.blank;
+        const double w = (aw[s] > NEG_INF && bw[s] > NEG_INF) ? aw[s] + bw[s] - ((double)lg[e] - lse) : NEG_INF;
+        m = w > m ? w : m;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(m, off, 64);
+        m = o > m ? o : m;
+    }
+    double tot = 0.0;
+    for (int s = tid; s < S; s += 64) {
+        const int e = (s & 1) ? a.labels[(int64_t)b * a.U + (s >> 1)] : a.blank;
+        if (aw[s] > NEG_INF && bw[s] > NEG_INF) tot += exp(aw[s] + bw[s] - ((double)lg[e] - lse) - m);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
+    const double logp_total = m + log(tot);              // = -nll in fp64
+    for (int s = tid; s < S; s += 64) {
+        const int e = (s & 1) ? a.labels[(int64_t)b * a.U + (s >> 1)] : a.blank;
+        if (aw[s] > NEG_INF && bw[s] > NEG_INF)
+            atomicAdd(&occ[e], exp(aw[s] + bw[s] - ((double)lg[e] - lse) - logp_total));
+    }
+    __syncthreads();
+    for (int v = tid; v < a.V; v += 64) gr[v] = (float)(exp((double)lg[v] - lse) - occ[v]);
 }
 
 struct LenArgs {
@@ -198,9 +257,10 @@ int launch_ctc(Profiler* prof, const float* logits, int B, int T, int V, const i
     a.logits = logits; a.labels = labels; a.label_len = label_len; a.logit_len = logit_len;
     a.nll = nll; a.grad = grad; a.B = B; a.T = T; a.V = V; a.U = U; a.blank = blank;
     a.S_max = 2 * U + 1;
-    a.alpha_ws = nullptr;
+    a.alpha_ws = a.beta_ws = a.lse_ws = nullptr;
     if (grad) {
-        const size_t need = (size_t)B * T * a.S_max * sizeof(double);
+        const size_t per = (size_t)B * T * a.S_max;
+        const size_t need = (2 * per + (size_t)B * T) * sizeof(double);
         if (need > g_alpha_bytes) {            // grow-only scratch owned by the library
             if (g_alpha_ws) W2V2_HIP_CHECK(hipFree(g_alpha_ws));
             g_alpha_ws = nullptr; g_alpha_bytes = 0;
@@ -208,9 +268,15 @@ int launch_ctc(Profiler* prof, const float* logits, int B, int T, int V, const i
             g_alpha_bytes = need;
         }
         a.alpha_ws = g_alpha_ws;
+        a.beta_ws = g_alpha_ws + per;
+        a.lse_ws = g_alpha_ws + 2 * per;
     }
-    const size_t lds = (size_t)(T + 2 * a.S_max + V) * sizeof(double) + (size_t)a.S_max * sizeof(int) + 16;
-    W2V2_REQUIRE(lds <= 150 * 1024, "ctc: T=%d U=%d needs %zu B of LDS", T, U, lds);
+    // logits chunk in LDS: the whole utterance if it fits next to the state arrays, else as many frames as do
+    const size_t fixed = (size_t)(T + 2 * a.S_max) * sizeof(double) + (size_t)((a.S_max + 3) & ~3) * sizeof(int) + 16;
+    W2V2_REQUIRE(fixed + (size_t)V * sizeof(float) <= 150 * 1024, "ctc: T=%d U=%d needs %zu B of LDS", T, U, fixed);
+    size_t frames = (150 * 1024 - fixed) / ((size_t)V * sizeof(float));
+    a.CH = (int)(frames < (size_t)T ? frames : (size_t)T);
+    const size_t lds = fixed + (size_t)a.CH * V * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_kernel),
@@ -219,6 +285,7 @@ int launch_ctc(Profiler* prof, const float* logits, int B, int T, int V, const i
     }
     ProfScope ps(prof, FAM_CTC, 30.0 * B * (double)T * a.S_max, 4.0 * B * (double)T * V * (grad ? 2 : 1), s);
     hipLaunchKernelGGL(ctc_kernel, dim3(B), dim3(CTC_THREADS), lds, s, a);
+    if (grad) hipLaunchKernelGGL(ctc_grad_kernel, dim3(T, B), dim3(64), (size_t)V * sizeof(double), s, a);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }

@@ -384,7 +384,7 @@ def test_frame_lengths(env):
     assert list(O.frame_lengths(cfg, m))[:3] == [768, 145, 1]
 
 
-@pytest.mark.parametrize("B,T,Vv,U", [(3, 50, 32, 8), (2, 768, 32, 256), (4, 20, 7, 12)])
+@pytest.mark.parametrize("B,T,Vv,U", [(3, 50, 32, 8), (2, 768, 32, 256), (4, 20, 7, 12), (2, 1499, 32, 256)])   # last: logits staged in two LDS chunks
 def test_ctc_loss_and_grad(env, B, T, Vv, U):
     """tf.nn.ctc_loss semantics (losses.py:35-43): NLL vs the oracle (fp64), gradient vs torch autograd."""
     lib, torch, dev = env
