@@ -590,16 +590,28 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(AttnBwdArgs a, A
     }
 }
 
-template <int DH>
-int launch_attn_train(const AttnArgs& a, const AttnTrain& tr, hipStream_t s) {
-    constexpr int NW = 4;
+template <int DH, int NW>
+int launch_attn_train_impl(const AttnArgs& a, const AttnTrain& tr, hipStream_t s) {
     const size_t lds = (size_t)2 * 2 * KT * DH * sizeof(float);
-    W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<DH, NW, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static bool attr_set = false;
+    if (!attr_set) {
+        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<DH, NW, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
     dim3 grid((a.T + NW * 32 - 1) / (NW * 32), a.heads, a.B), block(NW * 64);
     hipLaunchKernelGGL((attention_kernel<DH, NW, true>), grid, block, lds, s, a, tr);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
+}
+
+// 12 waves per block (3 per SIMD) when the sequence is long enough to fill whole blocks, as the inference launcher picks
+template <int DH>
+int launch_attn_train(const AttnArgs& a, const AttnTrain& tr, hipStream_t s) {
+    if constexpr (DH == 64) {
+        if (a.T >= 384) return launch_attn_train_impl<DH, 12>(a, tr, s);
+    }
+    return launch_attn_train_impl<DH, 4>(a, tr, s);
 }
 
 template <int DH>
