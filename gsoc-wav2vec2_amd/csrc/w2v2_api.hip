@@ -305,7 +305,7 @@ static int ensure_shadows(w2v2_model* m, int B, int T, hipStream_t s) {
 extern "C" {
 
 const char* w2v2_last_error(void) { return g_err; }
-const char* w2v2_version(void) { return "w2v2-gfx950 0.1 (fp32 MFMA path)"; }
+const char* w2v2_version(void) { return "w2v2-gfx950 0.1 (fp32 MFMA path; bf16-operand precision mode)"; }
 
 int w2v2_create(const w2v2_config* cfg, w2v2_model** out) {
     W2V2_REQUIRE(cfg && out, "create: null argument");
