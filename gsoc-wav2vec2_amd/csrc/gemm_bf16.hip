@@ -72,7 +72,7 @@ template <> struct FVec<2> { using type = f32x2; };
 // then goes on the per-lane SOURCE address, as in gemm_f32.hip), 7 = fp32 with A TRANSPOSED in memory ((K, M), the
 // activation itself in a weight-gradient GEMM  dW = X^T dY): A takes B's register-transposing path, no transposed copy.  Shadows hold exactly the values the fp32 path would round to, so all five
 // produce bit-identical results.
-template <int SRC, int BM, int BN, int WM, int WN, int MINB, int ABL = 0>
+template <int SRC, int BM, int BN, int WM, int WN, int MINB>
 __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args g) {
     constexpr bool FAST = SRC >= 1, A16 = SRC == 2 || (SRC >= 4 && SRC <= 6), B16 = SRC == 3 || (SRC >= 4 && SRC <= 6);
     constexpr bool DMA = SRC == 5 || SRC == 6;      // both shadows, LDS-DMA staging (no registers, no ds_write)
@@ -172,19 +172,6 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
     }
 
     auto load_tile = [&](int kt) {
-        if constexpr (ABL == 1) {     // ablation: no global loads
-            if (kt == 0) {
-#pragma unroll
-                for (int i = 0; i < NA; ++i) ra[i] = f32x4{1.f, 2.f, 3.f, 4.f};
-#pragma unroll
-                for (int i = 0; i < NB; ++i)
-#pragma unroll
-                    for (int kk = 0; kk < 8; ++kk)
-#pragma unroll
-                        for (int j = 0; j < PN; ++j) rb[i][kk][j] = 1.f + j;
-            }
-            return;
-        }
         const int k0 = kt * BK;
         if constexpr (A16) {
 #pragma unroll
@@ -229,15 +216,6 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
     };
     auto store_tile = [&](int buf) {
         unsigned char* S = smem16 + buf * STAGE;
-        if constexpr (ABL == 2) {     // ablation: loads consumed, no convert / LDS store
-            float t = 0.f;
-#pragma unroll
-            for (int i = 0; i < NA; ++i) t += ra[i][0] + ra[i][3];
-#pragma unroll
-            for (int i = 0; i < NB; ++i) t += rb[i][0][0] + rb[i][7][1];
-            if (t == 123.456f) S[tid] = 1;
-            return;
-        }
         if constexpr (A16) {
 #pragma unroll
             for (int i = 0; i < NA16; ++i) *reinterpret_cast<u32x4*>(S + a16_lds[i]) = ra16[i];
@@ -310,7 +288,6 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
     // 16-byte slot 2 s + lh of both images
     auto compute = [&](int buf) {
         const unsigned char* S = smem16 + buf * STAGE;
-        if constexpr (ABL == 3) return;   // ablation: no fragment reads / MFMA
         // Fragment reads run one k-step ahead of the MFMAs that consume them: a 16-deep bf16 MFMA is only 32 cycles, so
         // an LDS round trip (~100+ cycles) in front of each group of 4 would otherwise be the critical path.
         bf16x8 a[2][MT], b[2][NTL];

@@ -44,7 +44,6 @@ struct GemmArgs {
     int64_t lda, ldb, ldc, strideA, strideB, strideC;
     int M, N, K, act;
     int tiles_m, tiles_n;
-    int order;      // tile order experiment knob (W2V2_GEMM_ORDER): 0 XCD-chunked N-fastest, 1 plain, 2 XCD-chunked M-fastest, 3 XCD-chunked 8x8 super-tiles
 };
 
 __device__ __forceinline__ float ld_a(const float* A, const GemmArgs& g, int row, int k) {
@@ -240,21 +239,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_f32_dma_kernel(GemmArg
     const int wm = wave / WN, wn = wave % WN, li = lane & 31, lh = lane >> 5;
     const int nwg = g.tiles_m * g.tiles_n;
     int bid = blockIdx.x;
-    if (g.order != 1) {
+    {   // XCD-aware order: each XCD owns a contiguous run of tiles, N fastest (three other orders measured within 1 %)
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
-    if (g.order == 2) {
-        tn = bid / g.tiles_m;
-        tm = bid % g.tiles_m;
-    } else if (g.order == 3) {
-        // super-tiles of 8 row-tiles x all column tiles walked column-major inside (B panel reused 8x back to back)
-        const int per = 8 * g.tiles_n, st = bid / per, in = bid % per;
-        const int rows_here = min(8, g.tiles_m - st * 8);
-        tm = st * 8 + in % rows_here;
-        tn = in / rows_here;
-    }
+    const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int z = blockIdx.z;
     const float* __restrict__ A = g.A + (int64_t)z * g.strideA;
@@ -427,11 +416,6 @@ int launch_gemm_ex(Profiler* prof, const float* A, int64_t lda, int64_t strideA,
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.residual = residual;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.strideA = strideA; g.strideB = strideB; g.strideC = strideC;
     g.M = M; g.N = N; g.K = K; g.act = act;
-    {
-        static int ord = -1;
-        if (ord < 0) { const char* e = getenv("W2V2_GEMM_ORDER"); ord = e ? atoi(e) : 0; }
-        g.order = ord;
-    }
     const bool fast = (K % BK == 0) && (N % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) &&
                       (strideA % 4 == 0) && (strideB % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
