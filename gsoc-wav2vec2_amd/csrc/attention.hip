@@ -665,13 +665,19 @@ namespace w2v2 {
 
 int launch_attention_train(Profiler* prof, const float* qkv, const int32_t* frame_len, float* ctx, int B, int T,
                            int H, int heads, const AttnTrain& tr, hipStream_t s) {
+    return launch_attention_train_x(prof, qkv, frame_len, ctx, nullptr, B, T, H, heads, tr, s);
+}
+
+int launch_attention_train_x(Profiler* prof, const float* qkv, const int32_t* frame_len, float* ctx, uint16_t* ctx16, int B, int T,
+                             int H, int heads, const AttnTrain& tr, hipStream_t s) {
     W2V2_REQUIRE(qkv && ctx && tr.lse, "attention_train: null operand");
     W2V2_REQUIRE(B > 0 && T > 0 && heads > 0 && H % heads == 0 && tr.p >= 0.f && tr.p < 1.f, "attention_train: bad sizes");
     const int dh = H / heads;
     AttnArgs a{qkv, frame_len, ctx, B, T, H, heads, 1.0f / sqrtf((float)dh)};
     ProfScope ps(prof, FAM_ATTENTION, 4.0 * B * (double)heads * T * (double)T * dh, 4.0 * B * (double)T * 4.0 * H, s);
     if (gemm_get_precision() == 1 && attention_bf16_supported(dh))
-        return launch_attention_fwd_bf16(qkv, frame_len, ctx, nullptr, B, T, H, heads, &tr, s);
+        return launch_attention_fwd_bf16(qkv, frame_len, ctx, ctx16, B, T, H, heads, &tr, s);
+    W2V2_REQUIRE(!ctx16, "attention_train: a bf16 shadow output needs the bf16 kernel (precision 1, head size 64)");
     switch (dh) {
         case 32: return launch_attn_train<32>(a, tr, s);
         case 64: return launch_attn_train<64>(a, tr, s);

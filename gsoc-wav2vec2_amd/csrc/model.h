@@ -59,6 +59,8 @@ struct w2v2_model {
 
 
 // implemented in w2v2_api.hip
+bool w2v2_shadows_enabled();                                              // W2V2_BF16_SHADOWS != 0
+int w2v2_ensure_shadows(w2v2_model* m, int B, int T, hipStream_t s);     // allocate activation shadows, (re)build weight shadows
 int w2v2_ensure_workspace(w2v2_model* m, int B, int64_t L);
 // implemented in w2v2_train.hip
 void w2v2_train_destroy(w2v2_model* m);

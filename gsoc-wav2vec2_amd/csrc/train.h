@@ -55,6 +55,8 @@ struct AdamChunk {
 };
 int launch_adam_multi(const AdamChunk* chunks_dev, int nchunks, const float* grads, float* m, float* v, float lr_t, float b1,
                       float b2, float eps, hipStream_t s);
+int launch_dropout_fwd_x(const float* x, const float* res, float* y, uint16_t* y16 /* optional bf16 shadow */, int64_t n, int act,
+                         float p, uint64_t seed, uint32_t stream_id, hipStream_t s);
 int launch_dropout_fwd(const float* x, const float* res, float* y, int64_t n, int act, float p,
                        uint64_t seed, uint32_t stream_id, hipStream_t s);
 int launch_dropout_bwd(const float* u, const float* dy, float* dx, int64_t n, int act, float p,
@@ -85,6 +87,8 @@ int launch_attention_fwd_bf16(const float* qkv, const int32_t* frame_len, float*
                               int heads, const AttnTrain* tr, hipStream_t s);
 int launch_attention_bwd_bf16(const float* qkv, const int32_t* frame_len, const float* dctx, const float* dvec,
                               float* dqkv, int B, int T, int H, int heads, const AttnTrain& tr, hipStream_t s);
+int launch_attention_train_x(Profiler* prof, const float* qkv, const int32_t* frame_len, float* ctx, uint16_t* ctx16, int B, int T,
+                             int H, int heads, const AttnTrain& tr, hipStream_t s);
 int launch_attention_train(Profiler* prof, const float* qkv, const int32_t* frame_len, float* ctx, int B, int T,
                            int H, int heads, const AttnTrain& tr, hipStream_t s);
 // dqkv (B, T, 3H) = gradient of the packed q|k|v given dctx (B, T, H); ctx is the forward output

@@ -38,8 +38,8 @@ __device__ __forceinline__ float gelu_grad(float u, int act) {
 // y = dropout(act(x)) [+ res]           (act may be 0).  HBM-bound: 16 bytes per lane per access when the tensor allows.
 template <bool VEC>
 __global__ void dropout_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
-                                   float* __restrict__ y, int64_t n, int act, float p, uint64_t seed,
-                                   uint32_t stream) {
+                                   float* __restrict__ y, uint16_t* __restrict__ y16 /* optional bf16 shadow of y */, int64_t n,
+                                   int act, float p, uint64_t seed, uint32_t stream) {
     const float inv = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     const uint32_t key = dropout_key(seed, stream), thr = dropout_threshold(p);
     if (VEC) {
@@ -56,12 +56,15 @@ __global__ void dropout_fwd_kernel(const float* __restrict__ x, const float* __r
                 v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
             }
             reinterpret_cast<float4*>(y)[i] = make_float4(v[0], v[1], v[2], v[3]);
+            if (y16) reinterpret_cast<uint2*>(y16)[i] = make_uint2(pack_bf16_rne(v[0], v[1]), pack_bf16_rne(v[2], v[3]));
         }
     } else {
         for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS) {
             float v = apply_act(x[i], act);
             if (p > 0.f) v = dropout_keep32(key, (uint32_t)i, thr) ? v * inv : 0.0f;
-            y[i] = res ? v + res[i] : v;
+            v = res ? v + res[i] : v;
+            y[i] = v;
+            if (y16) y16[i] = (uint16_t)pack_bf16_rne(v, 0.f);
         }
     }
 }
@@ -387,12 +390,18 @@ __global__ void mask_rows_kernel(const float* __restrict__ x, const int32_t* __r
 
 int launch_dropout_fwd(const float* x, const float* res, float* y, int64_t n, int act, float p,
                        uint64_t seed, uint32_t stream_id, hipStream_t s) {
+    return launch_dropout_fwd_x(x, res, y, nullptr, n, act, p, seed, stream_id, s);
+}
+
+int launch_dropout_fwd_x(const float* x, const float* res, float* y, uint16_t* y16, int64_t n, int act, float p,
+                         uint64_t seed, uint32_t stream_id, hipStream_t s) {
     W2V2_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, "dropout_fwd: bad argument");
-    const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res)) & 15) == 0;
+    const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res)) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(y16) & 7) == 0;
     if (vec)
-        hipLaunchKernelGGL(dropout_fwd_kernel<true>, dim3(ew_grid(n >> 2)), dim3(EW_THREADS), 0, s, x, res, y, n, act, p, seed, stream_id);
+        hipLaunchKernelGGL(dropout_fwd_kernel<true>, dim3(ew_grid(n >> 2)), dim3(EW_THREADS), 0, s, x, res, y, y16, n, act, p, seed, stream_id);
     else
-        hipLaunchKernelGGL(dropout_fwd_kernel<false>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, s, x, res, y, n, act, p, seed, stream_id);
+        hipLaunchKernelGGL(dropout_fwd_kernel<false>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, s, x, res, y, y16, n, act, p, seed, stream_id);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }

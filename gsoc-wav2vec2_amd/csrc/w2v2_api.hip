@@ -241,7 +241,7 @@ int w2v2_ensure_workspace(w2v2_model* m, int B, int64_t L) {
 // ---- bf16 shadows for the inference forward in precision mode 1 ------------------------------------------
 // W2V2_BF16_SHADOWS=0 turns them off (every GEMM then rounds its fp32 operands itself): same results bit for
 // bit, used by the tests to prove exactly that.
-static bool shadows_enabled() {
+bool w2v2_shadows_enabled() {
     const char* e = getenv("W2V2_BF16_SHADOWS");      // read per call: tests flip it between two forwards
     return !(e && atoi(e) == 0);
 }
@@ -254,7 +254,7 @@ static int sh_alloc(std::vector<void*>& pool, uint16_t** out, int64_t n) {
     return W2V2_OK;
 }
 
-static int ensure_shadows(w2v2_model* m, int B, int T, hipStream_t s) {
+int w2v2_ensure_shadows(w2v2_model* m, int B, int T, hipStream_t s) {
     const w2v2_config& c = m->cfg;
     const int64_t H = c.hidden_size, F = c.intermediate_size, BT = (int64_t)B * T;
     if (!m->sh_ready) {
@@ -478,9 +478,9 @@ int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const i
     // Precision mode 1 with bf16 shadows: every producer of a GEMM operand also writes its nearest-even bf16 copy, the
     // GEMMs stream those (2 bytes per element, no conversion) and the weights come from (N, K) bf16 shadows.  `sh`
     // false = plain pointers everywhere: the GEMMs then round their fp32 operands themselves, with identical results.
-    const bool sh = m->precision == 1 && shadows_enabled();
+    const bool sh = m->precision == 1 && w2v2_shadows_enabled();
     if (sh)
-        if (int e = ensure_shadows(m, B, T, s)) return e;
+        if (int e = w2v2_ensure_shadows(m, B, T, s)) return e;
     const bool attn16 = sh && attention_bf16_supported(H / c.num_heads);
     auto W16 = [&](const float* w) -> const uint16_t* { return sh ? m->w16[w] : nullptr; };
     auto gemm = [&](const float* A, const uint16_t* A16, int64_t lda, int64_t strideA, const float* Bw, int64_t ldb, float* Cc,

@@ -307,35 +307,57 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
     t->seed = seed;
     auto fe = [&](int i, const char* leaf) { return m->P("feature_extractor/conv_layers/" + std::to_string(i) + leaf); };
 
+    // Precision mode 1: the same bf16 shadows as the inference forward (w2v2_api.hip).  Every producer of a forward GEMM
+    // operand -- conv0, GEMM epilogues, LayerNorm, dropout, attention -- also writes the nearest-even bf16 copy, so the
+    // forward GEMMs stream 2-byte operands by LDS-DMA instead of converting fp32 in registers.  The shadow buffers are
+    // transient scratch (the backward works from the saved fp32 activations); results are bit-identical either way.
+    const bool sh = m->precision == 1 && w2v2_shadows_enabled();
+    if (sh)
+        if (int e = w2v2_ensure_shadows(m, B, T, s)) return e;
+    const bool attn16 = sh && attention_bf16_supported(H / c.num_heads);
+    auto gemm = [&](const float* A, const uint16_t* A16, int64_t lda, int64_t strideA, const float* Bw, int64_t ldb, float* Cc,
+                    uint16_t* C16, int64_t ldc, int64_t strideC, const float* bias, const float* res, int M, int N, int K,
+                    int nbatch, int act_) -> int {
+        if (!sh) return launch_gemm(pf, A, lda, strideA, Bw, ldb, Cc, ldc, strideC, bias, res, M, N, K, nbatch, act_, s);
+        GemmShadows x;
+        x.A16 = A16; x.B16 = m->w16[Bw]; x.C16 = C16; x.ldb16 = K;
+        return launch_gemm_bf16_x(pf, A, lda, strideA, Bw, ldb, 0, Cc, ldc, strideC, bias, res, M, N, K, nbatch, act_, x, s);
+    };
+    auto S16 = [&](uint16_t* p16) -> uint16_t* { return sh ? p16 : nullptr; };
+    const int NC = c.num_conv_layers;
+
     // ---- frozen feature extractor: identical to inference (no dropout inside, feature_extractor.py:54-59) ----
-    if (int e = launch_conv0(pf, wave, fe(0, "/conv/kernel"), c.conv_bias ? fe(0, "/conv/bias") : nullptr,
-                             fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"), m->conv[0], m->conv0_ws, B, L,
-                             c.kernal_sizes[0], c.strides[0], c.filter_sizes[0], 1e-5f, layer_mode ? 1 : 0, act, s))
+    if (int e = launch_conv0_x(pf, wave, fe(0, "/conv/kernel"), c.conv_bias ? fe(0, "/conv/bias") : nullptr,
+                               fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"), m->conv[0],
+                               (sh && !layer_mode) ? m->conv16[0] : nullptr, m->conv0_ws, B, L, c.kernal_sizes[0], c.strides[0],
+                               c.filter_sizes[0], 1e-5f, layer_mode ? 1 : 0, act, s))
         return e;
     if (layer_mode)
-        if (int e = launch_layer_norm(pf, m->conv[0], m->conv[0], fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"),
-                                      (int64_t)B * m->conv_T[0], c.filter_sizes[0], 1e-5f, act, s))
+        if (int e = launch_layer_norm_x(pf, m->conv[0], m->conv[0], fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"),
+                                        (int64_t)B * m->conv_T[0], c.filter_sizes[0], 1e-5f, act, sh ? m->conv16[0] : nullptr, s))
             return e;
-    for (int i = 1; i < c.num_conv_layers; ++i) {
+    for (int i = 1; i < NC; ++i) {
         const int cin = c.filter_sizes[i - 1], cout = c.filter_sizes[i];
         const int Tin = m->conv_T[i - 1], Tout = m->conv_T[i];
-        if (int e = launch_gemm(pf, m->conv[i - 1], (int64_t)c.strides[i] * cin, (int64_t)Tin * cin, fe(i, "/conv/kernel"),
-                                cout, m->conv[i], cout, (int64_t)Tout * cout, c.conv_bias ? fe(i, "/conv/bias") : nullptr,
-                                nullptr, Tout, cout, c.kernal_sizes[i] * cin, B, layer_mode ? 0 : act, s))
+        uint16_t* o16 = (sh && i + 1 < NC) ? m->conv16[i] : nullptr;
+        if (int e = gemm(m->conv[i - 1], sh ? m->conv16[i - 1] : nullptr, (int64_t)c.strides[i] * cin, (int64_t)Tin * cin,
+                         fe(i, "/conv/kernel"), cout, m->conv[i], layer_mode ? nullptr : o16, cout, (int64_t)Tout * cout,
+                         c.conv_bias ? fe(i, "/conv/bias") : nullptr, nullptr, Tout, cout, c.kernal_sizes[i] * cin, B,
+                         layer_mode ? 0 : act))
             return e;
         if (layer_mode)
-            if (int e = launch_layer_norm(pf, m->conv[i], m->conv[i], fe(i, "/layer_norm/gamma"), fe(i, "/layer_norm/beta"),
-                                          (int64_t)B * Tout, cout, 1e-5f, act, s))
+            if (int e = launch_layer_norm_x(pf, m->conv[i], m->conv[i], fe(i, "/layer_norm/gamma"), fe(i, "/layer_norm/beta"),
+                                            (int64_t)B * Tout, cout, 1e-5f, act, o16, s))
                 return e;
     }
     // ---- feature projection: LN -> Dense -> Dropout (feature_extractor.py:92-95) ----
-    const int C = c.filter_sizes[c.num_conv_layers - 1];
-    const float* conv_out = m->conv[c.num_conv_layers - 1];
-    if (int e = launch_layer_norm(pf, conv_out, m->ln512, m->P("feature_projection/layer_norm/gamma"),
-                                  m->P("feature_projection/layer_norm/beta"), BT, C, eps, 0, s))
+    const int C = c.filter_sizes[NC - 1];
+    const float* conv_out = m->conv[NC - 1];
+    if (int e = launch_layer_norm_x(pf, conv_out, m->ln512, m->P("feature_projection/layer_norm/gamma"),
+                                    m->P("feature_projection/layer_norm/beta"), BT, C, eps, 0, S16(m->ln512_16), s))
         return e;
-    if (int e = launch_gemm(pf, m->ln512, C, 0, m->P("feature_projection/projection/kernel"), H, m->proj, H, 0,
-                            m->P("feature_projection/projection/bias"), nullptr, (int)BT, H, C, 1, 0, s))
+    if (int e = gemm(m->ln512, S16(m->ln512_16), C, 0, m->P("feature_projection/projection/kernel"), H, m->proj, nullptr, H, 0,
+                     m->P("feature_projection/projection/bias"), nullptr, (int)BT, H, C, 1, 0))
         return e;
     if (int e = launch_dropout_fwd(m->proj, nullptr, t->hd, BT * H, 0, p, seed, DS_FEATURE_PROJECTION, s)) return e;
     // ---- spec-augment: masked frames <- masked_spec_embed (modeling.py:193-199, spec_augment.py:119-127) ----
@@ -367,7 +389,8 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
             pre = m->t0;
         }
         float* h0 = prenorm ? t->hs0 : m->hs[0];      // prenorm: m->hs[0] aliases posout, keep the dropped copy apart
-        if (int e = launch_dropout_fwd(pre, nullptr, h0, BT * H, 0, p, seed, DS_ENCODER_IN, s)) return e;
+        // postnorm: layer 0's q|k|v GEMM reads this tensor -> shadow
+        if (int e = launch_dropout_fwd_x(pre, nullptr, h0, (sh && !prenorm) ? m->hs16[0] : nullptr, BT * H, 0, p, seed, DS_ENCODER_IN, s)) return e;
     }
     for (int i = 0; i < c.num_layers; ++i) {
         const std::string b = "encoder/layers/" + std::to_string(i);
@@ -375,38 +398,42 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
         const float* x = (prenorm && i == 0) ? t->hs0 : m->hs[i];
         l.keep = sd_keep_host ? sd_keep_host[i] : 1.0f;
         const float* attn_in = x;
+        const uint16_t* attn_in16 = (sh && !prenorm) ? m->hs16[i] : nullptr;   // postnorm: written by the producer of hs[i]
         if (prenorm) {     // x + drop(attn(LN(x)))   (encoder.py:114-119)
-            if (int e = launch_layer_norm(pf, x, l.a, m->P(b + "/layer_norm/gamma"), m->P(b + "/layer_norm/beta"), BT, H, eps, 0, s)) return e;
+            if (int e = launch_layer_norm_x(pf, x, l.a, m->P(b + "/layer_norm/gamma"), m->P(b + "/layer_norm/beta"), BT, H, eps, 0,
+                                            S16(m->t0_16), s))
+                return e;
             attn_in = l.a;
+            attn_in16 = S16(m->t0_16);
         }
-        if (int e = launch_gemm(pf, attn_in, H, 0, m->qkv_w[i], 3 * H, l.qkv, 3 * H, 0, m->qkv_b[i], nullptr, (int)BT, 3 * H, H, 1, 0, s)) return e;
+        if (int e = gemm(attn_in, attn_in16, H, 0, m->qkv_w[i], 3 * H, l.qkv, nullptr, 3 * H, 0, m->qkv_b[i], nullptr, (int)BT, 3 * H, H, 1, 0)) return e;
         AttnTrain tr{p, seed, layer_stream(i, 0), l.lse};
-        if (int e = launch_attention_train(pf, l.qkv, flen, l.ctx, B, T, H, c.num_heads, tr, s)) return e;
+        if (int e = launch_attention_train_x(pf, l.qkv, flen, l.ctx, attn16 ? m->ctx16 : nullptr, B, T, H, c.num_heads, tr, s)) return e;
         // o = ctx Wo + bo;  t1 = dropout(o) + x   (encoder.py:116-119)
-        if (int e = launch_gemm(pf, l.ctx, H, 0, m->P(b + "/attention/out_proj/kernel"), H, m->t0, H, 0,
-                                m->P(b + "/attention/out_proj/bias"), nullptr, (int)BT, H, H, 1, 0, s))
+        if (int e = gemm(l.ctx, attn16 ? m->ctx16 : nullptr, H, 0, m->P(b + "/attention/out_proj/kernel"), H, m->t0, nullptr, H, 0,
+                         m->P(b + "/attention/out_proj/bias"), nullptr, (int)BT, H, H, 1, 0))
             return e;
         if (int e = launch_dropout_fwd(m->t0, x, l.t1, BT * H, 0, p, seed, layer_stream(i, 1), s)) return e;
         // postnorm: t2 = LN1(t1) feeds the FFN and is its residual; prenorm: t2 = LN2(t1) feeds the FFN, t1 is the residual
         const char* ln_a = prenorm ? "/final_layer_norm" : "/layer_norm";
-        if (int e = launch_layer_norm(pf, l.t1, l.t2, m->P(b + ln_a + "/gamma"), m->P(b + ln_a + "/beta"), BT, H, eps, 0, s)) return e;
+        if (int e = launch_layer_norm_x(pf, l.t1, l.t2, m->P(b + ln_a + "/gamma"), m->P(b + ln_a + "/beta"), BT, H, eps, 0, S16(m->t2_16), s)) return e;
         const float* ffn_res = prenorm ? l.t1 : l.t2;
         float* ffn_out = prenorm ? m->hs[i + 1] : l.t3;
         if (l.keep != 0.f) {
             // u = t2 W1 + b1;  gd = dropout(GELU(u));  out = res + keep * (gd W2 + b2)   (encoder.py:127-130)
-            if (int e = launch_gemm(pf, l.t2, H, 0, m->P(b + "/feed_forward/intermediate_dense/kernel"), F, l.u, F, 0,
-                                    m->P(b + "/feed_forward/intermediate_dense/bias"), nullptr, (int)BT, F, H, 1, 0, s))
+            if (int e = gemm(l.t2, S16(m->t2_16), H, 0, m->P(b + "/feed_forward/intermediate_dense/kernel"), F, l.u, nullptr, F, 0,
+                             m->P(b + "/feed_forward/intermediate_dense/bias"), nullptr, (int)BT, F, H, 1, 0))
                 return e;
-            if (int e = launch_dropout_fwd(l.u, nullptr, l.gd, BT * F, act, p, seed, layer_stream(i, 2), s)) return e;
-            if (int e = launch_gemm(pf, l.gd, F, 0, m->P(b + "/feed_forward/output_dense/kernel"), H, ffn_out, H, 0,
-                                    m->P(b + "/feed_forward/output_dense/bias"), ffn_res, (int)BT, H, F, 1, 0, s))
+            if (int e = launch_dropout_fwd_x(l.u, nullptr, l.gd, S16(m->ffn16), BT * F, act, p, seed, layer_stream(i, 2), s)) return e;
+            if (int e = gemm(l.gd, S16(m->ffn16), F, 0, m->P(b + "/feed_forward/output_dense/kernel"), H, ffn_out, nullptr, H, 0,
+                             m->P(b + "/feed_forward/output_dense/bias"), ffn_res, (int)BT, H, F, 1, 0))
                 return e;
         } else {
             W2V2_HIP_CHECK(hipMemcpyAsync(ffn_out, ffn_res, (size_t)BT * H * 4, hipMemcpyDeviceToDevice, s));
         }
         if (!prenorm)
-            if (int e = launch_layer_norm(pf, l.t3, m->hs[i + 1], m->P(b + "/final_layer_norm/gamma"),
-                                          m->P(b + "/final_layer_norm/beta"), BT, H, eps, 0, s))
+            if (int e = launch_layer_norm_x(pf, l.t3, m->hs[i + 1], m->P(b + "/final_layer_norm/gamma"),
+                                            m->P(b + "/final_layer_norm/beta"), BT, H, eps, 0, S16(m->hs16[i + 1]), s))
                 return e;
     }
     // ---- [prenorm: final encoder LN] -> Dropout -> lm_head (encoder.py:274-275, modeling.py:253-254) ----
@@ -417,9 +444,9 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
             return e;
         head_in = m->enc_out;
     }
-    if (int e = launch_dropout_fwd(head_in, nullptr, t->hdf, BT * H, 0, p, seed, DS_HEAD, s)) return e;
-    if (int e = launch_gemm(pf, t->hdf, H, 0, m->P("lm_head/kernel"), c.vocab_size, logits_out, c.vocab_size, 0,
-                            m->P("lm_head/bias"), nullptr, (int)BT, c.vocab_size, H, 1, 0, s))
+    if (int e = launch_dropout_fwd_x(head_in, nullptr, t->hdf, S16(m->enc16), BT * H, 0, p, seed, DS_HEAD, s)) return e;
+    if (int e = gemm(t->hdf, S16(m->enc16), H, 0, m->P("lm_head/kernel"), c.vocab_size, logits_out, nullptr, c.vocab_size, 0,
+                     m->P("lm_head/bias"), nullptr, (int)BT, c.vocab_size, H, 1, 0))
         return e;
     t->forward_done = true;
     return W2V2_OK;
