@@ -44,7 +44,8 @@ struct w2v2_model {
     // bf16 shadows (precision mode 1, inference forward; w2v2_api.hip::ensure_shadows).  Weight shadows are the
     // GEMM kernels transposed to (N, K); activation shadows are written by the producing kernels.
     bool sh_ready = false, w16_valid = false;
-    std::unordered_map<const float*, uint16_t*> w16;
+    std::unordered_map<const float*, uint16_t*> w16;      // (N, K): forward GEMMs
+    std::unordered_map<const float*, uint16_t*> w16p;     // plain (K, N) bf16 copy = the (N, K) shadow of W^T: dX GEMMs
     std::vector<void*> sh_allocs, w16_allocs;
     std::vector<uint16_t*> conv16, hs16;
     uint16_t *ln512_16 = nullptr, *ctx16 = nullptr, *t0_16 = nullptr, *t2_16 = nullptr, *ffn16 = nullptr, *enc16 = nullptr;

@@ -281,7 +281,14 @@ int w2v2_ensure_shadows(w2v2_model* m, int B, int T, hipStream_t s) {
             uint16_t*& dst = m->w16[w];
             if (!dst)
                 if (int e = sh_alloc(m->w16_allocs, &dst, (int64_t)K * N)) return e;
-            return launch_transpose_to_bf16(w, dst, K, N, s);
+            if (int e = launch_transpose_to_bf16(w, dst, K, N, s)) return e;
+            if (m->train && N % 64 == 0 && (K * (int64_t)N) % 4 == 0) {     // training: the backward's dX GEMM contracts over N
+                uint16_t*& dp = m->w16p[w];
+                if (!dp)
+                    if (int e = sh_alloc(m->w16_allocs, &dp, (int64_t)K * N)) return e;
+                return launch_to_bf16(w, dp, (int64_t)K * N, s);
+            }
+            return W2V2_OK;
         };
         for (int i = 1; i < c.num_conv_layers; ++i)
             if (int e = shadow(m->P("feature_extractor/conv_layers/" + std::to_string(i) + "/conv/kernel"),

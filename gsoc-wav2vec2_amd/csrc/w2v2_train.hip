@@ -461,6 +461,22 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     }
     const w2v2_config& c = m->cfg;
     PrecisionScope precision(m->precision);
+    // dX = dY W^T reads the fp32 transposed copy WT ([out][in]) as its B operand; in precision mode 1 with shadows the bf16
+    // copy of W itself ([in][out] = (N, K) for this GEMM) is the B shadow -- no transpose needed.  Bit-identical results.
+    const bool shb = m->precision == 1 && w2v2_shadows_enabled() && m->w16_valid;
+    auto gemm_dx = [&](const float* A, int64_t lda, const float* WT, const float* W, float* Cc, int64_t ldc, const float* res,
+                       int M, int N, int K, hipStream_t st) -> int {
+        if (shb) {
+            auto it = m->w16p.find(W);
+            if (it != m->w16p.end()) {
+                GemmShadows x;
+                x.B16 = it->second;
+                x.ldb16 = K;
+                return launch_gemm_bf16_x(m->prof, A, lda, 0, WT, N, 0, Cc, ldc, 0, nullptr, res, M, N, K, 1, 0, x, st);
+            }
+        }
+        return launch_gemm(m->prof, A, lda, 0, WT, N, Cc, ldc, 0, nullptr, res, M, N, K, 1, 0, st);
+    };
     for (size_t i = 0; i < m->params.size(); ++i)
         if (t->trainable[i] && m->params[i].name.compare(0, 18, "feature_extractor/") == 0) {
             set_error("train_backward: `%s` is trainable, but the conv feature extractor has no backward "
@@ -527,12 +543,12 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
             if (int e = weight_grad(m, l.gd, dh, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
                                     G(b + "/feed_forward/output_dense/bias"), s))
                 return e;
-            if (int e = launch_gemm(pf, dh, H, 0, l.W2T, F, t->gf, F, 0, nullptr, nullptr, (int)BT, F, H, 1, 0, s)) return e;
+            if (int e = gemm_dx(dh, H, l.W2T, m->P(b + "/feed_forward/output_dense/kernel"), t->gf, F, nullptr, (int)BT, F, H, s)) return e;
             if (int e = launch_dropout_bwd(l.u, t->gf, t->gf, BT * F, act, p, seed, layer_stream(i, 2), s)) return e;
             if (int e = weight_grad(m, l.t2, t->gf, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
                                     G(b + "/feed_forward/intermediate_dense/bias"), s))
                 return e;
-            if (int e = launch_gemm(pf, t->gf, F, 0, l.W1T, H, tmp, H, 0, nullptr, nullptr, (int)BT, H, F, 1, 0, s)) return e;
+            if (int e = gemm_dx(t->gf, F, l.W1T, m->P(b + "/feed_forward/intermediate_dense/kernel"), tmp, H, nullptr, (int)BT, H, F, s)) return e;
             float* dg2 = G(b + "/final_layer_norm/gamma");
             float* db2 = G(b + "/final_layer_norm/beta");
             if (int e = launch_ln_bwd(l.t1, m->P(b + "/final_layer_norm/gamma"), tmp, tmp2, dg2 ? dg2 : t->dummy,
@@ -546,11 +562,11 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         if (int e = launch_dropout_bwd(nullptr, dt1, d_o, BT * H, 0, p, seed, layer_stream(i, 1), s)) return e;
         if (int e = weight_grad(m, l.ctx, d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), G(b + "/attention/out_proj/bias"), s)) return e;
         float* dctx = tmp2;
-        if (int e = launch_gemm(pf, d_o, H, 0, l.WoT, H, dctx, H, 0, nullptr, nullptr, (int)BT, H, H, 1, 0, s)) return e;
+        if (int e = gemm_dx(d_o, H, l.WoT, m->P(b + "/attention/out_proj/kernel"), dctx, H, nullptr, (int)BT, H, H, s)) return e;
         AttnTrain tr{p, seed, layer_stream(i, 0), l.lse};
         if (int e = launch_attention_bwd(pf, l.qkv, flen, l.ctx, dctx, t->g3h, t->dvec, B, T, H, c.num_heads, tr, s)) return e;
         if (int e = qkv_weight_grad(b, l.a)) return e;
-        if (int e = launch_gemm(pf, t->g3h, 3 * H, 0, l.WqkvT, H, tmp, H, 0, nullptr, nullptr, (int)BT, H, 3 * H, 1, 0, s)) return e;
+        if (int e = gemm_dx(t->g3h, 3 * H, l.WqkvT, m->qkv_w[i], tmp, H, nullptr, (int)BT, H, 3 * H, s)) return e;
         float* dg1 = G(b + "/layer_norm/gamma");
         float* db1 = G(b + "/layer_norm/beta");
         if (int e = launch_ln_bwd(x, m->P(b + "/layer_norm/gamma"), tmp, tmp2, dg1 ? dg1 : t->dummy, db1 ? db1 : t->dummy + H, BT, H,
@@ -575,14 +591,14 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
             if (int e = weight_grad(m, l.gd, dt3, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
                                     G(b + "/feed_forward/output_dense/bias"), s))
                 return e;
-            if (int e = launch_gemm(pf, dt3, H, 0, l.W2T, F, t->gf, F, 0, nullptr, nullptr, (int)BT, F, H, 1, 0, s)) return e;
+            if (int e = gemm_dx(dt3, H, l.W2T, m->P(b + "/feed_forward/output_dense/kernel"), t->gf, F, nullptr, (int)BT, F, H, s)) return e;
             // du = dgd * keep/(1-p) * GELU'(u)
             if (int e = launch_dropout_bwd(l.u, t->gf, t->gf, BT * F, act, p, seed, layer_stream(i, 2), s)) return e;
             if (int e = weight_grad(m, l.t2, t->gf, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
                                     G(b + "/feed_forward/intermediate_dense/bias"), s))
                 return e;
             // dt2 = du W1^T + dt3 (the residual branch)
-            if (int e = launch_gemm(pf, t->gf, F, 0, l.W1T, H, dt2, H, 0, nullptr, dt3, (int)BT, H, F, 1, 0, s)) return e;
+            if (int e = gemm_dx(t->gf, F, l.W1T, m->P(b + "/feed_forward/intermediate_dense/kernel"), dt2, H, dt3, (int)BT, H, F, s)) return e;
         } else {
             W2V2_HIP_CHECK(hipMemcpyAsync(dt2, dt3, (size_t)BT * H * 4, hipMemcpyDeviceToDevice, s));
         }
@@ -598,12 +614,12 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         if (int e = launch_dropout_bwd(nullptr, dt1, d_o, BT * H, 0, p, seed, layer_stream(i, 1), s)) return e;
         if (int e = weight_grad(m, l.ctx, d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), G(b + "/attention/out_proj/bias"), s)) return e;
         float* dctx = tmp2;   // dt2 is dead
-        if (int e = launch_gemm(pf, d_o, H, 0, l.WoT, H, dctx, H, 0, nullptr, nullptr, (int)BT, H, H, 1, 0, s)) return e;
+        if (int e = gemm_dx(d_o, H, l.WoT, m->P(b + "/attention/out_proj/kernel"), dctx, H, nullptr, (int)BT, H, H, s)) return e;
         AttnTrain tr{p, seed, layer_stream(i, 0), l.lse};
         if (int e = launch_attention_bwd(pf, l.qkv, flen, l.ctx, dctx, t->g3h, t->dvec, B, T, H, c.num_heads, tr, s)) return e;
         if (int e = qkv_weight_grad(b, m->hs[i])) return e;
         // dx = dqkv Wqkv^T + dt1 (residual)
-        if (int e = launch_gemm(pf, t->g3h, 3 * H, 0, l.WqkvT, H, dh, H, 0, nullptr, dt1, (int)BT, H, 3 * H, 1, 0, s)) return e;
+        if (int e = gemm_dx(t->g3h, 3 * H, l.WqkvT, m->qkv_w[i], dh, H, dt1, (int)BT, H, 3 * H, s)) return e;
     }
     // ---- encoder input: postnorm hs[0] = dropout(LN(posout));  prenorm hs0 = dropout(posout) ----
     float* dpos = tmp2;
@@ -665,7 +681,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     if (dgp || dbp) {
         float* dln = tmp2;       // (BT, C) fits a (BT, H) buffer when C <= H; otherwise use the FFN scratch
         if (C > H) dln = t->gf;
-        if (int e = launch_gemm(pf, dproj, H, 0, t->WpT, C, dln, C, 0, nullptr, nullptr, (int)BT, C, H, 1, 0, s)) return e;
+        if (int e = gemm_dx(dproj, H, t->WpT, m->P("feature_projection/projection/kernel"), dln, C, nullptr, (int)BT, C, H, s)) return e;
         float* dxc = C > H ? t->g3h : tmp;    // gradient w.r.t. the frozen conv output: computed and dropped
         if (int e = launch_ln_bwd(m->conv[c.num_conv_layers - 1], m->P("feature_projection/layer_norm/gamma"), dln, dxc,
                                   dgp ? dgp : t->dummy, dbp ? dbp : t->dummy + C, BT, C, eps, t->red_ws, s))
