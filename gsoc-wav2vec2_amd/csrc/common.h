@@ -95,6 +95,10 @@ struct GemmShadows {
     // A is stored TRANSPOSED: element (m, k) at A[k * lda + m] (fp32).  The weight-gradient GEMM dW = X^T dY passes the
     // activation X itself this way, so no transposed copy of X is made in precision mode 1.
     bool transA = false;
+    // two-level batch z = zo * zmod + zi for a grouped conv run as one GEMM launch: A(16) advances with z (strideA), B16 and
+    // bias with zi (strideB16, strideBias), C / residual with zo * strideC2 + zi * strideC.  zmod = 0: plain batch.
+    int zmod = 0;
+    int64_t strideB16 = 0, strideC2 = 0, strideBias = 0;
 };
 int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
                        int64_t strideB, float* C, int64_t ldc, int64_t strideC, const float* bias,
@@ -136,6 +140,13 @@ int launch_weight_norm_regroup(Profiler* prof, const float* wv, const float* wg,
 int launch_pos_conv(Profiler* prof, const float* x, const float* wg, const float* bias,
                     const int32_t* frame_len, float* y, int B, int T, int H, int K, int groups,
                     int act, hipStream_t s);
+
+// precision mode 1: the grouped positional conv as one batched bf16 GEMM (posconv.hip)
+int64_t pos_conv_bf16_pack_elems(int B, int T, int H, int K);
+int launch_pos_conv_weight_shadow(const float* wg, uint16_t* w16, int K, int cg, int groups, hipStream_t s);
+int launch_pos_conv_bf16(Profiler* prof, const float* x, const uint16_t* w16, const float* bias, const int32_t* frame_len,
+                         float* y, float* pre_act, uint16_t* pack16, float* xz_ws, int B, int T, int H, int K, int groups,
+                         int act, int pad_left, int add_residual, hipStream_t s);
 
 int launch_attention(Profiler* prof, const float* qkv, const int32_t* frame_len, float* ctx, int B,
                      int T, int H, int heads, hipStream_t s);

@@ -48,6 +48,10 @@ struct Gemm16Args {
     const uint16_t* B16;
     uint16_t* C16;
     int64_t ldb16;
+    // two-level batch (grouped conv as GEMM): z = zo * zmod + zi.  A advances with z; B16 and bias with zi; C / residual
+    // with zo * strideC2 + zi * strideC.  zmod = 0: plain batch (C advances with z * strideC, B16 and bias are shared).
+    int zmod;
+    int64_t strideB16, strideC2, strideBias;
 };
 
 // two fp32 -> one dword of two bf16, round to nearest even (gfx950 instruction; no builtin in ROCm 7.2)
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
             const int idx = tid + i * NT, r = idx >> 3, ks = idx & 7;
             int col = n0 + r;
             col = col < g.N ? col : g.N - 1;
-            b16_src[i] = g.B16 + (int64_t)col * g.ldb16 + ks * 8;
+            b16_src[i] = g.B16 + (int64_t)(g.zmod ? z % g.zmod : 0) * g.strideB16 + (int64_t)col * g.ldb16 + ks * 8;
             b16_lds[i] = BM * ROWB + r * ROWB + ((ks ^ swz(r)) << 4);
         }
     }
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
             const int r = (wave * PPB + i) * 8 + (lane >> 3);
             int col = n0 + r;
             col = col < g.N ? col : g.N - 1;
-            db[i] = g.B16 + (int64_t)col * g.ldb16 + (((lane & 7) ^ swz(r)) << 3);
+            db[i] = g.B16 + (int64_t)(g.zmod ? z % g.zmod : 0) * g.strideB16 + (int64_t)col * g.ldb16 + (((lane & 7) ^ swz(r)) << 3);
         }
         auto issue = [&](int kt, int buf) {
             unsigned char* S = smem16 + buf * STAGE;
@@ -398,9 +402,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
     }
 
     // ---- epilogue (gemm_epilogue.h): bias -> act -> + residual -> fp32 store and / or bf16 shadow ----
-    const int64_t tile_off = (int64_t)z * g.strideC + (int64_t)(m0 + wm * WTM) * g.ldc + (n0 + wn * WTN);
+    const int zi = g.zmod ? z % g.zmod : z, zo = g.zmod ? z / g.zmod : 0;
+    const int64_t tile_off = (int64_t)zo * g.strideC2 + (int64_t)zi * g.strideC + (int64_t)(m0 + wm * WTM) * g.ldc + (n0 + wn * WTN);
     gemm_epilogue<MT, NTL, true>(acc, g.C ? g.C + tile_off : nullptr, g.C16 ? g.C16 + tile_off : nullptr,
-                                 g.residual ? g.residual + tile_off : nullptr, g.bias ? g.bias + (n0 + wn * WTN) : nullptr,
+                                 g.residual ? g.residual + tile_off : nullptr,
+                                 g.bias ? g.bias + (g.zmod ? (int64_t)zi * g.strideBias : 0) + (n0 + wn * WTN) : nullptr,
                                  (int)g.ldc, g.M - (m0 + wm * WTM), g.N - (n0 + wn * WTN), g.act, li, lh);
 }
 
@@ -467,6 +473,8 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.strideA = strideA; g.strideB = strideB; g.strideC = strideC;
     g.M = M; g.N = N; g.K = K; g.act = act;
     g.A16 = x.A16; g.B16 = x.B16; g.C16 = x.C16; g.ldb16 = x.ldb16 ? x.ldb16 : K;
+    g.zmod = x.zmod; g.strideB16 = x.strideB16; g.strideC2 = x.strideC2; g.strideBias = x.strideBias;
+    W2V2_REQUIRE(x.zmod >= 0 && (x.zmod == 0 || nbatch % x.zmod == 0), "gemm_bf16: batch %d is not a multiple of the inner batch %d", nbatch, x.zmod);
     const bool kfast = K % BK == 0;
     const bool a32 = A && (lda % 4 == 0) && (strideA % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
     const bool b32 = B && (N % 4 == 0) && (ldb % 4 == 0) && (strideB % 4 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
@@ -493,6 +501,7 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
                      bbytes * (double)K * N, s);
     int cfg = forced_cfg16();
     if (cfg == 2 && src == 1) return launch_src16<1, 256, 256, 2, 4, 1>(g, nbatch, s);   // tile study: 8 waves of 128x64
+    if (N <= 64 && src == 5) return launch_src16<5, 128, 64, 2, 2, 2>(g, nbatch, s);     // narrow outputs (grouped conv: 48 | 64 columns)
     return launch_cfg16<128, 128, 2, 2, 2>(g, src, nbatch, s);
 }
 

@@ -49,6 +49,9 @@ struct w2v2_model {
     std::vector<void*> sh_allocs, w16_allocs;
     std::vector<uint16_t*> conv16, hs16;
     uint16_t *ln512_16 = nullptr, *ctx16 = nullptr, *t0_16 = nullptr, *t2_16 = nullptr, *ffn16 = nullptr, *enc16 = nullptr;
+    // bf16 positional conv (precision mode 1; posconv.hip): kernel shadow (groups, og, K cg), pack scratch (B, G, T+K-1, cg)
+    uint16_t *pos_w16 = nullptr, *pos_pack16 = nullptr;
+    bool pos16_valid = false;
     w2v2::Profiler* prof = nullptr;
     struct TrainState* train = nullptr;      // owned by w2v2_train.hip (null until the first training call)
 
@@ -61,7 +64,9 @@ struct w2v2_model {
 
 // implemented in w2v2_api.hip
 bool w2v2_shadows_enabled();                                              // W2V2_BF16_SHADOWS != 0
-int w2v2_ensure_shadows(w2v2_model* m, int B, int T, hipStream_t s);     // allocate activation shadows, (re)build weight shadows
+int w2v2_ensure_shadows(w2v2_model* m, int B, int T, hipStream_t s);
+bool w2v2_pos_conv_bf16_ok(const w2v2_model* m);                          // precision 1 and a supported group shape
+int w2v2_ensure_pos16(w2v2_model* m, int B, int T, hipStream_t s);       // kernel shadow + pack scratch     // allocate activation shadows, (re)build weight shadows
 int w2v2_ensure_workspace(w2v2_model* m, int B, int64_t L);
 // implemented in w2v2_train.hip
 void w2v2_train_destroy(w2v2_model* m);

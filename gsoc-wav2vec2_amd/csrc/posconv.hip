@@ -18,6 +18,7 @@
 // shifted row -- the Toeplitz structure means no im2col and no re-fetch; the
 // per-tap weight tile (C_in/g x C_out/g) is double-buffered through LDS.
 #include "common.h"
+#include "gemm_epilogue.h"
 #include "train.h"
 
 namespace w2v2 {
@@ -425,6 +426,116 @@ int launch_weight_norm_bwd(const float* wv, const float* wgain, const float* dwg
     hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(K), dim3(256), 0, s, wv, wgain, dwg, dwv, dwgain, K, cg, H, groups);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
+}
+
+}  // namespace w2v2
+
+// ======================================================================================
+// Precision mode 1: the grouped positional conv as ONE batched GEMM on the bf16 matrix pipe.
+// Per (sample, group) the conv is  y[t, n] = sum_{j, c} x[t + j - pad, g cg + c] w[g][j][c][n]; with the group's channels
+// packed as P[b][g][r][c] (r = frame + pad, zero rows outside [0, T) and at masked frames) the operand of output frame t
+// is the CONTIGUOUS run P[b][g][t * cg .. t * cg + K * cg): a GEMM with overlapping rows (lda = cg < K cg), exactly the
+// trick gemm_f32.hip plays for the strided convs, M = T, N = cg, K_gemm = K * cg (6144 for base), batch = B * groups.
+// The regrouped kernel (groups, K, cg, og) is already each group's (K cg, og) B matrix; its (og, K cg) bf16 shadow is
+// built once per weight change.  x and the effective kernel are rounded to bf16, accumulation is fp32.
+// ======================================================================================
+namespace w2v2 {
+namespace {
+
+// x (B, T, H) fp32 -> P (B, G, Tp, cg) bf16 with Tp = T + K - 1, `pad` zero rows in front; frames >= frame_len[b] are zero.
+// Optionally also writes xz (B, T, H) fp32 = the masked x (the residual of the forward pass).
+__global__ __launch_bounds__(256) void pos_pack_kernel(const float* __restrict__ x, const int32_t* __restrict__ frame_len,
+                                                       uint16_t* __restrict__ P, float* __restrict__ xz, int B, int T, int H,
+                                                       int groups, int Tp, int pad) {
+    const int cg = H / groups;
+    const int64_t total = (int64_t)B * groups * Tp * (cg / 4);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % (cg / 4));
+        const int r = (int)((i / (cg / 4)) % Tp);
+        const int g = (int)((i / ((int64_t)(cg / 4) * Tp)) % groups);
+        const int b = (int)(i / ((int64_t)(cg / 4) * Tp * groups));
+        const int t = r - pad;
+        const int flen = frame_len ? frame_len[b] : T;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool inside = t >= 0 && t < T;
+        if (inside && t < flen) v = *reinterpret_cast<const float4*>(x + ((int64_t)b * T + t) * H + g * cg + 4 * c4);
+        *reinterpret_cast<uint2*>(P + (((int64_t)b * groups + g) * Tp + r) * cg + 4 * c4) =
+            make_uint2(pack_bf16_rne(v.x, v.y), pack_bf16_rne(v.z, v.w));
+        if (xz && inside) *reinterpret_cast<float4*>(xz + ((int64_t)b * T + t) * H + g * cg + 4 * c4) = v;
+    }
+}
+
+// y = res + act(pre)   (training forward: the pre-activation is kept for the backward, so the GEMM cannot fuse this)
+__global__ __launch_bounds__(256) void pos_finish_kernel(const float* __restrict__ pre, const float* __restrict__ res,
+                                                         float* __restrict__ y, int64_t n4, int act) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 p = reinterpret_cast<const float4*>(pre)[i];
+        float4 o = make_float4(act == 1 ? gelu_erf_fast(p.x) : (act == 2 ? gelu_tanh(p.x) : p.x),
+                               act == 1 ? gelu_erf_fast(p.y) : (act == 2 ? gelu_tanh(p.y) : p.y),
+                               act == 1 ? gelu_erf_fast(p.z) : (act == 2 ? gelu_tanh(p.z) : p.z),
+                               act == 1 ? gelu_erf_fast(p.w) : (act == 2 ? gelu_tanh(p.w) : p.w));
+        if (res) {
+            const float4 r = reinterpret_cast<const float4*>(res)[i];
+            o = make_float4(o.x + r.x, o.y + r.y, o.z + r.z, o.w + r.w);
+        }
+        reinterpret_cast<float4*>(y)[i] = o;
+    }
+}
+
+}  // namespace
+
+int64_t pos_conv_bf16_pack_elems(int B, int T, int H, int K) { return (int64_t)B * (T + K - 1) * H; }
+
+// w16: (groups, og, K cg) bf16 shadow of the regrouped kernel wg (groups, K, cg, og)
+int launch_pos_conv_weight_shadow(const float* wg, uint16_t* w16, int K, int cg, int groups, hipStream_t s) {
+    W2V2_REQUIRE(wg && w16 && K > 0 && cg > 0 && groups > 0, "pos_conv_weight_shadow: bad argument");
+    for (int g = 0; g < groups; ++g)
+        if (int e = launch_transpose_to_bf16(wg + (int64_t)g * K * cg * cg, w16 + (int64_t)g * cg * K * cg, K * cg, cg, s)) return e;
+    return W2V2_OK;
+}
+
+// Same contract as launch_pos_conv_ex.  pack16: pos_conv_bf16_pack_elems() bf16 of scratch; xz_ws: (B, T, H) fp32 of scratch,
+// needed only when frame_len && add_residual (the residual is the MASKED input).
+int launch_pos_conv_bf16(Profiler* prof, const float* x, const uint16_t* w16, const float* bias, const int32_t* frame_len,
+                         float* y, float* pre_act, uint16_t* pack16, float* xz_ws, int B, int T, int H, int K, int groups,
+                         int act, int pad_left, int add_residual, hipStream_t s) {
+    W2V2_REQUIRE(x && w16 && y && pack16, "pos_conv_bf16: null operand");
+    W2V2_REQUIRE(B > 0 && T > 0 && K > 0 && groups > 0 && H % groups == 0 && pad_left >= 0 && pad_left < K, "pos_conv_bf16: bad sizes");
+    const int cg = H / groups, Tp = T + K - 1;
+    W2V2_REQUIRE(cg % 8 == 0 && cg <= 64 && (K * cg) % 64 == 0, "pos_conv_bf16: channels per group %d / taps %d unsupported", cg, K);
+    const bool masked_res = add_residual && frame_len;
+    W2V2_REQUIRE(!masked_res || xz_ws, "pos_conv_bf16: the masked residual needs the xz workspace");
+    ProfScope ps(prof, FAM_POSCONV, 2.0 * B * (double)T * H * cg * K, 8.0 * B * (double)T * H + 2.0 * K * cg * H, s);
+    {
+        const int64_t total = (int64_t)B * groups * Tp * (cg / 4);
+        int64_t blocks = (total + 255) / 256;
+        blocks = blocks > 8192 ? 8192 : blocks;
+        hipLaunchKernelGGL(pos_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, frame_len, pack16, masked_res ? xz_ws : nullptr, B, T,
+                           H, groups, Tp, pad_left);
+    }
+    const float* res = add_residual ? (masked_res ? xz_ws : x) : nullptr;
+    GemmShadows gx;
+    gx.A16 = pack16;
+    gx.B16 = w16;
+    gx.ldb16 = (int64_t)K * cg;
+    gx.zmod = groups;
+    gx.strideB16 = (int64_t)cg * K * cg;
+    gx.strideC2 = (int64_t)T * H;
+    gx.strideBias = cg;
+    // A: row t of (b, g) starts at pack16 + ((b G + g) Tp + t) cg  -> lda = cg, batch stride Tp cg
+    if (pre_act) {
+        if (int e = launch_gemm_bf16_x(nullptr, nullptr, cg, (int64_t)Tp * cg, nullptr, cg, 0, pre_act, H, cg, bias, nullptr, T, cg, K * cg,
+                                       B * groups, 0, gx, s))
+            return e;
+        const int64_t n4 = (int64_t)B * T * H / 4;
+        int64_t blocks = (n4 + 255) / 256;
+        blocks = blocks > 8192 ? 8192 : blocks;
+        hipLaunchKernelGGL(pos_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pre_act, res, y, n4, act);
+        W2V2_HIP_CHECK(hipGetLastError());
+        return W2V2_OK;
+    }
+    return launch_gemm_bf16_x(nullptr, nullptr, cg, (int64_t)Tp * cg, nullptr, cg, 0, y, H, cg, bias, res, T, cg, K * cg, B * groups, act,
+                              gx, s);
 }
 
 }  // namespace w2v2

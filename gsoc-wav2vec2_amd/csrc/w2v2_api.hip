@@ -170,6 +170,7 @@ static void free_workspace(w2v2_model* m) {
     m->conv16.clear();
     m->hs16.clear();
     m->sh_ready = false;
+    m->pos_pack16 = nullptr;       // lives in `allocs`
     m->acts.clear();
     m->conv.clear();
     m->conv_T.clear();
@@ -309,6 +310,27 @@ int w2v2_ensure_shadows(w2v2_model* m, int B, int T, hipStream_t s) {
     return W2V2_OK;
 }
 
+bool w2v2_pos_conv_bf16_ok(const w2v2_model* m) {
+    const int cg = m->cfg.hidden_size / m->cfg.num_conv_pos_embedding_groups;
+    return m->precision == 1 && cg % 8 == 0 && cg <= 64 && (m->cfg.num_conv_pos_embeddings * cg) % 64 == 0;
+}
+
+int w2v2_ensure_pos16(w2v2_model* m, int B, int T, hipStream_t s) {
+    const w2v2_config& c = m->cfg;
+    const int H = c.hidden_size, K = c.num_conv_pos_embeddings, G = c.num_conv_pos_embedding_groups, cg = H / G;
+    if (!m->pos_w16) W2V2_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m->pos_w16), (size_t)K * cg * H * sizeof(uint16_t)));
+    if (!m->pos16_valid) {
+        if (int e = launch_pos_conv_weight_shadow(m->pos_wg, m->pos_w16, K, cg, G, s)) return e;
+        m->pos16_valid = true;
+    }
+    if (!m->pos_pack16) {
+        float* p = nullptr;
+        if (int e = ws_alloc(m, &p, (pos_conv_bf16_pack_elems(B, T, H, K) + 1) / 2 + 4)) return e;
+        m->pos_pack16 = reinterpret_cast<uint16_t*>(p);
+    }
+    return W2V2_OK;
+}
+
 extern "C" {
 
 const char* w2v2_last_error(void) { return g_err; }
@@ -356,6 +378,7 @@ void w2v2_destroy(w2v2_model* m) {
     for (auto p : m->qkv_w) (void)hipFree(p);
     for (auto p : m->qkv_b) (void)hipFree(p);
     for (void* p : m->w16_allocs) (void)hipFree(p);
+    if (m->pos_w16) (void)hipFree(m->pos_w16);
     profiler_destroy(m->prof);
     delete m;
 }
@@ -438,6 +461,7 @@ int w2v2_finalize(w2v2_model* m, void* stream) {
     }
     m->finalized = true;
     m->w16_valid = false;      // the bf16 weight shadows (if any) follow the variables
+    m->pos16_valid = false;
     return W2V2_OK;
 }
 
@@ -540,9 +564,16 @@ int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const i
         if (int e = launch_frame_lengths(pf, mask, m->frame_len, B, L, c.kernal_sizes, c.strides, c.num_conv_layers, s)) return e;
         flen = m->frame_len;
     }
-    if (int e = launch_pos_conv(pf, m->proj, m->pos_wg, m->P("encoder/pos_conv_embed/conv/bias"), flen, m->posout, B, T,
-                                H, c.num_conv_pos_embeddings, c.num_conv_pos_embedding_groups, act, s))
+    if (w2v2_pos_conv_bf16_ok(m)) {      // precision mode 1: one batched bf16 GEMM over (sample, group); m->t0 is free here
+        if (int e = w2v2_ensure_pos16(m, B, T, s)) return e;
+        if (int e = launch_pos_conv_bf16(pf, m->proj, m->pos_w16, m->P("encoder/pos_conv_embed/conv/bias"), flen, m->posout, nullptr,
+                                         m->pos_pack16, m->t0, B, T, H, c.num_conv_pos_embeddings, c.num_conv_pos_embedding_groups,
+                                         act, c.num_conv_pos_embeddings / 2, 1, s))
+            return e;
+    } else if (int e = launch_pos_conv(pf, m->proj, m->pos_wg, m->P("encoder/pos_conv_embed/conv/bias"), flen, m->posout, B, T,
+                                       H, c.num_conv_pos_embeddings, c.num_conv_pos_embedding_groups, act, s)) {
         return e;
+    }
     if (!prenorm)
         if (int e = launch_layer_norm_x(pf, m->posout, m->hs[0], m->P("encoder/layer_norm/gamma"),
                                         m->P("encoder/layer_norm/beta"), BT, H, eps, 0, sh ? m->hs16[0] : nullptr, s))

@@ -36,6 +36,8 @@ struct TrainState {
     std::vector<LayerSave> layers;
     float *hd = nullptr, *hm = nullptr, *pos_c = nullptr, *hdf = nullptr, *hs0 = nullptr;
     float *WpT = nullptr, *WlmT = nullptr, *pos_wg_t = nullptr, *dwg = nullptr;
+    uint16_t* pos_w16_t = nullptr;           // bf16 (groups, og, K cg) shadow of pos_wg_t (precision mode 1); follows transposes_fresh
+    bool pos_w16_t_fresh = false;
     uint8_t* spec_mask = nullptr;       // (B*T) device copy, or null when not applied
     bool have_spec = false, have_mask = false;
     float p = 0.f;
@@ -73,6 +75,7 @@ void w2v2_train_destroy(w2v2_model* m) {
     if (!m || !m->train) return;
     t_free(m->train);
     if (m->train->adam_chunks) (void)hipFree(m->train->adam_chunks);
+    if (m->train->pos_w16_t) (void)hipFree(m->train->pos_w16_t);
     delete m->train;
     m->train = nullptr;
 }
@@ -195,6 +198,7 @@ static int refresh_transposes(w2v2_model* m, hipStream_t s) {
     }
     const int K = c.num_conv_pos_embeddings, G = c.num_conv_pos_embedding_groups;
     if (int e = launch_pos_conv_flip_regroup(m->pos_wg, t->pos_wg_t, K, H / G, G, s)) return e;
+    t->pos_w16_t_fresh = false;
     t->transposes_fresh = true;
     return W2V2_OK;
 }
@@ -376,10 +380,17 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
         flen = m->frame_len;
     }
     // posout = xz + GELU(c), c saved for backward
-    if (int e = launch_pos_conv_ex(pf, enc_x, m->pos_wg, m->P("encoder/pos_conv_embed/conv/bias"), flen, m->posout, t->pos_c,
-                                   B, T, H, c.num_conv_pos_embeddings, c.num_conv_pos_embedding_groups, act,
-                                   c.num_conv_pos_embeddings / 2, 1, s))
+    if (w2v2_pos_conv_bf16_ok(m)) {      // precision mode 1: batched bf16 GEMM (posconv.hip); m->t0 is free scratch here
+        if (int e = w2v2_ensure_pos16(m, B, T, s)) return e;
+        if (int e = launch_pos_conv_bf16(pf, enc_x, m->pos_w16, m->P("encoder/pos_conv_embed/conv/bias"), flen, m->posout, t->pos_c,
+                                         m->pos_pack16, m->t0, B, T, H, c.num_conv_pos_embeddings, c.num_conv_pos_embedding_groups,
+                                         act, c.num_conv_pos_embeddings / 2, 1, s))
+            return e;
+    } else if (int e = launch_pos_conv_ex(pf, enc_x, m->pos_wg, m->P("encoder/pos_conv_embed/conv/bias"), flen, m->posout, t->pos_c,
+                                          B, T, H, c.num_conv_pos_embeddings, c.num_conv_pos_embedding_groups, act,
+                                          c.num_conv_pos_embeddings / 2, 1, s)) {
         return e;
+    }
     const bool prenorm = c.attention_norm_type == 1;
     // postnorm: hs[0] = dropout(LN(posout));  prenorm: hs[0] = dropout(posout)   (encoder.py:267-270)
     {
@@ -657,7 +668,18 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     }
     // dxz = dpos + conv^T(dc)   (transposed kernel, pad_left = K - 1 - K/2), then the frame mask
     float* dxz = dh;
-    if (int e = launch_pos_conv_ex(pf, dc, t->pos_wg_t, nullptr, nullptr, dxz, nullptr, B, T, H, K, Gr, 0, K - 1 - K / 2, 0, s)) return e;
+    if (w2v2_pos_conv_bf16_ok(m) && m->pos_pack16) {
+        if (!t->pos_w16_t) W2V2_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&t->pos_w16_t), (size_t)K * cg * H * sizeof(uint16_t)));
+        if (!t->pos_w16_t_fresh) {
+            if (int e = launch_pos_conv_weight_shadow(t->pos_wg_t, t->pos_w16_t, K, cg, Gr, s)) return e;
+            t->pos_w16_t_fresh = true;
+        }
+        if (int e = launch_pos_conv_bf16(pf, dc, t->pos_w16_t, nullptr, nullptr, dxz, nullptr, m->pos_pack16, nullptr, B, T, H, K, Gr, 0,
+                                         K - 1 - K / 2, 0, s))
+            return e;
+    } else if (int e = launch_pos_conv_ex(pf, dc, t->pos_wg_t, nullptr, nullptr, dxz, nullptr, B, T, H, K, Gr, 0, K - 1 - K / 2, 0, s)) {
+        return e;
+    }
     if (int e = launch_axpby(dxz, dpos, dxz, BT * H, 1.f, 1.f, s)) return e;
     if (flen)
         if (int e = launch_mask_rows(dxz, flen, dxz, B, T, H, s)) return e;

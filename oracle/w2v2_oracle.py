@@ -52,7 +52,9 @@ _POOL = None
 # Operand rounding of the dense contractions (Conv1D layers >= 1 and every Dense): None = the reference's
 # fp32 arithmetic; "bf16" = both operands rounded to bfloat16 (nearest-even) before an exact product and a
 # wide sum -- the restatement of W2V2_PRECISION_BF16 (include/w2v2.h), i.e. of a mixed_bfloat16 Keras policy
-# on those layers.  Attention, positional conv, norms and conv0 stay unrounded, as in the build.
+# on those layers.  The grouped positional conv rounds x and the weight-normalised kernel the same way (the build runs it
+# as one batched GEMM in that mode); attention rounds its operands inside the kernel (not emulated here), norms and
+# conv0 stay unrounded.
 GEMM_OPERANDS = None
 
 
@@ -218,7 +220,7 @@ def grouped_conv1d_same(x, kernel, bias, groups, padding):
             xg, shape=(B, T_out, K * cg), strides=(Tp * cg * it, cg * it, it), writeable=False)
         wg = kernel[:, :, g * og:(g + 1) * og].reshape(K * cg, og)
         for b in range(B):
-            y[b, :, g * og:(g + 1) * og] = np.ascontiguousarray(win[b]) @ wg
+            y[b, :, g * og:(g + 1) * og] = _mm(np.ascontiguousarray(win[b]), wg)   # operand rounding as the Dense layers
     return y + bias
 
 

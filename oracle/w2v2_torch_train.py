@@ -90,7 +90,7 @@ def train_forward(config, w, wave, attention_mask=None, p=0.0, seed=0, spec_mask
     K, G = c.num_conv_pos_embeddings, c.num_conv_pos_embedding_groups
     wv, wg = w["encoder/pos_conv_embed/conv/weight_v"], w["encoder/pos_conv_embed/conv/weight_g"]
     kern = wv / torch.sqrt(torch.clamp((wv ** 2).sum((1, 2), keepdim=True), min=1e-12)) * wg      # (K, cg, H)
-    y = torch.nn.functional.conv1d(x.transpose(1, 2), kern.permute(2, 1, 0), w["encoder/pos_conv_embed/conv/bias"],
+    y = torch.nn.functional.conv1d(_r(x).transpose(1, 2), _r(kern).permute(2, 1, 0), w["encoder/pos_conv_embed/conv/bias"],
                                    padding=K // 2, groups=G).transpose(1, 2)
     if K % 2 == 0:
         y = y[:, :-1]

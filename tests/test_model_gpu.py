@@ -110,6 +110,20 @@ def test_bf16_precision_logits(torch_mod, name):
             y = O.layer_norm(y, w[f"{base}/layer_norm/gamma"].astype(np.float64), w[f"{base}/layer_norm/beta"].astype(np.float64), 1e-5)
         e = H.max_err(acts[i], O.gelu(y))
         assert e < 3e-5 * max(1.0, np.abs(y).max()), f"conv{i}: {e:.3e}"
+    # teacher-forced positional conv (one batched bf16 GEMM in this mode): the build's own `projection` activation in,
+    # `encoder_in` out; x and the weight-normalised kernel are rounded at the same points, fp32 accumulation differs
+    x_in = m.activation("projection")
+    flen = None if mask is None else O.frame_lengths(cfg, mask)
+    if flen is not None:
+        x_in = np.where(np.arange(x_in.shape[1])[None, :, None] < np.asarray(flen)[:, None, None], x_in, 0.0).astype(np.float32)
+    with H.oracle_operands("bf16"):
+        ref_pos = x_in.astype(np.float64) + O.pos_conv_embed(cfg, {k: v.astype(np.float64) for k, v in w.items()}, x_in.astype(np.float64))
+    if cfg.attention_norm_type == "postnorm":
+        ref_pos = O.layer_norm(ref_pos, w["encoder/layer_norm/gamma"].astype(np.float64), w["encoder/layer_norm/beta"].astype(np.float64),
+                               cfg.layer_norm_eps)
+    e_pos = H.max_err(m.activation("encoder_in"), ref_pos)
+    print(f"{name}: bf16 positional conv, teacher-forced: {e_pos:.3e}")
+    assert e_pos < 1e-4 * max(1.0, np.abs(ref_pos).max()), e_pos
     m.set_precision("fp32")
     assert np.array_equal(m(g["wave"], attention_mask=mask).numpy(), fp32)
 
