@@ -110,8 +110,9 @@ int64_t w2v2_num_frames(const w2v2_model* m, int64_t num_samples);
  *                        fp32 bias / GELU / residual / storage: what BASELINE configs "bf16 CTC fine-tune"
  *                        ask for (mixed precision; variables, optimizer state and activations stay fp32).
  *                        Attention (head size 64) takes bf16 q, k, v and probabilities on the same pipe with
- *                        fp32 scores / softmax / accumulation.
- * Everything else (conv0 + GroupNorm, LayerNorm, positional conv, CTC) is fp32 in both modes. */
+ *                        fp32 scores / softmax / accumulation; the grouped positional conv runs as one batched
+ *                        GEMM with bf16-rounded input and kernel.
+ * Everything else (conv0 + GroupNorm, LayerNorm, softmax, CTC) is fp32 in both modes. */
 #define W2V2_PRECISION_FP32 0
 #define W2V2_PRECISION_BF16 1
 int w2v2_set_precision(w2v2_model* m, int32_t mode);
