@@ -347,3 +347,27 @@ def test_from_pretrained_hf_checkpoint_directory(torch_mod, tmp_path):
     m2 = wav2vec2.Wav2Vec2ForCTC.from_pretrained(str(d), input_shape=(2, 4000))
     assert m2.config == cfg
     assert np.array_equal(m2(g["wave"]).numpy(), want)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_odd_vocab_and_length(torch_mod, precision):
+    """A vocabulary that is not a multiple of 4 (guarded lm_head GEMM: no 16-byte columns) and an input length that
+    leaves ragged frame counts at every conv layer, B = 3: the guarded paths inside the model, against the oracle."""
+    import wav2vec2
+    from dataclasses import replace
+    cfg = replace(H.case_config("tiny_base"), vocab_size=29)
+    w = V.seeded_weights(cfg, seed=11)
+    L = 5003
+    x = V.hash_normal("odd/wave", 3 * L, 4).reshape(3, L)
+    m = wav2vec2.Wav2Vec2ForCTC(cfg, input_shape=(3, L))
+    m.set_weights(w)
+    m.set_precision(precision)
+    got = m(x).numpy()
+    assert got.shape == (3, cfg.num_frames(L), 29) and np.isfinite(got).all()
+    if precision == "fp32":
+        ref = O.ctc_forward(cfg, w, x)
+        assert H.max_err(got, ref) < H.ATOL_AIM
+    else:
+        with H.oracle_operands("bf16"):
+            ref = O.ctc_forward(cfg, w, x)
+        assert H.max_err(got, ref) < ATOL_BF16_LOGITS
