@@ -99,6 +99,8 @@ struct GemmShadows {
     // bias with zi (strideB16, strideBias), C / residual with zo * strideC2 + zi * strideC.  zmod = 0: plain batch.
     int zmod = 0;
     int64_t strideB16 = 0, strideC2 = 0, strideBias = 0;
+    int64_t strideB2 = 0;        // fp32 B with a two-level batch: B advances with zo * strideB2 + zi * strideB
+    bool overlapA = false;       // transposed A whose rows overlap (lda < M): the packed positional-conv input
 };
 int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
                        int64_t strideB, float* C, int64_t ldc, int64_t strideC, const float* bias,
@@ -147,6 +149,11 @@ int launch_pos_conv_weight_shadow(const float* wg, uint16_t* w16, int K, int cg,
 int launch_pos_conv_bf16(Profiler* prof, const float* x, const uint16_t* w16, const float* bias, const int32_t* frame_len,
                          float* y, float* pre_act, uint16_t* pack16, float* xz_ws, int B, int T, int H, int K, int groups,
                          int act, int pad_left, int add_residual, hipStream_t s);
+
+// kernel gradient of the positional conv as a batched transposed-A GEMM (precision mode 1, T % 64 == 0):
+//   dwg (groups, K, cg, og) = sum over samples and frames; pack32: (B, G, T+K-1, cg) fp32 scratch, slabs: B * K*cg*H fp32 scratch
+int launch_pos_conv_dw_bf16(Profiler* prof, const float* xz, const float* dc, float* dwg, float* pack32, float* slabs, float* red_ws,
+                            int B, int T, int H, int K, int groups, hipStream_t s);
 
 int launch_attention(Profiler* prof, const float* qkv, const int32_t* frame_len, float* ctx, int B,
                      int T, int H, int heads, hipStream_t s);

@@ -51,7 +51,7 @@ struct Gemm16Args {
     // two-level batch (grouped conv as GEMM): z = zo * zmod + zi.  A advances with z; B16 and bias with zi; C / residual
     // with zo * strideC2 + zi * strideC.  zmod = 0: plain batch (C advances with z * strideC, B16 and bias are shared).
     int zmod;
-    int64_t strideB16, strideC2, strideBias;
+    int64_t strideB16, strideC2, strideBias, strideB2;
 };
 
 // two fp32 -> one dword of two bf16, round to nearest even (gfx950 instruction; no builtin in ROCm 7.2)
@@ -107,7 +107,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
     const int m0 = tm * BM, n0 = tn * BN;
     const int z = blockIdx.z;
     const float* __restrict__ A = g.A + (int64_t)z * g.strideA;
-    const float* __restrict__ Bm = g.B + (int64_t)z * g.strideB;
+    const float* __restrict__ Bm = g.B + (g.zmod ? (int64_t)(z / g.zmod) * g.strideB2 + (int64_t)(z % g.zmod) * g.strideB
+                                                 : (int64_t)z * g.strideB);
 
     const int nk = (g.K + BK - 1) / BK;
 
@@ -473,7 +474,7 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.strideA = strideA; g.strideB = strideB; g.strideC = strideC;
     g.M = M; g.N = N; g.K = K; g.act = act;
     g.A16 = x.A16; g.B16 = x.B16; g.C16 = x.C16; g.ldb16 = x.ldb16 ? x.ldb16 : K;
-    g.zmod = x.zmod; g.strideB16 = x.strideB16; g.strideC2 = x.strideC2; g.strideBias = x.strideBias;
+    g.zmod = x.zmod; g.strideB16 = x.strideB16; g.strideC2 = x.strideC2; g.strideBias = x.strideBias; g.strideB2 = x.strideB2;
     W2V2_REQUIRE(x.zmod >= 0 && (x.zmod == 0 || nbatch % x.zmod == 0), "gemm_bf16: batch %d is not a multiple of the inner batch %d", nbatch, x.zmod);
     const bool kfast = K % BK == 0;
     const bool a32 = A && (lda % 4 == 0) && (strideA % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
@@ -486,7 +487,7 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
     if (dma < 0) { const char* e = getenv("W2V2_GEMM16_DMA"); dma = e ? atoi(e) : 1; }
     if (x.transA) {
         W2V2_REQUIRE(A && kfast && b32 && (M % 4 == 0) && (lda % 4 == 0) && (strideA % 4 == 0) &&
-                         ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && lda >= M,
+                         ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda >= M || x.overlapA),
                      "gemm_bf16: transposed A needs fp32 A and B, K %% 64 == 0, M %% 4 == 0 and 16-byte alignment");
         src = 7;
     } else if (a16 && b16) src = dma == 2 ? 6 : (dma ? 5 : 4);
@@ -502,6 +503,7 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
     int cfg = forced_cfg16();
     if (cfg == 2 && src == 1) return launch_src16<1, 256, 256, 2, 4, 1>(g, nbatch, s);   // tile study: 8 waves of 128x64
     if (N <= 64 && src == 5) return launch_src16<5, 128, 64, 2, 2, 2>(g, nbatch, s);     // narrow outputs (grouped conv: 48 | 64 columns)
+    if (N <= 64 && src == 7) return launch_src16<7, 128, 64, 2, 2, 2>(g, nbatch, s);
     return launch_cfg16<128, 128, 2, 2, 2>(g, src, nbatch, s);
 }
 

@@ -465,6 +465,23 @@ __global__ __launch_bounds__(256) void pos_pack_kernel(const float* __restrict__
     }
 }
 
+// fp32 variant of the pack (the kernel-gradient GEMM reads A transposed from fp32 and rounds it itself)
+__global__ __launch_bounds__(256) void pos_pack32_kernel(const float* __restrict__ x, float* __restrict__ P, int B, int T, int H,
+                                                         int groups, int Tp, int pad) {
+    const int cg = H / groups;
+    const int64_t total = (int64_t)B * groups * Tp * (cg / 4);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % (cg / 4));
+        const int r = (int)((i / (cg / 4)) % Tp);
+        const int g = (int)((i / ((int64_t)(cg / 4) * Tp)) % groups);
+        const int b = (int)(i / ((int64_t)(cg / 4) * Tp * groups));
+        const int t = r - pad;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0 && t < T) v = *reinterpret_cast<const float4*>(x + ((int64_t)b * T + t) * H + g * cg + 4 * c4);
+        *reinterpret_cast<float4*>(P + (((int64_t)b * groups + g) * Tp + r) * cg + 4 * c4) = v;
+    }
+}
+
 // y = res + act(pre)   (training forward: the pre-activation is kept for the backward, so the GEMM cannot fuse this)
 __global__ __launch_bounds__(256) void pos_finish_kernel(const float* __restrict__ pre, const float* __restrict__ res,
                                                          float* __restrict__ y, int64_t n4, int act) {
@@ -536,6 +553,34 @@ int launch_pos_conv_bf16(Profiler* prof, const float* x, const uint16_t* w16, co
     }
     return launch_gemm_bf16_x(nullptr, nullptr, cg, (int64_t)Tp * cg, nullptr, cg, 0, y, H, cg, bias, res, T, cg, K * cg, B * groups, act,
                               gx, s);
+}
+
+// dwg[g][f = j cg + c][n] = sum_{b, t} xz[b][t + j - pad][g cg + c] dc[b][t][g og + n]: per (sample, group) a GEMM with the
+// packed input as a TRANSPOSED, overlapping-row A (element (f, t) at P[t cg + f]) and dc as B; one slab per sample, summed after.
+int launch_pos_conv_dw_bf16(Profiler* prof, const float* xz, const float* dc, float* dwg, float* pack32, float* slabs, float* red_ws,
+                            int B, int T, int H, int K, int groups, hipStream_t s) {
+    W2V2_REQUIRE(xz && dc && dwg && pack32 && slabs, "pos_conv_dw_bf16: null operand");
+    const int cg = H / groups, Tp = T + K - 1;
+    W2V2_REQUIRE(T % 64 == 0 && cg % 4 == 0 && cg <= 64 && B <= 64, "pos_conv_dw_bf16: unsupported shape");
+    ProfScope ps(prof, FAM_POSCONV, 2.0 * B * (double)T * H * cg * K, 8.0 * B * (double)T * H + 4.0 * (B + 1.0) * K * cg * H, s);
+    {
+        const int64_t total = (int64_t)B * groups * Tp * (cg / 4);
+        int64_t blocks = (total + 255) / 256;
+        blocks = blocks > 8192 ? 8192 : blocks;
+        hipLaunchKernelGGL(pos_pack32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, xz, pack32, B, T, H, groups, Tp, K / 2);
+    }
+    GemmShadows gx;
+    gx.transA = true;
+    gx.overlapA = true;
+    gx.zmod = groups;
+    gx.strideB2 = (int64_t)T * H;
+    gx.strideC2 = (int64_t)groups * K * cg * cg;
+    const int M = K * cg;
+    // A^T: element (m = f, k = t) of batch z = b G + g at pack32[z Tp cg + t cg + f]; B (k = t, n) at dc[b T H + t H + g og + n]
+    if (int e = launch_gemm_bf16_x(nullptr, pack32, cg, (int64_t)Tp * cg, dc, H, cg, slabs, cg, (int64_t)K * cg * cg, nullptr, nullptr, M, cg, T,
+                                   B * groups, 0, gx, s))
+        return e;
+    return launch_colsum(slabs, dwg, B, (int)((int64_t)groups * K * cg * cg), red_ws, 0, s);
 }
 
 }  // namespace w2v2

@@ -36,6 +36,7 @@ struct TrainState {
     std::vector<LayerSave> layers;
     float *hd = nullptr, *hm = nullptr, *pos_c = nullptr, *hdf = nullptr, *hs0 = nullptr;
     float *WpT = nullptr, *WlmT = nullptr, *pos_wg_t = nullptr, *dwg = nullptr;
+    float *pos_pack32 = nullptr, *pos_dw_slabs = nullptr;   // scratch of the GEMM-formulated positional-conv kernel gradient
     uint16_t* pos_w16_t = nullptr;           // bf16 (groups, og, K cg) shadow of pos_wg_t (precision mode 1); follows transposes_fresh
     bool pos_w16_t_fresh = false;
     uint8_t* spec_mask = nullptr;       // (B*T) device copy, or null when not applied
@@ -112,6 +113,7 @@ static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
         else (void)hipFree(p);
     t->allocs = keep;
     t->layers.clear();
+    t->pos_pack32 = t->pos_dw_slabs = nullptr;      // lazily re-allocated at the new shape
     const w2v2_config& c = m->cfg;
     const int64_t H = c.hidden_size, F = c.intermediate_size, BT = (int64_t)B * T;
     const int64_t C = c.filter_sizes[c.num_conv_layers - 1];
@@ -659,7 +661,16 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     float* gv = G("encoder/pos_conv_embed/conv/weight_v");
     float* gg = G("encoder/pos_conv_embed/conv/weight_g");
     if (gv || gg) {
-        if (int e = launch_pos_conv_dw(pf, xz, dc, t->dwg, nullptr, B, T, H, K, Gr, s)) return e;
+        if (w2v2_pos_conv_bf16_ok(m) && T % 64 == 0 && B <= 64) {
+            // precision mode 1: batched transposed-A GEMM on the bf16 pipe (one (K cg, og) slab per sample and group, summed after)
+            if (!t->pos_pack32) {
+                if (int e = t_alloc(t, &t->pos_pack32, (int64_t)B * (T + K - 1) * H)) return e;
+                if (int e = t_alloc(t, &t->pos_dw_slabs, (int64_t)B * K * cg * H)) return e;
+            }
+            if (int e = launch_pos_conv_dw_bf16(pf, xz, dc, t->dwg, t->pos_pack32, t->pos_dw_slabs, t->red_ws, B, T, H, K, Gr, s)) return e;
+        } else if (int e = launch_pos_conv_dw(pf, xz, dc, t->dwg, nullptr, B, T, H, K, Gr, s)) {
+            return e;
+        }
         float* gvd = gv ? gv : t->dwv_scratch;   // scratch targets when only one of the pair trains
         float* ggd = gg ? gg : t->dummy;
         if (int e = launch_weight_norm_bwd(m->P("encoder/pos_conv_embed/conv/weight_v"), m->P("encoder/pos_conv_embed/conv/weight_g"),
