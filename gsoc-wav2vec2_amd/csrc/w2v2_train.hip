@@ -228,8 +228,11 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
         int S = 1;
         const int64_t tiles = (int64_t)((Kin + 127) / 128) * ((Nout + 127) / 128);
         const int kq = direct ? 64 : 32;        // K granularity of the kernel that will run
+        // slabs cost a reduction pass each: the fast bf16 GEMM is happy with ~2 blocks per slot (61.5 vs 62.1 ms per step),
+        // the fp32 one wants ~4 to balance its long tiles (183.8 vs 189.4 ms)
+        const int64_t max_blocks = direct ? 1024 : 2048;
         for (int cand = 32; cand >= 2; cand >>= 1)
-            if (M % (cand * kq) == 0 && tiles * cand <= 2048 && (int64_t)(cand + 1) * Kin * Nout <= t->slab_floats) {
+            if (M % (cand * kq) == 0 && tiles * cand <= max_blocks && (int64_t)(cand + 1) * Kin * Nout <= t->slab_floats) {
                 S = cand;
                 break;
             }
