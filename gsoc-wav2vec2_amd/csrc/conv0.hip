@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(Conv0Args a) {
                     const int c = c0 + 256 * j;
                     if (c < a.C) {
                         float v = MODE == 1 ? apply_act(fmaf(y[j], sc[j], sh[j]), a.act) : y[j];
-                        a.out[((int64_t)b * a.T0 + t0 + t) * a.C + c] = v;
+                        __builtin_nontemporal_store(v, &a.out[((int64_t)b * a.T0 + t0 + t) * a.C + c]);   // 3.2 GB streamed once
                         if (a.out16) a.out16[((int64_t)b * a.T0 + t0 + t) * a.C + c] = (uint16_t)pack_bf16_rne(v, 0.f);
                     }
                 }
