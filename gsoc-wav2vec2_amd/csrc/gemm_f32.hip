@@ -389,6 +389,34 @@ int forced_cfg() {
     return v;
 }
 
+// ---- split-K for small problems (serving: B = 1) ------------------------------------------------------------------
+// A single utterance gives the N = 768 GEMMs 36 tiles of 64x64 for 256 CUs, each walking a K = 3072 loop of 96 steps
+// alone.  Splitting K over S batches (the batched-strides contract of this kernel: A advances along its columns, B along
+// its rows, C is a slab) fills the chip; this kernel then folds the slabs with the epilogue the GEMM skipped.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C, const float* __restrict__ bias,
+                                                            const float* __restrict__ residual, int M, int N, int64_t ldc, int S, int act) {
+    const int64_t n4 = (int64_t)M * N / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t e = i * 4, row = e / N;
+        const int col = (int)(e % N);
+        float4 acc = reinterpret_cast<const float4*>(slabs)[i];
+        for (int z = 1; z < S; ++z) {
+            const float4 v = reinterpret_cast<const float4*>(slabs + (int64_t)z * M * N)[i];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        if (bias) { acc.x += bias[col]; acc.y += bias[col + 1]; acc.z += bias[col + 2]; acc.w += bias[col + 3]; }
+        acc.x = apply_act(acc.x, act); acc.y = apply_act(acc.y, act); acc.z = apply_act(acc.z, act); acc.w = apply_act(acc.w, act);
+        if (residual) {
+            const float4 r = *reinterpret_cast<const float4*>(residual + row * ldc + col);
+            acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+        }
+        *reinterpret_cast<float4*>(C + row * ldc + col) = acc;
+    }
+}
+
+float* g_splitk_ws = nullptr;       // grow-only scratch owned by the library (slabs)
+size_t g_splitk_floats = 0;
+
 thread_local int tl_precision = 0;
 
 }  // namespace
@@ -430,6 +458,32 @@ int launch_gemm_ex(Profiler* prof, const float* A, int64_t lda, int64_t strideA,
     // (cfg 14 = 128x96 tiles with 6 waves, meant to turn the 2.25 "rounds" of the N = 768 GEMMs into 3.0 exact ones:
     // measured 100 TF against 114-121 -- blocks are not scheduled in lock-step rounds, so the quantisation it removes
     // does not exist, and the 6-wave block is simply less efficient.)
+    if (cfg < 0 && fast && nbatch == 1 && strideB == 0 && K >= 1024 && (ldc % 4) == 0 &&
+        ((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0) {
+        const int64_t tiles64 = (int64_t)((M + 63) / 64) * ((N + 63) / 64);
+        int S = 1;
+        for (int cand = 8; cand >= 2; cand >>= 1)
+            if (K % (cand * BK) == 0 && K / cand >= 256 && tiles64 * cand <= 512) { S = cand; break; }
+        if (S > 1 && tiles64 <= 256) {
+            const size_t need = (size_t)S * M * N;
+            if (need > g_splitk_floats) {
+                if (g_splitk_ws) W2V2_HIP_CHECK(hipFree(g_splitk_ws));
+                g_splitk_ws = nullptr; g_splitk_floats = 0;
+                W2V2_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g_splitk_ws), need * sizeof(float)));
+                g_splitk_floats = need;
+            }
+            GemmArgs h = g;
+            h.C = g_splitk_ws; h.bias = nullptr; h.residual = nullptr; h.act = 0;
+            h.K = K / S; h.strideA = K / S; h.strideB = (int64_t)(K / S) * ldb; h.ldc = N; h.strideC = (int64_t)M * N;
+            if (int e = launch_dma<2, 2, 2, 32, 64, 64>(h, S, s)) return e;
+            const int64_t n4 = (int64_t)M * N / 4;
+            int64_t blocks = (n4 + 255) / 256;
+            blocks = blocks > 2048 ? 2048 : blocks;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g_splitk_ws, C, bias, residual, M, N, ldc, S, act);
+            W2V2_HIP_CHECK(hipGetLastError());
+            return W2V2_OK;
+        }
+    }
     if (cfg < 0) {
         cfg = 7;
         // small problems (batch 1-4 of the transformer GEMMs: M = 768 rows is 6 row tiles): 128x128 tiles leave most
