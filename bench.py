@@ -144,7 +144,7 @@ def main():
     ap.add_argument("--model", choices=["base", "large-robust"], default="base",
                     help="base = wav2vec2-base (the headline); large-robust = 24L/1024d prenorm, LayerNorm convs, conv bias, "
                          "attention mask (BASELINE configs[3] / [4] shapes, e.g. --batch 16 --samples 480000)")
-    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+    ap.add_argument("--precision", choices=["fp32", "bf16", "bf16x3"], default="fp32",
                     help="fp32 = the reference's arithmetic and the headline metric; bf16 = Dense / Conv1D operands rounded "
                          "to bf16 with fp32 accumulation (BASELINE configs[2]/[4] 'bf16 CTC fine-tune'), reported separately")
     ap.add_argument("--mode", choices=["forward", "train"], default="forward",
@@ -172,7 +172,7 @@ def main():
     model = wav2vec2.Wav2Vec2ForCTC(cfg, input_shape=(args.batch, args.samples))
     model.set_weights(weights)
     model.set_precision(args.precision)
-    gemm_family = "gemm_f32" if args.precision == "fp32" else "gemm_bf16"
+    gemm_family = {"fp32": "gemm_f32", "bf16": "gemm_bf16", "bf16x3": "gemm_split"}[args.precision]
     B, L = args.batch, args.samples
     T = cfg.num_frames(L)
 
@@ -248,7 +248,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "bf16 operands, f32 accumulate (Dense / Conv1D); f32 elsewhere",
+            "dtype": {"fp32": "f32", "bf16": "bf16 operands, f32 accumulate (Dense / Conv1D); f32 elsewhere",
+                      "bf16x3": "f32 operands as exact 3 x bf16 sums, 6 bf16 MFMA products per f32 product, f32 accumulate (Dense / Conv1D); f32 elsewhere"}[args.precision],
             "data": "synthetic",
             "config": {"workload": (f"wav2vec2-{args.model} {args.precision} forward-only, batch={B}x{L} samples per GPU"
                                     + (" (BASELINE configs[1])" if (args.model, B, L, args.precision) == ("base", 32, 246000, "fp32") else "")
@@ -262,10 +263,13 @@ def main():
         if prof:
             gm = prof[gemm_family]
             ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
-            peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+            # bf16x3: the algorithmic (fp32-product) rate is bounded by the bf16 pipe / 6 products
+            peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16x3": round(PEAK_BF16_MFMA_TFLOPS / 6, 1)}[args.precision]
             res["roofline"] = {
                 "kernel": ("gemm_f32_dma_kernel (fp32 MFMA 32x32x2, LDS-DMA staged: conv1-6 implicit GEMM + all Dense layers)" if args.precision == "fp32"
-                           else "gemm_bf16_kernel (bf16 MFMA 32x32x16; operands from bf16 shadows or fp32 rounded on the way into LDS: conv1-6 + all Dense)"),
+                           else "gemm_bf16_kernel (bf16 MFMA 32x32x16; operands from bf16 shadows or fp32 rounded on the way into LDS: conv1-6 + all Dense)"
+                           if args.precision == "bf16" else
+                           "gemm_split_kernel (fp32 GEMM as 6 bf16 MFMA 32x32x16 products of exact 3-term operand splits; peak = bf16 dense peak / 6)"),
                 "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": measured_traffic() if args.precision == "fp32" else None,
                 "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
@@ -281,7 +285,7 @@ def main():
                 for k, v in prof_all.items() if v["launches"] > 0}
             res["families_note"] = "per-family breakdown from 2 extra untimed steps with every family instrumented"
             # whole-forward algorithmic rate: 235.56 GFLOP per 246000-sample utterance scales with T
-            flops_step = sum(v["flops"] for k, v in prof_all.items() if k in ("gemm_f32", "gemm_bf16", "pos_conv", "attention", "conv0_apply")) / 2
+            flops_step = sum(v["flops"] for k, v in prof_all.items() if k in ("gemm_f32", "gemm_bf16", "gemm_split", "pos_conv", "attention", "conv0_apply")) / 2
             res["forward_tflops"] = round(flops_step * world / (elapsed / args.steps) / 1e12, 2)
         if args.mode == "train":
             res["final_loss"] = round(float(out), 4)

@@ -38,6 +38,7 @@ enum Family {
     FAM_CONV0_APPLY,       // conv0 recompute + GroupNorm + GELU + single write  (HBM: 100.76 MB/utt write)
     FAM_GEMM,              // fp32 MFMA GEMM / implicit-GEMM conv / Dense        (MFMA f32)
     FAM_GEMM_BF16,         // same contractions, bf16 operands / fp32 accumulate (MFMA bf16; precision mode 1)
+    FAM_GEMM_SPLIT,        // same contractions, fp32 operands as 3 bf16 terms each, 6 MFMA products (precision mode 2)
     FAM_LAYERNORM,         // row LayerNorm (+GELU)                              (HBM)
     FAM_POSCONV,           // grouped positional conv, MFMA 16x16x4 f32          (MFMA f32)
     FAM_ATTENTION,         // fused QK^T-softmax-PV, MFMA 32x32x2 f32            (MFMA f32)
@@ -87,6 +88,14 @@ int launch_gemm_bf16(Profiler* prof, const float* A, int64_t lda, int64_t stride
 // tensor -- exactly what the kernel would round to itself -- so using one changes speed, never results.
 //   A16: same shape / strides (in elements) as A;   B16: B TRANSPOSED, [N][K] with row stride ldb16 (0 = K);
 //   C16: bf16 copy of the output for the consumer GEMM (C itself may then be null: the fp32 store is skipped).
+// fp32 GEMM as six bf16 MFMA products per fp32 product (gemm_split.hip, precision mode 2): A fp32 (M, K) rows lda apart,
+// the weight pre-split by launch_split_weight into three (N, K) bf16 planes (3 N K elements).
+bool gemm_split_supported(const float* A, int64_t lda, int64_t strideA, int M, int N, int K);
+int launch_split_weight(const float* w, uint16_t* planes, int K, int N, hipStream_t s);
+int launch_gemm_split(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const uint16_t* planes, float* C, int64_t ldc,
+                      int64_t strideC, const float* bias, const float* residual, int M, int N, int K, int nbatch, int act,
+                      hipStream_t s);
+
 struct GemmShadows {
     const uint16_t* A16 = nullptr;
     const uint16_t* B16 = nullptr;

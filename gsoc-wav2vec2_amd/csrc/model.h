@@ -52,6 +52,10 @@ struct w2v2_model {
     // bf16 positional conv (precision mode 1; posconv.hip): kernel shadow (groups, og, K cg), pack scratch (B, G, T+K-1, cg)
     uint16_t *pos_w16 = nullptr, *pos_pack16 = nullptr;
     bool pos16_valid = false;
+    // precision mode 2 (gemm_split.hip): three (N, K) bf16 planes per GEMM weight, built on first use, rebuilt after finalize
+    std::unordered_map<const float*, uint16_t*> w48;
+    std::vector<void*> w48_allocs;
+    bool w48_valid = false;
     w2v2::Profiler* prof = nullptr;
     struct TrainState* train = nullptr;      // owned by w2v2_train.hip (null until the first training call)
 

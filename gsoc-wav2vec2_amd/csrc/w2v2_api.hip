@@ -31,7 +31,7 @@ void set_error(const char* fmt, ...) {
 }
 
 const char* family_name(int f) {
-    static const char* names[FAM_COUNT] = {"conv0_stats", "conv0_apply", "gemm_f32", "gemm_bf16", "layer_norm",
+    static const char* names[FAM_COUNT] = {"conv0_stats", "conv0_apply", "gemm_f32", "gemm_bf16", "gemm_split", "layer_norm",
                                            "pos_conv",    "attention",   "ctc",      "misc"};
     return (f >= 0 && f < FAM_COUNT) ? names[f] : "?";
 }
@@ -378,6 +378,7 @@ void w2v2_destroy(w2v2_model* m) {
     for (auto p : m->qkv_w) (void)hipFree(p);
     for (auto p : m->qkv_b) (void)hipFree(p);
     for (void* p : m->w16_allocs) (void)hipFree(p);
+    for (void* p : m->w48_allocs) (void)hipFree(p);
     if (m->pos_w16) (void)hipFree(m->pos_w16);
     profiler_destroy(m->prof);
     delete m;
@@ -461,6 +462,7 @@ int w2v2_finalize(w2v2_model* m, void* stream) {
     }
     m->finalized = true;
     m->w16_valid = false;      // the bf16 weight shadows (if any) follow the variables
+    m->w48_valid = false;
     m->pos16_valid = false;
     return W2V2_OK;
 }
@@ -476,7 +478,7 @@ int64_t w2v2_num_frames(const w2v2_model* m, int64_t n) {
 
 int w2v2_set_precision(w2v2_model* m, int32_t mode) {
     W2V2_REQUIRE(m, "set_precision: null model");
-    W2V2_REQUIRE(mode == W2V2_PRECISION_FP32 || mode == W2V2_PRECISION_BF16, "set_precision: unknown mode %d", mode);
+    W2V2_REQUIRE(mode == W2V2_PRECISION_FP32 || mode == W2V2_PRECISION_BF16 || mode == W2V2_PRECISION_BF16X3, "set_precision: unknown mode %d", mode);
     m->precision = mode;
     return W2V2_OK;
 }
@@ -514,9 +516,31 @@ int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const i
         if (int e = w2v2_ensure_shadows(m, B, T, s)) return e;
     const bool attn16 = sh && attention_bf16_supported(H / c.num_heads);
     auto W16 = [&](const float* w) -> const uint16_t* { return sh ? m->w16[w] : nullptr; };
+    // Precision mode 2: fp32 operands, each an exact sum of three bf16 terms, six MFMA products (gemm_split.hip).  The
+    // weight planes are built on first use; shapes the split kernel does not take (lm_head: N = 32) stay on the fp32 MFMA.
+    if (m->precision == W2V2_PRECISION_BF16X3 && !m->w48_valid) {
+        for (void* p : m->w48_allocs) (void)hipFree(p);       // planes of the previous variables
+        m->w48_allocs.clear();
+        m->w48.clear();
+        m->w48_valid = true;
+    }
+    auto split_planes = [&](const float* Bw, int K, int N, const uint16_t** out) -> int {
+        uint16_t*& dst = m->w48[Bw];
+        if (!dst) {
+            if (int e = sh_alloc(m->w48_allocs, &dst, 3 * (int64_t)K * N)) return e;
+            if (int e = launch_split_weight(Bw, dst, K, N, s)) return e;
+        }
+        *out = dst;
+        return W2V2_OK;
+    };
     auto gemm = [&](const float* A, const uint16_t* A16, int64_t lda, int64_t strideA, const float* Bw, int64_t ldb, float* Cc,
                     uint16_t* C16, int64_t ldc, int64_t strideC, const float* bias, const float* res, int M, int N, int K,
                     int nbatch, int act_) -> int {
+        if (m->precision == W2V2_PRECISION_BF16X3 && ldb == N && gemm_split_supported(A, lda, strideA, M, N, K)) {
+            const uint16_t* planes = nullptr;
+            if (int e = split_planes(Bw, K, N, &planes)) return e;
+            return launch_gemm_split(pf, A, lda, strideA, planes, Cc, ldc, strideC, bias, res, M, N, K, nbatch, act_, s);
+        }
         if (!sh) return launch_gemm(pf, A, lda, strideA, Bw, ldb, Cc, ldc, strideC, bias, res, M, N, K, nbatch, act_, s);
         GemmShadows x;
         x.A16 = A16; x.B16 = W16(Bw); x.C16 = C16; x.ldb16 = K;
@@ -703,7 +727,7 @@ int w2v2_op_gemm(const float* A, int64_t lda, int64_t strideA, const float* B, i
                        reinterpret_cast<hipStream_t>(stream));
 }
 int w2v2_op_set_precision(int32_t mode) {
-    W2V2_REQUIRE(mode == W2V2_PRECISION_FP32 || mode == W2V2_PRECISION_BF16, "op_set_precision: unknown mode %d", mode);
+    W2V2_REQUIRE(mode == W2V2_PRECISION_FP32 || mode == W2V2_PRECISION_BF16 || mode == W2V2_PRECISION_BF16X3, "op_set_precision: unknown mode %d", mode);
     gemm_set_precision(mode);
     return W2V2_OK;
 }
@@ -712,6 +736,19 @@ int w2v2_op_gemm_bf16(const float* A, int64_t lda, int64_t strideA, const float*
                       int32_t N, int32_t K, int32_t nbatch, int32_t act, void* stream) {
     return launch_gemm_bf16(nullptr, A, lda, strideA, B, ldb, 0, C, ldc, strideC, bias, residual, M, N, K, nbatch, act,
                             reinterpret_cast<hipStream_t>(stream));
+}
+int w2v2_op_gemm_split(const float* A, int64_t lda, int64_t strideA, const float* B, float* C, int64_t ldc, int64_t strideC,
+                       const float* bias, const float* residual, int32_t M, int32_t N, int32_t K, int32_t nbatch, int32_t act,
+                       void* stream) {
+    W2V2_REQUIRE(A && B && C && N > 0 && K > 0, "op_gemm_split: null operand");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    uint16_t* planes = nullptr;
+    W2V2_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&planes), (size_t)3 * K * N * sizeof(uint16_t)));
+    int e = launch_split_weight(B, planes, K, N, s);
+    if (!e) e = launch_gemm_split(nullptr, A, lda, strideA, planes, C, ldc, strideC, bias, residual, M, N, K, nbatch, act, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(planes);
+    return e;
 }
 int w2v2_op_gemm_bf16_at(const float* At, int64_t lda, int64_t strideA, const float* B, int64_t ldb, int64_t strideB,
                          float* C, int64_t ldc, int64_t strideC, int32_t M, int32_t N, int32_t K, int32_t nbatch, void* stream) {

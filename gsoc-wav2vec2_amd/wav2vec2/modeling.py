@@ -200,19 +200,21 @@ class TFKerasModel:
         N.check(self._lib.w2v2_set_trainable(self._handle, name_prefix.encode(), int(bool(trainable))), "w2v2_set_trainable")
 
     # ---- arithmetic of the dense contractions --------------------------------
-    PRECISIONS = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "mixed_bfloat16": 1}
+    PRECISIONS = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "mixed_bfloat16": 1, "bf16x3": 2}
 
     def set_precision(self, precision):
         """"fp32" (default: the reference's arithmetic) or "bf16" (Conv1D layers 1..6 and every Dense take
         bf16-rounded operands with fp32 accumulation, forward and backward -- the mixed-precision policy the
-        bf16 fine-tune configurations ask for; variables, activations and optimizer state stay fp32)."""
+        bf16 fine-tune configurations ask for; variables, activations and optimizer state stay fp32), or "bf16x3"
+        (inference forward: fp32 operands split exactly into three bf16 terms, six bf16 MFMA products per fp32
+        product, fp32 accumulation -- fp32-level results at the bf16 matrix cores' rate; csrc/gemm_split.hip)."""
         if precision not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(set(self.PRECISIONS))}, got {precision!r}")
         N.check(self._lib.w2v2_set_precision(self._handle, self.PRECISIONS[precision]), "w2v2_set_precision")
 
     @property
     def precision(self):
-        return "bf16" if self._lib.w2v2_get_precision(self._handle) == 1 else "fp32"
+        return {0: "fp32", 1: "bf16", 2: "bf16x3"}[self._lib.w2v2_get_precision(self._handle)]
 
     # ---- persistence (reference modeling.py:22-27, 41-84) -------------------
     def save_weights(self, path):

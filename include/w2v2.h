@@ -112,9 +112,16 @@ int64_t w2v2_num_frames(const w2v2_model* m, int64_t num_samples);
  *                        Attention (head size 64) takes bf16 q, k, v and probabilities on the same pipe with
  *                        fp32 scores / softmax / accumulation; the grouped positional conv runs as one batched
  *                        GEMM with bf16-rounded input and kernel.
- * Everything else (conv0 + GroupNorm, LayerNorm, softmax, CTC) is fp32 in both modes. */
+ *   W2V2_PRECISION_BF16X3  fp32 results from the bf16 matrix cores (inference forward): every fp32 operand is written
+ *                        exactly as a sum of three bf16 terms and each fp32 product is evaluated as the six bf16 x bf16
+ *                        products of order <= 2, accumulated in fp32 (the dropped terms are < 2^-23 of the product, below
+ *                        the rounding of an fp32 running sum).  Same fp32 inputs, outputs and error level as
+ *                        W2V2_PRECISION_FP32 -- logits within the same 1e-3 of the reference -- at the bf16 pipe's rate.
+ *                        Shapes the split kernel does not take, attention, the positional conv and training stay fp32.
+ * Everything else (conv0 + GroupNorm, LayerNorm, softmax, CTC) is fp32 in all modes. */
 #define W2V2_PRECISION_FP32 0
 #define W2V2_PRECISION_BF16 1
+#define W2V2_PRECISION_BF16X3 2
 int w2v2_set_precision(w2v2_model* m, int32_t mode);
 int w2v2_get_precision(const w2v2_model* m);
 
@@ -219,6 +226,14 @@ int w2v2_op_gemm_bf16(const float* A_dev, int64_t lda, int64_t strideA,
                       float* C_dev, int64_t ldc, int64_t strideC,
                       const float* bias_dev, const float* residual_dev,
                       int32_t M, int32_t N, int32_t K, int32_t nbatch, int32_t act, void* stream);
+
+/* C_z = act(A_z B + bias) + residual_z with fp32 operands split exactly into three bf16 terms each and six bf16 MFMA
+ * products per fp32 product (W2V2_PRECISION_BF16X3's GEMM; B dense (K, N), split into planes inside the call).
+ * N % 256 == 0, K % 32 == 0, lda % 4 == 0, 16-byte aligned A. */
+int w2v2_op_gemm_split(const float* A_dev, int64_t lda, int64_t strideA, const float* B_dev,
+                       float* C_dev, int64_t ldc, int64_t strideC,
+                       const float* bias_dev, const float* residual_dev,
+                       int32_t M, int32_t N, int32_t K, int32_t nbatch, int32_t act, void* stream);
 
 /* The weight-gradient form of the same GEMM: C_z (M, N) = A_z^T B_z with A given TRANSPOSED, (K, M) fp32 row-major with
  * row stride lda (>= M), and per-batch strides on A, B and C (split-K: batch z covers rows [z K, (z+1) K) of both

@@ -152,6 +152,30 @@ def test_bf16_shadows_do_not_change_results(torch_mod, name):
         assert np.array_equal(res["0"][k], res["1"][k]), f"{k}: max diff {H.max_err(res['0'][k], res['1'][k]):.3e}"
 
 
+@pytest.mark.parametrize("name", ["tiny_base", "base_sample_unpadded", "base_sample_padded", "robust_masked"])
+def test_bf16x3_precision_is_fp32_grade(torch_mod, name):
+    """Precision mode "bf16x3" (fp32 GEMMs evaluated as six bf16 MFMA products of exact three-term operand splits) must
+    meet the FP32 bar, not a bf16 one: the same 2e-4 against the HF fp64 logits as test_logits_match_golden, and an
+    error no worse than 1.5x the native fp32 path's on the same fixture."""
+    g = H.golden(name)
+    m, cfg = build(name)
+    mask = g.get("attention_mask")
+    mask = None if mask is None else mask.astype(np.int32)
+    e32 = H.max_err(m(g["wave"], attention_mask=mask).numpy(), g["logits_f64"])
+    m.set_precision("bf16x3")
+    assert m.precision == "bf16x3"
+    got = m(g["wave"], attention_mask=mask).numpy()
+    e3 = H.max_err(got, g["logits_f64"])
+    print(f"{name}: max|logits - HF fp64|  bf16x3 {e3:.3e}   fp32 {e32:.3e}")
+    report(f"{name}/bf16x3_logits_vs_hf_f64", e3)
+    assert e3 < H.ATOL_AIM
+    assert e3 < 1.5 * e32 + 2e-5
+    prof_ok = m.activation("layer0")
+    assert np.isfinite(prof_ok).all()
+    m.set_precision("fp32")
+    assert H.max_err(m(g["wave"], attention_mask=mask).numpy(), g["logits_f64"]) == e32      # planes do not leak into fp32 mode
+
+
 def test_set_precision_rejects_unknown(torch_mod):
     m, cfg = build("tiny_base")
     with pytest.raises(ValueError):

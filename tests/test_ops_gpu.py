@@ -177,6 +177,77 @@ def test_strided_conv_as_overlapping_gemm_bf16(env, Tin, Cin, Cout, k, s, B):
 
 
 
+@pytest.mark.parametrize("M,N_,K,act,use_bias,use_res", [
+    (128, 256, 32, 0, False, False), (300, 256, 128, 1, True, False), (1000, 768, 96, 0, True, True),
+    (2048, 768, 3072, 0, True, True), (515, 2304, 768, 2, True, False), (2100, 512, 1536, 1, True, False)])   # (large enough that the fp32 kernel does not split K)
+def test_gemm_split_is_fp32_grade(env, M, N_, K, act, use_bias, use_res):
+    """W2V2_PRECISION_BF16X3's GEMM (csrc/gemm_split.hip): fp32 operands as exact three-term bf16 sums, six bf16 MFMA
+    products per fp32 product, fp32 accumulation.  The claim is fp32-LEVEL accuracy, so the bar is the native fp32 MFMA
+    kernel's: the same tolerance against fp64 as test_gemm_matches_numpy, and an error no larger than 1.5x what the
+    fp32 kernel commits on the same operands (measured: 0.8-1.0x)."""
+    lib, torch, dev = env
+    A, B = rnd("As", (M, K)), rnd("Bs", (K, N_), 0.2)
+    bias = rnd("biass", (N_,)) if use_bias else None
+    res = rnd("ress", (M, N_)) if use_res else None
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    if use_bias:
+        ref = ref + bias
+    if act:
+        ref = O.gelu(ref, approximate=(act == 2))
+    if use_res:
+        ref = ref + res
+    tA, tB = dev_t(torch, dev, A), dev_t(torch, dev, B)
+    tb = dev_t(torch, dev, bias) if use_bias else None
+    tr = dev_t(torch, dev, res) if use_res else None
+    out = torch.full((M, N_), float("nan"), device=dev)
+    nat = torch.full((M, N_), float("nan"), device=dev)
+    N.check(lib.w2v2_op_gemm_split(N.ptr(tA), K, 0, N.ptr(tB), N.ptr(out), N_, 0, N.ptr(tb), N.ptr(tr), M, N_, K, 1, act, stream()))
+    N.check(lib.w2v2_op_gemm(N.ptr(tA), K, 0, N.ptr(tB), N_, N.ptr(nat), N_, 0, N.ptr(tb), N.ptr(tr), M, N_, K, 1, act, stream()))
+    got, native = out.cpu().numpy(), nat.cpu().numpy()
+    assert np.isfinite(got).all()
+    scale = max(1.0, np.abs(ref).max())
+    assert H.max_err(got, ref) < 2e-5 * scale
+    rms = lambda x: float(np.sqrt(np.mean((x - ref) ** 2)))
+    assert rms(got) <= 1.5 * rms(native) + 1e-9, (rms(got), rms(native))
+
+
+def test_gemm_split_exact_on_three_term_operands(env):
+    """The split itself is exact: operands whose fp32 significands use all 24 bits but whose products and sums stay
+    exactly representable give the exact integer result (a two-term split would lose the low 8 bits of each operand)."""
+    lib, torch, dev = env
+    M, N_, K = 128, 256, 32
+    idx = np.arange(M * K, dtype=np.int64).reshape(M, K)
+    A = (((idx * 2654435761) % 4096) + 4096 * ((idx * 40503) % 4096)).astype(np.float32)      # 24-bit integers
+    B = np.zeros((K, N_), np.float32)
+    B[np.arange(N_) % K, np.arange(N_)] = 1.0                                                   # column n selects A[:, n % K]
+    B[(np.arange(N_) + 1) % K, np.arange(N_)] = -1.0                                            # ... minus its neighbour
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    out = torch.empty((M, N_), device=dev)
+    N.check(lib.w2v2_op_gemm_split(N.ptr(dev_t(torch, dev, A)), K, 0, N.ptr(dev_t(torch, dev, B)), N.ptr(out), N_, 0, None, None,
+                                   M, N_, K, 1, 0, stream()))
+    assert np.array_equal(out.cpu().numpy().astype(np.float64), ref)
+
+
+def test_strided_conv_as_overlapping_gemm_split(env):
+    lib, torch, dev = env
+    Tin, Cin, Cout, k, s, B = 49199 // 16, 512, 512, 3, 2, 2
+    x, w = rnd("xs", (B, Tin, Cin)), rnd("ws", (k, Cin, Cout), 0.1)
+    bias = rnd("cbs", (Cout,))
+    ref = O.gelu(O.conv1d_valid(x.astype(np.float64), w.astype(np.float64), s, bias.astype(np.float64)))
+    Tout = 1 + (Tin - k) // s
+    out = torch.empty((B, Tout, Cout), device=dev)
+    N.check(lib.w2v2_op_gemm_split(N.ptr(dev_t(torch, dev, x)), s * Cin, Tin * Cin, N.ptr(dev_t(torch, dev, w)), N.ptr(out), Cout,
+                                   Tout * Cout, N.ptr(dev_t(torch, dev, bias)), None, Tout, Cout, k * Cin, B, 1, stream()))
+    assert H.max_err(out.cpu().numpy(), ref) < 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_gemm_split_rejects_unsupported_shapes(env):
+    lib, torch, dev = env
+    A, B = dev_t(torch, dev, rnd("Ar", (64, 32))), dev_t(torch, dev, rnd("Br", (32, 96)))
+    out = torch.empty((64, 96), device=dev)
+    assert lib.w2v2_op_gemm_split(N.ptr(A), 32, 0, N.ptr(B), N.ptr(out), 96, 0, None, None, 64, 96, 32, 1, 0, stream()) == -1   # N % 256
+
+
 @pytest.mark.parametrize("rows,Kin,Nout,S", [(256, 128, 132, 1), (512, 768, 64, 4), (1024, 132, 256, 8)])
 def test_gemm_bf16_transposed_a_split_k(env, rows, Kin, Nout, S):
     """dW = X^T dY as the training step runs it in precision mode 1: X (rows, Kin) is passed as the TRANSPOSED A of the GEMM

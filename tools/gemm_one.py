@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "gsoc-wav2vec2_amd"))
 import torch
 from wav2vec2 import _native as N
-name = sys.argv[1]; iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10; bf16 = len(sys.argv) > 3 and sys.argv[3] == "bf16"
+name = sys.argv[1]; iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10; bf16 = len(sys.argv) > 3 and sys.argv[3] == "bf16"; split = len(sys.argv) > 3 and sys.argv[3] == "split"
 B = 32; BT = B * 768
 S = {"conv1": (24599, 512, 1536, 1024, 49199 * 512, B, 1), "qkv": (BT, 2304, 768, 768, 0, 1, 0),
      "ffn1": (BT, 3072, 768, 768, 0, 1, 1), "ffn2": (BT, 768, 3072, 3072, 0, 1, 0), "out": (BT, 768, 768, 768, 0, 1, 0)}
@@ -16,6 +16,9 @@ A = torch.randn(a_elems, device=dev); Bm = torch.randn(K, Nn, device=dev) * 0.05
 C = torch.empty(nb * M * Nn, device=dev); bias = torch.randn(Nn, device=dev)
 st = N.current_stream()
 for _ in range(iters):
+    if split:
+        N.check(lib.w2v2_op_gemm_split(N.ptr(A), lda, sA, N.ptr(Bm), N.ptr(C), Nn, M * Nn, N.ptr(bias), None, M, Nn, K, nb, act, st))
+        continue
     N.check((lib.w2v2_op_gemm_bf16 if bf16 else lib.w2v2_op_gemm)(N.ptr(A), lda, sA, N.ptr(Bm), Nn, N.ptr(C), Nn, M * Nn, N.ptr(bias), None, M, Nn, K, nb, act, st))
 torch.cuda.synchronize()
 print("done", name)
