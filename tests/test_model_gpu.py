@@ -303,6 +303,20 @@ def test_linearity_of_lm_head_at_full_size(torch_mod):
     assert np.array_equal(a[perm], b)
 
 
+def test_bf16x3_batch_rows_are_position_independent(torch_mod):
+    """The same bit-for-bit batch-permutation property in precision mode bf16x3 (every tile of the split GEMM sums K in
+    the same order, so a row's result does not depend on where it sits in the batch)."""
+    m, cfg = build("base_sample_padded")
+    m.set_precision("bf16x3")
+    B, L = 4, 246000
+    x = V.hash_normal("full/wave3", B * L, 4).reshape(B, L)
+    a = m(x).numpy()
+    perm = np.array([2, 0, 3, 1])
+    b = m(x[perm]).numpy()
+    assert np.isfinite(a).all()
+    assert np.array_equal(a[perm], b)
+
+
 def test_large_robust_full_length_vs_oracle(torch_mod):
     """BASELINE config 4 shape: wav2vec2-large-robust (24L / 1024d, prenorm, LayerNorm convs, conv bias)
     at 246000 samples with an attention mask (one full row, one row with 100000 padded samples)."""
