@@ -305,8 +305,12 @@ class TFKerasModel:
     def _forward(self, batch, attention_mask, training, out_channels):
         if training:
             raise NotImplementedError(
-                "training=True (dropout, spec-augment, stochastic depth) is not built yet; "
-                "only the inference forward / CTC path is implemented")
+                "the training-mode forward (dropout, spec-augment, stochastic depth) needs a seed and host-drawn "
+                "masks: use wav2vec2.Trainer(model, loss).forward / .step instead of model(x, training=True)")
+        # the tuple call convention of the reference's fixed-length export wrappers (export2hub.py:40-57):
+        # model((speech, attention_mask))
+        if isinstance(batch, tuple) and len(batch) == 2 and attention_mask is None:
+            batch, attention_mask = batch
         # same (non-fatal) warnings as reference modeling.py:183-186
         if self.config.is_robust and attention_mask is None:
             logger.warning("You should pass `attention_mask` when working with Wav2Vec2 new checkpoints")

@@ -248,3 +248,104 @@ def test_stage2_learning_rate_schedule():
     from wav2vec2.training import stage2_learning_rate
     assert [stage2_learning_rate(e) for e in (0, 9, 10, 11, 30)] == [1e-4, 1e-4, 1e-4, 5e-5, 5e-5]
     assert stage2_learning_rate(3, lr1=2e-4, lr2=1e-5, transition_epochs=2) == 1e-5
+
+
+# ---- TFRecord files of the reference's schema (make_tfrecords.py:10-23, data_utils.py:17-27), no TensorFlow -----
+def _tf_protos():
+    """Message classes built with google.protobuf from descriptors transcribed from the published example.proto /
+    feature.proto / tensor.proto / tensor_shape.proto field numbers -- an independent serializer to check ours against."""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    fd = descriptor_pb2.FileDescriptorProto(name="w2v2_tf_subset.proto", package="w2v2tf", syntax="proto3")
+    F = descriptor_pb2.FieldDescriptorProto
+
+    def msg(name, fields, nested=()):
+        m = descriptor_pb2.DescriptorProto(name=name)
+        for fname, num, typ, label, tname in fields:
+            f = m.field.add(name=fname, number=num, type=typ, label=label)
+            if tname:
+                f.type_name = tname
+        for n in nested:
+            m.nested_type.add().CopyFrom(n)
+        return m
+
+    OPT, REP = F.LABEL_OPTIONAL, F.LABEL_REPEATED
+    fd.message_type.add().CopyFrom(msg("BytesList", [("value", 1, F.TYPE_BYTES, REP, None)]))
+    fd.message_type.add().CopyFrom(msg("Feature", [("bytes_list", 1, F.TYPE_MESSAGE, OPT, ".w2v2tf.BytesList")]))
+    entry = msg("FeatureEntry", [("key", 1, F.TYPE_STRING, OPT, None), ("value", 2, F.TYPE_MESSAGE, OPT, ".w2v2tf.Feature")])
+    entry.options.map_entry = True
+    fd.message_type.add().CopyFrom(msg("Features", [("feature", 1, F.TYPE_MESSAGE, REP, ".w2v2tf.Features.FeatureEntry")], nested=[entry]))
+    fd.message_type.add().CopyFrom(msg("Example", [("features", 1, F.TYPE_MESSAGE, OPT, ".w2v2tf.Features")]))
+    dim = msg("Dim", [("size", 1, F.TYPE_INT64, OPT, None), ("name", 2, F.TYPE_STRING, OPT, None)])
+    fd.message_type.add().CopyFrom(msg("TensorShapeProto", [("dim", 2, F.TYPE_MESSAGE, REP, ".w2v2tf.TensorShapeProto.Dim"),
+                                                            ("unknown_rank", 3, F.TYPE_BOOL, OPT, None)], nested=[dim]))
+    fd.message_type.add().CopyFrom(msg("TensorProto", [("dtype", 1, F.TYPE_INT32, OPT, None),
+                                                       ("tensor_shape", 2, F.TYPE_MESSAGE, OPT, ".w2v2tf.TensorShapeProto"),
+                                                       ("version_number", 3, F.TYPE_INT32, OPT, None),
+                                                       ("tensor_content", 4, F.TYPE_BYTES, OPT, None)]))
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    get = getattr(message_factory, "GetMessageClass", None)
+    cls = (lambda n: get(pool.FindMessageTypeByName("w2v2tf." + n))) if get else \
+          (lambda n: message_factory.MessageFactory(pool).GetPrototype(pool.FindMessageTypeByName("w2v2tf." + n)))
+    return cls("Example"), cls("TensorProto")
+
+
+def test_crc32c_known_answers():
+    from wav2vec2 import tfrecord as T
+    assert T.crc32c(b"123456789") == 0xE3069283                      # the CRC catalogue's check value for CRC-32C
+    assert T.crc32c(bytes(32)) == 0x8A9136AA                          # RFC 3720 B.4
+    assert T.crc32c(bytes([0xFF] * 32)) == 0x62A8AB43
+    assert T.crc32c(bytes(range(32))) == 0x46DD794E
+    assert T.masked_crc32c(b"") == 0xA282EAD8                        # crc 0 rotated is 0: the mask constant alone
+
+
+def test_tensor_and_example_bytes_match_protobuf():
+    from wav2vec2 import tfrecord as T
+    Example, TensorProto = _tf_protos()
+    speech = (np.arange(7, dtype=np.float32) - 3) / 4
+    label = np.array([5, 9, 9, 11, 0, 0], np.int32)
+    for arr, dt in ((speech, 1), (label, 3), (np.zeros((2, 3), np.float32), 1), (np.float32(2.5), 1)):
+        tp = TensorProto(dtype=dt, tensor_content=np.asarray(arr).tobytes())
+        for d in np.asarray(arr).shape:
+            tp.tensor_shape.dim.add(size=d)
+        if np.asarray(arr).ndim == 0:
+            tp.tensor_shape.SetInParent()
+        assert T.serialize_tensor(arr) == tp.SerializeToString(deterministic=True)
+        back = T.parse_tensor(tp.SerializeToString(), arr.dtype)
+        assert back.dtype == arr.dtype and back.shape == np.asarray(arr).shape and np.array_equal(back, arr)
+    ex = Example()
+    ex.features.feature["speech"].bytes_list.value.append(T.serialize_tensor(speech))
+    ex.features.feature["label"].bytes_list.value.append(T.serialize_tensor(label))
+    assert T.create_tfrecord(speech, label) == ex.SerializeToString(deterministic=True)
+    s, l = T.read_tfrecords(ex.SerializeToString())                   # any map order parses
+    assert np.array_equal(s, speech) and np.array_equal(l, label) and s.dtype == np.float32 and l.dtype == np.int32
+    parsed = Example.FromString(T.create_tfrecord(speech, label))
+    assert set(parsed.features.feature) == {"speech", "label"}
+
+
+def test_tfrecord_file_roundtrip_and_corruption(tmp_path):
+    from wav2vec2 import tfrecord as T
+    from wav2vec2.data_utils import batchify
+    rs = np.random.RandomState(0)
+    samples = [(rs.randn(n).astype(np.float32), rs.randint(1, 32, size=u).astype(np.int32)) for n, u in ((1000, 7), (1, 0), (4097, 256))]
+    path = str(tmp_path / "dev-clean-0.tfrecord")
+    T.write_dataset(path, samples)
+    raw = open(path, "rb").read()
+    assert int.from_bytes(raw[:8], "little") == len(T.create_tfrecord(*samples[0]))      # length prefix of record 0
+    got = list(T.read_dataset(path))
+    assert len(got) == 3
+    for (s, l), (s2, l2) in zip(samples, got):
+        assert np.array_equal(s, s2) and np.array_equal(l, l2)
+    # the reference's pipeline from here: normalise -> truncate -> right-pad (data_utils.py:52-78)
+    speech, _ = batchify([s for s, _ in got], audio_maxlen=2000)
+    assert speech.shape == (3, 2000) and abs(speech[0, :1000].mean()) < 1e-5 and not speech[0, 1000:].any()
+    bad = bytearray(raw)
+    bad[40] ^= 1
+    open(path, "wb").write(bytes(bad))
+    with pytest.raises(ValueError):
+        list(T.read_dataset(path))
+    open(path, "wb").write(raw[:-3])
+    with pytest.raises(ValueError):
+        list(T.read_dataset(path))
+    with pytest.raises(ValueError):                                    # dtype check of parse_tensor(out_type=...)
+        T.parse_tensor(T.serialize_tensor(np.zeros(3, np.int32)), np.float32)

@@ -202,6 +202,16 @@ def test_padding_changes_valid_frames(torch_mod):
     assert np.abs(lp[:, :145] - lu).max() > 0.1
 
 
+def test_tuple_input_call_convention(torch_mod):
+    """export2hub.py:40-57: the robust exporters are called as model((speech, attention_mask))."""
+    g = H.golden("robust_masked")
+    m, cfg = build("robust_masked")
+    mask = g["attention_mask"].astype(np.int32)
+    a = m(g["wave"], attention_mask=mask).numpy()
+    b = m((g["wave"], mask)).numpy()
+    assert np.array_equal(a, b)
+
+
 def test_batch_rows_are_independent(torch_mod):
     g = H.golden("tiny_base")
     m, _ = build("tiny_base")
