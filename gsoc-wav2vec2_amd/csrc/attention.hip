@@ -649,6 +649,9 @@ int launch_attention_x(Profiler* prof, const float* qkv, const int32_t* frame_le
     if (gemm_get_precision() == 1 && attention_bf16_supported(dh))
         return launch_attention_fwd_bf16(qkv, frame_len, ctx, ctx16, B, T, H, heads, nullptr, s);
     W2V2_REQUIRE(!ctx16, "attention: a bf16 shadow output needs the bf16 kernel (precision 1, head size 64)");
+    if (gemm_get_precision() == 2 && attention_split_supported(dh) && H % 4 == 0 &&
+        ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(ctx)) & 15) == 0)
+        return launch_attention_split(qkv, frame_len, ctx, B, T, H, heads, s);     // fp32-level results, bf16 matrix cores
     switch (dh) {
         case 32: return launch_attn<32>(a, s);
         case 64: return launch_attn<64>(a, s);

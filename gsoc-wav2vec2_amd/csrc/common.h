@@ -168,6 +168,8 @@ int launch_attention(Profiler* prof, const float* qkv, const int32_t* frame_len,
                      int T, int H, int heads, hipStream_t s);
 
 bool attention_bf16_supported(int head_size);   // attention_bf16.hip: head size 64
+bool attention_split_supported(int head_size);  // attention_split.hip (precision mode 2): head size 64
+int launch_attention_split(const float* qkv, const int32_t* frame_len, float* ctx, int B, int T, int H, int heads, hipStream_t s);
 int launch_attention_x(Profiler* prof, const float* qkv, const int32_t* frame_len, float* ctx, int B, int T, int H,
                        int heads, uint16_t* ctx16 /* optional bf16 shadow of ctx (bf16 kernel only) */, hipStream_t s);
 

@@ -22,6 +22,9 @@
 // {k, k+4}, {k+1, k+5}, ... within an 8-wide k block.
 #include <stdlib.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "common.h"
 #include "gemm_epilogue.h"
 
@@ -414,8 +417,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
-float* g_splitk_ws = nullptr;       // grow-only scratch owned by the library (slabs)
-size_t g_splitk_floats = 0;
+// Grow-only split-K scratch owned by the library, one buffer per stream: launches on one stream are ordered, so its
+// buffer is never in use by two GEMMs at once; different streams (other models, other host threads) get their own.
+struct StreamScratch { float* p = nullptr; size_t floats = 0; };
+std::mutex g_scratch_mu;
+std::unordered_map<hipStream_t, StreamScratch> g_scratch;
+
+int splitk_scratch(hipStream_t s, size_t need, float** out) {
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    StreamScratch& e = g_scratch[s];
+    if (need > e.floats) {
+        if (e.p) W2V2_HIP_CHECK(hipFree(e.p));           // (hipFree waits for the device: no kernel still reads the old one)
+        e.p = nullptr; e.floats = 0;
+        W2V2_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e.p), need * sizeof(float)));
+        e.floats = need;
+    }
+    *out = e.p;
+    return W2V2_OK;
+}
 
 thread_local int tl_precision = 0;
 
@@ -466,20 +485,16 @@ int launch_gemm_ex(Profiler* prof, const float* A, int64_t lda, int64_t strideA,
             if (K % (cand * BK) == 0 && K / cand >= 256 && tiles64 * cand <= 512) { S = cand; break; }
         if (S > 1 && tiles64 <= 256) {
             const size_t need = (size_t)S * M * N;
-            if (need > g_splitk_floats) {
-                if (g_splitk_ws) W2V2_HIP_CHECK(hipFree(g_splitk_ws));
-                g_splitk_ws = nullptr; g_splitk_floats = 0;
-                W2V2_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g_splitk_ws), need * sizeof(float)));
-                g_splitk_floats = need;
-            }
+            float* ws = nullptr;
+            if (int e = splitk_scratch(s, need, &ws)) return e;
             GemmArgs h = g;
-            h.C = g_splitk_ws; h.bias = nullptr; h.residual = nullptr; h.act = 0;
+            h.C = ws; h.bias = nullptr; h.residual = nullptr; h.act = 0;
             h.K = K / S; h.strideA = K / S; h.strideB = (int64_t)(K / S) * ldb; h.ldc = N; h.strideC = (int64_t)M * N;
             if (int e = launch_dma<2, 2, 2, 32, 64, 64>(h, S, s)) return e;
             const int64_t n4 = (int64_t)M * N / 4;
             int64_t blocks = (n4 + 255) / 256;
             blocks = blocks > 2048 ? 2048 : blocks;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g_splitk_ws, C, bias, residual, M, N, ldc, S, act);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ws, C, bias, residual, M, N, ldc, S, act);
             W2V2_HIP_CHECK(hipGetLastError());
             return W2V2_OK;
         }

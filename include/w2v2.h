@@ -117,7 +117,8 @@ int64_t w2v2_num_frames(const w2v2_model* m, int64_t num_samples);
  *                        products of order <= 2, accumulated in fp32 (the dropped terms are < 2^-23 of the product, below
  *                        the rounding of an fp32 running sum).  Same fp32 inputs, outputs and error level as
  *                        W2V2_PRECISION_FP32 -- logits within the same 1e-3 of the reference -- at the bf16 pipe's rate.
- *                        Shapes the split kernel does not take, attention, the positional conv and training stay fp32.
+ *                        Attention (head size 64) takes the same route; shapes the split kernels do not take, the
+ *                        positional conv and training stay on the fp32 MFMA.
  * Everything else (conv0 + GroupNorm, LayerNorm, softmax, CTC) is fp32 in all modes. */
 #define W2V2_PRECISION_FP32 0
 #define W2V2_PRECISION_BF16 1

@@ -422,6 +422,51 @@ def test_attention_bf16(env, bf16_ops, B, T, Hh, heads, flen):
     assert err.max() < 2e-2 and err.mean() < 2e-3
 
 
+@pytest.fixture
+def bf16x3_ops(env):
+    """Per-kernel calls in W2V2_PRECISION_BF16X3 for the duration of one test."""
+    lib = env[0]
+    N.check(lib.w2v2_op_set_precision(2))
+    yield
+    N.check(lib.w2v2_op_set_precision(0))
+
+
+@pytest.mark.parametrize("B,T,Hh,heads,flen", [(1, 145, 768, 12, None), (2, 768, 128, 2, None), (2, 200, 128, 2, [200, 61]),
+                                                (1, 97, 64, 1, [0]), (2, 64, 64, 1, None), (1, 33, 128, 2, None), (1, 300, 64, 1, [257])])
+def test_attention_split_is_fp32_grade(env, bf16x3_ops, B, T, Hh, heads, flen):
+    """Precision mode bf16x3's attention (csrc/attention_split.hip, head size 64): q d^-0.5, k, v and the probabilities as
+    exact three-term bf16 sums, six MFMA products per fp32 product.  Same fp64 formula and the SAME 2e-5 bound as the fp32
+    kernel's test_attention, plus: no worse than 1.5x the fp32 kernel's error on the same input."""
+    lib, torch, dev = env
+    d = Hh // heads
+    assert d == 64
+    qkv = rnd("qkv", (B, T, 3 * Hh), 2.0)
+    q, k, v = [qkv[:, :, i * Hh:(i + 1) * Hh].astype(np.float64).reshape(B, T, heads, d).transpose(0, 2, 1, 3) for i in range(3)]
+    s = (q * d ** -0.5) @ k.transpose(0, 1, 3, 2)
+    if flen is not None:
+        keep = np.arange(T)[None, :] < np.asarray(flen)[:, None]
+        s = (s.astype(np.float32) + ((1.0 - keep) * -10000.0)[:, None, None, :].astype(np.float32)).astype(np.float64)
+    s = s - s.max(-1, keepdims=True)
+    p = np.exp(s)
+    p /= p.sum(-1, keepdims=True)
+    ref = (p @ v).transpose(0, 2, 1, 3).reshape(B, T, Hh)
+    tf = dev_t(torch, dev, np.asarray(flen, dtype=np.int32)) if flen is not None else None
+    tq = dev_t(torch, dev, qkv)
+    out = torch.full((B, T, Hh), float("nan"), device=dev)
+    N.check(lib.w2v2_op_attention(N.ptr(tq), N.ptr(tf), N.ptr(out), B, T, Hh, heads, stream()))
+    got = out.cpu().numpy()
+    N.check(lib.w2v2_op_set_precision(0))
+    nat = torch.full((B, T, Hh), float("nan"), device=dev)
+    N.check(lib.w2v2_op_attention(N.ptr(tq), N.ptr(tf), N.ptr(nat), B, T, Hh, heads, stream()))
+    native = nat.cpu().numpy()
+    assert np.isfinite(got).all()
+    e3, e32 = H.max_err(got, ref), H.max_err(native, ref)
+    print(f"split attention: max err {e3:.3e} (fp32 kernel {e32:.3e})")
+    assert not np.array_equal(got, native)          # a different kernel did run
+    assert e3 < 2e-5
+    assert e3 < 1.5 * e32 + 1e-6
+
+
 def test_attention_softmax_spike(env):
     """One key dominating by ~60 nats mid-sequence: forces the online-softmax rescale."""
     lib, torch, dev = env
