@@ -505,6 +505,28 @@ int launch_gemm_ex(Profiler* prof, const float* A, int64_t lda, int64_t strideA,
         // of the 256 CUs idle and serialise a long K loop per tile, so switch to 64x64 tiles (4x the blocks, 4 waves)
         const int64_t tiles128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * nbatch;
         if (fast && tiles128 < 384) cfg = 16;
+        // Tail fill.  512 blocks of the 128x128 kernel are resident (2 per CU); T tiles whose last, partial round fills at
+        // most half of those slots (N = 768 at B = 32: 1152 = 2 x 512 + 128) leave most CUs idle for one whole tile time.
+        // The rows of that partial round are computed with 64x64 tiles instead (4x the blocks, a quarter of the time each).
+        // Every output element still sums its K products in the same order, so results do not depend on the tiling
+        // (a row's value is independent of its position in the batch: test_linearity_of_lm_head_at_full_size).
+        static int tail_knob = -1;
+        if (tail_knob < 0) { const char* e = getenv("W2V2_GEMM_TAIL"); tail_knob = e ? atoi(e) : 1; }     // tuning knob
+        const int64_t tn = (N + 127) / 128, S = 512, r = tiles128 % S;
+        if (tail_knob && fast && cfg == 7 && nbatch == 1 && tiles128 > S && r != 0 && 2 * r <= S) {
+            const int64_t main_rows = ((tiles128 - r) / tn) * 128;
+            if (main_rows > 0 && main_rows < M) {
+                GemmArgs h = g;
+                h.M = (int)main_rows;
+                if (int e = launch_dma<2, 4, 2>(h, 1, s)) return e;
+                GemmArgs t = g;
+                t.A = g.A + main_rows * lda;
+                t.C = g.C + main_rows * ldc;
+                t.residual = g.residual ? g.residual + main_rows * ldc : nullptr;
+                t.M = M - (int)main_rows;
+                return launch_dma<2, 2, 2, 32, 64, 64>(t, 1, s);
+            }
+        }
     }
     switch (cfg) {
         case 16: if (fast) return launch_dma<2, 2, 2, 32, 64, 64>(g, nbatch, s); return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
