@@ -84,10 +84,6 @@ int launch_gemm(Profiler* prof, const float* A, int64_t lda, int64_t strideA, co
 int launch_gemm_bf16(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
                      int64_t strideB, float* C, int64_t ldc, int64_t strideC, const float* bias,
                      const float* residual, int M, int N, int K, int nbatch, int act, hipStream_t s);
-// Optional bf16 shadows of the operands (precision mode 1).  A shadow holds nearest-even bf16 roundings of the fp32
-// tensor -- exactly what the kernel would round to itself -- so using one changes speed, never results.
-//   A16: same shape / strides (in elements) as A;   B16: B TRANSPOSED, [N][K] with row stride ldb16 (0 = K);
-//   C16: bf16 copy of the output for the consumer GEMM (C itself may then be null: the fp32 store is skipped).
 // fp32 GEMM as six bf16 MFMA products per fp32 product (gemm_split.hip, precision mode 2): A fp32 (M, K) rows lda apart,
 // the weight pre-split by launch_split_weight into three (N, K) bf16 planes (3 N K elements).
 bool gemm_split_supported(const float* A, int64_t lda, int64_t strideA, int M, int N, int K);
@@ -96,6 +92,10 @@ int launch_gemm_split(Profiler* prof, const float* A, int64_t lda, int64_t strid
                       int64_t strideC, const float* bias, const float* residual, int M, int N, int K, int nbatch, int act,
                       hipStream_t s);
 
+// Optional bf16 shadows of the operands (precision mode 1).  A shadow holds nearest-even bf16 roundings of the fp32
+// tensor -- exactly what the kernel would round to itself -- so using one changes speed, never results.
+//   A16: same shape / strides (in elements) as A;   B16: B TRANSPOSED, [N][K] with row stride ldb16 (0 = K);
+//   C16: bf16 copy of the output for the consumer GEMM (C itself may then be null: the fp32 store is skipped).
 struct GemmShadows {
     const uint16_t* A16 = nullptr;
     const uint16_t* B16 = nullptr;
