@@ -85,7 +85,7 @@ int launch_gemm_bf16(Profiler* prof, const float* A, int64_t lda, int64_t stride
                      int64_t strideB, float* C, int64_t ldc, int64_t strideC, const float* bias,
                      const float* residual, int M, int N, int K, int nbatch, int act, hipStream_t s);
 // fp32 GEMM as six bf16 MFMA products per fp32 product (gemm_split.hip, precision mode 2): A fp32 (M, K) rows lda apart,
-// the weight pre-split by launch_split_weight into three (N, K) bf16 planes (3 N K elements).
+// the weight pre-split by launch_split_weight into three bf16 planes stored as the kernel's LDS images (3 N K elements).
 bool gemm_split_supported(const float* A, int64_t lda, int64_t strideA, int M, int N, int K);
 int launch_split_weight(const float* w, uint16_t* planes, int K, int N, hipStream_t s);
 int launch_gemm_split(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const uint16_t* planes, float* C, int64_t ldc,

@@ -223,8 +223,9 @@ def test_batch_rows_are_independent(torch_mod):
     assert np.array_equal(out[:2], both) and np.array_equal(out[8:], both)
 
 
-def test_ctc_loss_matches_golden(torch_mod):
-    """reference tests/test_wav2vec2.py:217-237: loss within 1e-3 of HF."""
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_ctc_loss_matches_golden(torch_mod, precision):
+    """reference tests/test_wav2vec2.py:217-237: loss within 1e-3 of HF.  (bf16x3 is held to the fp32 bar.)"""
     import wav2vec2
     # atol 1e-3 is the reference's bar at ITS test size (2 x 46797 samples, T = 145) = base_sample_unpadded.
     # At 246000 samples the loss sums 768 frames and is 3-5x larger; the HF fp32 run itself sits 1.4e-3
@@ -233,10 +234,11 @@ def test_ctc_loss_matches_golden(torch_mod):
                              ("base_sample_padded", 1e-3, 1e-5)):
         g = H.golden(name)
         m, cfg = build(name)
+        m.set_precision(precision)
         logits = m(g["wave"])
         loss_fn = wav2vec2.CTCLoss(cfg, g["wave"].shape, division_factor=1)
         nll = loss_fn.per_sample(g["labels"], logits).cpu().numpy()
-        report(f"{name}/ctc_nll_abs_err", float(np.abs(nll - g["ctc_nll_f64"]).max()))
+        report(f"{name}/ctc_nll_abs_err" + ("" if precision == "fp32" else "_" + precision), float(np.abs(nll - g["ctc_nll_f64"]).max()))
         report(f"{name}/ctc_hf_f32_abs_err", float(np.abs(g["ctc_nll_f32"] - g["ctc_nll_f64"]).max()))
         assert np.allclose(nll, g["ctc_nll_f64"], atol=atol, rtol=rtol), (nll, g["ctc_nll_f64"])
         total = float(loss_fn(g["labels"], logits))
