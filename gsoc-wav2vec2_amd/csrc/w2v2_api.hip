@@ -536,7 +536,9 @@ int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const i
     auto gemm = [&](const float* A, const uint16_t* A16, int64_t lda, int64_t strideA, const float* Bw, int64_t ldb, float* Cc,
                     uint16_t* C16, int64_t ldc, int64_t strideC, const float* bias, const float* res, int M, int N, int K,
                     int nbatch, int act_) -> int {
-        if (m->precision == W2V2_PRECISION_BF16X3 && ldb == N && gemm_split_supported(A, lda, strideA, M, N, K)) {
+        // (below ~half a wave of 128 x 256 tiles the fp32 path's small tiles and split-K serve a single utterance better)
+        const int64_t split_tiles = (int64_t)((M + 127) / 128) * (N / 256) * nbatch;
+        if (m->precision == W2V2_PRECISION_BF16X3 && ldb == N && split_tiles >= 128 && gemm_split_supported(A, lda, strideA, M, N, K)) {
             const uint16_t* planes = nullptr;
             if (int e = split_planes(Bw, K, N, &planes)) return e;
             return launch_gemm_split(pf, A, lda, strideA, planes, Cc, ldc, strideC, bias, res, M, N, K, nbatch, act_, s);

@@ -329,6 +329,25 @@ def test_bf16x3_batch_rows_are_position_independent(torch_mod):
     assert np.array_equal(a[perm], b)
 
 
+def test_bf16x3_ragged_shapes_at_base_width(torch_mod):
+    """bf16x3 at the real layer widths (so the split GEMM / attention kernels run, unlike on the tiny configs) with every M
+    ragged: B = 3 rows of 20563 samples (T = 63: not a multiple of the 64-key attention tile or of the 128-row GEMM tile)
+    and a ragged attention mask.  Against the fp32 path on the same input (which is itself pinned to the oracle)."""
+    import wav2vec2
+    cfg = H.case_config("robust_masked")
+    w = H.case_weights("robust_masked")
+    L = 20563
+    x = V.hash_normal("ragged/wave", 3 * L, 4).reshape(3, L)
+    mask = (np.arange(L)[None, :] < np.array([L, 9000, 15001])[:, None]).astype(np.int32)
+    m = wav2vec2.Wav2Vec2ForCTC(cfg, input_shape=(3, L))
+    m.set_weights(w)
+    a = m(x, attention_mask=mask).numpy()
+    m.set_precision("bf16x3")
+    b = m(x, attention_mask=mask).numpy()
+    assert np.isfinite(b).all() and not np.array_equal(a, b)
+    assert H.max_err(a, b) < 1e-4
+
+
 def test_large_robust_full_length_vs_oracle(torch_mod):
     """BASELINE config 4 shape: wav2vec2-large-robust (24L / 1024d, prenorm, LayerNorm convs, conv bias)
     at 246000 samples with an attention mask (one full row, one row with 100000 padded samples)."""
@@ -399,7 +418,7 @@ def test_from_pretrained_hf_checkpoint_directory(torch_mod, tmp_path):
     assert np.array_equal(m2(g["wave"]).numpy(), want)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3"])
 def test_odd_vocab_and_length(torch_mod, precision):
     """A vocabulary that is not a multiple of 4 (guarded lm_head GEMM: no 16-byte columns) and an input length that
     leaves ragged frame counts at every conv layer, B = 3: the guarded paths inside the model, against the oracle."""
@@ -414,7 +433,7 @@ def test_odd_vocab_and_length(torch_mod, precision):
     m.set_precision(precision)
     got = m(x).numpy()
     assert got.shape == (3, cfg.num_frames(L), 29) and np.isfinite(got).all()
-    if precision == "fp32":
+    if precision in ("fp32", "bf16x3"):              # bf16x3 is held to the fp32 bar
         ref = O.ctc_forward(cfg, w, x)
         assert H.max_err(got, ref) < H.ATOL_AIM
     else:

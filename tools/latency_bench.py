@@ -8,10 +8,12 @@ import wav2vec2
 from wav2vec2 import variables as V
 from wav2vec2.config import RobustWav2Vec2Config
 torch.cuda.set_device(0)
+PREC = sys.argv[1] if len(sys.argv) > 1 else "fp32"      # fp32 | bf16 | bf16x3
 out = {}
 for name, cfg, cases in (("base", wav2vec2.Wav2Vec2Config(), [(1, 50000), (1, 246000), (4, 246000), (8, 246000), (32, 246000), (64, 246000), (16, 480000)]),
                          ("large-robust", RobustWav2Vec2Config(), [(16, 246000)])):
     m = wav2vec2.Wav2Vec2ForCTC(cfg)
+    m.set_precision(PREC)
     for B, L in cases:
         x = torch.randn(B, L, device="cuda")
         mask = torch.ones(B, L, dtype=torch.int32, device="cuda") if cfg.is_robust else None
