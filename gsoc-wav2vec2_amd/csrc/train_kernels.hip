@@ -120,35 +120,46 @@ __global__ void transpose_kernel(const float* __restrict__ x, float* __restrict_
     }
 }
 
-// stage 1: partial[chunk][c] = sum over the chunk's rows of x[r][c]   (fp32 within a chunk).  HBM-bound: a thread owns
-// 4 columns (16-byte loads) and keeps 4 rows in flight.
+// stage 1: partial[chunk][c] = sum over the chunk's rows of x[r][c]   (fp32 within a chunk).  HBM-bound, so the launch must
+// put thousands of loads in flight: VEC blocks are 64 float4 column groups (256 columns) x 4 row lanes, every thread keeps
+// 4 rows in flight, and chunks are 128 rows -- (cols / 256) x (rows / 128) blocks (576 for the (24576, 768) tensors; the first
+// version's 1024-column blocks gave those 96 blocks for 256 CUs and ran at 1.9 TB/s).
 template <bool VEC>
 __global__ void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
                                       int64_t rows, int cols, int rows_per_chunk) {
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
     const int64_t r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
     if (VEC) {
-        const int c = (blockIdx.x * EW_THREADS + threadIdx.x) * 4;
-        if (c >= cols) return;
+        __shared__ float4 red[4][64];
+        const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+        const int c = (blockIdx.x * 64 + cx) * 4;
         float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
-        int64_t r = r0;
-        for (; r + 3 < r1; r += 4) {
-            const float4 v0 = *reinterpret_cast<const float4*>(x + r * cols + c);
-            const float4 v1 = *reinterpret_cast<const float4*>(x + (r + 1) * cols + c);
-            const float4 v2 = *reinterpret_cast<const float4*>(x + (r + 2) * cols + c);
-            const float4 v3 = *reinterpret_cast<const float4*>(x + (r + 3) * cols + c);
-            a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
-            a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
-            a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
-            a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+        if (c < cols) {
+            int64_t r = r0 + ry;
+            for (; r + 12 < r1; r += 16) {
+                const float4 v0 = *reinterpret_cast<const float4*>(x + r * cols + c);
+                const float4 v1 = *reinterpret_cast<const float4*>(x + (r + 4) * cols + c);
+                const float4 v2 = *reinterpret_cast<const float4*>(x + (r + 8) * cols + c);
+                const float4 v3 = *reinterpret_cast<const float4*>(x + (r + 12) * cols + c);
+                a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+                a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+                a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+                a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+            }
+            for (; r < r1; r += 4) {
+                const float4 v0 = *reinterpret_cast<const float4*>(x + r * cols + c);
+                a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+            }
         }
-        for (; r < r1; ++r) {
-            const float4 v0 = *reinterpret_cast<const float4*>(x + r * cols + c);
-            a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        red[ry][cx] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
+                                  (a0.w + a1.w) + (a2.w + a3.w));
+        __syncthreads();
+        if (ry == 0 && c < cols) {
+            const float4 p0 = red[0][cx], p1 = red[1][cx], p2 = red[2][cx], p3 = red[3][cx];
+            *reinterpret_cast<float4*>(partial + (int64_t)blockIdx.y * cols + c) =
+                make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z),
+                            (p0.w + p1.w) + (p2.w + p3.w));
         }
-        *reinterpret_cast<float4*>(partial + (int64_t)blockIdx.y * cols + c) =
-            make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
-                        (a0.w + a1.w) + (a2.w + a3.w));
     } else {
         const int c = blockIdx.x * EW_THREADS + threadIdx.x;
         if (c >= cols) return;
@@ -190,8 +201,15 @@ __global__ __launch_bounds__(256) void colsum_final_wide_kernel(const float* __r
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx;
     double acc = 0.0;
-    if (c < cols)
-        for (int k = ry; k < nchunks; k += 8) acc += (double)partial[(int64_t)k * ld + c];
+    if (c < cols) {
+        int k = ry;
+        for (; k + 24 < nchunks; k += 32) {          // four independent loads in flight per lane
+            const float v0 = partial[(int64_t)k * ld + c], v1 = partial[(int64_t)(k + 8) * ld + c];
+            const float v2 = partial[(int64_t)(k + 16) * ld + c], v3 = partial[(int64_t)(k + 24) * ld + c];
+            acc += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+        }
+        for (; k < nchunks; k += 8) acc += (double)partial[(int64_t)k * ld + c];
+    }
     red[ry][cx] = acc;
     __syncthreads();
     if (ry == 0 && c < cols) {
@@ -426,7 +444,7 @@ int launch_transpose(const float* x, float* y, int rows, int cols, int nbatch, h
     return W2V2_OK;
 }
 
-constexpr int COLSUM_CHUNK = 256;    // rows per stage-1 block
+constexpr int COLSUM_CHUNK = 128;    // rows per stage-1 block
 
 int64_t colsum_ws_floats(int64_t rows, int cols) { return ((rows + COLSUM_CHUNK - 1) / COLSUM_CHUNK) * (int64_t)cols + 8; }
 
@@ -446,7 +464,7 @@ int launch_colsum(const float* x, float* out, int64_t rows, int cols, float* ws,
     }
     W2V2_REQUIRE(ws, "colsum: null workspace");
     const int nchunks = (int)((rows + COLSUM_CHUNK - 1) / COLSUM_CHUNK);
-    dim3 grid((cols + per_block - 1) / per_block, nchunks);
+    dim3 grid(vec ? (cols + 255) / 256 : (cols + per_block - 1) / per_block, nchunks);
     if (vec)
         hipLaunchKernelGGL(colsum_partial_kernel<true>, grid, dim3(EW_THREADS), 0, s, x, ws, rows, cols, COLSUM_CHUNK);
     else
