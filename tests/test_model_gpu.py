@@ -440,3 +440,26 @@ def test_odd_vocab_and_length(torch_mod, precision):
         with H.oracle_operands("bf16"):
             ref = O.ctc_forward(cfg, w, x)
         assert H.max_err(got, ref) < ATOL_BF16_LOGITS
+
+
+def test_models_release_device_memory(torch_mod):
+    """Creating, running (all three precision modes: weight shadows / split planes are per-model allocations) and dropping
+    models returns the device memory: free memory after ten cycles is within 64 MiB of the level after the first one."""
+    import gc
+    torch = torch_mod
+    g = H.golden("base_sample_unpadded")
+
+    def cycle():
+        m, cfg = build("base_sample_unpadded")
+        for prec in ("fp32", "bf16", "bf16x3"):
+            m.set_precision(prec)
+            m(g["wave"])
+        del m
+        gc.collect()
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+
+    first = cycle()
+    for _ in range(9):
+        last = cycle()
+    assert first - last < 64 * 2 ** 20, (first, last)
