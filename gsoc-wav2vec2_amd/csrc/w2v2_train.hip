@@ -57,6 +57,9 @@ struct TrainState {
           *slabs = nullptr, *red_ws = nullptr, *dvec = nullptr, *dummy = nullptr, *dwqkv = nullptr, *dwv_scratch = nullptr;
     int64_t slab_floats = 0;
     bool forward_done = false;
+    // gradient buckets for overlapping the data-parallel all-reduce with the backward: completion order
+    //   0 = lm_head, 1 .. N = encoder layers N-1 .. 0, N+1 = everything in front of layer 0 in the flat buffer
+    std::vector<hipEvent_t> bucket_ev;
 };
 
 static int t_alloc(TrainState* t, float** out, int64_t floats) {
@@ -77,6 +80,7 @@ void w2v2_train_destroy(w2v2_model* m) {
     t_free(m->train);
     if (m->train->adam_chunks) (void)hipFree(m->train->adam_chunks);
     if (m->train->pos_w16_t) (void)hipFree(m->train->pos_w16_t);
+    for (hipEvent_t ev : m->train->bucket_ev) (void)hipEventDestroy(ev);
     delete m->train;
     m->train = nullptr;
 }
@@ -509,6 +513,17 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     const int32_t* flen = t->have_mask ? m->frame_len : nullptr;
     W2V2_HIP_CHECK(hipMemsetAsync(t->grads, 0, (size_t)t->gtotal * 4, s));
     if (int e = refresh_transposes(m, s)) return e;
+    const int nbuckets = c.num_layers + 2;
+    while ((int)t->bucket_ev.size() < nbuckets) {
+        hipEvent_t ev;
+        W2V2_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        t->bucket_ev.push_back(ev);
+    }
+    // bucket k's slice of the flat buffer is final once this is recorded (w2v2_train_bucket_wait)
+    auto bucket_done = [&](int k) -> int {
+        W2V2_HIP_CHECK(hipEventRecord(t->bucket_ev[k], s));
+        return W2V2_OK;
+    };
     auto G = [&](const std::string& n) { return is_trainable(m, n) ? grad_of(m, n) : nullptr; };
     // does anything below the head train?
     bool below_head = false;
@@ -517,7 +532,12 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
 
     // ---- head ----
     if (int e = weight_grad(m, t->hdf, dlogits, (int)BT, H, V, G("lm_head/kernel"), G("lm_head/bias"), s)) return e;
-    if (!below_head) return W2V2_OK;            // stage 1 of the reference: only lm_head trains (main.py:210)
+    if (int e = bucket_done(0)) return e;
+    if (!below_head) {                          // stage 1 of the reference: only lm_head trains (main.py:210)
+        for (int k = 1; k < nbuckets; ++k)
+            if (int e = bucket_done(k)) return e;
+        return W2V2_OK;
+    }
     float *dh = t->gh[0], *tmp = t->gh[1], *tmp2 = t->gh[2], *tmp3 = t->gh[3];
     const bool prenorm = c.attention_norm_type == 1;
     if (int e = launch_gemm(pf, dlogits, V, 0, t->WlmT, H, tmp, H, 0, nullptr, nullptr, (int)BT, H, V, 1, 0, s)) return e;
@@ -589,6 +609,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
                                   eps, t->red_ws, s))
             return e;
         if (int e = launch_axpby(dt1, tmp2, dh, BT * H, 1.f, 1.f, s)) return e;          // residual + LN1 branch
+        if (int e = bucket_done(c.num_layers - i)) return e;
     }
 
     for (int i = c.num_layers - 1; i >= 0 && !prenorm; --i) {
@@ -636,6 +657,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         if (int e = qkv_weight_grad(b, m->hs[i])) return e;
         // dx = dqkv Wqkv^T + dt1 (residual)
         if (int e = gemm_dx(t->g3h, 3 * H, l.WqkvT, m->qkv_w[i], dh, H, dt1, (int)BT, H, 3 * H, s)) return e;
+        if (int e = bucket_done(c.num_layers - i)) return e;
     }
     // ---- encoder input: postnorm hs[0] = dropout(LN(posout));  prenorm hs0 = dropout(posout) ----
     float* dpos = tmp2;
@@ -723,6 +745,41 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
                                   dgp ? dgp : t->dummy, dbp ? dbp : t->dummy + C, BT, C, eps, t->red_ws, s))
             return e;
     }
+    return bucket_done(nbuckets - 1);
+}
+
+/* Gradient buckets: slices of the flat buffer in the order the backward completes them.  Data-parallel callers enqueue
+ * one all-reduce per bucket on a communication stream that waits (w2v2_train_bucket_wait) for that bucket only, so the
+ * collectives of the upper layers run under the backward of the lower ones. */
+int w2v2_train_num_buckets(const w2v2_model* m) { return m ? m->cfg.num_layers + 2 : W2V2_EINVAL; }
+
+int w2v2_train_bucket(w2v2_model* m, int32_t k, int64_t* offset, int64_t* numel) {
+    W2V2_REQUIRE(m && offset && numel, "train_bucket: null argument");
+    TrainState* t = get_state(m);
+    const int nl = m->cfg.num_layers, nb = nl + 2;
+    W2V2_REQUIRE(k >= 0 && k < nb, "train_bucket: bucket %d outside [0, %d)", k, nb);
+    // inventory order: [front: everything before encoder/layers/0][layers 0 .. N-1][lm_head]
+    auto first_with = [&](const std::string& prefix) -> int64_t {
+        for (size_t i = 0; i < m->params.size(); ++i)
+            if (m->params[i].name.compare(0, prefix.size(), prefix) == 0) return t->goff[i];
+        return t->gtotal;
+    };
+    auto layer_begin = [&](int i) { return i < nl ? first_with("encoder/layers/" + std::to_string(i) + "/") : first_with("lm_head/"); };
+    int64_t lo, hi;
+    if (k == 0) { lo = first_with("lm_head/"); hi = t->gtotal; }
+    else if (k <= nl) { const int i = nl - k; lo = layer_begin(i); hi = layer_begin(i + 1); }
+    else { lo = 0; hi = layer_begin(0); }
+    W2V2_REQUIRE(lo <= hi, "train_bucket: the variable inventory is not in [front | layers | lm_head] order");
+    *offset = lo;
+    *numel = hi - lo;
+    return W2V2_OK;
+}
+
+int w2v2_train_bucket_wait(w2v2_model* m, int32_t k, void* stream) {
+    W2V2_REQUIRE(m && m->train, "train_bucket_wait: no training state");
+    TrainState* t = m->train;
+    W2V2_REQUIRE(k >= 0 && k < (int)t->bucket_ev.size(), "train_bucket_wait: bucket %d has not been produced yet (run a backward first)", k);
+    W2V2_HIP_CHECK(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), t->bucket_ev[k], 0));
     return W2V2_OK;
 }
 

@@ -36,7 +36,7 @@ def stage2_learning_rate(epoch, lr1=1e-4, lr2=5e-5, transition_epochs=10):
 
 class Trainer:
     def __init__(self, model, loss, learning_rate=1e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-7, seed=0,
-                 dropout=None, apply_spec_augment=None):
+                 dropout=None, apply_spec_augment=None, overlap_all_reduce=True):
         if not getattr(model, "_with_lm_head", False):
             raise ValueError("Trainer needs a Wav2Vec2ForCTC model")
         self.model, self.loss = model, loss
@@ -48,6 +48,8 @@ class Trainer:
         self.iterations = 0                               # Keras optimizer.iterations
         self._rng = np.random.RandomState(seed)           # host RNG: spec-augment spans, stochastic depth
         self.last = {}
+        self.overlap_all_reduce = bool(overlap_all_reduce)   # per-bucket all-reduces under the backward (all_reduce_gradients)
+        self._comm_stream = None
 
     # -- pieces (also used by the parity tests) ----------------------------------------------------
     def forward(self, batch, attention_mask=None, spec_mask=None, sd_keep=None, step_seed=None):
@@ -93,12 +95,49 @@ class Trainer:
         N.check(m._lib.w2v2_grad_buffer(m._handle, C.byref(ptr), C.byref(n)), "w2v2_grad_buffer")
         return torch.as_tensor(_DeviceBuffer(ptr.value, n.value), device=torch.device("cuda", torch.cuda.current_device()))
 
-    def all_reduce_gradients(self):
+    def gradient_buckets(self):
+        """[(offset, numel)] slices of the flat gradient buffer in the order the backward completes them
+        (lm_head, layers N-1 .. 0, the front of the model); they tile the buffer."""
+        m = self.model
+        out = []
+        for k in range(m._lib.w2v2_train_num_buckets(m._handle)):
+            off, n = C.c_int64(), C.c_int64()
+            N.check(m._lib.w2v2_train_bucket(m._handle, k, C.byref(off), C.byref(n)), "w2v2_train_bucket")
+            out.append((off.value, n.value))
+        return out
+
+    def all_reduce_gradients(self, force=False):
         """SUM over data-parallel ranks: the loss is pre-divided by the global batch (losses.py:45,
-        main.py:198-200), so the sum is the global mean -- one RCCL all-reduce on the flat buffer."""
+        main.py:198-200), so the sum is the global mean.
+
+        Called right after `backward` -- which only ENQUEUES the backward kernels -- this issues one RCCL all-reduce per
+        gradient bucket on a communication stream that waits for that bucket alone (an event the backward records when
+        the bucket's slice is final), so the collectives of the upper layers run under the backward of the lower ones;
+        the calling stream then waits for all of them.  A layer of wav2vec2-base is a 28 MB bucket (large: 50 MB): big
+        enough for the ring to run at link speed over xGMI, small enough that only the last one is exposed.
+        `overlap_all_reduce=False` (constructor) falls back to a single all-reduce of the whole buffer."""
+        import torch
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.grad_buffer(), op=dist.ReduceOp.SUM)
+        active = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)
+        if not active:
+            return
+        buf = self.grad_buffer()
+        if not self.overlap_all_reduce:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            return
+        m = self.model
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream()
+        cs = self._comm_stream
+        works = []
+        for k, (off, n) in enumerate(self.gradient_buckets()):
+            if n == 0:
+                continue
+            N.check(m._lib.w2v2_train_bucket_wait(m._handle, k, C.c_void_p(cs.cuda_stream)), "w2v2_train_bucket_wait")
+            with torch.cuda.stream(cs):
+                works.append(dist.all_reduce(buf[off:off + n], op=dist.ReduceOp.SUM, async_op=True))
+        for w in works:
+            w.wait()              # the current stream (optimizer step next) waits for the collectives
 
     def apply_gradients(self):
         m = self.model

@@ -174,6 +174,15 @@ int w2v2_train_forward(w2v2_model* m, const float* wave_dev, int32_t B, int64_t 
                        uint64_t seed, float* logits_dev, void* stream);
 int w2v2_train_backward(w2v2_model* m, const float* grad_logits_dev, void* stream);
 int w2v2_grad_buffer(w2v2_model* m, float** dev_ptr, int64_t* numel);
+/* Gradient buckets for overlapping the data-parallel all-reduce with the backward (the reference leaves this to
+ * tf.distribute; main.py:156,192).  Bucket k is a contiguous slice [offset, offset + numel) of the flat gradient buffer;
+ * buckets are numbered in the order w2v2_train_backward completes them: 0 = lm_head, 1 .. N = encoder layers N-1 .. 0,
+ * N+1 = everything in front of layer 0 (positional conv, feature projection, ...).  They tile the buffer exactly.
+ * w2v2_train_bucket_wait makes `stream` wait until bucket k of the LAST enqueued backward is final -- and for nothing
+ * else, so a collective enqueued behind it runs under the rest of the backward. */
+int w2v2_train_num_buckets(const w2v2_model* m);
+int w2v2_train_bucket(w2v2_model* m, int32_t k, int64_t* offset, int64_t* numel);
+int w2v2_train_bucket_wait(w2v2_model* m, int32_t k, void* stream);
 int w2v2_get_grad(w2v2_model* m, const char* name, float* host_dst, int64_t numel, void* stream);
 int w2v2_adam_step(w2v2_model* m, float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
 

@@ -401,3 +401,50 @@ def test_trainer_defaults_run_with_dropout_and_spec_augment(env):
     assert tr.last["spec_mask"].shape == (2, cfg.num_frames(L)) and tr.last["spec_mask"].sum() > 0
     buf = tr.grad_buffer()
     assert buf.numel() >= 94_396_320 and bool(buf.isfinite().all())
+
+
+def test_gradient_buckets_tile_the_flat_buffer_and_overlap_path_is_exact(env):
+    """The data-parallel all-reduce is issued per gradient bucket on a side stream that waits for that bucket's event only
+    (Trainer.all_reduce_gradients).  On one rank a SUM all-reduce is the identity, so running the bucketed path through
+    RCCL (world size 1) must leave every gradient bit-identical -- which also proves the event waits: a collective that
+    ran before its slice was final would copy stale values back over it."""
+    import os
+    import torch
+    import torch.distributed as dist
+    import wav2vec2
+    m, cfg, w = build("tiny_base", 4000)
+    g = H.golden("tiny_base")
+    loss_fn = wav2vec2.CTCLoss(cfg, g["wave"].shape)
+    tr = wav2vec2.Trainer(m, loss_fn, dropout=0.1, apply_spec_augment=False, seed=3)
+    logits = tr.forward(g["wave"], step_seed=5)
+    _, dlog = loss_fn.per_sample(g["labels"], logits, with_grad=True)
+    tr.backward(dlog)
+    buckets = tr.gradient_buckets()
+    total = tr.grad_buffer().numel()
+    assert len(buckets) == cfg.num_layers + 2
+    covered = sorted(buckets)
+    assert covered[0][0] == 0 and covered[-1][0] + covered[-1][1] == total
+    for (o0, n0), (o1, _) in zip(covered, covered[1:]):
+        assert o0 + n0 == o1                                  # contiguous, no overlap, no gap
+    lm = tr.gradient("lm_head/kernel")
+    ref = tr.grad_buffer().clone()
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29617")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        created = True
+    try:
+        tr.backward(dlog)                                     # enqueue the backward again ...
+        tr.all_reduce_gradients(force=True)                   # ... and the per-bucket collectives right behind it
+        torch.cuda.synchronize()
+        assert torch.equal(tr.grad_buffer(), ref)
+        tr.overlap_all_reduce = False
+        tr.backward(dlog)
+        tr.all_reduce_gradients(force=True)
+        torch.cuda.synchronize()
+        assert torch.equal(tr.grad_buffer(), ref)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert np.array_equal(lm, tr.gradient("lm_head/kernel"))
