@@ -225,47 +225,56 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
                        float* db, hipStream_t s) {
     TrainState* t = m->train;
     if (dW) {
-        // precision mode 1: the bf16 GEMM stages A^T from X directly (its B path transposes in registers anyway)
+        // dW (Kin, Nout) = A^T dY over the M = B T rows: few output tiles and a very long K, so the rows are cut into S slabs
+        // (one GEMM batch each) that a column sum folds.  precision mode 1 stages A^T from X directly (the bf16 GEMM's B path
+        // transposes in registers anyway); fp32 goes through a transposed copy.
         const bool direct = gemm_get_precision() == 1 && Kin % 4 == 0 && Nout % 4 == 0;
-        if (!direct)
-            if (int e = launch_transpose(A, t->at, M, Kin, 1, s)) return e;
-        int S = 1;
+        const int kq = direct ? 64 : 32;        // K granularity of the fast kernel that will run
+        // The fast kernels need every slab to be a multiple of kq rows.  M need not be (T = 1499 at 480000 samples gives
+        // B T = 23984): the first Mq = kq floor(M / kq) rows go through the fast path in S equal slabs, S a divisor of
+        // Mq / kq, and the R = M - Mq < kq leftover rows form one more slab on the guarded kernel (0.2 % of the work).
+        // (Before this, such an M fell back to ONE guarded GEMM over all rows: 256 tiles, K = 23984.)
+        const int64_t units = M / kq;
+        const int Mq = (int)(units * kq), R = M - Mq;
         const int64_t tiles = (int64_t)((Kin + 127) / 128) * ((Nout + 127) / 128);
-        const int kq = direct ? 64 : 32;        // K granularity of the kernel that will run
         // slabs cost a reduction pass each: the fast bf16 GEMM is happy with ~2 blocks per slot (61.5 vs 62.1 ms per step),
         // the fp32 one wants ~4 to balance its long tiles (183.8 vs 189.4 ms)
         const int64_t max_blocks = direct ? 1024 : 2048;
-        for (int cand = 32; cand >= 2; cand >>= 1)
-            if (M % (cand * kq) == 0 && tiles * cand <= max_blocks && (int64_t)(cand + 1) * Kin * Nout <= t->slab_floats) {
+        int S = units > 0 ? 1 : 0;
+        for (int cand = 32; cand >= 2; --cand)
+            if (units > 0 && units % cand == 0 && tiles * cand <= max_blocks &&
+                (int64_t)(cand + 2) * Kin * Nout <= t->slab_floats) {
                 S = cand;
                 break;
             }
-        const int Kp = M / S;
-        if (direct && Kp % 64 == 0) {
-            GemmShadows x;
-            x.transA = true;
-            float* dst = S == 1 ? dW : t->slabs;
-            if (int e = launch_gemm_bf16_x(m->prof, A, Kin, (int64_t)Kp * Kin, dY, Nout, (int64_t)Kp * Nout, dst, Nout,
-                                           (int64_t)Kin * Nout, nullptr, nullptr, Kin, Nout, Kp, S, 0, x, s))
-                return e;
-            if (S > 1)
-                if (int e = launch_colsum(t->slabs, dW, S, Kin * Nout, t->slabs + (int64_t)S * Kin * Nout, 0, s)) return e;
-        } else if (direct) {
-            if (int e = launch_transpose(A, t->at, M, Kin, 1, s)) return e;
-            if (int e = launch_gemm_ex(m->prof, t->at, M, S == 1 ? 0 : Kp, dY, Nout, S == 1 ? 0 : (int64_t)Kp * Nout, S == 1 ? dW : t->slabs,
-                                       Nout, (int64_t)Kin * Nout, nullptr, nullptr, Kin, Nout, Kp, S, 0, s))
-                return e;
-            if (S > 1)
-                if (int e = launch_colsum(t->slabs, dW, S, Kin * Nout, t->slabs + (int64_t)S * Kin * Nout, 0, s)) return e;
-        } else if (S == 1) {
-            if (int e = launch_gemm_ex(m->prof, t->at, M, 0, dY, Nout, 0, dW, Nout, 0, nullptr, nullptr, Kin, Nout, M, 1, 0, s)) return e;
-        } else {
-            if (int e = launch_gemm_ex(m->prof, t->at, M, Kp, dY, Nout, (int64_t)Kp * Nout, t->slabs, Nout,
-                                       (int64_t)Kin * Nout, nullptr, nullptr, Kin, Nout, Kp, S, 0, s))
-                return e;
-            // sum the S slabs (rows = S, cols = Kin*Nout); the one-chunk partial scratch lives behind the slabs
-            if (int e = launch_colsum(t->slabs, dW, S, Kin * Nout, t->slabs + (int64_t)S * Kin * Nout, 0, s)) return e;
+        const int nslabs = S + (R ? 1 : 0);
+        W2V2_REQUIRE(nslabs == 1 || (int64_t)(nslabs + 1) * Kin * Nout <= t->slab_floats, "weight_grad: slab scratch too small");
+        float* dst = nslabs == 1 ? dW : t->slabs;
+        const int Kp = S ? Mq / S : 0;
+        if (S) {
+            if (direct) {
+                GemmShadows x;
+                x.transA = true;
+                if (int e = launch_gemm_bf16_x(m->prof, A, Kin, (int64_t)Kp * Kin, dY, Nout, (int64_t)Kp * Nout, dst, Nout,
+                                               (int64_t)Kin * Nout, nullptr, nullptr, Kin, Nout, Kp, S, 0, x, s))
+                    return e;
+            } else {
+                if (int e = launch_transpose(A, t->at, Mq, Kin, 1, s)) return e;          // at = (Kin, Mq)
+                if (int e = launch_gemm_ex(m->prof, t->at, Mq, S == 1 ? 0 : Kp, dY, Nout, S == 1 ? 0 : (int64_t)Kp * Nout, dst, Nout,
+                                           (int64_t)Kin * Nout, nullptr, nullptr, Kin, Nout, Kp, S, 0, s))
+                    return e;
+            }
         }
+        if (R) {                                 // leftover rows [Mq, M): transposed copy (Kin, R), guarded kernel, slab S
+            float* atr = t->at + (int64_t)Kin * Mq;
+            if (int e = launch_transpose(A + (int64_t)Mq * Kin, atr, R, Kin, 1, s)) return e;
+            if (int e = launch_gemm_ex(m->prof, atr, R, 0, dY + (int64_t)Mq * Nout, Nout, 0, dst + (int64_t)S * Kin * Nout, Nout, 0,
+                                       nullptr, nullptr, Kin, Nout, R, 1, 0, s))
+                return e;
+        }
+        // sum the slabs (rows = nslabs, cols = Kin * Nout); the one-chunk partial scratch lives behind the slabs
+        if (nslabs > 1)
+            if (int e = launch_colsum(t->slabs, dW, nslabs, Kin * Nout, t->slabs + (int64_t)nslabs * Kin * Nout, 0, s)) return e;
     }
     if (db)
         if (int e = launch_colsum(dY, db, M, Nout, t->red_ws, 0, s)) return e;

@@ -285,14 +285,16 @@ def test_gradients_match_autograd_base_dims(env):
     print("worst relative gradient error (base dims)", worst)
 
 
-def test_bf16_precision_training_step(env):
+@pytest.mark.parametrize("L,frames", [(20560, 64), (24080, 75)])
+def test_bf16_precision_training_step(env, L, frames):
     """bf16 fine-tune arithmetic (BASELINE configs 3 / 5): training-mode logits equal the torch oracle with
     bf16-rounded Dense operands; gradients agree at a bf16-sized tolerance (the build also rounds dY inside its
-    backward GEMMs, autograd's straight-through rounding does not)."""
+    backward GEMMs, autograd's straight-through rounding does not).
+    T = 64: B T = 128 rows, the weight-gradient GEMMs take the split-K, transposed-A path with two 64-row slabs.
+    T = 75: B T = 150 = 2 x 64 + 22: the same plus the leftover-row slab (what T = 1499 at 480000 samples needs)."""
     import wav2vec2
-    L = 20560               # T = 64 frames: B T = 128 rows, so the weight-gradient GEMMs take the split-K, transposed-A path
     m, cfg, w = build("base_sample_padded", L)
-    assert cfg.num_frames(L) == 64
+    assert cfg.num_frames(L) == frames
     m.set_precision("bf16")
     x = V.hash_normal("train/wave16", 2 * L, 8).reshape(2, L)
     labels = np.array([[5, 9, 9, 11, 0, 0], [7, 6, 0, 0, 0, 0]], np.int32)
