@@ -234,19 +234,26 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
         // B T = 23984): the first Mq = kq floor(M / kq) rows go through the fast path in S equal slabs, S a divisor of
         // Mq / kq, and the R = M - Mq < kq leftover rows form one more slab on the guarded kernel (0.2 % of the work).
         // (Before this, such an M fell back to ONE guarded GEMM over all rows: 256 tiles, K = 23984.)
-        const int64_t units = M / kq;
-        const int Mq = (int)(units * kq), R = M - Mq;
         const int64_t tiles = (int64_t)((Kin + 127) / 128) * ((Nout + 127) / 128);
         // slabs cost a reduction pass each: the fast bf16 GEMM is happy with ~2 blocks per slot (61.5 vs 62.1 ms per step),
         // the fp32 one wants ~4 to balance its long tiles (183.8 vs 189.4 ms)
         const int64_t max_blocks = direct ? 1024 : 2048;
-        int S = units > 0 ? 1 : 0;
-        for (int cand = 32; cand >= 2; --cand)
-            if (units > 0 && units % cand == 0 && tiles * cand <= max_blocks &&
-                (int64_t)(cand + 2) * Kin * Nout <= t->slab_floats) {
-                S = cand;
-                break;
-            }
+        int cap = 32;                                                   // most slabs worth having / that fit the scratch
+        while (cap > 1 && (tiles * cap > max_blocks || (int64_t)(cap + 2) * Kin * Nout > t->slab_floats)) --cap;
+        // S must divide the number of kq-row units; if M / kq has no useful divisor (a prime, say), give up to 15 more
+        // units to the leftover slab until one appears
+        const int64_t units0 = M / kq;
+        int64_t units = units0;
+        int S = units0 > 0 ? 1 : 0;
+        for (int drop = 0; drop < 16 && units0 - drop > 0; ++drop) {
+            const int64_t u = units0 - drop;
+            int d = 1;
+            for (int cand = cap; cand >= 2; --cand)
+                if (u % cand == 0) { d = cand; break; }
+            if (d > S) { S = d; units = u; }
+            if (2 * d >= cap) break;                                    // good enough: stop giving rows away
+        }
+        const int Mq = (int)(units * kq), R = M - Mq;
         const int nslabs = S + (R ? 1 : 0);
         W2V2_REQUIRE(nslabs == 1 || (int64_t)(nslabs + 1) * Kin * Nout <= t->slab_floats, "weight_grad: slab scratch too small");
         float* dst = nslabs == 1 ? dW : t->slabs;

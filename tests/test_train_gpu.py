@@ -450,3 +450,30 @@ def test_gradient_buckets_tile_the_flat_buffer_and_overlap_path_is_exact(env):
         if created:
             dist.destroy_process_group()
     assert np.array_equal(lm, tr.gradient("lm_head/kernel"))
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_weight_gradient_slabs_with_awkward_row_counts(env, precision):
+    """B T = 1190 rows: 37 units of 32 (fp32) / 18 of 64 plus 38 rows (bf16).  37 is prime, so the weight-gradient GEMMs
+    hand one unit to the leftover slab and split the other 36 into equal slabs; either way every row must be counted once.
+    fp32 against torch autograd at the usual tolerance; the bf16 run against the fp32 run at a bf16-sized one."""
+    import wav2vec2
+    L = 190640
+    m, cfg, w = build("tiny_base", L)
+    assert cfg.num_frames(L) == 595
+    x = V.hash_normal("train/wave_long", 2 * L, 8).reshape(2, L)
+    labels = np.zeros((2, 40), np.int32)
+    labels[0, :30] = 1 + np.arange(30) % 31
+    labels[1, :17] = 3 + np.arange(17) % 20
+    loss_fn = wav2vec2.CTCLoss(cfg, x.shape, division_factor=2)
+    tr = wav2vec2.Trainer(m, loss_fn, dropout=0.0, apply_spec_augment=False, seed=3)
+    m.set_precision(precision)
+    logits = tr.forward(x, step_seed=5)
+    nll, dlog = loss_fn.per_sample(labels, logits, with_grad=True)
+    tr.backward(dlog)
+    loss, ref_nll, ref_logits, ref_grads = TT.loss_and_grads(cfg, w, x, labels, p=0.0, seed=5, division_factor=2)
+    if precision == "fp32":
+        assert H.max_err(logits.cpu().numpy(), ref_logits) < 5e-5
+        grads_close(tr, ref_grads, rtol=5e-4)
+    else:
+        grads_close(tr, ref_grads, rtol=8e-2)
