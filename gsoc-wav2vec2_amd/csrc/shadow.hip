@@ -33,7 +33,60 @@ __global__ __launch_bounds__(256) void transpose_to_bf16_kernel(const float* __r
     }
 }
 
+// q | k | v packing of one layer's attention projections: three (H, H) kernels -> one (H, 3H), three (H) biases -> (3H)
+// (and the reverse for their gradients).  One launch per layer instead of three strided + three linear copies.
+struct QkvPtrs {
+    float* packed_w;    // (H, 3H)
+    float* packed_b;    // (3H)
+    float* w[3];        // (H, H) each; null = skip (frozen variable on the unpack side)
+    float* b[3];        // (H)
+    int H;
+};
+
+template <bool PACK>
+__global__ __launch_bounds__(256) void qkv_pack_kernel(QkvPtrs a) {
+    const int j = blockIdx.y, H = a.H, hv = H >> 2;
+    float* w = a.w[j];
+    if (w) {
+        const int64_t n4 = (int64_t)H * hv;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+            const int64_t r = i / hv, c = (i % hv) * 4;
+            float4* one = reinterpret_cast<float4*>(w + r * H + c);
+            float4* all = reinterpret_cast<float4*>(a.packed_w + r * 3 * H + (int64_t)j * H + c);
+            if (PACK) *all = *one; else *one = *all;
+        }
+    }
+    float* b = a.b[j];
+    if (b && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < H; i += 256) {
+            if (PACK) a.packed_b[j * H + i] = b[i]; else b[i] = a.packed_b[j * H + i];
+        }
+}
+
 }  // namespace
+
+static int launch_qkv(bool pack, float* packed_w, float* packed_b, float* const w[3], float* const b[3], int H, hipStream_t s) {
+    W2V2_REQUIRE(packed_w && packed_b && H > 0 && H % 4 == 0, "qkv_pack: bad argument");
+    QkvPtrs a;
+    a.packed_w = packed_w; a.packed_b = packed_b; a.H = H;
+    uintptr_t bits = reinterpret_cast<uintptr_t>(packed_w);
+    for (int j = 0; j < 3; ++j) { a.w[j] = w[j]; a.b[j] = b[j]; bits |= reinterpret_cast<uintptr_t>(w[j]); }
+    W2V2_REQUIRE((bits & 15) == 0, "qkv_pack: unaligned buffer");
+    const int blocks = (int)(((int64_t)H * H / 4 + 255) / 256);
+    if (pack) hipLaunchKernelGGL(qkv_pack_kernel<true>, dim3(blocks < 256 ? blocks : 256, 3), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(qkv_pack_kernel<false>, dim3(blocks < 256 ? blocks : 256, 3), dim3(256), 0, s, a);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+int launch_qkv_pack(float* packed_w, float* packed_b, const float* const w[3], const float* const b[3], int H, hipStream_t s) {
+    float* wn[3] = {const_cast<float*>(w[0]), const_cast<float*>(w[1]), const_cast<float*>(w[2])};
+    float* bn[3] = {const_cast<float*>(b[0]), const_cast<float*>(b[1]), const_cast<float*>(b[2])};
+    W2V2_REQUIRE(wn[0] && wn[1] && wn[2] && bn[0] && bn[1] && bn[2], "qkv_pack: null source");
+    return launch_qkv(true, packed_w, packed_b, wn, bn, H, s);
+}
+int launch_qkv_unpack(const float* packed_w, const float* packed_b, float* const w[3], float* const b[3], int H, hipStream_t s) {
+    return launch_qkv(false, const_cast<float*>(packed_w), const_cast<float*>(packed_b), w, b, H, s);
+}
 
 int launch_to_bf16(const float* x, uint16_t* y, int64_t n, hipStream_t s) {
     W2V2_REQUIRE(x && y && n > 0, "to_bf16: bad argument");

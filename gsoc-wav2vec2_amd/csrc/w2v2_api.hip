@@ -452,12 +452,20 @@ int w2v2_finalize(w2v2_model* m, void* stream) {
     for (int i = 0; i < c.num_layers; ++i) {
         const std::string b = "encoder/layers/" + std::to_string(i) + "/attention/";
         const char* names[3] = {"q_proj", "k_proj", "v_proj"};
+        const float* wj[3];
+        const float* bj[3];
         for (int j = 0; j < 3; ++j) {
-            W2V2_HIP_CHECK(hipMemcpy2DAsync(m->qkv_w[i] + j * H, (size_t)3 * H * sizeof(float),
-                                            m->P(b + names[j] + "/kernel"), (size_t)H * sizeof(float),
-                                            (size_t)H * sizeof(float), (size_t)H, hipMemcpyDeviceToDevice, s));
-            W2V2_HIP_CHECK(hipMemcpyAsync(m->qkv_b[i] + j * H, m->P(b + names[j] + "/bias"),
-                                          (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
+            wj[j] = m->P(b + names[j] + "/kernel");
+            bj[j] = m->P(b + names[j] + "/bias");
+        }
+        if (H % 4 == 0) {
+            if (int e = launch_qkv_pack(m->qkv_w[i], m->qkv_b[i], wj, bj, H, s)) return e;
+        } else {
+            for (int j = 0; j < 3; ++j) {
+                W2V2_HIP_CHECK(hipMemcpy2DAsync(m->qkv_w[i] + j * H, (size_t)3 * H * sizeof(float), wj[j], (size_t)H * sizeof(float),
+                                                (size_t)H * sizeof(float), (size_t)H, hipMemcpyDeviceToDevice, s));
+                W2V2_HIP_CHECK(hipMemcpyAsync(m->qkv_b[i] + j * H, bj[j], (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
+            }
         }
     }
     m->finalized = true;

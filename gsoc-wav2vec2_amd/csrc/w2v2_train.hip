@@ -574,6 +574,15 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         float* dbqkv = dWqkv + (int64_t)3 * H * H;
         if (int e = weight_grad(m, attn_in, t->g3h, (int)BT, H, 3 * H, dWqkv, dbqkv, s)) return e;
         const char* names[3] = {"q_proj", "k_proj", "v_proj"};
+        if (H % 4 == 0) {
+            float* gw3[3];
+            float* gb3[3];
+            for (int j = 0; j < 3; ++j) {
+                gw3[j] = G(b + "/attention/" + names[j] + "/kernel");
+                gb3[j] = G(b + "/attention/" + names[j] + "/bias");
+            }
+            return launch_qkv_unpack(dWqkv, dbqkv, gw3, gb3, H, s);
+        }
         for (int j = 0; j < 3; ++j) {
             float* gw = G(b + "/attention/" + names[j] + "/kernel");
             float* gb = G(b + "/attention/" + names[j] + "/bias");
