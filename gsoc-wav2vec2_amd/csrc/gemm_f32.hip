@@ -506,14 +506,16 @@ int launch_gemm_ex(Profiler* prof, const float* A, int64_t lda, int64_t strideA,
         const int64_t tiles128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * nbatch;
         if (fast && tiles128 < 384) cfg = 16;
         // Tail fill.  512 blocks of the 128x128 kernel are resident (2 per CU); T tiles whose last, partial round fills at
-        // most half of those slots (N = 768 at B = 32: 1152 = 2 x 512 + 128) leave most CUs idle for one whole tile time.
+        // most a quarter of those slots (N = 768 at B = 32: 1152 = 2 x 512 + 128) leave most CUs idle for one whole tile time.
+        // (A half-full last round is better left alone: large-robust at B = 16 has 768 = 512 + 256 tiles for N = 1024,
+        // a third of the work would move to the slower 64x64 kernel, 82.3 vs 80.5 ms per forward.)
         // The rows of that partial round are computed with 64x64 tiles instead (4x the blocks, a quarter of the time each).
         // Every output element still sums its K products in the same order, so results do not depend on the tiling
         // (a row's value is independent of its position in the batch: test_linearity_of_lm_head_at_full_size).
         static int tail_knob = -1;
         if (tail_knob < 0) { const char* e = getenv("W2V2_GEMM_TAIL"); tail_knob = e ? atoi(e) : 1; }     // tuning knob
         const int64_t tn = (N + 127) / 128, S = 512, r = tiles128 % S;
-        if (tail_knob && fast && cfg == 7 && nbatch == 1 && tiles128 > S && r != 0 && 2 * r <= S) {
+        if (tail_knob && fast && cfg == 7 && nbatch == 1 && tiles128 > S && r != 0 && 4 * r <= S) {
             const int64_t main_rows = ((tiles128 - r) / tn) * 128;
             if (main_rows > 0 && main_rows < M) {
                 GemmArgs h = g;
