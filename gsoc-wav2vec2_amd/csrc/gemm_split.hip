@@ -11,16 +11,20 @@
 // tests/test_ops_gpu.py measures the error against fp64 next to the native fp32 MFMA kernel's (same order of magnitude;
 // the model-level logits keep the fp32 path's distance to the fp64 reference).
 //
-// Dataflow per 128 x 256 x 32 tile step (8 waves, each a 64 x 64 block of 32x32 accumulators):
-//   * B (a weight, constant across calls) is pre-split once into three (N, K) bf16 planes (launch_split_weight);
-//     the kernel copies its 3 x 256 x 32 slab HBM/L2 -> LDS with global_load_lds_dwordx4 (no registers, no VALU),
-//   * A (an activation, fp32 in HBM) is loaded as float4, split in registers (~5.5 VALU ops per element, issued in
-//     the shadow of the MFMAs of the other wave on the SIMD) and written to three LDS planes,
-//   * 2 k16 sub-steps: 12 ds_read_b128 feed 24 MFMAs per wave.
-// LDS rows are 64 bytes (32 bf16); the 16-byte slot index is XOR-ed with (row >> 2) & 3, which makes the fragment
-// reads (16 consecutive rows x one slot) and the A stores (8 lanes per row) bank-conflict free; the DMA applies
-// the same XOR on its per-lane source address because its LDS destination is lane-linear.
-// LDS: 2 stages x (3 x 8 KiB + 3 x 16 KiB) = 144 KiB, one 512-thread block per CU.
+// Dataflow per 128 x 256 x 16 tile step (8 waves, each a 64 x 64 block of 32x32 accumulators; BK = 16 is the default,
+// a BK = 32 instantiation is kept behind W2V2_SPLIT_BK for comparison):
+//   * B (a weight, constant across calls) is pre-split once into three bf16 planes stored as this kernel's LDS images,
+//     [K / BK][plane][N][BK] with the slot XOR already applied (launch_split_weight); each step's 3 x 256 x 16 slab is
+//     24 KiB of consecutive memory that global_load_lds_dwordx4 copies HBM/L2 -> LDS with linear addresses (no registers,
+//     no VALU, every cache line used once),
+//   * A (an activation, fp32 in HBM) is loaded as float4, split in registers (11 VALU ops per 4 elements) and written
+//     to three LDS planes,
+//   * 12 ds_read_b128 feed 24 MFMAs per wave and k16 step.
+// LDS rows are 2 BK bytes; the 16-byte slot index is XOR-ed with row bits ((row >> 3) & 1 at BK = 16, (row >> 2) & 3 at
+// BK = 32), which makes the fragment reads and the A stores bank-conflict free (SQ_LDS_BANK_CONFLICT = 0).
+// LDS: 2 stages x 3 x (128 + 256) x 32 B = 72 KiB, two 512-thread blocks per CU (4 waves per SIMD, <= 128 VGPRs).
+// The staging of the next step is threaded between the MFMA groups (see `step` below); results do not depend on the
+// tiling: every output element sums its K products in the same order.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
