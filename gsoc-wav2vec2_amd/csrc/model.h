@@ -53,9 +53,9 @@ struct w2v2_model {
     uint16_t *pos_w16 = nullptr, *pos_pack16 = nullptr;
     bool pos16_valid = false;
     // precision mode 2 (gemm_split.hip): three (N, K) bf16 planes per GEMM weight, built on first use, rebuilt after finalize
-    std::unordered_map<const float*, uint16_t*> w48;
-    std::vector<void*> w48_allocs;
-    bool w48_valid = false;
+    struct SplitPlanes { uint16_t* p = nullptr; int64_t elems = 0; uint64_t epoch = 0; };
+    std::unordered_map<const float*, SplitPlanes> w48;     // keyed by the fp32 matrix (a variable, or a transposed copy)
+    uint64_t w48_epoch = 1;                                 // bumped whenever the variables change: entries re-split lazily
     w2v2::Profiler* prof = nullptr;
     struct TrainState* train = nullptr;      // owned by w2v2_train.hip (null until the first training call)
 
@@ -72,6 +72,10 @@ int w2v2_ensure_shadows(w2v2_model* m, int B, int T, hipStream_t s);
 bool w2v2_pos_conv_bf16_ok(const w2v2_model* m);                          // precision 1 and a supported group shape
 int w2v2_ensure_pos16(w2v2_model* m, int B, int T, hipStream_t s);       // kernel shadow + pack scratch     // allocate activation shadows, (re)build weight shadows
 int w2v2_ensure_workspace(w2v2_model* m, int B, int64_t L);
+// precision mode 2: the LDS-image bf16 planes of the (K, N) fp32 matrix `W` (built / refreshed on demand; gemm_split.hip)
+int w2v2_split_planes(w2v2_model* m, const float* W, int K, int N, hipStream_t s, const uint16_t** planes);
+// whether GEMM (M, N, K) x nbatch with this A should take the split kernel in the model's current precision mode
+bool w2v2_use_split_gemm(const w2v2_model* m, const float* A, int64_t lda, int64_t strideA, int64_t ldb, int M, int N, int K, int nbatch);
 // implemented in w2v2_train.hip
 void w2v2_train_destroy(w2v2_model* m);
 void w2v2_train_invalidate(w2v2_model* m);

@@ -310,6 +310,31 @@ int w2v2_ensure_shadows(w2v2_model* m, int B, int T, hipStream_t s) {
     return W2V2_OK;
 }
 
+bool w2v2_use_split_gemm(const w2v2_model* m, const float* A, int64_t lda, int64_t strideA, int64_t ldb, int M, int N, int K, int nbatch) {
+    if (m->precision != W2V2_PRECISION_BF16X3 || ldb != N || N % 256 != 0) return false;
+    // (below ~half a wave of 128 x 256 tiles the fp32 path's small tiles and split-K serve a single utterance better)
+    const int64_t split_tiles = (int64_t)((M + 127) / 128) * (N / 256) * nbatch;
+    return split_tiles >= 128 && gemm_split_supported(A, lda, strideA, M, N, K);
+}
+
+int w2v2_split_planes(w2v2_model* m, const float* W, int K, int N, hipStream_t s, const uint16_t** planes) {
+    w2v2_model::SplitPlanes& e = m->w48[W];
+    const int64_t need = 3 * (int64_t)K * N;
+    if (!e.p || e.elems != need) {
+        if (e.p) W2V2_HIP_CHECK(hipFree(e.p));
+        e.p = nullptr;
+        W2V2_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e.p), (size_t)need * sizeof(uint16_t)));
+        e.elems = need;
+        e.epoch = 0;
+    }
+    if (e.epoch != m->w48_epoch) {
+        if (int err = launch_split_weight(W, e.p, K, N, s)) return err;
+        e.epoch = m->w48_epoch;
+    }
+    *planes = e.p;
+    return W2V2_OK;
+}
+
 bool w2v2_pos_conv_bf16_ok(const w2v2_model* m) {
     const int cg = m->cfg.hidden_size / m->cfg.num_conv_pos_embedding_groups;
     return m->precision == 1 && cg % 8 == 0 && cg <= 64 && (m->cfg.num_conv_pos_embeddings * cg) % 64 == 0;
@@ -378,7 +403,8 @@ void w2v2_destroy(w2v2_model* m) {
     for (auto p : m->qkv_w) (void)hipFree(p);
     for (auto p : m->qkv_b) (void)hipFree(p);
     for (void* p : m->w16_allocs) (void)hipFree(p);
-    for (void* p : m->w48_allocs) (void)hipFree(p);
+    for (auto& kv : m->w48)
+        if (kv.second.p) (void)hipFree(kv.second.p);
     if (m->pos_w16) (void)hipFree(m->pos_w16);
     profiler_destroy(m->prof);
     delete m;
@@ -470,7 +496,7 @@ int w2v2_finalize(w2v2_model* m, void* stream) {
     }
     m->finalized = true;
     m->w16_valid = false;      // the bf16 weight shadows (if any) follow the variables
-    m->w48_valid = false;
+    ++m->w48_epoch;
     m->pos16_valid = false;
     return W2V2_OK;
 }
@@ -526,29 +552,12 @@ int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const i
     auto W16 = [&](const float* w) -> const uint16_t* { return sh ? m->w16[w] : nullptr; };
     // Precision mode 2: fp32 operands, each an exact sum of three bf16 terms, six MFMA products (gemm_split.hip).  The
     // weight planes are built on first use; shapes the split kernel does not take (lm_head: N = 32) stay on the fp32 MFMA.
-    if (m->precision == W2V2_PRECISION_BF16X3 && !m->w48_valid) {
-        for (void* p : m->w48_allocs) (void)hipFree(p);       // planes of the previous variables
-        m->w48_allocs.clear();
-        m->w48.clear();
-        m->w48_valid = true;
-    }
-    auto split_planes = [&](const float* Bw, int K, int N, const uint16_t** out) -> int {
-        uint16_t*& dst = m->w48[Bw];
-        if (!dst) {
-            if (int e = sh_alloc(m->w48_allocs, &dst, 3 * (int64_t)K * N)) return e;
-            if (int e = launch_split_weight(Bw, dst, K, N, s)) return e;
-        }
-        *out = dst;
-        return W2V2_OK;
-    };
     auto gemm = [&](const float* A, const uint16_t* A16, int64_t lda, int64_t strideA, const float* Bw, int64_t ldb, float* Cc,
                     uint16_t* C16, int64_t ldc, int64_t strideC, const float* bias, const float* res, int M, int N, int K,
                     int nbatch, int act_) -> int {
-        // (below ~half a wave of 128 x 256 tiles the fp32 path's small tiles and split-K serve a single utterance better)
-        const int64_t split_tiles = (int64_t)((M + 127) / 128) * (N / 256) * nbatch;
-        if (m->precision == W2V2_PRECISION_BF16X3 && ldb == N && split_tiles >= 128 && gemm_split_supported(A, lda, strideA, M, N, K)) {
+        if (w2v2_use_split_gemm(m, A, lda, strideA, ldb, M, N, K, nbatch)) {
             const uint16_t* planes = nullptr;
-            if (int e = split_planes(Bw, K, N, &planes)) return e;
+            if (int e = w2v2_split_planes(m, Bw, K, N, s, &planes)) return e;
             return launch_gemm_split(pf, A, lda, strideA, planes, Cc, ldc, strideC, bias, res, M, N, K, nbatch, act_, s);
         }
         if (!sh) return launch_gemm(pf, A, lda, strideA, Bw, ldb, Cc, ldc, strideC, bias, res, M, N, K, nbatch, act_, s);

@@ -347,6 +347,11 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
     auto gemm = [&](const float* A, const uint16_t* A16, int64_t lda, int64_t strideA, const float* Bw, int64_t ldb, float* Cc,
                     uint16_t* C16, int64_t ldc, int64_t strideC, const float* bias, const float* res, int M, int N, int K,
                     int nbatch, int act_) -> int {
+        if (w2v2_use_split_gemm(m, A, lda, strideA, ldb, M, N, K, nbatch)) {      // precision mode 2 (gemm_split.hip)
+            const uint16_t* planes = nullptr;
+            if (int e = w2v2_split_planes(m, Bw, K, N, s, &planes)) return e;
+            return launch_gemm_split(pf, A, lda, strideA, planes, Cc, ldc, strideC, bias, res, M, N, K, nbatch, act_, s);
+        }
         if (!sh) return launch_gemm(pf, A, lda, strideA, Bw, ldb, Cc, ldc, strideC, bias, res, M, N, K, nbatch, act_, s);
         GemmShadows x;
         x.A16 = A16; x.B16 = m->w16[Bw]; x.C16 = C16; x.ldb16 = K;
@@ -510,6 +515,11 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
                 x.ldb16 = K;
                 return launch_gemm_bf16_x(m->prof, A, lda, 0, WT, N, 0, Cc, ldc, 0, nullptr, res, M, N, K, 1, 0, x, st);
             }
+        }
+        if (w2v2_use_split_gemm(m, A, lda, 0, N, M, N, K, 1)) {                   // precision mode 2: planes of the transposed copy
+            const uint16_t* planes = nullptr;
+            if (int e = w2v2_split_planes(m, WT, K, N, st, &planes)) return e;
+            return launch_gemm_split(m->prof, A, lda, 0, planes, Cc, ldc, 0, nullptr, res, M, N, K, 1, 0, st);
         }
         return launch_gemm(m->prof, A, lda, 0, WT, N, Cc, ldc, 0, nullptr, res, M, N, K, 1, 0, st);
     };

@@ -206,8 +206,9 @@ class TFKerasModel:
         """"fp32" (default: the reference's arithmetic) or "bf16" (Conv1D layers 1..6 and every Dense take
         bf16-rounded operands with fp32 accumulation, forward and backward -- the mixed-precision policy the
         bf16 fine-tune configurations ask for; variables, activations and optimizer state stay fp32), or "bf16x3"
-        (inference forward: fp32 operands split exactly into three bf16 terms, six bf16 MFMA products per fp32
-        product, fp32 accumulation -- fp32-level results at the bf16 matrix cores' rate; csrc/gemm_split.hip)."""
+        (fp32 operands split exactly into three bf16 terms, six bf16 MFMA products per fp32 product, fp32
+        accumulation -- fp32-level results at the bf16 matrix cores' rate; forward GEMMs and attention, and the
+        data-gradient GEMMs of the training step; csrc/gemm_split.hip, attention_split.hip)."""
         if precision not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(set(self.PRECISIONS))}, got {precision!r}")
         N.check(self._lib.w2v2_set_precision(self._handle, self.PRECISIONS[precision]), "w2v2_set_precision")

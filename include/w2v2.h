@@ -112,13 +112,14 @@ int64_t w2v2_num_frames(const w2v2_model* m, int64_t num_samples);
  *                        Attention (head size 64) takes bf16 q, k, v and probabilities on the same pipe with
  *                        fp32 scores / softmax / accumulation; the grouped positional conv runs as one batched
  *                        GEMM with bf16-rounded input and kernel.
- *   W2V2_PRECISION_BF16X3  fp32 results from the bf16 matrix cores (inference forward): every fp32 operand is written
+ *   W2V2_PRECISION_BF16X3  fp32 results from the bf16 matrix cores (forward, and the data-gradient GEMMs of the
+ *                        training step): every fp32 operand is written
  *                        exactly as a sum of three bf16 terms and each fp32 product is evaluated as the six bf16 x bf16
  *                        products of order <= 2, accumulated in fp32 (the dropped terms are < 2^-23 of the product, below
  *                        the rounding of an fp32 running sum).  Same fp32 inputs, outputs and error level as
  *                        W2V2_PRECISION_FP32 -- logits within the same 1e-3 of the reference -- at the bf16 pipe's rate.
  *                        Attention (head size 64) takes the same route; shapes the split kernels do not take, the
- *                        positional conv and training stay on the fp32 MFMA.
+ *                        positional conv, the weight-gradient GEMMs and the training attention stay on the fp32 MFMA.
  * Everything else (conv0 + GroupNorm, LayerNorm, softmax, CTC) is fp32 in all modes. */
 #define W2V2_PRECISION_FP32 0
 #define W2V2_PRECISION_BF16 1

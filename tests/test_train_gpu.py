@@ -477,3 +477,42 @@ def test_weight_gradient_slabs_with_awkward_row_counts(env, precision):
         grads_close(tr, ref_grads, rtol=5e-4)
     else:
         grads_close(tr, ref_grads, rtol=8e-2)
+
+
+def test_bf16x3_training_matches_fp32_path(env):
+    """Precision mode bf16x3 in the training step: the forward GEMMs and the data-gradient GEMMs (planes of the transposed
+    weight copies) take the three-term split kernel once they have >= 128 tiles, i.e. only at real batch sizes -- too large
+    for the autograd oracle.  So the reference here is the library's own fp32 path (pinned to torch autograd by the tests
+    above) on the same input, masks and seed, B = 8 x 246000: logits within 1e-4, gradients within 5e-4 of max|g|."""
+    import wav2vec2
+    B, L = 8, 246000
+    cfg = H.case_config("base_sample_padded")
+    w = H.case_weights("base_sample_padded")
+    x = V.hash_normal("train/wave_big", B * L, 8).reshape(B, L)
+    rs = np.random.RandomState(3)
+    labels = np.zeros((B, 64), np.int32)
+    for b in range(B):
+        n = rs.randint(20, 60)
+        labels[b, :n] = rs.randint(1, 32, size=n)
+    names = ("lm_head/kernel", "encoder/layers/11/feed_forward/output_dense/kernel", "encoder/layers/5/feed_forward/intermediate_dense/kernel",
+             "encoder/layers/5/attention/q_proj/kernel", "encoder/layers/0/attention/out_proj/kernel",
+             "encoder/layers/0/layer_norm/gamma", "encoder/pos_conv_embed/conv/weight_v", "feature_projection/projection/kernel")
+    res = {}
+    for prec in ("fp32", "bf16x3"):
+        m = wav2vec2.Wav2Vec2ForCTC(cfg, input_shape=(B, L))
+        m.set_weights(w)
+        m.freeze_feature_extractor()
+        m.set_precision(prec)
+        loss_fn = wav2vec2.CTCLoss(cfg, x.shape, division_factor=B)
+        tr = wav2vec2.Trainer(m, loss_fn, dropout=0.1, apply_spec_augment=False, seed=1)
+        logits = tr.forward(x, step_seed=11)
+        _, dlog = loss_fn.per_sample(labels, logits, with_grad=True)
+        tr.backward(dlog)
+        res[prec] = dict(logits=logits.cpu().numpy(), grads={n: tr.gradient(n) for n in names})
+        del tr, m
+    assert not np.array_equal(res["fp32"]["logits"], res["bf16x3"]["logits"])       # the split kernels did run
+    assert H.max_err(res["fp32"]["logits"], res["bf16x3"]["logits"]) < 1e-4
+    for n in names:
+        a, b = res["fp32"]["grads"][n], res["bf16x3"]["grads"][n]
+        assert np.abs(a).max() > 0
+        assert np.abs(a - b).max() <= 5e-4 * np.abs(a).max(), (n, np.abs(a - b).max(), np.abs(a).max())
