@@ -263,8 +263,6 @@ __global__ void frame_len_finish_kernel(int32_t* __restrict__ out, int B, LenArg
     out[b] = (int32_t)(n < 0 ? 0 : n);
 }
 
-double* g_alpha_ws = nullptr;
-size_t g_alpha_bytes = 0;
 
 }  // namespace
 
@@ -282,15 +280,12 @@ int launch_ctc(Profiler* prof, const float* logits, int B, int T, int V, const i
     if (grad) {
         const size_t per = (size_t)B * T * a.S_max;
         const size_t need = (2 * per + (size_t)B * T) * sizeof(double);
-        if (need > g_alpha_bytes) {            // grow-only scratch owned by the library
-            if (g_alpha_ws) W2V2_HIP_CHECK(hipFree(g_alpha_ws));
-            g_alpha_ws = nullptr; g_alpha_bytes = 0;
-            W2V2_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g_alpha_ws), need));
-            g_alpha_bytes = need;
-        }
-        a.alpha_ws = g_alpha_ws;
-        a.beta_ws = g_alpha_ws + per;
-        a.lse_ws = g_alpha_ws + 2 * per;
+        void* raw = nullptr;                    // alpha | beta | lse, fp64: per-stream scratch owned by the library
+        if (int e = stream_scratch(SCRATCH_CTC, s, need, &raw)) return e;
+        double* ws = reinterpret_cast<double*>(raw);
+        a.alpha_ws = ws;
+        a.beta_ws = ws + per;
+        a.lse_ws = ws + 2 * per;
     }
     // logits chunk in LDS: the whole utterance if it fits next to the state arrays, else as many frames as do
     const size_t fixed = (size_t)(T + 2 * a.S_max) * sizeof(double) + (size_t)((a.S_max + 3) & ~3) * sizeof(int) + 16;

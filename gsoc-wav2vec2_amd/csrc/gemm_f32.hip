@@ -22,8 +22,6 @@
 // {k, k+4}, {k+1, k+5}, ... within an 8-wide k block.
 #include <stdlib.h>
 
-#include <mutex>
-#include <unordered_map>
 
 #include "common.h"
 #include "gemm_epilogue.h"
@@ -417,25 +415,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
-// Grow-only split-K scratch owned by the library, one buffer per stream: launches on one stream are ordered, so its
-// buffer is never in use by two GEMMs at once; different streams (other models, other host threads) get their own.
-struct StreamScratch { float* p = nullptr; size_t floats = 0; };
-std::mutex g_scratch_mu;
-std::unordered_map<hipStream_t, StreamScratch> g_scratch;
-
-int splitk_scratch(hipStream_t s, size_t need, float** out) {
-    std::lock_guard<std::mutex> lock(g_scratch_mu);
-    StreamScratch& e = g_scratch[s];
-    if (need > e.floats) {
-        if (e.p) W2V2_HIP_CHECK(hipFree(e.p));           // (hipFree waits for the device: no kernel still reads the old one)
-        e.p = nullptr; e.floats = 0;
-        W2V2_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e.p), need * sizeof(float)));
-        e.floats = need;
-    }
-    *out = e.p;
-    return W2V2_OK;
-}
-
 thread_local int tl_precision = 0;
 
 }  // namespace
@@ -486,7 +465,9 @@ int launch_gemm_ex(Profiler* prof, const float* A, int64_t lda, int64_t strideA,
         if (S > 1 && tiles64 <= 256) {
             const size_t need = (size_t)S * M * N;
             float* ws = nullptr;
-            if (int e = splitk_scratch(s, need, &ws)) return e;
+            void* raw = nullptr;
+            if (int e = stream_scratch(SCRATCH_SPLITK, s, need * sizeof(float), &raw)) return e;
+            ws = reinterpret_cast<float*>(raw);
             GemmArgs h = g;
             h.C = ws; h.bias = nullptr; h.residual = nullptr; h.act = 0;
             h.K = K / S; h.strideA = K / S; h.strideB = (int64_t)(K / S) * ldb; h.ldc = N; h.strideC = (int64_t)M * N;

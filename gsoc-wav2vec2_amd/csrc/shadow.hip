@@ -2,6 +2,10 @@
 // operand to on its own, materialised once so the GEMM streams 2 bytes per element instead of 4 and skips the
 // conversion.  Activations get their shadow from the producing kernel (GEMM / LayerNorm / conv0 / attention
 // epilogues); the kernels here serve the weights, which change only when variables are set or the optimizer steps.
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "common.h"
 
 namespace w2v2 {
@@ -86,6 +90,27 @@ int launch_qkv_pack(float* packed_w, float* packed_b, const float* const w[3], c
 }
 int launch_qkv_unpack(const float* packed_w, const float* packed_b, float* const w[3], float* const b[3], int H, hipStream_t s) {
     return launch_qkv(false, const_cast<float*>(packed_w), const_cast<float*>(packed_b), w, b, H, s);
+}
+
+// Grow-only device scratch owned by the library, one buffer per (purpose, stream): launches on one stream are ordered, so
+// a buffer is never in use by two kernels at once, and different streams (other models, other host threads) get their own.
+namespace {
+struct StreamScratch { void* p = nullptr; size_t bytes = 0; };
+std::mutex g_scratch_mu;
+std::map<std::pair<int, hipStream_t>, StreamScratch> g_scratch;
+}  // namespace
+
+int stream_scratch(int slot, hipStream_t s, size_t bytes, void** out) {
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    StreamScratch& e = g_scratch[std::make_pair(slot, s)];
+    if (bytes > e.bytes) {
+        if (e.p) W2V2_HIP_CHECK(hipFree(e.p));           // (hipFree waits for the device: no kernel still uses the old one)
+        e.p = nullptr; e.bytes = 0;
+        W2V2_HIP_CHECK(hipMalloc(&e.p, bytes));
+        e.bytes = bytes;
+    }
+    *out = e.p;
+    return W2V2_OK;
 }
 
 int launch_to_bf16(const float* x, uint16_t* y, int64_t n, hipStream_t s) {
