@@ -237,24 +237,31 @@ def main():
 
     # Beside the headline (never as it): the same workload in precision mode "bf16x3" -- fp32-level results from the bf16
     # matrix cores.  Single-process forward runs of the fp32 configuration only; timed after the headline.
+    def measure_bf16x3(ref_logits):
+        model.set_precision("bf16x3")
+        try:
+            for _ in range(max(1, args.warmup)):
+                out3 = model(x, attention_mask=amask)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                out3 = model(x, attention_mask=amask)
+            torch.cuda.synchronize()
+            e3 = time.perf_counter() - t1
+        finally:
+            model.set_precision("fp32")
+        return {"precision": "bf16x3 (fp32 operands as exact 3 x bf16 sums, 6 bf16 MFMA products per fp32 product, fp32 accumulate)",
+                "value": round(B * L / SAMPLE_RATE * args.steps / e3, 2), "unit": "audio-seconds/s",
+                "ms_per_step": round(1e3 * e3 / args.steps, 3),
+                "max_abs_logit_diff_vs_fp32_path": float((out3 - ref_logits).abs().max()),
+                "note": "opt-in mode, not the headline; logit error vs the fp64 reference equals the fp32 path's (tests/test_model_gpu.py)"}
+
     alt = None
     if world == 1 and args.mode == "forward" and args.precision == "fp32" and not args.no_alt:
-        ref_logits = out
-        model.set_precision("bf16x3")
-        for _ in range(max(1, args.warmup)):
-            out3 = model(x, attention_mask=amask)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            out3 = model(x, attention_mask=amask)
-        torch.cuda.synchronize()
-        e3 = time.perf_counter() - t1
-        alt = {"precision": "bf16x3 (fp32 operands as exact 3 x bf16 sums, 6 bf16 MFMA products per fp32 product, fp32 accumulate)",
-               "value": round(B * L / SAMPLE_RATE * args.steps / e3, 2), "unit": "audio-seconds/s",
-               "ms_per_step": round(1e3 * e3 / args.steps, 3),
-               "max_abs_logit_diff_vs_fp32_path": float((out3 - ref_logits).abs().max()),
-               "note": "opt-in mode, not the headline; logit error vs the fp64 reference equals the fp32 path's (tests/test_model_gpu.py)"}
-        model.set_precision("fp32")
+        try:                                                   # never let the side measurement cost the headline line
+            alt = measure_bf16x3(out)
+        except Exception as exc:                               # noqa: BLE001
+            alt = {"precision": "bf16x3", "error": repr(exc)}
 
     if rank == 0:
         audio_s = world * B * L / SAMPLE_RATE * args.steps
