@@ -321,7 +321,11 @@ def main():
         if args.mode == "train":
             res["final_loss"] = round(float(out), 4)
         if world == 1 and not args.no_cpu_baseline and args.mode == "forward" and args.model == "base" and args.precision == "fp32":
-            res["cpu_baseline"] = cpu_baseline(cfg, weights, L)
+            try:
+                res["cpu_baseline"] = cpu_baseline(cfg, weights, L)
+            except Exception as exc:                           # noqa: BLE001 -- the GPU line must still be printed
+                res["cpu_baseline"] = {"value": None, "unit": "audio-seconds/s", "cores": 0, "kind": "port",
+                                       "sample": f"CPU baseline failed: {exc!r}"}
         print(json.dumps(res), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
