@@ -818,6 +818,20 @@ int w2v2_train_bucket_wait(w2v2_model* m, int32_t k, void* stream) {
     return W2V2_OK;
 }
 
+/* Adam's first / second moment buffers (flat, the gradient buffer's layout) for checkpoint / resume. */
+int w2v2_adam_buffers(w2v2_model* m, float** m_dev, float** v_dev, int64_t* numel) {
+    W2V2_REQUIRE(m && m_dev && v_dev && numel, "adam_buffers: null argument");
+    TrainState* t = m->train;
+    if (!t || !t->adam_m) {
+        set_error("adam_buffers: run a training forward first");
+        return W2V2_ESTATE;
+    }
+    *m_dev = t->adam_m;
+    *v_dev = t->adam_v;
+    *numel = t->gtotal;
+    return W2V2_OK;
+}
+
 int w2v2_grad_buffer(w2v2_model* m, float** dev_ptr, int64_t* numel) {
     W2V2_REQUIRE(m && dev_ptr && numel, "grad_buffer: null argument");
     TrainState* t = m->train;

@@ -63,6 +63,7 @@ PROTOTYPES = {
     "w2v2_train_forward": (C.c_int, [_P, _P, _I32, _I64, _P, _P, _P, C.c_float, C.c_uint64, _P, _P]),
     "w2v2_train_backward": (C.c_int, [_P, _P, _P]),
     "w2v2_grad_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I64)]),
+    "w2v2_adam_buffers": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64)]),
     "w2v2_train_num_buckets": (C.c_int, [_P]),
     "w2v2_train_bucket": (C.c_int, [_P, _I32, C.POINTER(_I64), C.POINTER(_I64)]),
     "w2v2_train_bucket_wait": (C.c_int, [_P, _I32, _P]),

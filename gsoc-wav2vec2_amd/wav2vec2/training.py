@@ -146,6 +146,53 @@ class Trainer:
                                       float(self.epsilon), self.iterations, N.current_stream()), "w2v2_adam_step")
         m._dirty = False          # w2v2_adam_step re-derives the packed / normalised tensors itself
 
+    # -- checkpoint / resume ----------------------------------------------------------------------------
+    def _adam_views(self):
+        import torch
+        m = self.model
+        pm, pv, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        N.check(m._lib.w2v2_adam_buffers(m._handle, C.byref(pm), C.byref(pv), C.byref(n)), "w2v2_adam_buffers")
+        dev = torch.device("cuda", torch.cuda.current_device())
+        return (torch.as_tensor(_DeviceBuffer(pm.value, n.value), device=dev),
+                torch.as_tensor(_DeviceBuffer(pv.value, n.value), device=dev))
+
+    def state_dict(self):
+        """Everything a resumed run needs besides the model's variables (`model.save_weights` / `save_pretrained`): the
+        optimizer step count, Adam's moments, the hyper-parameters and the host RNG that draws spec-augment spans and
+        stochastic-depth decisions.  The reference's per-epoch ModelCheckpoint (training_utils.py:38-45) is the analogue."""
+        state = dict(iterations=int(self.iterations), learning_rate=float(self.learning_rate), beta_1=float(self.beta_1),
+                     beta_2=float(self.beta_2), epsilon=float(self.epsilon), seed=int(self.seed), rng=self._rng.get_state())
+        if self.iterations > 0:
+            am, av = self._adam_views()
+            state["adam_m"], state["adam_v"] = am.cpu().numpy(), av.cpu().numpy()
+        return state
+
+    def load_state_dict(self, state, batch_shape=None):
+        """Inverse of `state_dict`.  The moment buffers live in the model's training state, which is sized at the first
+        training forward: pass `batch_shape=(B, L)` (any shape; it only triggers the allocation) when loading into a
+        trainer that has not run a step yet."""
+        import torch
+        views = None
+        if "adam_m" in state:
+            try:
+                views = self._adam_views()
+            except Exception:
+                if batch_shape is None:
+                    raise
+                B, L = batch_shape                       # allocate the training state (before the host RNG is restored:
+                self.forward(torch.zeros((B, L), device="cuda"), step_seed=0)      # this forward may draw spec-augment spans)
+                views = self._adam_views()
+            if views[0].numel() != state["adam_m"].size:
+                raise ValueError("optimizer state belongs to a different model (moment buffer size mismatch)")
+        self.iterations = int(state["iterations"])
+        for k in ("learning_rate", "beta_1", "beta_2", "epsilon"):
+            setattr(self, k, float(state[k]))
+        self.seed = int(state["seed"])
+        self._rng.set_state(state["rng"])
+        if views is not None:
+            for dst, key in zip(views, ("adam_m", "adam_v")):
+                dst.copy_(torch.from_numpy(np.ascontiguousarray(state[key], np.float32)).to(dst.device))
+
     # -- the step ------------------------------------------------------------------------------------
     def step(self, batch, labels, attention_mask=None):
         logits = self.forward(batch, attention_mask)

@@ -184,6 +184,9 @@ int w2v2_grad_buffer(w2v2_model* m, float** dev_ptr, int64_t* numel);
 int w2v2_train_num_buckets(const w2v2_model* m);
 int w2v2_train_bucket(w2v2_model* m, int32_t k, int64_t* offset, int64_t* numel);
 int w2v2_train_bucket_wait(w2v2_model* m, int32_t k, void* stream);
+/* Adam's moment buffers (device, flat, same layout as the gradient buffer): what a training checkpoint must carry besides
+ * the variables and the step count (the reference's ModelCheckpoint writes a TF checkpoint, training_utils.py:38-45). */
+int w2v2_adam_buffers(w2v2_model* m, float** m_dev, float** v_dev, int64_t* numel);
 int w2v2_get_grad(w2v2_model* m, const char* name, float* host_dst, int64_t numel, void* stream);
 int w2v2_adam_step(w2v2_model* m, float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
 

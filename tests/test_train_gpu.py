@@ -516,3 +516,42 @@ def test_bf16x3_training_matches_fp32_path(env):
         a, b = res["fp32"]["grads"][n], res["bf16x3"]["grads"][n]
         assert np.abs(a).max() > 0
         assert np.abs(a - b).max() <= 5e-4 * np.abs(a).max(), (n, np.abs(a - b).max(), np.abs(a).max())
+
+
+def test_trainer_checkpoint_resume_is_exact(env, tmp_path):
+    """Three optimizer steps in one run == two steps, save (variables + Trainer.state_dict), load into a fresh model and
+    trainer, one more step: bit-identical variables (dropout seeds follow the restored step count, spec-augment spans the
+    restored host RNG, Adam its restored moments)."""
+    import pickle
+    import wav2vec2
+    g = H.golden("tiny_base")
+    x, labels = g["wave"], g["labels"]
+
+    def fresh():
+        m, cfg, w = build("tiny_base", 4000)
+        tr = wav2vec2.Trainer(m, wav2vec2.CTCLoss(cfg, x.shape, division_factor=2), learning_rate=1e-3, dropout=0.1,
+                              apply_spec_augment=True, seed=9)
+        return m, tr
+
+    m1, t1 = fresh()
+    for _ in range(3):
+        t1.step(x, labels)
+    want = m1.get_weights()
+
+    m2, t2 = fresh()
+    for _ in range(2):
+        t2.step(x, labels)
+    m2.save_weights(str(tmp_path / "tf_model.npz"))
+    with open(tmp_path / "trainer.pkl", "wb") as f:
+        pickle.dump(t2.state_dict(), f)
+    del m2, t2
+
+    m3, t3 = fresh()
+    m3.load_weights(str(tmp_path / "tf_model.npz"))
+    with open(tmp_path / "trainer.pkl", "rb") as f:
+        t3.load_state_dict(pickle.load(f), batch_shape=x.shape)
+    assert t3.iterations == 2
+    t3.step(x, labels)
+    got = m3.get_weights()
+    for n in want:
+        assert np.array_equal(want[n], got[n]), n
