@@ -432,9 +432,11 @@ def test_gradient_buckets_tile_the_flat_buffer_and_overlap_path_is_exact(env):
     ref = tr.grad_buffer().clone()
     created = False
     if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29617")
-        dist.init_process_group("nccl", rank=0, world_size=1)
+        import socket
+        with socket.socket() as sock:                         # a free port: no clash with another test process on the box
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
         created = True
     try:
         tr.backward(dlog)                                     # enqueue the backward again ...
