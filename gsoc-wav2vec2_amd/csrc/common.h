@@ -110,6 +110,10 @@ struct GemmShadows {
     int64_t strideB16 = 0, strideC2 = 0, strideBias = 0;
     int64_t strideB2 = 0;        // fp32 B with a two-level batch: B advances with zo * strideB2 + zi * strideB
     bool overlapA = false;       // transposed A whose rows overlap (lda < M): the packed positional-conv input
+    // transposed-A form only: also write the column sums of B over each batch's K rows to colsum[z * strideCS + n]
+    // (dW = X^T dY has the bias gradient 1^T dY for free: dY is in registers while it is staged)
+    float* colsum = nullptr;
+    int64_t strideCS = 0;
 };
 int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
                        int64_t strideB, float* C, int64_t ldc, int64_t strideC, const float* bias,

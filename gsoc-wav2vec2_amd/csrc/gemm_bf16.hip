@@ -52,6 +52,10 @@ struct Gemm16Args {
     // with zo * strideC2 + zi * strideC.  zmod = 0: plain batch (C advances with z * strideC, B16 and bias are shared).
     int zmod;
     int64_t strideB16, strideC2, strideBias, strideB2;
+    // SRC 7 (weight gradient dW = X^T dY): optional column sums of B over this batch's K rows -> colsum[z * strideCS + n]
+    // (the bias gradient: B = dY is already in registers while it is staged, so the sums cost 8 adds per patch column)
+    float* colsum;
+    int64_t strideCS;
 };
 
 // two fp32 -> one dword of two bf16, round to nearest even (gfx950 instruction; no builtin in ROCm 7.2)
@@ -111,12 +115,18 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
                                                  : (int64_t)z * g.strideB);
 
     const int nk = (g.K + BK - 1) / BK;
+    const bool do_colsum = AT && g.colsum != nullptr && tm == 0;      // block-uniform
 
     // ---- global -> register staging.  Every wave-level load is fully coalesced: A as 16 lanes x 16 B per
     // 256-byte row, B as NQ lanes x (4 PN) B per k-row.  The vector L1 (64 B/clk/CU) is the resource this kernel
     // leans on hardest -- 64 KiB of fp32 per 128x128x64 tile step -- so no request may touch a line twice.
     f32x4 ra[NA];
     bvec rb[NB][8];
+    float cs[AT ? NB : 1][PN];        // per-thread partial column sums of B (SRC 7 with g.colsum, row-tile 0 only)
+#pragma unroll
+    for (int i = 0; i < (AT ? NB : 1); ++i)
+#pragma unroll
+        for (int j = 0; j < PN; ++j) cs[i][j] = 0.f;
     int64_t a_off[NA], b_off[NB];
     int a_lds[NA];
 #pragma unroll
@@ -251,6 +261,18 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
             p[0] = pack_bf16(ra[i][0], ra[i][1]);
             p[1] = pack_bf16(ra[i][2], ra[i][3]);
             *reinterpret_cast<u32x2*>(S + a_lds[i]) = p;
+        }
+        if constexpr (AT) {
+            if (do_colsum) {
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+#pragma unroll
+                    for (int j = 0; j < PN; ++j) {
+                        float t4 = (rb[i][0][j] + rb[i][1][j]) + (rb[i][2][j] + rb[i][3][j]);
+                        t4 += (rb[i][4][j] + rb[i][5][j]) + (rb[i][6][j] + rb[i][7][j]);
+                        cs[i][j] += t4;
+                    }
+            }
         }
 #pragma unroll
         for (int i = 0; i < (B16 ? 0 : NB); ++i) {
@@ -402,6 +424,25 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
         compute((nk - 1) & 1);
     }
 
+    if constexpr (AT) {
+        if (do_colsum) {       // fold the 8 k-groups of each column through LDS (fixed order), one value per column and batch
+            __syncthreads();   // every wave is done with the operand images
+            float* red = reinterpret_cast<float*>(smem16);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int q = (tid + i * NT) % NQ, ks = (tid + i * NT) / NQ;
+#pragma unroll
+                for (int j = 0; j < PN; ++j) red[ks * BN + PN * q + j] = cs[i][j];
+            }
+            __syncthreads();
+            if (tid < BN && n0 + tid < g.N) {
+                float t8 = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) t8 += red[ks * BN + tid];
+                g.colsum[(int64_t)z * g.strideCS + n0 + tid] = t8;
+            }
+        }
+    }
     // ---- epilogue (gemm_epilogue.h): bias -> act -> + residual -> fp32 store and / or bf16 shadow ----
     const int zi = g.zmod ? z % g.zmod : z, zo = g.zmod ? z / g.zmod : 0;
     const int64_t tile_off = (int64_t)zo * g.strideC2 + (int64_t)zi * g.strideC + (int64_t)(m0 + wm * WTM) * g.ldc + (n0 + wn * WTN);
@@ -475,6 +516,7 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
     g.M = M; g.N = N; g.K = K; g.act = act;
     g.A16 = x.A16; g.B16 = x.B16; g.C16 = x.C16; g.ldb16 = x.ldb16 ? x.ldb16 : K;
     g.zmod = x.zmod; g.strideB16 = x.strideB16; g.strideC2 = x.strideC2; g.strideBias = x.strideBias; g.strideB2 = x.strideB2;
+    g.colsum = x.transA ? x.colsum : nullptr; g.strideCS = x.strideCS;
     W2V2_REQUIRE(x.zmod >= 0 && (x.zmod == 0 || nbatch % x.zmod == 0), "gemm_bf16: batch %d is not a multiple of the inner batch %d", nbatch, x.zmod);
     const bool kfast = K % BK == 0;
     const bool a32 = A && (lda % 4 == 0) && (strideA % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);

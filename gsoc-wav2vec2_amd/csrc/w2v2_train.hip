@@ -56,6 +56,8 @@ struct TrainState {
     float *gh[4] = {nullptr, nullptr, nullptr, nullptr}, *gf = nullptr, *g3h = nullptr, *at = nullptr,
           *slabs = nullptr, *red_ws = nullptr, *dvec = nullptr, *dummy = nullptr, *dwqkv = nullptr, *dwv_scratch = nullptr;
     int64_t slab_floats = 0;
+    float* cs_ws = nullptr;           // (slabs + 1, widest N): per-slab column sums of dY from the weight-gradient GEMM
+    int64_t cs_floats = 0;
     bool forward_done = false;
     // gradient buckets for overlapping the data-parallel all-reduce with the backward: completion order
     //   0 = lm_head, 1 .. N = encoder layers N-1 .. 0, N+1 = everything in front of layer 0 in the flat buffer
@@ -170,6 +172,8 @@ static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
     if (int e = t_alloc(t, &t->at, widest * BT)) return e;
     t->slab_floats = 33 * (F * H > 3 * H * H ? F * H : 3 * H * H);      // 32 split-K slabs + the reduction scratch
     if (int e = t_alloc(t, &t->slabs, t->slab_floats)) return e;
+    t->cs_floats = 34 * (F > 3 * H ? F : 3 * H);
+    if (int e = t_alloc(t, &t->cs_ws, t->cs_floats)) return e;
     if (int e = t_alloc(t, &t->dwqkv, 3 * H * H + 3 * H)) return e;
     if (int e = t_alloc(t, &t->dummy, 2 * (H + C + F))) return e;       // sink for gradients of frozen LN params
     if (int e = t_alloc(t, &t->dwv_scratch, K * cg * H)) return e;
@@ -224,6 +228,7 @@ static bool is_trainable(w2v2_model* m, const std::string& name) {
 static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, int Kin, int Nout, float* dW,
                        float* db, hipStream_t s) {
     TrainState* t = m->train;
+    bool fused_bias = false;
     if (dW) {
         // dW (Kin, Nout) = A^T dY over the M = B T rows: few output tiles and a very long K, so the rows are cut into S slabs
         // (one GEMM batch each) that a column sum folds.  precision mode 1 stages A^T from X directly (the bf16 GEMM's B path
@@ -262,6 +267,9 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
             if (direct) {
                 GemmShadows x;
                 x.transA = true;
+                // the bias gradient rides along: the kernel's row-tile-0 blocks sum the dY columns they stage anyway
+                fused_bias = db != nullptr && (int64_t)(nslabs + 1) * Nout <= t->cs_floats;
+                if (fused_bias) { x.colsum = t->cs_ws; x.strideCS = Nout; }
                 if (int e = launch_gemm_bf16_x(m->prof, A, Kin, (int64_t)Kp * Kin, dY, Nout, (int64_t)Kp * Nout, dst, Nout,
                                                (int64_t)Kin * Nout, nullptr, nullptr, Kin, Nout, Kp, S, 0, x, s))
                     return e;
@@ -282,8 +290,14 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
         // sum the slabs (rows = nslabs, cols = Kin * Nout); the one-chunk partial scratch lives behind the slabs
         if (nslabs > 1)
             if (int e = launch_colsum(t->slabs, dW, nslabs, Kin * Nout, t->slabs + (int64_t)nslabs * Kin * Nout, 0, s)) return e;
+        if (fused_bias) {
+            // per-slab column sums of dY are in cs_ws (S, Nout); the leftover rows add one more row, then one small fold
+            if (R)
+                if (int e = launch_colsum(dY + (int64_t)Mq * Nout, t->cs_ws + (int64_t)S * Nout, R, Nout, t->red_ws, 0, s)) return e;
+            if (int e = launch_colsum(t->cs_ws, db, nslabs, Nout, t->red_ws, 0, s)) return e;
+        }
     }
-    if (db)
+    if (db && !fused_bias)
         if (int e = launch_colsum(dY, db, M, Nout, t->red_ws, 0, s)) return e;
     return W2V2_OK;
 }
