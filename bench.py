@@ -16,7 +16,10 @@ Rank 0 prints ONE JSON line.  Extra objects:
                   FLOPs / HIP-event time of its launches inside the timed region, against the
                   157.3 TFLOP/s fp32 matrix peak of gfx950.
   cpu_baseline -- the CPU oracle (numpy restatement of the reference path; TensorFlow cannot be
-                  run here) timed on this box's host cores on a bounded sample (B=1), rank 0, N=1 only.
+                  run here) timed on this box's host cores per BASELINE.md section 3 (B=1 and B=8, best /
+                  median of 5, plus an aggregate of concurrent workers), rank 0, N=1 only.
+  max_abs_logit_err -- rows 0-1 of the timed batch are the committed HF fixture's waveforms; the
+                  logits of the timed forward are compared with HF-PyTorch fp64 (bar 1e-3).
 """
 
 import argparse
@@ -39,81 +42,180 @@ PEAK_HBM_GBS = 8000.0
 _CPU_WORKER = r"""
 import os, sys, time
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "gsoc-wav2vec2_amd"))
+import numpy as np
 from threadpoolctl import threadpool_limits
 from oracle import w2v2_oracle as O
 from wav2vec2 import variables as V
 from wav2vec2.config import Wav2Vec2Config
-cfg = Wav2Vec2Config(); w = V.seeded_weights(cfg, seed=0)
+cfg = Wav2Vec2Config(); w = dict(np.load({weights!r}))
 x = V.hash_normal("bench/cpu", {L}, {seed}).reshape(1, {L})
 with threadpool_limits(limits={nt}):
-    O.ctc_forward(cfg, w, x)
-    t0 = time.perf_counter()
+    O.ctc_forward(cfg, w, x)                       # warm-up
+    print("CPU_WORKER_READY", flush=True)
+    sys.stdin.readline()                           # all workers start their timed forwards together
+    t0 = time.time()
     for _ in range({reps}):
         O.ctc_forward(cfg, w, x)
-    print("CPU_WORKER_SECONDS", time.perf_counter() - t0, flush=True)
+    print("CPU_WORKER_SPAN", t0, time.time(), flush=True)
 """
 
 
-def cpu_baseline(cfg, weights, L):
-    """CPU restatement of the reference path (oracle/: numpy + OpenBLAS + threaded ufuncs) on this box's host
-    cores.  OpenBLAS at its default thread count is SLOWER than at 8-16 threads for these shapes, so the BLAS
-    width is probed first; then as many such workers as the physical cores allow (at most 8) run concurrently,
-    one utterance each (utterances are independent), as fresh subprocesses with a hard timeout -- never a
-    fork of this GPU process.  The aggregate is the baseline; the single-worker figure is reported too."""
+def _cpu_model():
+    model, phys = "unknown CPU", set()
+    try:
+        pid = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name") and model == "unknown CPU":
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("physical id"):
+                    pid = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    phys.add((pid, line.split(":", 1)[1].strip()))
+    except OSError:
+        pass
+    return model, len(phys)
+
+
+def _timed_runs(fn, runs):
+    import statistics
+    fn()                                                   # 1 warm-up (BASELINE.md section 3)
+    ts = []
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return min(ts), statistics.median(ts), ts
+
+
+def cpu_baseline(cfg, weights, L, wave_row0=None):
+    """BASELINE.md section 3: the CPU restatement of the reference path (oracle/: numpy + OpenBLAS + threaded ufuncs;
+    TensorFlow cannot be run) on this box's host cores -- base, fp32, L = 246000, B = 1 and B = 8 (row 0 = sample.wav
+    normalised then zero-padded, other rows seeded noise), 1 warm-up, best and median of 5, CPU model and core counts
+    printed.  OpenBLAS gets SLOWER beyond 8-32 threads on these shapes, so the BLAS width is probed first, and a third
+    leg fills the host with several such workers, one utterance each (utterances are independent), as fresh
+    subprocesses started together -- never a fork of this GPU process.  `value` is the best figure of the three legs
+    (the aggregate when it ran); a leg that fails says why in `legs`."""
     import subprocess
+    import tempfile
+    import numpy as np
     from threadpoolctl import threadpool_limits
     from oracle import w2v2_oracle as O
     from wav2vec2 import variables as V
-    x = V.hash_normal("bench/cpu", L, 0).reshape(1, L)
     ncpu = os.cpu_count() or 1
-    best_nt, best_t = 1, float("inf")
-    for nt in (8, 16, 32):
+    model, phys = _cpu_model()
+    phys = phys or max(1, ncpu // 2)
+    rows = [V.hash_normal("bench/cpu", L, i) for i in range(8)]
+    if wave_row0 is not None:
+        rows[0] = np.asarray(wave_row0, np.float32)
+    x8 = np.stack(rows)
+    x1 = x8[:1]
+    # -- BLAS width probe (B = 1, one timed forward per width after a warm-up)
+    probe = {}
+    for nt in (8, 16, 32, 64):
         if nt > ncpu:
             continue
         with threadpool_limits(limits=nt):
-            O.ctc_forward(cfg, weights, x)
+            O.ctc_forward(cfg, weights, x1)
             t0 = time.perf_counter()
-            O.ctc_forward(cfg, weights, x)
-            dt = time.perf_counter() - t0
-        if dt < best_t:
-            best_nt, best_t = nt, dt
-    single = L / SAMPLE_RATE / best_t
-    procs = max(1, min(8, (ncpu // 2) // best_nt))     # physical cores / BLAS width, at most 8 workers
-    reps, agg, used = 2, single, 1
+            O.ctc_forward(cfg, weights, x1)
+            probe[nt] = time.perf_counter() - t0
+    if not probe:
+        probe[ncpu] = float("inf")
+    best_nt = min(probe, key=probe.get)
+    legs = {}
+    # -- leg 1: B = 1, best / median of 5
+    with threadpool_limits(limits=best_nt):
+        b1, m1, _ = _timed_runs(lambda: O.ctc_forward(cfg, weights, x1), 5)
+    legs["B=1"] = {"best_s": round(b1, 4), "median_s": round(m1, 4), "runs": 5, "threads": best_nt,
+                   "audio_s_per_s_best": round(L / SAMPLE_RATE / b1, 2), "audio_s_per_s_median": round(L / SAMPLE_RATE / m1, 2)}
+    # -- leg 2: B = 8 in one process (5 timed runs unless one forward takes > 6 s, then 3 -- the bench must stay bounded)
+    nt8 = min(ncpu, max(best_nt, 32)) if probe.get(32, float("inf")) < 1.5 * probe[best_nt] else best_nt
+    with threadpool_limits(limits=nt8):
+        t0 = time.perf_counter()
+        O.ctc_forward(cfg, weights, x8)
+        first = time.perf_counter() - t0
+        runs8 = 5 if first < 6.0 else 3
+        b8, m8, _ = _timed_runs(lambda: O.ctc_forward(cfg, weights, x8), runs8)
+    legs["B=8"] = {"best_s": round(b8, 4), "median_s": round(m8, 4), "runs": runs8, "threads": nt8,
+                   "audio_s_per_s_best": round(8 * L / SAMPLE_RATE / b8, 2), "audio_s_per_s_median": round(8 * L / SAMPLE_RATE / m8, 2)}
+    # -- leg 3: fill the host: W concurrent single-utterance workers of the probed width, timed forwards started together
+    procs = int(os.environ.get("W2V2_CPU_WORKERS", 0)) or max(1, min(8, phys // best_nt))
+    reps = 3
     if procs > 1:
-        children = []
+        children, tmp = [], None
         try:
+            tmp = tempfile.NamedTemporaryFile(suffix=".npz", delete=False)
+            tmp.close()
+            np.savez(tmp.name, **weights)
             for i in range(procs):
-                code = _CPU_WORKER.format(root=ROOT, L=L, seed=i, nt=best_nt, reps=reps)
-                children.append(subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE,
-                                                 stderr=subprocess.DEVNULL, text=True))
-            times = []
-            deadline = time.perf_counter() + 90.0
+                code = _CPU_WORKER.format(root=ROOT, L=L, seed=i, nt=best_nt, reps=reps, weights=tmp.name)
+                children.append(subprocess.Popen([sys.executable, "-c", code], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                                 stderr=subprocess.PIPE, text=True))
+            deadline = time.perf_counter() + 150.0
+            for ch in children:                                        # wait until every worker is warmed up
+                line = ""
+                while "CPU_WORKER_READY" not in line:
+                    if time.perf_counter() > deadline:
+                        raise TimeoutError("workers not ready within 150 s")
+                    line = ch.stdout.readline()
+                    if line == "":
+                        raise RuntimeError(f"worker exited early: {ch.stderr.read()[-400:]}")
             for ch in children:
-                out, _ = ch.communicate(timeout=max(1.0, deadline - time.perf_counter()))
-                for line in out.splitlines():
-                    if line.startswith("CPU_WORKER_SECONDS"):
-                        times.append(float(line.split()[1]))
-            if len(times) == procs:
-                agg, used = procs * reps * L / SAMPLE_RATE / max(times), procs
-        except Exception:  # noqa: BLE001 -- keep the single-worker figure
-            pass
+                ch.stdin.write("go\n")
+                ch.stdin.flush()
+            spans = []
+            for ch in children:
+                out, err = ch.communicate(timeout=max(1.0, deadline - time.perf_counter()))
+                hit = [ln for ln in out.splitlines() if ln.startswith("CPU_WORKER_SPAN")]
+                if not hit:
+                    raise RuntimeError(f"worker gave no timing: {err[-400:]}")
+                spans.append(tuple(float(v) for v in hit[0].split()[1:3]))
+            wall = max(e for _, e in spans) - min(b for b, _ in spans)
+            legs["aggregate"] = {"workers": procs, "threads_each": best_nt, "forwards_each": reps, "wall_s": round(wall, 3),
+                                 "audio_s_per_s": round(procs * reps * L / SAMPLE_RATE / wall, 2)}
+        except Exception as exc:                                       # noqa: BLE001 -- reported, not hidden
+            legs["aggregate"] = {"workers": procs, "threads_each": best_nt, "error": repr(exc)[:300]}
         finally:
             for ch in children:
                 if ch.poll() is None:
                     ch.kill()
-    if agg < single:
-        agg, used = single, 1
+            if tmp is not None:
+                try:
+                    os.unlink(tmp.name)
+                except OSError:
+                    pass
+    else:
+        legs["aggregate"] = {"workers": 1, "note": f"{phys} physical cores / {best_nt} BLAS threads leaves room for one worker only"}
+    cands = [(legs["B=1"]["audio_s_per_s_best"], best_nt, "B=1"), (legs["B=8"]["audio_s_per_s_best"], nt8, "B=8")]
+    if "audio_s_per_s" in legs["aggregate"]:
+        cands.append((legs["aggregate"]["audio_s_per_s"], procs * best_nt, "aggregate"))
+    value, cores, which = max(cands)
     return {
-        "value": round(agg, 3),
+        "value": round(value, 3),
         "unit": "audio-seconds/s",
-        "cores": used * best_nt,
+        "cores": cores,
         "kind": "port",
-        "sample": f"numpy oracle (CPU restatement of the reference path; TensorFlow not run), wav2vec2-base fp32, "
-                  f"{used} concurrent worker(s) x {reps if used > 1 else 1} forward(s) of 1 x {L} samples, {best_nt} BLAS threads "
-                  f"each (probed 8/16/32); single worker {single:.1f} audio-s/s",
-        "host_cpus": ncpu,
+        "sample": f"CPU restatement of the reference path (numpy oracle; TensorFlow not run), wav2vec2-base fp32, L = {L}: "
+                  f"value = best leg ({which}); legs: B=1 and B=8 best / median of 5 after 1 warm-up, plus an aggregate of "
+                  f"concurrent single-utterance workers; BLAS width probed {sorted(probe)} -> {best_nt}",
+        "cpu_model": model, "host_cpus": ncpu, "physical_cores": phys,
+        "blas_probe_s": {str(k): round(v, 4) for k, v in probe.items()},
+        "legs": legs,
+        "reference_published": "1.10 (TF jit) / 2.58 (TF eager) / 3.71 (ONNX) audio-s/s at L = 50000, B = 1, Colab CPU (BASELINE.md section 1)",
     }
+
+
+def golden_rows(L):
+    """The two committed waveforms of tests/golden/base_sample_padded.npz (row 0 = data/sample.wav normalised then
+    right-padded with zeros to 246000, row 1 = seeded noise) and their HF-PyTorch fp64 logits."""
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "base_sample_padded.npz")
+    with np.load(path) as z:
+        wave, logits = z["wave"], z["logits_f64"]
+    if wave.shape[1] != L:
+        return None, None
+    return wave, logits
 
 
 def measured_traffic():
@@ -180,6 +282,13 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     x = torch.randn((B, L), generator=gen, device=dev, dtype=torch.float32)   # resident in HBM
+    # Parity inside the timed workload: rows 0-1 of every rank's batch are the two waveforms of the committed
+    # HF fixture, so the logits the timed forward produces for them are checked against HF-PyTorch fp64.
+    gold_wave, gold_logits = (None, None)
+    if args.model == "base" and args.mode == "forward" and B >= 2:
+        gold_wave, gold_logits = golden_rows(L)
+        if gold_wave is not None:
+            x[:2] = torch.from_numpy(gold_wave).to(dev)
     amask = torch.ones((B, L), device=dev, dtype=torch.int32) if cfg.is_robust else None   # robust models take a mask
 
     def barrier():
@@ -232,6 +341,13 @@ def main():
         assert bool(torch.isfinite(out).all()), "training loss is not finite"
     else:
         assert tuple(out.shape) == (B, T, cfg.vocab_size) and bool(torch.isfinite(out).all())
+    logit_err = None
+    if gold_logits is not None:
+        # `out` is the output of the last TIMED-configuration forward (per-family instrumentation does not change results)
+        logit_err = float((out[:2].double().cpu() - torch.from_numpy(gold_logits).double()).abs().max())
+        bar = 1e-3 if args.precision in ("fp32", "bf16x3") else 0.15
+        assert logit_err < bar, f"rank {rank}: max |logits - HF fp64| = {logit_err:.3e} exceeds {bar}"
+        logit_err = D.max_over_ranks(logit_err, device=dev)
 
     elapsed = D.max_over_ranks(elapsed, device=dev)      # the slowest rank defines the step
 
@@ -316,13 +432,20 @@ def main():
             # whole-forward algorithmic rate: 235.56 GFLOP per 246000-sample utterance scales with T
             flops_step = sum(v["flops"] for k, v in prof_all.items() if k in ("gemm_f32", "gemm_bf16", "gemm_split", "pos_conv", "attention", "conv0_apply")) / 2
             res["forward_tflops"] = round(flops_step * world / (elapsed / args.steps) / 1e12, 2)
+        if logit_err is not None:
+            res["max_abs_logit_err"] = logit_err
+            res["logit_err_note"] = ("rows 0-1 of the timed batch = tests/golden/base_sample_padded.npz (sample.wav normalised + zero-padded to "
+                                     f"{L}, and a noise row); max |logits - HF-PyTorch fp64 logits| over both rows, max over ranks; bar "
+                                     + ("1e-3 (BASELINE.json; the reference's TF-vs-HF bar)" if args.precision != "bf16" else "0.15 (bf16 mode, self-declared)"))
         if alt:
             res["bf16x3"] = alt
         if args.mode == "train":
             res["final_loss"] = round(float(out), 4)
         if world == 1 and not args.no_cpu_baseline and args.mode == "forward" and args.model == "base" and args.precision == "fp32":
             try:
-                res["cpu_baseline"] = cpu_baseline(cfg, weights, L)
+                res["cpu_baseline"] = cpu_baseline(cfg, weights, L, None if gold_wave is None else gold_wave[0])
+                if res["cpu_baseline"]["value"]:
+                    res["gpu_over_cpu"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
             except Exception as exc:                           # noqa: BLE001 -- the GPU line must still be printed
                 res["cpu_baseline"] = {"value": None, "unit": "audio-seconds/s", "cores": 0, "kind": "port",
                                        "sample": f"CPU baseline failed: {exc!r}"}

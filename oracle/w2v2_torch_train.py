@@ -64,7 +64,8 @@ def conv_stack(config, w, wave):
         O.GEMM_OPERANDS = prev
 
 
-def train_forward(config, w, wave, attention_mask=None, p=0.0, seed=0, spec_mask=None, sd_keep=None):
+def train_forward(config, w, wave, attention_mask=None, p=0.0, seed=0, spec_mask=None, sd_keep=None,
+                  checkpoint_layers=False):
     """w: {local_name: torch.float64 tensor (requires_grad for trainables)}.  Returns logits (B, T, V)."""
     pre = config.attention_norm_type == "prenorm"
     c = config
@@ -98,7 +99,7 @@ def train_forward(config, w, wave, attention_mask=None, p=0.0, seed=0, spec_mask
     if not pre:                                                      # encoder.py:267-268
         x = _ln(x, w["encoder/layer_norm/gamma"], w["encoder/layer_norm/beta"], eps)
     x = _drop(x, p, seed, V.DS_ENCODER_IN)
-    for i in range(c.num_layers):
+    def layer(x, i):
         b = f"encoder/layers/{i}"
 
         def proj(name, t):
@@ -127,6 +128,16 @@ def train_forward(config, w, wave, attention_mask=None, p=0.0, seed=0, spec_mask
             x = x + keep_l * f
         if not pre:
             x = _ln(x, w[f"{b}/final_layer_norm/gamma"], w[f"{b}/final_layer_norm/beta"], eps)
+        return x
+
+    for i in range(c.num_layers):
+        if checkpoint_layers:
+            # long inputs (T = 1499, 24 layers): keep one layer's T x T tensors alive at a time; every mask is a pure
+            # function of (seed, site, index), so the recomputation in the backward reproduces the forward exactly
+            from torch.utils.checkpoint import checkpoint
+            x = checkpoint(layer, x, i, use_reentrant=False)
+        else:
+            x = layer(x, i)
     if pre:                                                          # encoder.py:274-275
         x = _ln(x, w["encoder/layer_norm/gamma"], w["encoder/layer_norm/beta"], eps)
     x = _drop(x, p, seed, V.DS_HEAD)
@@ -146,7 +157,7 @@ def ctc_loss_sum(config, logits, labels, division_factor=1.0):
 
 
 def loss_and_grads(config, weights, wave, labels, attention_mask=None, p=0.0, seed=0, spec_mask=None,
-                   sd_keep=None, division_factor=1.0, trainable=None):
+                   sd_keep=None, division_factor=1.0, trainable=None, checkpoint_layers=False):
     """Reference loss, per-sample nll, logits and {name: gradient} for the trainable variables."""
     w = {}
     for k, v in weights.items():
@@ -154,7 +165,7 @@ def loss_and_grads(config, weights, wave, labels, attention_mask=None, p=0.0, se
         frozen = k.startswith("feature_extractor/") or (trainable is not None and not trainable(k))
         t.requires_grad_(not frozen)
         w[k] = t
-    logits = train_forward(config, w, wave, attention_mask, p, seed, spec_mask, sd_keep)
+    logits = train_forward(config, w, wave, attention_mask, p, seed, spec_mask, sd_keep, checkpoint_layers)
     loss, nll = ctc_loss_sum(config, logits, labels, division_factor)
     loss.backward()
     grads = {k: (t.grad.numpy() if t.grad is not None else None) for k, t in w.items() if t.requires_grad}

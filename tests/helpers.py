@@ -69,3 +69,29 @@ class oracle_operands:
         from oracle import w2v2_torch_train as TT
         O.GEMM_OPERANDS, TT.GEMM_OPERANDS = self.prev
         return False
+
+
+def train_golden_grads(g):
+    """{local_name: (stride, flat fp64 slice)} of a tests/golden/train_*.npz fixture (make_train_golden.py):
+    whole tensors are stored as `grad:<name>`, flat strided slices as `grad:<name>@<stride>`."""
+    out = {}
+    for k, v in g.items():
+        if not k.startswith("grad:"):
+            continue
+        name, _, st = k[5:].partition("@")
+        out[name] = (int(st) if st else 1, np.asarray(v, dtype=np.float64).reshape(-1))
+    return out
+
+
+def grad_slice_errors(get_grad, g):
+    """Worst relative error max|got - ref| / max|ref| over the fixture's gradient slices; `get_grad(name)` returns
+    the full gradient in the TF variable layout."""
+    worst = ("", 0.0)
+    for name, (st, ref) in train_golden_grads(g).items():
+        got = np.asarray(get_grad(name), dtype=np.float64).reshape(-1)[::st]
+        assert got.shape == ref.shape, name
+        scale = max(1e-3, float(np.abs(ref).max()))
+        e = float(np.abs(got - ref).max()) / scale
+        if e > worst[1]:
+            worst = (name, e)
+    return worst
