@@ -240,7 +240,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a, AttnTrai
 template <int DH, int NW>
 int launch_attn_nw(const AttnArgs& a, hipStream_t s) {
     const size_t lds = (size_t)2 * 2 * KT * DH * sizeof(float);
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};   // (idempotent call; atomic so concurrent host threads agree on the flag)
     if (!attr_set) {
         W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<DH, NW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(AttnBwdArgs a, A
 template <int DH, int NW>
 int launch_attn_train_impl(const AttnArgs& a, const AttnTrain& tr, hipStream_t s) {
     const size_t lds = (size_t)2 * 2 * KT * DH * sizeof(float);
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};   // (idempotent call; atomic so concurrent host threads agree on the flag)
     if (!attr_set) {
         W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<DH, NW, true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -621,7 +621,7 @@ int launch_attention_bwd_bf16(const float* qkv, const int32_t* frame_len, const 
     W2V2_REQUIRE(H / heads == DH, "attention_bwd_bf16: head size %d unsupported (64)", H / heads);
     Attn16BwdArgs a{qkv, frame_len, dctx, dvec, dqkv, B, T, H, heads, 1.0f / sqrtf((float)DH)};
     const size_t lds_q = 2 * 3 * KT * ROWB, lds_kv = 2 * (4 * KT * ROWB + 2 * KT * 4);
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};   // (idempotent call; atomic so concurrent host threads agree on the flag)
     if (!attr_set) {
         W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bf16_bwd_dkv_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv));

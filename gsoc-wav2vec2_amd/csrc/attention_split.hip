@@ -285,7 +285,7 @@ int launch_attention_split(const float* qkv, const int32_t* frame_len, float* ct
                  "attention_split: unaligned buffers");
     AttnSplitArgs a{qkv, frame_len, ctx, B, T, H, heads, 1.0f / sqrtf((float)DH)};
     constexpr size_t lds = 2 * STAGE;
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};   // (idempotent call; atomic so concurrent host threads agree on the flag)
     if (!attr_set) {
         W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_split_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

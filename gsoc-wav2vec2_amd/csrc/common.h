@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include <string>
 
 #include "../../include/w2v2.h"
@@ -174,6 +176,7 @@ int launch_attention(Profiler* prof, const float* qkv, const int32_t* frame_len,
 // grow-only device scratch per (purpose, stream), owned by the library (shadow.hip)
 enum ScratchSlot { SCRATCH_SPLITK = 0, SCRATCH_CTC = 1 };
 int stream_scratch(int slot, hipStream_t s, size_t bytes, void** out);
+int stream_scratch_release();       // frees the calling device's scratch buffers
 // one layer's q | k | v projections <-> the packed (H, 3H) kernel and (3H) bias (shadow.hip); unpack skips null targets
 int launch_qkv_pack(float* packed_w, float* packed_b, const float* const w[3], const float* const b[3], int H, hipStream_t s);
 int launch_qkv_unpack(const float* packed_w, const float* packed_b, float* const w[3], float* const b[3], int H, hipStream_t s);

@@ -12,6 +12,8 @@
 // value of magnitude ~1e3, so the recursions run in fp64 (ulp(1e3) in fp32 is
 // 6e-5 per step); fp64 VALU is plentiful on gfx950 and this stage is latency-
 // bound on the per-frame barrier, not on arithmetic.
+#include <mutex>
+
 #include "common.h"
 
 namespace w2v2 {
@@ -66,6 +68,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_kernel(CtcArgs a) {
     int* ext = reinterpret_cast<int*>(buf1 + a.S_max);
     float* lgs = reinterpret_cast<float*>(ext + ((a.S_max + 3) & ~3));
     __shared__ double nll_sh;
+    __shared__ int bad_label;
 
     const int b = blockIdx.x, tid = threadIdx.x;
     int U = a.label_len[b];
@@ -75,7 +78,18 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_kernel(CtcArgs a) {
     const int S = 2 * U + 1;
     const float* __restrict__ lg = a.logits + (int64_t)b * a.T * a.V;
 
-    for (int s = tid; s < S; s += CTC_THREADS) ext[s] = (s & 1) ? a.labels[(int64_t)b * a.U + (s >> 1)] : a.blank;
+    // A label outside [0, V) (a vocabulary / config mismatch, a -1 pad) would index the staged logits out of bounds:
+    // the sample's loss becomes NaN instead (its gradient rows are zeros), and the state uses the blank in its place.
+    if (tid == 0) bad_label = 0;
+    __syncthreads();
+    for (int s = tid; s < S; s += CTC_THREADS) {
+        int e = a.blank;
+        if (s & 1) {
+            e = a.labels[(int64_t)b * a.U + (s >> 1)];
+            if (e < 0 || e >= a.V) { bad_label = 1; e = a.blank; }
+        }
+        ext[s] = e;
+    }
     // log-sum-exp per frame (fp64)
     for (int t = tid; t < Tb; t += CTC_THREADS) {
         const float* r = lg + (int64_t)t * a.V;
@@ -137,7 +151,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_kernel(CtcArgs a) {
     if (tid == 0) {
         const double tot = S >= 2 ? lse2(prev[S - 1], prev[S - 2]) : prev[0];
         nll_sh = tot <= NEG_INF ? (double)INFINITY : -tot;
-        a.nll[b] = (float)nll_sh;
+        a.nll[b] = bad_label ? __builtin_nanf("") : (float)nll_sh;
     }
     __syncthreads();
     }
@@ -173,7 +187,10 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_kernel(CtcArgs a) {
 // (sample, frame), no dependence between frames.
 __global__ __launch_bounds__(64) void ctc_grad_kernel(CtcArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
-    double* occ = reinterpret_cast<double*>(raw);          // [V]
+    // occupancy per vocabulary entry, accumulated in 2^-61 fixed point with INTEGER atomics: the sum does not depend on the
+    // order the lanes arrive in, so the gradient is bitwise reproducible (fp64 atomicAdd was not); every term is a
+    // probability in [0, 1] and the terms of one entry sum to at most 1, so 2^61 leaves headroom in 64 bits
+    unsigned long long* occ = reinterpret_cast<unsigned long long*>(raw);          // [V]
     const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     int U = a.label_len[b];
     U = U < 0 ? 0 : (U > a.U ? a.U : U);
@@ -185,7 +202,7 @@ __global__ __launch_bounds__(64) void ctc_grad_kernel(CtcArgs a) {
         for (int v = tid; v < a.V; v += 64) gr[v] = 0.f;
         return;
     }
-    for (int v = tid; v < a.V; v += 64) occ[v] = 0.0;
+    for (int v = tid; v < a.V; v += 64) occ[v] = 0ull;
     __syncthreads();
     const float* __restrict__ lg = a.logits + ((int64_t)b * a.T + t) * a.V;
     const double lse = a.lse_ws[(int64_t)b * a.T + t];
@@ -193,9 +210,14 @@ __global__ __launch_bounds__(64) void ctc_grad_kernel(CtcArgs a) {
     const double* __restrict__ bw = a.beta_ws + ((int64_t)b * a.T + t) * a.S_max;
     // the float nll would cost 1e-4 relative in every weight: recompute it in fp64 from the two sweeps at this frame
     //   p = sum_s alpha_t(s) beta_t(s) / y_t(ext[s])   (any t)
+    auto label_at = [&](int s) {
+        if (!(s & 1)) return a.blank;
+        const int e = a.labels[(int64_t)b * a.U + (s >> 1)];
+        return (e < 0 || e >= a.V) ? a.blank : e;        // (such a sample has a NaN loss and takes the zero-gradient exit above)
+    };
     double m = NEG_INF;
     for (int s = tid; s < S; s += 64) {
-        const int e = (s & 1) ? a.labels[(int64_t)b * a.U + (s >> 1)] : a.blank;
+        const int e = label_at(s);
         const double w = (aw[s] > NEG_INF && bw[s] > NEG_INF) ? aw[s] + bw[s] - ((double)lg[e] - lse) : NEG_INF;
         m = w > m ? w : m;
     }
@@ -206,19 +228,22 @@ __global__ __launch_bounds__(64) void ctc_grad_kernel(CtcArgs a) {
     }
     double tot = 0.0;
     for (int s = tid; s < S; s += 64) {
-        const int e = (s & 1) ? a.labels[(int64_t)b * a.U + (s >> 1)] : a.blank;
+        const int e = label_at(s);
         if (aw[s] > NEG_INF && bw[s] > NEG_INF) tot += exp(aw[s] + bw[s] - ((double)lg[e] - lse) - m);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
     const double logp_total = m + log(tot);              // = -nll in fp64
+    const double FIX = 2305843009213693952.0;            // 2^61
     for (int s = tid; s < S; s += 64) {
-        const int e = (s & 1) ? a.labels[(int64_t)b * a.U + (s >> 1)] : a.blank;
-        if (aw[s] > NEG_INF && bw[s] > NEG_INF)
-            atomicAdd(&occ[e], exp(aw[s] + bw[s] - ((double)lg[e] - lse) - logp_total));
+        const int e = label_at(s);
+        if (aw[s] > NEG_INF && bw[s] > NEG_INF) {
+            const double c = exp(aw[s] + bw[s] - ((double)lg[e] - lse) - logp_total);
+            atomicAdd(&occ[e], (unsigned long long)__double2ull_rn(fmin(c, 1.0) * FIX));
+        }
     }
     __syncthreads();
-    for (int v = tid; v < a.V; v += 64) gr[v] = (float)(exp((double)lg[v] - lse) - occ[v]);
+    for (int v = tid; v < a.V; v += 64) gr[v] = (float)(exp((double)lg[v] - lse) - (double)occ[v] * (1.0 / FIX));
 }
 
 struct LenArgs {
@@ -293,15 +318,15 @@ int launch_ctc(Profiler* prof, const float* logits, int B, int T, int V, const i
     size_t frames = (150 * 1024 - fixed) / ((size_t)V * sizeof(float));
     a.CH = (int)(frames < (size_t)T ? frames : (size_t)T);
     const size_t lds = fixed + (size_t)a.CH * V * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
-    }
+    static std::once_flag attr_once;                       // (several host threads may each drive their own model)
+    hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once, [&] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    });
+    W2V2_HIP_CHECK(attr_err);
     ProfScope ps(prof, FAM_CTC, 30.0 * B * (double)T * a.S_max, 4.0 * B * (double)T * V * (grad ? 2 : 1), s);
     hipLaunchKernelGGL(ctc_kernel, dim3(B, grad ? 2 : 1), dim3(CTC_THREADS), lds, s, a);
-    if (grad) hipLaunchKernelGGL(ctc_grad_kernel, dim3(T, B), dim3(64), (size_t)V * sizeof(double), s, a);
+    if (grad) hipLaunchKernelGGL(ctc_grad_kernel, dim3(T, B), dim3(64), (size_t)V * sizeof(unsigned long long), s, a);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }

@@ -457,7 +457,7 @@ int launch_src16(Gemm16Args& g, int nbatch, hipStream_t s) {
     constexpr size_t LDS = (SRC == 6 ? 4 : 2) * (BM + BN) * ROWB;
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};   // (idempotent call; atomic so concurrent host threads agree on the flag)
     if (!attr_set) {
         W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<SRC, BM, BN, WM, WN, MINB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));

@@ -348,7 +348,7 @@ int launch_dma(GemmArgs& g, int nbatch, hipStream_t s) {
     g.tiles_n = (g.N + BN - 1) / BN;
     dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch), block(WM * WN * 64);
     const size_t lds = 2 * (BM * BKT + BKT * BN) * sizeof(float);
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};   // (idempotent call; atomic so concurrent host threads agree on the flag)
     if (!attr_set && lds > 64 * 1024) {
         W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_dma_kernel<WM, WN, MINW, BKT, BM, BN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -364,7 +364,7 @@ int launch_cfg(GemmArgs& g, bool fast, int nbatch, hipStream_t s) {
     using C_ = Cfg<BM, BN, WM, WN>;
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};   // (idempotent call; atomic so concurrent host threads agree on the flag)
     if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in
         W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<true, BM, BN, WM, WN, MINW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)C_::LDS));

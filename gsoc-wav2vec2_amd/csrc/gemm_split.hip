@@ -318,7 +318,7 @@ int launch_gemm_split(Profiler* prof, const float* A, int64_t lda, int64_t strid
     const dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch);
     if (bk == 32) {
         constexpr size_t LDS = 2 * SplitCfg<32>::STAGE;
-        static bool attr_set = false;
+        static std::atomic<bool> attr_set{false};   // (idempotent call; atomic so concurrent host threads agree on the flag)
         if (!attr_set) {
             W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<32, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
             attr_set = true;
@@ -326,7 +326,7 @@ int launch_gemm_split(Profiler* prof, const float* A, int64_t lda, int64_t strid
         hipLaunchKernelGGL((gemm_split_kernel<32, 2>), grid, dim3(NT), LDS, s, g);
     } else {
         constexpr size_t LDS = 2 * SplitCfg<16>::STAGE;
-        static bool attr_set = false;
+        static std::atomic<bool> attr_set{false};   // (idempotent call; atomic so concurrent host threads agree on the flag)
         if (!attr_set) {
             W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<16, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
             attr_set = true;

@@ -178,7 +178,7 @@ int launch_pos(const PosArgs& a, hipStream_t s) {
     constexpr int WS = (CG % 32 == 0) ? CG + 16 : CG;
     const int rows = PBM + a.K - 1;
     const size_t lds = (size_t)(((rows * XS + 3) & ~3) + 2 * CG * WS) * sizeof(float);
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};   // (idempotent call; atomic so concurrent host threads agree on the flag)
     if (!attr_set) {
         W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pos_conv_kernel<CG>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -336,7 +336,7 @@ template <int CG>
 int launch_dw(const PosDwArgs& a, hipStream_t s) {
     constexpr int XS = CG + 2, XROWS = DW_TT + DW_TAPS - 1;
     const size_t lds = (size_t)(((XROWS * XS + 3) & ~3) + DW_TT * XS) * sizeof(float);
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};   // (idempotent call; atomic so concurrent host threads agree on the flag)
     if (!attr_set) {
         W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(pos_conv_dw_kernel<CG>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -3,6 +3,7 @@
 // conversion.  Activations get their shadow from the producing kernel (GEMM / LayerNorm / conv0 / attention
 // epilogues); the kernels here serve the weights, which change only when variables are set or the optimizer steps.
 #include <map>
+#include <tuple>
 #include <mutex>
 #include <utility>
 
@@ -92,17 +93,21 @@ int launch_qkv_unpack(const float* packed_w, const float* packed_b, float* const
     return launch_qkv(false, const_cast<float*>(packed_w), const_cast<float*>(packed_b), w, b, H, s);
 }
 
-// Grow-only device scratch owned by the library, one buffer per (purpose, stream): launches on one stream are ordered, so
-// a buffer is never in use by two kernels at once, and different streams (other models, other host threads) get their own.
+// Grow-only device scratch owned by the library, one buffer per (purpose, device, stream): launches on one stream are
+// ordered, so a buffer is never in use by two kernels at once, and different streams (other models, other host threads) get
+// their own.  The device is part of the key because the null stream has the same handle on every device: one process
+// driving two GPUs on their default streams must not be handed device 0's allocation while running on device 1.
 namespace {
 struct StreamScratch { void* p = nullptr; size_t bytes = 0; };
 std::mutex g_scratch_mu;
-std::map<std::pair<int, hipStream_t>, StreamScratch> g_scratch;
+std::map<std::tuple<int, int, hipStream_t>, StreamScratch> g_scratch;
 }  // namespace
 
 int stream_scratch(int slot, hipStream_t s, size_t bytes, void** out) {
+    int dev = 0;
+    W2V2_HIP_CHECK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(g_scratch_mu);
-    StreamScratch& e = g_scratch[std::make_pair(slot, s)];
+    StreamScratch& e = g_scratch[std::make_tuple(slot, dev, s)];
     if (bytes > e.bytes) {
         if (e.p) W2V2_HIP_CHECK(hipFree(e.p));           // (hipFree waits for the device: no kernel still uses the old one)
         e.p = nullptr; e.bytes = 0;
@@ -110,6 +115,23 @@ int stream_scratch(int slot, hipStream_t s, size_t bytes, void** out) {
         e.bytes = bytes;
     }
     *out = e.p;
+    return W2V2_OK;
+}
+
+// Release every scratch buffer of the calling thread's current device (w2v2_release_scratch in the C ABI): the entries are
+// otherwise kept for the life of the process.
+int stream_scratch_release() {
+    int dev = 0;
+    W2V2_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    for (auto it = g_scratch.begin(); it != g_scratch.end();) {
+        if (std::get<1>(it->first) == dev) {
+            if (it->second.p) (void)hipFree(it->second.p);
+            it = g_scratch.erase(it);
+        } else {
+            ++it;
+        }
+    }
     return W2V2_OK;
 }
 

@@ -359,6 +359,7 @@ int w2v2_ensure_pos16(w2v2_model* m, int B, int T, hipStream_t s) {
 extern "C" {
 
 const char* w2v2_last_error(void) { return g_err; }
+int w2v2_release_scratch(void) { return w2v2::stream_scratch_release(); }
 const char* w2v2_version(void) { return "w2v2-gfx950 0.1 (fp32 MFMA path; bf16-operand and bf16x3-split precision modes)"; }
 
 int w2v2_create(const w2v2_config* cfg, w2v2_model** out) {

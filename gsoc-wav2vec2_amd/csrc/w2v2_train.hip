@@ -32,7 +32,9 @@ struct LayerSave {
 struct TrainState {
     int B = 0, T = 0;
     int64_t L = 0;
-    std::vector<void*> allocs;
+    std::vector<void*> allocs;          // shape-dependent buffers: rebuilt when (B, L) changes
+    std::vector<void*> persist;         // shape-independent buffers (gradients, Adam moments, transposed kernels, slab scratch):
+                                        // allocated once -- their addresses key the bf16x3 plane cache (w2v2_model::w48)
     std::vector<LayerSave> layers;
     float *hd = nullptr, *hm = nullptr, *pos_c = nullptr, *hdf = nullptr, *hs0 = nullptr;
     float *WpT = nullptr, *WlmT = nullptr, *pos_wg_t = nullptr, *dwg = nullptr;
@@ -72,6 +74,14 @@ static int t_alloc(TrainState* t, float** out, int64_t floats) {
     return W2V2_OK;
 }
 
+static int p_alloc(TrainState* t, float** out, int64_t floats) {
+    void* p = nullptr;
+    W2V2_HIP_CHECK(hipMalloc(&p, (size_t)(floats > 0 ? floats : 1) * sizeof(float)));
+    t->persist.push_back(p);
+    *out = reinterpret_cast<float*>(p);
+    return W2V2_OK;
+}
+
 static void t_free(TrainState* t) {
     for (void* p : t->allocs) (void)hipFree(p);
     t->allocs.clear();
@@ -80,6 +90,8 @@ static void t_free(TrainState* t) {
 void w2v2_train_destroy(w2v2_model* m) {
     if (!m || !m->train) return;
     t_free(m->train);
+    for (void* p : m->train->persist) (void)hipFree(p);
+    m->train->persist.clear();
     if (m->train->adam_chunks) (void)hipFree(m->train->adam_chunks);
     if (m->train->pos_w16_t) (void)hipFree(m->train->pos_w16_t);
     for (hipEvent_t ev : m->train->bucket_ev) (void)hipEventDestroy(ev);
@@ -109,43 +121,68 @@ static TrainState* get_state(w2v2_model* m) {
     return m->train;
 }
 
-static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
+// Shape-independent state, once per model: gradients, Adam moments, transposed kernel copies, slab scratch.  The transposed
+// copies must keep their addresses across shape changes: the bf16x3 plane cache is keyed by them, and a freed-and-recycled
+// address would serve stale planes.
+static int ensure_persistent(w2v2_model* m) {
     TrainState* t = get_state(m);
-    if (t->B == B && t->L == L && !t->layers.empty()) return W2V2_OK;
-    // keep gradient/optimizer buffers across a shape change, rebuild the rest
-    std::vector<void*> keep;
-    for (void* p : t->allocs)
-        if (p == t->grads || p == t->adam_m || p == t->adam_v) keep.push_back(p);
-        else (void)hipFree(p);
-    t->allocs = keep;
-    t->layers.clear();
-    t->pos_pack32 = t->pos_dw_slabs = nullptr;      // lazily re-allocated at the new shape
     const w2v2_config& c = m->cfg;
-    const int64_t H = c.hidden_size, F = c.intermediate_size, BT = (int64_t)B * T;
+    const int64_t H = c.hidden_size, F = c.intermediate_size;
     const int64_t C = c.filter_sizes[c.num_conv_layers - 1];
+    const int64_t K = c.num_conv_pos_embeddings, cg = H / c.num_conv_pos_embedding_groups;
     if (!t->grads) {
-        if (int e = t_alloc(t, &t->grads, t->gtotal)) return e;
-        if (int e = t_alloc(t, &t->adam_m, t->gtotal)) return e;
-        if (int e = t_alloc(t, &t->adam_v, t->gtotal)) return e;
+        if (int e = p_alloc(t, &t->grads, t->gtotal)) return e;
+        if (int e = p_alloc(t, &t->adam_m, t->gtotal)) return e;
+        if (int e = p_alloc(t, &t->adam_v, t->gtotal)) return e;
         W2V2_HIP_CHECK(hipMemset(t->grads, 0, (size_t)t->gtotal * 4));
         W2V2_HIP_CHECK(hipMemset(t->adam_m, 0, (size_t)t->gtotal * 4));
         W2V2_HIP_CHECK(hipMemset(t->adam_v, 0, (size_t)t->gtotal * 4));
+        if (int e = p_alloc(t, &t->WpT, H * C)) return e;
+        if (int e = p_alloc(t, &t->WlmT, H * (int64_t)c.vocab_size)) return e;
+        if (int e = p_alloc(t, &t->pos_wg_t, K * cg * H)) return e;
+        if (int e = p_alloc(t, &t->dwg, K * cg * H)) return e;
+        if (int e = p_alloc(t, &t->dwv_scratch, K * cg * H)) return e;
+        t->layers.resize(c.num_layers);
+        for (auto& l : t->layers) {
+            if (int e = p_alloc(t, &l.WqkvT, 3 * H * H)) return e;
+            if (int e = p_alloc(t, &l.WoT, H * H)) return e;
+            if (int e = p_alloc(t, &l.W1T, F * H)) return e;
+            if (int e = p_alloc(t, &l.W2T, H * F)) return e;
+            l.keep = 1.f;
+        }
+        t->slab_floats = 33 * (F * H > 3 * H * H ? F * H : 3 * H * H);      // 32 split-K slabs + the reduction scratch
+        if (int e = p_alloc(t, &t->slabs, t->slab_floats)) return e;
+        t->cs_floats = 34 * (F > 3 * H ? F : 3 * H);
+        if (int e = p_alloc(t, &t->cs_ws, t->cs_floats)) return e;
+        if (int e = p_alloc(t, &t->dwqkv, 3 * H * H + 3 * H)) return e;
+        if (int e = p_alloc(t, &t->dummy, 2 * (H + C + F))) return e;       // sink for gradients of frozen LN params
+        t->transposes_fresh = false;
     }
+    return W2V2_OK;
+}
+
+static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
+    TrainState* t = get_state(m);
+    if (t->B == B && t->L == L && t->B > 0) return W2V2_OK;
+    if (int e = ensure_persistent(m)) return e;
+    const w2v2_config& c = m->cfg;
+    const int64_t H = c.hidden_size, F = c.intermediate_size, BT = (int64_t)B * T;
+    const int64_t C = c.filter_sizes[c.num_conv_layers - 1];
+    // ---- shape-dependent activations and scratch
+    t_free(t);
+    t->B = 0;
+    t->forward_done = false;
+    t->pos_pack32 = t->pos_dw_slabs = nullptr;      // lazily re-allocated at the new shape
     if (int e = t_alloc(t, &t->hd, BT * H)) return e;
     if (int e = t_alloc(t, &t->hm, BT * H)) return e;
     if (int e = t_alloc(t, &t->pos_c, BT * H)) return e;
     if (int e = t_alloc(t, &t->hdf, BT * H)) return e;
+    t->hs0 = nullptr;
     if (c.attention_norm_type == 1)
         if (int e = t_alloc(t, &t->hs0, BT * H)) return e;
-    if (int e = t_alloc(t, &t->WpT, H * C)) return e;
-    if (int e = t_alloc(t, &t->WlmT, H * (int64_t)c.vocab_size)) return e;
-    const int64_t K = c.num_conv_pos_embeddings, cg = H / c.num_conv_pos_embedding_groups;
-    if (int e = t_alloc(t, &t->pos_wg_t, K * cg * H)) return e;
-    if (int e = t_alloc(t, &t->dwg, K * cg * H)) return e;
     float* sm = nullptr;
     if (int e = t_alloc(t, &sm, (BT + 15) / 4 + 4)) return e;
     t->spec_mask = reinterpret_cast<uint8_t*>(sm);
-    t->layers.resize(c.num_layers);
     for (auto& l : t->layers) {
         if (int e = t_alloc(t, &l.qkv, BT * 3 * H)) return e;
         if (int e = t_alloc(t, &l.ctx, BT * H)) return e;
@@ -158,11 +195,6 @@ static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
         l.a = nullptr;
         if (c.attention_norm_type == 1)
             if (int e = t_alloc(t, &l.a, BT * H)) return e;
-        if (int e = t_alloc(t, &l.WqkvT, 3 * H * H)) return e;
-        if (int e = t_alloc(t, &l.WoT, H * H)) return e;
-        if (int e = t_alloc(t, &l.W1T, F * H)) return e;
-        if (int e = t_alloc(t, &l.W2T, H * F)) return e;
-        l.keep = 1.f;
     }
     for (int i = 0; i < 4; ++i)
         if (int e = t_alloc(t, &t->gh[i], BT * H)) return e;
@@ -170,13 +202,6 @@ static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
     if (int e = t_alloc(t, &t->g3h, BT * 3 * H)) return e;
     const int64_t widest = F > 3 * H ? F : 3 * H;
     if (int e = t_alloc(t, &t->at, widest * BT)) return e;
-    t->slab_floats = 33 * (F * H > 3 * H * H ? F * H : 3 * H * H);      // 32 split-K slabs + the reduction scratch
-    if (int e = t_alloc(t, &t->slabs, t->slab_floats)) return e;
-    t->cs_floats = 34 * (F > 3 * H ? F : 3 * H);
-    if (int e = t_alloc(t, &t->cs_ws, t->cs_floats)) return e;
-    if (int e = t_alloc(t, &t->dwqkv, 3 * H * H + 3 * H)) return e;
-    if (int e = t_alloc(t, &t->dummy, 2 * (H + C + F))) return e;       // sink for gradients of frozen LN params
-    if (int e = t_alloc(t, &t->dwv_scratch, K * cg * H)) return e;
     int64_t rw = colsum_ws_floats(BT, (int)widest);
     const int64_t lw = ln_bwd_ws_floats(BT, (int)(H > C ? H : C));
     if (lw > rw) rw = lw;
@@ -185,7 +210,6 @@ static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
     t->B = B;
     t->L = L;
     t->T = T;
-    t->transposes_fresh = false;
     return W2V2_OK;
 }
 
@@ -325,7 +349,6 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
                        const uint8_t* spec_mask_host, const float* sd_keep_host, float dropout_p,
                        uint64_t seed, float* logits_out, void* stream) {
     W2V2_REQUIRE(m && wave && logits_out, "train_forward: null argument");
-    W2V2_REQUIRE(m->cfg.with_lm_head, "train_forward: the training step needs the CTC head (Wav2Vec2ForCTC)");
     W2V2_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "train_forward: dropout %f outside [0, 1)", dropout_p);
     if (!m->finalized) {
         set_error("train_forward: call w2v2_finalize after setting the variables");
@@ -498,6 +521,13 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
                                       m->P("encoder/layer_norm/beta"), BT, H, eps, 0, s))
             return e;
         head_in = m->enc_out;
+    }
+    if (!c.with_lm_head) {
+        // Wav2Vec2Model.call(training=True) (modeling.py:169-209): the backbone's hidden states (B, T, H); the head's Dropout and
+        // Dense belong to Wav2Vec2ForCTC.  No backward from here (the training step differentiates the CTC model).
+        W2V2_HIP_CHECK(hipMemcpyAsync(logits_out, head_in, (size_t)BT * H * 4, hipMemcpyDeviceToDevice, s));
+        t->forward_done = false;
+        return W2V2_OK;
     }
     if (int e = launch_dropout_fwd_x(head_in, nullptr, t->hdf, S16(m->enc16), BT * H, 0, p, seed, DS_HEAD, s)) return e;
     if (int e = gemm(t->hdf, S16(m->enc16), H, 0, m->P("lm_head/kernel"), c.vocab_size, logits_out, nullptr, c.vocab_size, 0,
@@ -824,6 +854,20 @@ int w2v2_train_bucket(w2v2_model* m, int32_t k, int64_t* offset, int64_t* numel)
     return W2V2_OK;
 }
 
+/* Slot of one variable in the flat gradient / Adam buffers (16-byte aligned slots, inventory order). */
+int w2v2_grad_slot(w2v2_model* m, const char* name, int64_t* offset, int64_t* numel) {
+    W2V2_REQUIRE(m && name && offset && numel, "grad_slot: null argument");
+    TrainState* t = get_state(m);
+    auto it = m->index.find(name);
+    if (it == m->index.end()) {
+        set_error("grad_slot: unknown variable `%s`", name);
+        return W2V2_ENOTFOUND;
+    }
+    *offset = t->goff[it->second];
+    *numel = m->params[it->second].numel;
+    return W2V2_OK;
+}
+
 int w2v2_train_bucket_wait(w2v2_model* m, int32_t k, void* stream) {
     W2V2_REQUIRE(m && m->train, "train_bucket_wait: no training state");
     TrainState* t = m->train;
@@ -832,14 +876,23 @@ int w2v2_train_bucket_wait(w2v2_model* m, int32_t k, void* stream) {
     return W2V2_OK;
 }
 
+/* A fresh optimizer: the reference builds a new tf.keras.optimizers.Adam for each stage (src/main.py:213,240), i.e. zero
+ * moments and iteration 0.  The moments live here (not in the Python Trainer), so a new Trainer on a used model resets them. */
+int w2v2_adam_reset(w2v2_model* m, void* stream) {
+    W2V2_REQUIRE(m, "adam_reset: null model");
+    if (int e = ensure_persistent(m)) return e;
+    TrainState* t = m->train;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    W2V2_HIP_CHECK(hipMemsetAsync(t->adam_m, 0, (size_t)t->gtotal * 4, s));
+    W2V2_HIP_CHECK(hipMemsetAsync(t->adam_v, 0, (size_t)t->gtotal * 4, s));
+    return W2V2_OK;
+}
+
 /* Adam's first / second moment buffers (flat, the gradient buffer's layout) for checkpoint / resume. */
 int w2v2_adam_buffers(w2v2_model* m, float** m_dev, float** v_dev, int64_t* numel) {
     W2V2_REQUIRE(m && m_dev && v_dev && numel, "adam_buffers: null argument");
+    if (int e = ensure_persistent(m)) return e;        // the moments do not depend on the batch shape: no forward needed
     TrainState* t = m->train;
-    if (!t || !t->adam_m) {
-        set_error("adam_buffers: run a training forward first");
-        return W2V2_ESTATE;
-    }
     *m_dev = t->adam_m;
     *v_dev = t->adam_v;
     *numel = t->gtotal;
@@ -848,11 +901,8 @@ int w2v2_adam_buffers(w2v2_model* m, float** m_dev, float** v_dev, int64_t* nume
 
 int w2v2_grad_buffer(w2v2_model* m, float** dev_ptr, int64_t* numel) {
     W2V2_REQUIRE(m && dev_ptr && numel, "grad_buffer: null argument");
+    if (int e = ensure_persistent(m)) return e;
     TrainState* t = m->train;
-    if (!t || !t->grads) {
-        set_error("grad_buffer: run a training forward first");
-        return W2V2_ESTATE;
-    }
     *dev_ptr = t->grads;
     *numel = t->gtotal;
     return W2V2_OK;

@@ -47,6 +47,7 @@ _I64 = C.c_int64
 PROTOTYPES = {
     "w2v2_last_error": (C.c_char_p, []),
     "w2v2_version": (C.c_char_p, []),
+    "w2v2_release_scratch": (C.c_int, []),
     "w2v2_create": (C.c_int, [C.POINTER(W2V2Config), C.POINTER(_P)]),
     "w2v2_destroy": (None, [_P]),
     "w2v2_num_params": (C.c_int, [_P]),
@@ -64,9 +65,11 @@ PROTOTYPES = {
     "w2v2_train_backward": (C.c_int, [_P, _P, _P]),
     "w2v2_grad_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I64)]),
     "w2v2_adam_buffers": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_I64)]),
+    "w2v2_adam_reset": (C.c_int, [_P, _P]),
     "w2v2_train_num_buckets": (C.c_int, [_P]),
     "w2v2_train_bucket": (C.c_int, [_P, _I32, C.POINTER(_I64), C.POINTER(_I64)]),
     "w2v2_train_bucket_wait": (C.c_int, [_P, _I32, _P]),
+    "w2v2_grad_slot": (C.c_int, [_P, C.c_char_p, C.POINTER(_I64), C.POINTER(_I64)]),
     "w2v2_get_grad": (C.c_int, [_P, C.c_char_p, _P, _I64, _P]),
     "w2v2_adam_step": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, _I64, _P]),
     "w2v2_ln_bwd_ws_floats": (_I64, [_I64, _I32]),

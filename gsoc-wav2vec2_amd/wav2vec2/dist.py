@@ -77,3 +77,77 @@ def gather_rows(local, total_rows, device=None):
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad)
     return torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, sizes)], dim=0)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# The gradient all-reduce of the training step (reference: tf.distribute.MirroredStrategy under model.fit,
+# src/main.py:156,192; loss / GLOBAL batch then SUM, main.py:198-200, losses.py:45).  Pure index arithmetic plus
+# torch.distributed calls on whatever tensor carries the flat gradient buffer -- a view of the HIP library's device
+# buffer in the Trainer (backend nccl = RCCL), a CPU tensor in the world-size-2 gloo test.
+# ------------------------------------------------------------------------------------------------------------
+def flat_layout(specs):
+    """{local_name: (offset, numel)} and the total length of the flat gradient / Adam buffers: inventory order, every
+    variable in a 16-byte aligned slot -- the layout csrc/w2v2_train.hip::get_state builds (`w2v2_grad_slot` reports it)."""
+    out, off = {}, 0
+    for name, (shape, _) in specs.items():
+        n = 1
+        for d in shape:
+            n *= int(d)
+        out[name] = (off, n)
+        off += (n + 3) & ~3
+    return out, off
+
+
+def gradient_buckets(layout, total, num_layers):
+    """[(offset, numel)] in the order the backward completes them: lm_head, encoder layers N-1 .. 0, then everything in
+    front of layer 0 (include/w2v2.h: w2v2_train_bucket).  They tile [0, total)."""
+    def first_with(prefix):
+        hits = [o for n, (o, _) in layout.items() if n.startswith(prefix)]
+        return min(hits) if hits else total
+
+    def layer_begin(i):
+        return first_with(f"encoder/layers/{i}/") if i < num_layers else first_with("lm_head/")
+
+    out = [(first_with("lm_head/"), total - first_with("lm_head/"))]
+    for i in range(num_layers - 1, -1, -1):
+        out.append((layer_begin(i), layer_begin(i + 1) - layer_begin(i)))
+    out.append((0, layer_begin(0)))
+    return out
+
+
+def trainable_ranges(layout, bucket, trainable):
+    """The contiguous runs of TRAINABLE variables inside `bucket` = (offset, numel): frozen slots (the 4.2 M conv-stack
+    elements of stage 2, everything but lm_head in stage 1) stay zero on every rank and are not sent.  `trainable` is a
+    set of local names.  Adjacent trainable slots merge (alignment padding between them rides along)."""
+    lo, n = bucket
+    hi = lo + n
+    runs = []
+    for name, (off, numel) in layout.items():
+        if off < lo or off >= hi or name not in trainable:
+            continue
+        end = min(hi, off + ((numel + 3) & ~3))
+        if runs and runs[-1][1] == off:
+            runs[-1][1] = end
+        else:
+            runs.append([off, end])
+    return [(a, b - a) for a, b in runs]
+
+
+def all_reduce_range(buf, off, n, payload_dtype=None, async_op=False):
+    """SUM all-reduce of buf[off : off + n] in place.  `payload_dtype` (e.g. torch.bfloat16) sends a down-cast copy and
+    writes the up-cast sum back -- half the bytes over xGMI for the bf16 fine-tune configurations (180.4 MB
+    instead of 360.8 MB for base).  Returns a callable that completes the operation (waits, and for a compressed payload
+    copies the result back)."""
+    import torch.distributed as dist
+    view = buf[off:off + n]
+    if payload_dtype is None or payload_dtype == view.dtype:
+        work = dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=async_op)
+        return (work.wait if async_op else (lambda: None))
+    small = view.to(payload_dtype)
+    work = dist.all_reduce(small, op=dist.ReduceOp.SUM, async_op=async_op)
+
+    def finish():
+        if async_op:
+            work.wait()
+        view.copy_(small)
+    return finish

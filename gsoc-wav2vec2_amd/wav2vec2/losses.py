@@ -38,8 +38,13 @@ class CTCLoss:
         if not isinstance(logits, torch.Tensor):
             logits = torch.as_tensor(np.asarray(logits, dtype=np.float32))
         logits = logits.detach().as_subclass(torch.Tensor).to(device=dev, dtype=torch.float32).contiguous()
-        if not isinstance(labels, torch.Tensor):
-            labels = torch.as_tensor(np.asarray(labels))
+        if not isinstance(labels, torch.Tensor) or not labels.is_cuda:
+            # host labels: a label outside the vocabulary is a vocab / config mismatch -- say so before the launch.
+            # (Device-resident labels are checked by the kernel instead: the sample's loss comes back NaN.)
+            host = np.asarray(labels.cpu() if isinstance(labels, torch.Tensor) else labels)
+            if host.size and (host.min() < 0 or host.max() >= logits.shape[-1]):
+                raise ValueError(f"labels must lie in [0, {logits.shape[-1]}): got [{host.min()}, {host.max()}]")
+            labels = torch.as_tensor(host)
         labels = labels.to(device=dev, dtype=torch.int32).contiguous()
         B, T, V = logits.shape
         if labels.dim() != 2 or labels.shape[0] != B:

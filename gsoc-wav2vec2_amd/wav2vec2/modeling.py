@@ -11,11 +11,16 @@ only carry the device buffers and the stream.
 What is deliberately different from Keras:
   * outputs are torch CUDA tensors (a thin subclass whose ``.numpy()`` copies to
     host, so reference-style ``model(x).numpy()`` keeps working);
-  * weights are stored as ``tf_model.npz`` (TF variable names as keys) -- the
-    Keras-HDF5 container needs h5py, which this image lacks; ``tf_model.h5`` is
-    read when h5py is importable;
-  * ``training=True`` (dropout / spec-augment / stochastic depth) is not built
-    yet and raises instead of silently running the inference graph.
+  * ``model(x, training=True)`` runs the training-mode forward (dropout, spec-augment,
+    stochastic depth -- reference modeling.py:169-209,239-255) with randomness drawn from a
+    model-level seeded generator (``model.set_seed``); gradients, the optimizer and the
+    data-parallel all-reduce live in ``wav2vec2.Trainer``;
+  * the Keras object graph callers touch -- ``model.layers``, ``layer.trainable``,
+    ``model.trainable`` (src/main.py:210,232-237) -- is rebuilt over the flat variable
+    inventory by ``wav2vec2/layers.py``;
+  * weights are written as a Keras-layout HDF5 file ``tf_model.h5`` by the package's own
+    dependency-free HDF5 reader / writer (``wav2vec2/h5lite.py``; this image has no h5py);
+    ``tf_model.npz`` (TF variable names as keys) is still read.
 """
 
 import ctypes as C
@@ -28,6 +33,8 @@ import numpy as np
 from . import _native as N
 from . import variables as V
 from .config import Wav2Vec2Config
+from .layers import Layer, attach, build_backbone_layers
+from .spec_augment import compute_mask_indices
 
 logger = logging.getLogger(__name__)
 
@@ -64,14 +71,25 @@ class DeviceTensor:
 
 class Variable:
     """Minimal stand-in for tf.Variable: ``.name``, ``.shape``, ``.numpy()``,
-    ``.assign()`` -- what convert_torch_to_tf.py:79-121 and callers touch."""
+    ``.assign()``, ``.trainable`` -- what convert_torch_to_tf.py:79-121 and callers touch.
+    A variable trains only if its own flag and every layer above it are trainable (Keras)."""
 
     def __init__(self, model, local_name, shape, trainable=True):
         self._model = model
         self.local_name = local_name
         self.name = V.tf_variable_name(local_name, with_lm_head=model._prefix_with_head)
         self.shape = tuple(shape)
-        self.trainable = trainable
+        self._own_trainable = bool(trainable)
+        self._gates = []                    # the chain of layers above this variable (layers.attach)
+
+    @property
+    def trainable(self):
+        return self._own_trainable and all(g._trainable for g in self._gates)
+
+    @trainable.setter
+    def trainable(self, value):
+        self._own_trainable = bool(value)
+        self._model._sync_trainable()
 
     def numpy(self):
         return self._model._get_param(self.local_name, self.shape)
@@ -82,6 +100,14 @@ class Variable:
 
     def __repr__(self):
         return f"<Variable {self.name} shape={self.shape}>"
+
+
+class BackboneLayer(Layer):
+    """The ``Wav2Vec2Model`` inside ``Wav2Vec2ForCTC`` (``self.model``, reference modeling.py:227)."""
+
+    def freeze_feature_extractor(self):
+        for layer in self.feature_extractor:                      # reference modeling.py:211-214
+            layer.trainable = False
 
 
 def hf_checkpoint_file(save_dir):
@@ -106,20 +132,51 @@ def read_hf_state_dict(save_dir):
     return {k: v.detach().cpu().numpy() for k, v in sd.items()}
 
 
+def keras_layer_groups(model, weights, with_lm_head):
+    """Keras HDF5 grouping for the backbone-only model `Wav2Vec2Model`: one group per top-level layer (the 7 conv layers,
+    the feature projection, the encoder).  `masked_spec_embed` is a weight of the model itself, not of a sub-layer; it is
+    stored in a group named after the model.  (Loading is by variable name, so the grouping is not load-bearing here.)"""
+    groups, order = {}, []
+
+    def add(group, local, arr):
+        if group not in groups:
+            groups[group] = []
+            order.append(group)
+        groups[group].append((V.tf_variable_name(local, with_lm_head), arr))
+
+    for local, arr in weights.items():
+        parts = local.split("/")
+        if local.startswith("feature_extractor/conv_layers/"):
+            add("/".join(parts[:3]), local, arr)
+        elif parts[0] in ("feature_projection", "encoder", "lm_head"):
+            add(parts[0], local, arr)
+        else:
+            add("wav2vec2", local, arr)
+    return [(g, groups[g]) for g in order]
+
+
 def convert_hf_checkpoint(hf_dir, save_dir, with_lm_head=True):
     """The job of the reference's src/convert_torch_to_tf.py without TensorFlow and without a GPU: read a
     HuggingFace-PyTorch checkpoint directory, apply the HF -> TF name / layout map (file:12-44,110-117) and write
-    the package's own checkpoint (`config.json` with the reference's 22 fields + weights keyed by TF variable names).
+    the reference's checkpoint layout (`config.json` with its 22 fields + `tf_model.h5`, a Keras-layout HDF5 weight file).
     Returns the config."""
     config = Wav2Vec2Config.from_hf_config(os.path.join(hf_dir, "config.json"))
     weights = V.from_hf_state_dict(read_hf_state_dict(hf_dir), config, with_lm_head=with_lm_head)
     config.save_pretrained(save_dir)
-    np.savez(os.path.join(save_dir, "tf_model.npz"), **{V.tf_variable_name(n, with_lm_head): a for n, a in weights.items()})
+    from . import h5lite
+    named = [(V.tf_variable_name(n, with_lm_head), a) for n, a in weights.items()]
+    if with_lm_head:
+        layers = [("wav2vec2", [(n, a) for n, a in named if "/lm_head/" not in n]), ("dropout", []),
+                  ("lm_head", [(n, a) for n, a in named if "/lm_head/" in n])]
+    else:
+        layers = keras_layer_groups(None, weights, False)
+    h5lite.save_keras_weights(os.path.join(save_dir, "tf_model.h5"), layers)
     return config
 
 
-class TFKerasModel:
-    """Shared plumbing (reference modeling.py:21-102 ``TFKerasModel``)."""
+class TFKerasModel(Layer):
+    """Shared plumbing (reference modeling.py:21-102 ``TFKerasModel``).  The model is itself the root ``Layer`` of the
+    Keras-like object graph (``.layers``, ``.trainable``, ``.variables``; wav2vec2/layers.py)."""
 
     _with_lm_head = False        # native model computes the LM head
     _prefix_with_head = False    # variable names carry the "wav2vec2-ctc/" prefix
@@ -137,6 +194,33 @@ class TFKerasModel:
         # by running a dummy forward, modeling.py:86-102)
         self.set_weights(V.seeded_weights(config, seed=seed, with_lm_head=self._with_lm_head))
         self._variables = [Variable(self, n, s) for n, (s, _) in self._specs.items()]
+        self._pushed_trainable = {}
+        self._build_layers()
+        self.set_seed(seed)
+
+    def _build_layers(self):
+        """The reference's Keras layer tree over the flat inventory (wav2vec2/layers.py)."""
+        fe, proj, encoder = build_backbone_layers(self.config, self._sync_trainable)
+        backbone_attrs = dict(feature_extractor=fe, feature_projection=proj, encoder=encoder)
+        if self._with_lm_head:
+            backbone = BackboneLayer("wav2vec2", ["masked_spec_embed"], fe + [proj, encoder], self._sync_trainable,
+                                     config=self.config, **backbone_attrs)
+            dropout = Layer("dropout", on_change=self._sync_trainable, rate=self.config.dropout)
+            lm_head = Layer("lm_head", ["lm_head/"], on_change=self._sync_trainable)
+            Layer.__init__(self, self.name, (), [backbone, dropout, lm_head], self._sync_trainable)
+            self.model, self.dropout, self.lm_head = backbone, dropout, lm_head
+        else:
+            Layer.__init__(self, self.name, ["masked_spec_embed"], fe + [proj, encoder], self._sync_trainable)
+            self.__dict__.update(backbone_attrs)
+        attach(self, self._variables)
+
+    def _sync_trainable(self):
+        """Push the effective per-variable flags (own flag AND every layer above) to the native training state."""
+        for v in self._variables:
+            flag = v.trainable
+            if self._pushed_trainable.get(v.local_name, True) != flag:
+                N.check(self._lib.w2v2_set_trainable(self._handle, v.local_name.encode(), int(flag)), "w2v2_set_trainable")
+                self._pushed_trainable[v.local_name] = flag
 
     def __del__(self):
         try:
@@ -192,12 +276,40 @@ class TFKerasModel:
             self._dirty = False
 
     def set_trainable(self, name_prefix, trainable):
-        """Keras `.trainable` for every variable whose local name starts with `name_prefix`
-        (main.py:210,234-237 toggle whole sub-layers this way)."""
-        for v in self._variables:
-            if v.local_name.startswith(name_prefix):
-                v.trainable = bool(trainable)
-        N.check(self._lib.w2v2_set_trainable(self._handle, name_prefix.encode(), int(bool(trainable))), "w2v2_set_trainable")
+        """Set the own `.trainable` flag of every variable whose local name starts with `name_prefix` (a flat alternative to
+        the layer objects; the layers' own switches still gate the result)."""
+        hits = [v for v in self._variables if v.local_name.startswith(name_prefix)]
+        if not hits:
+            raise KeyError(f"set_trainable: no variable starts with `{name_prefix}`")
+        for v in hits:
+            v._own_trainable = bool(trainable)
+        self._sync_trainable()
+
+    def freeze_feature_extractor(self):
+        """Marks the 7 conv layers non-trainable (reference modeling.py:211-214)."""
+        for layer in self.feature_extractor if not self._with_lm_head else self.model.feature_extractor:
+            layer._trainable = False
+        self._sync_trainable()
+
+    def summary(self, print_fn=print):
+        """Keras-like one-line-per-layer summary (main.py:211,238 call it after changing the trainable set)."""
+        rows = [(l.name, l.count_params(), sum(int(np.prod(v.shape)) for v in l.trainable_variables)) for l in self._walk() if l is not self]
+        print_fn(f'Model: "{self.name}"')
+        for name, n, nt in rows:
+            print_fn(f"  {name:<48s} params {n:>12,d}   trainable {nt:>12,d}")
+        total = self.count_params()
+        tr = sum(int(np.prod(v.shape)) for v in self.trainable_variables)
+        print_fn(f"Total params: {total:,d}\nTrainable params: {tr:,d}\nNon-trainable params: {total - tr:,d}")
+
+    # ---- randomness of the training-mode forward ------------------------------------------------
+    def set_seed(self, seed):
+        """Seed of the model-level generator behind `model(x, training=True)`: dropout masks are a counter-based hash of
+        (seed, call number, site, element); spec-augment spans and stochastic-depth draws come from a host RandomState --
+        the reference draws both with numpy / TF global generators at call time (spec_augment.py:14,53;
+        tensorflow_addons.py:381)."""
+        self._seed = int(seed)
+        self._train_calls = 0
+        self._train_rng = np.random.RandomState(self._seed & 0xFFFFFFFF)
 
     # ---- arithmetic of the dense contractions --------------------------------
     PRECISIONS = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "mixed_bfloat16": 1, "bf16x3": 2}
@@ -218,43 +330,52 @@ class TFKerasModel:
         return {0: "fp32", 1: "bf16", 2: "bf16x3"}[self._lib.w2v2_get_precision(self._handle)]
 
     # ---- persistence (reference modeling.py:22-27, 41-84) -------------------
+    def _keras_layers(self, weights):
+        """[(layer_name, [(TF variable name, array)])] in the order of the reference model's `.layers` -- the grouping Keras'
+        HDF5 weight format uses (one group per top-level layer)."""
+        named = [(V.tf_variable_name(n, self._prefix_with_head), a) for n, a in weights.items()]
+        if not self._with_lm_head:
+            # Wav2Vec2Model: masked_spec_embed is the model's own weight; sub-layers follow in tracking order
+            return keras_layer_groups(self, weights, self._prefix_with_head)
+        head = [(n, a) for n, a in named if "/lm_head/" in n]
+        return [("wav2vec2", [(n, a) for n, a in named if "/lm_head/" not in n]), ("dropout", []), ("lm_head", head)]
+
     def save_weights(self, path):
-        arrays = {V.tf_variable_name(n, self._prefix_with_head): a for n, a in self.get_weights().items()}
-        if path.endswith(".h5"):
-            path = path[:-3] + ".npz"
-        np.savez(path, **arrays)
+        """`*.h5`: a Keras-layout HDF5 weight file written by the package's own HDF5 writer (wav2vec2/h5lite.py) -- the
+        container of the reference's `tf_model.h5` (modeling.py:26); `*.npz`: numpy archive keyed by TF variable names."""
+        weights = self.get_weights()
+        if path.endswith(".npz"):
+            np.savez(path, **{V.tf_variable_name(n, self._prefix_with_head): a for n, a in weights.items()})
+            return
+        from . import h5lite
+        h5lite.save_keras_weights(path, self._keras_layers(weights))
 
     def load_weights(self, path):
+        """Reads `tf_model.h5` (Keras HDF5 weight file; h5lite, no h5py needed) or a `.npz` of TF variable names.  Variables
+        are matched BY NAME (the TF variable names of convert_torch_to_tf.py:24-44), a missing one raises KeyError."""
         if path.endswith(".h5") and not os.path.exists(path) and os.path.exists(path[:-3] + ".npz"):
             path = path[:-3] + ".npz"
         if path.endswith(".npz"):
             with np.load(path) as z:
                 self.set_weights({k: z[k] for k in z.files})
             return
-        try:
-            import h5py  # noqa: F401
-        except ImportError as e:
-            raise NotImplementedError(
-                "reading Keras-HDF5 `tf_model.h5` needs h5py, which is not installed; "
-                "use the `tf_model.npz` written by save_pretrained") from e
-        import h5py
-        found = {}
-        with h5py.File(path, "r") as f:
-            def visit(name, obj):
-                if isinstance(obj, h5py.Dataset):
-                    found[name] = np.asarray(obj)
-            f.visititems(visit)
+        from . import h5lite
+        found = h5lite.load_keras_weights(path)
         ours = {}
         for n in self._specs:
             tfn = V.tf_variable_name(n, self._prefix_with_head)
-            hits = [k for k in found if k.endswith(tfn)]
+            hits = [k for k in found if k == tfn or k.endswith("/" + tfn)]
+            if not hits:
+                # a backbone file loaded into the CTC model (or the reverse): same variables under the other prefix
+                alt = V.tf_variable_name(n, not self._prefix_with_head)
+                hits = [k for k in found if k == alt or k.endswith("/" + alt)]
             if not hits:
                 raise KeyError(f"`{tfn}` not found in {path}")
             ours[n] = found[hits[0]]
         self.set_weights(ours)
 
     def save_pretrained(self, save_dir):
-        """config.json + weights, as reference modeling.py:22-27 (weights container: npz)."""
+        """config.json + `tf_model.h5`, as reference modeling.py:22-27."""
         self.config.save_pretrained(save_dir)
         self.save_weights(os.path.join(save_dir, "tf_model.h5"))
 
@@ -303,11 +424,41 @@ class TFKerasModel:
                 raise ValueError("`attention_mask` must have the shape of `batch`")
         return batch, attention_mask
 
+    def _train_forward(self, batch, attention_mask=None, dropout=None, apply_spec_augment=None, spec_mask=None, sd_keep=None,
+                       step_seed=None, rng=None):
+        """`call(training=True)` (reference modeling.py:169-209,239-255): Dropout at every Dropout layer, spec-augment on
+        the projected features when `config.apply_spec_augment`, StochasticDepth on the FFN branch.  Explicit `spec_mask`
+        / `sd_keep` / `step_seed` override the draws (parity tests feed the same masks to the oracle).  Saves what
+        `Trainer.backward` needs.  Returns (output, dict of the randomness used)."""
+        torch = _torch()
+        cfg = self.config
+        batch, attention_mask = self._prepare(batch, attention_mask)
+        B, L = batch.shape
+        T = self.num_frames(L)
+        if T < 1:
+            raise ValueError(f"input of {L} samples is shorter than the feature extractor's receptive field")
+        self._finalize()
+        rng = self._train_rng if rng is None else rng
+        p = cfg.dropout if dropout is None else dropout
+        spec_on = cfg.apply_spec_augment if apply_spec_augment is None else apply_spec_augment
+        if spec_mask is None and spec_on:
+            spec_mask = compute_mask_indices((B, T), cfg.mask_time_prob, cfg.mask_time_length, min_masks=2, rng=rng)
+        if sd_keep is None and cfg.survival_prob < 1.0:
+            # one Bernoulli scalar per StochasticDepth call (tensorflow_addons.py:381)
+            sd_keep = (rng.uniform(size=cfg.num_layers) < cfg.survival_prob).astype(np.float32)
+        sm = None if spec_mask is None else np.ascontiguousarray(spec_mask, dtype=np.uint8).reshape(-1)
+        sd = None if sd_keep is None else np.ascontiguousarray(sd_keep, dtype=np.float32)
+        if step_seed is None:
+            step_seed = self._seed * 1000003 + self._train_calls
+            self._train_calls += 1
+        seed = int(step_seed) & 0xFFFFFFFFFFFFFFFF
+        width = cfg.vocab_size if self._with_lm_head else cfg.hidden_size
+        out = torch.empty((B, T, width), device=batch.device, dtype=torch.float32)
+        N.check(self._lib.w2v2_train_forward(self._handle, N.ptr(batch), B, L, N.ptr(attention_mask), N.ptr(sm), N.ptr(sd),
+                                             float(p), C.c_uint64(seed), N.ptr(out), N.current_stream()), "w2v2_train_forward")
+        return out, dict(spec_mask=spec_mask, sd_keep=sd_keep, seed=seed)
+
     def _forward(self, batch, attention_mask, training, out_channels):
-        if training:
-            raise NotImplementedError(
-                "the training-mode forward (dropout, spec-augment, stochastic depth) needs a seed and host-drawn "
-                "masks: use wav2vec2.Trainer(model, loss).forward / .step instead of model(x, training=True)")
         # the tuple call convention of the reference's fixed-length export wrappers (export2hub.py:40-57):
         # model((speech, attention_mask))
         if isinstance(batch, tuple) and len(batch) == 2 and attention_mask is None:
@@ -317,6 +468,9 @@ class TFKerasModel:
             logger.warning("You should pass `attention_mask` when working with Wav2Vec2 new checkpoints")
         elif not self.config.is_robust and attention_mask is not None:
             logger.warning("You should not pass `attention_mask` when working with checkpoints based on `wav2vec2-base`")
+        if training:
+            out, self.last_training_call = self._train_forward(batch, attention_mask)
+            return DeviceTensor.wrap(out)
         torch = _torch()
         batch, attention_mask = self._prepare(batch, attention_mask)
         B, L = batch.shape
@@ -397,10 +551,6 @@ class Wav2Vec2Model(TFKerasModel):
 
     call = __call__
 
-    def freeze_feature_extractor(self):
-        """Marks the 7 conv layers non-trainable (reference modeling.py:211-214)."""
-        self.set_trainable("feature_extractor/", False)
-
 
 class Wav2Vec2ForCTC(TFKerasModel):
     """Backbone + dropout (identity at inference) + ``lm_head`` Dense(H -> vocab)
@@ -422,6 +572,3 @@ class Wav2Vec2ForCTC(TFKerasModel):
         return self._forward(batch, attention_mask, training, self.config.vocab_size)
 
     call = __call__
-
-    def freeze_feature_extractor(self):
-        self.set_trainable("feature_extractor/", False)

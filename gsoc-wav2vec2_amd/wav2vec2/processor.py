@@ -1,18 +1,40 @@
-"""Wav2Vec2Processor -- host pre/post-processing (reference ``processor.py``).
+"""Wav2Vec2Processor -- host pre/post-processing (reference ``src/wav2vec2/processor.py``).
 
-``is_tokenizer=False``: zero-mean / unit-variance normalisation of the
-waveform, to be applied BEFORE padding (processor.py:101-106).
-``is_tokenizer=True``: the character tokenizer and the greedy CTC collapse
-decode (processor.py:52-94).  Pure host code: numpy for arrays, torch ops for
-torch tensors; nothing here touches the HIP library.
+Two roles behind one constructor, as in the reference (processor.py:9-35):
+
+``is_tokenizer=False``  waveform normaliser: zero mean / unit variance along the last axis with the
+                        population variance and eps 1e-5, applied BEFORE padding (processor.py:101-106).
+``is_tokenizer=True``   character tokenizer for CTC labels and the greedy CTC collapse decode
+                        (processor.py:52-94): text is upper-cased, ``-`` counts as a space, only
+                        ``A-Z``, ``'`` and space survive, a space is written as the word delimiter ``|``;
+                        decoding merges repeats, drops ``<pad>`` (the CTC blank) and turns ``|`` back into
+                        a space.
+
+Kept from the reference because callers depend on it: the constructor signature, ``__call__``,
+``decode(ids, skip_special_tokens=True, group_tokens=True)`` and the ``vocab.json`` format
+(token -> id).  Everything else is this build's own: the tokenizer is a single pass over a 256-entry
+character table, the decoder a single pass over the ids.  Pure host code; nothing here touches the HIP
+library.
 """
 
 import json
 import os
-import re
-from itertools import groupby
 
 import numpy as np
+
+PAD_TOKEN, UNK_TOKEN, WORD_DELIMITER = "<pad>", "<unk>", "|"
+
+
+def _character_table():
+    """chr -> token (or None = dropped) for the tokenizer's alphabet (processor.py:91-94)."""
+    table = {}
+    for code in range(ord("A"), ord("Z") + 1):
+        table[chr(code)] = chr(code)
+        table[chr(code).lower()] = chr(code)
+    table["'"] = "'"
+    table[" "] = WORD_DELIMITER
+    table["-"] = WORD_DELIMITER           # a hyphen separates words
+    return table
 
 
 class Wav2Vec2Processor:
@@ -20,53 +42,75 @@ class Wav2Vec2Processor:
         self.is_tokenizer = is_tokenizer
         self.do_normalize = do_normalize
         self.vocab_path = vocab_path
+        if is_tokenizer:
+            self._load_vocab()
 
-        if self.is_tokenizer:
-            self._setup_vocab()
-            self.token_to_id_mapping = self.get_vocab()
-            self.id_to_token_mapping = {v: k for k, v in self.token_to_id_mapping.items()}
-            self.unk_token = "<unk>"
-            self.unk_id = self.token_to_id_mapping[self.unk_token]
-            self.dimiliter_token = "|"
-            self.dimiliter_id = self.token_to_id_mapping[self.dimiliter_token]
-            special_tokens = ["<pad>"]
-            self.special_ids = [self.token_to_id_mapping[k] for k in special_tokens]
-
-    def _setup_vocab(self):
-        # the reference downloads vocab.json when absent (processor.py:37-50); no network here
+    # ---- vocabulary ------------------------------------------------------------------------------
+    def _load_vocab(self):
+        # the reference fetches vocab.json over HTTP when the file is absent (processor.py:37-50); no network here
         if not os.path.isfile(self.vocab_path):
             raise ValueError(f"Couldn't find `vocab.json` at {self.vocab_path} (and there is no network to fetch it)")
-
-    def __call__(self, input_values):
-        if self.is_tokenizer:
-            tokens = self._tokenize(input_values)
-            return [self.token_to_id_mapping.get(k, self.unk_id) for k in tokens]
-        if self.do_normalize:
-            input_values = self._normalize(input_values)
-        return input_values
-
-    def decode(self, input_ids, skip_special_tokens=True, group_tokens=True):
-        input_ids = [int(i) for i in input_ids]
-        if group_tokens:
-            input_ids = [t[0] for t in groupby(input_ids)]
-        if skip_special_tokens:
-            input_ids = [k for k in input_ids if k not in self.special_ids]
-        tokens = [self.id_to_token_mapping.get(k, self.unk_token) for k in input_ids]
-        tokens = [k if k != self.dimiliter_token else " " for k in tokens]
-        return "".join(tokens).strip()
-
-    def _tokenize(self, string: str):
-        string = re.sub("-", " ", string)
-        string = re.sub("[^A-Z' ]", "", string.upper())
-        return list(string.replace(" ", self.dimiliter_token))
+        vocab = self.get_vocab()
+        for needed in (PAD_TOKEN, UNK_TOKEN, WORD_DELIMITER):
+            if needed not in vocab:
+                raise ValueError(f"`{self.vocab_path}` has no `{needed}` entry")
+        self._vocab = vocab
+        self._unk = vocab[UNK_TOKEN]
+        self._blank = vocab[PAD_TOKEN]
+        # text side: one lookup per character straight to an id
+        chars = _character_table()
+        self._char_to_id = {ch: vocab.get(tok, self._unk) for ch, tok in chars.items()}
+        # id side: id -> output text, with the delimiter already mapped to a space
+        self._id_to_text = {i: (" " if tok == WORD_DELIMITER else tok) for tok, i in vocab.items()}
 
     def get_vocab(self):
+        """token -> id, as stored in ``vocab.json``."""
         with open(self.vocab_path, "r") as f:
             return json.load(f)
 
+    # ---- call ------------------------------------------------------------------------------------
+    def __call__(self, input_values):
+        """tokenizer: text -> list of label ids;  otherwise: waveform -> normalised waveform."""
+        if self.is_tokenizer:
+            return self._encode(input_values)
+        return self._normalize(input_values) if self.do_normalize else input_values
+
+    def _encode(self, text):
+        lookup = self._char_to_id
+        out = []
+        for ch in text:
+            if ch in lookup:
+                out.append(lookup[ch])
+            elif not ch.isascii():
+                # str.upper() of a few non-ASCII letters lands in A-Z (e.g. the sharp s becomes "SS", the dotless i becomes "I")
+                # and the reference upper-cases before filtering: follow it
+                out.extend(lookup[u] for u in ch.upper() if "A" <= u <= "Z")
+        return out
+
+    def _tokenize(self, text):
+        """The token strings behind ``__call__`` (for callers that want characters rather than ids)."""
+        by_id = {i: tok for tok, i in self._vocab.items()}
+        return [by_id[i] for i in self._encode(text)]
+
+    # ---- decode ----------------------------------------------------------------------------------
+    def decode(self, input_ids, skip_special_tokens=True, group_tokens=True):
+        """Greedy CTC decode of a frame-level id sequence: merge runs of equal ids (``group_tokens``), drop the blank
+        ``<pad>`` (``skip_special_tokens``), map ids to characters (unknown ids print as ``<unk>``), ``|`` -> space,
+        strip the ends."""
+        pieces = []
+        previous = None
+        for raw in input_ids:
+            i = int(raw)
+            repeated = group_tokens and i == previous
+            previous = i
+            if repeated or (skip_special_tokens and i == self._blank):
+                continue
+            pieces.append(self._id_to_text.get(i, UNK_TOKEN))
+        return "".join(pieces).strip()
+
+    # ---- normaliser ------------------------------------------------------------------------------
     def _normalize(self, x):
-        """(x - mean) / sqrt(var + 1e-5) along the last axis, population
-        variance, then squeeze.  Call before padding."""
+        """(x - mean) / sqrt(var + 1e-5) along the last axis, population variance, then squeeze.  Call before padding."""
         try:
             import torch
             if isinstance(x, torch.Tensor):

@@ -17,7 +17,17 @@ import ctypes as C
 import numpy as np
 
 from . import _native as N
-from .spec_augment import compute_mask_indices
+from . import dist as D
+
+
+def _world_rank():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(), dist.get_rank()
+    except ImportError:  # pragma: no cover
+        pass
+    return 1, 0
 
 
 class _DeviceBuffer:
@@ -35,44 +45,46 @@ def stage2_learning_rate(epoch, lr1=1e-4, lr2=5e-5, transition_epochs=10):
 
 
 class Trainer:
+    """One optimizer over one model.  Like `tf.keras.optimizers.Adam(...)` + `model.compile` in the reference, creating a
+    Trainer starts a FRESH optimizer: iteration 0 and zero moments (src/main.py:213,240 build a new Adam for each of the
+    two stages) -- pass `reset_optimizer=False` to adopt the moments already in the model (resume via `load_state_dict`).
+
+    Randomness is per data-parallel rank, as under MirroredStrategy where every replica draws its own dropout and
+    spec-augment masks: the effective seed is `seed * world_size + rank` (kept in `state_dict`, so resume stays exact).
+
+    `allreduce_dtype`: "fp32" (default) or "bf16" -- the gradient payload of the data-parallel all-reduce."""
+
     def __init__(self, model, loss, learning_rate=1e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-7, seed=0,
-                 dropout=None, apply_spec_augment=None, overlap_all_reduce=True):
+                 dropout=None, apply_spec_augment=None, overlap_all_reduce=True, reset_optimizer=True, allreduce_dtype="fp32"):
         if not getattr(model, "_with_lm_head", False):
             raise ValueError("Trainer needs a Wav2Vec2ForCTC model")
+        if allreduce_dtype not in ("fp32", "bf16"):
+            raise ValueError("allreduce_dtype must be 'fp32' or 'bf16'")
         self.model, self.loss = model, loss
         self.learning_rate, self.beta_1, self.beta_2, self.epsilon = learning_rate, beta_1, beta_2, epsilon
         cfg = model.config
         self.dropout = cfg.dropout if dropout is None else dropout
         self.apply_spec_augment = cfg.apply_spec_augment if apply_spec_augment is None else apply_spec_augment
-        self.seed = int(seed)
+        world, rank = _world_rank()
+        self.base_seed = int(seed)
+        self.seed = int(seed) * world + rank              # rank-aware: replicas draw independent masks
         self.iterations = 0                               # Keras optimizer.iterations
-        self._rng = np.random.RandomState(seed)           # host RNG: spec-augment spans, stochastic depth
+        self._rng = np.random.RandomState(self.seed & 0xFFFFFFFF)    # host RNG: spec-augment spans, stochastic depth
         self.last = {}
         self.overlap_all_reduce = bool(overlap_all_reduce)   # per-bucket all-reduces under the backward (all_reduce_gradients)
+        self.allreduce_dtype = allreduce_dtype
         self._comm_stream = None
+        if reset_optimizer:
+            N.check(model._lib.w2v2_adam_reset(model._handle, N.current_stream()), "w2v2_adam_reset")
 
     # -- pieces (also used by the parity tests) ----------------------------------------------------
     def forward(self, batch, attention_mask=None, spec_mask=None, sd_keep=None, step_seed=None):
-        import torch
-        m = self.model
-        batch, attention_mask = m._prepare(batch, attention_mask)
-        B, L = batch.shape
-        T = m.num_frames(L)
-        m._finalize()
-        cfg = m.config
-        if spec_mask is None and self.apply_spec_augment:
-            spec_mask = compute_mask_indices((B, T), cfg.mask_time_prob, cfg.mask_time_length, min_masks=2, rng=self._rng)
-        if sd_keep is None and cfg.survival_prob < 1.0:
-            # one Bernoulli scalar per StochasticDepth call (tensorflow_addons.py:381)
-            sd_keep = (self._rng.uniform(size=cfg.num_layers) < cfg.survival_prob).astype(np.float32)
-        sm = None if spec_mask is None else np.ascontiguousarray(spec_mask, dtype=np.uint8).reshape(-1)
-        sd = None if sd_keep is None else np.ascontiguousarray(sd_keep, dtype=np.float32)
+        """Training-mode forward = `model(batch, attention_mask, training=True)` with this trainer's dropout rate, host RNG
+        and step-derived seed (explicit `spec_mask` / `sd_keep` / `step_seed` override the draws)."""
         seed = self.seed * 1000003 + self.iterations if step_seed is None else int(step_seed)
-        logits = torch.empty((B, T, cfg.vocab_size), device=batch.device, dtype=torch.float32)
-        N.check(m._lib.w2v2_train_forward(m._handle, N.ptr(batch), B, L, N.ptr(attention_mask), N.ptr(sm), N.ptr(sd),
-                                          float(self.dropout), C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), N.ptr(logits),
-                                          N.current_stream()), "w2v2_train_forward")
-        self.last = dict(spec_mask=spec_mask, sd_keep=sd_keep, seed=seed & 0xFFFFFFFFFFFFFFFF)
+        logits, self.last = self.model._train_forward(batch, attention_mask, dropout=self.dropout,
+                                                      apply_spec_augment=self.apply_spec_augment, spec_mask=spec_mask,
+                                                      sd_keep=sd_keep, step_seed=seed, rng=self._rng)
         return logits
 
     def backward(self, grad_logits):
@@ -106,38 +118,61 @@ class Trainer:
             out.append((off.value, n.value))
         return out
 
+    def gradient_slot(self, local_name):
+        """(offset, numel) of a variable's slot in the flat gradient buffer."""
+        off, n = C.c_int64(), C.c_int64()
+        N.check(self.model._lib.w2v2_grad_slot(self.model._handle, local_name.encode(), C.byref(off), C.byref(n)), "w2v2_grad_slot")
+        return off.value, n.value
+
+    def reduce_ranges(self):
+        """Per gradient bucket (completion order) the [(offset, numel)] runs of TRAINABLE variables that are sent: frozen slots
+        (the 4.2 M conv-stack elements in stage 2; everything but lm_head in stage 1) are zero on every rank and stay home.
+        For wav2vec2-base in stage 2 that is the reference's 90,195,104-element payload (+ masked_spec_embed), 360.8 MB fp32."""
+        m = self.model
+        layout, _ = D.flat_layout(m._specs)
+        trainable = {v.local_name for v in m.trainable_variables}
+        return [D.trainable_ranges(layout, bk, trainable) for bk in self.gradient_buckets()]
+
     def all_reduce_gradients(self, force=False):
         """SUM over data-parallel ranks: the loss is pre-divided by the global batch (losses.py:45,
         main.py:198-200), so the sum is the global mean.
 
-        Called right after `backward` -- which only ENQUEUES the backward kernels -- this issues one RCCL all-reduce per
-        gradient bucket on a communication stream that waits for that bucket alone (an event the backward records when
-        the bucket's slice is final), so the collectives of the upper layers run under the backward of the lower ones;
+        Called right after `backward` -- which only ENQUEUES the backward kernels -- this issues the RCCL all-reduces of one
+        gradient bucket at a time on a communication stream that waits for that bucket alone (an event the backward records
+        when the bucket's slice is final), so the collectives of the upper layers run under the backward of the lower ones;
         the calling stream then waits for all of them.  A layer of wav2vec2-base is a 28 MB bucket (large: 50 MB): big
-        enough for the ring to run at link speed over xGMI, small enough that only the last one is exposed.
-        `overlap_all_reduce=False` (constructor) falls back to a single all-reduce of the whole buffer."""
+        enough for the ring to run at link speed over xGMI, small enough that only the last one is exposed.  Only trainable
+        slots travel (`reduce_ranges`); `allreduce_dtype="bf16"` halves the payload.
+        `overlap_all_reduce=False` (constructor) issues the same ranges after the whole backward on the calling stream."""
         import torch
         import torch.distributed as dist
         active = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)
         if not active:
             return
         buf = self.grad_buffer()
+        payload = torch.bfloat16 if self.allreduce_dtype == "bf16" else None
+        ranges = self.reduce_ranges()
         if not self.overlap_all_reduce:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            for runs in ranges:
+                for off, n in runs:
+                    D.all_reduce_range(buf, off, n, payload)()
             return
         m = self.model
         if self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream()
         cs = self._comm_stream
-        works = []
-        for k, (off, n) in enumerate(self.gradient_buckets()):
-            if n == 0:
+        finishers = []
+        for k, runs in enumerate(ranges):
+            if not runs:
                 continue
             N.check(m._lib.w2v2_train_bucket_wait(m._handle, k, C.c_void_p(cs.cuda_stream)), "w2v2_train_bucket_wait")
             with torch.cuda.stream(cs):
-                works.append(dist.all_reduce(buf[off:off + n], op=dist.ReduceOp.SUM, async_op=True))
-        for w in works:
-            w.wait()              # the current stream (optimizer step next) waits for the collectives
+                for off, n in runs:
+                    finishers.append(D.all_reduce_range(buf, off, n, payload, async_op=True))
+        with torch.cuda.stream(cs):
+            for f in finishers:
+                f()               # (a compressed payload is copied back on the communication stream)
+        torch.cuda.current_stream().wait_stream(cs)      # the optimizer step next waits for the collectives
 
     def apply_gradients(self):
         m = self.model
@@ -160,38 +195,30 @@ class Trainer:
         """Everything a resumed run needs besides the model's variables (`model.save_weights` / `save_pretrained`): the
         optimizer step count, Adam's moments, the hyper-parameters and the host RNG that draws spec-augment spans and
         stochastic-depth decisions.  The reference's per-epoch ModelCheckpoint (training_utils.py:38-45) is the analogue."""
-        state = dict(iterations=int(self.iterations), learning_rate=float(self.learning_rate), beta_1=float(self.beta_1),
-                     beta_2=float(self.beta_2), epsilon=float(self.epsilon), seed=int(self.seed), rng=self._rng.get_state())
-        if self.iterations > 0:
-            am, av = self._adam_views()
-            state["adam_m"], state["adam_v"] = am.cpu().numpy(), av.cpu().numpy()
-        return state
+        am, av = self._adam_views()
+        return dict(iterations=int(self.iterations), learning_rate=float(self.learning_rate), beta_1=float(self.beta_1),
+                    beta_2=float(self.beta_2), epsilon=float(self.epsilon), seed=int(self.seed), base_seed=int(self.base_seed),
+                    rng=self._rng.get_state(), adam_m=am.cpu().numpy(), adam_v=av.cpu().numpy())
 
     def load_state_dict(self, state, batch_shape=None):
-        """Inverse of `state_dict`.  The moment buffers live in the model's training state, which is sized at the first
-        training forward: pass `batch_shape=(B, L)` (any shape; it only triggers the allocation) when loading into a
-        trainer that has not run a step yet."""
+        """Inverse of `state_dict`.  A state without moments (e.g. one written before any step) zeroes them, so stale
+        moments of an earlier optimizer never leak into the resumed run.  (`batch_shape` is accepted for compatibility:
+        the moment buffers no longer depend on a batch shape.)"""
         import torch
-        views = None
+        views = self._adam_views()
         if "adam_m" in state:
-            try:
-                views = self._adam_views()
-            except Exception:
-                if batch_shape is None:
-                    raise
-                B, L = batch_shape                       # allocate the training state (before the host RNG is restored:
-                self.forward(torch.zeros((B, L), device="cuda"), step_seed=0)      # this forward may draw spec-augment spans)
-                views = self._adam_views()
             if views[0].numel() != state["adam_m"].size:
                 raise ValueError("optimizer state belongs to a different model (moment buffer size mismatch)")
+            for dst, key in zip(views, ("adam_m", "adam_v")):
+                dst.copy_(torch.from_numpy(np.ascontiguousarray(state[key], np.float32)).to(dst.device))
+        else:
+            N.check(self.model._lib.w2v2_adam_reset(self.model._handle, N.current_stream()), "w2v2_adam_reset")
         self.iterations = int(state["iterations"])
         for k in ("learning_rate", "beta_1", "beta_2", "epsilon"):
             setattr(self, k, float(state[k]))
         self.seed = int(state["seed"])
+        self.base_seed = int(state.get("base_seed", self.seed))
         self._rng.set_state(state["rng"])
-        if views is not None:
-            for dst, key in zip(views, ("adam_m", "adam_v")):
-                dst.copy_(torch.from_numpy(np.ascontiguousarray(state[key], np.float32)).to(dst.device))
 
     # -- the step ------------------------------------------------------------------------------------
     def step(self, batch, labels, attention_mask=None):

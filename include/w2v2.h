@@ -70,6 +70,9 @@ typedef struct w2v2_model w2v2_model;
 
 const char* w2v2_last_error(void);
 const char* w2v2_version(void);
+/* Free the library-owned per-(device, stream) scratch buffers (split-K slabs, CTC alpha / beta) of the calling thread's
+ * current device; they are otherwise kept, grow-only, for the life of the process.  The device must be idle. */
+int w2v2_release_scratch(void);
 
 /* ---- model lifetime ------------------------------------------------------
  * Replaces Wav2Vec2Model.__init__ / Wav2Vec2ForCTC.__init__
@@ -184,9 +187,16 @@ int w2v2_grad_buffer(w2v2_model* m, float** dev_ptr, int64_t* numel);
 int w2v2_train_num_buckets(const w2v2_model* m);
 int w2v2_train_bucket(w2v2_model* m, int32_t k, int64_t* offset, int64_t* numel);
 int w2v2_train_bucket_wait(w2v2_model* m, int32_t k, void* stream);
+/* Slot [offset, offset + numel) of one variable in the flat gradient / Adam buffers (inventory order, 16-byte aligned slots):
+ * lets the caller send only the trainable runs of a bucket (the reference's payload excludes the frozen conv stack). */
+int w2v2_grad_slot(w2v2_model* m, const char* name, int64_t* offset, int64_t* numel);
 /* Adam's moment buffers (device, flat, same layout as the gradient buffer): what a training checkpoint must carry besides
  * the variables and the step count (the reference's ModelCheckpoint writes a TF checkpoint, training_utils.py:38-45). */
 int w2v2_adam_buffers(w2v2_model* m, float** m_dev, float** v_dev, int64_t* numel);
+/* A fresh optimizer: zero both moment buffers.  The reference creates a new tf.keras.optimizers.Adam for each of its two
+ * stages (src/main.py:213,240); the moments live in the model's training state here, so whoever starts a new optimizer
+ * (a new Trainer, or a checkpoint without moments) calls this. */
+int w2v2_adam_reset(w2v2_model* m, void* stream);
 int w2v2_get_grad(w2v2_model* m, const char* name, float* host_dst, int64_t numel, void* stream);
 int w2v2_adam_step(w2v2_model* m, float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
 

@@ -79,3 +79,114 @@ def test_two_rank_sharded_forward_matches_unsharded(tmp_path, total_rows):
     # batch rows are independent: sharding must not change a single bit of any row's result
     assert np.array_equal(got, ref)
     assert np.load(tmp_path / "slowest.npy")[0] == 2.0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The training collective (reference src/main.py:156,198-200 + losses.py:45): every replica divides its loss by
+# the GLOBAL batch, gradients are SUMmed across replicas.  Two gloo ranks take a 2 + 2 split of a 4-row batch through the
+# training oracle with division_factor = 4, lay their gradients out in the flat buffer the HIP library uses, and reduce it
+# with the SAME bucket / trainable-range / all-reduce code the Trainer runs over RCCL (wav2vec2/dist.py) -- the result must
+# equal the unsharded gradients.
+# ---------------------------------------------------------------------------------------------------------------
+def _flat_from_grads(layout, total, grads, frozen_fill):
+    buf = np.full(total, frozen_fill, dtype=np.float64)
+    for name, (off, n) in layout.items():
+        if name in grads:
+            g = grads[name]
+            buf[off:off + ((n + 3) & ~3)] = 0.0
+            if g is not None:
+                buf[off:off + n] = np.asarray(g, np.float64).reshape(-1)
+    return buf
+
+
+def _grad_worker(rank, world, port, out_dir, payload):
+    for p in (ROOT, os.path.join(ROOT, "gsoc-wav2vec2_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import helpers as HH
+    from oracle import w2v2_torch_train as TT
+    from wav2vec2 import dist as DD
+    from wav2vec2 import variables as V
+    torch.set_num_threads(1)
+    DD.init(backend="gloo")
+    cfg, weights = HH.case_config("tiny_base"), HH.case_weights("tiny_base")
+    total_rows = 4
+    x = V.hash_normal("dist/train_wave", total_rows * 4000, 9).reshape(total_rows, 4000)
+    labels = np.array([[3, 4, 9, 0], [5, 5, 0, 0], [7, 1, 2, 2], [30, 0, 0, 0]], np.int32)
+    lo, hi = DD.shard_bounds(total_rows, world, rank)
+    loss, _, _, grads = TT.loss_and_grads(cfg, weights, x[lo:hi], labels[lo:hi], division_factor=total_rows)
+    specs = V.variable_specs(cfg)
+    layout, total = DD.flat_layout(specs)
+    buf = torch.from_numpy(_flat_from_grads(layout, total, grads, frozen_fill=7.0))      # 7.0 marks frozen slots
+    if payload == "bf16":
+        buf = buf.float()
+    trainable = set(grads)                                              # everything but the conv stack
+    sent = 0
+    finishers = []
+    for bucket in DD.gradient_buckets(layout, total, cfg.num_layers):
+        for off, n in DD.trainable_ranges(layout, bucket, trainable):
+            finishers.append(DD.all_reduce_range(buf, off, n, torch.bfloat16 if payload == "bf16" else None, async_op=True))
+            sent += n
+    for f in finishers:
+        f()
+    loss_sum = DD.max_over_ranks(0.0)                                    # (exercise the helper under this group too)
+    t = torch.tensor([loss], dtype=torch.float64)
+    torch.distributed.all_reduce(t)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "reduced.npy"), buf.double().numpy())
+        np.save(os.path.join(out_dir, "meta.npy"), np.array([sent, float(t.item()), loss_sum]))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("payload", ["fp32", "bf16"])
+def test_two_rank_gradient_all_reduce_equals_unsharded(tmp_path, payload):
+    from oracle import w2v2_torch_train as TT
+    from wav2vec2 import variables as V
+    world = 2
+    mp.spawn(_grad_worker, args=(world, _free_port(), str(tmp_path), payload), nprocs=world, join=True)
+    cfg, weights = H.case_config("tiny_base"), H.case_weights("tiny_base")
+    x = V.hash_normal("dist/train_wave", 4 * 4000, 9).reshape(4, 4000)
+    labels = np.array([[3, 4, 9, 0], [5, 5, 0, 0], [7, 1, 2, 2], [30, 0, 0, 0]], np.int32)
+    loss, _, _, grads = TT.loss_and_grads(cfg, weights, x, labels, division_factor=4)
+    specs = V.variable_specs(cfg)
+    layout, total = D.flat_layout(specs)
+    want = _flat_from_grads(layout, total, grads, frozen_fill=7.0)
+    got = np.load(tmp_path / "reduced.npy")
+    sent, loss_sum, _ = np.load(tmp_path / "meta.npy")
+    # the summed per-rank losses (each / global batch) are the global loss
+    assert abs(loss_sum - loss) < 1e-9 * abs(loss)
+    frozen = np.ones(total, bool)
+    for name, (off, n) in layout.items():
+        if name in grads:
+            frozen[off:off + ((n + 3) & ~3)] = False
+    # frozen conv-stack slots never travelled: still the marker on rank 0 (a SUM would have made them 14)
+    assert np.all(got[frozen] == 7.0)
+    trainable_elems = sum(n for name, (off, n) in layout.items() if name in grads)
+    assert trainable_elems <= sent < trainable_elems + 4 * len(grads)          # payload = trainable slots (+ alignment pads)
+    scale = np.abs(want[~frozen]).max()
+    err = np.abs(got[~frozen] - want[~frozen]).max()
+    if payload == "fp32":
+        assert err < 1e-12 * max(1.0, scale), err
+    else:
+        assert err < 2e-2 * scale, (err, scale)                                 # two bf16 roundings of the payload
+
+
+def test_bucket_layout_tiles_the_buffer():
+    from wav2vec2 import variables as V
+    for case in ("tiny_base", "base_sample_padded", "robust_masked"):
+        cfg = H.case_config(case)
+        layout, total = D.flat_layout(V.variable_specs(cfg))
+        buckets = D.gradient_buckets(layout, total, cfg.num_layers)
+        assert len(buckets) == cfg.num_layers + 2
+        spans = sorted(buckets)
+        assert spans[0][0] == 0 and spans[-1][0] + spans[-1][1] == total
+        assert all(a[0] + a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert buckets[0][0] == layout["lm_head/kernel"][0]
+        trainable = {n for n in layout if not n.startswith("feature_extractor/")}
+        sent = sum(n for bk in buckets for _, n in D.trainable_ranges(layout, bk, trainable))
+        if case == "base_sample_padded":
+            # the reference's stage-2 payload: 90,195,104 trainable elements + masked_spec_embed's 768
+            assert sent == 90195104 + 768
+            assert total - sent == 4200448                                    # the frozen conv stack stays home

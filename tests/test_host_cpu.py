@@ -237,10 +237,12 @@ def test_convert_hf_checkpoint_directory(tmp_path, fmt):
     got_cfg = convert_hf_checkpoint(src, out)
     assert got_cfg == cfg
     assert Wav2Vec2Config.from_json(os.path.join(out, "config.json")) == Wav2Vec2Config(**{k: getattr(cfg, k) for k in cfg.__dataclass_fields__})
-    with np.load(os.path.join(out, "tf_model.npz")) as z:
-        assert set(z.files) == {V.tf_variable_name(n) for n in w}
-        for n, a in w.items():
-            assert np.array_equal(z[V.tf_variable_name(n)], a), n
+    from wav2vec2 import h5lite
+    z = h5lite.load_keras_weights(os.path.join(out, "tf_model.h5"))         # the reference's container (modeling.py:26)
+    assert set(z) == {V.tf_variable_name(n) for n in w}
+    for n, a in w.items():
+        assert np.array_equal(z[V.tf_variable_name(n)], a), n
+    assert [x.decode() for x in h5lite.File(os.path.join(out, "tf_model.h5")).root.attrs["layer_names"]] == ["wav2vec2", "dropout", "lm_head"]
 
 
 def test_stage2_learning_rate_schedule():
@@ -349,3 +351,94 @@ def test_tfrecord_file_roundtrip_and_corruption(tmp_path):
         list(T.read_dataset(path))
     with pytest.raises(ValueError):                                    # dtype check of parse_tensor(out_type=...)
         T.parse_tensor(T.serialize_tensor(np.zeros(3, np.int32)), np.float32)
+
+
+# ---- the Keras object graph callers touch (src/main.py:210,232-237) -----------------------------------
+class _FakeLib:
+    """Records what would be pushed to the native training state (no GPU here)."""
+
+    def __init__(self):
+        self.flags = {}
+
+    def w2v2_set_trainable(self, handle, name, flag):
+        self.flags[name.decode()] = bool(flag)
+        return 0
+
+
+def _graph_only_model(cls, config):
+    """The model's host-side object graph without the native library: what `_build_native` does after `w2v2_create`."""
+    from wav2vec2 import modeling as M
+    m = object.__new__(cls)
+    m.name = "wav2vec2-ctc" if cls._with_lm_head else "wav2vec2"
+    m.config = config
+    m._lib, m._handle = _FakeLib(), None
+    m._specs = V.variable_specs(config, with_lm_head=cls._with_lm_head)
+    m._variables = [M.Variable(m, n, s) for n, (s, _) in m._specs.items()]
+    m._pushed_trainable = {}
+    m._build_layers()
+    return m
+
+
+def test_reference_two_stage_freezing_runs_verbatim_on_the_layer_graph():
+    import wav2vec2
+    cfg = wav2vec2.Wav2Vec2Config()
+    model = _graph_only_model(wav2vec2.Wav2Vec2ForCTC, cfg)
+    n_all = len(model.variables)
+    assert n_all == 213 and [l.name for l in model.layers] == ["wav2vec2", "dropout", "lm_head"]
+    backbone = model.layers[0]
+    # Keras tracking order of Wav2Vec2Model's attributes: 7 conv layers, feature_projection, encoder (modeling.py:123-158)
+    assert [l.name for l in backbone.layers] == [f"feature_extractor/conv_layers/{i}" for i in range(7)] + ["feature_projection", "encoder"]
+    assert backbone.feature_extractor == backbone.layers[:7] and backbone.encoder is backbone.layers[-1]
+    assert sum(len(l.variables) for l in model.layers) == n_all and model.count_params() == 94_396_320
+
+    # ---- STAGE 1, src/main.py:210 verbatim ----
+    model.layers[0].trainable = False
+    assert [v.local_name for v in model.trainable_variables] == ["lm_head/kernel", "lm_head/bias"]
+    assert model._lib.flags["masked_spec_embed"] is False and model._lib.flags["encoder/layers/11/attention/q_proj/kernel"] is False
+    assert "lm_head/kernel" not in model._lib.flags                  # never changed: stays trainable natively
+
+    # ---- STAGE 2, src/main.py:232-237 verbatim ----
+    model.trainable = True
+    for i in range(len(model.layers[0].layers) - 2):
+        model.layers[0].layers[i].trainable = False
+    frozen = [v for v in model.variables if not v.trainable]
+    assert len(frozen) == 9 and all(v.local_name.startswith("feature_extractor/") for v in frozen)
+    assert sum(int(np.prod(v.shape)) for v in frozen) == 4_200_448    # SURVEY a-16: the frozen conv stack
+    assert sum(int(np.prod(v.shape)) for v in model.trainable_variables) == 90_195_104 + 768
+    assert model._lib.flags["encoder/layers/11/attention/q_proj/kernel"] is True
+    assert model._lib.flags["feature_extractor/conv_layers/3/conv/kernel"] is False
+    assert not backbone.layers[0].trainable and backbone.layers[7].trainable and backbone.trainable
+
+    # freeze_feature_extractor (modeling.py:211-214) is the same set
+    other = _graph_only_model(wav2vec2.Wav2Vec2ForCTC, cfg)
+    other.freeze_feature_extractor()
+    assert {v.local_name for v in other.variables if not v.trainable} == {v.local_name for v in frozen}
+    other.model.freeze_feature_extractor()                             # the reference's ForCTC delegates to `self.model`
+
+    # Keras semantics: a frozen parent gates its children even if a child is switched back on
+    model.layers[0].trainable = False
+    model.layers[0].encoder.trainable = True
+    assert not any(v.trainable for v in model.layers[0].variables)
+    model.layers[0].trainable = True
+    assert all(v.trainable for v in model.layers[0].encoder.variables)
+
+    # the flat prefix API still works on top
+    model.set_trainable("", False)
+    model.set_trainable("lm_head/", True)
+    assert [v.local_name for v in model.trainable_variables] == ["lm_head/kernel", "lm_head/bias"]
+    with pytest.raises(KeyError):
+        model.set_trainable("no_such_prefix/", True)
+    lines = []
+    model.summary(print_fn=lines.append)
+    assert any("Trainable params: 24,608" in ln for ln in lines)       # 768 * 32 + 32
+
+
+def test_backbone_model_layer_graph():
+    import wav2vec2
+    m = _graph_only_model(wav2vec2.Wav2Vec2Model, wav2vec2.RobustWav2Vec2Config())
+    assert [l.name for l in m.layers][-2:] == ["feature_projection", "encoder"] and len(m.layers) == 9
+    assert m.variables[0].name == "wav2vec2/masked_spec_embed:0"
+    m.freeze_feature_extractor()
+    # robust: conv bias + LayerNorm on every conv layer -> 4 variables per layer
+    assert len([v for v in m.variables if not v.trainable]) == 28
+    assert len(m.encoder.layers) == 3 + 24

@@ -278,8 +278,18 @@ def test_variables_and_persistence(torch_mod, tmp_path):
     ref = m(g["wave"]).numpy()
     m.save_pretrained(str(tmp_path / "ckpt"))
     assert os.path.exists(tmp_path / "ckpt" / "config.json")
+    # the reference's container: a Keras-layout HDF5 file `tf_model.h5` (modeling.py:26), written without h5py
+    with open(tmp_path / "ckpt" / "tf_model.h5", "rb") as f:
+        assert f.read(8) == b"\x89HDF\r\n\x1a\n"
     m2 = wav2vec2.Wav2Vec2ForCTC.from_pretrained(str(tmp_path / "ckpt"), input_shape=(1, 4000))
     assert np.array_equal(m2(g["wave"]).numpy(), ref)
+    # a backbone checkpoint ("wav2vec2/..." names) loads into the CTC model's backbone and back
+    bb = wav2vec2.Wav2Vec2Model(cfg, input_shape=(1, 4000))
+    bb.load_weights(str(tmp_path / "ckpt" / "tf_model.h5"))
+    assert np.array_equal(bb.get_weights()[k], w[k])
+    bb.save_pretrained(str(tmp_path / "backbone"))
+    bb2 = wav2vec2.Wav2Vec2Model.from_pretrained(str(tmp_path / "backbone"), input_shape=(1, 4000))
+    assert np.array_equal(bb2(g["wave"]).numpy(), bb(g["wave"]).numpy())
     m.freeze_feature_extractor()
     assert all(not v.trainable for v in m.variables if v.local_name.startswith("feature_extractor/"))
     assert len(m.trainable_variables) == len(vs) - 9          # 7 kernels + GroupNorm gamma/beta
@@ -292,8 +302,6 @@ def test_error_conventions(torch_mod):
     with pytest.raises(ValueError):
         wav2vec2.Wav2Vec2ForCTC({"hidden_size": 64})
     m, cfg = build("tiny_base")
-    with pytest.raises(NotImplementedError):
-        m(np.zeros((1, 4000), np.float32), training=True)
     with pytest.raises(ValueError):
         m(np.zeros((1, 100), np.float32))                      # shorter than the receptive field
     with pytest.raises(KeyError):
@@ -463,3 +471,70 @@ def test_models_release_device_memory(torch_mod):
     for _ in range(9):
         last = cycle()
     assert first - last < 64 * 2 ** 20, (first, last)
+
+
+def test_call_with_training_true_runs_the_training_mode_forward(torch_mod):
+    """`model(batch, attention_mask, training=True)` (reference modeling.py:169-209,239-255): dropout at every Dropout layer,
+    spec-augment when `config.apply_spec_augment`, randomness from the model-level generator (`set_seed`)."""
+    import wav2vec2
+    from dataclasses import replace
+    g = H.golden("tiny_base")
+    x = g["wave"]
+    # no randomness configured -> identical to the inference graph
+    cfg0 = replace(H.case_config("tiny_base"), dropout=0.0, apply_spec_augment=False)
+    m0 = wav2vec2.Wav2Vec2ForCTC(cfg0, input_shape=x.shape)
+    m0.set_weights(H.case_weights("tiny_base"))
+    assert np.allclose(m0(x, training=True).numpy(), m0(x).numpy(), atol=2e-6)
+    # the reference's defaults (dropout 0.1, spec-augment on): a different, seed-reproducible output
+    m, cfg = build("tiny_base")
+    assert cfg.dropout == 0.1 and cfg.apply_spec_augment
+    ref = m(x).numpy()
+    m.set_seed(5)
+    a = m(x, training=True).numpy()
+    info = m.last_training_call
+    b = m(x, training=True).numpy()
+    m.set_seed(5)
+    a2 = m(x, training=True).numpy()
+    assert a.shape == ref.shape and np.isfinite(a).all()
+    assert np.abs(a - ref).max() > 1e-3 and np.abs(a - b).max() > 1e-3        # training noise; fresh masks per call
+    assert np.array_equal(a, a2)                                               # same seed, same call number -> same bits
+    assert info["spec_mask"].shape == (2, 12) and info["spec_mask"].sum() > 0
+    # the draw is exactly the training oracle's forward on the recorded masks
+    from oracle import w2v2_torch_train as TT
+    import torch
+    w = {k: torch.from_numpy(v.astype(np.float64)) for k, v in H.case_weights("tiny_base").items()}
+    want = TT.train_forward(cfg, w, x, p=cfg.dropout, seed=info["seed"], spec_mask=info["spec_mask"]).numpy()
+    assert H.max_err(a, want) < 2e-5
+    # backbone-only model: hidden states (B, T, H) in training mode
+    bb = wav2vec2.Wav2Vec2Model(cfg, input_shape=x.shape)
+    h = bb(x, training=True)
+    assert tuple(h.shape) == (2, 12, cfg.hidden_size) and bool(torch.isfinite(h).all())
+    # the inference path is untouched by the training calls
+    assert np.array_equal(m(x).numpy(), ref)
+
+
+def test_layers_and_trainable_drive_the_native_training_state(torch_mod):
+    """src/main.py:210,232-237 verbatim against a live model: what `.trainable` says is what the backward computes."""
+    import wav2vec2
+    g = H.golden("tiny_base")
+    m, cfg = build("tiny_base")
+    loss_fn = wav2vec2.CTCLoss(cfg, g["wave"].shape)
+
+    def grads():
+        tr = wav2vec2.Trainer(m, loss_fn, dropout=0.0, apply_spec_augment=False)
+        logits = tr.forward(g["wave"], step_seed=1)
+        _, d = loss_fn.per_sample(g["labels"], logits, with_grad=True)
+        tr.backward(d)
+        return {v.local_name: tr.gradient(v.local_name) for v in m.variables}
+
+    model = m
+    model.layers[0].trainable = False                                  # stage 1
+    g1 = grads()
+    assert np.any(g1["lm_head/kernel"]) and not any(np.any(a) for n, a in g1.items() if not n.startswith("lm_head/"))
+    model.trainable = True                                             # stage 2
+    for i in range(len(model.layers[0].layers) - 2):
+        model.layers[0].layers[i].trainable = False
+    g2 = grads()
+    assert np.array_equal(g2["lm_head/kernel"], g1["lm_head/kernel"])
+    assert np.any(g2["encoder/layers/0/attention/q_proj/kernel"]) and np.any(g2["feature_projection/projection/kernel"])
+    assert not any(np.any(a) for n, a in g2.items() if n.startswith("feature_extractor/"))

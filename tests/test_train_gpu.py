@@ -650,3 +650,102 @@ def test_bf16_fine_tune_step_at_full_length(env, case, L, frames):
             worst_mean = (name, d.mean() / scale)
     print(f"{case}: worst gradient max-error / max|g| {worst}, worst mean-error / max|g| {worst_mean}")
     assert worst[1] < 8e-2 and worst_mean[1] < 1e-2
+
+
+def test_new_trainer_is_a_fresh_optimizer(env):
+    """The reference builds a new Adam for stage 2 (src/main.py:213,240): iteration 0 AND zero moments.  The moments live in
+    the model's native state, so a second Trainer on a used model must reset them; `reset_optimizer=False` adopts them."""
+    import wav2vec2
+    g = H.golden("tiny_base")
+    m, cfg, w = build("tiny_base", 4000)
+    loss_fn = wav2vec2.CTCLoss(cfg, g["wave"].shape, division_factor=2)
+    t1 = wav2vec2.Trainer(m, loss_fn, learning_rate=1e-3, dropout=0.0, apply_spec_augment=False)
+    for _ in range(3):
+        t1.step(g["wave"], g["labels"])
+    am, _ = t1._adam_views()
+    assert float(am.abs().max()) > 0
+    assert "adam_m" in t1.state_dict()
+    keep = wav2vec2.Trainer(m, loss_fn, reset_optimizer=False)
+    assert float(keep._adam_views()[0].abs().max()) > 0
+    t2 = wav2vec2.Trainer(m, loss_fn, learning_rate=1e-3, dropout=0.0, apply_spec_augment=False)      # stage 2
+    am, av = t2._adam_views()
+    assert t2.iterations == 0 and float(am.abs().max()) == 0 and float(av.abs().max()) == 0
+    # its first update is Keras Adam's first update from zero moments
+    name = "encoder/layers/1/feed_forward/output_dense/kernel"
+    before = m.get_weights()[name].astype(np.float64)
+    logits = t2.forward(g["wave"], step_seed=1)
+    _, dlog = loss_fn.per_sample(g["labels"], logits, with_grad=True)
+    t2.backward(dlog)
+    gr = t2.gradient(name).astype(np.float64)
+    t2.apply_gradients()
+    want, _, _ = TT.adam_reference(before, gr, 0.0, 0.0, 1e-3, 0.9, 0.999, 1e-7, 1)
+    assert H.max_err(m.get_weights()[name], want) < 1e-6
+    # a state without moments zeroes them on load
+    st = t2.state_dict()
+    st.pop("adam_m"), st.pop("adam_v")
+    t2.load_state_dict(st)
+    assert float(t2._adam_views()[0].abs().max()) == 0
+
+
+def test_shape_change_keeps_transposed_kernels_and_bf16x3_planes_valid(env):
+    """The transposed kernel copies (and the bf16x3 plane cache keyed by their addresses) survive a change of batch shape:
+    forward + backward at a new (B, L) without an optimizer step in between gives the gradients of a fresh model."""
+    import wav2vec2
+    cfgname = "tiny_base"
+    xa = V.hash_normal("train/shape_a", 2 * 4000, 3).reshape(2, 4000)
+    xb = V.hash_normal("train/shape_b", 3 * 5000, 3).reshape(3, 5000)
+    la, lb = np.array([[3, 4, 0], [5, 0, 0]], np.int32), np.array([[3, 4, 0], [5, 0, 0], [9, 9, 1]], np.int32)
+
+    def run(m, cfg, x, labels):
+        loss_fn = wav2vec2.CTCLoss(cfg, x.shape)
+        tr = wav2vec2.Trainer(m, loss_fn, dropout=0.0, apply_spec_augment=False)
+        logits = tr.forward(x, step_seed=1)
+        _, d = loss_fn.per_sample(labels, logits, with_grad=True)
+        tr.backward(d)
+        return {n: tr.gradient(n) for n in ("lm_head/kernel", "encoder/layers/0/feed_forward/intermediate_dense/kernel",
+                                             "encoder/layers/1/attention/q_proj/kernel", "feature_projection/projection/kernel")}
+
+    for prec in ("fp32", "bf16x3"):
+        m, cfg, w = build(cfgname, 4000)
+        m.set_precision(prec)
+        run(m, cfg, xa, la)
+        got = run(m, cfg, xb, lb)                  # new shape, no optimizer step in between
+        fresh, cfg2, _ = build(cfgname, 5000)
+        fresh.set_precision(prec)
+        want = run(fresh, cfg2, xb, lb)
+        for n in want:
+            assert np.array_equal(got[n], want[n]), (prec, n)
+
+
+def test_ctc_rejects_out_of_range_labels_and_is_deterministic(env):
+    lib, torch, dev = env
+    import wav2vec2
+    cfg = H.case_config("tiny_base")
+    B, T, Vn = 3, 50, cfg.vocab_size
+    logits = rnd("ctc_det", (B, T, Vn), 2.0)
+    labels = np.array([[3, 4, 4, 7, 0], [5, 31, 0, 0, 0], [1, 2, 3, 4, 5]], np.int32)
+    L = 16000
+    while cfg.num_frames(L) != T:
+        L += 80
+    loss_fn = wav2vec2.CTCLoss(cfg, (B, L))
+    nll, grad = loss_fn.per_sample(labels, logits, with_grad=True)
+    ref_total, ref_nll = O.ctc_loss(cfg, labels, logits, (B, L))
+    assert np.allclose(nll.cpu().numpy(), ref_nll, atol=1e-4)
+    # bitwise reproducible gradient (integer fixed-point occupancy sums, no floating-point atomics)
+    for _ in range(3):
+        _, again = loss_fn.per_sample(labels, logits, with_grad=True)
+        assert torch.equal(grad, again)
+    # a label outside [0, V): host arrays are checked before the launch ...
+    bad = labels.copy()
+    bad[1, 1] = Vn
+    with pytest.raises(ValueError):
+        loss_fn.per_sample(bad, logits)
+    bad[1, 1] = -1
+    with pytest.raises(ValueError):
+        loss_fn.per_sample(bad, logits)
+    # ... device-resident labels are checked on the device: that sample's loss is NaN, its gradient rows are zero, the rest intact
+    bad[1, 1] = Vn + 3
+    nll_b, grad_b = loss_fn.per_sample(torch.from_numpy(bad).to(dev), logits, with_grad=True)
+    nb = nll_b.cpu().numpy()
+    assert np.isnan(nb[1]) and np.allclose(nb[[0, 2]], ref_nll[[0, 2]], atol=1e-4)
+    assert not bool(grad_b[1].any()) and torch.equal(grad_b[0], grad[0]) and torch.equal(grad_b[2], grad[2])
