@@ -127,6 +127,58 @@ __global__ __launch_bounds__(256) void conv0_kernel(Conv0Args a) {
     }
 }
 
+// Apply / plain-conv pass with 16-byte stores: a lane owns FOUR consecutive channels (40 taps in registers for K = 10), so
+// a wave-level store is 64 x 16 B = 1 KiB of one output row instead of 256 B, and the bf16 shadow goes out as 8-byte
+// stores.  C / 4 lanes cover a frame; the block's 256 threads work on 256 / (C / 4) frames at a time (2 for C = 512).
+// The stage is bound by its single 3.2 GB output write (B = 32 x 246000): what matters is how few, how wide and how
+// regular the store instructions are.  MODE 1: scale/shift + activation (group norm), MODE 2: plain conv(+bias).
+using f32x4_c0 = __attribute__((ext_vector_type(4))) float;
+using u32x2_c0 = __attribute__((ext_vector_type(2))) unsigned;
+
+template <int MODE, int KT, int ST>
+__global__ __launch_bounds__(256) void conv0_apply4_kernel(Conv0Args a, int tpr /* lanes per frame = C / 4 */) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int t0 = chunk * TC;
+    const int nt = min(TC, a.T0 - t0);
+    const int nx = (nt - 1) * ST + KT;
+    const float* __restrict__ wv = a.wave + (int64_t)b * a.L + (int64_t)t0 * ST;
+    for (int i = threadIdx.x; i < nx; i += 256) xs[i] = wv[i];
+    const int q = threadIdx.x % tpr, fp = threadIdx.x / tpr, fpb = 256 / tpr, c = 4 * q;
+    f32x4_c0 w[KT], bs = {0.f, 0.f, 0.f, 0.f}, sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KT; ++k) w[k] = *reinterpret_cast<const f32x4_c0*>(a.kernel + (int64_t)k * a.C + c);
+    if (a.bias) bs = *reinterpret_cast<const f32x4_c0*>(a.bias + c);
+    if (MODE == 1) {
+        sc = *reinterpret_cast<const f32x4_c0*>(a.scale_shift + ((int64_t)b * 2 + 0) * a.C + c);
+        sh = *reinterpret_cast<const f32x4_c0*>(a.scale_shift + ((int64_t)b * 2 + 1) * a.C + c);
+    }
+    __syncthreads();
+    float* __restrict__ orow = a.out + ((int64_t)b * a.T0 + t0) * a.C + c;
+    uint16_t* __restrict__ orow16 = a.out16 ? a.out16 + ((int64_t)b * a.T0 + t0) * a.C + c : nullptr;
+    for (int t = fp; t < nt; t += fpb) {
+        const float* xp = xs + t * ST;
+        f32x4_c0 y = bs;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            const float xv = xp[k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = fmaf(xv, w[k][j], y[j]);
+        }
+        if (MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = apply_act(fmaf(y[j], sc[j], sh[j]), a.act);
+        }
+        __builtin_nontemporal_store(y, reinterpret_cast<f32x4_c0*>(orow + (int64_t)t * a.C));
+        if (orow16) {
+            u32x2_c0 h;
+            h[0] = pack_bf16_rne(y[0], y[1]);
+            h[1] = pack_bf16_rne(y[2], y[3]);
+            *reinterpret_cast<u32x2_c0*>(orow16 + (int64_t)t * a.C) = h;
+        }
+    }
+}
+
 // (b, c): fp64 combine of chunk partials -> scale = rsqrt(var+eps)*gamma, shift = beta - mean*scale
 __global__ void conv0_finalize_kernel(Conv0Args a, int B) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -236,6 +288,18 @@ template <int MODE>
 void launch_mode(const Conv0Args& a, int B, hipStream_t s) {
     dim3 grid(a.nchunks, B), block(256);
     const size_t lds = ((size_t)(TC - 1) * a.stride + a.K + 4) * sizeof(float);
+    // the 16-byte-store kernel: C / 4 lanes per frame must tile the block, and every pointer it vectorises must be aligned
+    const int tpr = a.C / 4;
+    const bool vec_ok = MODE != 0 && a.K == 10 && a.stride == 5 && a.C % 4 == 0 && tpr >= 1 && tpr <= 256 && 256 % tpr == 0 &&
+                        ((reinterpret_cast<uintptr_t>(a.out) | reinterpret_cast<uintptr_t>(a.kernel) |
+                          reinterpret_cast<uintptr_t>(a.bias) | (MODE == 1 ? reinterpret_cast<uintptr_t>(a.scale_shift) : 0)) & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(a.out16) & 7) == 0;
+    if constexpr (MODE != 0) {
+        if (vec_ok) {
+            hipLaunchKernelGGL((conv0_apply4_kernel<MODE, 10, 5>), grid, block, lds, s, a, tpr);
+            return;
+        }
+    }
     if (a.K == 10 && a.stride == 5)
         hipLaunchKernelGGL((conv0_kernel<MODE, 10, 5>), grid, block, lds, s, a);
     else

@@ -312,7 +312,9 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
         b_swz[t] = swz(r);
     }
     // which 8 k of a 16-deep MFMA step a lane supplies is free as long as A and B agree: lane half lh takes
-    // 16-byte slot 2 s + lh of both images
+    // 16-byte slot 2 s + lh of both images.  The MFMA is issued as (B fragment, A fragment): the accumulator block is C^T,
+    // a lane owns one output ROW and four consecutive COLUMNS per register quad, so the epilogue moves 16 bytes per
+    // instruction (gemm_epilogue_t).  Products and the fp32 summation order per output element are unchanged.
     auto compute = [&](int buf) {
         const unsigned char* S = smem16 + buf * STAGE;
         // Fragment reads run one k-step ahead of the MFMAs that consume them: a 16-deep bf16 MFMA is only 32 cycles, so
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NTL; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1][mt], b[s & 1][nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[s & 1][nt], a[s & 1][mt], acc[mt][nt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
     // ---- epilogue (gemm_epilogue.h): bias -> act -> + residual -> fp32 store and / or bf16 shadow ----
     const int zi = g.zmod ? z % g.zmod : z, zo = g.zmod ? z / g.zmod : 0;
     const int64_t tile_off = (int64_t)zo * g.strideC2 + (int64_t)zi * g.strideC + (int64_t)(m0 + wm * WTM) * g.ldc + (n0 + wn * WTN);
-    gemm_epilogue<MT, NTL, true>(acc, g.C ? g.C + tile_off : nullptr, g.C16 ? g.C16 + tile_off : nullptr,
+    gemm_epilogue_t<MT, NTL, true>(acc, g.C ? g.C + tile_off : nullptr, g.C16 ? g.C16 + tile_off : nullptr,
                                  g.residual ? g.residual + tile_off : nullptr,
                                  g.bias ? g.bias + (g.zmod ? (int64_t)zi * g.strideBias : 0) + (n0 + wn * WTN) : nullptr,
                                  (int)g.ldc, g.M - (m0 + wm * WTM), g.N - (n0 + wn * WTN), g.act, li, lh);
