@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(Conv0Args a) {
                     const int c = c0 + 256 * j;
                     if (c < a.C) {
                         float v = MODE == 1 ? apply_act(fmaf(y[j], sc[j], sh[j]), a.act) : y[j];
-                        __builtin_nontemporal_store(v, &a.out[((int64_t)b * a.T0 + t0 + t) * a.C + c]);   // 3.2 GB streamed once
+                        if (a.out) __builtin_nontemporal_store(v, &a.out[((int64_t)b * a.T0 + t0 + t) * a.C + c]);   // 3.2 GB streamed once
                         if (a.out16) a.out16[((int64_t)b * a.T0 + t0 + t) * a.C + c] = (uint16_t)pack_bf16_rne(v, 0.f);
                     }
                 }
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void conv0_apply4_kernel(Conv0Args a, int tpr 
         sh = *reinterpret_cast<const f32x4_c0*>(a.scale_shift + ((int64_t)b * 2 + 1) * a.C + c);
     }
     __syncthreads();
-    float* __restrict__ orow = a.out + ((int64_t)b * a.T0 + t0) * a.C + c;
+    float* __restrict__ orow = a.out ? a.out + ((int64_t)b * a.T0 + t0) * a.C + c : nullptr;
     uint16_t* __restrict__ orow16 = a.out16 ? a.out16 + ((int64_t)b * a.T0 + t0) * a.C + c : nullptr;
     for (int t = fp; t < nt; t += fpb) {
         const float* xp = xs + t * ST;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void conv0_apply4_kernel(Conv0Args a, int tpr 
 #pragma unroll
             for (int j = 0; j < 4; ++j) y[j] = apply_act(fmaf(y[j], sc[j], sh[j]), a.act);
         }
-        __builtin_nontemporal_store(y, reinterpret_cast<f32x4_c0*>(orow + (int64_t)t * a.C));
+        if (orow) __builtin_nontemporal_store(y, reinterpret_cast<f32x4_c0*>(orow + (int64_t)t * a.C));
         if (orow16) {
             u32x2_c0 h;
             h[0] = pack_bf16_rne(y[0], y[1]);
@@ -328,7 +328,7 @@ int launch_conv0(Profiler* prof, const float* wave, const float* kernel, const f
 int launch_conv0_x(Profiler* prof, const float* wave, const float* kernel, const float* bias,
                    const float* gamma, const float* beta, float* out, uint16_t* out16, float* ws, int B, int64_t L,
                    int K, int stride, int C, float eps, int norm_mode, int act, hipStream_t s) {
-    W2V2_REQUIRE(wave && kernel && out, "conv0: null operand");
+    W2V2_REQUIRE(wave && kernel && (out || out16), "conv0: null operand");
     W2V2_REQUIRE(B > 0 && C > 0 && K > 0 && K <= 32 && stride > 0 && L >= K,
                  "conv0: unsupported B=%d C=%d K=%d stride=%d L=%lld", B, C, K, stride, (long long)L);
     W2V2_REQUIRE(norm_mode == 0 || norm_mode == 1, "conv0: bad norm_mode %d", norm_mode);
@@ -337,7 +337,7 @@ int launch_conv0_x(Profiler* prof, const float* wave, const float* kernel, const
     a.L = L; a.K = K; a.stride = stride; a.C = C; a.eps = eps; a.norm_mode = norm_mode; a.act = act;
     a.T0 = (int)(1 + (L - K) / stride);
     a.nchunks = conv0_nchunks(L, K, stride);
-    const double out_bytes = 4.0 * B * (double)a.T0 * C, in_bytes = 4.0 * B * (double)L;
+    const double out_bytes = (out ? 4.0 : 0.0) * B * (double)a.T0 * C + (out16 ? 2.0 : 0.0) * B * (double)a.T0 * C, in_bytes = 4.0 * B * (double)L;
     const double flops = 2.0 * B * (double)a.T0 * C * K;
     if (norm_mode == 1) {
         ProfScope ps(prof, FAM_CONV0_APPLY, flops, in_bytes + out_bytes, s);

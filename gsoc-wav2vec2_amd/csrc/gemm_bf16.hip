@@ -56,6 +56,8 @@ struct Gemm16Args {
     // (the bias gradient: B = dY is already in registers while it is staged, so the sums cost 8 adds per patch column)
     float* colsum;
     int64_t strideCS;
+    int abl;      // timing ablations (W2V2_GEMM16_ABL, results are wrong by construction): 1 = no operand traffic in the K loop,
+                  // 2 = no MFMAs, 4 = no epilogue
 };
 
 // two fp32 -> one dword of two bf16, round to nearest even (gfx950 instruction; no builtin in ROCm 7.2)
@@ -312,9 +314,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
         b_swz[t] = swz(r);
     }
     // which 8 k of a 16-deep MFMA step a lane supplies is free as long as A and B agree: lane half lh takes
-    // 16-byte slot 2 s + lh of both images.  The MFMA is issued as (B fragment, A fragment): the accumulator block is C^T,
-    // a lane owns one output ROW and four consecutive COLUMNS per register quad, so the epilogue moves 16 bytes per
-    // instruction (gemm_epilogue_t).  Products and the fp32 summation order per output element are unchanged.
+    // 16-byte slot 2 s + lh of both images
     auto compute = [&](int buf) {
         const unsigned char* S = smem16 + buf * STAGE;
         // Fragment reads run one k-step ahead of the MFMAs that consume them: a 16-deep bf16 MFMA is only 32 cycles, so
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NTL; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[s & 1][nt], a[s & 1][mt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1][mt], b[s & 1][nt], acc[mt][nt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -382,9 +382,9 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
             __syncthreads();                    // carries the vmcnt(0) that retires the DMA
             for (int kt = 0; kt + 1 < nk; ++kt) {
                 const int cur = kt & 1;
-                issue(kt + 1, cur ^ 1);
+                if (!(g.abl & 1)) issue(kt + 1, cur ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
-                compute(cur);
+                if (!(g.abl & 2)) compute(cur);
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();
             }
@@ -448,7 +448,16 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
     // ---- epilogue (gemm_epilogue.h): bias -> act -> + residual -> fp32 store and / or bf16 shadow ----
     const int zi = g.zmod ? z % g.zmod : z, zo = g.zmod ? z / g.zmod : 0;
     const int64_t tile_off = (int64_t)zo * g.strideC2 + (int64_t)zi * g.strideC + (int64_t)(m0 + wm * WTM) * g.ldc + (n0 + wn * WTN);
-    gemm_epilogue_t<MT, NTL, true>(acc, g.C ? g.C + tile_off : nullptr, g.C16 ? g.C16 + tile_off : nullptr,
+    // the operand images are dead once every wave has issued its last MFMA: the accumulators go out through wave-private
+    // LDS patches so that every store writes whole 128-byte row segments (gemm_epilogue_lds)
+    if (g.abl & 4) {
+        if (acc[0][0][0] == 12345.678f) g.C[0] = 1.f;       // keep the accumulators alive
+        return;
+    }
+    // Epilogue forms measured in round 2 (profiles/r02_gemm_bf16_study.md): these row-major C/D blocks with dword stores
+    // (2 rows x 128 B per instruction) beat both C^T accumulators with 16-byte stores straight from registers (32 rows x 32 B:
+    // 532 vs 613 TF on the forward mix) and C^T through wave-private LDS patches (whole 128-byte segments, 16 B per lane: 586).
+    gemm_epilogue<MT, NTL, true>(acc, g.C ? g.C + tile_off : nullptr, g.C16 ? g.C16 + tile_off : nullptr,
                                  g.residual ? g.residual + tile_off : nullptr,
                                  g.bias ? g.bias + (g.zmod ? (int64_t)zi * g.strideBias : 0) + (n0 + wn * WTN) : nullptr,
                                  (int)g.ldc, g.M - (m0 + wm * WTM), g.N - (n0 + wn * WTN), g.act, li, lh);
@@ -519,6 +528,9 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
     g.A16 = x.A16; g.B16 = x.B16; g.C16 = x.C16; g.ldb16 = x.ldb16 ? x.ldb16 : K;
     g.zmod = x.zmod; g.strideB16 = x.strideB16; g.strideC2 = x.strideC2; g.strideBias = x.strideBias; g.strideB2 = x.strideB2;
     g.colsum = x.transA ? x.colsum : nullptr; g.strideCS = x.strideCS;
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("W2V2_GEMM16_ABL"); abl = e ? atoi(e) : 0; }
+    g.abl = abl;
     W2V2_REQUIRE(x.zmod >= 0 && (x.zmod == 0 || nbatch % x.zmod == 0), "gemm_bf16: batch %d is not a multiple of the inner batch %d", nbatch, x.zmod);
     const bool kfast = K % BK == 0;
     const bool a32 = A && (lda % 4 == 0) && (strideA % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
@@ -548,6 +560,10 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
     if (cfg == 2 && src == 1) return launch_src16<1, 256, 256, 2, 4, 1>(g, nbatch, s);   // tile study: 8 waves of 128x64
     if (N <= 64 && src == 5) return launch_src16<5, 128, 64, 2, 2, 2>(g, nbatch, s);     // narrow outputs (grouped conv: 48 | 64 columns)
     if (N <= 64 && src == 7) return launch_src16<7, 128, 64, 2, 2, 2>(g, nbatch, s);
+    // both operands from shadows by LDS-DMA: 8 waves of 64x32 per 128x128 tile (2 x 4 per SIMD pair, 2 blocks / CU) measured
+    // 670 TF on the forward mix against 642 for 4 waves of 64x64 (more waves issuing DMA pieces and fragment reads); the
+    // register-staged sources keep 4 waves (their patch ownership is tied to 256 threads)
+    if (src == 5 && cfg != 0) return launch_src16<5, 128, 128, 2, 4, 2>(g, nbatch, s);
     return launch_cfg16<128, 128, 2, 2, 2>(g, src, nbatch, s);
 }
 

@@ -85,75 +85,6 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16_t (&acc)[MT][NTL], fl
     }
 }
 
-// The same epilogue for accumulators held TRANSPOSED: the kernel issued mfma(B fragment, A fragment), so the 32x32 block
-// in a lane's registers is C^T -- lane l owns output ROW (l & 31) and register r holds COLUMN (r & 3) + 8 (r >> 2) +
-// 4 (l >> 5): four consecutive columns per register quad.  A lane therefore stores 16 bytes at a time (dwordx4 for the
-// fp32 tensor, dwordx2 for its bf16 shadow, dwordx4 residual loads, float4 bias) -- 4 store instructions per accumulator
-// instead of 16 (32 with the shadow).  With 16-deep bf16 MFMAs a K = 768 tile is only ~6 k matrix cycles per wave and
-// the 128 narrow stores per lane of the row-major form were a store-issue tail longer than that; this form issues 32.
-// Vector path: interior sub-tile, ldc % 4 == 0 and 16-byte (fp32) / 8-byte (bf16) aligned bases -- decided once per wave.
-using f32x4_e = __attribute__((ext_vector_type(4))) float;
-using u32x2_e = __attribute__((ext_vector_type(2))) unsigned;
-
-template <int MT, int NTL, bool FAST_GELU>
-__device__ __forceinline__ void gemm_epilogue_t(const f32x16_t (&acc)[MT][NTL], float* __restrict__ C, uint16_t* __restrict__ C16,
-                                                const float* __restrict__ R, const float* __restrict__ bias, int ldc,
-                                                int rows_left, int cols_left, int act, int li, int lh) {
-    const bool interior = rows_left >= MT * 32 && cols_left >= NTL * 32;
-    const bool vec = interior && (ldc & 3) == 0 && ((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(R)) & 15) == 0 &&
-                     (reinterpret_cast<uintptr_t>(C16) & 7) == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0;
-#pragma unroll
-    for (int nt = 0; nt < NTL; ++nt) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c0 = nt * 32 + 8 * g + 4 * lh;                 // first of this lane's 4 consecutive columns
-            f32x4_e bv = {0.f, 0.f, 0.f, 0.f};
-            if (bias) {
-                if (vec) {
-                    bv = *reinterpret_cast<const f32x4_e*>(bias + c0);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) bv[j] = (c0 + j < cols_left) ? bias[c0 + j] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int row = mt * 32 + li;
-                f32x4_e v;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][4 * g + j] + bv[j];
-                if (act == 1) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = FAST_GELU ? gelu_erf_fast(v[j]) : gelu_erf(v[j]);
-                } else if (act == 2) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = gelu_tanh(v[j]);
-                }
-                const int off = row * ldc + c0;
-                if (vec) {
-                    if (R) v += *reinterpret_cast<const f32x4_e*>(R + off);
-                    if (C) *reinterpret_cast<f32x4_e*>(C + off) = v;
-                    if (C16) {
-                        u32x2_e h;
-                        h[0] = pack_bf16_rne(v[0], v[1]);
-                        h[1] = pack_bf16_rne(v[2], v[3]);
-                        *reinterpret_cast<u32x2_e*>(C16 + off) = h;
-                    }
-                } else if (row < rows_left) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (c0 + j < cols_left) {
-                            float o = v[j];
-                            if (R) o += R[off + j];
-                            if (C) C[off + j] = o;
-                            if (C16) C16[off + j] = (uint16_t)pack_bf16_rne(o, 0.0f);
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
 #endif
 
 }  // namespace w2v2

@@ -34,6 +34,7 @@ struct w2v2_model {
     int64_t ws_L = 0;
     std::vector<void*> allocs;
     std::map<std::string, Act> acts;
+    std::vector<std::string> acts_skipped;   // stage outputs the LAST forward wrote only as bf16 (precision mode 1): no fp32 copy to read back
     std::vector<float*> conv;                // conv stack outputs
     std::vector<int> conv_T;
     float *conv0_ws = nullptr, *ln512 = nullptr, *proj = nullptr, *posout = nullptr;
@@ -68,6 +69,8 @@ struct w2v2_model {
 
 // implemented in w2v2_api.hip
 bool w2v2_shadows_enabled();                                              // W2V2_BF16_SHADOWS != 0
+bool w2v2_conv_out_bf16_only(const w2v2_model* m, int i, bool sh);         // conv-stack output i is written only as bf16 this forward
+bool w2v2_keep_activations();                                             // W2V2_KEEP_ACTIVATIONS == 1: also write the fp32 copies nothing reads
 int w2v2_ensure_shadows(w2v2_model* m, int B, int T, hipStream_t s);
 bool w2v2_pos_conv_bf16_ok(const w2v2_model* m);                          // precision 1 and a supported group shape
 int w2v2_ensure_pos16(w2v2_model* m, int B, int T, hipStream_t s);       // kernel shadow + pack scratch     // allocate activation shadows, (re)build weight shadows

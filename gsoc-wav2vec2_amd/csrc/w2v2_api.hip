@@ -247,6 +247,25 @@ bool w2v2_shadows_enabled() {
     return !(e && atoi(e) == 0);
 }
 
+// Precision mode 1 with shadows: a conv-stack output whose only consumer is the next layer's GEMM (reading the bf16 shadow)
+// is written ONLY as bf16 -- 6.3 GB of fp32 stores per B = 32 x 246000 forward that nothing would read.  Stage taps of
+// those tensors (w2v2_copy_activation) then report an error; W2V2_KEEP_ACTIVATIONS=1 (read per call) keeps the fp32 copies.
+bool w2v2_keep_activations() {
+    const char* e = getenv("W2V2_KEEP_ACTIVATIONS");
+    return e && atoi(e) != 0;
+}
+
+// Whether conv-stack output i (0 .. NC-2) may be written ONLY as bf16 in the coming forward: group-norm mode with shadows,
+// and layer i+1's GEMM is certain to take the bf16 shadow as its A operand (gemm_bf16.hip: K % 64 == 0 and 16-byte
+// aligned rows / batch strides) -- otherwise that GEMM reads the fp32 tensor and it must exist.
+bool w2v2_conv_out_bf16_only(const w2v2_model* m, int i, bool sh) {
+    const w2v2_config& c = m->cfg;
+    if (!sh || c.feature_extractor_norm_type == 1 || i + 1 >= c.num_conv_layers || w2v2_keep_activations()) return false;
+    const int64_t cin = c.filter_sizes[i], K = (int64_t)c.kernal_sizes[i + 1] * cin, lda = (int64_t)c.strides[i + 1] * cin;
+    const int64_t strideA = (int64_t)m->conv_T[i] * cin;
+    return K % 64 == 0 && lda % 8 == 0 && strideA % 8 == 0;
+}
+
 static int sh_alloc(std::vector<void*>& pool, uint16_t** out, int64_t n) {
     void* p = nullptr;
     W2V2_HIP_CHECK(hipMalloc(&p, (size_t)(n > 0 ? n : 1) * sizeof(uint16_t)));
@@ -570,8 +589,13 @@ int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const i
     const bool ffn_sh_only = sh && F % 64 == 0;      // the output dense can then always take the shadow (K = F)
 
     // ---- feature extractor (feature_extractor.py:54-59) ----
+    // group-norm mode with shadows: conv0 .. conv(NC-2) feed only the next layer's GEMM; where that GEMM reads the bf16 shadow
+    // the fp32 copy is not written at all (w2v2_conv_out_bf16_only)
+    m->acts_skipped.clear();
+    for (int i = 0; i + 1 < NC; ++i)
+        if (w2v2_conv_out_bf16_only(m, i, sh)) m->acts_skipped.push_back("conv" + std::to_string(i));
     if (int e = launch_conv0_x(pf, wave, fe(0, "/conv/kernel"), c.conv_bias ? fe(0, "/conv/bias") : nullptr,
-                               fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"), m->conv[0],
+                               fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"), w2v2_conv_out_bf16_only(m, 0, sh) ? nullptr : m->conv[0],
                                (sh && !layer_mode) ? m->conv16[0] : nullptr, m->conv0_ws, B, L, c.kernal_sizes[0], c.strides[0],
                                c.filter_sizes[0], 1e-5f, layer_mode ? 1 : 0, act, s))
         return e;
@@ -585,8 +609,8 @@ int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const i
         uint16_t* o16 = (sh && i + 1 < NC) ? m->conv16[i] : nullptr;     // the last conv output feeds a LayerNorm
         // strided Conv1D == GEMM over an overlapping window view: lda = stride * C_in < K * C_in
         if (int e = gemm(m->conv[i - 1], sh ? m->conv16[i - 1] : nullptr, (int64_t)c.strides[i] * cin, (int64_t)Tin * cin,
-                         fe(i, "/conv/kernel"), cout, m->conv[i], layer_mode ? nullptr : o16, cout, (int64_t)Tout * cout,
-                         c.conv_bias ? fe(i, "/conv/bias") : nullptr, nullptr, Tout, cout, c.kernal_sizes[i] * cin, B,
+                         fe(i, "/conv/kernel"), cout, w2v2_conv_out_bf16_only(m, i, sh) ? nullptr : m->conv[i], layer_mode ? nullptr : o16, cout,
+                         (int64_t)Tout * cout, c.conv_bias ? fe(i, "/conv/bias") : nullptr, nullptr, Tout, cout, c.kernal_sizes[i] * cin, B,
                          layer_mode ? 0 : act))
             return e;
         if (layer_mode)
@@ -711,6 +735,12 @@ int w2v2_copy_activation(w2v2_model* m, const char* name, float* host_dst, int64
     }
     const Act& a = it->second;
     W2V2_REQUIRE(numel == a.shape[0] * a.shape[1] * a.shape[2], "copy_activation: `%s` element count mismatch", name);
+    for (const std::string& skipped : m->acts_skipped)
+        if (skipped == name) {
+            set_error("activation `%s` was written only as bf16 by the last forward (precision mode bf16: its one consumer reads the "
+                      "shadow); set W2V2_KEEP_ACTIVATIONS=1 to keep the fp32 copy", name);
+            return W2V2_ESTATE;
+        }
     W2V2_HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
     W2V2_HIP_CHECK(hipMemcpy(host_dst, a.ptr, (size_t)numel * sizeof(float), hipMemcpyDeviceToHost));
     return W2V2_OK;

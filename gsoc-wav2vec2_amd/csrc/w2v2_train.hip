@@ -54,6 +54,7 @@ struct TrainState {
     int64_t gtotal = 0;
     std::vector<char> trainable;
     bool transposes_fresh = false;
+    bool transposes_full = false;            // the per-layer fp32 transposed kernels are current (not needed in bf16 mode)
     // scratch
     float *gh[4] = {nullptr, nullptr, nullptr, nullptr}, *gf = nullptr, *g3h = nullptr, *at = nullptr,
           *slabs = nullptr, *red_ws = nullptr, *dvec = nullptr, *dummy = nullptr, *dwqkv = nullptr, *dwv_scratch = nullptr;
@@ -215,25 +216,42 @@ static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
 
 static int refresh_transposes(w2v2_model* m, hipStream_t s) {
     TrainState* t = m->train;
-    if (t->transposes_fresh) return W2V2_OK;
+    // Precision mode 1 with shadows takes the plain bf16 copy of W as the (N, K) shadow of W^T in every data-gradient GEMM
+    // that has one (all of the transformer's and the projection's), so the fp32 transposed copies of those kernels are
+    // never read: only lm_head's (N = 32: no shadow) and the flipped positional kernel are needed.  `transposes_full`
+    // remembers whether the fp32 copies are current, for a later switch back to fp32 / bf16x3 on the same model.
     const w2v2_config& c = m->cfg;
+    bool need_full = !(m->precision == 1 && w2v2_shadows_enabled() && m->w16_valid);
+    if (!need_full) {      // every kernel whose fp32 copy is skipped must really have its bf16 stand-in (shapes with N % 64 != 0 do not)
+        auto has = [&](const float* w) { return m->w16p.find(w) != m->w16p.end(); };
+        need_full = !has(m->P("feature_projection/projection/kernel"));
+        for (int i = 0; i < c.num_layers && !need_full; ++i) {
+            const std::string b = "encoder/layers/" + std::to_string(i);
+            need_full = !(has(m->qkv_w[i]) && has(m->P(b + "/attention/out_proj/kernel")) &&
+                          has(m->P(b + "/feed_forward/intermediate_dense/kernel")) && has(m->P(b + "/feed_forward/output_dense/kernel")));
+        }
+    }
+    if (t->transposes_fresh && (t->transposes_full || !need_full)) return W2V2_OK;
     const int H = c.hidden_size, F = c.intermediate_size;
     const int C = c.filter_sizes[c.num_conv_layers - 1];
-    if (int e = launch_transpose(m->P("feature_projection/projection/kernel"), t->WpT, C, H, 1, s)) return e;
     if (c.with_lm_head)
         if (int e = launch_transpose(m->P("lm_head/kernel"), t->WlmT, H, c.vocab_size, 1, s)) return e;
-    for (int i = 0; i < c.num_layers; ++i) {
-        const std::string b = "encoder/layers/" + std::to_string(i);
-        LayerSave& l = t->layers[i];
-        if (int e = launch_transpose(m->qkv_w[i], l.WqkvT, H, 3 * H, 1, s)) return e;
-        if (int e = launch_transpose(m->P(b + "/attention/out_proj/kernel"), l.WoT, H, H, 1, s)) return e;
-        if (int e = launch_transpose(m->P(b + "/feed_forward/intermediate_dense/kernel"), l.W1T, H, F, 1, s)) return e;
-        if (int e = launch_transpose(m->P(b + "/feed_forward/output_dense/kernel"), l.W2T, F, H, 1, s)) return e;
+    if (need_full) {
+        if (int e = launch_transpose(m->P("feature_projection/projection/kernel"), t->WpT, C, H, 1, s)) return e;
+        for (int i = 0; i < c.num_layers; ++i) {
+            const std::string b = "encoder/layers/" + std::to_string(i);
+            LayerSave& l = t->layers[i];
+            if (int e = launch_transpose(m->qkv_w[i], l.WqkvT, H, 3 * H, 1, s)) return e;
+            if (int e = launch_transpose(m->P(b + "/attention/out_proj/kernel"), l.WoT, H, H, 1, s)) return e;
+            if (int e = launch_transpose(m->P(b + "/feed_forward/intermediate_dense/kernel"), l.W1T, H, F, 1, s)) return e;
+            if (int e = launch_transpose(m->P(b + "/feed_forward/output_dense/kernel"), l.W2T, F, H, 1, s)) return e;
+        }
     }
     const int K = c.num_conv_pos_embeddings, G = c.num_conv_pos_embedding_groups;
     if (int e = launch_pos_conv_flip_regroup(m->pos_wg, t->pos_wg_t, K, H / G, G, s)) return e;
     t->pos_w16_t_fresh = false;
     t->transposes_fresh = true;
+    t->transposes_full = need_full;
     return W2V2_OK;
 }
 
@@ -398,8 +416,11 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
     const int NC = c.num_conv_layers;
 
     // ---- frozen feature extractor: identical to inference (no dropout inside, feature_extractor.py:54-59) ----
+    m->acts_skipped.clear();                   // conv outputs written only as bf16: see w2v2_api.hip::w2v2_conv_out_bf16_only
+    for (int i = 0; i + 1 < NC; ++i)
+        if (w2v2_conv_out_bf16_only(m, i, sh)) m->acts_skipped.push_back("conv" + std::to_string(i));
     if (int e = launch_conv0_x(pf, wave, fe(0, "/conv/kernel"), c.conv_bias ? fe(0, "/conv/bias") : nullptr,
-                               fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"), m->conv[0],
+                               fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"), w2v2_conv_out_bf16_only(m, 0, sh) ? nullptr : m->conv[0],
                                (sh && !layer_mode) ? m->conv16[0] : nullptr, m->conv0_ws, B, L, c.kernal_sizes[0], c.strides[0],
                                c.filter_sizes[0], 1e-5f, layer_mode ? 1 : 0, act, s))
         return e;
@@ -412,8 +433,8 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
         const int Tin = m->conv_T[i - 1], Tout = m->conv_T[i];
         uint16_t* o16 = (sh && i + 1 < NC) ? m->conv16[i] : nullptr;
         if (int e = gemm(m->conv[i - 1], sh ? m->conv16[i - 1] : nullptr, (int64_t)c.strides[i] * cin, (int64_t)Tin * cin,
-                         fe(i, "/conv/kernel"), cout, m->conv[i], layer_mode ? nullptr : o16, cout, (int64_t)Tout * cout,
-                         c.conv_bias ? fe(i, "/conv/bias") : nullptr, nullptr, Tout, cout, c.kernal_sizes[i] * cin, B,
+                         fe(i, "/conv/kernel"), cout, w2v2_conv_out_bf16_only(m, i, sh) ? nullptr : m->conv[i], layer_mode ? nullptr : o16, cout,
+                         (int64_t)Tout * cout, c.conv_bias ? fe(i, "/conv/bias") : nullptr, nullptr, Tout, cout, c.kernal_sizes[i] * cin, B,
                          layer_mode ? 0 : act))
             return e;
         if (layer_mode)

@@ -80,7 +80,8 @@ ATOL_BF16_LOGITS = 0.15
 
 
 @pytest.mark.parametrize("name", ["tiny_base", "tiny_robust", "base_sample_unpadded", "robust_masked"])
-def test_bf16_precision_logits(torch_mod, name):
+def test_bf16_precision_logits(torch_mod, name, monkeypatch):
+    monkeypatch.setenv("W2V2_KEEP_ACTIVATIONS", "1")      # the conv taps below: keep the fp32 copies this mode otherwise skips
     g = H.golden(name)
     m, cfg = build(name)
     w = H.case_weights(name)
@@ -141,6 +142,7 @@ def test_bf16_shadows_do_not_change_results(torch_mod, name):
     taps = [f"conv{i}" for i in range(len(cfg.kernal_sizes))] + ["projection", "encoder_in", "layer0", "encoder_out"]
     res = {}
     try:
+        os.environ["W2V2_KEEP_ACTIVATIONS"] = "1"
         for flag in ("0", "1"):
             os.environ["W2V2_BF16_SHADOWS"] = flag
             out = m(g["wave"], attention_mask=mask).numpy()
@@ -148,8 +150,19 @@ def test_bf16_shadows_do_not_change_results(torch_mod, name):
             res[flag]["logits"] = out
     finally:
         os.environ.pop("W2V2_BF16_SHADOWS", None)
+        os.environ.pop("W2V2_KEEP_ACTIVATIONS", None)
     for k in taps + ["logits"]:
         assert np.array_equal(res["0"][k], res["1"][k]), f"{k}: max diff {H.max_err(res['0'][k], res['1'][k]):.3e}"
+    # default in this mode: conv-stack outputs whose only consumer reads the bf16 shadow are written ONLY as bf16 (no fp32
+    # stores nothing would read): same logits bit for bit, and the taps of those stages say so instead of returning stale data
+    out = m(g["wave"], attention_mask=mask).numpy()
+    assert np.array_equal(out, res["1"]["logits"])
+    if cfg.feature_extractor_norm_type == "group":
+        with pytest.raises(RuntimeError, match="only as bf16"):
+            m.activation("conv1")
+        assert np.array_equal(m.activation(f"conv{len(cfg.kernal_sizes) - 1}"), res["1"][f"conv{len(cfg.kernal_sizes) - 1}"])
+    else:
+        assert np.array_equal(m.activation("conv1"), res["1"]["conv1"])
 
 
 @pytest.mark.parametrize("name", ["tiny_base", "base_sample_unpadded", "base_sample_padded", "robust_masked"])
