@@ -283,6 +283,7 @@ struct Attn16BwdArgs {
     const float* d_o;       // (B, T, H)
     const float* dvec;      // (B, heads, T)
     float* dqkv;            // (B, T, 3H)
+    uint16_t* dqkv16;       // optional bf16 shadow of dqkv (the A operand of the q|k|v data-gradient GEMM)
     int B, T, H, heads;
     float scale;
 };
@@ -464,13 +465,17 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dq_kernel(Attn16Bwd
         __syncthreads();
     }
     if (qok) {
-        float* op = a.dqkv + ((int64_t)b * a.T + q0 + li) * ld + head * DH + 4 * lh;
+        const int64_t o0 = ((int64_t)b * a.T + q0 + li) * ld + head * DH + 4 * lh;
+        float* op = a.dqkv + o0;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<f32x4*>(op + 32 * d + 8 * g) =
-                    f32x4{dq[d][4 * g] * a.scale, dq[d][4 * g + 1] * a.scale, dq[d][4 * g + 2] * a.scale, dq[d][4 * g + 3] * a.scale};
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = f32x4{dq[d][4 * g] * a.scale, dq[d][4 * g + 1] * a.scale, dq[d][4 * g + 2] * a.scale, dq[d][4 * g + 3] * a.scale};
+                *reinterpret_cast<f32x4*>(op + 32 * d + 8 * g) = v;
+                if (a.dqkv16)
+                    *reinterpret_cast<u32x2*>(a.dqkv16 + o0 + 32 * d + 8 * g) = u32x2{pack_bf16_rne(v[0], v[1]), pack_bf16_rne(v[2], v[3])};
+            }
     }
 }
 
@@ -581,17 +586,22 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
         __syncthreads();
     }
     if (kok) {
-        float* kp = a.dqkv + ((int64_t)b * a.T + key) * ld + a.H + head * DH + 4 * lh;
+        const int64_t k0 = ((int64_t)b * a.T + key) * ld + a.H + head * DH + 4 * lh;
+        float* kp = a.dqkv + k0;
         float* vp = kp + a.H;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 // kf was pre-scaled for S, so dS is the gradient of the SCALED score: dK = scale * dS^T Q
-                *reinterpret_cast<f32x4*>(kp + 32 * d + 8 * g) =
-                    f32x4{dk[d][4 * g] * a.scale, dk[d][4 * g + 1] * a.scale, dk[d][4 * g + 2] * a.scale, dk[d][4 * g + 3] * a.scale};
-                *reinterpret_cast<f32x4*>(vp + 32 * d + 8 * g) =
-                    f32x4{dvv[d][4 * g], dvv[d][4 * g + 1], dvv[d][4 * g + 2], dvv[d][4 * g + 3]};
+                const f32x4 kv = f32x4{dk[d][4 * g] * a.scale, dk[d][4 * g + 1] * a.scale, dk[d][4 * g + 2] * a.scale, dk[d][4 * g + 3] * a.scale};
+                const f32x4 vv = f32x4{dvv[d][4 * g], dvv[d][4 * g + 1], dvv[d][4 * g + 2], dvv[d][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(kp + 32 * d + 8 * g) = kv;
+                *reinterpret_cast<f32x4*>(vp + 32 * d + 8 * g) = vv;
+                if (a.dqkv16) {
+                    *reinterpret_cast<u32x2*>(a.dqkv16 + k0 + 32 * d + 8 * g) = u32x2{pack_bf16_rne(kv[0], kv[1]), pack_bf16_rne(kv[2], kv[3])};
+                    *reinterpret_cast<u32x2*>(a.dqkv16 + k0 + a.H + 32 * d + 8 * g) = u32x2{pack_bf16_rne(vv[0], vv[1]), pack_bf16_rne(vv[2], vv[3])};
+                }
             }
     }
 }
@@ -617,9 +627,10 @@ int launch_attention_fwd_bf16(const float* qkv, const int32_t* frame_len, float*
 
 // D must already be in `dvec` (attn_dvec_kernel, fp32, launched by the caller)
 int launch_attention_bwd_bf16(const float* qkv, const int32_t* frame_len, const float* dctx, const float* dvec,
-                              float* dqkv, int B, int T, int H, int heads, const AttnTrain& tr, hipStream_t s) {
+                              float* dqkv, uint16_t* dqkv16, int B, int T, int H, int heads, const AttnTrain& tr, hipStream_t s) {
     W2V2_REQUIRE(H / heads == DH, "attention_bwd_bf16: head size %d unsupported (64)", H / heads);
-    Attn16BwdArgs a{qkv, frame_len, dctx, dvec, dqkv, B, T, H, heads, 1.0f / sqrtf((float)DH)};
+    W2V2_REQUIRE((reinterpret_cast<uintptr_t>(dqkv16) & 7) == 0, "attention_bwd_bf16: unaligned shadow");
+    Attn16BwdArgs a{qkv, frame_len, dctx, dvec, dqkv, dqkv16, B, T, H, heads, 1.0f / sqrtf((float)DH)};
     const size_t lds_q = 2 * 3 * KT * ROWB, lds_kv = 2 * (4 * KT * ROWB + 2 * KT * 4);
     static std::atomic<bool> attr_set{false};   // (idempotent call; atomic so concurrent host threads agree on the flag)
     if (!attr_set) {

@@ -61,12 +61,16 @@ int launch_dropout_fwd(const float* x, const float* res, float* y, int64_t n, in
                        uint64_t seed, uint32_t stream_id, hipStream_t s);
 int launch_dropout_bwd(const float* u, const float* dy, float* dx, int64_t n, int act, float p,
                        uint64_t seed, uint32_t stream_id, hipStream_t s);
+int launch_dropout_bwd_x(const float* u, const float* dy, float* dx, uint16_t* dx16 /* optional bf16 shadow */, int64_t n, int act,
+                         float p, uint64_t seed, uint32_t stream_id, hipStream_t s);
 int launch_transpose(const float* x, float* y, int rows, int cols, int nbatch, hipStream_t s);
 int64_t colsum_ws_floats(int64_t rows, int cols);
 int launch_colsum(const float* x, float* out, int64_t rows, int cols, float* ws, int accumulate, hipStream_t s);
 int64_t ln_bwd_ws_floats(int64_t rows, int C);
 int launch_ln_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma,
                   float* dbeta, int64_t rows, int C, float eps, float* ws, hipStream_t s);
+int launch_ln_bwd_x(const float* x, const float* gamma, const float* dy, float* dx, uint16_t* dx16 /* optional bf16 shadow */,
+                    float* dgamma, float* dbeta, int64_t rows, int C, float eps, float* ws, hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1, float b2,
                 float eps, hipStream_t s);
 int launch_spec_aug_fwd(const float* x, const uint8_t* mask, const float* embed, float* y, int64_t rows, int H, hipStream_t s);
@@ -86,7 +90,8 @@ bool attention_bf16_supported(int head_size);
 int launch_attention_fwd_bf16(const float* qkv, const int32_t* frame_len, float* ctx, uint16_t* ctx16, int B, int T, int H,
                               int heads, const AttnTrain* tr, hipStream_t s);
 int launch_attention_bwd_bf16(const float* qkv, const int32_t* frame_len, const float* dctx, const float* dvec,
-                              float* dqkv, int B, int T, int H, int heads, const AttnTrain& tr, hipStream_t s);
+                              float* dqkv, uint16_t* dqkv16 /* optional bf16 shadow */, int B, int T, int H, int heads,
+                              const AttnTrain& tr, hipStream_t s);
 int launch_attention_train_x(Profiler* prof, const float* qkv, const int32_t* frame_len, float* ctx, uint16_t* ctx16, int B, int T,
                              int H, int heads, const AttnTrain& tr, hipStream_t s);
 int launch_attention_train(Profiler* prof, const float* qkv, const int32_t* frame_len, float* ctx, int B, int T,
@@ -94,7 +99,7 @@ int launch_attention_train(Profiler* prof, const float* qkv, const int32_t* fram
 // dqkv (B, T, 3H) = gradient of the packed q|k|v given dctx (B, T, H); ctx is the forward output
 int launch_attention_bwd(Profiler* prof, const float* qkv, const int32_t* frame_len, const float* ctx,
                          const float* dctx, float* dqkv, float* dvec_ws, int B, int T, int H, int heads,
-                         const AttnTrain& tr, hipStream_t s);
+                         const AttnTrain& tr, hipStream_t s, uint16_t* dqkv16 = nullptr /* bf16 shadow of dqkv (bf16 kernels only) */);
 
 // positional conv, training variants (posconv.hip)
 int launch_pos_conv_ex(Profiler* prof, const float* x, const float* wg, const float* bias,

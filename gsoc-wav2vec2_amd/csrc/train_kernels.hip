@@ -72,8 +72,8 @@ __global__ void dropout_fwd_kernel(const float* __restrict__ x, const float* __r
 // dx = dy * keep/(1-p) * act'(u)
 template <bool VEC>
 __global__ void dropout_bwd_kernel(const float* __restrict__ u, const float* __restrict__ dy,
-                                   float* __restrict__ dx, int64_t n, int act, float p, uint64_t seed,
-                                   uint32_t stream) {
+                                   float* __restrict__ dx, uint16_t* __restrict__ dx16 /* optional bf16 shadow of dx */, int64_t n, int act,
+                                   float p, uint64_t seed, uint32_t stream) {
     const float inv = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     const uint32_t key = dropout_key(seed, stream), thr = dropout_threshold(p);
     if (VEC) {
@@ -90,6 +90,7 @@ __global__ void dropout_bwd_kernel(const float* __restrict__ u, const float* __r
                 g[0] *= gelu_grad(uv.x, act); g[1] *= gelu_grad(uv.y, act); g[2] *= gelu_grad(uv.z, act); g[3] *= gelu_grad(uv.w, act);
             }
             reinterpret_cast<float4*>(dx)[i] = make_float4(g[0], g[1], g[2], g[3]);
+            if (dx16) reinterpret_cast<uint2*>(dx16)[i] = make_uint2(pack_bf16_rne(g[0], g[1]), pack_bf16_rne(g[2], g[3]));
         }
     } else {
         for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS) {
@@ -97,6 +98,7 @@ __global__ void dropout_bwd_kernel(const float* __restrict__ u, const float* __r
             if (p > 0.f) g = dropout_keep32(key, (uint32_t)i, thr) ? g * inv : 0.0f;
             if (act) g *= gelu_grad(u[i], act);
             dx[i] = g;
+            if (dx16) dx16[i] = (uint16_t)pack_bf16_rne(g, 0.f);
         }
     }
 }
@@ -226,6 +228,7 @@ __global__ __launch_bounds__(256) void colsum_final_wide_kernel(const float* __r
 template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ dy, float* __restrict__ dx,
+                                                     uint16_t* __restrict__ dx16 /* optional bf16 shadow of dx */,
                                                      float* __restrict__ partial, int64_t rows, int C, float eps) {
     extern __shared__ float red[];   // 4 waves x 2 x C
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -304,10 +307,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int c = (i * 64 + lane) * 4;
-                if (c < C)
-                    *reinterpret_cast<float4*>(dxr + c) =
-                        make_float4(rstd * (gv[i][0] - s1 - xv[i][0] * s2), rstd * (gv[i][1] - s1 - xv[i][1] * s2),
-                                    rstd * (gv[i][2] - s1 - xv[i][2] * s2), rstd * (gv[i][3] - s1 - xv[i][3] * s2));
+                if (c < C) {
+                    const float4 o = make_float4(rstd * (gv[i][0] - s1 - xv[i][0] * s2), rstd * (gv[i][1] - s1 - xv[i][1] * s2),
+                                                 rstd * (gv[i][2] - s1 - xv[i][2] * s2), rstd * (gv[i][3] - s1 - xv[i][3] * s2));
+                    *reinterpret_cast<float4*>(dxr + c) = o;
+                    if (dx16) *reinterpret_cast<uint2*>(dx16 + row * C + c) = make_uint2(pack_bf16_rne(o.x, o.y), pack_bf16_rne(o.z, o.w));
+                }
             }
         } else {
 #pragma unroll
@@ -315,7 +320,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int c = (i * 64 + lane) * 4 + e;
-                    if (c < C) dxr[c] = rstd * (gv[i][e] - s1 - xv[i][e] * s2);
+                    if (c < C) {
+                        const float o = rstd * (gv[i][e] - s1 - xv[i][e] * s2);
+                        dxr[c] = o;
+                        if (dx16) dx16[row * C + c] = (uint16_t)pack_bf16_rne(o, 0.f);
+                    }
                 }
         }
     }
@@ -426,12 +435,18 @@ int launch_dropout_fwd_x(const float* x, const float* res, float* y, uint16_t* y
 
 int launch_dropout_bwd(const float* u, const float* dy, float* dx, int64_t n, int act, float p,
                        uint64_t seed, uint32_t stream_id, hipStream_t s) {
+    return launch_dropout_bwd_x(u, dy, dx, nullptr, n, act, p, seed, stream_id, s);
+}
+
+int launch_dropout_bwd_x(const float* u, const float* dy, float* dx, uint16_t* dx16, int64_t n, int act, float p,
+                         uint64_t seed, uint32_t stream_id, hipStream_t s) {
     W2V2_REQUIRE(dy && dx && n > 0 && p >= 0.f && p < 1.f && (act == 0 || u), "dropout_bwd: bad argument");
-    const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
+    const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(dx16) & 7) == 0;
     if (vec)
-        hipLaunchKernelGGL(dropout_bwd_kernel<true>, dim3(ew_grid(n >> 2)), dim3(EW_THREADS), 0, s, u, dy, dx, n, act, p, seed, stream_id);
+        hipLaunchKernelGGL(dropout_bwd_kernel<true>, dim3(ew_grid(n >> 2)), dim3(EW_THREADS), 0, s, u, dy, dx, dx16, n, act, p, seed, stream_id);
     else
-        hipLaunchKernelGGL(dropout_bwd_kernel<false>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, s, u, dy, dx, n, act, p, seed, stream_id);
+        hipLaunchKernelGGL(dropout_bwd_kernel<false>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, s, u, dy, dx, dx16, n, act, p, seed, stream_id);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -482,16 +497,22 @@ int64_t ln_bwd_ws_floats(int64_t rows, int C) { return (int64_t)ln_bwd_blocks(ro
 
 int launch_ln_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma,
                   float* dbeta, int64_t rows, int C, float eps, float* ws, hipStream_t s) {
+    return launch_ln_bwd_x(x, gamma, dy, dx, nullptr, dgamma, dbeta, rows, C, eps, ws, s);
+}
+
+int launch_ln_bwd_x(const float* x, const float* gamma, const float* dy, float* dx, uint16_t* dx16, float* dgamma,
+                    float* dbeta, int64_t rows, int C, float eps, float* ws, hipStream_t s) {
     W2V2_REQUIRE(x && gamma && dy && dx && dgamma && dbeta && ws, "ln_bwd: null operand");
+    W2V2_REQUIRE(!dx16 || ((C & 3) == 0 && (reinterpret_cast<uintptr_t>(dx16) & 7) == 0), "ln_bwd: the bf16 shadow needs C %% 4 == 0");
     W2V2_REQUIRE(rows > 0 && C > 0 && C <= 1024, "ln_bwd: rows=%lld C=%d unsupported (C <= 1024)", (long long)rows, C);
     const int nb = ln_bwd_blocks(rows);
     const size_t lds = (size_t)4 * 2 * C * sizeof(float);
     if (C <= 256)
-        hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, ws, rows, C, eps);
+        hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, dx16, ws, rows, C, eps);
     else if (C <= 512)
-        hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, ws, rows, C, eps);
+        hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, dx16, ws, rows, C, eps);
     else
-        hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, ws, rows, C, eps);
+        hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, dx16, ws, rows, C, eps);
     // partial is (nb, 2C): dgamma = column sums of its first C columns, dbeta of its last C
     const dim3 g2((C + EW_THREADS - 1) / EW_THREADS);
     (void)g2;

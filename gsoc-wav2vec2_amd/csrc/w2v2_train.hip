@@ -59,6 +59,9 @@ struct TrainState {
     float *gh[4] = {nullptr, nullptr, nullptr, nullptr}, *gf = nullptr, *g3h = nullptr, *at = nullptr,
           *slabs = nullptr, *red_ws = nullptr, *dvec = nullptr, *dummy = nullptr, *dwqkv = nullptr, *dwv_scratch = nullptr;
     int64_t slab_floats = 0;
+    // bf16 shadows of the gradient tensors that are the A operand of a data-gradient GEMM (precision mode 1): written by the
+    // producing kernel (LayerNorm / dropout / attention backward), consumed by the GEMM enqueued right behind it
+    uint16_t *dy16_h = nullptr, *dy16_f = nullptr, *dy16_3h = nullptr;
     float* cs_ws = nullptr;           // (slabs + 1, widest N): per-slab column sums of dY from the weight-gradient GEMM
     int64_t cs_floats = 0;
     bool forward_done = false;
@@ -208,6 +211,14 @@ static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
     if (lw > rw) rw = lw;
     if (int e = t_alloc(t, &t->red_ws, rw + 16)) return e;
     if (int e = t_alloc(t, &t->dvec, (int64_t)B * c.num_heads * T)) return e;
+    {
+        float* raw = nullptr;                   // (BT, H) + (BT, F) + (BT, 3H) bf16, each 16-byte aligned
+        auto up8 = [](int64_t n) { return (n + 7) & ~(int64_t)7; };
+        if (int e = t_alloc(t, &raw, (up8(BT * H) + up8(BT * F) + up8(BT * 3 * H)) / 2 + 16)) return e;
+        t->dy16_h = reinterpret_cast<uint16_t*>(raw);
+        t->dy16_f = t->dy16_h + up8(BT * H);
+        t->dy16_3h = t->dy16_f + up8(BT * F);
+    }
     t->B = B;
     t->L = L;
     t->T = T;
@@ -570,12 +581,14 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     // dX = dY W^T reads the fp32 transposed copy WT ([out][in]) as its B operand; in precision mode 1 with shadows the bf16
     // copy of W itself ([in][out] = (N, K) for this GEMM) is the B shadow -- no transpose needed.  Bit-identical results.
     const bool shb = m->precision == 1 && w2v2_shadows_enabled() && m->w16_valid;
-    auto gemm_dx = [&](const float* A, int64_t lda, const float* WT, const float* W, float* Cc, int64_t ldc, const float* res,
-                       int M, int N, int K, hipStream_t st) -> int {
+    // A16: the producer's bf16 shadow of A (or null): with it both operands stream by LDS-DMA (gemm_bf16.hip source 5)
+    auto gemm_dx = [&](const float* A, const uint16_t* A16, int64_t lda, const float* WT, const float* W, float* Cc, int64_t ldc,
+                       const float* res, int M, int N, int K, hipStream_t st) -> int {
         if (shb) {
             auto it = m->w16p.find(W);
             if (it != m->w16p.end()) {
                 GemmShadows x;
+                x.A16 = A16;
                 x.B16 = it->second;
                 x.ldb16 = K;
                 return launch_gemm_bf16_x(m->prof, A, lda, 0, WT, N, 0, Cc, ldc, 0, nullptr, res, M, N, K, 1, 0, x, st);
@@ -588,6 +601,11 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         }
         return launch_gemm(m->prof, A, lda, 0, WT, N, Cc, ldc, 0, nullptr, res, M, N, K, 1, 0, st);
     };
+    // bf16 shadows of dY (written by its producer) for the data-gradient GEMMs: only where the consumer will take them
+    const int dhead = c.hidden_size / c.num_heads;
+    uint16_t* const s16h = shb ? t->dy16_h : nullptr;
+    uint16_t* const s16f = shb ? t->dy16_f : nullptr;
+    uint16_t* const s16q = (shb && attention_bf16_supported(dhead)) ? t->dy16_3h : nullptr;
     for (size_t i = 0; i < m->params.size(); ++i)
         if (t->trainable[i] && m->params[i].name.compare(0, 18, "feature_extractor/") == 0) {
             set_error("train_backward: `%s` is trainable, but the conv feature extractor has no backward "
@@ -679,12 +697,12 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
             if (int e = weight_grad(m, l.gd, dh, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
                                     G(b + "/feed_forward/output_dense/bias"), s))
                 return e;
-            if (int e = gemm_dx(dh, H, l.W2T, m->P(b + "/feed_forward/output_dense/kernel"), t->gf, F, nullptr, (int)BT, F, H, s)) return e;
-            if (int e = launch_dropout_bwd(l.u, t->gf, t->gf, BT * F, act, p, seed, layer_stream(i, 2), s)) return e;
+            if (int e = gemm_dx(dh, nullptr, H, l.W2T, m->P(b + "/feed_forward/output_dense/kernel"), t->gf, F, nullptr, (int)BT, F, H, s)) return e;
+            if (int e = launch_dropout_bwd_x(l.u, t->gf, t->gf, s16f, BT * F, act, p, seed, layer_stream(i, 2), s)) return e;
             if (int e = weight_grad(m, l.t2, t->gf, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
                                     G(b + "/feed_forward/intermediate_dense/bias"), s))
                 return e;
-            if (int e = gemm_dx(t->gf, F, l.W1T, m->P(b + "/feed_forward/intermediate_dense/kernel"), tmp, H, nullptr, (int)BT, H, F, s)) return e;
+            if (int e = gemm_dx(t->gf, s16f, F, l.W1T, m->P(b + "/feed_forward/intermediate_dense/kernel"), tmp, H, nullptr, (int)BT, H, F, s)) return e;
             float* dg2 = G(b + "/final_layer_norm/gamma");
             float* db2 = G(b + "/final_layer_norm/beta");
             if (int e = launch_ln_bwd(l.t1, m->P(b + "/final_layer_norm/gamma"), tmp, tmp2, dg2 ? dg2 : t->dummy,
@@ -695,14 +713,14 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
             W2V2_HIP_CHECK(hipMemcpyAsync(dt1, dh, (size_t)BT * H * 4, hipMemcpyDeviceToDevice, s));
         }
         float* d_o = tmp;
-        if (int e = launch_dropout_bwd(nullptr, dt1, d_o, BT * H, 0, p, seed, layer_stream(i, 1), s)) return e;
+        if (int e = launch_dropout_bwd_x(nullptr, dt1, d_o, s16h, BT * H, 0, p, seed, layer_stream(i, 1), s)) return e;
         if (int e = weight_grad(m, l.ctx, d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), G(b + "/attention/out_proj/bias"), s)) return e;
         float* dctx = tmp2;
-        if (int e = gemm_dx(d_o, H, l.WoT, m->P(b + "/attention/out_proj/kernel"), dctx, H, nullptr, (int)BT, H, H, s)) return e;
+        if (int e = gemm_dx(d_o, s16h, H, l.WoT, m->P(b + "/attention/out_proj/kernel"), dctx, H, nullptr, (int)BT, H, H, s)) return e;
         AttnTrain tr{p, seed, layer_stream(i, 0), l.lse};
-        if (int e = launch_attention_bwd(pf, l.qkv, flen, l.ctx, dctx, t->g3h, t->dvec, B, T, H, c.num_heads, tr, s)) return e;
+        if (int e = launch_attention_bwd(pf, l.qkv, flen, l.ctx, dctx, t->g3h, t->dvec, B, T, H, c.num_heads, tr, s, s16q)) return e;
         if (int e = qkv_weight_grad(b, l.a)) return e;
-        if (int e = gemm_dx(t->g3h, 3 * H, l.WqkvT, m->qkv_w[i], tmp, H, nullptr, (int)BT, H, 3 * H, s)) return e;
+        if (int e = gemm_dx(t->g3h, s16q, 3 * H, l.WqkvT, m->qkv_w[i], tmp, H, nullptr, (int)BT, H, 3 * H, s)) return e;
         float* dg1 = G(b + "/layer_norm/gamma");
         float* db1 = G(b + "/layer_norm/beta");
         if (int e = launch_ln_bwd(x, m->P(b + "/layer_norm/gamma"), tmp, tmp2, dg1 ? dg1 : t->dummy, db1 ? db1 : t->dummy + H, BT, H,
@@ -719,8 +737,8 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         float* dt3 = tmp;
         float* dg2 = G(b + "/final_layer_norm/gamma");
         float* db2 = G(b + "/final_layer_norm/beta");
-        if (int e = launch_ln_bwd(l.t3, m->P(b + "/final_layer_norm/gamma"), dh, dt3, dg2 ? dg2 : t->dummy, db2 ? db2 : t->dummy + H,
-                                  BT, H, eps, t->red_ws, s))
+        if (int e = launch_ln_bwd_x(l.t3, m->P(b + "/final_layer_norm/gamma"), dh, dt3, (l.keep != 0.f && H % 4 == 0) ? s16h : nullptr,
+                                    dg2 ? dg2 : t->dummy, db2 ? db2 : t->dummy + H, BT, H, eps, t->red_ws, s))
             return e;
         float* dt2 = tmp2;
         if (l.keep != 0.f) {
@@ -728,14 +746,14 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
             if (int e = weight_grad(m, l.gd, dt3, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
                                     G(b + "/feed_forward/output_dense/bias"), s))
                 return e;
-            if (int e = gemm_dx(dt3, H, l.W2T, m->P(b + "/feed_forward/output_dense/kernel"), t->gf, F, nullptr, (int)BT, F, H, s)) return e;
+            if (int e = gemm_dx(dt3, H % 4 == 0 ? s16h : nullptr, H, l.W2T, m->P(b + "/feed_forward/output_dense/kernel"), t->gf, F, nullptr, (int)BT, F, H, s)) return e;
             // du = dgd * keep/(1-p) * GELU'(u)
-            if (int e = launch_dropout_bwd(l.u, t->gf, t->gf, BT * F, act, p, seed, layer_stream(i, 2), s)) return e;
+            if (int e = launch_dropout_bwd_x(l.u, t->gf, t->gf, s16f, BT * F, act, p, seed, layer_stream(i, 2), s)) return e;
             if (int e = weight_grad(m, l.t2, t->gf, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
                                     G(b + "/feed_forward/intermediate_dense/bias"), s))
                 return e;
             // dt2 = du W1^T + dt3 (the residual branch)
-            if (int e = gemm_dx(t->gf, F, l.W1T, m->P(b + "/feed_forward/intermediate_dense/kernel"), dt2, H, dt3, (int)BT, H, F, s)) return e;
+            if (int e = gemm_dx(t->gf, s16f, F, l.W1T, m->P(b + "/feed_forward/intermediate_dense/kernel"), dt2, H, dt3, (int)BT, H, F, s)) return e;
         } else {
             W2V2_HIP_CHECK(hipMemcpyAsync(dt2, dt3, (size_t)BT * H * 4, hipMemcpyDeviceToDevice, s));
         }
@@ -747,16 +765,16 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
                                   eps, t->red_ws, s))
             return e;
         // t1 = dropout(o) + x,  o = ctx Wo + bo
-        float* d_o = tmp;     // dt3 is dead
-        if (int e = launch_dropout_bwd(nullptr, dt1, d_o, BT * H, 0, p, seed, layer_stream(i, 1), s)) return e;
+        float* d_o = tmp;     // dt3 (and its shadow) is dead
+        if (int e = launch_dropout_bwd_x(nullptr, dt1, d_o, s16h, BT * H, 0, p, seed, layer_stream(i, 1), s)) return e;
         if (int e = weight_grad(m, l.ctx, d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), G(b + "/attention/out_proj/bias"), s)) return e;
         float* dctx = tmp2;   // dt2 is dead
-        if (int e = gemm_dx(d_o, H, l.WoT, m->P(b + "/attention/out_proj/kernel"), dctx, H, nullptr, (int)BT, H, H, s)) return e;
+        if (int e = gemm_dx(d_o, s16h, H, l.WoT, m->P(b + "/attention/out_proj/kernel"), dctx, H, nullptr, (int)BT, H, H, s)) return e;
         AttnTrain tr{p, seed, layer_stream(i, 0), l.lse};
-        if (int e = launch_attention_bwd(pf, l.qkv, flen, l.ctx, dctx, t->g3h, t->dvec, B, T, H, c.num_heads, tr, s)) return e;
+        if (int e = launch_attention_bwd(pf, l.qkv, flen, l.ctx, dctx, t->g3h, t->dvec, B, T, H, c.num_heads, tr, s, s16q)) return e;
         if (int e = qkv_weight_grad(b, m->hs[i])) return e;
         // dx = dqkv Wqkv^T + dt1 (residual)
-        if (int e = gemm_dx(t->g3h, 3 * H, l.WqkvT, m->qkv_w[i], dh, H, dt1, (int)BT, H, 3 * H, s)) return e;
+        if (int e = gemm_dx(t->g3h, s16q, 3 * H, l.WqkvT, m->qkv_w[i], dh, H, dt1, (int)BT, H, 3 * H, s)) return e;
         if (int e = bucket_done(c.num_layers - i)) return e;
     }
     // ---- encoder input: postnorm hs[0] = dropout(LN(posout));  prenorm hs0 = dropout(posout) ----
@@ -839,7 +857,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     if (dgp || dbp) {
         float* dln = tmp2;       // (BT, C) fits a (BT, H) buffer when C <= H; otherwise use the FFN scratch
         if (C > H) dln = t->gf;
-        if (int e = gemm_dx(dproj, H, t->WpT, m->P("feature_projection/projection/kernel"), dln, C, nullptr, (int)BT, C, H, s)) return e;
+        if (int e = gemm_dx(dproj, nullptr, H, t->WpT, m->P("feature_projection/projection/kernel"), dln, C, nullptr, (int)BT, C, H, s)) return e;
         float* dxc = C > H ? t->g3h : tmp;    // gradient w.r.t. the frozen conv output: computed and dropped
         if (int e = launch_ln_bwd(m->conv[c.num_conv_layers - 1], m->P("feature_projection/layer_norm/gamma"), dln, dxc,
                                   dgp ? dgp : t->dummy, dbp ? dbp : t->dummy + C, BT, C, eps, t->red_ws, s))
