@@ -15,6 +15,10 @@
 //   pass 2 (apply):  recompute, scale/shift, GELU, write once, coalesced along C.
 // A thread owns channels (the kernel taps live in its registers); the waveform
 // chunk is staged in LDS and read as a wave-uniform broadcast.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
 
 namespace w2v2 {
@@ -137,10 +141,11 @@ using u32x2_c0 = __attribute__((ext_vector_type(2))) unsigned;
 
 template <int MODE, int KT, int ST>
 __global__ __launch_bounds__(256) void conv0_apply4_kernel(Conv0Args a, int tpr /* lanes per frame = C / 4 */) {
+    constexpr int TCB = TC;      // frames per block: 32 / 128 / 256 / 512 measured 0.644 / 0.638 / 0.655 / 0.711 ms against 0.627-0.635 for 64
     extern __shared__ __attribute__((aligned(16))) float xs[];
     const int b = blockIdx.y, chunk = blockIdx.x;
-    const int t0 = chunk * TC;
-    const int nt = min(TC, a.T0 - t0);
+    const int t0 = chunk * TCB;
+    const int nt = min(TCB, a.T0 - t0);
     const int nx = (nt - 1) * ST + KT;
     const float* __restrict__ wv = a.wave + (int64_t)b * a.L + (int64_t)t0 * ST;
     for (int i = threadIdx.x; i < nx; i += 256) xs[i] = wv[i];
@@ -169,6 +174,8 @@ __global__ __launch_bounds__(256) void conv0_apply4_kernel(Conv0Args a, int tpr 
 #pragma unroll
             for (int j = 0; j < 4; ++j) y[j] = apply_act(fmaf(y[j], sc[j], sh[j]), a.act);
         }
+        // nontemporal: 0.635 ms against 0.657 with plain stores (3.2 GB streamed once; tools/write_bw.hip: a bare 128-KiB-per-block
+        // fill reaches 5.7-5.9 TB/s, hipMemsetAsync 6.5, this kernel 5.1-5.2 including the waveform reads and the arithmetic)
         if (orow) __builtin_nontemporal_store(y, reinterpret_cast<f32x4_c0*>(orow + (int64_t)t * a.C));
         if (orow16) {
             u32x2_c0 h;
