@@ -150,6 +150,15 @@ int launch_conv0_x(Profiler* prof, const float* wave, const float* kernel, const
                    int B, int64_t L, int K, int stride, int C, float eps, int norm_mode, int act, hipStream_t s);
 // fp32 -> bf16 (nearest even): plain copy, and [K][N] -> [N][K] transpose (GEMM weight shadows)
 int launch_to_bf16(const float* x, uint16_t* y, int64_t n, hipStream_t s);
+// one 64 x 64 tile of one weight for the single-launch shadow refresh (shadow.hip): w (K, N) fp32 -> wt (N, K) bf16 and / or
+// plain (K, N) bf16 (either may be null)
+struct ShadowJob {
+    const float* w;
+    uint16_t* wt;
+    uint16_t* plain;
+    int K, N, k0, n0;
+};
+int launch_weight_shadows_multi(const ShadowJob* jobs_dev, int njobs, hipStream_t s);
 int launch_transpose_to_bf16(const float* w, uint16_t* wt, int K, int N, hipStream_t s);
 
 int launch_weight_norm_regroup(Profiler* prof, const float* wv, const float* wg, float* out, int K,

@@ -48,6 +48,9 @@ struct w2v2_model {
     std::unordered_map<const float*, uint16_t*> w16;      // (N, K): forward GEMMs
     std::unordered_map<const float*, uint16_t*> w16p;     // plain (K, N) bf16 copy = the (N, K) shadow of W^T: dX GEMMs
     std::vector<void*> sh_allocs, w16_allocs;
+    w2v2::ShadowJob* shadow_jobs = nullptr;               // device table of the single-launch weight-shadow refresh
+    int shadow_njobs = 0;
+    bool shadow_jobs_train = false;                       // the table includes the plain copies (built after training state existed)
     std::vector<uint16_t*> conv16, hs16;
     uint16_t *ln512_16 = nullptr, *ctx16 = nullptr, *t0_16 = nullptr, *t2_16 = nullptr, *ffn16 = nullptr, *enc16 = nullptr;
     // bf16 positional conv (precision mode 1; posconv.hip): kernel shadow (groups, og, K cg), pack scratch (B, G, T+K-1, cg)

@@ -38,6 +38,29 @@ __global__ __launch_bounds__(256) void transpose_to_bf16_kernel(const float* __r
     }
 }
 
+// All weight shadows of a model in ONE launch: block -> (weight, 64 x 64 tile) through a device table.  After every optimizer
+// step the bf16 training path refreshes ~75 transposed shadows and ~55 plain copies; as separate launches that was ~130
+// launches and ~1.3 ms per step for 0.75 GB of traffic.  A tile is read once (coalesced fp32), written as a plain bf16 copy
+// (when the weight has one) and, through LDS, as the transposed (N, K) shadow.
+__global__ __launch_bounds__(256) void weight_shadows_multi_kernel(const ShadowJob* __restrict__ jobs) {
+    __shared__ float tile[64][65];
+    const ShadowJob j = jobs[blockIdx.x];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int k = j.k0 + r, n = j.n0 + tx;
+        const bool ok = k < j.K && n < j.N;
+        const float v = ok ? j.w[(int64_t)k * j.N + n] : 0.f;
+        tile[r][tx] = v;
+        if (ok && j.plain) j.plain[(int64_t)k * j.N + n] = (uint16_t)pack_bf16_rne(v, 0.f);
+    }
+    __syncthreads();
+    if (j.wt)
+        for (int r = ty; r < 64; r += 4) {
+            const int n = j.n0 + r, k = j.k0 + tx;
+            if (n < j.N && k < j.K) j.wt[(int64_t)n * j.K + k] = (uint16_t)pack_bf16_rne(tile[tx][r], 0.f);
+        }
+}
+
 // q | k | v packing of one layer's attention projections: three (H, H) kernels -> one (H, 3H), three (H) biases -> (3H)
 // (and the reverse for their gradients).  One launch per layer instead of three strided + three linear copies.
 struct QkvPtrs {
@@ -139,6 +162,13 @@ int launch_to_bf16(const float* x, uint16_t* y, int64_t n, hipStream_t s) {
     W2V2_REQUIRE(x && y && n > 0, "to_bf16: bad argument");
     W2V2_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0, "to_bf16: unaligned buffer");
     hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, x, y, n);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
+int launch_weight_shadows_multi(const ShadowJob* jobs_dev, int njobs, hipStream_t s) {
+    W2V2_REQUIRE(jobs_dev && njobs > 0, "weight_shadows_multi: bad argument");
+    hipLaunchKernelGGL(weight_shadows_multi_kernel, dim3((unsigned)njobs), dim3(256), 0, s, jobs_dev);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }

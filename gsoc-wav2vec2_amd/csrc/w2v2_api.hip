@@ -297,33 +297,47 @@ int w2v2_ensure_shadows(w2v2_model* m, int B, int T, hipStream_t s) {
         m->sh_ready = true;
     }
     if (!m->w16_valid) {
-        auto shadow = [&](const float* w, int K, int N) -> int {
-            uint16_t*& dst = m->w16[w];
-            if (!dst)
-                if (int e = sh_alloc(m->w16_allocs, &dst, (int64_t)K * N)) return e;
-            if (int e = launch_transpose_to_bf16(w, dst, K, N, s)) return e;
-            if (m->train && N % 64 == 0 && (K * (int64_t)N) % 4 == 0) {     // training: the backward's dX GEMM contracts over N
-                uint16_t*& dp = m->w16p[w];
-                if (!dp)
-                    if (int e = sh_alloc(m->w16_allocs, &dp, (int64_t)K * N)) return e;
-                return launch_to_bf16(w, dp, (int64_t)K * N, s);
+        // (re)build the job table when it does not exist yet or the plain copies have become necessary (training started)
+        const bool want_plain = m->train != nullptr;
+        if (!m->shadow_jobs || (want_plain && !m->shadow_jobs_train)) {
+            std::vector<ShadowJob> jobs;
+            auto shadow = [&](const float* w, int K, int N) -> int {
+                uint16_t*& dst = m->w16[w];
+                if (!dst)
+                    if (int e = sh_alloc(m->w16_allocs, &dst, (int64_t)K * N)) return e;
+                uint16_t* plain = nullptr;
+                if (want_plain && N % 64 == 0 && (K * (int64_t)N) % 4 == 0) {     // training: the backward's dX GEMM contracts over N
+                    uint16_t*& dp = m->w16p[w];
+                    if (!dp)
+                        if (int e = sh_alloc(m->w16_allocs, &dp, (int64_t)K * N)) return e;
+                    plain = dp;
+                }
+                for (int k0 = 0; k0 < K; k0 += 64)
+                    for (int n0 = 0; n0 < N; n0 += 64) jobs.push_back(ShadowJob{w, dst, plain, K, N, k0, n0});
+                return W2V2_OK;
+            };
+            for (int i = 1; i < c.num_conv_layers; ++i)
+                if (int e = shadow(m->P("feature_extractor/conv_layers/" + std::to_string(i) + "/conv/kernel"),
+                                   c.kernal_sizes[i] * c.filter_sizes[i - 1], c.filter_sizes[i]))
+                    return e;
+            if (int e = shadow(m->P("feature_projection/projection/kernel"), c.filter_sizes[c.num_conv_layers - 1], (int)H)) return e;
+            for (int i = 0; i < c.num_layers; ++i) {
+                const std::string b = "encoder/layers/" + std::to_string(i);
+                if (int e = shadow(m->qkv_w[i], (int)H, 3 * (int)H)) return e;
+                if (int e = shadow(m->P(b + "/attention/out_proj/kernel"), (int)H, (int)H)) return e;
+                if (int e = shadow(m->P(b + "/feed_forward/intermediate_dense/kernel"), (int)H, (int)F)) return e;
+                if (int e = shadow(m->P(b + "/feed_forward/output_dense/kernel"), (int)F, (int)H)) return e;
             }
-            return W2V2_OK;
-        };
-        for (int i = 1; i < c.num_conv_layers; ++i)
-            if (int e = shadow(m->P("feature_extractor/conv_layers/" + std::to_string(i) + "/conv/kernel"),
-                               c.kernal_sizes[i] * c.filter_sizes[i - 1], c.filter_sizes[i]))
-                return e;
-        if (int e = shadow(m->P("feature_projection/projection/kernel"), c.filter_sizes[c.num_conv_layers - 1], (int)H)) return e;
-        for (int i = 0; i < c.num_layers; ++i) {
-            const std::string b = "encoder/layers/" + std::to_string(i);
-            if (int e = shadow(m->qkv_w[i], (int)H, 3 * (int)H)) return e;
-            if (int e = shadow(m->P(b + "/attention/out_proj/kernel"), (int)H, (int)H)) return e;
-            if (int e = shadow(m->P(b + "/feed_forward/intermediate_dense/kernel"), (int)H, (int)F)) return e;
-            if (int e = shadow(m->P(b + "/feed_forward/output_dense/kernel"), (int)F, (int)H)) return e;
+            if (c.with_lm_head)
+                if (int e = shadow(m->P("lm_head/kernel"), (int)H, c.vocab_size)) return e;
+            if (m->shadow_jobs) W2V2_HIP_CHECK(hipFree(m->shadow_jobs));
+            m->shadow_jobs = nullptr;
+            W2V2_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m->shadow_jobs), jobs.size() * sizeof(ShadowJob)));
+            W2V2_HIP_CHECK(hipMemcpy(m->shadow_jobs, jobs.data(), jobs.size() * sizeof(ShadowJob), hipMemcpyHostToDevice));
+            m->shadow_njobs = (int)jobs.size();
+            m->shadow_jobs_train = want_plain;
         }
-        if (c.with_lm_head)
-            if (int e = shadow(m->P("lm_head/kernel"), (int)H, c.vocab_size)) return e;
+        if (int e = launch_weight_shadows_multi(m->shadow_jobs, m->shadow_njobs, s)) return e;
         m->w16_valid = true;
     }
     return W2V2_OK;
@@ -426,6 +440,7 @@ void w2v2_destroy(w2v2_model* m) {
     for (auto& kv : m->w48)
         if (kv.second.p) (void)hipFree(kv.second.p);
     if (m->pos_w16) (void)hipFree(m->pos_w16);
+    if (m->shadow_jobs) (void)hipFree(m->shadow_jobs);
     profiler_destroy(m->prof);
     delete m;
 }
