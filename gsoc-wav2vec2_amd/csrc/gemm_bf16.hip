@@ -48,7 +48,6 @@ struct Gemm16Args {
     const uint16_t* B16;
     uint16_t* C16;
     int64_t ldb16;
-    const uint16_t* B16p;      // SRC 8: plain (K, N) bf16 copy of B (row stride ldb, batch stride strideB)
     // two-level batch (grouped conv as GEMM): z = zo * zmod + zi.  A advances with z; B16 and bias with zi; C / residual
     // with zo * strideC2 + zi * strideC.  zmod = 0: plain batch (C advances with z * strideC, B16 and bias are shared).
     int zmod;
@@ -68,11 +67,6 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     return r;
 }
 
-// two bf16 halves (the same half `hi` of two dwords) -> one dword (k1 in the high half): one v_perm_b32
-__device__ __forceinline__ unsigned perm_pair(unsigned k1, unsigned k0, int hi) {
-    return hi ? __builtin_amdgcn_perm(k1, k0, 0x07060302u) : __builtin_amdgcn_perm(k1, k0, 0x05040100u);
-}
-
 // 16-byte-slot swizzle of an LDS row (8 slots per 128-byte row).  Chosen so that all three access patterns are
 // bank-conflict free: ds_read_b128 fragment reads (16-lane groups {0-3,12-15,20-27}, ... of consecutive rows),
 // the A stores (16 lanes = one row) and the transposing B stores (8 lanes = rows 4 q + j or 2 q + j, q = 8g..8g+7).
@@ -86,18 +80,13 @@ template <> struct FVec<2> { using type = f32x2; };
 // 2 = A from its bf16 shadow, 3 = B from its bf16 [N][K] shadow, 4 = both shadows (no conversion at all: the tile
 // step streams 32 KiB instead of 64), 5 = both shadows copied HBM/L2 -> LDS by global_load_lds_dwordx4 (the swizzle
 // then goes on the per-lane SOURCE address, as in gemm_f32.hip), 7 = fp32 with A TRANSPOSED in memory ((K, M), the
-// activation itself in a weight-gradient GEMM  dW = X^T dY): A takes B's register-transposing path, no transposed copy;
-// 8 = the same with A^T and B read from their bf16 shadows (8-byte loads of 4 consecutive m | n, two 16-bit halves permuted
-// into k-pairs with v_perm_b32 instead of rounded with v_cvt_pk) -- half the operand bytes of 7; blocks that also sum the
-// columns of B (the bias gradient) read B in fp32 as 7 does.  Shadows hold exactly the values the fp32 path would round to,
-// so all of them produce bit-identical results.
+// activation itself in a weight-gradient GEMM  dW = X^T dY): A takes B's register-transposing path, no transposed copy.  Shadows hold exactly the values the fp32 path would round to, so all five
+// produce bit-identical results.
 template <int SRC, int BM, int BN, int WM, int WN, int MINB>
 __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args g) {
     constexpr bool FAST = SRC >= 1, A16 = SRC == 2 || (SRC >= 4 && SRC <= 6), B16 = SRC == 3 || (SRC >= 4 && SRC <= 6);
-    static_assert(SRC != 8 || (2 * BN >= WM * WN * 64), "source 8 needs 4-column B patches");
     constexpr bool DMA = SRC == 5 || SRC == 6;      // both shadows, LDS-DMA staging (no registers, no ds_write)
-    constexpr bool AT = SRC == 7 || SRC == 8;       // A given TRANSPOSED ((K, M), m-contiguous): staged like B
-    constexpr bool AT16 = SRC == 8;                 // ... from bf16 shadows of A^T and B
+    constexpr bool AT = SRC == 7;                   // A given TRANSPOSED ((K, M) fp32, m-contiguous): staged like B
     constexpr int NS = SRC == 6 ? 4 : 2;   // LDS stages; SRC 6 = 4-stage ring, three tiles in flight across raw barriers
     constexpr int NT = WM * WN * 64;
     constexpr int NA16 = BM * 8 / NT, NB16 = BN * 8 / NT;   // 16-byte (8 x bf16) chunks per thread when a shadow is the source
@@ -158,13 +147,9 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
         b_off[i] = (int64_t)(ks * 8) * g.ldb + col;
     }
 
-    // A^T source (SRC 7 / 8): 8(k) x 4(m) patches exactly like B; element (m, k) of A lives at A[k * lda + m]
+    // A^T source (SRC 7): 8(k) x 4(m) patches exactly like B; element (m, k) of A lives at A[k * lda + m]
     constexpr int NQA = BM / 4, NAT = 8 * NQA / NT;
-    f32x4 rat[(AT && !AT16) ? NAT : 1][8];
-    u32x2 rat16[AT16 ? NAT : 1][8], rb16p[AT16 ? NB : 1][8];      // SRC 8: the same patches as 4 bf16 = 2 dwords per k row
-    const uint16_t* __restrict__ A16t = AT16 ? g.A16 + (int64_t)z * g.strideA : nullptr;
-    const uint16_t* __restrict__ B16pz = AT16 ? g.B16p + (int64_t)z * g.strideB : nullptr;
-    const bool b_fp32 = !AT16 || do_colsum;          // block-uniform: the column sums need the unrounded B
+    f32x4 rat[AT ? NAT : 1][8];
     int64_t at_off[AT ? NAT : 1];
     if constexpr (AT) {
 #pragma unroll
@@ -213,18 +198,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
 #pragma unroll
             for (int i = 0; i < NB16; ++i) rb16[i] = *reinterpret_cast<const u32x4*>(b16_src[i] + k0);
         }
-        if constexpr (AT16) {
-#pragma unroll
-            for (int i = 0; i < NAT; ++i)
-#pragma unroll
-                for (int kk = 0; kk < 8; ++kk) rat16[i][kk] = *reinterpret_cast<const u32x2*>(A16t + at_off[i] + (int64_t)(k0 + kk) * g.lda);
-            if (!b_fp32) {
-#pragma unroll
-                for (int i = 0; i < NB; ++i)
-#pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) rb16p[i][kk] = *reinterpret_cast<const u32x2*>(B16pz + b_off[i] + (int64_t)(k0 + kk) * g.ldb);
-            }
-        } else if constexpr (AT) {
+        if constexpr (AT) {
 #pragma unroll
             for (int i = 0; i < NAT; ++i)
 #pragma unroll
@@ -243,7 +217,6 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
         }
 #pragma unroll
         for (int i = 0; i < (B16 ? 0 : NB); ++i) {
-            if (AT16 && !b_fp32) break;                  // SRC 8, no column sums in this block: B came from its shadow above
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
                 if constexpr (FAST) {
@@ -268,34 +241,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
 #pragma unroll
             for (int i = 0; i < NB16; ++i) *reinterpret_cast<u32x4*>(S + b16_lds[i]) = rb16[i];
         }
-        if constexpr (AT16) {
-#pragma unroll
-            for (int i = 0; i < NAT; ++i) {
-                const int q = (tid + i * NT) % NQA, ks = (tid + i * NT) / NQA;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    u32x4 p;
-#pragma unroll
-                    for (int c2 = 0; c2 < 4; ++c2) p[c2] = perm_pair(rat16[i][2 * c2 + 1][j >> 1], rat16[i][2 * c2][j >> 1], j & 1);
-                    const int r = 4 * q + j;
-                    *reinterpret_cast<u32x4*>(S + r * ROWB + ((ks ^ swz(r)) << 4)) = p;
-                }
-            }
-            if (!b_fp32) {
-#pragma unroll
-                for (int i = 0; i < NB; ++i) {
-                    const int q = (tid + i * NT) % NQ, ks = (tid + i * NT) / NQ;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        u32x4 p;
-#pragma unroll
-                        for (int c2 = 0; c2 < 4; ++c2) p[c2] = perm_pair(rb16p[i][2 * c2 + 1][j >> 1], rb16p[i][2 * c2][j >> 1], j & 1);
-                        const int r = 4 * q + j;
-                        *reinterpret_cast<u32x4*>(S + BM * ROWB + r * ROWB + ((ks ^ swz(r)) << 4)) = p;
-                    }
-                }
-            }
-        } else if constexpr (AT) {
+        if constexpr (AT) {
 #pragma unroll
             for (int i = 0; i < NAT; ++i) {
                 const int q = (tid + i * NT) % NQA, ks = (tid + i * NT) / NQA;
@@ -332,7 +278,6 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
         }
 #pragma unroll
         for (int i = 0; i < (B16 ? 0 : NB); ++i) {
-            if (AT16 && !b_fp32) break;
             const int q = (tid + i * NT) % NQ, ks = (tid + i * NT) / NQ;
 #pragma unroll
             for (int j = 0; j < PN; ++j) {       // register transpose: column j of the patch becomes 8 consecutive k
@@ -545,7 +490,6 @@ int launch_cfg16(Gemm16Args& g, int src, int nbatch, hipStream_t s) {
         case 5: return launch_src16<5, BM, BN, WM, WN, MINB>(g, nbatch, s);
         case 6: return launch_src16<6, BM, BN, WM, WN, 1>(g, nbatch, s);
         case 7: return launch_src16<7, BM, BN, WM, WN, MINB>(g, nbatch, s);
-        case 8: return launch_src16<8, BM, BN, WM, WN, MINB>(g, nbatch, s);
         default: return launch_src16<0, BM, BN, WM, WN, MINB>(g, nbatch, s);
     }
 }
@@ -584,7 +528,6 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
     g.A16 = x.A16; g.B16 = x.B16; g.C16 = x.C16; g.ldb16 = x.ldb16 ? x.ldb16 : K;
     g.zmod = x.zmod; g.strideB16 = x.strideB16; g.strideC2 = x.strideC2; g.strideBias = x.strideBias; g.strideB2 = x.strideB2;
     g.colsum = x.transA ? x.colsum : nullptr; g.strideCS = x.strideCS;
-    g.B16p = x.B16p;
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("W2V2_GEMM16_ABL"); abl = e ? atoi(e) : 0; }
     g.abl = abl;
@@ -603,16 +546,13 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
                          ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda >= M || x.overlapA),
                      "gemm_bf16: transposed A needs fp32 A and B, K %% 64 == 0, M %% 4 == 0 and 16-byte alignment");
         src = 7;
-        static int at16 = -1;
-        if (at16 < 0) { const char* e = getenv("W2V2_GEMM16_AT16"); at16 = e ? atoi(e) : 1; }      // tuning knob
-        if (at16 && x.A16 && x.B16p && N > 64 && ((reinterpret_cast<uintptr_t>(x.A16) | reinterpret_cast<uintptr_t>(x.B16p)) & 7) == 0) src = 8;
     } else if (a16 && b16) src = dma == 2 ? 6 : (dma ? 5 : 4);
     else if (a16 && b32) src = 2;
     else if (b16 && a32) src = 3;
     else if (kfast && a32 && b32) src = 1;
     else src = 0;
     W2V2_REQUIRE(src != 0 || (A && B), "gemm_bf16: a shadow-only operand needs K %% 64 == 0 and 16-byte alignment");
-    const double abytes = (src == 2 || (src >= 4 && src <= 6) || src == 8) ? 2.0 : 4.0, bbytes = ((src >= 3 && src <= 6) || src == 8) ? 2.0 : 4.0;
+    const double abytes = (src == 2 || (src >= 4 && src <= 6)) ? 2.0 : 4.0, bbytes = (src >= 3 && src <= 6) ? 2.0 : 4.0;
     ProfScope ps(prof, FAM_GEMM_BF16, 2.0 * M * (double)N * K * nbatch,
                  nbatch * (abytes * (double)M * K + (C ? 4.0 : 0.0) * (double)M * N + (x.C16 ? 2.0 : 0.0) * (double)M * N) +
                      bbytes * (double)K * N, s);
