@@ -160,6 +160,7 @@ struct ShadowJob {
 };
 int launch_weight_shadows_multi(const ShadowJob* jobs_dev, int njobs, hipStream_t s);
 int launch_transpose_to_bf16(const float* w, uint16_t* wt, int K, int N, hipStream_t s);
+int launch_transpose_to_bf16_batched(const float* w, uint16_t* wt, int K, int N, int nbatch, hipStream_t s);   // nbatch dense (K, N) matrices
 
 int launch_weight_norm_regroup(Profiler* prof, const float* wv, const float* wg, float* out, int K,
                                int cg, int H, int groups, hipStream_t s);

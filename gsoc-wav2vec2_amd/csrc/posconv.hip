@@ -506,9 +506,7 @@ int64_t pos_conv_bf16_pack_elems(int B, int T, int H, int K) { return (int64_t)B
 // w16: (groups, og, K cg) bf16 shadow of the regrouped kernel wg (groups, K, cg, og)
 int launch_pos_conv_weight_shadow(const float* wg, uint16_t* w16, int K, int cg, int groups, hipStream_t s) {
     W2V2_REQUIRE(wg && w16 && K > 0 && cg > 0 && groups > 0, "pos_conv_weight_shadow: bad argument");
-    for (int g = 0; g < groups; ++g)
-        if (int e = launch_transpose_to_bf16(wg + (int64_t)g * K * cg * cg, w16 + (int64_t)g * cg * K * cg, K * cg, cg, s)) return e;
-    return W2V2_OK;
+    return launch_transpose_to_bf16_batched(wg, w16, K * cg, cg, groups, s);       // one launch for all groups
 }
 
 // Same contract as launch_pos_conv_ex.  pack16: pos_conv_bf16_pack_elems() bf16 of scratch; xz_ws: (B, T, H) fp32 of scratch,

@@ -25,6 +25,8 @@ __global__ __launch_bounds__(256) void to_bf16_kernel(const float* __restrict__ 
 // w (K, N) row-major fp32  ->  wt (N, K) row-major bf16, through a 64 x 64 LDS tile (both sides coalesced)
 __global__ __launch_bounds__(256) void transpose_to_bf16_kernel(const float* __restrict__ w, uint16_t* __restrict__ wt, int K, int N) {
     __shared__ float tile[64][65];
+    w += (int64_t)blockIdx.z * K * N;            // batch of equally shaped matrices, densely packed on both sides
+    wt += (int64_t)blockIdx.z * K * N;
     const int k0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int r = ty; r < 64; r += 4) {
@@ -174,8 +176,12 @@ int launch_weight_shadows_multi(const ShadowJob* jobs_dev, int njobs, hipStream_
 }
 
 int launch_transpose_to_bf16(const float* w, uint16_t* wt, int K, int N, hipStream_t s) {
-    W2V2_REQUIRE(w && wt && K > 0 && N > 0, "transpose_to_bf16: bad argument");
-    hipLaunchKernelGGL(transpose_to_bf16_kernel, dim3((N + 63) / 64, (K + 63) / 64), dim3(256), 0, s, w, wt, K, N);
+    return launch_transpose_to_bf16_batched(w, wt, K, N, 1, s);
+}
+
+int launch_transpose_to_bf16_batched(const float* w, uint16_t* wt, int K, int N, int nbatch, hipStream_t s) {
+    W2V2_REQUIRE(w && wt && K > 0 && N > 0 && nbatch > 0, "transpose_to_bf16: bad argument");
+    hipLaunchKernelGGL(transpose_to_bf16_kernel, dim3((N + 63) / 64, (K + 63) / 64, nbatch), dim3(256), 0, s, w, wt, K, N);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
