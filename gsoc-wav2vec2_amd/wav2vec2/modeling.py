@@ -379,16 +379,35 @@ class TFKerasModel(Layer):
         self.config.save_pretrained(save_dir)
         self.save_weights(os.path.join(save_dir, "tf_model.h5"))
 
+    def push_to_hub(self, directory: str, model_id: str):
+        """Upload a `save_pretrained` directory to the HuggingFace Hub (reference modeling.py:29-39, which calls
+        `ModelHubMixin.push_to_hub(directory, model_id=...)`).  Needs `huggingface_hub` and network access; whatever the
+        client raises (no token, no network) is passed on."""
+        from huggingface_hub import HfApi
+        return HfApi().upload_folder(folder_path=directory, repo_id=model_id)
+
+    @staticmethod
+    def _download(model_id):
+        """`config.json` + `tf_model.h5` of a Hub repository into the local cache (reference modeling.py:57-74 shells out to
+        wget); returns the directory.  Any failure -- there is no network on the build / GPU boxes -- becomes the reference's
+        ValueError."""
+        try:
+            from huggingface_hub import snapshot_download
+            return snapshot_download(model_id, allow_patterns=["config.json", "tf_model.h5"])
+        except Exception as e:  # noqa: BLE001
+            raise ValueError(f"Couldn't download model weights from https://huggingface.co/{model_id}") from e
+
     @classmethod
     def from_pretrained(cls, model_id, **config_kwargs):
-        """Load from a local directory (reference modeling.py:41-84).  The
-        reference downloads from the HuggingFace Hub when the directory does not
-        exist; this build has no network path and raises the same ValueError the
-        reference raises on a failed download."""
+        """Load from a local directory, or from the HuggingFace Hub when `model_id` is not a directory (reference
+        modeling.py:41-84).  A failed download raises the same ValueError the reference raises."""
         save_dir = model_id
         if not os.path.isdir(save_dir):
-            raise ValueError(f"Couldn't download model weights from https://huggingface.co/{model_id}")
-        print(f"Loading weights locally from `{save_dir}`")
+            print(f"Downloading model weights from https://huggingface.co/{model_id} ... ", end="")
+            save_dir = cls._download(model_id)
+            print("Done")
+        else:
+            print(f"Loading weights locally from `{save_dir}`")
         input_shape = config_kwargs.pop("input_shape", (1, 2048))
         has_own = any(os.path.exists(os.path.join(save_dir, f)) for f in ("tf_model.h5", "tf_model.npz"))
         if not has_own and hf_checkpoint_file(save_dir):

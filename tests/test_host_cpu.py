@@ -442,3 +442,13 @@ def test_backbone_model_layer_graph():
     # robust: conv bias + LayerNorm on every conv layer -> 4 variables per layer
     assert len([v for v in m.variables if not v.trainable]) == 28
     assert len(m.encoder.layers) == 3 + 24
+
+
+def test_from_pretrained_download_failure_is_the_reference_error(monkeypatch):
+    """No local directory -> the Hub is tried (reference modeling.py:57-74); without network that fails, and the failure
+    is the reference's ValueError -- raised before any device is touched, so it is checkable here."""
+    import wav2vec2
+    monkeypatch.setenv("HF_HUB_OFFLINE", "1")
+    with pytest.raises(ValueError, match="Couldn't download model weights from https://huggingface.co/no-such-org/no-such-model"):
+        wav2vec2.Wav2Vec2ForCTC.from_pretrained("no-such-org/no-such-model")
+    assert hasattr(wav2vec2.Wav2Vec2ForCTC, "push_to_hub")

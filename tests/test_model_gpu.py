@@ -76,7 +76,7 @@ def test_logits_match_golden(torch_mod, name):
 # output by ulp_bf16(x) * |w| ~ 6e-3, and every later layer re-rounds the difference.  So the model-level bar is
 # bf16-sized, and the bit-level claim is made where inputs are identical: the GEMM itself (test_ops_gpu.py) and
 # each conv layer fed with the build's own previous activation (below).
-ATOL_BF16_LOGITS = 0.15
+ATOL_BF16_LOGITS = 0.10      # measured (round 2): 0.026-0.050 vs the rounded-operand oracle, 0.043-0.072 vs HF fp64
 
 
 @pytest.mark.parametrize("name", ["tiny_base", "tiny_robust", "base_sample_unpadded", "robust_masked"])
