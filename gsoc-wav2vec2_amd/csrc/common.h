@@ -116,6 +116,12 @@ struct GemmShadows {
     // (dW = X^T dY has the bias gradient 1^T dY for free: dY is in registers while it is staged)
     float* colsum = nullptr;
     int64_t strideCS = 0;
+    // transposed-A form with BOTH operands from bf16 shadows in their natural row-major layouts: A16 = bf16 copy of the
+    // (K, M) activation (same lda / strideA as A), B16p = bf16 copy of the (K, N) gradient (same ldb / strideB as B).  Both then
+    // stream into LDS by DMA as they lie in memory ([k][m] and [k][n] rows) and the k-contiguous MFMA fragments come out of the
+    // transposing LDS read ds_read_b64_tr_b16 (gemm_bf16.hip: gemm_bf16_tr_kernel).  No column sums in this form (they are sums
+    // of the UNROUNDED gradient): `colsum` must be null.
+    const uint16_t* B16p = nullptr;
 };
 int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
                        int64_t strideB, float* C, int64_t ldc, int64_t strideC, const float* bias,

@@ -48,6 +48,7 @@ struct Gemm16Args {
     const uint16_t* B16;
     uint16_t* C16;
     int64_t ldb16;
+    const uint16_t* B16p;      // weight-gradient tr form: plain (K, N) bf16 copy of B (row stride ldb, batch stride strideB)
     // two-level batch (grouped conv as GEMM): z = zo * zmod + zi.  A advances with z; B16 and bias with zi; C / residual
     // with zo * strideC2 + zi * strideC.  zmod = 0: plain batch (C advances with z * strideC, B16 and bias are shared).
     int zmod;
@@ -463,6 +464,154 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
                                  (int)g.ldc, g.M - (m0 + wm * WTM), g.N - (n0 + wn * WTN), g.act, li, lh);
 }
 
+// ---- weight-gradient form dW = X^T dY with both operands by LDS-DMA and a TRANSPOSING LDS read ---------------------------
+// X (K, M) and dY (K, N) lie in memory with the contraction index k as the SLOW dimension, the opposite of what an MFMA
+// fragment wants (8 consecutive k per lane).  Source 7 above transposes in registers (fp32 loads, v_cvt_pk, 16-byte LDS
+// stores); measured, that loop is bound by the latency of its loads at two blocks per CU (372 TF).  Here the bf16 shadows of
+// both operands go into LDS exactly as they lie in memory -- rows of 128 m | n = 256 B, 64 k rows per stage, 1-KiB DMA pieces
+// of 4 rows -- and the fragments are read with ds_read_b64_tr_b16 (tools/tr_read_probe.hip pins its semantics on this chip:
+// within a 16-lane group lane l supplies the address of 4 consecutive columns 4 (l % 4) .. + 3 of row l / 4, and lane c
+// receives rows 0 .. 3 of column c).  A lane of a 32x32x16 MFMA needs column (lane % 32) and the 8 k rows 8 (lane / 32) .. + 7:
+// two such reads.  Same tile / stage / barrier structure as the forward LDS-DMA kernel (source 5).  No epilogue extras:
+// C (M, N) fp32 slabs, one per batch.
+template <int WM, int WN, int MINB>
+__global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_tr_kernel(Gemm16Args g) {
+    constexpr int BM = 128, BN = 128, NWV = WM * WN;
+    constexpr int WTM = BM / WM, WTN = BN / WN, MT = WTM / 32, NTL = WTN / 32;
+    constexpr int RB = 256;                         // bytes per LDS row (128 bf16)
+    constexpr int IMG = BK * RB, STAGE = 2 * IMG;   // A^T image, B image: 16 KiB each
+    constexpr int PIECES = IMG / 1024, PP = PIECES / NWV;     // 1-KiB pieces (4 rows) per image, per wave
+    static_assert(PIECES % NWV == 0 && MT >= 1 && NTL >= 1, "bad wave grid");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN, li = lane & 31, lh = lane >> 5;
+
+    const int nwg = g.tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.z;
+    const uint16_t* __restrict__ Az = g.A16 + (int64_t)z * g.strideA + m0;
+    const uint16_t* __restrict__ Bz = g.B16p + (int64_t)z * g.strideB + n0;
+    const int nk = g.K / BK;
+
+    // DMA: piece p of an image = rows 4p .. 4p+3; lane -> row 4p + lane / 16, 16-byte chunk lane % 16 (8 columns)
+    const uint16_t* da[PP];
+    const uint16_t* db[PP];
+#pragma unroll
+    for (int i = 0; i < PP; ++i) {
+        // bank swizzle: the four rows of a transposing read sit 256 B = one full bank sweep apart, so the 16-byte chunk index is
+        // XORed with 4 (row % 4): the physical slot `lane & 15` of row r holds logical chunk (lane & 15) ^ 4 (r & 3)
+        const int row = (wave * PP + i) * 4 + (lane >> 4);
+        const int chunk = (lane & 15) ^ (4 * (row & 3));
+        da[i] = Az + (int64_t)row * g.lda + 8 * chunk;
+        db[i] = Bz + (int64_t)row * g.ldb + 8 * chunk;
+    }
+    auto issue = [&](int kt, int buf) {
+        unsigned char* S = smem16 + buf * STAGE;
+        const int64_t k0 = (int64_t)kt * BK;
+#pragma unroll
+        for (int i = 0; i < PP; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(da[i] + k0 * g.lda),
+                                             (__attribute__((address_space(3))) void*)(S + (wave * PP + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < PP; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db[i] + k0 * g.ldb),
+                                             (__attribute__((address_space(3))) void*)(S + IMG + (wave * PP + i) * 1024), 16, 0, 0);
+    };
+
+    // fragment addresses: group = lane / 16 -> column half (group & 1), k half = lane / 32; l = lane % 16 -> row l / 4, chunk l % 4
+    const int l16 = lane & 15, grp = (lane >> 4) & 1;
+    // (every row base 16 s + 8 lh [+ 4] is a multiple of 4, so row % 4 = l16 / 4 and the swizzle is a per-lane constant)
+    auto swz_col = [&](int col) { const int byte = col * 2; return (((byte >> 4) ^ (4 * (l16 >> 2))) << 4) | (byte & 15); };
+    int a_off[MT], b_off[NTL];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) a_off[t] = (8 * lh + (l16 >> 2)) * RB + swz_col(wm * WTM + t * 32 + 16 * grp + 4 * (l16 & 3));
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) b_off[t] = IMG + (8 * lh + (l16 >> 2)) * RB + swz_col(wn * WTN + t * 32 + 16 * grp + 4 * (l16 & 3));
+
+    using v4s = __attribute__((ext_vector_type(4))) short;
+    auto frag = [&](const unsigned char* S, int off, int s) -> bf16x8 {
+        // rows 16 s + 8 lh + {0..3} and + {4..7}: the two halves of the 8-deep k run this lane supplies
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(S + off + (16 * s) * RB));
+        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(S + off + (16 * s + 4) * RB));
+        union { v4s h[2]; bf16x8 v; } u;
+        u.h[0] = lo;
+        u.h[1] = hi;
+        return u.v;
+    };
+
+    f32x16 acc[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    auto compute = [&](int buf) {
+        const unsigned char* S = smem16 + buf * STAGE;
+        bf16x8 a[2][MT], b[2][NTL];
+        auto read_frags = [&](int s, int slot) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) a[slot][t] = frag(S, a_off[t], s);
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) b[slot][t] = frag(S, b_off[t], s);
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            if (s + 1 < BK / 16) read_frags(s + 1, (s + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTL; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1][mt], b[s & 1][nt], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    issue(0, 0);
+    __syncthreads();                    // carries the vmcnt(0) that retires the DMA
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        const int cur = kt & 1;
+        issue(kt + 1, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+    compute((nk - 1) & 1);
+
+    const int64_t tile_off = (int64_t)z * g.strideC + (int64_t)(m0 + wm * WTM) * g.ldc + (n0 + wn * WTN);
+    gemm_epilogue<MT, NTL, true>(acc, g.C + tile_off, nullptr, nullptr, nullptr, (int)g.ldc, g.M - (m0 + wm * WTM), g.N - (n0 + wn * WTN),
+                                 0, li, lh);
+}
+
+int launch_tr16(Gemm16Args& g, int nbatch, hipStream_t s) {
+    constexpr size_t LDS = 2 * 2 * BK * 256;
+    g.tiles_m = g.M / 128;
+    g.tiles_n = g.N / 128;
+    static int waves8 = -1;
+    if (waves8 < 0) { const char* e = getenv("W2V2_GEMM16_TR_WAVES"); waves8 = e ? (atoi(e) == 8) : 1; }      // tuning knob (8 waves: 49.6 ms per step, 4: 49.9)
+    static std::atomic<bool> attr_set{false};   // (idempotent call; atomic so concurrent host threads agree on the flag)
+    if (!attr_set) {
+        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_tr_kernel<2, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_tr_kernel<2, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        attr_set = true;
+    }
+    dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch);
+    if (waves8) hipLaunchKernelGGL((gemm_bf16_tr_kernel<2, 4, 2>), grid, dim3(512), LDS, s, g);
+    else hipLaunchKernelGGL((gemm_bf16_tr_kernel<2, 2, 2>), grid, dim3(256), LDS, s, g);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
 template <int SRC, int BM, int BN, int WM, int WN, int MINB>
 int launch_src16(Gemm16Args& g, int nbatch, hipStream_t s) {
     constexpr size_t LDS = (SRC == 6 ? 4 : 2) * (BM + BN) * ROWB;
@@ -528,6 +677,7 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
     g.A16 = x.A16; g.B16 = x.B16; g.C16 = x.C16; g.ldb16 = x.ldb16 ? x.ldb16 : K;
     g.zmod = x.zmod; g.strideB16 = x.strideB16; g.strideC2 = x.strideC2; g.strideBias = x.strideBias; g.strideB2 = x.strideB2;
     g.colsum = x.transA ? x.colsum : nullptr; g.strideCS = x.strideCS;
+    g.B16p = x.B16p;
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("W2V2_GEMM16_ABL"); abl = e ? atoi(e) : 0; }
     g.abl = abl;
@@ -546,6 +696,14 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
                          ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda >= M || x.overlapA),
                      "gemm_bf16: transposed A needs fp32 A and B, K %% 64 == 0, M %% 4 == 0 and 16-byte alignment");
         src = 7;
+        // both bf16 shadows, whole 128 x 128 tiles, 16-byte aligned rows: LDS-DMA + transposing LDS reads
+        static int tr = -1;
+        if (tr < 0) { const char* e = getenv("W2V2_GEMM16_TR"); tr = e ? atoi(e) : 1; }      // tuning knob
+        if (tr && x.A16 && x.B16p && !x.colsum && !x.overlapA && M % 128 == 0 && N % 128 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
+            strideA % 8 == 0 && strideB % 8 == 0 && ((reinterpret_cast<uintptr_t>(x.A16) | reinterpret_cast<uintptr_t>(x.B16p)) & 15) == 0) {
+            ProfScope ps(prof, FAM_GEMM_BF16, 2.0 * M * (double)N * K * nbatch, nbatch * (2.0 * K * ((double)M + N) + 4.0 * (double)M * N), s);
+            return launch_tr16(g, nbatch, s);
+        }
     } else if (a16 && b16) src = dma == 2 ? 6 : (dma ? 5 : 4);
     else if (a16 && b32) src = 2;
     else if (b16 && a32) src = 3;

@@ -27,6 +27,9 @@ struct LayerSave {
     float* a;                           // prenorm only: LN(x), the attention input
     float *WqkvT, *WoT, *W1T, *W2T;     // transposed kernels for the data-gradient GEMMs
     float keep;                         // stochastic-depth draw of the last forward
+    // precision mode 1: bf16 shadows of the activations the weight-gradient GEMMs contract with (dW = X^T dY reads X as a
+    // transposed A).  Written by the forward's producers like the shared shadows, but kept per layer until the backward.
+    uint16_t *a16 = nullptr, *ctx16 = nullptr, *t2_16 = nullptr, *gd16 = nullptr;
 };
 
 struct TrainState {
@@ -65,6 +68,7 @@ struct TrainState {
     float* cs_ws = nullptr;           // (slabs + 1, widest N): per-slab column sums of dY from the weight-gradient GEMM
     int64_t cs_floats = 0;
     bool forward_done = false;
+    bool x16_valid = false, x16_attn = false;     // the last forward wrote the per-layer bf16 shadows (/ ctx16 from the bf16 attention)
     // gradient buckets for overlapping the data-parallel all-reduce with the backward: completion order
     //   0 = lm_head, 1 .. N = encoder layers N-1 .. 0, N+1 = everything in front of layer 0 in the flat buffer
     std::vector<hipEvent_t> bucket_ev;
@@ -200,6 +204,18 @@ static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
         if (c.attention_norm_type == 1)
             if (int e = t_alloc(t, &l.a, BT * H)) return e;
     }
+    {
+        // per-layer X shadows: (3 H + F) bf16 per row and layer (base, B = 32: 2.7 GB)
+        auto up8 = [](int64_t n) { return (n + 7) & ~(int64_t)7; };
+        for (auto& l : t->layers) {
+            float* raw = nullptr;
+            if (int e = t_alloc(t, &raw, (3 * up8(BT * H) + up8(BT * F)) / 2 + 16)) return e;
+            l.a16 = reinterpret_cast<uint16_t*>(raw);
+            l.ctx16 = l.a16 + up8(BT * H);
+            l.t2_16 = l.ctx16 + up8(BT * H);
+            l.gd16 = l.t2_16 + up8(BT * H);
+        }
+    }
     for (int i = 0; i < 4; ++i)
         if (int e = t_alloc(t, &t->gh[i], BT * H)) return e;
     if (int e = t_alloc(t, &t->gf, BT * F)) return e;
@@ -278,8 +294,9 @@ static bool is_trainable(w2v2_model* m, const std::string& name) {
 }
 
 // dW (Kin x Nout) = A^T (Kin x M) dY (M x Nout), db = column sums of dY.  A is (M x Kin) row-major.
+// A16 / dY16: bf16 shadows of A and dY (row-major, same shapes) or null: with both, the fast slabs read half the bytes
 static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, int Kin, int Nout, float* dW,
-                       float* db, hipStream_t s) {
+                       float* db, hipStream_t s, const uint16_t* A16 = nullptr, const uint16_t* dY16 = nullptr) {
     TrainState* t = m->train;
     bool fused_bias = false;
     if (dW) {
@@ -320,8 +337,12 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
             if (direct) {
                 GemmShadows x;
                 x.transA = true;
-                // the bias gradient rides along: the kernel's row-tile-0 blocks sum the dY columns they stage anyway
-                fused_bias = db != nullptr && (int64_t)(nslabs + 1) * Nout <= t->cs_floats;
+                // both bf16 shadows and whole 128 x 128 tiles: the LDS-DMA + transposing-read kernel; it has no fp32 dY in registers,
+                // so the bias gradient (a sum of the UNROUNDED dY) takes the column-sum pass below instead of riding along
+                const bool tr_form = A16 && dY16 && Kin % 128 == 0 && Nout % 128 == 0;
+                if (tr_form) { x.A16 = A16; x.B16p = dY16; }
+                // otherwise the bias gradient rides along: the kernel's row-tile-0 blocks sum the dY columns they stage anyway
+                fused_bias = !tr_form && db != nullptr && (int64_t)(nslabs + 1) * Nout <= t->cs_floats;
                 if (fused_bias) { x.colsum = t->cs_ws; x.strideCS = Nout; }
                 if (int e = launch_gemm_bf16_x(m->prof, A, Kin, (int64_t)Kp * Kin, dY, Nout, (int64_t)Kp * Nout, dst, Nout,
                                                (int64_t)Kin * Nout, nullptr, nullptr, Kin, Nout, Kp, S, 0, x, s))
@@ -511,31 +532,31 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
         const uint16_t* attn_in16 = (sh && !prenorm) ? m->hs16[i] : nullptr;   // postnorm: written by the producer of hs[i]
         if (prenorm) {     // x + drop(attn(LN(x)))   (encoder.py:114-119)
             if (int e = launch_layer_norm_x(pf, x, l.a, m->P(b + "/layer_norm/gamma"), m->P(b + "/layer_norm/beta"), BT, H, eps, 0,
-                                            S16(m->t0_16), s))
+                                            S16(l.a16), s))
                 return e;
             attn_in = l.a;
-            attn_in16 = S16(m->t0_16);
+            attn_in16 = S16(l.a16);
         }
         if (int e = gemm(attn_in, attn_in16, H, 0, m->qkv_w[i], 3 * H, l.qkv, nullptr, 3 * H, 0, m->qkv_b[i], nullptr, (int)BT, 3 * H, H, 1, 0)) return e;
         AttnTrain tr{p, seed, layer_stream(i, 0), l.lse};
-        if (int e = launch_attention_train_x(pf, l.qkv, flen, l.ctx, attn16 ? m->ctx16 : nullptr, B, T, H, c.num_heads, tr, s)) return e;
+        if (int e = launch_attention_train_x(pf, l.qkv, flen, l.ctx, attn16 ? l.ctx16 : nullptr, B, T, H, c.num_heads, tr, s)) return e;
         // o = ctx Wo + bo;  t1 = dropout(o) + x   (encoder.py:116-119)
-        if (int e = gemm(l.ctx, attn16 ? m->ctx16 : nullptr, H, 0, m->P(b + "/attention/out_proj/kernel"), H, m->t0, nullptr, H, 0,
+        if (int e = gemm(l.ctx, attn16 ? l.ctx16 : nullptr, H, 0, m->P(b + "/attention/out_proj/kernel"), H, m->t0, nullptr, H, 0,
                          m->P(b + "/attention/out_proj/bias"), nullptr, (int)BT, H, H, 1, 0))
             return e;
         if (int e = launch_dropout_fwd(m->t0, x, l.t1, BT * H, 0, p, seed, layer_stream(i, 1), s)) return e;
         // postnorm: t2 = LN1(t1) feeds the FFN and is its residual; prenorm: t2 = LN2(t1) feeds the FFN, t1 is the residual
         const char* ln_a = prenorm ? "/final_layer_norm" : "/layer_norm";
-        if (int e = launch_layer_norm_x(pf, l.t1, l.t2, m->P(b + ln_a + "/gamma"), m->P(b + ln_a + "/beta"), BT, H, eps, 0, S16(m->t2_16), s)) return e;
+        if (int e = launch_layer_norm_x(pf, l.t1, l.t2, m->P(b + ln_a + "/gamma"), m->P(b + ln_a + "/beta"), BT, H, eps, 0, S16(l.t2_16), s)) return e;
         const float* ffn_res = prenorm ? l.t1 : l.t2;
         float* ffn_out = prenorm ? m->hs[i + 1] : l.t3;
         if (l.keep != 0.f) {
             // u = t2 W1 + b1;  gd = dropout(GELU(u));  out = res + keep * (gd W2 + b2)   (encoder.py:127-130)
-            if (int e = gemm(l.t2, S16(m->t2_16), H, 0, m->P(b + "/feed_forward/intermediate_dense/kernel"), F, l.u, nullptr, F, 0,
+            if (int e = gemm(l.t2, S16(l.t2_16), H, 0, m->P(b + "/feed_forward/intermediate_dense/kernel"), F, l.u, nullptr, F, 0,
                              m->P(b + "/feed_forward/intermediate_dense/bias"), nullptr, (int)BT, F, H, 1, 0))
                 return e;
-            if (int e = launch_dropout_fwd_x(l.u, nullptr, l.gd, S16(m->ffn16), BT * F, act, p, seed, layer_stream(i, 2), s)) return e;
-            if (int e = gemm(l.gd, S16(m->ffn16), F, 0, m->P(b + "/feed_forward/output_dense/kernel"), H, ffn_out, nullptr, H, 0,
+            if (int e = launch_dropout_fwd_x(l.u, nullptr, l.gd, S16(l.gd16), BT * F, act, p, seed, layer_stream(i, 2), s)) return e;
+            if (int e = gemm(l.gd, S16(l.gd16), F, 0, m->P(b + "/feed_forward/output_dense/kernel"), H, ffn_out, nullptr, H, 0,
                              m->P(b + "/feed_forward/output_dense/bias"), ffn_res, (int)BT, H, F, 1, 0))
                 return e;
         } else {
@@ -566,6 +587,8 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
                      m->P("lm_head/bias"), nullptr, (int)BT, c.vocab_size, H, 1, 0))
         return e;
     t->forward_done = true;
+    t->x16_valid = sh;                 // the per-layer X shadows (and hs16) hold this forward's activations
+    t->x16_attn = attn16;
     return W2V2_OK;
 }
 
@@ -606,6 +629,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     uint16_t* const s16h = shb ? t->dy16_h : nullptr;
     uint16_t* const s16f = shb ? t->dy16_f : nullptr;
     uint16_t* const s16q = (shb && attention_bf16_supported(dhead)) ? t->dy16_3h : nullptr;
+    const bool xs = shb && t->x16_valid;             // X shadows of the forward are there for the weight-gradient GEMMs
     for (size_t i = 0; i < m->params.size(); ++i)
         if (t->trainable[i] && m->params[i].name.compare(0, 18, "feature_extractor/") == 0) {
             set_error("train_backward: `%s` is trainable, but the conv feature extractor has no backward "
@@ -661,11 +685,11 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
             return e;
     }
 
-    auto qkv_weight_grad = [&](const std::string& b, const float* attn_in) -> int {
+    auto qkv_weight_grad = [&](const std::string& b, const float* attn_in, const uint16_t* attn_in16) -> int {
         // packed q|k|v projection: dW (H, 3H) -> the three (H, H) kernels, db (3H) -> the three biases
         float* dWqkv = t->dwqkv;
         float* dbqkv = dWqkv + (int64_t)3 * H * H;
-        if (int e = weight_grad(m, attn_in, t->g3h, (int)BT, H, 3 * H, dWqkv, dbqkv, s)) return e;
+        if (int e = weight_grad(m, attn_in, t->g3h, (int)BT, H, 3 * H, dWqkv, dbqkv, s, (xs && s16q) ? attn_in16 : nullptr, s16q)) return e;
         const char* names[3] = {"q_proj", "k_proj", "v_proj"};
         if (H % 4 == 0) {
             float* gw3[3];
@@ -700,7 +724,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
             if (int e = gemm_dx(dh, nullptr, H, l.W2T, m->P(b + "/feed_forward/output_dense/kernel"), t->gf, F, nullptr, (int)BT, F, H, s)) return e;
             if (int e = launch_dropout_bwd_x(l.u, t->gf, t->gf, s16f, BT * F, act, p, seed, layer_stream(i, 2), s)) return e;
             if (int e = weight_grad(m, l.t2, t->gf, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
-                                    G(b + "/feed_forward/intermediate_dense/bias"), s))
+                                    G(b + "/feed_forward/intermediate_dense/bias"), s, xs ? l.t2_16 : nullptr, s16f))
                 return e;
             if (int e = gemm_dx(t->gf, s16f, F, l.W1T, m->P(b + "/feed_forward/intermediate_dense/kernel"), tmp, H, nullptr, (int)BT, H, F, s)) return e;
             float* dg2 = G(b + "/final_layer_norm/gamma");
@@ -714,12 +738,14 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         }
         float* d_o = tmp;
         if (int e = launch_dropout_bwd_x(nullptr, dt1, d_o, s16h, BT * H, 0, p, seed, layer_stream(i, 1), s)) return e;
-        if (int e = weight_grad(m, l.ctx, d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), G(b + "/attention/out_proj/bias"), s)) return e;
+        if (int e = weight_grad(m, l.ctx, d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), G(b + "/attention/out_proj/bias"), s,
+                                (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h))
+            return e;
         float* dctx = tmp2;
         if (int e = gemm_dx(d_o, s16h, H, l.WoT, m->P(b + "/attention/out_proj/kernel"), dctx, H, nullptr, (int)BT, H, H, s)) return e;
         AttnTrain tr{p, seed, layer_stream(i, 0), l.lse};
         if (int e = launch_attention_bwd(pf, l.qkv, flen, l.ctx, dctx, t->g3h, t->dvec, B, T, H, c.num_heads, tr, s, s16q)) return e;
-        if (int e = qkv_weight_grad(b, l.a)) return e;
+        if (int e = qkv_weight_grad(b, l.a, l.a16)) return e;
         if (int e = gemm_dx(t->g3h, s16q, 3 * H, l.WqkvT, m->qkv_w[i], tmp, H, nullptr, (int)BT, H, 3 * H, s)) return e;
         float* dg1 = G(b + "/layer_norm/gamma");
         float* db1 = G(b + "/layer_norm/beta");
@@ -744,13 +770,13 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         if (l.keep != 0.f) {
             // t3 = t2 + f,  f = gd W2 + b2
             if (int e = weight_grad(m, l.gd, dt3, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
-                                    G(b + "/feed_forward/output_dense/bias"), s))
+                                    G(b + "/feed_forward/output_dense/bias"), s, xs ? l.gd16 : nullptr, H % 4 == 0 ? s16h : nullptr))
                 return e;
             if (int e = gemm_dx(dt3, H % 4 == 0 ? s16h : nullptr, H, l.W2T, m->P(b + "/feed_forward/output_dense/kernel"), t->gf, F, nullptr, (int)BT, F, H, s)) return e;
             // du = dgd * keep/(1-p) * GELU'(u)
             if (int e = launch_dropout_bwd_x(l.u, t->gf, t->gf, s16f, BT * F, act, p, seed, layer_stream(i, 2), s)) return e;
             if (int e = weight_grad(m, l.t2, t->gf, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
-                                    G(b + "/feed_forward/intermediate_dense/bias"), s))
+                                    G(b + "/feed_forward/intermediate_dense/bias"), s, xs ? l.t2_16 : nullptr, s16f))
                 return e;
             // dt2 = du W1^T + dt3 (the residual branch)
             if (int e = gemm_dx(t->gf, s16f, F, l.W1T, m->P(b + "/feed_forward/intermediate_dense/kernel"), dt2, H, dt3, (int)BT, H, F, s)) return e;
@@ -767,12 +793,14 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         // t1 = dropout(o) + x,  o = ctx Wo + bo
         float* d_o = tmp;     // dt3 (and its shadow) is dead
         if (int e = launch_dropout_bwd_x(nullptr, dt1, d_o, s16h, BT * H, 0, p, seed, layer_stream(i, 1), s)) return e;
-        if (int e = weight_grad(m, l.ctx, d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), G(b + "/attention/out_proj/bias"), s)) return e;
+        if (int e = weight_grad(m, l.ctx, d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), G(b + "/attention/out_proj/bias"), s,
+                                (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h))
+            return e;
         float* dctx = tmp2;   // dt2 is dead
         if (int e = gemm_dx(d_o, s16h, H, l.WoT, m->P(b + "/attention/out_proj/kernel"), dctx, H, nullptr, (int)BT, H, H, s)) return e;
         AttnTrain tr{p, seed, layer_stream(i, 0), l.lse};
         if (int e = launch_attention_bwd(pf, l.qkv, flen, l.ctx, dctx, t->g3h, t->dvec, B, T, H, c.num_heads, tr, s, s16q)) return e;
-        if (int e = qkv_weight_grad(b, m->hs[i])) return e;
+        if (int e = qkv_weight_grad(b, m->hs[i], m->hs16.size() > (size_t)i ? m->hs16[i] : nullptr)) return e;
         // dx = dqkv Wqkv^T + dt1 (residual)
         if (int e = gemm_dx(t->g3h, s16q, 3 * H, l.WqkvT, m->qkv_w[i], dh, H, dt1, (int)BT, H, 3 * H, s)) return e;
         if (int e = bucket_done(c.num_layers - i)) return e;
