@@ -63,6 +63,8 @@ int launch_dropout_bwd(const float* u, const float* dy, float* dx, int64_t n, in
                        uint64_t seed, uint32_t stream_id, hipStream_t s);
 int launch_dropout_bwd_x(const float* u, const float* dy, float* dx, uint16_t* dx16 /* optional bf16 shadow */, int64_t n, int act,
                          float p, uint64_t seed, uint32_t stream_id, hipStream_t s);
+int launch_dropout_bwd_colsum(const float* u, const float* dy, float* dx, uint16_t* dx16, float* colsum, int64_t rows, int cols,
+                              int act, float p, uint64_t seed, uint32_t stream_id, float* ws, hipStream_t s);
 int launch_transpose(const float* x, float* y, int rows, int cols, int nbatch, hipStream_t s);
 int64_t colsum_ws_floats(int64_t rows, int cols);
 int launch_colsum(const float* x, float* out, int64_t rows, int cols, float* ws, int accumulate, hipStream_t s);
@@ -70,7 +72,8 @@ int64_t ln_bwd_ws_floats(int64_t rows, int C);
 int launch_ln_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma,
                   float* dbeta, int64_t rows, int C, float eps, float* ws, hipStream_t s);
 int launch_ln_bwd_x(const float* x, const float* gamma, const float* dy, float* dx, uint16_t* dx16 /* optional bf16 shadow */,
-                    float* dgamma, float* dbeta, int64_t rows, int C, float eps, float* ws, hipStream_t s);
+                    float* dgamma, float* dbeta, int64_t rows, int C, float eps, float* ws, hipStream_t s,
+                    float* dxsum = nullptr /* optional: column sums of dx (C floats) */);
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1, float b2,
                 float eps, hipStream_t s);
 int launch_spec_aug_fwd(const float* x, const uint8_t* mask, const float* embed, float* y, int64_t rows, int H, hipStream_t s);

@@ -9,6 +9,8 @@
 // Dropout masks are NOT stored: keep(seed, stream, index) is a counter-based hash (splitmix64), the same
 // integer function as wav2vec2/variables.py::dropout_keep, regenerated wherever the mask is needed
 // (forward, backward, and inside the attention kernels).
+#include <type_traits>
+
 #include "common.h"
 #include "train.h"
 
@@ -100,6 +102,50 @@ __global__ void dropout_bwd_kernel(const float* __restrict__ u, const float* __r
             dx[i] = g;
             if (dx16) dx16[i] = (uint16_t)pack_bf16_rne(g, 0.f);
         }
+    }
+}
+
+// dropout backward over a (rows, cols) tensor that ALSO leaves the column sums of its result: the result is the dY of a Dense
+// layer, whose bias gradient is exactly that sum (fp32, unrounded).  Same element function and hash index (r cols + c) as
+// dropout_bwd_kernel; the loop is the column-sum kernel's: 64 float4 column groups x 4 row lanes per block, 128-row chunks,
+// partial[chunk][cols] folded by colsum_final_wide.  Needs cols % 4 == 0 and 16-byte aligned tensors.
+__global__ __launch_bounds__(256) void dropout_bwd_colsum_kernel(const float* __restrict__ u, const float* __restrict__ dy,
+                                                                 float* __restrict__ dx, uint16_t* __restrict__ dx16,
+                                                                 float* __restrict__ partial, int64_t rows, int cols, int rows_per_chunk,
+                                                                 int act, float p, uint64_t seed, uint32_t stream) {
+    __shared__ float4 red[4][64];
+    const float inv = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    const uint32_t key = dropout_key(seed, stream), thr = dropout_threshold(p);
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + cx) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < cols) {
+        for (int64_t r = r0 + ry; r < r1; r += 4) {
+            const int64_t i = r * cols + c;
+            const float4 gv = *reinterpret_cast<const float4*>(dy + i);
+            float g[4] = {gv.x, gv.y, gv.z, gv.w};
+            if (p > 0.f) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = dropout_keep32(key, (uint32_t)(i + e), thr) ? g[e] * inv : 0.0f;
+            }
+            if (act) {
+                const float4 uv = *reinterpret_cast<const float4*>(u + i);
+                g[0] *= gelu_grad(uv.x, act); g[1] *= gelu_grad(uv.y, act); g[2] *= gelu_grad(uv.z, act); g[3] *= gelu_grad(uv.w, act);
+            }
+            *reinterpret_cast<float4*>(dx + i) = make_float4(g[0], g[1], g[2], g[3]);
+            if (dx16) *reinterpret_cast<uint2*>(dx16 + i) = make_uint2(pack_bf16_rne(g[0], g[1]), pack_bf16_rne(g[2], g[3]));
+            acc.x += g[0]; acc.y += g[1]; acc.z += g[2]; acc.w += g[3];
+        }
+    }
+    red[ry][cx] = acc;
+    __syncthreads();
+    if (ry == 0 && c < cols) {
+        const float4 p0 = red[0][cx], p1 = red[1][cx], p2 = red[2][cx], p3 = red[3][cx];
+        *reinterpret_cast<float4*>(partial + (int64_t)blockIdx.y * cols + c) =
+            make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z),
+                        (p0.w + p1.w) + (p2.w + p3.w));
     }
 }
 
@@ -225,18 +271,25 @@ __global__ __launch_bounds__(256) void colsum_final_wide_kernel(const float* __r
 // LayerNorm backward.  One wave per row (grid-stride); per-lane dgamma / dbeta partials live in
 // registers across the rows a wave visits, are combined across the block's 4 waves through LDS and
 // written as partial[block][2][C]; colsum_final reduces them.
-template <int NV>
+// DXSUM: also leave the column sums of dx (dx is the dY of the Dense layer in front of this LayerNorm: its bias gradient) as a
+// third group of C partials.
+template <int NV, bool DXSUM>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ dy, float* __restrict__ dx,
                                                      uint16_t* __restrict__ dx16 /* optional bf16 shadow of dx */,
                                                      float* __restrict__ partial, int64_t rows, int C, float eps) {
-    extern __shared__ float red[];   // 4 waves x 2 x C
+    extern __shared__ float red[];   // 4 waves x NG x C
+    constexpr int NG = DXSUM ? 3 : 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float dg[NV][4], db[NV][4];
+    float dg[NV][4], db[NV][4], ds[DXSUM ? NV : 1][4];
 #pragma unroll
     for (int i = 0; i < NV; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) dg[i][e] = db[i][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < (DXSUM ? NV : 1); ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ds[i][e] = 0.f;
     const bool vec = (C & 3) == 0;
     float gam[NV][4];
 #pragma unroll
@@ -312,6 +365,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
                                                  rstd * (gv[i][2] - s1 - xv[i][2] * s2), rstd * (gv[i][3] - s1 - xv[i][3] * s2));
                     *reinterpret_cast<float4*>(dxr + c) = o;
                     if (dx16) *reinterpret_cast<uint2*>(dx16 + row * C + c) = make_uint2(pack_bf16_rne(o.x, o.y), pack_bf16_rne(o.z, o.w));
+                    if constexpr (DXSUM) { ds[i][0] += o.x; ds[i][1] += o.y; ds[i][2] += o.z; ds[i][3] += o.w; }
                 }
             }
         } else {
@@ -324,6 +378,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
                         const float o = rstd * (gv[i][e] - s1 - xv[i][e] * s2);
                         dxr[c] = o;
                         if (dx16) dx16[row * C + c] = (uint16_t)pack_bf16_rne(o, 0.f);
+                        if constexpr (DXSUM) ds[i][e] += o;
                     }
                 }
         }
@@ -334,15 +389,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
         for (int e = 0; e < 4; ++e) {
             const int c = (i * 64 + lane) * 4 + e;
             if (c < C) {
-                red[(wave * 2 + 0) * C + c] = dg[i][e];
-                red[(wave * 2 + 1) * C + c] = db[i][e];
+                red[(wave * NG + 0) * C + c] = dg[i][e];
+                red[(wave * NG + 1) * C + c] = db[i][e];
+                if constexpr (DXSUM) red[(wave * NG + 2) * C + c] = ds[i][e];
             }
         }
     __syncthreads();
-    for (int c = threadIdx.x; c < 2 * C; c += 256) {
+    for (int c = threadIdx.x; c < NG * C; c += 256) {
         const int which = c / C, cc = c % C;
-        partial[(int64_t)blockIdx.x * 2 * C + c] =
-            red[(0 * 2 + which) * C + cc] + red[(1 * 2 + which) * C + cc] + red[(2 * 2 + which) * C + cc] + red[(3 * 2 + which) * C + cc];
+        partial[(int64_t)blockIdx.x * NG * C + c] =
+            red[(0 * NG + which) * C + cc] + red[(1 * NG + which) * C + cc] + red[(2 * NG + which) * C + cc] + red[(3 * NG + which) * C + cc];
     }
 }
 
@@ -489,35 +545,58 @@ int launch_colsum(const float* x, float* out, int64_t rows, int cols, float* ws,
     return W2V2_OK;
 }
 
+// dx = dropout-backward(dy) as launch_dropout_bwd_x, plus colsum[c] = sum over rows of dx[r][c] (the bias gradient of the Dense
+// layer dx is the output gradient of).  ws: colsum_ws_floats(rows, cols) floats.  Falls back to the two separate passes when
+// the tensors do not allow 16-byte accesses.
+int launch_dropout_bwd_colsum(const float* u, const float* dy, float* dx, uint16_t* dx16, float* colsum, int64_t rows, int cols,
+                              int act, float p, uint64_t seed, uint32_t stream_id, float* ws, hipStream_t s) {
+    W2V2_REQUIRE(dy && dx && colsum && ws && rows > 0 && cols > 0 && p >= 0.f && p < 1.f && (act == 0 || u), "dropout_bwd_colsum: bad argument");
+    const bool vec = (cols & 3) == 0 && ((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) |
+                                           reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(colsum)) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(dx16) & 7) == 0;
+    if (!vec) {
+        if (int e = launch_dropout_bwd_x(u, dy, dx, dx16, rows * cols, act, p, seed, stream_id, s)) return e;
+        return launch_colsum(dx, colsum, rows, cols, ws, 0, s);
+    }
+    const int nchunks = (int)((rows + COLSUM_CHUNK - 1) / COLSUM_CHUNK);
+    hipLaunchKernelGGL(dropout_bwd_colsum_kernel, dim3((cols + 255) / 256, nchunks), dim3(256), 0, s, u, dy, dx, dx16, ws, rows, cols,
+                       COLSUM_CHUNK, act, p, seed, stream_id);
+    hipLaunchKernelGGL(colsum_final_wide_kernel, dim3((cols + 31) / 32), dim3(256), 0, s, ws, colsum, nchunks, cols, (int64_t)cols, 0);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
 static int ln_bwd_blocks(int64_t rows) {
     int64_t b = (rows + 3) / 4;
     return (int)(b > 1024 ? 1024 : b);
 }
-int64_t ln_bwd_ws_floats(int64_t rows, int C) { return (int64_t)ln_bwd_blocks(rows) * 2 * C + 8; }
+int64_t ln_bwd_ws_floats(int64_t rows, int C) { return (int64_t)ln_bwd_blocks(rows) * 3 * C + 8; }
 
 int launch_ln_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma,
                   float* dbeta, int64_t rows, int C, float eps, float* ws, hipStream_t s) {
-    return launch_ln_bwd_x(x, gamma, dy, dx, nullptr, dgamma, dbeta, rows, C, eps, ws, s);
+    return launch_ln_bwd_x(x, gamma, dy, dx, nullptr, dgamma, dbeta, rows, C, eps, ws, s, nullptr);
 }
 
 int launch_ln_bwd_x(const float* x, const float* gamma, const float* dy, float* dx, uint16_t* dx16, float* dgamma,
-                    float* dbeta, int64_t rows, int C, float eps, float* ws, hipStream_t s) {
+                    float* dbeta, int64_t rows, int C, float eps, float* ws, hipStream_t s, float* dxsum) {
     W2V2_REQUIRE(x && gamma && dy && dx && dgamma && dbeta && ws, "ln_bwd: null operand");
     W2V2_REQUIRE(!dx16 || ((C & 3) == 0 && (reinterpret_cast<uintptr_t>(dx16) & 7) == 0), "ln_bwd: the bf16 shadow needs C %% 4 == 0");
     W2V2_REQUIRE(rows > 0 && C > 0 && C <= 1024, "ln_bwd: rows=%lld C=%d unsupported (C <= 1024)", (long long)rows, C);
     const int nb = ln_bwd_blocks(rows);
-    const size_t lds = (size_t)4 * 2 * C * sizeof(float);
-    if (C <= 256)
-        hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, dx16, ws, rows, C, eps);
-    else if (C <= 512)
-        hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, dx16, ws, rows, C, eps);
-    else
-        hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, dx16, ws, rows, C, eps);
-    // partial is (nb, 2C): dgamma = column sums of its first C columns, dbeta of its last C
-    const dim3 g2((C + EW_THREADS - 1) / EW_THREADS);
-    (void)g2;
-    hipLaunchKernelGGL(colsum_final_wide_kernel, dim3((C + 31) / 32), dim3(256), 0, s, ws, dgamma, nb, C, (int64_t)2 * C, 0);
-    hipLaunchKernelGGL(colsum_final_wide_kernel, dim3((C + 31) / 32), dim3(256), 0, s, ws + C, dbeta, nb, C, (int64_t)2 * C, 0);
+    const int ng = dxsum ? 3 : 2;
+    const size_t lds = (size_t)4 * ng * C * sizeof(float);
+    auto go = [&](auto nv) {
+        constexpr int NV = decltype(nv)::value;
+        if (dxsum) hipLaunchKernelGGL((ln_bwd_kernel<NV, true>), dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, dx16, ws, rows, C, eps);
+        else hipLaunchKernelGGL((ln_bwd_kernel<NV, false>), dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, dx16, ws, rows, C, eps);
+    };
+    if (C <= 256) go(std::integral_constant<int, 1>{});
+    else if (C <= 512) go(std::integral_constant<int, 2>{});
+    else go(std::integral_constant<int, 4>{});
+    // partial is (nb, ng C): dgamma = column sums of its first C columns, dbeta of the next C [, the sums of dx of the last C]
+    hipLaunchKernelGGL(colsum_final_wide_kernel, dim3((C + 31) / 32), dim3(256), 0, s, ws, dgamma, nb, C, (int64_t)ng * C, 0);
+    hipLaunchKernelGGL(colsum_final_wide_kernel, dim3((C + 31) / 32), dim3(256), 0, s, ws + C, dbeta, nb, C, (int64_t)ng * C, 0);
+    if (dxsum) hipLaunchKernelGGL(colsum_final_wide_kernel, dim3((C + 31) / 32), dim3(256), 0, s, ws + 2 * C, dxsum, nb, C, (int64_t)ng * C, 0);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }

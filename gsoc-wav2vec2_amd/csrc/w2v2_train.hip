@@ -644,6 +644,18 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     const float eps = c.layer_norm_eps, p = t->p;
     const uint64_t seed = t->seed;
     const int32_t* flen = t->have_mask ? m->frame_len : nullptr;
+    // With the shadows on, the weight-gradient GEMMs take the LDS-DMA / transposing-read kernel, which has no fp32 dY in
+    // registers to sum for the bias gradient: the PRODUCER of each dY leaves its column sums instead (dropout backward,
+    // LayerNorm backward), and weight_grad is called without a bias target.  `bias_from_producer` says that happened.
+    auto dropout_bwd_bias = [&](const float* u, const float* dy, float* dx, uint16_t* dx16, int64_t rows, int cols, int act_, uint32_t stream_id,
+                                float* bias_grad, bool* bias_done) -> int {
+        *bias_done = false;
+        if (shb && bias_grad) {
+            *bias_done = true;
+            return launch_dropout_bwd_colsum(u, dy, dx, dx16, bias_grad, rows, cols, act_, p, seed, stream_id, t->red_ws, s);
+        }
+        return launch_dropout_bwd_x(u, dy, dx, dx16, rows * cols, act_, p, seed, stream_id, s);
+    };
     W2V2_HIP_CHECK(hipMemsetAsync(t->grads, 0, (size_t)t->gtotal * 4, s));
     if (int e = refresh_transposes(m, s)) return e;
     const int nbuckets = c.num_layers + 2;
@@ -722,9 +734,10 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
                                     G(b + "/feed_forward/output_dense/bias"), s))
                 return e;
             if (int e = gemm_dx(dh, nullptr, H, l.W2T, m->P(b + "/feed_forward/output_dense/kernel"), t->gf, F, nullptr, (int)BT, F, H, s)) return e;
-            if (int e = launch_dropout_bwd_x(l.u, t->gf, t->gf, s16f, BT * F, act, p, seed, layer_stream(i, 2), s)) return e;
+            bool b1_done = false;
+            if (int e = dropout_bwd_bias(l.u, t->gf, t->gf, s16f, BT, F, act, layer_stream(i, 2), G(b + "/feed_forward/intermediate_dense/bias"), &b1_done)) return e;
             if (int e = weight_grad(m, l.t2, t->gf, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
-                                    G(b + "/feed_forward/intermediate_dense/bias"), s, xs ? l.t2_16 : nullptr, s16f))
+                                    b1_done ? nullptr : G(b + "/feed_forward/intermediate_dense/bias"), s, xs ? l.t2_16 : nullptr, s16f))
                 return e;
             if (int e = gemm_dx(t->gf, s16f, F, l.W1T, m->P(b + "/feed_forward/intermediate_dense/kernel"), tmp, H, nullptr, (int)BT, H, F, s)) return e;
             float* dg2 = G(b + "/final_layer_norm/gamma");
@@ -737,9 +750,10 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
             W2V2_HIP_CHECK(hipMemcpyAsync(dt1, dh, (size_t)BT * H * 4, hipMemcpyDeviceToDevice, s));
         }
         float* d_o = tmp;
-        if (int e = launch_dropout_bwd_x(nullptr, dt1, d_o, s16h, BT * H, 0, p, seed, layer_stream(i, 1), s)) return e;
-        if (int e = weight_grad(m, l.ctx, d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), G(b + "/attention/out_proj/bias"), s,
-                                (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h))
+        bool bo_done = false;
+        if (int e = dropout_bwd_bias(nullptr, dt1, d_o, s16h, BT, H, 0, layer_stream(i, 1), G(b + "/attention/out_proj/bias"), &bo_done)) return e;
+        if (int e = weight_grad(m, l.ctx, d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"),
+                                bo_done ? nullptr : G(b + "/attention/out_proj/bias"), s, (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h))
             return e;
         float* dctx = tmp2;
         if (int e = gemm_dx(d_o, s16h, H, l.WoT, m->P(b + "/attention/out_proj/kernel"), dctx, H, nullptr, (int)BT, H, H, s)) return e;
@@ -763,20 +777,23 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         float* dt3 = tmp;
         float* dg2 = G(b + "/final_layer_norm/gamma");
         float* db2 = G(b + "/final_layer_norm/beta");
+        // (dt3 is the dY of the FFN down-projection: its column sums are that layer's bias gradient)
+        float* const gb2 = (shb && l.keep != 0.f) ? G(b + "/feed_forward/output_dense/bias") : nullptr;
         if (int e = launch_ln_bwd_x(l.t3, m->P(b + "/final_layer_norm/gamma"), dh, dt3, (l.keep != 0.f && H % 4 == 0) ? s16h : nullptr,
-                                    dg2 ? dg2 : t->dummy, db2 ? db2 : t->dummy + H, BT, H, eps, t->red_ws, s))
+                                    dg2 ? dg2 : t->dummy, db2 ? db2 : t->dummy + H, BT, H, eps, t->red_ws, s, gb2))
             return e;
         float* dt2 = tmp2;
         if (l.keep != 0.f) {
             // t3 = t2 + f,  f = gd W2 + b2
             if (int e = weight_grad(m, l.gd, dt3, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
-                                    G(b + "/feed_forward/output_dense/bias"), s, xs ? l.gd16 : nullptr, H % 4 == 0 ? s16h : nullptr))
+                                    gb2 ? nullptr : G(b + "/feed_forward/output_dense/bias"), s, xs ? l.gd16 : nullptr, H % 4 == 0 ? s16h : nullptr))
                 return e;
             if (int e = gemm_dx(dt3, H % 4 == 0 ? s16h : nullptr, H, l.W2T, m->P(b + "/feed_forward/output_dense/kernel"), t->gf, F, nullptr, (int)BT, F, H, s)) return e;
-            // du = dgd * keep/(1-p) * GELU'(u)
-            if (int e = launch_dropout_bwd_x(l.u, t->gf, t->gf, s16f, BT * F, act, p, seed, layer_stream(i, 2), s)) return e;
+            // du = dgd * keep/(1-p) * GELU'(u)   (+ its column sums = the up-projection's bias gradient)
+            bool b1_done = false;
+            if (int e = dropout_bwd_bias(l.u, t->gf, t->gf, s16f, BT, F, act, layer_stream(i, 2), G(b + "/feed_forward/intermediate_dense/bias"), &b1_done)) return e;
             if (int e = weight_grad(m, l.t2, t->gf, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
-                                    G(b + "/feed_forward/intermediate_dense/bias"), s, xs ? l.t2_16 : nullptr, s16f))
+                                    b1_done ? nullptr : G(b + "/feed_forward/intermediate_dense/bias"), s, xs ? l.t2_16 : nullptr, s16f))
                 return e;
             // dt2 = du W1^T + dt3 (the residual branch)
             if (int e = gemm_dx(t->gf, s16f, F, l.W1T, m->P(b + "/feed_forward/intermediate_dense/kernel"), dt2, H, dt3, (int)BT, H, F, s)) return e;
@@ -792,9 +809,10 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
             return e;
         // t1 = dropout(o) + x,  o = ctx Wo + bo
         float* d_o = tmp;     // dt3 (and its shadow) is dead
-        if (int e = launch_dropout_bwd_x(nullptr, dt1, d_o, s16h, BT * H, 0, p, seed, layer_stream(i, 1), s)) return e;
-        if (int e = weight_grad(m, l.ctx, d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), G(b + "/attention/out_proj/bias"), s,
-                                (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h))
+        bool bo_done = false;
+        if (int e = dropout_bwd_bias(nullptr, dt1, d_o, s16h, BT, H, 0, layer_stream(i, 1), G(b + "/attention/out_proj/bias"), &bo_done)) return e;
+        if (int e = weight_grad(m, l.ctx, d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"),
+                                bo_done ? nullptr : G(b + "/attention/out_proj/bias"), s, (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h))
             return e;
         float* dctx = tmp2;   // dt2 is dead
         if (int e = gemm_dx(d_o, s16h, H, l.WoT, m->P(b + "/attention/out_proj/kernel"), dctx, H, nullptr, (int)BT, H, H, s)) return e;
