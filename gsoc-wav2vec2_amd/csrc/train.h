@@ -79,6 +79,8 @@ int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float l
 int launch_spec_aug_fwd(const float* x, const uint8_t* mask, const float* embed, float* y, int64_t rows, int H, hipStream_t s);
 int launch_spec_aug_bwd(const float* dy, const uint8_t* mask, float* dx, float* dmasked, int64_t rows, int H, hipStream_t s);
 int launch_axpby(const float* a, const float* b, float* y, int64_t n, float alpha, float beta, hipStream_t s);
+int launch_axpby_x(const float* a, const float* b, float* y, uint16_t* y16 /* optional bf16 shadow */, int64_t n, float alpha, float beta,
+                   hipStream_t s);
 int launch_mask_rows(const float* x, const int32_t* frame_len, float* y, int B, int T, int H, hipStream_t s);
 
 // attention, training variants (attention.hip)

@@ -457,6 +457,20 @@ __global__ void axpby_kernel(const float* __restrict__ a, const float* __restric
     for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS)
         y[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
 }
+// 16 bytes per lane, optional bf16 shadow of the result (n % 4 == 0, aligned operands)
+__global__ void axpby4_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, uint16_t* __restrict__ y16,
+                              int64_t n4, float alpha, float beta) {
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n4; i += (int64_t)gridDim.x * EW_THREADS) {
+        const float4 av = reinterpret_cast<const float4*>(a)[i];
+        float4 o = make_float4(alpha * av.x, alpha * av.y, alpha * av.z, alpha * av.w);
+        if (b) {
+            const float4 bv = reinterpret_cast<const float4*>(b)[i];
+            o.x += beta * bv.x; o.y += beta * bv.y; o.z += beta * bv.z; o.w += beta * bv.w;
+        }
+        reinterpret_cast<float4*>(y)[i] = o;
+        if (y16) reinterpret_cast<uint2*>(y16)[i] = make_uint2(pack_bf16_rne(o.x, o.y), pack_bf16_rne(o.z, o.w));
+    }
+}
 
 // zero rows t >= frame_len[b] of a (B, T, H) tensor (encoder.py:253 and its gradient)
 __global__ void mask_rows_kernel(const float* __restrict__ x, const int32_t* __restrict__ frame_len,
@@ -632,7 +646,21 @@ int launch_spec_aug_bwd(const float* dy, const uint8_t* mask, float* dx, float* 
 }
 
 int launch_axpby(const float* a, const float* b, float* y, int64_t n, float alpha, float beta, hipStream_t s) {
+    return launch_axpby_x(a, b, y, nullptr, n, alpha, beta, s);
+}
+
+// y = alpha a + beta b (b may be null); y16: optional bf16 shadow of y (written only on the 16-byte path; returns an error if
+// it was asked for and the operands do not allow that path, so a caller never consumes a shadow that was not written)
+int launch_axpby_x(const float* a, const float* b, float* y, uint16_t* y16, int64_t n, float alpha, float beta, hipStream_t s) {
     W2V2_REQUIRE(a && y && n > 0, "axpby: bad argument");
+    const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(y16) & 7) == 0;
+    if (vec) {
+        hipLaunchKernelGGL(axpby4_kernel, dim3(ew_grid(n >> 2)), dim3(EW_THREADS), 0, s, a, b, y, y16, n >> 2, alpha, beta);
+        W2V2_HIP_CHECK(hipGetLastError());
+        return W2V2_OK;
+    }
+    W2V2_REQUIRE(!y16, "axpby: the bf16 shadow needs n %% 4 == 0 and 16-byte aligned operands");
     hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, s, a, b, y, n, alpha, beta);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;

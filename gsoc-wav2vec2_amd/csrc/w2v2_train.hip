@@ -723,17 +723,20 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         return W2V2_OK;
     };
 
+    bool dh16_valid = false;
     for (int i = c.num_layers - 1; i >= 0 && prenorm; --i) {
         // prenorm layer (encoder.py:111-134):  t1 = x + drop(attn(LN1(x)));  out = t1 + keep * FFN(LN2(t1))
         const std::string b = "encoder/layers/" + std::to_string(i);
         LayerSave& l = t->layers[i];
         const float* x = i == 0 ? t->hs0 : m->hs[i];
         float* dt1 = tmp3;
+        // dh's bf16 shadow (written by the previous iteration's closing axpby into s16h, which is free again by then)
+        const uint16_t* dh16 = dh16_valid ? s16h : nullptr;
         if (l.keep != 0.f) {
             if (int e = weight_grad(m, l.gd, dh, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
-                                    G(b + "/feed_forward/output_dense/bias"), s))
+                                    G(b + "/feed_forward/output_dense/bias"), s, (xs && dh16) ? l.gd16 : nullptr, dh16))
                 return e;
-            if (int e = gemm_dx(dh, nullptr, H, l.W2T, m->P(b + "/feed_forward/output_dense/kernel"), t->gf, F, nullptr, (int)BT, F, H, s)) return e;
+            if (int e = gemm_dx(dh, dh16, H, l.W2T, m->P(b + "/feed_forward/output_dense/kernel"), t->gf, F, nullptr, (int)BT, F, H, s)) return e;
             bool b1_done = false;
             if (int e = dropout_bwd_bias(l.u, t->gf, t->gf, s16f, BT, F, act, layer_stream(i, 2), G(b + "/feed_forward/intermediate_dense/bias"), &b1_done)) return e;
             if (int e = weight_grad(m, l.t2, t->gf, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
@@ -766,7 +769,10 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         if (int e = launch_ln_bwd(x, m->P(b + "/layer_norm/gamma"), tmp, tmp2, dg1 ? dg1 : t->dummy, db1 ? db1 : t->dummy + H, BT, H,
                                   eps, t->red_ws, s))
             return e;
-        if (int e = launch_axpby(dt1, tmp2, dh, BT * H, 1.f, 1.f, s)) return e;          // residual + LN1 branch
+        // residual + LN1 branch (+ the shadow the next iteration's down-projection GEMMs stream)
+        dh16_valid = s16h && (BT * H) % 4 == 0 &&
+                     ((reinterpret_cast<uintptr_t>(dt1) | reinterpret_cast<uintptr_t>(tmp2) | reinterpret_cast<uintptr_t>(dh)) & 15) == 0;
+        if (int e = launch_axpby_x(dt1, tmp2, dh, dh16_valid ? s16h : nullptr, BT * H, 1.f, 1.f, s)) return e;
         if (int e = bucket_done(c.num_layers - i)) return e;
     }
 
