@@ -635,19 +635,19 @@ int launch_attn_bwd(const AttnBwdArgs& a, const AttnTrain& tr, const float* ctx,
 
 int launch_attention(Profiler* prof, const float* qkv, const int32_t* frame_len, float* ctx, int B,
                      int T, int H, int heads, hipStream_t s) {
-    return launch_attention_x(prof, qkv, frame_len, ctx, B, T, H, heads, nullptr, s);
+    return launch_attention_x(prof, qkv, nullptr, frame_len, ctx, B, T, H, heads, nullptr, s);
 }
 
-int launch_attention_x(Profiler* prof, const float* qkv, const int32_t* frame_len, float* ctx, int B, int T, int H,
+int launch_attention_x(Profiler* prof, const float* qkv, const uint16_t* qkv16, const int32_t* frame_len, float* ctx, int B, int T, int H,
                        int heads, uint16_t* ctx16, hipStream_t s) {
-    W2V2_REQUIRE(qkv && ctx, "attention: null operand");
     W2V2_REQUIRE(B > 0 && T > 0 && heads > 0 && H % heads == 0, "attention: bad sizes");
     const int dh = H / heads;
-    AttnArgs a{qkv, frame_len, ctx, B, T, H, heads, 1.0f / sqrtf((float)dh)};
     ProfScope ps(prof, FAM_ATTENTION, 4.0 * B * (double)heads * T * (double)T * dh,
                  4.0 * B * (double)T * 4.0 * H, s);
     if (gemm_get_precision() == 1 && attention_bf16_supported(dh))
-        return launch_attention_fwd_bf16(qkv, frame_len, ctx, ctx16, B, T, H, heads, nullptr, s);
+        return launch_attention_fwd_bf16(qkv, qkv16, frame_len, ctx, ctx16, B, T, H, heads, nullptr, s);
+    W2V2_REQUIRE(qkv && ctx, "attention: null operand");
+    AttnArgs a{qkv, frame_len, ctx, B, T, H, heads, 1.0f / sqrtf((float)dh)};
     W2V2_REQUIRE(!ctx16, "attention: a bf16 shadow output needs the bf16 kernel (precision 1, head size 64)");
     if (gemm_get_precision() == 2 && attention_split_supported(dh) && H % 4 == 0 &&
         ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(ctx)) & 15) == 0)
@@ -668,18 +668,19 @@ namespace w2v2 {
 
 int launch_attention_train(Profiler* prof, const float* qkv, const int32_t* frame_len, float* ctx, int B, int T,
                            int H, int heads, const AttnTrain& tr, hipStream_t s) {
-    return launch_attention_train_x(prof, qkv, frame_len, ctx, nullptr, B, T, H, heads, tr, s);
+    return launch_attention_train_x(prof, qkv, nullptr, frame_len, ctx, nullptr, B, T, H, heads, tr, s);
 }
 
-int launch_attention_train_x(Profiler* prof, const float* qkv, const int32_t* frame_len, float* ctx, uint16_t* ctx16, int B, int T,
-                             int H, int heads, const AttnTrain& tr, hipStream_t s) {
-    W2V2_REQUIRE(qkv && ctx && tr.lse, "attention_train: null operand");
+int launch_attention_train_x(Profiler* prof, const float* qkv, const uint16_t* qkv16, const int32_t* frame_len, float* ctx, uint16_t* ctx16,
+                             int B, int T, int H, int heads, const AttnTrain& tr, hipStream_t s) {
+    W2V2_REQUIRE((qkv || qkv16) && ctx && tr.lse, "attention_train: null operand");
     W2V2_REQUIRE(B > 0 && T > 0 && heads > 0 && H % heads == 0 && tr.p >= 0.f && tr.p < 1.f, "attention_train: bad sizes");
     const int dh = H / heads;
-    AttnArgs a{qkv, frame_len, ctx, B, T, H, heads, 1.0f / sqrtf((float)dh)};
     ProfScope ps(prof, FAM_ATTENTION, 4.0 * B * (double)heads * T * (double)T * dh, 4.0 * B * (double)T * 4.0 * H, s);
     if (gemm_get_precision() == 1 && attention_bf16_supported(dh))
-        return launch_attention_fwd_bf16(qkv, frame_len, ctx, ctx16, B, T, H, heads, &tr, s);
+        return launch_attention_fwd_bf16(qkv, qkv16, frame_len, ctx, ctx16, B, T, H, heads, &tr, s);
+    W2V2_REQUIRE(qkv, "attention_train: the fp32 kernels need the fp32 qkv");
+    AttnArgs a{qkv, frame_len, ctx, B, T, H, heads, 1.0f / sqrtf((float)dh)};
     W2V2_REQUIRE(!ctx16, "attention_train: a bf16 shadow output needs the bf16 kernel (precision 1, head size 64)");
     switch (dh) {
         case 32: return launch_attn_train<32>(a, tr, s);
@@ -692,16 +693,17 @@ int launch_attention_train_x(Profiler* prof, const float* qkv, const int32_t* fr
 
 int launch_attention_bwd(Profiler* prof, const float* qkv, const int32_t* frame_len, const float* ctx,
                          const float* dctx, float* dqkv, float* dvec_ws, int B, int T, int H, int heads,
-                         const AttnTrain& tr, hipStream_t s, uint16_t* dqkv16) {
-    W2V2_REQUIRE(qkv && ctx && dctx && dqkv && dvec_ws && tr.lse, "attention_bwd: null operand");
+                         const AttnTrain& tr, hipStream_t s, uint16_t* dqkv16, const uint16_t* qkv16, const uint16_t* dctx16) {
+    W2V2_REQUIRE((qkv || qkv16) && ctx && dctx && dqkv && dvec_ws && tr.lse, "attention_bwd: null operand");
     W2V2_REQUIRE(B > 0 && T > 0 && heads > 0 && H % heads == 0, "attention_bwd: bad sizes");
     const int dh = H / heads;
-    AttnBwdArgs a{qkv, frame_len, dctx, dvec_ws, dqkv, B, T, H, heads, 1.0f / sqrtf((float)dh)};
     ProfScope ps(prof, FAM_ATTENTION, 10.0 * B * (double)heads * T * (double)T * dh, 4.0 * B * (double)T * 8.0 * H, s);
     if (gemm_get_precision() == 1 && attention_bf16_supported(dh)) {
         hipLaunchKernelGGL(attn_dvec_kernel<64>, dim3((unsigned)((int64_t)B * T)), dim3(256), 0, s, ctx, dctx, dvec_ws, B, T, H, heads);
-        return launch_attention_bwd_bf16(qkv, frame_len, dctx, dvec_ws, dqkv, dqkv16, B, T, H, heads, tr, s);
+        return launch_attention_bwd_bf16(qkv, qkv16, frame_len, dctx, dctx16, dvec_ws, dqkv, dqkv16, B, T, H, heads, tr, s);
     }
+    W2V2_REQUIRE(qkv, "attention_bwd: the fp32 kernels need the fp32 qkv");
+    AttnBwdArgs a{qkv, frame_len, dctx, dvec_ws, dqkv, B, T, H, heads, 1.0f / sqrtf((float)dh)};
     W2V2_REQUIRE(!dqkv16, "attention_bwd: a bf16 shadow of dqkv is only written by the bf16 kernels (head size 64, precision mode 1)");
     switch (dh) {
         case 32: return launch_attn_bwd<32>(a, tr, ctx, dvec_ws, s);

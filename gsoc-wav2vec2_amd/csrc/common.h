@@ -190,7 +190,7 @@ int launch_attention(Profiler* prof, const float* qkv, const int32_t* frame_len,
                      int T, int H, int heads, hipStream_t s);
 
 // grow-only device scratch per (purpose, stream), owned by the library (shadow.hip)
-enum ScratchSlot { SCRATCH_SPLITK = 0, SCRATCH_CTC = 1 };
+enum ScratchSlot { SCRATCH_SPLITK = 0, SCRATCH_CTC = 1, SCRATCH_QKV16 = 2, SCRATCH_DCTX16 = 3 };
 int stream_scratch(int slot, hipStream_t s, size_t bytes, void** out);
 int stream_scratch_release();       // frees the calling device's scratch buffers
 // one layer's q | k | v projections <-> the packed (H, 3H) kernel and (3H) bias (shadow.hip); unpack skips null targets
@@ -199,7 +199,9 @@ int launch_qkv_unpack(const float* packed_w, const float* packed_b, float* const
 bool attention_bf16_supported(int head_size);   // attention_bf16.hip: head size 64
 bool attention_split_supported(int head_size);  // attention_split.hip (precision mode 2): head size 64
 int launch_attention_split(const float* qkv, const int32_t* frame_len, float* ctx, int B, int T, int H, int heads, hipStream_t s);
-int launch_attention_x(Profiler* prof, const float* qkv, const int32_t* frame_len, float* ctx, int B, int T, int H,
+// qkv16: optional bf16 shadow of qkv (precision mode 1 with head size 64 reads ONLY it; qkv may then be null.  Without it that
+// kernel rounds qkv into scratch first).  ctx may be null when ctx16 is given.
+int launch_attention_x(Profiler* prof, const float* qkv, const uint16_t* qkv16, const int32_t* frame_len, float* ctx, int B, int T, int H,
                        int heads, uint16_t* ctx16 /* optional bf16 shadow of ctx (bf16 kernel only) */, hipStream_t s);
 
 int launch_frame_lengths(Profiler* prof, const int32_t* mask, int32_t* frame_len, int B, int64_t L,

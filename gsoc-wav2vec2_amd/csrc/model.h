@@ -52,6 +52,7 @@ struct w2v2_model {
     int shadow_njobs = 0;
     bool shadow_jobs_train = false;                       // the table includes the plain copies (built after training state existed)
     std::vector<uint16_t*> conv16, hs16;
+    uint16_t *qkv16 = nullptr;                            // q|k|v as the bf16 attention kernels read it (the fp32 copy is then not written)
     uint16_t *ln512_16 = nullptr, *ctx16 = nullptr, *t0_16 = nullptr, *t2_16 = nullptr, *ffn16 = nullptr, *enc16 = nullptr;
     // bf16 positional conv (precision mode 1; posconv.hip): kernel shadow (groups, og, K cg), pack scratch (B, G, T+K-1, cg)
     uint16_t *pos_w16 = nullptr, *pos_pack16 = nullptr;

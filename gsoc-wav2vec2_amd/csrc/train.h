@@ -92,19 +92,22 @@ struct AttnTrain {
 };
 // bf16 matrix-pipe attention (attention_bf16.hip); taken by launch_attention* while the thread's precision is 1
 bool attention_bf16_supported(int head_size);
-int launch_attention_fwd_bf16(const float* qkv, const int32_t* frame_len, float* ctx, uint16_t* ctx16, int B, int T, int H,
-                              int heads, const AttnTrain* tr, hipStream_t s);
-int launch_attention_bwd_bf16(const float* qkv, const int32_t* frame_len, const float* dctx, const float* dvec,
-                              float* dqkv, uint16_t* dqkv16 /* optional bf16 shadow */, int B, int T, int H, int heads,
+// (the kernels read bf16 shadows of qkv / dctx; a null shadow is made from the fp32 tensor in per-stream scratch)
+int launch_attention_fwd_bf16(const float* qkv, const uint16_t* qkv16, const int32_t* frame_len, float* ctx, uint16_t* ctx16, int B,
+                              int T, int H, int heads, const AttnTrain* tr, hipStream_t s);
+int launch_attention_bwd_bf16(const float* qkv, const uint16_t* qkv16, const int32_t* frame_len, const float* dctx, const uint16_t* dctx16,
+                              const float* dvec, float* dqkv, uint16_t* dqkv16 /* optional bf16 shadow */, int B, int T, int H, int heads,
                               const AttnTrain& tr, hipStream_t s);
-int launch_attention_train_x(Profiler* prof, const float* qkv, const int32_t* frame_len, float* ctx, uint16_t* ctx16, int B, int T,
-                             int H, int heads, const AttnTrain& tr, hipStream_t s);
+int launch_attention_train_x(Profiler* prof, const float* qkv, const uint16_t* qkv16, const int32_t* frame_len, float* ctx, uint16_t* ctx16,
+                             int B, int T, int H, int heads, const AttnTrain& tr, hipStream_t s);
 int launch_attention_train(Profiler* prof, const float* qkv, const int32_t* frame_len, float* ctx, int B, int T,
                            int H, int heads, const AttnTrain& tr, hipStream_t s);
 // dqkv (B, T, 3H) = gradient of the packed q|k|v given dctx (B, T, H); ctx is the forward output
+// (bf16 kernels: qkv16 / dctx16 are the optional shadows of qkv / dctx, qkv may be null when qkv16 is given)
 int launch_attention_bwd(Profiler* prof, const float* qkv, const int32_t* frame_len, const float* ctx,
                          const float* dctx, float* dqkv, float* dvec_ws, int B, int T, int H, int heads,
-                         const AttnTrain& tr, hipStream_t s, uint16_t* dqkv16 = nullptr /* bf16 shadow of dqkv (bf16 kernels only) */);
+                         const AttnTrain& tr, hipStream_t s, uint16_t* dqkv16 = nullptr /* bf16 shadow of dqkv (bf16 kernels only) */,
+                         const uint16_t* qkv16 = nullptr, const uint16_t* dctx16 = nullptr);
 
 // positional conv, training variants (posconv.hip)
 int launch_pos_conv_ex(Profiler* prof, const float* x, const float* wg, const float* bias,

@@ -290,6 +290,7 @@ int w2v2_ensure_shadows(w2v2_model* m, int B, int T, hipStream_t s) {
             m->hs16.push_back(p);
         }
         if (int e = sh_alloc(m->sh_allocs, &m->ctx16, BT * H)) return e;
+        if (int e = sh_alloc(m->sh_allocs, &m->qkv16, BT * 3 * H)) return e;
         if (int e = sh_alloc(m->sh_allocs, &m->t0_16, BT * H)) return e;
         if (int e = sh_alloc(m->sh_allocs, &m->t2_16, BT * H)) return e;
         if (int e = sh_alloc(m->sh_allocs, &m->ffn16, BT * F)) return e;
@@ -673,8 +674,13 @@ int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const i
             attn_in = m->t0;
             attn_in16 = sh ? m->t0_16 : nullptr;
         }
-        if (int e = gemm(attn_in, attn_in16, H, 0, m->qkv_w[i], 3 * H, m->qkv, nullptr, 3 * H, 0, m->qkv_b[i], nullptr, (int)BT, 3 * H, H, 1, 0)) return e;
-        if (int e = launch_attention_x(pf, m->qkv, flen, m->ctx, B, T, H, c.num_heads, attn16 ? m->ctx16 : nullptr, s)) return e;
+        // the bf16 attention kernels read q | k | v only as bf16: the projection then writes just that shadow
+        if (int e = gemm(attn_in, attn_in16, H, 0, m->qkv_w[i], 3 * H, attn16 ? nullptr : m->qkv, attn16 ? m->qkv16 : nullptr, 3 * H, 0, m->qkv_b[i],
+                         nullptr, (int)BT, 3 * H, H, 1, 0))
+            return e;
+        if (int e = launch_attention_x(pf, attn16 ? nullptr : m->qkv, attn16 ? m->qkv16 : nullptr, flen, m->ctx, B, T, H, c.num_heads,
+                                       attn16 ? m->ctx16 : nullptr, s))
+            return e;
         // out projection + residual (encoder.py:31,117-119)
         if (int e = gemm(m->ctx, attn16 ? m->ctx16 : nullptr, H, 0, m->P(b + "/attention/out_proj/kernel"), H, m->t1, nullptr, H, 0,
                          m->P(b + "/attention/out_proj/bias"), x, (int)BT, H, H, 1, 0))

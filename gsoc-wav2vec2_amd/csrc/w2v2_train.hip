@@ -29,7 +29,7 @@ struct LayerSave {
     float keep;                         // stochastic-depth draw of the last forward
     // precision mode 1: bf16 shadows of the activations the weight-gradient GEMMs contract with (dW = X^T dY reads X as a
     // transposed A).  Written by the forward's producers like the shared shadows, but kept per layer until the backward.
-    uint16_t *a16 = nullptr, *ctx16 = nullptr, *t2_16 = nullptr, *gd16 = nullptr;
+    uint16_t *a16 = nullptr, *ctx16 = nullptr, *t2_16 = nullptr, *gd16 = nullptr, *qkv16 = nullptr;
 };
 
 struct TrainState {
@@ -64,7 +64,7 @@ struct TrainState {
     int64_t slab_floats = 0;
     // bf16 shadows of the gradient tensors that are the A operand of a data-gradient GEMM (precision mode 1): written by the
     // producing kernel (LayerNorm / dropout / attention backward), consumed by the GEMM enqueued right behind it
-    uint16_t *dy16_h = nullptr, *dy16_f = nullptr, *dy16_3h = nullptr;
+    uint16_t *dy16_h = nullptr, *dy16_f = nullptr, *dy16_3h = nullptr, *dy16_ctx = nullptr;
     float* cs_ws = nullptr;           // (slabs + 1, widest N): per-slab column sums of dY from the weight-gradient GEMM
     int64_t cs_floats = 0;
     bool forward_done = false;
@@ -209,11 +209,12 @@ static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
         auto up8 = [](int64_t n) { return (n + 7) & ~(int64_t)7; };
         for (auto& l : t->layers) {
             float* raw = nullptr;
-            if (int e = t_alloc(t, &raw, (3 * up8(BT * H) + up8(BT * F)) / 2 + 16)) return e;
+            if (int e = t_alloc(t, &raw, (6 * up8(BT * H) + up8(BT * F)) / 2 + 16)) return e;
             l.a16 = reinterpret_cast<uint16_t*>(raw);
             l.ctx16 = l.a16 + up8(BT * H);
             l.t2_16 = l.ctx16 + up8(BT * H);
             l.gd16 = l.t2_16 + up8(BT * H);
+            l.qkv16 = l.gd16 + up8(BT * F);          // q | k | v as the bf16 attention kernels read it
         }
     }
     for (int i = 0; i < 4; ++i)
@@ -230,10 +231,11 @@ static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
     {
         float* raw = nullptr;                   // (BT, H) + (BT, F) + (BT, 3H) bf16, each 16-byte aligned
         auto up8 = [](int64_t n) { return (n + 7) & ~(int64_t)7; };
-        if (int e = t_alloc(t, &raw, (up8(BT * H) + up8(BT * F) + up8(BT * 3 * H)) / 2 + 16)) return e;
+        if (int e = t_alloc(t, &raw, (2 * up8(BT * H) + up8(BT * F) + up8(BT * 3 * H)) / 2 + 16)) return e;
         t->dy16_h = reinterpret_cast<uint16_t*>(raw);
         t->dy16_f = t->dy16_h + up8(BT * H);
         t->dy16_3h = t->dy16_f + up8(BT * F);
+        t->dy16_ctx = t->dy16_3h + up8(BT * 3 * H);      // dctx as the bf16 attention backward reads it
     }
     t->B = B;
     t->L = L;
@@ -537,9 +539,14 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
             attn_in = l.a;
             attn_in16 = S16(l.a16);
         }
-        if (int e = gemm(attn_in, attn_in16, H, 0, m->qkv_w[i], 3 * H, l.qkv, nullptr, 3 * H, 0, m->qkv_b[i], nullptr, (int)BT, 3 * H, H, 1, 0)) return e;
+        // the bf16 attention kernels (forward and backward) read q | k | v only as bf16: the projection then writes just that shadow
+        if (int e = gemm(attn_in, attn_in16, H, 0, m->qkv_w[i], 3 * H, attn16 ? nullptr : l.qkv, attn16 ? l.qkv16 : nullptr, 3 * H, 0, m->qkv_b[i],
+                         nullptr, (int)BT, 3 * H, H, 1, 0))
+            return e;
         AttnTrain tr{p, seed, layer_stream(i, 0), l.lse};
-        if (int e = launch_attention_train_x(pf, l.qkv, flen, l.ctx, attn16 ? l.ctx16 : nullptr, B, T, H, c.num_heads, tr, s)) return e;
+        if (int e = launch_attention_train_x(pf, attn16 ? nullptr : l.qkv, attn16 ? l.qkv16 : nullptr, flen, l.ctx, attn16 ? l.ctx16 : nullptr, B, T,
+                                             H, c.num_heads, tr, s))
+            return e;
         // o = ctx Wo + bo;  t1 = dropout(o) + x   (encoder.py:116-119)
         if (int e = gemm(l.ctx, attn16 ? l.ctx16 : nullptr, H, 0, m->P(b + "/attention/out_proj/kernel"), H, m->t0, nullptr, H, 0,
                          m->P(b + "/attention/out_proj/bias"), nullptr, (int)BT, H, H, 1, 0))
@@ -606,12 +613,14 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     const bool shb = m->precision == 1 && w2v2_shadows_enabled() && m->w16_valid;
     // A16: the producer's bf16 shadow of A (or null): with it both operands stream by LDS-DMA (gemm_bf16.hip source 5)
     auto gemm_dx = [&](const float* A, const uint16_t* A16, int64_t lda, const float* WT, const float* W, float* Cc, int64_t ldc,
-                       const float* res, int M, int N, int K, hipStream_t st) -> int {
+                       const float* res, int M, int N, int K, hipStream_t st, uint16_t* C16 = nullptr) -> int {
+        // (C16: bf16 shadow of the result, only from the shadow branch -- callers ask for it only when `dx_shadowed(W)`)
         if (shb) {
             auto it = m->w16p.find(W);
             if (it != m->w16p.end()) {
                 GemmShadows x;
                 x.A16 = A16;
+                x.C16 = C16;
                 x.B16 = it->second;
                 x.ldb16 = K;
                 return launch_gemm_bf16_x(m->prof, A, lda, 0, WT, N, 0, Cc, ldc, 0, nullptr, res, M, N, K, 1, 0, x, st);
@@ -624,6 +633,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         }
         return launch_gemm(m->prof, A, lda, 0, WT, N, Cc, ldc, 0, nullptr, res, M, N, K, 1, 0, st);
     };
+    auto dx_shadowed = [&](const float* W) { return shb && m->w16p.find(W) != m->w16p.end(); };
     // bf16 shadows of dY (written by its producer) for the data-gradient GEMMs: only where the consumer will take them
     const int dhead = c.hidden_size / c.num_heads;
     uint16_t* const s16h = shb ? t->dy16_h : nullptr;
@@ -759,9 +769,13 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
                                 bo_done ? nullptr : G(b + "/attention/out_proj/bias"), s, (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h))
             return e;
         float* dctx = tmp2;
-        if (int e = gemm_dx(d_o, s16h, H, l.WoT, m->P(b + "/attention/out_proj/kernel"), dctx, H, nullptr, (int)BT, H, H, s)) return e;
+        // (the bf16 attention backward reads dctx and q | k | v as bf16: the GEMM leaves the dctx shadow, the forward left qkv16)
+        uint16_t* const dctx16 = (s16q && dx_shadowed(m->P(b + "/attention/out_proj/kernel"))) ? t->dy16_ctx : nullptr;
+        if (int e = gemm_dx(d_o, s16h, H, l.WoT, m->P(b + "/attention/out_proj/kernel"), dctx, H, nullptr, (int)BT, H, H, s, dctx16)) return e;
         AttnTrain tr{p, seed, layer_stream(i, 0), l.lse};
-        if (int e = launch_attention_bwd(pf, l.qkv, flen, l.ctx, dctx, t->g3h, t->dvec, B, T, H, c.num_heads, tr, s, s16q)) return e;
+        if (int e = launch_attention_bwd(pf, t->x16_attn ? nullptr : l.qkv, flen, l.ctx, dctx, t->g3h, t->dvec, B, T, H, c.num_heads, tr, s, s16q,
+                                         t->x16_attn ? l.qkv16 : nullptr, dctx16))
+            return e;
         if (int e = qkv_weight_grad(b, l.a, l.a16)) return e;
         if (int e = gemm_dx(t->g3h, s16q, 3 * H, l.WqkvT, m->qkv_w[i], tmp, H, nullptr, (int)BT, H, 3 * H, s)) return e;
         float* dg1 = G(b + "/layer_norm/gamma");
@@ -821,9 +835,13 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
                                 bo_done ? nullptr : G(b + "/attention/out_proj/bias"), s, (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h))
             return e;
         float* dctx = tmp2;   // dt2 is dead
-        if (int e = gemm_dx(d_o, s16h, H, l.WoT, m->P(b + "/attention/out_proj/kernel"), dctx, H, nullptr, (int)BT, H, H, s)) return e;
+        // (the bf16 attention backward reads dctx and q | k | v as bf16: the GEMM leaves the dctx shadow, the forward left qkv16)
+        uint16_t* const dctx16 = (s16q && dx_shadowed(m->P(b + "/attention/out_proj/kernel"))) ? t->dy16_ctx : nullptr;
+        if (int e = gemm_dx(d_o, s16h, H, l.WoT, m->P(b + "/attention/out_proj/kernel"), dctx, H, nullptr, (int)BT, H, H, s, dctx16)) return e;
         AttnTrain tr{p, seed, layer_stream(i, 0), l.lse};
-        if (int e = launch_attention_bwd(pf, l.qkv, flen, l.ctx, dctx, t->g3h, t->dvec, B, T, H, c.num_heads, tr, s, s16q)) return e;
+        if (int e = launch_attention_bwd(pf, t->x16_attn ? nullptr : l.qkv, flen, l.ctx, dctx, t->g3h, t->dvec, B, T, H, c.num_heads, tr, s, s16q,
+                                         t->x16_attn ? l.qkv16 : nullptr, dctx16))
+            return e;
         if (int e = qkv_weight_grad(b, m->hs[i], m->hs16.size() > (size_t)i ? m->hs16[i] : nullptr)) return e;
         // dx = dqkv Wqkv^T + dt1 (residual)
         if (int e = gemm_dx(t->g3h, s16q, 3 * H, l.WqkvT, m->qkv_w[i], dh, H, dt1, (int)BT, H, 3 * H, s)) return e;
