@@ -64,6 +64,14 @@ __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast
 // 16-byte-slot swizzle of a row-major 128-byte-row image (see the header)
 __device__ __forceinline__ int swz(int row) { return 4 * ((row >> 1) & 1) + ((row >> 2) & 3); }
 
+// Keep-bit words of the attention-probability dropout (AttnTrain::keep_bits): word [bh][key tile][lh][query], query padded
+// to whole 128-row blocks (Tq = 128 nqb), key tiles padded to Tq / 64; bit 16 kt + r of the word of (query q, key tile, lh) is
+// the decision for key  64 tile + 32 kt + (r & 3) + 8 (r >> 2) + 4 lh  -- the forward lane's accumulator register order.
+__device__ __forceinline__ int64_t keep_word(int bh, int tile, int lh, int nqb) {
+    const int Tq = nqb * NW * 32;
+    return (((int64_t)bh * (Tq / KT) + tile) * 2 + lh) * Tq;
+}
+
 // blockIdx -> work item such that one XCD (blockIdx % 8) walks consecutive items: the row blocks of one (sample, head)
 __device__ __forceinline__ int xcd_work(int bid, int nwork) {
     const int q = nwork >> 3, r = nwork & 7, xcd = bid & 7, idx = bid >> 3;
@@ -227,13 +235,17 @@ __global__ __launch_bounds__(NW * 64, 3) void attention_bf16_kernel(Attn16Args a
             // attention-probability dropout (encoder.py:42-44): the row sum above uses the un-dropped p; the
             // 1 / (1 - p) factor is applied once, with the final normalisation
             const uint32_t cbase = drop_row + (uint32_t)k0;
+            uint32_t bits = 0;                  // bit 16 kt + r = the keep decision of accumulator register r of sub-tile kt
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const uint32_t col = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    s[kt][r] = dropout_keep32(drop_key, cbase + col, drop_thr) ? s[kt][r] : 0.f;
+                    const bool keep = dropout_keep32(drop_key, cbase + col, drop_thr);
+                    s[kt][r] = keep ? s[kt][r] : 0.f;
+                    bits |= keep ? (1u << (16 * kt + r)) : 0u;
                 }
+            if (tr.keep_bits) tr.keep_bits[keep_word(bh, tile, lh, a.nqb) + q0 + li] = bits;
         }
 #pragma unroll
         for (int d = 0; d < 2; ++d)
@@ -301,6 +313,7 @@ struct Attn16BwdArgs {
 };
 
 // ---- dQ: block = 4 waves x 32 queries; streams 64-key tiles of K and V ----
+template <bool BITS>       // BITS: the forward left its keep decisions in tr.keep_bits (p > 0)
 __global__ __launch_bounds__(256, 3) void attention_bf16_bwd_dq_kernel(Attn16BwdArgs a, AttnTrain tr) {
     constexpr int STAGE = 2 * IMG;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_a16[];
@@ -347,6 +360,8 @@ __global__ __launch_bounds__(256, 3) void attention_bf16_bwd_dq_kernel(Attn16Bwd
     for (int tile = 0; tile < ntiles; ++tile) {
         const int k0 = tile * KT, buf = tile & 1;
         if (tile + 1 < ntiles) issue(tile + 1, buf ^ 1);
+        uint32_t bits = 0;
+        if (BITS) bits = tr.keep_bits[keep_word(bh, tile, lh, a.nqb) + q0 + li];     // (lands under the first MFMAs)
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char* Ks = smem_a16 + buf * STAGE;
         const unsigned char* Vs = Ks + IMG;
@@ -376,7 +391,8 @@ __global__ __launch_bounds__(256, 3) void attention_bf16_bwd_dq_kernel(Attn16Bwd
             for (int r = 0; r < 16; ++r) {
                 const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], C2, nlse));
                 float g = dp[r];
-                if (tr.p > 0.f) g = dropout_keep32(drop_key, cbase + (uint32_t)((r & 3) + 8 * (r >> 2)), drop_thr) ? g : 0.f;
+                if (BITS) g = (bits & (1u << (16 * kt + r))) ? g : 0.f;
+                else if (tr.p > 0.f) g = dropout_keep32(drop_key, cbase + (uint32_t)((r & 3) + 8 * (r >> 2)), drop_thr) ? g : 0.f;
                 s[r] = pv * fmaf(g, inv, -dv);
             }
             // dQ^T[d][q] += sum_key K^T[d][key] dS^T[key][q]
@@ -407,8 +423,9 @@ __global__ __launch_bounds__(256, 3) void attention_bf16_bwd_dq_kernel(Attn16Bwd
 }
 
 // ---- dK, dV: block = 4 waves x 32 keys; streams 64-query tiles of Q and dO (+ lse, D as two 64-float rows) ----
+template <bool BITS>
 __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16BwdArgs a, AttnTrain tr) {
-    constexpr int STAGE = 2 * IMG + 2 * KT * 4;
+    constexpr int STAGE = 2 * IMG + 2 * KT * 4 + (BITS ? NW * 2 * KT * 4 : 0);      // Q, dO images; lse, D; per wave: 2 x 64 keep words
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_a16[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int work = xcd_work(blockIdx.x, a.nwork);
@@ -426,6 +443,11 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
     const bool kok = key < a.T;
     const float kmask = key >= flen ? -10000.0f * LOG2E : 0.0f;      // the key's mask bias, in exponent units
     const uint32_t drop_key = dropout_key(tr.seed, tr.stream), drop_thr = dropout_threshold(tr.p);
+    // keep words (BITS): this wave's 32 keys are sub-tile kt = (c0 / 32) & 1 of key tile c0 / 64; lane li's key is register
+    // (li & 3) + 4 (li >> 3) of the forward lane half (li >> 2) & 1
+    const int Tq = a.nqb * NW * 32;
+    const uint32_t* __restrict__ kbits = BITS ? tr.keep_bits + keep_word(bh, c0 / KT, 0, a.nqb) : nullptr;
+    const int kb_half = (li >> 2) & 1, kb_bit = 16 * ((c0 >> 5) & 1) + (li & 3) + 4 * (li >> 3);
 
     TileDma dma;
     dma.init(wave, lane);
@@ -439,6 +461,13 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
             const float* src = (wave == 0 ? lsebase : dvbase) + min(tile * KT + lane, a.T - 1);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(S + 2 * IMG + wave * KT * 4), 4, 0, 0);
+        }
+        if (BITS) {             // the keep words of (these 64 queries) x (this wave's key tile), both halves lh
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbits + f * Tq + tile * KT + lane),
+                                                 (__attribute__((address_space(3))) void*)(S + 2 * IMG + 2 * KT * 4 + (2 * wave + f) * KT * 4), 4,
+                                                 0, 0);
         }
     };
     issue(0, 0);
@@ -465,6 +494,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
         const unsigned char* Qs = smem_a16 + buf * STAGE;
         const unsigned char* Os = Qs + IMG;
         const float* Ls = reinterpret_cast<const float*>(Qs + 2 * IMG);      // [0, KT): lse, [KT, 2KT): D
+        const uint32_t* Ws = reinterpret_cast<const uint32_t*>(Qs + 2 * IMG + 2 * KT * 4) + (2 * wave + kb_half) * KT;
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             f32x16 s, dp;
@@ -487,8 +517,9 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
                 float pv = __builtin_amdgcn_exp2f(fmaf(Ls[ql], -LOG2E, fmaf(s[r], C2, kmask)));
                 if (qtail) pv = t0 + ql < a.T ? pv : 0.f;
                 float g = dp[r], pd = pv;
-                if (tr.p > 0.f) {
-                    const bool keep = dropout_keep32(drop_key, didx + (uint32_t)((r & 3) + 8 * (r >> 2)) * (uint32_t)a.T, drop_thr);
+                if (BITS || tr.p > 0.f) {
+                    const bool keep = BITS ? ((Ws[ql] >> kb_bit) & 1u) != 0u
+                                           : dropout_keep32(drop_key, didx + (uint32_t)((r & 3) + 8 * (r >> 2)) * (uint32_t)a.T, drop_thr);
                     g = keep ? g : 0.f;
                     pd = keep ? pv * inv : 0.f;
                 }
@@ -549,6 +580,11 @@ int shadow_or_scratch(const float* x, const uint16_t* x16, int64_t n, int slot, 
 
 bool attention_bf16_supported(int head_size) { return head_size == DH; }
 
+int64_t attention_keep_bits_words(int B, int T, int heads) {
+    const int64_t Tq = (int64_t)((T + NW * 32 - 1) / (NW * 32)) * NW * 32;
+    return (int64_t)B * heads * (Tq / KT) * 2 * Tq;
+}
+
 // tr == nullptr: inference.  Otherwise the training forward (dropout on P, lse saved).
 // qkv16: the bf16 shadow of qkv (null: made here from the fp32 tensor).  ctx or ctx16 may be null (not both).
 int launch_attention_fwd_bf16(const float* qkv, const uint16_t* qkv16, const int32_t* frame_len, float* ctx, uint16_t* ctx16, int B,
@@ -587,10 +623,16 @@ int launch_attention_bwd_bf16(const float* qkv, const uint16_t* qkv16, const int
                  "attention_bwd_bf16: unaligned operand");
     const int nqb = (T + NW * 32 - 1) / (NW * 32);
     Attn16BwdArgs a{q16, frame_len, do16, dvec, dqkv, dqkv16, B, T, H, heads, nqb, nqb * heads * B};
-    const size_t lds_q = 2 * 2 * IMG, lds_kv = 2 * (2 * IMG + 2 * KT * 4);
+    const bool bits = tr.keep_bits && tr.p > 0.f;
+    const size_t lds_q = 2 * 2 * IMG, lds_kv = 2 * (2 * IMG + 2 * KT * 4 + (bits ? NW * 2 * KT * 4 : 0));
     dim3 grid(a.nwork), block(256);
-    hipLaunchKernelGGL(attention_bf16_bwd_dq_kernel, grid, block, lds_q, s, a, tr);
-    hipLaunchKernelGGL(attention_bf16_bwd_dkv_kernel, grid, block, lds_kv, s, a, tr);
+    if (bits) {
+        hipLaunchKernelGGL(attention_bf16_bwd_dq_kernel<true>, grid, block, lds_q, s, a, tr);
+        hipLaunchKernelGGL(attention_bf16_bwd_dkv_kernel<true>, grid, block, lds_kv, s, a, tr);
+    } else {
+        hipLaunchKernelGGL(attention_bf16_bwd_dq_kernel<false>, grid, block, lds_q, s, a, tr);
+        hipLaunchKernelGGL(attention_bf16_bwd_dkv_kernel<false>, grid, block, lds_kv, s, a, tr);
+    }
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }

@@ -665,7 +665,7 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
                        int64_t strideB, float* C, int64_t ldc, int64_t strideC, const float* bias,
                        const float* residual, int M, int N, int K, int nbatch, int act, const GemmShadows& x,
                        hipStream_t s) {
-    W2V2_REQUIRE((A || x.A16) && (B || x.B16) && (C || x.C16), "gemm_bf16: null operand");
+    W2V2_REQUIRE((A || x.A16) && (B || x.B16 || x.B16p) && (C || x.C16), "gemm_bf16: null operand");
     W2V2_REQUIRE(M > 0 && N > 0 && K > 0 && nbatch > 0, "gemm_bf16: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, nbatch);
     W2V2_REQUIRE(lda >= 1 && ldb >= N && ldc >= N && ldc < (1 << 23), "gemm_bf16: bad leading dimensions");
     static int dma = -1;
@@ -692,18 +692,19 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
     // 2 = LDS-DMA 4-stage ring with three tiles in flight, 1 block/CU (513: deeper prefetch does not pay for half the waves)
     if (dma < 0) { const char* e = getenv("W2V2_GEMM16_DMA"); dma = e ? atoi(e) : 1; }
     if (x.transA) {
-        W2V2_REQUIRE(A && kfast && b32 && (M % 4 == 0) && (lda % 4 == 0) && (strideA % 4 == 0) &&
-                         ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda >= M || x.overlapA),
-                     "gemm_bf16: transposed A needs fp32 A and B, K %% 64 == 0, M %% 4 == 0 and 16-byte alignment");
-        src = 7;
-        // both bf16 shadows, whole 128 x 128 tiles, 16-byte aligned rows: LDS-DMA + transposing LDS reads
+        // both bf16 shadows, whole 128 x 128 tiles, 16-byte aligned rows: LDS-DMA + transposing LDS reads (the fp32 operands are
+        // not touched and may be null)
         static int tr = -1;
         if (tr < 0) { const char* e = getenv("W2V2_GEMM16_TR"); tr = e ? atoi(e) : 1; }      // tuning knob
-        if (tr && x.A16 && x.B16p && !x.colsum && !x.overlapA && M % 128 == 0 && N % 128 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
+        if (tr && kfast && C && x.A16 && x.B16p && !x.colsum && !x.overlapA && M % 128 == 0 && N % 128 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
             strideA % 8 == 0 && strideB % 8 == 0 && ((reinterpret_cast<uintptr_t>(x.A16) | reinterpret_cast<uintptr_t>(x.B16p)) & 15) == 0) {
             ProfScope ps(prof, FAM_GEMM_BF16, 2.0 * M * (double)N * K * nbatch, nbatch * (2.0 * K * ((double)M + N) + 4.0 * (double)M * N), s);
             return launch_tr16(g, nbatch, s);
         }
+        W2V2_REQUIRE(A && kfast && b32 && (M % 4 == 0) && (lda % 4 == 0) && (strideA % 4 == 0) &&
+                         ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda >= M || x.overlapA),
+                     "gemm_bf16: transposed A needs fp32 A and B, K %% 64 == 0, M %% 4 == 0 and 16-byte alignment");
+        src = 7;
     } else if (a16 && b16) src = dma == 2 ? 6 : (dma ? 5 : 4);
     else if (a16 && b32) src = 2;
     else if (b16 && a32) src = 3;

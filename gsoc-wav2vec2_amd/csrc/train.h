@@ -78,6 +78,8 @@ int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float l
                 float eps, hipStream_t s);
 int launch_spec_aug_fwd(const float* x, const uint8_t* mask, const float* embed, float* y, int64_t rows, int H, hipStream_t s);
 int launch_spec_aug_bwd(const float* dy, const uint8_t* mask, float* dx, float* dmasked, int64_t rows, int H, hipStream_t s);
+// dst (Kin, Nout) = A16[R rows]^T B16[R rows], bf16 operands, fp32 accumulate: the leftover rows of a weight gradient
+int launch_dw_tail_bf16(const uint16_t* A16, int64_t lda, const uint16_t* B16, int64_t ldb, float* dst, int R, int Kin, int Nout, hipStream_t s);
 int launch_axpby(const float* a, const float* b, float* y, int64_t n, float alpha, float beta, hipStream_t s);
 int launch_axpby_x(const float* a, const float* b, float* y, uint16_t* y16 /* optional bf16 shadow */, int64_t n, float alpha, float beta,
                    hipStream_t s);
@@ -89,7 +91,12 @@ struct AttnTrain {
     uint64_t seed;
     uint32_t stream;
     float* lse;        // (B, heads, T) log-sum-exp of the (masked) scores, written by forward, read by backward
+    // optional (bf16 kernels, p > 0): the keep decisions of the forward, one bit per (query, key), so that the backward kernels
+    // read them instead of hashing every element twice more.  attention_keep_bits_words(B, T, heads) 32-bit words; layout in
+    // attention_bf16.hip.  Null: the backward recomputes the hash (same bits).
+    uint32_t* keep_bits = nullptr;
 };
+int64_t attention_keep_bits_words(int B, int T, int heads);
 // bf16 matrix-pipe attention (attention_bf16.hip); taken by launch_attention* while the thread's precision is 1
 bool attention_bf16_supported(int head_size);
 // (the kernels read bf16 shadows of qkv / dctx; a null shadow is made from the fp32 tensor in per-stream scratch)

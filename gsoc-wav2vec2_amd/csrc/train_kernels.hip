@@ -57,7 +57,7 @@ __global__ void dropout_fwd_kernel(const float* __restrict__ x, const float* __r
                 const float4 r = reinterpret_cast<const float4*>(res)[i];
                 v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
             }
-            reinterpret_cast<float4*>(y)[i] = make_float4(v[0], v[1], v[2], v[3]);
+            if (y) reinterpret_cast<float4*>(y)[i] = make_float4(v[0], v[1], v[2], v[3]);
             if (y16) reinterpret_cast<uint2*>(y16)[i] = make_uint2(pack_bf16_rne(v[0], v[1]), pack_bf16_rne(v[2], v[3]));
         }
     } else {
@@ -65,7 +65,7 @@ __global__ void dropout_fwd_kernel(const float* __restrict__ x, const float* __r
             float v = apply_act(x[i], act);
             if (p > 0.f) v = dropout_keep32(key, (uint32_t)i, thr) ? v * inv : 0.0f;
             v = res ? v + res[i] : v;
-            y[i] = v;
+            if (y) y[i] = v;
             if (y16) y16[i] = (uint16_t)pack_bf16_rne(v, 0.f);
         }
     }
@@ -91,7 +91,7 @@ __global__ void dropout_bwd_kernel(const float* __restrict__ u, const float* __r
                 const float4 uv = reinterpret_cast<const float4*>(u)[i];
                 g[0] *= gelu_grad(uv.x, act); g[1] *= gelu_grad(uv.y, act); g[2] *= gelu_grad(uv.z, act); g[3] *= gelu_grad(uv.w, act);
             }
-            reinterpret_cast<float4*>(dx)[i] = make_float4(g[0], g[1], g[2], g[3]);
+            if (dx) reinterpret_cast<float4*>(dx)[i] = make_float4(g[0], g[1], g[2], g[3]);
             if (dx16) reinterpret_cast<uint2*>(dx16)[i] = make_uint2(pack_bf16_rne(g[0], g[1]), pack_bf16_rne(g[2], g[3]));
         }
     } else {
@@ -99,7 +99,7 @@ __global__ void dropout_bwd_kernel(const float* __restrict__ u, const float* __r
             float g = dy[i];
             if (p > 0.f) g = dropout_keep32(key, (uint32_t)i, thr) ? g * inv : 0.0f;
             if (act) g *= gelu_grad(u[i], act);
-            dx[i] = g;
+            if (dx) dx[i] = g;
             if (dx16) dx16[i] = (uint16_t)pack_bf16_rne(g, 0.f);
         }
     }
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void dropout_bwd_colsum_kernel(const float* __
                 const float4 uv = *reinterpret_cast<const float4*>(u + i);
                 g[0] *= gelu_grad(uv.x, act); g[1] *= gelu_grad(uv.y, act); g[2] *= gelu_grad(uv.z, act); g[3] *= gelu_grad(uv.w, act);
             }
-            *reinterpret_cast<float4*>(dx + i) = make_float4(g[0], g[1], g[2], g[3]);
+            if (dx) *reinterpret_cast<float4*>(dx + i) = make_float4(g[0], g[1], g[2], g[3]);
             if (dx16) *reinterpret_cast<uint2*>(dx16 + i) = make_uint2(pack_bf16_rne(g[0], g[1]), pack_bf16_rne(g[2], g[3]));
             acc.x += g[0]; acc.y += g[1]; acc.z += g[2]; acc.w += g[3];
         }
@@ -147,6 +147,27 @@ __global__ __launch_bounds__(256) void dropout_bwd_colsum_kernel(const float* __
             make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z),
                         (p0.w + p1.w) + (p2.w + p3.w));
     }
+}
+
+// dst (Kin, Nout) = A16^T B16 over a FEW rows (the rows a weight gradient's fast slabs leave over): bf16 operands (exact
+// products), fp32 accumulation in row order.  Thread = one output column n and 8 consecutive output rows k.
+__global__ __launch_bounds__(256) void dw_tail_bf16_kernel(const uint16_t* __restrict__ A16, int64_t lda, const uint16_t* __restrict__ B16,
+                                                           int64_t ldb, float* __restrict__ dst, int R, int Kin, int Nout) {
+    const int n = blockIdx.x * 256 + threadIdx.x, k0 = blockIdx.y * 8;
+    if (n >= Nout) return;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < R; ++r) {
+        const float b = __uint_as_float((uint32_t)B16[(int64_t)r * ldb + n] << 16);
+        const uint4 av = *reinterpret_cast<const uint4*>(A16 + (int64_t)r * lda + k0);       // block-uniform: 8 bf16
+        const uint32_t aw[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[2 * j] = fmaf(__uint_as_float(aw[j] << 16), b, acc[2 * j]);
+            acc[2 * j + 1] = fmaf(__uint_as_float(aw[j] & 0xFFFF0000u), b, acc[2 * j + 1]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dst[(int64_t)(k0 + j) * Nout + n] = acc[j];
 }
 
 // batched transpose: y[b][c][r] = x[b][r][c]
@@ -492,7 +513,7 @@ int launch_dropout_fwd(const float* x, const float* res, float* y, int64_t n, in
 
 int launch_dropout_fwd_x(const float* x, const float* res, float* y, uint16_t* y16, int64_t n, int act, float p,
                          uint64_t seed, uint32_t stream_id, hipStream_t s) {
-    W2V2_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, "dropout_fwd: bad argument");
+    W2V2_REQUIRE(x && (y || y16) && n > 0 && p >= 0.f && p < 1.f, "dropout_fwd: bad argument");      // (y may be null: bf16 result only)
     const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res)) & 15) == 0 &&
                      (reinterpret_cast<uintptr_t>(y16) & 7) == 0;
     if (vec)
@@ -510,13 +531,21 @@ int launch_dropout_bwd(const float* u, const float* dy, float* dx, int64_t n, in
 
 int launch_dropout_bwd_x(const float* u, const float* dy, float* dx, uint16_t* dx16, int64_t n, int act, float p,
                          uint64_t seed, uint32_t stream_id, hipStream_t s) {
-    W2V2_REQUIRE(dy && dx && n > 0 && p >= 0.f && p < 1.f && (act == 0 || u), "dropout_bwd: bad argument");
+    W2V2_REQUIRE(dy && (dx || dx16) && n > 0 && p >= 0.f && p < 1.f && (act == 0 || u), "dropout_bwd: bad argument");   // (dx may be null)
     const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0 &&
                      (reinterpret_cast<uintptr_t>(dx16) & 7) == 0;
     if (vec)
         hipLaunchKernelGGL(dropout_bwd_kernel<true>, dim3(ew_grid(n >> 2)), dim3(EW_THREADS), 0, s, u, dy, dx, dx16, n, act, p, seed, stream_id);
     else
         hipLaunchKernelGGL(dropout_bwd_kernel<false>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, s, u, dy, dx, dx16, n, act, p, seed, stream_id);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
+int launch_dw_tail_bf16(const uint16_t* A16, int64_t lda, const uint16_t* B16, int64_t ldb, float* dst, int R, int Kin, int Nout, hipStream_t s) {
+    W2V2_REQUIRE(A16 && B16 && dst && R > 0 && Kin > 0 && Nout > 0 && Kin % 8 == 0 && lda % 8 == 0 && (reinterpret_cast<uintptr_t>(A16) & 15) == 0,
+                 "dw_tail_bf16: bad argument");
+    hipLaunchKernelGGL(dw_tail_bf16_kernel, dim3((Nout + 255) / 256, Kin / 8), dim3(256), 0, s, A16, lda, B16, ldb, dst, R, Kin, Nout);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -564,11 +593,12 @@ int launch_colsum(const float* x, float* out, int64_t rows, int cols, float* ws,
 // the tensors do not allow 16-byte accesses.
 int launch_dropout_bwd_colsum(const float* u, const float* dy, float* dx, uint16_t* dx16, float* colsum, int64_t rows, int cols,
                               int act, float p, uint64_t seed, uint32_t stream_id, float* ws, hipStream_t s) {
-    W2V2_REQUIRE(dy && dx && colsum && ws && rows > 0 && cols > 0 && p >= 0.f && p < 1.f && (act == 0 || u), "dropout_bwd_colsum: bad argument");
+    W2V2_REQUIRE(dy && (dx || dx16) && colsum && ws && rows > 0 && cols > 0 && p >= 0.f && p < 1.f && (act == 0 || u), "dropout_bwd_colsum: bad argument");
     const bool vec = (cols & 3) == 0 && ((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) |
                                            reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(colsum)) & 15) == 0 &&
                      (reinterpret_cast<uintptr_t>(dx16) & 7) == 0;
     if (!vec) {
+        W2V2_REQUIRE(dx, "dropout_bwd_colsum: a bf16-only result needs cols %% 4 == 0 and 16-byte aligned tensors");
         if (int e = launch_dropout_bwd_x(u, dy, dx, dx16, rows * cols, act, p, seed, stream_id, s)) return e;
         return launch_colsum(dx, colsum, rows, cols, ws, 0, s);
     }

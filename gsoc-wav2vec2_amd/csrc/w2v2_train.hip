@@ -30,6 +30,7 @@ struct LayerSave {
     // precision mode 1: bf16 shadows of the activations the weight-gradient GEMMs contract with (dW = X^T dY reads X as a
     // transposed A).  Written by the forward's producers like the shared shadows, but kept per layer until the backward.
     uint16_t *a16 = nullptr, *ctx16 = nullptr, *t2_16 = nullptr, *gd16 = nullptr, *qkv16 = nullptr;
+    uint32_t* keep_bits = nullptr;       // attention-probability dropout decisions of the forward (bf16 attention kernels)
 };
 
 struct TrainState {
@@ -68,6 +69,7 @@ struct TrainState {
     float* cs_ws = nullptr;           // (slabs + 1, widest N): per-slab column sums of dY from the weight-gradient GEMM
     int64_t cs_floats = 0;
     bool forward_done = false;
+    bool ffn16_only = false;                      // the last forward wrote dropout(GELU(u)) only as bf16 (no fp32 l.gd)
     bool x16_valid = false, x16_attn = false;     // the last forward wrote the per-layer bf16 shadows (/ ctx16 from the bf16 attention)
     // gradient buckets for overlapping the data-parallel all-reduce with the backward: completion order
     //   0 = lm_head, 1 .. N = encoder layers N-1 .. 0, N+1 = everything in front of layer 0 in the flat buffer
@@ -215,6 +217,11 @@ static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
             l.t2_16 = l.ctx16 + up8(BT * H);
             l.gd16 = l.t2_16 + up8(BT * H);
             l.qkv16 = l.gd16 + up8(BT * F);          // q | k | v as the bf16 attention kernels read it
+            float* kb = nullptr;
+            if (attention_bf16_supported((int)(H / c.num_heads))) {
+                if (int e = t_alloc(t, &kb, attention_keep_bits_words(B, T, c.num_heads))) return e;
+            }
+            l.keep_bits = reinterpret_cast<uint32_t*>(kb);
         }
     }
     for (int i = 0; i < 4; ++i)
@@ -335,13 +342,15 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
         W2V2_REQUIRE(nslabs == 1 || (int64_t)(nslabs + 1) * Kin * Nout <= t->slab_floats, "weight_grad: slab scratch too small");
         float* dst = nslabs == 1 ? dW : t->slabs;
         const int Kp = S ? Mq / S : 0;
+        // both bf16 shadows and whole 128 x 128 tiles: the LDS-DMA + transposing-read kernel; it has no fp32 dY in registers,
+        // so the bias gradient (a sum of the UNROUNDED dY) takes the column-sum pass below instead of riding along.  In this form
+        // the fp32 A / dY are not read at all (callers may pass null when nothing else needs them).
+        const bool tr_form = direct && A16 && dY16 && Kin % 128 == 0 && Nout % 128 == 0;
+        W2V2_REQUIRE(tr_form || (A && dY), "weight_grad: the fp32 operands are needed here (no bf16 shadows / shapes not whole 128-tiles)");
         if (S) {
             if (direct) {
                 GemmShadows x;
                 x.transA = true;
-                // both bf16 shadows and whole 128 x 128 tiles: the LDS-DMA + transposing-read kernel; it has no fp32 dY in registers,
-                // so the bias gradient (a sum of the UNROUNDED dY) takes the column-sum pass below instead of riding along
-                const bool tr_form = A16 && dY16 && Kin % 128 == 0 && Nout % 128 == 0;
                 if (tr_form) { x.A16 = A16; x.B16p = dY16; }
                 // otherwise the bias gradient rides along: the kernel's row-tile-0 blocks sum the dY columns they stage anyway
                 fused_bias = !tr_form && db != nullptr && (int64_t)(nslabs + 1) * Nout <= t->cs_floats;
@@ -356,7 +365,11 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
                     return e;
             }
         }
-        if (R) {                                 // leftover rows [Mq, M): transposed copy (Kin, R), guarded kernel, slab S
+        if (R && tr_form) {                      // leftover rows [Mq, M) from the same shadows
+            if (int e = launch_dw_tail_bf16(A16 + (int64_t)Mq * Kin, Kin, dY16 + (int64_t)Mq * Nout, Nout, dst + (int64_t)S * Kin * Nout, R, Kin,
+                                            Nout, s))
+                return e;
+        } else if (R) {                          // leftover rows [Mq, M): transposed copy (Kin, R), guarded kernel, slab S
             float* atr = t->at + (int64_t)Kin * Mq;
             if (int e = launch_transpose(A + (int64_t)Mq * Kin, atr, R, Kin, 1, s)) return e;
             if (int e = launch_gemm_ex(m->prof, atr, R, 0, dY + (int64_t)Mq * Nout, Nout, 0, dst + (int64_t)S * Kin * Nout, Nout, 0,
@@ -373,8 +386,10 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
             if (int e = launch_colsum(t->cs_ws, db, nslabs, Nout, t->red_ws, 0, s)) return e;
         }
     }
-    if (db && !fused_bias)
+    if (db && !fused_bias) {
+        W2V2_REQUIRE(dY, "weight_grad: the bias gradient needs the fp32 dY");
         if (int e = launch_colsum(dY, db, M, Nout, t->red_ws, 0, s)) return e;
+    }
     return W2V2_OK;
 }
 
@@ -525,6 +540,10 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
         // postnorm: layer 0's q|k|v GEMM reads this tensor -> shadow
         if (int e = launch_dropout_fwd_x(pre, nullptr, h0, (sh && !prenorm) ? m->hs16[0] : nullptr, BT * H, 0, p, seed, DS_ENCODER_IN, s)) return e;
     }
+    // FFN hidden activations as bf16 only: needs the shadow paths on both sides (forward GEMM by LDS-DMA, weight gradient in
+    // the transposing-read form, whole 128-tiles) and the plain bf16 copies of the FFN kernels for the data gradients
+    const bool ffn16_only = sh && m->w16_valid && F % 128 == 0 && H % 128 == 0 && (BT * F) % 4 == 0 && !m->w16p.empty();
+    t->ffn16_only = ffn16_only;
     for (int i = 0; i < c.num_layers; ++i) {
         const std::string b = "encoder/layers/" + std::to_string(i);
         LayerSave& l = t->layers[i];
@@ -543,7 +562,7 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
         if (int e = gemm(attn_in, attn_in16, H, 0, m->qkv_w[i], 3 * H, attn16 ? nullptr : l.qkv, attn16 ? l.qkv16 : nullptr, 3 * H, 0, m->qkv_b[i],
                          nullptr, (int)BT, 3 * H, H, 1, 0))
             return e;
-        AttnTrain tr{p, seed, layer_stream(i, 0), l.lse};
+        AttnTrain tr{p, seed, layer_stream(i, 0), l.lse, attn16 ? l.keep_bits : nullptr};
         if (int e = launch_attention_train_x(pf, attn16 ? nullptr : l.qkv, attn16 ? l.qkv16 : nullptr, flen, l.ctx, attn16 ? l.ctx16 : nullptr, B, T,
                                              H, c.num_heads, tr, s))
             return e;
@@ -562,8 +581,9 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
             if (int e = gemm(l.t2, S16(l.t2_16), H, 0, m->P(b + "/feed_forward/intermediate_dense/kernel"), F, l.u, nullptr, F, 0,
                              m->P(b + "/feed_forward/intermediate_dense/bias"), nullptr, (int)BT, F, H, 1, 0))
                 return e;
-            if (int e = launch_dropout_fwd_x(l.u, nullptr, l.gd, S16(l.gd16), BT * F, act, p, seed, layer_stream(i, 2), s)) return e;
-            if (int e = gemm(l.gd, S16(l.gd16), F, 0, m->P(b + "/feed_forward/output_dense/kernel"), H, ffn_out, nullptr, H, 0,
+            // (ffn16_only: every reader of gd -- this GEMM, and the down-projection's weight gradient -- streams the bf16 shadow)
+            if (int e = launch_dropout_fwd_x(l.u, nullptr, ffn16_only ? nullptr : l.gd, S16(l.gd16), BT * F, act, p, seed, layer_stream(i, 2), s)) return e;
+            if (int e = gemm(ffn16_only ? nullptr : l.gd, S16(l.gd16), F, 0, m->P(b + "/feed_forward/output_dense/kernel"), H, ffn_out, nullptr, H, 0,
                              m->P(b + "/feed_forward/output_dense/bias"), ffn_res, (int)BT, H, F, 1, 0))
                 return e;
         } else {
@@ -640,6 +660,10 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     uint16_t* const s16f = shb ? t->dy16_f : nullptr;
     uint16_t* const s16q = (shb && attention_bf16_supported(dhead)) ? t->dy16_3h : nullptr;
     const bool xs = shb && t->x16_valid;             // X shadows of the forward are there for the weight-gradient GEMMs
+    // the forward kept the FFN hidden activations only as bf16: the backward must then run entirely on the shadow paths
+    const bool f16 = t->ffn16_only;
+    W2V2_REQUIRE(!f16 || (xs && t->dy16_f && t->dy16_h), "train_backward: the forward ran with bf16 shadows (FFN activations kept as bf16 only); "
+                                                      "precision / W2V2_BF16_SHADOWS must not change before the backward");
     for (size_t i = 0; i < m->params.size(); ++i)
         if (t->trainable[i] && m->params[i].name.compare(0, 18, "feature_extractor/") == 0) {
             set_error("train_backward: `%s` is trainable, but the conv feature extractor has no backward "
@@ -734,6 +758,11 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     };
 
     bool dh16_valid = false;
+    if (prenorm && s16h && (BT * H) % 4 == 0 && (reinterpret_cast<uintptr_t>(dh) & 15) == 0) {
+        // the last layer's output gradient arrives in fp32 only: round it once so that its down-projection GEMMs stream shadows too
+        if (int e = launch_to_bf16(dh, s16h, BT * H, s)) return e;
+        dh16_valid = true;
+    }
     for (int i = c.num_layers - 1; i >= 0 && prenorm; --i) {
         // prenorm layer (encoder.py:111-134):  t1 = x + drop(attn(LN1(x)));  out = t1 + keep * FFN(LN2(t1))
         const std::string b = "encoder/layers/" + std::to_string(i);
@@ -743,16 +772,21 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         // dh's bf16 shadow (written by the previous iteration's closing axpby into s16h, which is free again by then)
         const uint16_t* dh16 = dh16_valid ? s16h : nullptr;
         if (l.keep != 0.f) {
-            if (int e = weight_grad(m, l.gd, dh, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
+            W2V2_REQUIRE(!f16 || dh16, "train_backward: no bf16 shadow of the layer's output gradient");
+            if (int e = weight_grad(m, f16 ? nullptr : l.gd, dh, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
                                     G(b + "/feed_forward/output_dense/bias"), s, (xs && dh16) ? l.gd16 : nullptr, dh16))
                 return e;
             if (int e = gemm_dx(dh, dh16, H, l.W2T, m->P(b + "/feed_forward/output_dense/kernel"), t->gf, F, nullptr, (int)BT, F, H, s)) return e;
             bool b1_done = false;
-            if (int e = dropout_bwd_bias(l.u, t->gf, t->gf, s16f, BT, F, act, layer_stream(i, 2), G(b + "/feed_forward/intermediate_dense/bias"), &b1_done)) return e;
-            if (int e = weight_grad(m, l.t2, t->gf, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
-                                    b1_done ? nullptr : G(b + "/feed_forward/intermediate_dense/bias"), s, xs ? l.t2_16 : nullptr, s16f))
+            float* const gb1 = G(b + "/feed_forward/intermediate_dense/bias");
+            // (f16: du is needed only as bf16 -- both consumers stream the shadow -- unless its fp32 column sums are still to be taken)
+            const bool du16_only = f16 && (!gb1 || shb) && dx_shadowed(m->P(b + "/feed_forward/intermediate_dense/kernel"));
+            float* const du = du16_only ? nullptr : t->gf;
+            if (int e = dropout_bwd_bias(l.u, t->gf, du, s16f, BT, F, act, layer_stream(i, 2), gb1, &b1_done)) return e;
+            if (int e = weight_grad(m, l.t2, du, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
+                                    b1_done ? nullptr : gb1, s, xs ? l.t2_16 : nullptr, s16f))
                 return e;
-            if (int e = gemm_dx(t->gf, s16f, F, l.W1T, m->P(b + "/feed_forward/intermediate_dense/kernel"), tmp, H, nullptr, (int)BT, H, F, s)) return e;
+            if (int e = gemm_dx(du, s16f, F, l.W1T, m->P(b + "/feed_forward/intermediate_dense/kernel"), tmp, H, nullptr, (int)BT, H, F, s)) return e;
             float* dg2 = G(b + "/final_layer_norm/gamma");
             float* db2 = G(b + "/final_layer_norm/beta");
             if (int e = launch_ln_bwd(l.t1, m->P(b + "/final_layer_norm/gamma"), tmp, tmp2, dg2 ? dg2 : t->dummy,
@@ -772,7 +806,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         // (the bf16 attention backward reads dctx and q | k | v as bf16: the GEMM leaves the dctx shadow, the forward left qkv16)
         uint16_t* const dctx16 = (s16q && dx_shadowed(m->P(b + "/attention/out_proj/kernel"))) ? t->dy16_ctx : nullptr;
         if (int e = gemm_dx(d_o, s16h, H, l.WoT, m->P(b + "/attention/out_proj/kernel"), dctx, H, nullptr, (int)BT, H, H, s, dctx16)) return e;
-        AttnTrain tr{p, seed, layer_stream(i, 0), l.lse};
+        AttnTrain tr{p, seed, layer_stream(i, 0), l.lse, t->x16_attn ? l.keep_bits : nullptr};
         if (int e = launch_attention_bwd(pf, t->x16_attn ? nullptr : l.qkv, flen, l.ctx, dctx, t->g3h, t->dvec, B, T, H, c.num_heads, tr, s, s16q,
                                          t->x16_attn ? l.qkv16 : nullptr, dctx16))
             return e;
@@ -805,18 +839,22 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         float* dt2 = tmp2;
         if (l.keep != 0.f) {
             // t3 = t2 + f,  f = gd W2 + b2
-            if (int e = weight_grad(m, l.gd, dt3, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
+            if (int e = weight_grad(m, f16 ? nullptr : l.gd, dt3, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
                                     gb2 ? nullptr : G(b + "/feed_forward/output_dense/bias"), s, xs ? l.gd16 : nullptr, H % 4 == 0 ? s16h : nullptr))
                 return e;
             if (int e = gemm_dx(dt3, H % 4 == 0 ? s16h : nullptr, H, l.W2T, m->P(b + "/feed_forward/output_dense/kernel"), t->gf, F, nullptr, (int)BT, F, H, s)) return e;
             // du = dgd * keep/(1-p) * GELU'(u)   (+ its column sums = the up-projection's bias gradient)
             bool b1_done = false;
-            if (int e = dropout_bwd_bias(l.u, t->gf, t->gf, s16f, BT, F, act, layer_stream(i, 2), G(b + "/feed_forward/intermediate_dense/bias"), &b1_done)) return e;
-            if (int e = weight_grad(m, l.t2, t->gf, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
-                                    b1_done ? nullptr : G(b + "/feed_forward/intermediate_dense/bias"), s, xs ? l.t2_16 : nullptr, s16f))
+            float* const gb1 = G(b + "/feed_forward/intermediate_dense/bias");
+            // (f16: du is needed only as bf16 -- both consumers stream the shadow, the column sums come from the producer)
+            const bool du16_only = f16 && (!gb1 || shb) && dx_shadowed(m->P(b + "/feed_forward/intermediate_dense/kernel"));
+            float* const du = du16_only ? nullptr : t->gf;
+            if (int e = dropout_bwd_bias(l.u, t->gf, du, s16f, BT, F, act, layer_stream(i, 2), gb1, &b1_done)) return e;
+            if (int e = weight_grad(m, l.t2, du, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
+                                    b1_done ? nullptr : gb1, s, xs ? l.t2_16 : nullptr, s16f))
                 return e;
             // dt2 = du W1^T + dt3 (the residual branch)
-            if (int e = gemm_dx(t->gf, s16f, F, l.W1T, m->P(b + "/feed_forward/intermediate_dense/kernel"), dt2, H, dt3, (int)BT, H, F, s)) return e;
+            if (int e = gemm_dx(du, s16f, F, l.W1T, m->P(b + "/feed_forward/intermediate_dense/kernel"), dt2, H, dt3, (int)BT, H, F, s)) return e;
         } else {
             W2V2_HIP_CHECK(hipMemcpyAsync(dt2, dt3, (size_t)BT * H * 4, hipMemcpyDeviceToDevice, s));
         }
@@ -838,7 +876,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         // (the bf16 attention backward reads dctx and q | k | v as bf16: the GEMM leaves the dctx shadow, the forward left qkv16)
         uint16_t* const dctx16 = (s16q && dx_shadowed(m->P(b + "/attention/out_proj/kernel"))) ? t->dy16_ctx : nullptr;
         if (int e = gemm_dx(d_o, s16h, H, l.WoT, m->P(b + "/attention/out_proj/kernel"), dctx, H, nullptr, (int)BT, H, H, s, dctx16)) return e;
-        AttnTrain tr{p, seed, layer_stream(i, 0), l.lse};
+        AttnTrain tr{p, seed, layer_stream(i, 0), l.lse, t->x16_attn ? l.keep_bits : nullptr};
         if (int e = launch_attention_bwd(pf, t->x16_attn ? nullptr : l.qkv, flen, l.ctx, dctx, t->g3h, t->dvec, B, T, H, c.num_heads, tr, s, s16q,
                                          t->x16_attn ? l.qkv16 : nullptr, dctx16))
             return e;
