@@ -693,16 +693,16 @@ int launch_attention_train_x(Profiler* prof, const float* qkv, const uint16_t* q
 
 int launch_attention_bwd(Profiler* prof, const float* qkv, const int32_t* frame_len, const float* ctx,
                          const float* dctx, float* dqkv, float* dvec_ws, int B, int T, int H, int heads,
-                         const AttnTrain& tr, hipStream_t s, uint16_t* dqkv16, const uint16_t* qkv16, const uint16_t* dctx16) {
-    W2V2_REQUIRE((qkv || qkv16) && ctx && dctx && dqkv && dvec_ws && tr.lse, "attention_bwd: null operand");
+                         const AttnTrain& tr, hipStream_t s, uint16_t* dqkv16, const uint16_t* qkv16, const uint16_t* dctx16, float* colpart) {
+    W2V2_REQUIRE((qkv || qkv16) && ctx && dctx && (dqkv || dqkv16) && dvec_ws && tr.lse, "attention_bwd: null operand");
     W2V2_REQUIRE(B > 0 && T > 0 && heads > 0 && H % heads == 0, "attention_bwd: bad sizes");
     const int dh = H / heads;
     ProfScope ps(prof, FAM_ATTENTION, 10.0 * B * (double)heads * T * (double)T * dh, 4.0 * B * (double)T * 8.0 * H, s);
     if (gemm_get_precision() == 1 && attention_bf16_supported(dh)) {
         hipLaunchKernelGGL(attn_dvec_kernel<64>, dim3((unsigned)((int64_t)B * T)), dim3(256), 0, s, ctx, dctx, dvec_ws, B, T, H, heads);
-        return launch_attention_bwd_bf16(qkv, qkv16, frame_len, dctx, dctx16, dvec_ws, dqkv, dqkv16, B, T, H, heads, tr, s);
+        return launch_attention_bwd_bf16(qkv, qkv16, frame_len, dctx, dctx16, dvec_ws, dqkv, dqkv16, B, T, H, heads, tr, s, colpart);
     }
-    W2V2_REQUIRE(qkv, "attention_bwd: the fp32 kernels need the fp32 qkv");
+    W2V2_REQUIRE(qkv && dqkv && !colpart, "attention_bwd: the fp32 kernels need the fp32 qkv / dqkv and leave no column sums");
     AttnBwdArgs a{qkv, frame_len, dctx, dvec_ws, dqkv, B, T, H, heads, 1.0f / sqrtf((float)dh)};
     W2V2_REQUIRE(!dqkv16, "attention_bwd: a bf16 shadow of dqkv is only written by the bf16 kernels (head size 64, precision mode 1)");
     switch (dh) {

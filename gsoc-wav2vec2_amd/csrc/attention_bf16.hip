@@ -306,11 +306,35 @@ struct Attn16BwdArgs {
     const int32_t* frame_len;
     const uint16_t* do16;   // (B, T, H) bf16 shadow of dO
     const float* dvec;      // (B, heads, T)
-    float* dqkv;            // (B, T, 3H)
+    float* dqkv;            // (B, T, 3H); may be null when dqkv16 is given
     uint16_t* dqkv16;       // optional bf16 shadow of dqkv (the A operand of the q|k|v data-gradient GEMM)
+    float* colpart;         // optional (B nqb, 3H): per-block column sums of dqkv over the block's valid rows (-> the q|k|v bias gradient)
     int B, T, H, heads;
     int nqb, nwork;
 };
+
+constexpr int COLSUM_LDS = (NW * 32 * 65 + NW * 64) * 4;       // block_colsum's LDS footprint (bytes)
+
+// out[d] (d < 64) = scale * sum over the block's valid rows of a [d][row] accumulator pair (row = lane li of each wave), in a fixed
+// order.  All threads of the block must call it; `lds` is free scratch (the tile stages, after the last barrier of the loop).
+__device__ __forceinline__ void block_colsum(const f32x16 (&acc)[2], bool row_ok, float scale, float* lds, int tid, float* out) {
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    float* W = lds + wave * (32 * 65) + li * 65 + 4 * lh;       // [row][d], rows padded to 65 floats: conflict-free both ways
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) W[32 * dt + (r & 3) + 8 * (r >> 2)] = row_ok ? acc[dt][r] * scale : 0.f;
+    __syncthreads();
+    const float* Wr = lds + wave * (32 * 65) + lane;             // thread (wave, d = lane): the wave's 32 rows of column d
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) sum += Wr[q * 65];
+    float* P2 = lds + NW * 32 * 65;
+    P2[tid] = sum;
+    __syncthreads();
+    if (tid < 64) out[tid] = (P2[tid] + P2[64 + tid]) + (P2[128 + tid] + P2[192 + tid]);
+    __syncthreads();
+}
 
 // ---- dQ: block = 4 waves x 32 queries; streams 64-key tiles of K and V ----
 template <bool BITS>       // BITS: the forward left its keep decisions in tr.keep_bits (p > 0)
@@ -409,17 +433,18 @@ __global__ __launch_bounds__(256, 3) void attention_bf16_bwd_dq_kernel(Attn16Bwd
     }
     if (qok) {
         const int64_t o0 = ((int64_t)b * a.T + q0 + li) * ld + head * DH + 4 * lh;
-        float* op = a.dqkv + o0;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 v = f32x4{dq[d][4 * g] * SCALE, dq[d][4 * g + 1] * SCALE, dq[d][4 * g + 2] * SCALE, dq[d][4 * g + 3] * SCALE};
-                *reinterpret_cast<f32x4*>(op + 32 * d + 8 * g) = v;
+                if (a.dqkv) *reinterpret_cast<f32x4*>(a.dqkv + o0 + 32 * d + 8 * g) = v;
                 if (a.dqkv16)
                     *reinterpret_cast<u32x2*>(a.dqkv16 + o0 + 32 * d + 8 * g) = u32x2{pack_bf16_rne(v[0], v[1]), pack_bf16_rne(v[2], v[3])};
             }
     }
+    if (a.colpart)
+        block_colsum(dq, qok, SCALE, reinterpret_cast<float*>(smem_a16), tid, a.colpart + ((int64_t)b * a.nqb + qb) * ld + head * DH);
 }
 
 // ---- dK, dV: block = 4 waves x 32 keys; streams 64-query tiles of Q and dO (+ lse, D as two 64-float rows) ----
@@ -542,8 +567,6 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
     }
     if (kok) {
         const int64_t k0 = ((int64_t)b * a.T + key) * ld + a.H + head * DH + 4 * lh;
-        float* kp = a.dqkv + k0;
-        float* vp = kp + a.H;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -551,13 +574,20 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
                 // S was the UNSCALED score, so dS is the gradient of the scaled one: dK = scale * dS^T Q
                 const f32x4 kv = f32x4{dk[d][4 * g] * SCALE, dk[d][4 * g + 1] * SCALE, dk[d][4 * g + 2] * SCALE, dk[d][4 * g + 3] * SCALE};
                 const f32x4 vv = f32x4{dvv[d][4 * g], dvv[d][4 * g + 1], dvv[d][4 * g + 2], dvv[d][4 * g + 3]};
-                *reinterpret_cast<f32x4*>(kp + 32 * d + 8 * g) = kv;
-                *reinterpret_cast<f32x4*>(vp + 32 * d + 8 * g) = vv;
+                if (a.dqkv) {
+                    *reinterpret_cast<f32x4*>(a.dqkv + k0 + 32 * d + 8 * g) = kv;
+                    *reinterpret_cast<f32x4*>(a.dqkv + k0 + a.H + 32 * d + 8 * g) = vv;
+                }
                 if (a.dqkv16) {
                     *reinterpret_cast<u32x2*>(a.dqkv16 + k0 + 32 * d + 8 * g) = u32x2{pack_bf16_rne(kv[0], kv[1]), pack_bf16_rne(kv[2], kv[3])};
                     *reinterpret_cast<u32x2*>(a.dqkv16 + k0 + a.H + 32 * d + 8 * g) = u32x2{pack_bf16_rne(vv[0], vv[1]), pack_bf16_rne(vv[2], vv[3])};
                 }
             }
+    }
+    if (a.colpart) {
+        float* cp = a.colpart + ((int64_t)b * a.nqb + kb) * ld + head * DH;
+        block_colsum(dk, kok, SCALE, reinterpret_cast<float*>(smem_a16), tid, cp + a.H);
+        block_colsum(dvv, kok, 1.0f, reinterpret_cast<float*>(smem_a16), tid, cp + 2 * a.H);
     }
 }
 
@@ -579,6 +609,8 @@ int shadow_or_scratch(const float* x, const uint16_t* x16, int64_t n, int slot, 
 }  // namespace
 
 bool attention_bf16_supported(int head_size) { return head_size == DH; }
+
+int attention_colpart_rows(int B, int T) { return B * ((T + NW * 32 - 1) / (NW * 32)); }
 
 int64_t attention_keep_bits_words(int B, int T, int heads) {
     const int64_t Tq = (int64_t)((T + NW * 32 - 1) / (NW * 32)) * NW * 32;
@@ -612,7 +644,8 @@ int launch_attention_fwd_bf16(const float* qkv, const uint16_t* qkv16, const int
 // here from the fp32 tensors).
 int launch_attention_bwd_bf16(const float* qkv, const uint16_t* qkv16, const int32_t* frame_len, const float* dctx, const uint16_t* dctx16,
                               const float* dvec, float* dqkv, uint16_t* dqkv16, int B, int T, int H, int heads, const AttnTrain& tr,
-                              hipStream_t s) {
+                              hipStream_t s, float* colpart) {
+    W2V2_REQUIRE(dqkv || dqkv16, "attention_bwd_bf16: no output");
     W2V2_REQUIRE(H / heads == DH && H % heads == 0, "attention_bwd_bf16: head size %d unsupported (64)", H / heads);
     W2V2_REQUIRE((int64_t)T * 3 * H < (1ll << 31), "attention_bwd_bf16: T x 3H too large for 32-bit row offsets");
     const uint16_t *q16 = nullptr, *do16 = nullptr;
@@ -622,9 +655,13 @@ int launch_attention_bwd_bf16(const float* qkv, const uint16_t* qkv16, const int
                      (reinterpret_cast<uintptr_t>(dqkv16) & 7) == 0,
                  "attention_bwd_bf16: unaligned operand");
     const int nqb = (T + NW * 32 - 1) / (NW * 32);
-    Attn16BwdArgs a{q16, frame_len, do16, dvec, dqkv, dqkv16, B, T, H, heads, nqb, nqb * heads * B};
+    Attn16BwdArgs a{q16, frame_len, do16, dvec, dqkv, dqkv16, colpart, B, T, H, heads, nqb, nqb * heads * B};
     const bool bits = tr.keep_bits && tr.p > 0.f;
-    const size_t lds_q = 2 * 2 * IMG, lds_kv = 2 * (2 * IMG + 2 * KT * 4 + (bits ? NW * 2 * KT * 4 : 0));
+    size_t lds_q = 2 * 2 * IMG, lds_kv = 2 * (2 * IMG + 2 * KT * 4 + (bits ? NW * 2 * KT * 4 : 0));
+    if (colpart) {
+        if (lds_q < (size_t)COLSUM_LDS) lds_q = COLSUM_LDS;
+        if (lds_kv < (size_t)COLSUM_LDS) lds_kv = COLSUM_LDS;
+    }
     dim3 grid(a.nwork), block(256);
     if (bits) {
         hipLaunchKernelGGL(attention_bf16_bwd_dq_kernel<true>, grid, block, lds_q, s, a, tr);

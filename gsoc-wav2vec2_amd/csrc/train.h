@@ -102,9 +102,12 @@ bool attention_bf16_supported(int head_size);
 // (the kernels read bf16 shadows of qkv / dctx; a null shadow is made from the fp32 tensor in per-stream scratch)
 int launch_attention_fwd_bf16(const float* qkv, const uint16_t* qkv16, const int32_t* frame_len, float* ctx, uint16_t* ctx16, int B,
                               int T, int H, int heads, const AttnTrain* tr, hipStream_t s);
+// colpart (optional): (attention_colpart_rows(B, T), 3H) per-block column sums of dqkv; summed over its rows they are the q|k|v
+// bias gradient.  dqkv may be null when dqkv16 is given.
 int launch_attention_bwd_bf16(const float* qkv, const uint16_t* qkv16, const int32_t* frame_len, const float* dctx, const uint16_t* dctx16,
                               const float* dvec, float* dqkv, uint16_t* dqkv16 /* optional bf16 shadow */, int B, int T, int H, int heads,
-                              const AttnTrain& tr, hipStream_t s);
+                              const AttnTrain& tr, hipStream_t s, float* colpart = nullptr);
+int attention_colpart_rows(int B, int T);
 int launch_attention_train_x(Profiler* prof, const float* qkv, const uint16_t* qkv16, const int32_t* frame_len, float* ctx, uint16_t* ctx16,
                              int B, int T, int H, int heads, const AttnTrain& tr, hipStream_t s);
 int launch_attention_train(Profiler* prof, const float* qkv, const int32_t* frame_len, float* ctx, int B, int T,
@@ -114,7 +117,7 @@ int launch_attention_train(Profiler* prof, const float* qkv, const int32_t* fram
 int launch_attention_bwd(Profiler* prof, const float* qkv, const int32_t* frame_len, const float* ctx,
                          const float* dctx, float* dqkv, float* dvec_ws, int B, int T, int H, int heads,
                          const AttnTrain& tr, hipStream_t s, uint16_t* dqkv16 = nullptr /* bf16 shadow of dqkv (bf16 kernels only) */,
-                         const uint16_t* qkv16 = nullptr, const uint16_t* dctx16 = nullptr);
+                         const uint16_t* qkv16 = nullptr, const uint16_t* dctx16 = nullptr, float* colpart = nullptr /* see launch_attention_bwd_bf16 */);
 
 // positional conv, training variants (posconv.hip)
 int launch_pos_conv_ex(Profiler* prof, const float* x, const float* wg, const float* bias,

@@ -61,7 +61,8 @@ struct TrainState {
     bool transposes_full = false;            // the per-layer fp32 transposed kernels are current (not needed in bf16 mode)
     // scratch
     float *gh[4] = {nullptr, nullptr, nullptr, nullptr}, *gf = nullptr, *g3h = nullptr, *at = nullptr,
-          *slabs = nullptr, *red_ws = nullptr, *dvec = nullptr, *dummy = nullptr, *dwqkv = nullptr, *dwv_scratch = nullptr;
+          *slabs = nullptr, *red_ws = nullptr, *dvec = nullptr, *dummy = nullptr, *dwqkv = nullptr, *dwv_scratch = nullptr,
+          *attn_colpart = nullptr;     // per-block column sums of dqkv from the bf16 attention backward (-> q|k|v bias gradient)
     int64_t slab_floats = 0;
     // bf16 shadows of the gradient tensors that are the A operand of a data-gradient GEMM (precision mode 1): written by the
     // producing kernel (LayerNorm / dropout / attention backward), consumed by the GEMM enqueued right behind it
@@ -235,6 +236,9 @@ static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
     if (lw > rw) rw = lw;
     if (int e = t_alloc(t, &t->red_ws, rw + 16)) return e;
     if (int e = t_alloc(t, &t->dvec, (int64_t)B * c.num_heads * T)) return e;
+    t->attn_colpart = nullptr;
+    if (attention_bf16_supported((int)(H / c.num_heads)))
+        if (int e = t_alloc(t, &t->attn_colpart, (int64_t)attention_colpart_rows(B, T) * 3 * H)) return e;
     {
         float* raw = nullptr;                   // (BT, H) + (BT, F) + (BT, 3H) bf16, each 16-byte aligned
         auto up8 = [](int64_t n) { return (n + 7) & ~(int64_t)7; };
@@ -731,11 +735,19 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
             return e;
     }
 
-    auto qkv_weight_grad = [&](const std::string& b, const float* attn_in, const uint16_t* attn_in16) -> int {
+    // dqkv only as bf16 (+ per-block column sums for the bias gradient) when all three of its readers can do without the fp32 copy
+    auto dqkv16_only = [&](int i, const uint16_t* attn_in16) {
+        return xs && s16q && t->x16_attn && t->attn_colpart && attn_in16 && H % 128 == 0 && dx_shadowed(m->qkv_w[i]);
+    };
+    auto qkv_weight_grad = [&](const std::string& b, const float* attn_in, const uint16_t* attn_in16, bool only16) -> int {
         // packed q|k|v projection: dW (H, 3H) -> the three (H, H) kernels, db (3H) -> the three biases
         float* dWqkv = t->dwqkv;
         float* dbqkv = dWqkv + (int64_t)3 * H * H;
-        if (int e = weight_grad(m, attn_in, t->g3h, (int)BT, H, 3 * H, dWqkv, dbqkv, s, (xs && s16q) ? attn_in16 : nullptr, s16q)) return e;
+        if (int e = weight_grad(m, attn_in, only16 ? nullptr : t->g3h, (int)BT, H, 3 * H, dWqkv, only16 ? nullptr : dbqkv, s,
+                                (xs && s16q) ? attn_in16 : nullptr, s16q))
+            return e;
+        if (only16)
+            if (int e = launch_colsum(t->attn_colpart, dbqkv, attention_colpart_rows(B, T), 3 * H, t->red_ws, 0, s)) return e;
         const char* names[3] = {"q_proj", "k_proj", "v_proj"};
         if (H % 4 == 0) {
             float* gw3[3];
@@ -798,20 +810,24 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         }
         float* d_o = tmp;
         bool bo_done = false;
-        if (int e = dropout_bwd_bias(nullptr, dt1, d_o, s16h, BT, H, 0, layer_stream(i, 1), G(b + "/attention/out_proj/bias"), &bo_done)) return e;
-        if (int e = weight_grad(m, l.ctx, d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"),
-                                bo_done ? nullptr : G(b + "/attention/out_proj/bias"), s, (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h))
+        float* const gbo = G(b + "/attention/out_proj/bias");
+        // (d_o is read only as bf16 when both of its GEMMs stream shadows and its column sums come from the producer)
+        const bool do16_only = xs && t->x16_attn && s16h && H % 128 == 0 && (BT * H) % 4 == 0 && dx_shadowed(m->P(b + "/attention/out_proj/kernel"));
+        if (int e = dropout_bwd_bias(nullptr, dt1, do16_only ? nullptr : d_o, s16h, BT, H, 0, layer_stream(i, 1), gbo, &bo_done)) return e;
+        if (int e = weight_grad(m, l.ctx, do16_only ? nullptr : d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), bo_done ? nullptr : gbo, s,
+                                (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h))
             return e;
         float* dctx = tmp2;
         // (the bf16 attention backward reads dctx and q | k | v as bf16: the GEMM leaves the dctx shadow, the forward left qkv16)
         uint16_t* const dctx16 = (s16q && dx_shadowed(m->P(b + "/attention/out_proj/kernel"))) ? t->dy16_ctx : nullptr;
-        if (int e = gemm_dx(d_o, s16h, H, l.WoT, m->P(b + "/attention/out_proj/kernel"), dctx, H, nullptr, (int)BT, H, H, s, dctx16)) return e;
+        if (int e = gemm_dx(do16_only ? nullptr : d_o, s16h, H, l.WoT, m->P(b + "/attention/out_proj/kernel"), dctx, H, nullptr, (int)BT, H, H, s, dctx16)) return e;
         AttnTrain tr{p, seed, layer_stream(i, 0), l.lse, t->x16_attn ? l.keep_bits : nullptr};
-        if (int e = launch_attention_bwd(pf, t->x16_attn ? nullptr : l.qkv, flen, l.ctx, dctx, t->g3h, t->dvec, B, T, H, c.num_heads, tr, s, s16q,
-                                         t->x16_attn ? l.qkv16 : nullptr, dctx16))
+        const bool q16 = dqkv16_only(i, l.a16);
+        if (int e = launch_attention_bwd(pf, t->x16_attn ? nullptr : l.qkv, flen, l.ctx, dctx, q16 ? nullptr : t->g3h, t->dvec, B, T, H, c.num_heads, tr,
+                                         s, s16q, t->x16_attn ? l.qkv16 : nullptr, dctx16, q16 ? t->attn_colpart : nullptr))
             return e;
-        if (int e = qkv_weight_grad(b, l.a, l.a16)) return e;
-        if (int e = gemm_dx(t->g3h, s16q, 3 * H, l.WqkvT, m->qkv_w[i], tmp, H, nullptr, (int)BT, H, 3 * H, s)) return e;
+        if (int e = qkv_weight_grad(b, l.a, l.a16, q16)) return e;
+        if (int e = gemm_dx(q16 ? nullptr : t->g3h, s16q, 3 * H, l.WqkvT, m->qkv_w[i], tmp, H, nullptr, (int)BT, H, 3 * H, s)) return e;
         float* dg1 = G(b + "/layer_norm/gamma");
         float* db1 = G(b + "/layer_norm/beta");
         if (int e = launch_ln_bwd(x, m->P(b + "/layer_norm/gamma"), tmp, tmp2, dg1 ? dg1 : t->dummy, db1 ? db1 : t->dummy + H, BT, H,
@@ -868,21 +884,26 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         // t1 = dropout(o) + x,  o = ctx Wo + bo
         float* d_o = tmp;     // dt3 (and its shadow) is dead
         bool bo_done = false;
-        if (int e = dropout_bwd_bias(nullptr, dt1, d_o, s16h, BT, H, 0, layer_stream(i, 1), G(b + "/attention/out_proj/bias"), &bo_done)) return e;
-        if (int e = weight_grad(m, l.ctx, d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"),
-                                bo_done ? nullptr : G(b + "/attention/out_proj/bias"), s, (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h))
+        float* const gbo = G(b + "/attention/out_proj/bias");
+        // (d_o is read only as bf16 when both of its GEMMs stream shadows and its column sums come from the producer)
+        const bool do16_only = xs && t->x16_attn && s16h && H % 128 == 0 && (BT * H) % 4 == 0 && dx_shadowed(m->P(b + "/attention/out_proj/kernel"));
+        if (int e = dropout_bwd_bias(nullptr, dt1, do16_only ? nullptr : d_o, s16h, BT, H, 0, layer_stream(i, 1), gbo, &bo_done)) return e;
+        if (int e = weight_grad(m, l.ctx, do16_only ? nullptr : d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), bo_done ? nullptr : gbo, s,
+                                (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h))
             return e;
         float* dctx = tmp2;   // dt2 is dead
         // (the bf16 attention backward reads dctx and q | k | v as bf16: the GEMM leaves the dctx shadow, the forward left qkv16)
         uint16_t* const dctx16 = (s16q && dx_shadowed(m->P(b + "/attention/out_proj/kernel"))) ? t->dy16_ctx : nullptr;
-        if (int e = gemm_dx(d_o, s16h, H, l.WoT, m->P(b + "/attention/out_proj/kernel"), dctx, H, nullptr, (int)BT, H, H, s, dctx16)) return e;
+        if (int e = gemm_dx(do16_only ? nullptr : d_o, s16h, H, l.WoT, m->P(b + "/attention/out_proj/kernel"), dctx, H, nullptr, (int)BT, H, H, s, dctx16)) return e;
         AttnTrain tr{p, seed, layer_stream(i, 0), l.lse, t->x16_attn ? l.keep_bits : nullptr};
-        if (int e = launch_attention_bwd(pf, t->x16_attn ? nullptr : l.qkv, flen, l.ctx, dctx, t->g3h, t->dvec, B, T, H, c.num_heads, tr, s, s16q,
-                                         t->x16_attn ? l.qkv16 : nullptr, dctx16))
+        const uint16_t* const hs16_i = m->hs16.size() > (size_t)i ? m->hs16[i] : nullptr;
+        const bool q16 = dqkv16_only(i, hs16_i);
+        if (int e = launch_attention_bwd(pf, t->x16_attn ? nullptr : l.qkv, flen, l.ctx, dctx, q16 ? nullptr : t->g3h, t->dvec, B, T, H, c.num_heads, tr,
+                                         s, s16q, t->x16_attn ? l.qkv16 : nullptr, dctx16, q16 ? t->attn_colpart : nullptr))
             return e;
-        if (int e = qkv_weight_grad(b, m->hs[i], m->hs16.size() > (size_t)i ? m->hs16[i] : nullptr)) return e;
+        if (int e = qkv_weight_grad(b, m->hs[i], hs16_i, q16)) return e;
         // dx = dqkv Wqkv^T + dt1 (residual)
-        if (int e = gemm_dx(t->g3h, s16q, 3 * H, l.WqkvT, m->qkv_w[i], dh, H, dt1, (int)BT, H, 3 * H, s)) return e;
+        if (int e = gemm_dx(q16 ? nullptr : t->g3h, s16q, 3 * H, l.WqkvT, m->qkv_w[i], dh, H, dt1, (int)BT, H, 3 * H, s)) return e;
         if (int e = bucket_done(c.num_layers - i)) return e;
     }
     // ---- encoder input: postnorm hs[0] = dropout(LN(posout));  prenorm hs0 = dropout(posout) ----
