@@ -182,9 +182,9 @@ int launch_pos_conv_bf16(Profiler* prof, const float* x, const uint16_t* w16, co
                          int act, int pad_left, int add_residual, hipStream_t s);
 
 // kernel gradient of the positional conv as a batched transposed-A GEMM (precision mode 1, T % 64 == 0):
-//   dwg (groups, K, cg, og) = sum over samples and frames; pack32: (B, G, T+K-1, cg) fp32 scratch, slabs: B * K*cg*H fp32 scratch
+//   dwg (groups, K, cg, og) = sum over samples and frames; pack32: (B, G, 64 ceil(T/64)+K-1, cg) fp32 scratch, slabs: B * K*cg*H fp32 scratch
 int launch_pos_conv_dw_bf16(Profiler* prof, const float* xz, const float* dc, float* dwg, float* pack32, float* slabs, float* red_ws,
-                            int B, int T, int H, int K, int groups, hipStream_t s);
+                            int B, int T, int H, int K, int groups, hipStream_t s, float* dc_pad = nullptr /* (B, 64 ceil(T/64), H): T % 64 != 0 */);
 
 int launch_attention(Profiler* prof, const float* qkv, const int32_t* frame_len, float* ctx, int B,
                      int T, int H, int heads, hipStream_t s);

@@ -555,11 +555,20 @@ int launch_pos_conv_bf16(Profiler* prof, const float* x, const uint16_t* w16, co
 
 // dwg[g][f = j cg + c][n] = sum_{b, t} xz[b][t + j - pad][g cg + c] dc[b][t][g og + n]: per (sample, group) a GEMM with the
 // packed input as a TRANSPOSED, overlapping-row A (element (f, t) at P[t cg + f]) and dc as B; one slab per sample, summed after.
+// T % 64 != 0: the contraction runs over Tk = 64 ceil(T / 64) frames, the extra ones contributing exact zeros: dc is copied into
+// `dc_pad` (B, Tk, H) with zero tail rows (required then), and the pack holds Tk + K - 1 rows (zeros beyond the padded input).
+// pack32: B (Tk + K - 1) H floats.
 int launch_pos_conv_dw_bf16(Profiler* prof, const float* xz, const float* dc, float* dwg, float* pack32, float* slabs, float* red_ws,
-                            int B, int T, int H, int K, int groups, hipStream_t s) {
+                            int B, int T, int H, int K, int groups, hipStream_t s, float* dc_pad) {
     W2V2_REQUIRE(xz && dc && dwg && pack32 && slabs, "pos_conv_dw_bf16: null operand");
-    const int cg = H / groups, Tp = T + K - 1;
-    W2V2_REQUIRE(T % 64 == 0 && cg % 4 == 0 && cg <= 64 && B <= 64, "pos_conv_dw_bf16: unsupported shape");
+    const int Tk = (T + 63) / 64 * 64;
+    const int cg = H / groups, Tp = Tk + K - 1;
+    W2V2_REQUIRE(cg % 4 == 0 && cg <= 64 && B <= 64 && (Tk == T || dc_pad), "pos_conv_dw_bf16: unsupported shape");
+    if (Tk != T) {
+        W2V2_HIP_CHECK(hipMemcpy2DAsync(dc_pad, (size_t)Tk * H * 4, dc, (size_t)T * H * 4, (size_t)T * H * 4, (size_t)B, hipMemcpyDeviceToDevice, s));
+        W2V2_HIP_CHECK(hipMemset2DAsync(dc_pad + (int64_t)T * H, (size_t)Tk * H * 4, 0, (size_t)(Tk - T) * H * 4, (size_t)B, s));
+        dc = dc_pad;
+    }
     ProfScope ps(prof, FAM_POSCONV, 2.0 * B * (double)T * H * cg * K, 8.0 * B * (double)T * H + 4.0 * (B + 1.0) * K * cg * H, s);
     {
         const int64_t total = (int64_t)B * groups * Tp * (cg / 4);
@@ -571,11 +580,11 @@ int launch_pos_conv_dw_bf16(Profiler* prof, const float* xz, const float* dc, fl
     gx.transA = true;
     gx.overlapA = true;
     gx.zmod = groups;
-    gx.strideB2 = (int64_t)T * H;
+    gx.strideB2 = (int64_t)Tk * H;
     gx.strideC2 = (int64_t)groups * K * cg * cg;
     const int M = K * cg;
-    // A^T: element (m = f, k = t) of batch z = b G + g at pack32[z Tp cg + t cg + f]; B (k = t, n) at dc[b T H + t H + g og + n]
-    if (int e = launch_gemm_bf16_x(nullptr, pack32, cg, (int64_t)Tp * cg, dc, H, cg, slabs, cg, (int64_t)K * cg * cg, nullptr, nullptr, M, cg, T,
+    // A^T: element (m = f, k = t) of batch z = b G + g at pack32[z Tp cg + t cg + f]; B (k = t, n) at dc[b Tk H + t H + g og + n]
+    if (int e = launch_gemm_bf16_x(nullptr, pack32, cg, (int64_t)Tp * cg, dc, H, cg, slabs, cg, (int64_t)K * cg * cg, nullptr, nullptr, M, cg, Tk,
                                    B * groups, 0, gx, s))
         return e;
     return launch_colsum(slabs, dwg, B, (int)((int64_t)groups * K * cg * cg), red_ws, 0, s);

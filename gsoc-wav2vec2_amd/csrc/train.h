@@ -73,7 +73,8 @@ int launch_ln_bwd(const float* x, const float* gamma, const float* dy, float* dx
                   float* dbeta, int64_t rows, int C, float eps, float* ws, hipStream_t s);
 int launch_ln_bwd_x(const float* x, const float* gamma, const float* dy, float* dx, uint16_t* dx16 /* optional bf16 shadow */,
                     float* dgamma, float* dbeta, int64_t rows, int C, float eps, float* ws, hipStream_t s,
-                    float* dxsum = nullptr /* optional: column sums of dx (C floats) */);
+                    float* dxsum = nullptr /* optional: column sums of dx (C floats) */,
+                    const float* residual = nullptr /* optional: dx = LN-backward(dy) + residual */);
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1, float b2,
                 float eps, hipStream_t s);
 int launch_spec_aug_fwd(const float* x, const uint8_t* mask, const float* embed, float* y, int64_t rows, int H, hipStream_t s);

@@ -150,24 +150,37 @@ __global__ __launch_bounds__(256) void dropout_bwd_colsum_kernel(const float* __
 }
 
 // dst (Kin, Nout) = A16^T B16 over a FEW rows (the rows a weight gradient's fast slabs leave over): bf16 operands (exact
-// products), fp32 accumulation in row order.  Thread = one output column n and 8 consecutive output rows k.
+// products), fp32 accumulation in row order.  Thread = 4 consecutive output columns n x 8 consecutive output rows k; the A run
+// of a row is block-uniform (scalar loads), the B run is one 8-byte load.
 __global__ __launch_bounds__(256) void dw_tail_bf16_kernel(const uint16_t* __restrict__ A16, int64_t lda, const uint16_t* __restrict__ B16,
                                                            int64_t ldb, float* __restrict__ dst, int R, int Kin, int Nout) {
-    const int n = blockIdx.x * 256 + threadIdx.x, k0 = blockIdx.y * 8;
+    const int n = (blockIdx.x * 256 + threadIdx.x) * 4, k0 = blockIdx.y * 8;
     if (n >= Nout) return;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float acc[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[j][e] = 0.f;
+#pragma unroll 4
     for (int r = 0; r < R; ++r) {
-        const float b = __uint_as_float((uint32_t)B16[(int64_t)r * ldb + n] << 16);
+        const uint2 bv = *reinterpret_cast<const uint2*>(B16 + (int64_t)r * ldb + n);
+        const float b[4] = {__uint_as_float(bv.x << 16), __uint_as_float(bv.x & 0xFFFF0000u), __uint_as_float(bv.y << 16),
+                            __uint_as_float(bv.y & 0xFFFF0000u)};
         const uint4 av = *reinterpret_cast<const uint4*>(A16 + (int64_t)r * lda + k0);       // block-uniform: 8 bf16
         const uint32_t aw[4] = {av.x, av.y, av.z, av.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            acc[2 * j] = fmaf(__uint_as_float(aw[j] << 16), b, acc[2 * j]);
-            acc[2 * j + 1] = fmaf(__uint_as_float(aw[j] & 0xFFFF0000u), b, acc[2 * j + 1]);
+            const float a0 = __uint_as_float(aw[j] << 16), a1 = __uint_as_float(aw[j] & 0xFFFF0000u);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[2 * j][e] = fmaf(a0, b[e], acc[2 * j][e]);
+                acc[2 * j + 1][e] = fmaf(a1, b[e], acc[2 * j + 1][e]);
+            }
         }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dst[(int64_t)(k0 + j) * Nout + n] = acc[j];
+    for (int j = 0; j < 8; ++j)
+        *reinterpret_cast<float4*>(dst + (int64_t)(k0 + j) * Nout + n) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
 }
 
 // batched transpose: y[b][c][r] = x[b][r][c]
@@ -298,7 +311,8 @@ template <int NV, bool DXSUM>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ dy, float* __restrict__ dx,
                                                      uint16_t* __restrict__ dx16 /* optional bf16 shadow of dx */,
-                                                     float* __restrict__ partial, int64_t rows, int C, float eps) {
+                                                     float* __restrict__ partial, int64_t rows, int C, float eps,
+                                                     const float* __restrict__ res /* optional: dx = LN-backward + res */) {
     extern __shared__ float red[];   // 4 waves x NG x C
     constexpr int NG = DXSUM ? 3 : 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -382,8 +396,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
             for (int i = 0; i < NV; ++i) {
                 const int c = (i * 64 + lane) * 4;
                 if (c < C) {
-                    const float4 o = make_float4(rstd * (gv[i][0] - s1 - xv[i][0] * s2), rstd * (gv[i][1] - s1 - xv[i][1] * s2),
-                                                 rstd * (gv[i][2] - s1 - xv[i][2] * s2), rstd * (gv[i][3] - s1 - xv[i][3] * s2));
+                    float4 o = make_float4(rstd * (gv[i][0] - s1 - xv[i][0] * s2), rstd * (gv[i][1] - s1 - xv[i][1] * s2),
+                                           rstd * (gv[i][2] - s1 - xv[i][2] * s2), rstd * (gv[i][3] - s1 - xv[i][3] * s2));
+                    if (res) {
+                        const float4 rv = *reinterpret_cast<const float4*>(res + row * C + c);
+                        o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+                    }
                     *reinterpret_cast<float4*>(dxr + c) = o;
                     if (dx16) *reinterpret_cast<uint2*>(dx16 + row * C + c) = make_uint2(pack_bf16_rne(o.x, o.y), pack_bf16_rne(o.z, o.w));
                     if constexpr (DXSUM) { ds[i][0] += o.x; ds[i][1] += o.y; ds[i][2] += o.z; ds[i][3] += o.w; }
@@ -396,7 +414,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
                 for (int e = 0; e < 4; ++e) {
                     const int c = (i * 64 + lane) * 4 + e;
                     if (c < C) {
-                        const float o = rstd * (gv[i][e] - s1 - xv[i][e] * s2);
+                        float o = rstd * (gv[i][e] - s1 - xv[i][e] * s2);
+                        if (res) o += res[row * C + c];
                         dxr[c] = o;
                         if (dx16) dx16[row * C + c] = (uint16_t)pack_bf16_rne(o, 0.f);
                         if constexpr (DXSUM) ds[i][e] += o;
@@ -543,9 +562,11 @@ int launch_dropout_bwd_x(const float* u, const float* dy, float* dx, uint16_t* d
 }
 
 int launch_dw_tail_bf16(const uint16_t* A16, int64_t lda, const uint16_t* B16, int64_t ldb, float* dst, int R, int Kin, int Nout, hipStream_t s) {
-    W2V2_REQUIRE(A16 && B16 && dst && R > 0 && Kin > 0 && Nout > 0 && Kin % 8 == 0 && lda % 8 == 0 && (reinterpret_cast<uintptr_t>(A16) & 15) == 0,
+    W2V2_REQUIRE(A16 && B16 && dst && R > 0 && Kin > 0 && Nout > 0 && Kin % 8 == 0 && lda % 8 == 0 && Nout % 4 == 0 && ldb % 4 == 0 &&
+                     (reinterpret_cast<uintptr_t>(A16) & 15) == 0 && (reinterpret_cast<uintptr_t>(B16) & 7) == 0 &&
+                     (reinterpret_cast<uintptr_t>(dst) & 15) == 0,
                  "dw_tail_bf16: bad argument");
-    hipLaunchKernelGGL(dw_tail_bf16_kernel, dim3((Nout + 255) / 256, Kin / 8), dim3(256), 0, s, A16, lda, B16, ldb, dst, R, Kin, Nout);
+    hipLaunchKernelGGL(dw_tail_bf16_kernel, dim3((Nout / 4 + 255) / 256, Kin / 8), dim3(256), 0, s, A16, lda, B16, ldb, dst, R, Kin, Nout);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -618,12 +639,13 @@ int64_t ln_bwd_ws_floats(int64_t rows, int C) { return (int64_t)ln_bwd_blocks(ro
 
 int launch_ln_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma,
                   float* dbeta, int64_t rows, int C, float eps, float* ws, hipStream_t s) {
-    return launch_ln_bwd_x(x, gamma, dy, dx, nullptr, dgamma, dbeta, rows, C, eps, ws, s, nullptr);
+    return launch_ln_bwd_x(x, gamma, dy, dx, nullptr, dgamma, dbeta, rows, C, eps, ws, s, nullptr, nullptr);
 }
 
 int launch_ln_bwd_x(const float* x, const float* gamma, const float* dy, float* dx, uint16_t* dx16, float* dgamma,
-                    float* dbeta, int64_t rows, int C, float eps, float* ws, hipStream_t s, float* dxsum) {
+                    float* dbeta, int64_t rows, int C, float eps, float* ws, hipStream_t s, float* dxsum, const float* residual) {
     W2V2_REQUIRE(x && gamma && dy && dx && dgamma && dbeta && ws, "ln_bwd: null operand");
+    W2V2_REQUIRE(!residual || (C & 3) != 0 || (reinterpret_cast<uintptr_t>(residual) & 15) == 0, "ln_bwd: unaligned residual");
     W2V2_REQUIRE(!dx16 || ((C & 3) == 0 && (reinterpret_cast<uintptr_t>(dx16) & 7) == 0), "ln_bwd: the bf16 shadow needs C %% 4 == 0");
     W2V2_REQUIRE(rows > 0 && C > 0 && C <= 1024, "ln_bwd: rows=%lld C=%d unsupported (C <= 1024)", (long long)rows, C);
     const int nb = ln_bwd_blocks(rows);
@@ -631,8 +653,8 @@ int launch_ln_bwd_x(const float* x, const float* gamma, const float* dy, float* 
     const size_t lds = (size_t)4 * ng * C * sizeof(float);
     auto go = [&](auto nv) {
         constexpr int NV = decltype(nv)::value;
-        if (dxsum) hipLaunchKernelGGL((ln_bwd_kernel<NV, true>), dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, dx16, ws, rows, C, eps);
-        else hipLaunchKernelGGL((ln_bwd_kernel<NV, false>), dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, dx16, ws, rows, C, eps);
+        if (dxsum) hipLaunchKernelGGL((ln_bwd_kernel<NV, true>), dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, dx16, ws, rows, C, eps, residual);
+        else hipLaunchKernelGGL((ln_bwd_kernel<NV, false>), dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, dx16, ws, rows, C, eps, residual);
     };
     if (C <= 256) go(std::integral_constant<int, 1>{});
     else if (C <= 512) go(std::integral_constant<int, 2>{});

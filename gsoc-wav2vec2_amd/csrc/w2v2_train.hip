@@ -42,7 +42,7 @@ struct TrainState {
     std::vector<LayerSave> layers;
     float *hd = nullptr, *hm = nullptr, *pos_c = nullptr, *hdf = nullptr, *hs0 = nullptr;
     float *WpT = nullptr, *WlmT = nullptr, *pos_wg_t = nullptr, *dwg = nullptr;
-    float *pos_pack32 = nullptr, *pos_dw_slabs = nullptr;   // scratch of the GEMM-formulated positional-conv kernel gradient
+    float *pos_pack32 = nullptr, *pos_dw_slabs = nullptr, *pos_dc_pad = nullptr;   // scratch of the GEMM-formulated positional-conv kernel gradient
     uint16_t* pos_w16_t = nullptr;           // bf16 (groups, og, K cg) shadow of pos_wg_t (precision mode 1); follows transposes_fresh
     bool pos_w16_t_fresh = false;
     uint8_t* spec_mask = nullptr;       // (B*T) device copy, or null when not applied
@@ -183,7 +183,7 @@ static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
     t_free(t);
     t->B = 0;
     t->forward_done = false;
-    t->pos_pack32 = t->pos_dw_slabs = nullptr;      // lazily re-allocated at the new shape
+    t->pos_pack32 = t->pos_dw_slabs = t->pos_dc_pad = nullptr;      // lazily re-allocated at the new shape
     if (int e = t_alloc(t, &t->hd, BT * H)) return e;
     if (int e = t_alloc(t, &t->hm, BT * H)) return e;
     if (int e = t_alloc(t, &t->pos_c, BT * H)) return e;
@@ -801,10 +801,10 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
             if (int e = gemm_dx(du, s16f, F, l.W1T, m->P(b + "/feed_forward/intermediate_dense/kernel"), tmp, H, nullptr, (int)BT, H, F, s)) return e;
             float* dg2 = G(b + "/final_layer_norm/gamma");
             float* db2 = G(b + "/final_layer_norm/beta");
-            if (int e = launch_ln_bwd(l.t1, m->P(b + "/final_layer_norm/gamma"), tmp, tmp2, dg2 ? dg2 : t->dummy,
-                                      db2 ? db2 : t->dummy + H, BT, H, eps, t->red_ws, s))
+            // dt1 = dh (residual) + LN2-backward(tmp), one pass
+            if (int e = launch_ln_bwd_x(l.t1, m->P(b + "/final_layer_norm/gamma"), tmp, dt1, nullptr, dg2 ? dg2 : t->dummy,
+                                        db2 ? db2 : t->dummy + H, BT, H, eps, t->red_ws, s, nullptr, dh))
                 return e;
-            if (int e = launch_axpby(dh, tmp2, dt1, BT * H, 1.f, 1.f, s)) return e;      // residual + LN2 branch
         } else {
             W2V2_HIP_CHECK(hipMemcpyAsync(dt1, dh, (size_t)BT * H * 4, hipMemcpyDeviceToDevice, s));
         }
@@ -830,13 +830,11 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         if (int e = gemm_dx(q16 ? nullptr : t->g3h, s16q, 3 * H, l.WqkvT, m->qkv_w[i], tmp, H, nullptr, (int)BT, H, 3 * H, s)) return e;
         float* dg1 = G(b + "/layer_norm/gamma");
         float* db1 = G(b + "/layer_norm/beta");
-        if (int e = launch_ln_bwd(x, m->P(b + "/layer_norm/gamma"), tmp, tmp2, dg1 ? dg1 : t->dummy, db1 ? db1 : t->dummy + H, BT, H,
-                                  eps, t->red_ws, s))
+        // dh = dt1 (residual) + LN1-backward(tmp), one pass (+ the shadow the next iteration's down-projection GEMMs stream)
+        dh16_valid = s16h && H % 4 == 0 && (reinterpret_cast<uintptr_t>(dt1) & 15) == 0;
+        if (int e = launch_ln_bwd_x(x, m->P(b + "/layer_norm/gamma"), tmp, dh, dh16_valid ? s16h : nullptr, dg1 ? dg1 : t->dummy,
+                                    db1 ? db1 : t->dummy + H, BT, H, eps, t->red_ws, s, nullptr, dt1))
             return e;
-        // residual + LN1 branch (+ the shadow the next iteration's down-projection GEMMs stream)
-        dh16_valid = s16h && (BT * H) % 4 == 0 &&
-                     ((reinterpret_cast<uintptr_t>(dt1) | reinterpret_cast<uintptr_t>(tmp2) | reinterpret_cast<uintptr_t>(dh)) & 15) == 0;
-        if (int e = launch_axpby_x(dt1, tmp2, dh, dh16_valid ? s16h : nullptr, BT * H, 1.f, 1.f, s)) return e;
         if (int e = bucket_done(c.num_layers - i)) return e;
     }
 
@@ -933,13 +931,18 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     float* gv = G("encoder/pos_conv_embed/conv/weight_v");
     float* gg = G("encoder/pos_conv_embed/conv/weight_g");
     if (gv || gg) {
-        if (w2v2_pos_conv_bf16_ok(m) && T % 64 == 0 && B <= 64) {
-            // precision mode 1: batched transposed-A GEMM on the bf16 pipe (one (K cg, og) slab per sample and group, summed after)
+        if (w2v2_pos_conv_bf16_ok(m) && B <= 64) {
+            // precision mode 1: batched transposed-A GEMM on the bf16 pipe (one (K cg, og) slab per sample and group, summed after);
+            // the frames are padded to a multiple of 64 with zero rows of dc (T = 1499 at 480000 samples)
+            const int Tk = (T + 63) / 64 * 64;
             if (!t->pos_pack32) {
-                if (int e = t_alloc(t, &t->pos_pack32, (int64_t)B * (T + K - 1) * H)) return e;
+                if (int e = t_alloc(t, &t->pos_pack32, (int64_t)B * (Tk + K - 1) * H)) return e;
                 if (int e = t_alloc(t, &t->pos_dw_slabs, (int64_t)B * K * cg * H)) return e;
+                if (Tk != T)
+                    if (int e = t_alloc(t, &t->pos_dc_pad, (int64_t)B * Tk * H)) return e;
             }
-            if (int e = launch_pos_conv_dw_bf16(pf, xz, dc, t->dwg, t->pos_pack32, t->pos_dw_slabs, t->red_ws, B, T, H, K, Gr, s)) return e;
+            if (int e = launch_pos_conv_dw_bf16(pf, xz, dc, t->dwg, t->pos_pack32, t->pos_dw_slabs, t->red_ws, B, T, H, K, Gr, s, t->pos_dc_pad))
+                return e;
         } else if (int e = launch_pos_conv_dw(pf, xz, dc, t->dwg, nullptr, B, T, H, K, Gr, s)) {
             return e;
         }
