@@ -14,22 +14,7 @@ namespace w2v2 {
 #ifdef __HIPCC__
 using f32x16_t = __attribute__((ext_vector_type(16))) float;
 
-// exact GELU 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.26: |erf error| < 1.5e-7 absolute, ~14 VALU
-// ops against ~35 for erff.  Used by the bf16 kernel only (FAST_GELU): its error is a smooth, i.e. BIASED, function of x,
-// and through 19 GELU layers that bias moved the fp32 CTC loss of the 246000-sample fixture from 5e-3 to 1.7e-2 off the
-// fp64 reference (logits 7.4e-5 -> 8.1e-5) -- invisible next to bf16 rounding, not acceptable for the fp32 path.
-__device__ __forceinline__ float gelu_erf_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
-    const float erf_abs = fmaf(-p * t, e, 1.0f);             // erf(|x| / sqrt 2)
-    return 0.5f * x + 0.5f * fabsf(x) * erf_abs;             // 0.5 x (1 + sign(x) erf(|x| / sqrt 2))
-}
-
+// (gelu_erf_fast: common.h)
 // C / C16 / R point at the wave sub-tile's first element (row 0, column 0 of the WTM x WTN block); any may be null.
 // bias points at the sub-tile's first column.  rows_left / cols_left = valid extent of the sub-tile.
 template <int MT, int NTL, bool FAST_GELU>

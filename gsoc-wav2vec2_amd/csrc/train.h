@@ -67,6 +67,7 @@ int launch_dropout_bwd_colsum(const float* u, const float* dy, float* dx, uint16
                               int act, float p, uint64_t seed, uint32_t stream_id, float* ws, hipStream_t s);
 int launch_transpose(const float* x, float* y, int rows, int cols, int nbatch, hipStream_t s);
 int64_t colsum_ws_floats(int64_t rows, int cols);
+int64_t dropout_bwd_colsum_ws_floats(int64_t rows, int cols);      // scratch of launch_dropout_bwd_colsum
 int launch_colsum(const float* x, float* out, int64_t rows, int cols, float* ws, int accumulate, hipStream_t s);
 int64_t ln_bwd_ws_floats(int64_t rows, int C);
 int launch_ln_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma,

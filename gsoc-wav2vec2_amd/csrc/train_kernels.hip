@@ -34,6 +34,18 @@ __device__ __forceinline__ float gelu_grad(float u, int act) {
         const float t = tanhf(c * (u + k * u * u * u));
         return 0.5f * (1.0f + t) + 0.5f * u * (1.0f - t * t) * c * (1.0f + 3.0f * k * u * u);
     }
+    if (act == 3) {   // act 1 evaluated the fast way (precision mode 1): erf by Abramowitz-Stegun 7.1.26, one exponential shared with the density
+        const float z = fabsf(u) * 0.70710678118654752440f;
+        const float tt = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+        float q = fmaf(1.061405429f, tt, -1.453152027f);
+        q = fmaf(q, tt, 1.421413741f);
+        q = fmaf(q, tt, -0.284496736f);
+        q = fmaf(q, tt, 0.254829592f);
+        const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);      // exp(-u^2 / 2)
+        const float erf_abs = fmaf(-q * tt, e, 1.0f);
+        const float cdf = 0.5f + copysignf(0.5f * erf_abs, u);
+        return fmaf(u * 0.39894228040143267794f, e, cdf);
+    }
     return 1.0f;
 }
 
@@ -277,11 +289,15 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, float* __
     }
 }
 // stage 2 for many chunks x few columns: 32 columns per block, the chunk loop split over 8 thread rows
+// (blockIdx.y = g selects one of up to three column groups that share the partial rows: partial + g cols -> out / out1 / out2)
 __global__ __launch_bounds__(256) void colsum_final_wide_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                                int nchunks, int cols, int64_t ld, int accumulate) {
+                                                                int nchunks, int cols, int64_t ld, int accumulate,
+                                                                float* __restrict__ out1 = nullptr, float* __restrict__ out2 = nullptr) {
     __shared__ double red[8][33];
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx;
+    partial += (int64_t)blockIdx.y * cols;
+    out = blockIdx.y == 0 ? out : (blockIdx.y == 1 ? out1 : out2);
     double acc = 0.0;
     if (c < cols) {
         int k = ry;
@@ -582,6 +598,8 @@ int launch_transpose(const float* x, float* y, int rows, int cols, int nbatch, h
 constexpr int COLSUM_CHUNK = 128;    // rows per stage-1 block
 
 int64_t colsum_ws_floats(int64_t rows, int cols) { return ((rows + COLSUM_CHUNK - 1) / COLSUM_CHUNK) * (int64_t)cols + 8; }
+// launch_dropout_bwd_colsum may cut its chunks down to 32 rows
+int64_t dropout_bwd_colsum_ws_floats(int64_t rows, int cols) { return ((rows + 31) / 32) * (int64_t)cols + 8; }
 
 int launch_colsum(const float* x, float* out, int64_t rows, int cols, float* ws, int accumulate, hipStream_t s) {
     W2V2_REQUIRE(x && out && rows > 0 && cols > 0, "colsum: bad argument");
@@ -610,7 +628,7 @@ int launch_colsum(const float* x, float* out, int64_t rows, int cols, float* ws,
 }
 
 // dx = dropout-backward(dy) as launch_dropout_bwd_x, plus colsum[c] = sum over rows of dx[r][c] (the bias gradient of the Dense
-// layer dx is the output gradient of).  ws: colsum_ws_floats(rows, cols) floats.  Falls back to the two separate passes when
+// layer dx is the output gradient of).  ws: dropout_bwd_colsum_ws_floats(rows, cols) floats.  Falls back to the two separate passes when
 // the tensors do not allow 16-byte accesses.
 int launch_dropout_bwd_colsum(const float* u, const float* dy, float* dx, uint16_t* dx16, float* colsum, int64_t rows, int cols,
                               int act, float p, uint64_t seed, uint32_t stream_id, float* ws, hipStream_t s) {
@@ -623,9 +641,14 @@ int launch_dropout_bwd_colsum(const float* u, const float* dy, float* dx, uint16
         if (int e = launch_dropout_bwd_x(u, dy, dx, dx16, rows * cols, act, p, seed, stream_id, s)) return e;
         return launch_colsum(dx, colsum, rows, cols, ws, 0, s);
     }
-    const int nchunks = (int)((rows + COLSUM_CHUNK - 1) / COLSUM_CHUNK);
-    hipLaunchKernelGGL(dropout_bwd_colsum_kernel, dim3((cols + 255) / 256, nchunks), dim3(256), 0, s, u, dy, dx, dx16, ws, rows, cols,
-                       COLSUM_CHUNK, act, p, seed, stream_id);
+    // narrow tensors (cols = H: 3 column blocks) get shorter chunks so that the grid still covers the chip (>= ~2000 blocks);
+    // ws: dropout_bwd_colsum_ws_floats(rows, cols) floats
+    int chunk = COLSUM_CHUNK;
+    const int colblocks = (cols + 255) / 256;
+    while (chunk > 32 && (rows + chunk - 1) / chunk * colblocks < 2048) chunk >>= 1;
+    const int nchunks = (int)((rows + chunk - 1) / chunk);
+    hipLaunchKernelGGL(dropout_bwd_colsum_kernel, dim3(colblocks, nchunks), dim3(256), 0, s, u, dy, dx, dx16, ws, rows, cols,
+                       chunk, act, p, seed, stream_id);
     hipLaunchKernelGGL(colsum_final_wide_kernel, dim3((cols + 31) / 32), dim3(256), 0, s, ws, colsum, nchunks, cols, (int64_t)cols, 0);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
@@ -660,9 +683,7 @@ int launch_ln_bwd_x(const float* x, const float* gamma, const float* dy, float* 
     else if (C <= 512) go(std::integral_constant<int, 2>{});
     else go(std::integral_constant<int, 4>{});
     // partial is (nb, ng C): dgamma = column sums of its first C columns, dbeta of the next C [, the sums of dx of the last C]
-    hipLaunchKernelGGL(colsum_final_wide_kernel, dim3((C + 31) / 32), dim3(256), 0, s, ws, dgamma, nb, C, (int64_t)ng * C, 0);
-    hipLaunchKernelGGL(colsum_final_wide_kernel, dim3((C + 31) / 32), dim3(256), 0, s, ws + C, dbeta, nb, C, (int64_t)ng * C, 0);
-    if (dxsum) hipLaunchKernelGGL(colsum_final_wide_kernel, dim3((C + 31) / 32), dim3(256), 0, s, ws + 2 * C, dxsum, nb, C, (int64_t)ng * C, 0);
+    hipLaunchKernelGGL(colsum_final_wide_kernel, dim3((C + 31) / 32, ng), dim3(256), 0, s, ws, dgamma, nb, C, (int64_t)ng * C, 0, dbeta, dxsum);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }

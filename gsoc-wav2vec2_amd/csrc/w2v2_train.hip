@@ -231,7 +231,7 @@ static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
     if (int e = t_alloc(t, &t->g3h, BT * 3 * H)) return e;
     const int64_t widest = F > 3 * H ? F : 3 * H;
     if (int e = t_alloc(t, &t->at, widest * BT)) return e;
-    int64_t rw = colsum_ws_floats(BT, (int)widest);
+    int64_t rw = dropout_bwd_colsum_ws_floats(BT, (int)widest);        // (>= colsum_ws_floats of the same shape)
     const int64_t lw = ln_bwd_ws_floats(BT, (int)(H > C ? H : C));
     if (lw > rw) rw = lw;
     if (int e = t_alloc(t, &t->red_ws, rw + 16)) return e;
@@ -438,6 +438,8 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
     const int H = c.hidden_size, F = c.intermediate_size;
     const int64_t BT = (int64_t)B * T;
     const int act = c.is_gelu_approx ? 2 : 1;
+    // element-wise kernels in precision mode 1 evaluate exact GELU / GELU' through the 5-term erf the bf16 GEMM epilogue uses (act 3)
+    const int act_ew = (act == 1 && m->precision == 1) ? 3 : act;
     const bool layer_mode = c.feature_extractor_norm_type == 1;
     const float eps = c.layer_norm_eps, p = dropout_p;
     t->p = p;
@@ -586,7 +588,7 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
                              m->P(b + "/feed_forward/intermediate_dense/bias"), nullptr, (int)BT, F, H, 1, 0))
                 return e;
             // (ffn16_only: every reader of gd -- this GEMM, and the down-projection's weight gradient -- streams the bf16 shadow)
-            if (int e = launch_dropout_fwd_x(l.u, nullptr, ffn16_only ? nullptr : l.gd, S16(l.gd16), BT * F, act, p, seed, layer_stream(i, 2), s)) return e;
+            if (int e = launch_dropout_fwd_x(l.u, nullptr, ffn16_only ? nullptr : l.gd, S16(l.gd16), BT * F, act_ew, p, seed, layer_stream(i, 2), s)) return e;
             if (int e = gemm(ffn16_only ? nullptr : l.gd, S16(l.gd16), F, 0, m->P(b + "/feed_forward/output_dense/kernel"), H, ffn_out, nullptr, H, 0,
                              m->P(b + "/feed_forward/output_dense/bias"), ffn_res, (int)BT, H, F, 1, 0))
                 return e;
@@ -679,6 +681,8 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     const int B = t->B, T = t->T, H = c.hidden_size, F = c.intermediate_size, V = c.vocab_size;
     const int64_t BT = (int64_t)B * T;
     const int act = c.is_gelu_approx ? 2 : 1;
+    // element-wise kernels in precision mode 1 evaluate exact GELU / GELU' through the 5-term erf the bf16 GEMM epilogue uses (act 3)
+    const int act_ew = (act == 1 && m->precision == 1) ? 3 : act;
     const float eps = c.layer_norm_eps, p = t->p;
     const uint64_t seed = t->seed;
     const int32_t* flen = t->have_mask ? m->frame_len : nullptr;
@@ -794,7 +798,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
             // (f16: du is needed only as bf16 -- both consumers stream the shadow -- unless its fp32 column sums are still to be taken)
             const bool du16_only = f16 && (!gb1 || shb) && dx_shadowed(m->P(b + "/feed_forward/intermediate_dense/kernel"));
             float* const du = du16_only ? nullptr : t->gf;
-            if (int e = dropout_bwd_bias(l.u, t->gf, du, s16f, BT, F, act, layer_stream(i, 2), gb1, &b1_done)) return e;
+            if (int e = dropout_bwd_bias(l.u, t->gf, du, s16f, BT, F, act_ew, layer_stream(i, 2), gb1, &b1_done)) return e;
             if (int e = weight_grad(m, l.t2, du, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
                                     b1_done ? nullptr : gb1, s, xs ? l.t2_16 : nullptr, s16f))
                 return e;
@@ -863,7 +867,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
             // (f16: du is needed only as bf16 -- both consumers stream the shadow, the column sums come from the producer)
             const bool du16_only = f16 && (!gb1 || shb) && dx_shadowed(m->P(b + "/feed_forward/intermediate_dense/kernel"));
             float* const du = du16_only ? nullptr : t->gf;
-            if (int e = dropout_bwd_bias(l.u, t->gf, du, s16f, BT, F, act, layer_stream(i, 2), gb1, &b1_done)) return e;
+            if (int e = dropout_bwd_bias(l.u, t->gf, du, s16f, BT, F, act_ew, layer_stream(i, 2), gb1, &b1_done)) return e;
             if (int e = weight_grad(m, l.t2, du, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
                                     b1_done ? nullptr : gb1, s, xs ? l.t2_16 : nullptr, s16f))
                 return e;
@@ -919,7 +923,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     // ---- positional conv: posout = xz + GELU(c),  c = conv(xz; W_eff) + bias ----
     const int K = c.num_conv_pos_embeddings, Gr = c.num_conv_pos_embedding_groups, cg = H / Gr;
     float* dc = tmp;
-    if (int e = launch_dropout_bwd(t->pos_c, dpos, dc, BT * H, act, 0.f, 0, 0, s)) return e;       // dc = dpos * GELU'(c)
+    if (int e = launch_dropout_bwd(t->pos_c, dpos, dc, BT * H, act_ew, 0.f, 0, 0, s)) return e;       // dc = dpos * GELU'(c)
     if (float* gb = G("encoder/pos_conv_embed/conv/bias"))
         if (int e = launch_colsum(dc, gb, BT, H, t->red_ws, 0, s)) return e;
     const float* enc_x = t->have_spec ? t->hm : t->hd;
