@@ -699,8 +699,8 @@ int launch_attention_bwd(Profiler* prof, const float* qkv, const int32_t* frame_
     const int dh = H / heads;
     ProfScope ps(prof, FAM_ATTENTION, 10.0 * B * (double)heads * T * (double)T * dh, 4.0 * B * (double)T * 8.0 * H, s);
     if (gemm_get_precision() == 1 && attention_bf16_supported(dh)) {
-        hipLaunchKernelGGL(attn_dvec_kernel<64>, dim3((unsigned)((int64_t)B * T)), dim3(256), 0, s, ctx, dctx, dvec_ws, B, T, H, heads);
-        return launch_attention_bwd_bf16(qkv, qkv16, frame_len, dctx, dctx16, dvec_ws, dqkv, dqkv16, B, T, H, heads, tr, s, colpart);
+        // (D = rowsum(dO o O) is computed by the dQ kernel from the fp32 ctx / dctx)
+        return launch_attention_bwd_bf16(qkv, qkv16, frame_len, dctx, dctx16, dvec_ws, dqkv, dqkv16, B, T, H, heads, tr, s, colpart, ctx);
     }
     W2V2_REQUIRE(qkv && dqkv && !colpart, "attention_bwd: the fp32 kernels need the fp32 qkv / dqkv and leave no column sums");
     AttnBwdArgs a{qkv, frame_len, dctx, dvec_ws, dqkv, B, T, H, heads, 1.0f / sqrtf((float)dh)};

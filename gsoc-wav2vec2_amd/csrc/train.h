@@ -107,8 +107,8 @@ int launch_attention_fwd_bf16(const float* qkv, const uint16_t* qkv16, const int
 // colpart (optional): (attention_colpart_rows(B, T), 3H) per-block column sums of dqkv; summed over its rows they are the q|k|v
 // bias gradient.  dqkv may be null when dqkv16 is given.
 int launch_attention_bwd_bf16(const float* qkv, const uint16_t* qkv16, const int32_t* frame_len, const float* dctx, const uint16_t* dctx16,
-                              const float* dvec, float* dqkv, uint16_t* dqkv16 /* optional bf16 shadow */, int B, int T, int H, int heads,
-                              const AttnTrain& tr, hipStream_t s, float* colpart = nullptr);
+                              float* dvec, float* dqkv, uint16_t* dqkv16 /* optional bf16 shadow */, int B, int T, int H, int heads,
+                              const AttnTrain& tr, hipStream_t s, float* colpart = nullptr, const float* ctx = nullptr /* fp32 O: D computed inside */);
 int attention_colpart_rows(int B, int T);
 int launch_attention_train_x(Profiler* prof, const float* qkv, const uint16_t* qkv16, const int32_t* frame_len, float* ctx, uint16_t* ctx16,
                              int B, int T, int H, int heads, const AttnTrain& tr, hipStream_t s);
