@@ -323,9 +323,11 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
         // Mq / kq, and the R = M - Mq < kq leftover rows form one more slab on the guarded kernel (0.2 % of the work).
         // (Before this, such an M fell back to ONE guarded GEMM over all rows: 256 tiles, K = 23984.)
         const int64_t tiles = (int64_t)((Kin + 127) / 128) * ((Nout + 127) / 128);
-        // slabs cost a reduction pass each: the fast bf16 GEMM is happy with ~2 blocks per slot (61.5 vs 62.1 ms per step),
+        // slabs cost a reduction pass each: the bf16 kernels are happiest with ONE block per resident slot (512),
         // the fp32 one wants ~4 to balance its long tiles (183.8 vs 189.4 ms)
-        const int64_t max_blocks = direct ? 1024 : 2048;
+        static int dwb = -1;
+        if (dwb < 0) { const char* e = getenv("W2V2_DW_BLOCKS"); dwb = e ? atoi(e) : 512; }      // tuning knob: 512 -> 40.0 ms per step, 1024 -> 40.5, 256 -> 47.0 (base, 32 x 246000)
+        const int64_t max_blocks = direct ? dwb : 2048;
         int cap = 32;                                                   // most slabs worth having / that fit the scratch
         while (cap > 1 && (tiles * cap > max_blocks || (int64_t)(cap + 2) * Kin * Nout > t->slab_floats)) --cap;
         // S must divide the number of kq-row units; if M / kq has no useful divisor (a prime, say), give up to 15 more
