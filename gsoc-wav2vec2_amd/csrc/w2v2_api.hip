@@ -573,6 +573,8 @@ int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const i
     const int H = c.hidden_size, F = c.intermediate_size;
     const int64_t BT = (int64_t)B * T;
     const int act = c.is_gelu_approx ? 2 : 1;
+    // element-wise kernels in precision mode 1 evaluate exact GELU through the 5-term erf the bf16 GEMM epilogue uses (act 3)
+    const int act_ew = (act == 1 && m->precision == 1) ? 3 : act;
     const bool layer_mode = c.feature_extractor_norm_type == 1;
     const bool prenorm = c.attention_norm_type == 1;
     const float eps = c.layer_norm_eps;
@@ -613,11 +615,11 @@ int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const i
     if (int e = launch_conv0_x(pf, wave, fe(0, "/conv/kernel"), c.conv_bias ? fe(0, "/conv/bias") : nullptr,
                                fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"), w2v2_conv_out_bf16_only(m, 0, sh) ? nullptr : m->conv[0],
                                (sh && !layer_mode) ? m->conv16[0] : nullptr, m->conv0_ws, B, L, c.kernal_sizes[0], c.strides[0],
-                               c.filter_sizes[0], 1e-5f, layer_mode ? 1 : 0, act, s))
+                               c.filter_sizes[0], 1e-5f, layer_mode ? 1 : 0, act_ew, s))
         return e;
     if (layer_mode)
         if (int e = launch_layer_norm_x(pf, m->conv[0], m->conv[0], fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"),
-                                        (int64_t)B * m->conv_T[0], c.filter_sizes[0], 1e-5f, act, sh ? m->conv16[0] : nullptr, s))
+                                        (int64_t)B * m->conv_T[0], c.filter_sizes[0], 1e-5f, act_ew, sh ? m->conv16[0] : nullptr, s))
             return e;
     for (int i = 1; i < NC; ++i) {
         const int cin = c.filter_sizes[i - 1], cout = c.filter_sizes[i];
@@ -631,7 +633,7 @@ int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const i
             return e;
         if (layer_mode)
             if (int e = launch_layer_norm_x(pf, m->conv[i], m->conv[i], fe(i, "/layer_norm/gamma"), fe(i, "/layer_norm/beta"),
-                                            (int64_t)B * Tout, cout, 1e-5f, act, o16, s))
+                                            (int64_t)B * Tout, cout, 1e-5f, act_ew, o16, s))
                 return e;
     }
     // ---- feature projection (feature_extractor.py:92-95) ----

@@ -479,11 +479,11 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
     if (int e = launch_conv0_x(pf, wave, fe(0, "/conv/kernel"), c.conv_bias ? fe(0, "/conv/bias") : nullptr,
                                fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"), w2v2_conv_out_bf16_only(m, 0, sh) ? nullptr : m->conv[0],
                                (sh && !layer_mode) ? m->conv16[0] : nullptr, m->conv0_ws, B, L, c.kernal_sizes[0], c.strides[0],
-                               c.filter_sizes[0], 1e-5f, layer_mode ? 1 : 0, act, s))
+                               c.filter_sizes[0], 1e-5f, layer_mode ? 1 : 0, act_ew, s))
         return e;
     if (layer_mode)
         if (int e = launch_layer_norm_x(pf, m->conv[0], m->conv[0], fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"),
-                                        (int64_t)B * m->conv_T[0], c.filter_sizes[0], 1e-5f, act, sh ? m->conv16[0] : nullptr, s))
+                                        (int64_t)B * m->conv_T[0], c.filter_sizes[0], 1e-5f, act_ew, sh ? m->conv16[0] : nullptr, s))
             return e;
     for (int i = 1; i < NC; ++i) {
         const int cin = c.filter_sizes[i - 1], cout = c.filter_sizes[i];
@@ -496,7 +496,7 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
             return e;
         if (layer_mode)
             if (int e = launch_layer_norm_x(pf, m->conv[i], m->conv[i], fe(i, "/layer_norm/gamma"), fe(i, "/layer_norm/beta"),
-                                            (int64_t)B * Tout, cout, 1e-5f, act, o16, s))
+                                            (int64_t)B * Tout, cout, 1e-5f, act_ew, o16, s))
                 return e;
     }
     // ---- feature projection: LN -> Dense -> Dropout (feature_extractor.py:92-95) ----
