@@ -17,8 +17,6 @@
 // The conv feature extractor has no backward: the reference never trains it in this path.
 #include <string.h>
 
-#include <functional>
-
 #include "model.h"
 #include "train.h"
 
@@ -77,10 +75,6 @@ struct TrainState {
     // gradient buckets for overlapping the data-parallel all-reduce with the backward: completion order
     //   0 = lm_head, 1 .. N = encoder layers N-1 .. 0, N+1 = everything in front of layer 0 in the flat buffer
     std::vector<hipEvent_t> bucket_ev;
-    // weight-gradient GEMMs that read only bf16 shadows run on a second stream beside the data-gradient chain (train_backward)
-    hipStream_t side = nullptr;
-    hipEvent_t ev_in = nullptr, ev_h = nullptr, ev_f = nullptr, ev_q = nullptr, ev_join = nullptr;
-    float* red_ws_side = nullptr;
 };
 
 static int t_alloc(TrainState* t, float** out, int64_t floats) {
@@ -112,9 +106,6 @@ void w2v2_train_destroy(w2v2_model* m) {
     if (m->train->adam_chunks) (void)hipFree(m->train->adam_chunks);
     if (m->train->pos_w16_t) (void)hipFree(m->train->pos_w16_t);
     for (hipEvent_t ev : m->train->bucket_ev) (void)hipEventDestroy(ev);
-    for (hipEvent_t ev : {m->train->ev_in, m->train->ev_h, m->train->ev_f, m->train->ev_q, m->train->ev_join})
-        if (ev) (void)hipEventDestroy(ev);
-    if (m->train->side) (void)hipStreamDestroy(m->train->side);
     delete m->train;
     m->train = nullptr;
 }
@@ -244,7 +235,6 @@ static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
     const int64_t lw = ln_bwd_ws_floats(BT, (int)(H > C ? H : C));
     if (lw > rw) rw = lw;
     if (int e = t_alloc(t, &t->red_ws, rw + 16)) return e;
-    if (int e = t_alloc(t, &t->red_ws_side, colsum_ws_floats(BT, (int)widest) + 16)) return e;
     if (int e = t_alloc(t, &t->dvec, (int64_t)B * c.num_heads * T)) return e;
     t->attn_colpart = nullptr;
     if (attention_bf16_supported((int)(H / c.num_heads)))
@@ -650,7 +640,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     // copy of W itself ([in][out] = (N, K) for this GEMM) is the B shadow -- no transpose needed.  Bit-identical results.
     const bool shb = m->precision == 1 && w2v2_shadows_enabled() && m->w16_valid;
     // A16: the producer's bf16 shadow of A (or null): with it both operands stream by LDS-DMA (gemm_bf16.hip source 5)
-    auto gemm_dx_raw = [&](const float* A, const uint16_t* A16, int64_t lda, const float* WT, const float* W, float* Cc, int64_t ldc,
+    auto gemm_dx = [&](const float* A, const uint16_t* A16, int64_t lda, const float* WT, const float* W, float* Cc, int64_t ldc,
                        const float* res, int M, int N, int K, hipStream_t st, uint16_t* C16 = nullptr) -> int {
         // (C16: bf16 shadow of the result, only from the shadow branch -- callers ask for it only when `dx_shadowed(W)`)
         if (shb) {
@@ -718,92 +708,9 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         W2V2_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         t->bucket_ev.push_back(ev);
     }
-    // ---- second stream for the weight gradients ----
-    // A weight-gradient GEMM that reads ONLY bf16 shadows (the transposing-read form) depends on nothing the data-gradient chain
-    // produces later and nothing later depends on it until the optimizer: it is enqueued on `side` and runs beside the chain
-    // (the attention backward is VALU-bound, the element-wise passes HBM-bound: the matrix pipe has room).  Ordering:
-    //   side waits for the main stream's position when the job is enqueued (its dY shadow has been produced);
-    //   the main stream waits for the last job that READ a dY shadow buffer before the next producer overwrites it
-    //   (three buffers: H-wide, F-wide, 3H-wide + the attention column-sum partials);
-    //   a bucket's event is recorded on `side` after it has caught up with the main stream, and the main stream joins at the end.
-    // Results do not depend on the interleaving (no atomics, disjoint outputs, private scratch).
-    static int side_knob = -1;
-    if (side_knob < 0) { const char* e = getenv("W2V2_SIDE_STREAM"); side_knob = e ? atoi(e) : 1; }      // tuning knob
-    const bool use_side = side_knob && shb && xs;
-    if (use_side && !t->side) {
-        W2V2_HIP_CHECK(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
-        for (hipEvent_t* ev : {&t->ev_in, &t->ev_h, &t->ev_f, &t->ev_q, &t->ev_join}) W2V2_HIP_CHECK(hipEventCreateWithFlags(ev, hipEventDisableTiming));
-    }
-    bool side_busy = false, pend[3] = {false, false, false};        // pend[c]: a side job still reads dY shadow buffer c
-    // A side job is not enqueued where it is issued but after the NEXT data-gradient GEMM of the main stream (run_deferred): it
-    // then runs beside the element-wise / attention kernels that follow (HBM- and VALU-bound) instead of beside a second GEMM.
-    std::function<int()> deferred;
-    auto run_deferred = [&]() -> int {
-        if (!deferred) return W2V2_OK;
-        std::function<int()> job;
-        job.swap(deferred);
-        return job();
-    };
-    enum { BUF_H = 0, BUF_F = 1, BUF_Q = 2 };
-    auto buf_event = [&](int cls) { return cls == BUF_H ? t->ev_h : (cls == BUF_F ? t->ev_f : t->ev_q); };
-    // call before a kernel on the main stream overwrites dY shadow buffer `cls`
-    auto before_write = [&](int cls) -> int {
-        if (int e = run_deferred()) return e;
-        if (pend[cls]) {
-            W2V2_HIP_CHECK(hipStreamWaitEvent(s, buf_event(cls), 0));
-            pend[cls] = false;
-        }
-        return W2V2_OK;
-    };
-    auto join_side = [&]() -> int {
-        if (int e = run_deferred()) return e;
-        if (side_busy) {
-            W2V2_HIP_CHECK(hipEventRecord(t->ev_join, t->side));
-            W2V2_HIP_CHECK(hipStreamWaitEvent(s, t->ev_join, 0));
-            side_busy = pend[0] = pend[1] = pend[2] = false;
-        }
-        return W2V2_OK;
-    };
-    auto side_follow = [&]() -> int {       // side waits for everything enqueued on the main stream so far
-        W2V2_HIP_CHECK(hipEventRecord(t->ev_in, s));
-        W2V2_HIP_CHECK(hipStreamWaitEvent(t->side, t->ev_in, 0));
-        return W2V2_OK;
-    };
-    // data-gradient GEMM on the main stream; the weight gradient issued just before it (same dY) follows it onto the side stream
-    auto gemm_dx = [&](const float* A, const uint16_t* A16, int64_t lda, const float* WT, const float* W, float* Cc, int64_t ldc, const float* res,
-                       int M, int N, int K, hipStream_t st, uint16_t* C16 = nullptr) -> int {
-        if (int e = gemm_dx_raw(A, A16, lda, WT, W, Cc, ldc, res, M, N, K, st, C16)) return e;
-        return run_deferred();
-    };
-    // weight gradient of one Dense layer; cls = the dY shadow buffer dY16 lives in
-    auto wgrad = [&](const float* A, const float* dY, int M, int Kin, int Nout, float* dW, float* db, const uint16_t* A16, const uint16_t* dY16,
-                     int cls) -> int {
-        const bool side_ok = use_side && dW && A16 && dY16 && Kin % 128 == 0 && Nout % 128 == 0 && (!db || dY);
-        if (!side_ok) {
-            if (int e = join_side()) return e;          // (the slab scratch is shared)
-            return weight_grad(m, A, dY, M, Kin, Nout, dW, db, s, A16, dY16);
-        }
-        if (db)         // a bias gradient nobody upstream produced: the column sums of the fp32 dY, on the main stream
-            if (int e = launch_colsum(dY, db, M, Nout, t->red_ws, 0, s)) return e;
-        if (int e = run_deferred()) return e;
-        pend[cls] = side_busy = true;               // (from now on the buffer is spoken for)
-        deferred = [&, A, dY, M, Kin, Nout, dW, A16, dY16, cls]() -> int {
-            if (int e = side_follow()) return e;
-            if (int e = weight_grad(m, A, dY, M, Kin, Nout, dW, nullptr, t->side, A16, dY16)) return e;
-            W2V2_HIP_CHECK(hipEventRecord(buf_event(cls), t->side));
-            return W2V2_OK;
-        };
-        return W2V2_OK;
-    };
     // bucket k's slice of the flat buffer is final once this is recorded (w2v2_train_bucket_wait)
     auto bucket_done = [&](int k) -> int {
-        if (int e = run_deferred()) return e;
-        if (side_busy) {
-            if (int e = side_follow()) return e;
-            W2V2_HIP_CHECK(hipEventRecord(t->bucket_ev[k], t->side));
-        } else {
-            W2V2_HIP_CHECK(hipEventRecord(t->bucket_ev[k], s));
-        }
+        W2V2_HIP_CHECK(hipEventRecord(t->bucket_ev[k], s));
         return W2V2_OK;
     };
     auto G = [&](const std::string& n) { return is_trainable(m, n) ? grad_of(m, n) : nullptr; };
@@ -838,19 +745,15 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     auto dqkv16_only = [&](int i, const uint16_t* attn_in16) {
         return xs && s16q && t->x16_attn && t->attn_colpart && attn_in16 && H % 128 == 0 && dx_shadowed(m->qkv_w[i]);
     };
-    auto qkv_job = [&](const std::string& b, const float* attn_in, const uint16_t* attn_in16, bool only16, bool on_side) -> int {
+    auto qkv_weight_grad = [&](const std::string& b, const float* attn_in, const uint16_t* attn_in16, bool only16) -> int {
         // packed q|k|v projection: dW (H, 3H) -> the three (H, H) kernels, db (3H) -> the three biases
         float* dWqkv = t->dwqkv;
         float* dbqkv = dWqkv + (int64_t)3 * H * H;
-        hipStream_t qs = on_side ? t->side : s;
-        if (on_side)
-            if (int e = side_follow()) return e;
-        if (int e = weight_grad(m, attn_in, only16 ? nullptr : t->g3h, (int)BT, H, 3 * H, dWqkv, only16 ? nullptr : dbqkv, qs,
+        if (int e = weight_grad(m, attn_in, only16 ? nullptr : t->g3h, (int)BT, H, 3 * H, dWqkv, only16 ? nullptr : dbqkv, s,
                                 (xs && s16q) ? attn_in16 : nullptr, s16q))
             return e;
         if (only16)
-            if (int e = launch_colsum(t->attn_colpart, dbqkv, attention_colpart_rows(B, T), 3 * H, on_side ? t->red_ws_side : t->red_ws, 0, qs))
-                return e;
+            if (int e = launch_colsum(t->attn_colpart, dbqkv, attention_colpart_rows(B, T), 3 * H, t->red_ws, 0, s)) return e;
         const char* names[3] = {"q_proj", "k_proj", "v_proj"};
         if (H % 4 == 0) {
             float* gw3[3];
@@ -859,9 +762,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
                 gw3[j] = G(b + "/attention/" + names[j] + "/kernel");
                 gb3[j] = G(b + "/attention/" + names[j] + "/bias");
             }
-            if (int e = launch_qkv_unpack(dWqkv, dbqkv, gw3, gb3, H, qs)) return e;
-            if (on_side) W2V2_HIP_CHECK(hipEventRecord(t->ev_q, t->side));
-            return W2V2_OK;
+            return launch_qkv_unpack(dWqkv, dbqkv, gw3, gb3, H, s);
         }
         for (int j = 0; j < 3; ++j) {
             float* gw = G(b + "/attention/" + names[j] + "/kernel");
@@ -871,18 +772,6 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
                                                 hipMemcpyDeviceToDevice, s));
             if (gb) W2V2_HIP_CHECK(hipMemcpyAsync(gb, dbqkv + j * H, (size_t)H * 4, hipMemcpyDeviceToDevice, s));
         }
-        return W2V2_OK;
-    };
-    auto qkv_weight_grad = [&](const std::string& b, const float* attn_in, const uint16_t* attn_in16, bool only16) -> int {
-        // (only16: everything in the job reads bf16 shadows / the column-sum partials: the whole group runs on the side stream)
-        const bool on_side = only16 && use_side && H % 128 == 0;
-        if (!on_side) {
-            if (int e = join_side()) return e;
-            return qkv_job(b, attn_in, attn_in16, only16, false);
-        }
-        if (int e = run_deferred()) return e;
-        pend[BUF_Q] = side_busy = true;
-        deferred = [&, b, attn_in, attn_in16]() -> int { return qkv_job(b, attn_in, attn_in16, true, true); };
         return W2V2_OK;
     };
 
@@ -902,8 +791,8 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         const uint16_t* dh16 = dh16_valid ? s16h : nullptr;
         if (l.keep != 0.f) {
             W2V2_REQUIRE(!f16 || dh16, "train_backward: no bf16 shadow of the layer's output gradient");
-            if (int e = wgrad(f16 ? nullptr : l.gd, dh, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
-                              G(b + "/feed_forward/output_dense/bias"), (xs && dh16) ? l.gd16 : nullptr, dh16, BUF_H))
+            if (int e = weight_grad(m, f16 ? nullptr : l.gd, dh, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
+                                    G(b + "/feed_forward/output_dense/bias"), s, (xs && dh16) ? l.gd16 : nullptr, dh16))
                 return e;
             if (int e = gemm_dx(dh, dh16, H, l.W2T, m->P(b + "/feed_forward/output_dense/kernel"), t->gf, F, nullptr, (int)BT, F, H, s)) return e;
             bool b1_done = false;
@@ -911,10 +800,9 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
             // (f16: du is needed only as bf16 -- both consumers stream the shadow -- unless its fp32 column sums are still to be taken)
             const bool du16_only = f16 && (!gb1 || shb) && dx_shadowed(m->P(b + "/feed_forward/intermediate_dense/kernel"));
             float* const du = du16_only ? nullptr : t->gf;
-            if (int e = before_write(BUF_F)) return e;
             if (int e = dropout_bwd_bias(l.u, t->gf, du, s16f, BT, F, act_ew, layer_stream(i, 2), gb1, &b1_done)) return e;
-            if (int e = wgrad(l.t2, du, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"), b1_done ? nullptr : gb1,
-                              xs ? l.t2_16 : nullptr, s16f, BUF_F))
+            if (int e = weight_grad(m, l.t2, du, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
+                                    b1_done ? nullptr : gb1, s, xs ? l.t2_16 : nullptr, s16f))
                 return e;
             if (int e = gemm_dx(du, s16f, F, l.W1T, m->P(b + "/feed_forward/intermediate_dense/kernel"), tmp, H, nullptr, (int)BT, H, F, s)) return e;
             float* dg2 = G(b + "/final_layer_norm/gamma");
@@ -931,10 +819,9 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         float* const gbo = G(b + "/attention/out_proj/bias");
         // (d_o is read only as bf16 when both of its GEMMs stream shadows and its column sums come from the producer)
         const bool do16_only = xs && t->x16_attn && s16h && H % 128 == 0 && (BT * H) % 4 == 0 && dx_shadowed(m->P(b + "/attention/out_proj/kernel"));
-        if (int e = before_write(BUF_H)) return e;
         if (int e = dropout_bwd_bias(nullptr, dt1, do16_only ? nullptr : d_o, s16h, BT, H, 0, layer_stream(i, 1), gbo, &bo_done)) return e;
-        if (int e = wgrad(l.ctx, do16_only ? nullptr : d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), bo_done ? nullptr : gbo,
-                          (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h, BUF_H))
+        if (int e = weight_grad(m, l.ctx, do16_only ? nullptr : d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), bo_done ? nullptr : gbo, s,
+                                (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h))
             return e;
         float* dctx = tmp2;
         // (the bf16 attention backward reads dctx and q | k | v as bf16: the GEMM leaves the dctx shadow, the forward left qkv16)
@@ -942,7 +829,6 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         if (int e = gemm_dx(do16_only ? nullptr : d_o, s16h, H, l.WoT, m->P(b + "/attention/out_proj/kernel"), dctx, H, nullptr, (int)BT, H, H, s, dctx16)) return e;
         AttnTrain tr{p, seed, layer_stream(i, 0), l.lse, t->x16_attn ? l.keep_bits : nullptr};
         const bool q16 = dqkv16_only(i, l.a16);
-        if (int e = before_write(BUF_Q)) return e;
         if (int e = launch_attention_bwd(pf, t->x16_attn ? nullptr : l.qkv, flen, l.ctx, dctx, q16 ? nullptr : t->g3h, t->dvec, B, T, H, c.num_heads, tr,
                                          s, s16q, t->x16_attn ? l.qkv16 : nullptr, dctx16, q16 ? t->attn_colpart : nullptr))
             return e;
@@ -952,7 +838,6 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         float* db1 = G(b + "/layer_norm/beta");
         // dh = dt1 (residual) + LN1-backward(tmp), one pass (+ the shadow the next iteration's down-projection GEMMs stream)
         dh16_valid = s16h && H % 4 == 0 && (reinterpret_cast<uintptr_t>(dt1) & 15) == 0;
-        if (int e = before_write(BUF_H)) return e;
         if (int e = launch_ln_bwd_x(x, m->P(b + "/layer_norm/gamma"), tmp, dh, dh16_valid ? s16h : nullptr, dg1 ? dg1 : t->dummy,
                                     db1 ? db1 : t->dummy + H, BT, H, eps, t->red_ws, s, nullptr, dt1))
             return e;
@@ -968,15 +853,14 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         float* db2 = G(b + "/final_layer_norm/beta");
         // (dt3 is the dY of the FFN down-projection: its column sums are that layer's bias gradient)
         float* const gb2 = (shb && l.keep != 0.f) ? G(b + "/feed_forward/output_dense/bias") : nullptr;
-        if (int e = before_write(BUF_H)) return e;
         if (int e = launch_ln_bwd_x(l.t3, m->P(b + "/final_layer_norm/gamma"), dh, dt3, (l.keep != 0.f && H % 4 == 0) ? s16h : nullptr,
                                     dg2 ? dg2 : t->dummy, db2 ? db2 : t->dummy + H, BT, H, eps, t->red_ws, s, gb2))
             return e;
         float* dt2 = tmp2;
         if (l.keep != 0.f) {
             // t3 = t2 + f,  f = gd W2 + b2
-            if (int e = wgrad(f16 ? nullptr : l.gd, dt3, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
-                              gb2 ? nullptr : G(b + "/feed_forward/output_dense/bias"), xs ? l.gd16 : nullptr, H % 4 == 0 ? s16h : nullptr, BUF_H))
+            if (int e = weight_grad(m, f16 ? nullptr : l.gd, dt3, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
+                                    gb2 ? nullptr : G(b + "/feed_forward/output_dense/bias"), s, xs ? l.gd16 : nullptr, H % 4 == 0 ? s16h : nullptr))
                 return e;
             if (int e = gemm_dx(dt3, H % 4 == 0 ? s16h : nullptr, H, l.W2T, m->P(b + "/feed_forward/output_dense/kernel"), t->gf, F, nullptr, (int)BT, F, H, s)) return e;
             // du = dgd * keep/(1-p) * GELU'(u)   (+ its column sums = the up-projection's bias gradient)
@@ -985,10 +869,9 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
             // (f16: du is needed only as bf16 -- both consumers stream the shadow, the column sums come from the producer)
             const bool du16_only = f16 && (!gb1 || shb) && dx_shadowed(m->P(b + "/feed_forward/intermediate_dense/kernel"));
             float* const du = du16_only ? nullptr : t->gf;
-            if (int e = before_write(BUF_F)) return e;
             if (int e = dropout_bwd_bias(l.u, t->gf, du, s16f, BT, F, act_ew, layer_stream(i, 2), gb1, &b1_done)) return e;
-            if (int e = wgrad(l.t2, du, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"), b1_done ? nullptr : gb1,
-                              xs ? l.t2_16 : nullptr, s16f, BUF_F))
+            if (int e = weight_grad(m, l.t2, du, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
+                                    b1_done ? nullptr : gb1, s, xs ? l.t2_16 : nullptr, s16f))
                 return e;
             // dt2 = du W1^T + dt3 (the residual branch)
             if (int e = gemm_dx(du, s16f, F, l.W1T, m->P(b + "/feed_forward/intermediate_dense/kernel"), dt2, H, dt3, (int)BT, H, F, s)) return e;
@@ -1008,10 +891,9 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         float* const gbo = G(b + "/attention/out_proj/bias");
         // (d_o is read only as bf16 when both of its GEMMs stream shadows and its column sums come from the producer)
         const bool do16_only = xs && t->x16_attn && s16h && H % 128 == 0 && (BT * H) % 4 == 0 && dx_shadowed(m->P(b + "/attention/out_proj/kernel"));
-        if (int e = before_write(BUF_H)) return e;
         if (int e = dropout_bwd_bias(nullptr, dt1, do16_only ? nullptr : d_o, s16h, BT, H, 0, layer_stream(i, 1), gbo, &bo_done)) return e;
-        if (int e = wgrad(l.ctx, do16_only ? nullptr : d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), bo_done ? nullptr : gbo,
-                          (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h, BUF_H))
+        if (int e = weight_grad(m, l.ctx, do16_only ? nullptr : d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), bo_done ? nullptr : gbo, s,
+                                (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h))
             return e;
         float* dctx = tmp2;   // dt2 is dead
         // (the bf16 attention backward reads dctx and q | k | v as bf16: the GEMM leaves the dctx shadow, the forward left qkv16)
@@ -1020,7 +902,6 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         AttnTrain tr{p, seed, layer_stream(i, 0), l.lse, t->x16_attn ? l.keep_bits : nullptr};
         const uint16_t* const hs16_i = m->hs16.size() > (size_t)i ? m->hs16[i] : nullptr;
         const bool q16 = dqkv16_only(i, hs16_i);
-        if (int e = before_write(BUF_Q)) return e;
         if (int e = launch_attention_bwd(pf, t->x16_attn ? nullptr : l.qkv, flen, l.ctx, dctx, q16 ? nullptr : t->g3h, t->dvec, B, T, H, c.num_heads, tr,
                                          s, s16q, t->x16_attn ? l.qkv16 : nullptr, dctx16, q16 ? t->attn_colpart : nullptr))
             return e;
@@ -1106,7 +987,6 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     float* dproj = tmp3;
     if (int e = launch_dropout_bwd(nullptr, dhd, dproj, BT * H, 0, p, seed, DS_FEATURE_PROJECTION, s)) return e;
     const int C = c.filter_sizes[c.num_conv_layers - 1];
-    if (int e = join_side()) return e;          // (the slab scratch is shared with the side jobs; the optimizer follows on the main stream)
     if (int e = weight_grad(m, m->ln512, dproj, (int)BT, C, H, G("feature_projection/projection/kernel"),
                             G("feature_projection/projection/bias"), s))
         return e;
