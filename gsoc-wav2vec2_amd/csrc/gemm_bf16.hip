@@ -17,6 +17,8 @@
 // a thread owns an 8(k) x 4(n) patch, loads it as eight float4 and writes four 16-byte rows.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "gemm_epilogue.h"
 
@@ -534,16 +536,25 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_tr_kernel(Gemm16A
 #pragma unroll
     for (int t = 0; t < NTL; ++t) b_off[t] = IMG + (8 * lh + (l16 >> 2)) * RB + swz_col(wn * WTN + t * 32 + 16 * grp + 4 * (l16 & 3));
 
-    using v4s = __attribute__((ext_vector_type(4))) short;
-    auto frag = [&](const unsigned char* S, int off, int s) -> bf16x8 {
+    // The transposing reads are issued as inline asm.  Through the builtin the compiler cannot tell them from a read of the
+    // stage the DMA is filling and drains vmcnt(0) in front of the first one -- i.e. it waits for the tile it has JUST requested,
+    // and the loop ran DMA and MFMAs strictly one after the other.  The price is hand-placed lgkmcnt waits (tied to the fragment
+    // registers through "+v" operands so that the MFMAs cannot move above them).  The compiler's own lgkmcnt bookkeeping stays
+    // safe: LDS operations complete in order, so extra operations in flight only make its waits longer, never too short.
+    using v2u = __attribute__((ext_vector_type(2))) unsigned;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem16;
+    auto frag = [&](unsigned stage, int off, int s) -> bf16x8 {
         // rows 16 s + 8 lh + {0..3} and + {4..7}: the two halves of the 8-deep k run this lane supplies
-        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(S + off + (16 * s) * RB));
-        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(S + off + (16 * s + 4) * RB));
-        union { v4s h[2]; bf16x8 v; } u;
+        v2u lo, hi;
+        const unsigned a0 = stage + (unsigned)off + (unsigned)(16 * s) * RB;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(a0));      // + 4 rows of 256 bytes
+        union { v2u h[2]; bf16x8 v; } u;
         u.h[0] = lo;
         u.h[1] = hi;
         return u.v;
     };
+    static_assert(4 * RB == 1024, "the asm offset above is 4 LDS rows");
 
     f32x16 acc[MT][NTL];
 #pragma unroll
@@ -553,8 +564,9 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_tr_kernel(Gemm16A
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    constexpr int NREADS = 2 * (MT + NTL);      // ds_read instructions per k-step
     auto compute = [&](int buf) {
-        const unsigned char* S = smem16 + buf * STAGE;
+        const unsigned S = lds0 + (unsigned)buf * STAGE;
         bf16x8 a[2][MT], b[2][NTL];
         auto read_frags = [&](int s, int slot) {
 #pragma unroll
@@ -562,17 +574,22 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_tr_kernel(Gemm16A
 #pragma unroll
             for (int t = 0; t < NTL; ++t) b[slot][t] = frag(S, b_off[t], s);
         };
+        static_assert(MT == 2 && NTL == 1, "the operand lists of the waits below are written for 2 x 1 fragments");
         read_frags(0, 0);
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
-            if (s + 1 < BK / 16) read_frags(s + 1, (s + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
+            // wait until only the next step's reads are outstanding, and pin this step's fragments behind the wait
+            if (s + 1 < BK / 16) {
+                read_frags(s + 1, (s + 1) & 1);
+                asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a[s & 1][0]), "+v"(a[s & 1][1]), "+v"(b[s & 1][0]) : "n"(NREADS));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[s & 1][0]), "+v"(a[s & 1][1]), "+v"(b[s & 1][0]));
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NTL; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1][mt], b[s & 1][nt], acc[mt][nt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -597,17 +614,14 @@ int launch_tr16(Gemm16Args& g, int nbatch, hipStream_t s) {
     constexpr size_t LDS = 2 * 2 * BK * 256;
     g.tiles_m = g.M / 128;
     g.tiles_n = g.N / 128;
-    static int waves8 = -1;
-    if (waves8 < 0) { const char* e = getenv("W2V2_GEMM16_TR_WAVES"); waves8 = e ? (atoi(e) == 8) : 1; }      // tuning knob (8 waves: 49.6 ms per step, 4: 49.9)
+    // 8 waves (2 x 4, 64 x 32 each): 49.6 ms per step against 49.9 with 4 waves of 64 x 64 when this kernel was introduced
     static std::atomic<bool> attr_set{false};   // (idempotent call; atomic so concurrent host threads agree on the flag)
     if (!attr_set) {
         W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_tr_kernel<2, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_tr_kernel<2, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         attr_set = true;
     }
     dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch);
-    if (waves8) hipLaunchKernelGGL((gemm_bf16_tr_kernel<2, 4, 2>), grid, dim3(512), LDS, s, g);
-    else hipLaunchKernelGGL((gemm_bf16_tr_kernel<2, 2, 2>), grid, dim3(256), LDS, s, g);
+    hipLaunchKernelGGL((gemm_bf16_tr_kernel<2, 4, 2>), grid, dim3(512), LDS, s, g);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
