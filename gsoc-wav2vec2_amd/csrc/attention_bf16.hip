@@ -469,7 +469,8 @@ __global__ __launch_bounds__(256, 3) void attention_bf16_bwd_dq_kernel(Attn16Bwd
 // ---- dK, dV: block = 4 waves x 32 keys; streams 64-query tiles of Q and dO (+ lse, D as two 64-float rows) ----
 template <bool BITS>
 __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16BwdArgs a, AttnTrain tr) {
-    constexpr int STAGE = 2 * IMG + 2 * KT * 4 + (BITS ? NW * 2 * KT * 4 : 0);      // Q, dO images; lse, D; per wave: 2 x 64 keep words
+    constexpr int WROW = KT + 4;      // keep words per (wave, lh) row, padded: the two rows a lane group reads land on different banks
+    constexpr int STAGE = 2 * IMG + 2 * KT * 4 + (BITS ? NW * 2 * WROW * 4 : 0);      // Q, dO images; lse, D; per wave: 2 rows of keep words
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_a16[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int work = xcd_work(blockIdx.x, a.nwork);
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
 #pragma unroll
             for (int f = 0; f < 2; ++f)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbits + f * Tq + tile * KT + lane),
-                                                 (__attribute__((address_space(3))) void*)(S + 2 * IMG + 2 * KT * 4 + (2 * wave + f) * KT * 4), 4,
+                                                 (__attribute__((address_space(3))) void*)(S + 2 * IMG + 2 * KT * 4 + (2 * wave + f) * WROW * 4), 4,
                                                  0, 0);
         }
     };
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
         const unsigned char* Qs = smem_a16 + buf * STAGE;
         const unsigned char* Os = Qs + IMG;
         const float* Ls = reinterpret_cast<const float*>(Qs + 2 * IMG);      // [0, KT): lse, [KT, 2KT): D
-        const uint32_t* Ws = reinterpret_cast<const uint32_t*>(Qs + 2 * IMG + 2 * KT * 4) + (2 * wave + kb_half) * KT;
+        const uint32_t* Ws = reinterpret_cast<const uint32_t*>(Qs + 2 * IMG + 2 * KT * 4) + (2 * wave + kb_half) * WROW;
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             f32x16 s, dp;
@@ -680,7 +681,7 @@ int launch_attention_bwd_bf16(const float* qkv, const uint16_t* qkv16, const int
     Attn16BwdArgs a{q16, frame_len, do16, dvec, fuse_d ? ctx : nullptr, fuse_d ? dctx : nullptr, dqkv, dqkv16, colpart, B, T, H, heads,
                     nqb, nqb * heads * B};
     const bool bits = tr.keep_bits && tr.p > 0.f;
-    size_t lds_q = 2 * 2 * IMG, lds_kv = 2 * (2 * IMG + 2 * KT * 4 + (bits ? NW * 2 * KT * 4 : 0));
+    size_t lds_q = 2 * 2 * IMG, lds_kv = 2 * (2 * IMG + 2 * KT * 4 + (bits ? NW * 2 * (KT + 4) * 4 : 0));
     if (colpart) {
         if (lds_q < (size_t)COLSUM_LDS) lds_q = COLSUM_LDS;
         if (lds_kv < (size_t)COLSUM_LDS) lds_kv = COLSUM_LDS;
