@@ -19,7 +19,7 @@
 namespace w2v2 {
 namespace {
 
-constexpr int CTC_THREADS = 256;
+constexpr int CTC_THREADS = 576;     // >= 2 U + 1 = 513 extended states at U = 256: one state per thread and recursion step (256: 0.77 ms at T = 768, B = 32)
 constexpr double NEG_INF = -1e300;   // finite sentinel: keeps (a - m) well-defined
 
 // log(sum exp) of two / three fp64 states.  The state values and the running sums stay fp64 (the loss adds ~768
