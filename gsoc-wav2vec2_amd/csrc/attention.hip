@@ -125,7 +125,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a, AttnTrai
     float m_run = -INFINITY, l_run = 0.f;
     // dropout hash inputs hoisted out of the tile loop: element index = ((b h + head) T + q) T + key, modulo 2^32
     const uint32_t drop_key = TRAIN ? dropout_key(tr.seed, tr.stream) : 0u, drop_thr = TRAIN ? dropout_threshold(tr.p) : 0u;
-    const uint32_t drop_row = (uint32_t)((((uint64_t)b * a.heads + head) * a.T + (uint64_t)min(q0 + li, a.T - 1)) * a.T);
+    const uint32_t drop_row = (uint32_t)((((uint64_t)b * a.heads + head) * a.T + (uint64_t)min(q0 + li, a.T - 1)) * attention_drop_stride(a.T));
 
     const int ntiles = (a.T + KT - 1) / KT;
     issue_tile(0, 0);
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(AttnBwdArgs a, At
     const int64_t sidx = ((int64_t)b * a.heads + head) * a.T + qr;
     const float lse = tr.lse[sidx], dv = a.dvec[sidx];
     const float inv = tr.p > 0.f ? 1.0f / (1.0f - tr.p) : 1.0f;
-    const uint64_t rowbase = (uint64_t)sidx * a.T;
+    const uint64_t rowbase = (uint64_t)sidx * attention_drop_stride(a.T);
     const uint32_t drop_key = dropout_key(tr.seed, tr.stream), drop_thr = dropout_threshold(tr.p);
 
     f32x16 dq[DT];
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(AttnBwdArgs a, A
     }
     const float inv = tr.p > 0.f ? 1.0f / (1.0f - tr.p) : 1.0f;
     const int64_t bh = (int64_t)b * a.heads + head;
-    const uint32_t drop_col = (uint32_t)((uint64_t)bh * a.T * a.T) + (uint32_t)kr;
+    const uint32_t drop_col = (uint32_t)((uint64_t)bh * a.T * attention_drop_stride(a.T)) + (uint32_t)kr;
 
     f32x16 dk[DT], dvv[DT];
 #pragma unroll
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(AttnBwdArgs a, A
             // (columns of keys >= T are clamped duplicates whose results are never stored, so only the QUERY bound
             // needs masking, and only on the last tile)
             const bool qtail = t0 + KT > a.T;
-            const uint32_t didx = drop_col + (uint32_t)(t0 + qt * 32 + 4 * lh) * (uint32_t)a.T;   // ((bh T + q) T + key) mod 2^32
+            const uint32_t didx = drop_col + (uint32_t)(t0 + qt * 32 + 4 * lh) * attention_drop_stride(a.T);   // ((bh T + q) T + key) mod 2^32
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ql = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(AttnBwdArgs a, A
                 if (qtail) pv = t0 + ql < a.T ? pv : 0.f;
                 float g = dp[r], pd = pv;
                 if (tr.p > 0.f) {
-                    const bool keep = dropout_keep32(drop_key, didx + (uint32_t)((r & 3) + 8 * (r >> 2)) * (uint32_t)a.T, drop_thr);
+                    const bool keep = dropout_keep32(drop_key, didx + (uint32_t)((r & 3) + 8 * (r >> 2)) * attention_drop_stride(a.T), drop_thr);
                     g = keep ? g : 0.f;
                     pd = keep ? pv * inv : 0.f;
                 }

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attention_bf16_kernel(Attn16Args a
     float m_run = -INFINITY, l_run = 0.f;     // running max (of the UNSCALED scores) and sum
     // dropout hash inputs hoisted out of the tile loop: element index = ((b h + head) T + q) T + key, modulo 2^32
     const uint32_t drop_key = TRAIN ? dropout_key(tr.seed, tr.stream) : 0u, drop_thr = TRAIN ? dropout_threshold(tr.p) : 0u;
-    const uint32_t drop_row = (uint32_t)(((uint64_t)bh * a.T + (uint64_t)min(q0 + li, a.T - 1)) * a.T);
+    const uint32_t drop_row = (uint32_t)(((uint64_t)bh * a.T + (uint64_t)min(q0 + li, a.T - 1)) * attention_drop_stride(a.T));
     const int xr = swz(li);                   // swizzle of this lane's fragment rows (sub * 32 + li: the sub-tile does not change it)
 
     const int ntiles = (a.T + KT - 1) / KT;
@@ -234,16 +234,19 @@ __global__ __launch_bounds__(NW * 64, 3) void attention_bf16_kernel(Attn16Args a
         if (TRAIN && tr.p > 0.f) {
             // attention-probability dropout (encoder.py:42-44): the row sum above uses the un-dropped p; the
             // 1 / (1 - p) factor is applied once, with the final normalisation
-            const uint32_t cbase = drop_row + (uint32_t)k0;
+            const uint32_t cbase = drop_row + (uint32_t)k0, thr1 = drop_thr - 1u;      // h >= thr  <=>  thr - 1 - h < 0 (16-bit h, thr)
             uint32_t bits = 0;                  // bit 16 kt + r = the keep decision of accumulator register r of sub-tile kt
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int r = 0; r < 16; r += 2) {      // registers r, r + 1 are keys 2j, 2j + 1 of an even-strided row: one hash word
                     const uint32_t col = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const bool keep = dropout_keep32(drop_key, cbase + col, drop_thr);
-                    s[kt][r] = keep ? s[kt][r] : 0.f;
-                    bits |= keep ? (1u << (16 * kt + r)) : 0u;
+                    const uint32_t w = dropout_word(drop_key, (cbase + col) >> 1);
+                    // all-ones / zero masks by integer arithmetic (sign of thr - 1 - h), applied with AND: no lane masks in SGPRs
+                    const uint32_t me = (uint32_t)((int32_t)(thr1 - (w & 0xFFFFu)) >> 31), mo = (uint32_t)((int32_t)(thr1 - (w >> 16)) >> 31);
+                    s[kt][r] = __uint_as_float(__float_as_uint(s[kt][r]) & me);
+                    s[kt][r + 1] = __uint_as_float(__float_as_uint(s[kt][r + 1]) & mo);
+                    bits |= (me & (1u << (16 * kt + r))) | (mo & (2u << (16 * kt + r)));
                 }
             if (tr.keep_bits) tr.keep_bits[keep_word(bh, tile, lh, a.nqb) + q0 + li] = bits;
         }
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(256, 3) void attention_bf16_bwd_dq_kernel(Attn16Bwd
         dv = a.dvec[sidx];
     }
     const float inv = tr.p > 0.f ? 1.0f / (1.0f - tr.p) : 1.0f;
-    const uint64_t rowbase = (uint64_t)sidx * a.T;
+    const uint64_t rowbase = (uint64_t)sidx * attention_drop_stride(a.T);
     const uint32_t drop_key = dropout_key(tr.seed, tr.stream), drop_thr = dropout_threshold(tr.p);
     const int xr = swz(li);
 
@@ -521,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
     load_col_frags(kf, base + kr * ld + a.H + 8 * lh);
     load_col_frags(vf, base + kr * ld + 2 * a.H + 8 * lh);
     const float inv = tr.p > 0.f ? 1.0f / (1.0f - tr.p) : 1.0f;
-    const uint32_t drop_col = (uint32_t)((uint64_t)bh * a.T * a.T) + (uint32_t)kr;
+    const uint32_t drop_col = (uint32_t)((uint64_t)bh * a.T * attention_drop_stride(a.T)) + (uint32_t)kr;
     const int xr = swz(li);
 
     f32x16 dk[2], dvv[2];
@@ -555,7 +558,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
             // (columns of keys >= T are clamped duplicates whose results are never stored, so only the QUERY bound
             // needs masking, and only on the last tile)
             const bool qtail = t0 + KT > a.T;
-            uint32_t didx = drop_col + (uint32_t)(t0 + qt * 32 + 4 * lh) * (uint32_t)a.T;   // ((bh T + q) T + key) mod 2^32
+            uint32_t didx = drop_col + (uint32_t)(t0 + qt * 32 + 4 * lh) * attention_drop_stride(a.T);   // ((bh T + q) T + key) mod 2^32
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ql = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
                 float g = dp[r], pd = pv;
                 if (BITS || tr.p > 0.f) {
                     const bool keep = BITS ? ((Ws[ql] >> kb_bit) & 1u) != 0u
-                                           : dropout_keep32(drop_key, didx + (uint32_t)((r & 3) + 8 * (r >> 2)) * (uint32_t)a.T, drop_thr);
+                                           : dropout_keep32(drop_key, didx + (uint32_t)((r & 3) + 8 * (r >> 2)) * attention_drop_stride(a.T), drop_thr);
                     g = keep ? g : 0.f;
                     pd = keep ? pv * inv : 0.f;
                 }

@@ -15,15 +15,17 @@ enum DropStream : uint32_t {
 };
 
 #ifdef __HIPCC__
-// keep(seed, stream, idx, p): counter-based hash, 32-bit arithmetic only (the attention kernels evaluate it
-// once per score; the first version used 64-bit splitmix per element, ~40 VALU ops, this is ~10):
-//   k   = low 32 bits of splitmix64(seed ^ stream * GOLD)                     -- loop-invariant
-//   h   = lowbias32(lo32(idx) * 0x9E3779B1 ^ k)   (Fibonacci pre-multiply spreads the sequential counter, then a
+// keep(seed, stream, idx, p): counter-based hash, 32-bit arithmetic only (the attention forward evaluates it once per
+// score; the first version used 64-bit splitmix per element, ~40 VALU ops; one lowbias32 per element ~16; now one per PAIR):
+//   k    = low 32 bits of splitmix64(seed ^ stream * GOLD)                    -- loop-invariant
+//   w    = lowbias32(lo32(idx >> 1) * 0x9E3779B1 ^ k)   (Fibonacci pre-multiply spreads the sequential counter, then a
 //                                               bijective multiply-xorshift mixer; lagged mask correlations < 1e-3)
-//   keep = h >= floor(p * 2^32)
-// The element index enters modulo 2^32: a mask pattern repeats after 4.29e9 elements of one tensor (the largest
-// here, the (B, heads, T, T) probabilities at B=16, T=1499, has 5.8e8).  Same integer function as
-// wav2vec2/variables.py::dropout_keep.
+//   keep = (idx odd ? w >> 16 : w & 0xFFFF) >= floor(p * 2^16)       -- the two 16-bit halves decide elements 2j and 2j + 1
+// The two quarter-rate 32-bit multiplies of the mixer are the expensive part on gfx950, so one hash word serves two
+// elements; p is realised to 2^-16 (0.1 -> 0.1000061).  The index enters modulo 2^32 (a pattern repeats after 8.6e9
+// elements of one tensor).  Attention probabilities index their (B heads T, T) matrix with the row stride rounded up to
+// even (attention_drop_stride), so that a pair never straddles two query rows.  Same integer function as
+// wav2vec2/variables.py::dropout_keep / attention_keep.
 __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
@@ -34,13 +36,20 @@ __device__ __forceinline__ uint32_t dropout_key(uint64_t seed, uint32_t stream) 
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     return (uint32_t)(z ^ (z >> 31));
 }
-__device__ __forceinline__ uint32_t dropout_threshold(float p) {
-    return (uint32_t)((double)p * 4294967296.0);
+__device__ __forceinline__ uint32_t dropout_threshold(float p) {      // 16-bit threshold
+    return (uint32_t)((double)p * 65536.0);
 }
-// fast form for inner loops: key and threshold hoisted by the caller, 32-bit index
+// the hash word of element pair (2 pair, 2 pair + 1): low half decides the even element, high half the odd one
+__device__ __forceinline__ uint32_t dropout_word(uint32_t key, uint32_t pair) { return lowbias32(pair * 0x9E3779B1u ^ key); }
+__device__ __forceinline__ bool dropout_keep_lo(uint32_t w, uint32_t thr) { return (w & 0xFFFFu) >= thr; }
+__device__ __forceinline__ bool dropout_keep_hi(uint32_t w, uint32_t thr) { return (w >> 16) >= thr; }
+// general form (one hash per call): key and threshold hoisted by the caller, 32-bit index
 __device__ __forceinline__ bool dropout_keep32(uint32_t key, uint32_t idx, uint32_t thr) {
-    return lowbias32(idx * 0x9E3779B1u ^ key) >= thr;
+    const uint32_t w = dropout_word(key, idx >> 1);
+    return ((idx & 1u) ? (w >> 16) : (w & 0xFFFFu)) >= thr;
 }
+// row stride of the attention-probability index space: T rounded up to even
+__device__ __forceinline__ uint32_t attention_drop_stride(int T) { return (uint32_t)(T + (T & 1)); }
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t stream, uint64_t idx, float p) {
     return dropout_keep32(dropout_key(seed, stream), (uint32_t)idx, dropout_threshold(p));
 }

@@ -63,7 +63,11 @@ __global__ void dropout_fwd_kernel(const float* __restrict__ x, const float* __r
             float v[4] = {apply_act(xv.x, act), apply_act(xv.y, act), apply_act(xv.z, act), apply_act(xv.w, act)};
             if (p > 0.f) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = dropout_keep32(key, (uint32_t)(4 * i + e), thr) ? v[e] * inv : 0.0f;
+                for (int e = 0; e < 4; e += 2) {       // elements 4 i + e, + 1 share one hash word
+                    const uint32_t w = dropout_word(key, ((uint32_t)(4 * i) >> 1) + (e >> 1));
+                    v[e] = dropout_keep_lo(w, thr) ? v[e] * inv : 0.0f;
+                    v[e + 1] = dropout_keep_hi(w, thr) ? v[e + 1] * inv : 0.0f;
+                }
             }
             if (res) {
                 const float4 r = reinterpret_cast<const float4*>(res)[i];
@@ -97,7 +101,11 @@ __global__ void dropout_bwd_kernel(const float* __restrict__ u, const float* __r
             float g[4] = {gv.x, gv.y, gv.z, gv.w};
             if (p > 0.f) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] = dropout_keep32(key, (uint32_t)(4 * i + e), thr) ? g[e] * inv : 0.0f;
+                for (int e = 0; e < 4; e += 2) {
+                    const uint32_t w = dropout_word(key, ((uint32_t)(4 * i) >> 1) + (e >> 1));
+                    g[e] = dropout_keep_lo(w, thr) ? g[e] * inv : 0.0f;
+                    g[e + 1] = dropout_keep_hi(w, thr) ? g[e + 1] * inv : 0.0f;
+                }
             }
             if (act) {
                 const float4 uv = reinterpret_cast<const float4*>(u)[i];
@@ -140,7 +148,11 @@ __global__ __launch_bounds__(256) void dropout_bwd_colsum_kernel(const float* __
             float g[4] = {gv.x, gv.y, gv.z, gv.w};
             if (p > 0.f) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] = dropout_keep32(key, (uint32_t)(i + e), thr) ? g[e] * inv : 0.0f;
+                for (int e = 0; e < 4; e += 2) {       // i = r cols + c is a multiple of 4
+                    const uint32_t w = dropout_word(key, ((uint32_t)i >> 1) + (e >> 1));
+                    g[e] = dropout_keep_lo(w, thr) ? g[e] * inv : 0.0f;
+                    g[e + 1] = dropout_keep_hi(w, thr) ? g[e + 1] * inv : 0.0f;
+                }
             }
             if (act) {
                 const float4 uv = *reinterpret_cast<const float4*>(u + i);

@@ -256,18 +256,27 @@ def _lowbias32(x):
 
 
 def dropout_hash(seed, stream, n, start=0):
-    """uint32 hash per element index, identical to csrc/train.h (integer arithmetic only): one lowbias32 round
-    over ((index mod 2^32) * 0x9E3779B1) xor a per-(seed, stream) key."""
+    """16-bit hash value per element index, identical to csrc/train.h (integer arithmetic only): elements 2j and 2j + 1 share
+    one lowbias32 word over ((j mod 2^31) * 0x9E3779B1) xor a per-(seed, stream) key -- the low half belongs to the even
+    element, the high half to the odd one."""
     key0 = np.array([(int(seed) ^ ((int(stream) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF],
                     dtype=np.uint64)
     key = np.uint32(int(_splitmix64(key0)[0]) & 0xFFFFFFFF)
     idx = np.arange(start, start + n, dtype=np.uint64)
     lo = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
     with np.errstate(over="ignore"):
-        return _lowbias32((lo * np.uint32(0x9E3779B1)) ^ key)
+        w = _lowbias32(((lo >> np.uint32(1)) * np.uint32(0x9E3779B1)) ^ key)
+    return np.where((lo & np.uint32(1)) != 0, w >> np.uint32(16), w & np.uint32(0xFFFF)).astype(np.uint32)
 
 
 def dropout_keep(seed, stream, n, p):
-    """Boolean keep mask: element kept iff hash >= floor(p * 2^32) (then scaled by 1 / (1 - p))."""
-    thr = np.uint32(min(int(float(np.float32(p)) * 4294967296.0), 0xFFFFFFFF))
+    """Boolean keep mask: element kept iff its 16-bit hash value >= floor(p * 2^16) (then scaled by 1 / (1 - p))."""
+    thr = np.uint32(min(int(float(np.float32(p)) * 65536.0), 0xFFFF))
     return dropout_hash(seed, stream, n) >= thr
+
+
+def attention_keep(seed, stream, rows, T, p):
+    """Keep mask of the attention probabilities, (rows, T) with rows = B * heads * T queries: the element index space has the
+    row stride T rounded up to even, so that a hash word never straddles two query rows (csrc/train.h::attention_drop_stride)."""
+    T2 = T + (T & 1)
+    return dropout_keep(seed, stream, rows * T2, p).reshape(rows, T2)[:, :T]

@@ -113,7 +113,9 @@ def train_forward(config, w, wave, attention_mask=None, p=0.0, seed=0, spec_mask
         if add_mask is not None:
             s = s + add_mask
         pr = torch.softmax(s, -1)
-        pr = _drop(pr, p, seed, V.layer_stream(i, 0))
+        if p > 0.0:     # attention probabilities: index space with an even row stride (V.attention_keep)
+            keep = torch.from_numpy(np.ascontiguousarray(V.attention_keep(seed, V.layer_stream(i, 0), pr.numel() // T, T, p)).reshape(tuple(pr.shape)))
+            pr = torch.where(keep, pr / (1.0 - p), torch.zeros_like(pr))
         ctx = (pr @ v).transpose(1, 2).reshape(B, T, H)
         o = _mm(ctx, w[f"{b}/attention/out_proj/kernel"]) + w[f"{b}/attention/out_proj/bias"]
         x = _drop(o, p, seed, V.layer_stream(i, 1)) + res

@@ -99,7 +99,7 @@ def test_attention_train_forward_backward(env, B, T, Hh, heads, p, flen):
     pr = torch.softmax(s, -1)
     lse_ref = torch.logsumexp(s, -1).detach().numpy()
     if p > 0:
-        keep = torch.from_numpy(V.dropout_keep(seed, stream, B * heads * T * T, p).reshape(B, heads, T, T))
+        keep = torch.from_numpy(np.ascontiguousarray(V.attention_keep(seed, stream, B * heads * T, T, p)).reshape(B, heads, T, T))
         pr = torch.where(keep, pr / (1 - p), torch.zeros_like(pr))
     ctx_ref = (pr @ v).transpose(1, 2).reshape(B, T, Hh)
     ctx_ref.backward(torch.from_numpy(dctx.astype(np.float64)))
@@ -147,7 +147,7 @@ def test_attention_train_forward_backward_bf16(env, B, T, Hh, heads, p, flen):
     pr = torch.softmax(s, -1)
     lse_ref = torch.logsumexp(s, -1).detach().numpy()
     if p > 0:
-        keep = torch.from_numpy(V.dropout_keep(seed, stream, B * heads * T * T, p).reshape(B, heads, T, T))
+        keep = torch.from_numpy(np.ascontiguousarray(V.attention_keep(seed, stream, B * heads * T, T, p)).reshape(B, heads, T, T))
         pr = torch.where(keep, pr / (1 - p), torch.zeros_like(pr))
     ctx_ref = (pr @ v).transpose(1, 2).reshape(B, T, Hh)
     ctx_ref.backward(torch.from_numpy(dctx.astype(np.float64)))
@@ -178,6 +178,37 @@ def test_attention_train_forward_backward_bf16(env, B, T, Hh, heads, p, flen):
         scale = max(1.0, np.abs(ref[:, :, sl]).max())
         print(f"   {name}: max err {err.max():.3e}, mean err {err.mean():.3e}, max|ref| {scale:.3f}")
         assert err.max() < 1e-2 * scale and err.mean() < 1e-3 * scale, f"{name}: {err.max():.3e}"
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_attention_train_is_bitwise_reproducible(env, precision):
+    """The same launch 25 times gives the same bits (forward ctx / lse, backward dqkv).  Regression guard: a first version of
+    the paired dropout decisions (32 lane masks alive at once in the bf16 forward) produced run-to-run differences on gfx950."""
+    lib, torch, dev = env
+    B, T, Hh, heads, p, seed, stream = 2, 150, 128, 2, 0.5, 7, V.layer_stream(1, 0)
+    tq = dev_t(torch, dev, rnd("attn/repro", (B, T, 3 * Hh)))
+    td = dev_t(torch, dev, rnd("attn/repro_d", (B, T, Hh)))
+    N.check(lib.w2v2_op_set_precision(precision))
+    try:
+        first = None
+        for it in range(25):
+            ctx = torch.zeros((B, T, Hh), device=dev)
+            lse = torch.zeros((B, heads, T), device=dev)
+            dqkv = torch.zeros((B, T, 3 * Hh), device=dev)
+            ws = torch.empty((B, heads, T), device=dev)
+            N.check(lib.w2v2_op_attention_train(N.ptr(tq), None, N.ptr(ctx), N.ptr(lse), B, T, Hh, heads, p, C.c_uint64(seed), stream,
+                                                N.current_stream()))
+            N.check(lib.w2v2_op_attention_bwd(N.ptr(tq), None, N.ptr(ctx), N.ptr(lse), N.ptr(td), N.ptr(dqkv), N.ptr(ws), B, T, Hh, heads, p,
+                                              C.c_uint64(seed), stream, N.current_stream()))
+            torch.cuda.synchronize()
+            got = (ctx.cpu().numpy(), lse.cpu().numpy(), dqkv.cpu().numpy())
+            if first is None:
+                first = got
+            else:
+                for a, b, name in zip(got, first, ("ctx", "lse", "dqkv")):
+                    assert np.array_equal(a, b), f"run {it}: {name} differs in {int((a != b).sum())} elements"
+    finally:
+        N.check(lib.w2v2_op_set_precision(0))
 
 
 # ------------------------------------------------------------------ whole step ---------------
