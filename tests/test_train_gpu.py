@@ -630,6 +630,32 @@ def _ragged_labels(B, U, lo, hi, seed):
     return labels
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_train_step_is_bitwise_reproducible(env, precision):
+    """Forward + loss + backward of the same batch with the same seeds, five times: identical logits and an identical flat
+    gradient buffer (no atomics on floats anywhere, fixed reduction orders, dropout from counters)."""
+    import wav2vec2
+    m, cfg, w = build("base_sample", 46797)
+    m.set_precision(precision)
+    x = V.hash_normal("train/repro", 2 * 46797, 8).reshape(2, 46797)
+    labels = _ragged_labels(2, 64, 10, 40, 3)
+    loss_fn = wav2vec2.CTCLoss(cfg, x.shape, division_factor=2)
+    tr = wav2vec2.Trainer(m, loss_fn, dropout=0.1, apply_spec_augment=False, seed=1)
+    spec = compute_mask_indices((2, cfg.num_frames(46797)), 0.05, 10, rng=np.random.RandomState(4))
+    first = None
+    for it in range(5):
+        logits = tr.forward(x, spec_mask=spec, step_seed=42)
+        nll, dlog = loss_fn.per_sample(labels, logits, with_grad=True)
+        tr.backward(dlog)
+        got = (logits.cpu().numpy().copy(), tr.grad_buffer().cpu().numpy().copy())
+        if first is None:
+            first = got
+        else:
+            assert np.array_equal(got[0], first[0]), f"run {it}: logits differ"
+            assert np.array_equal(got[1], first[1]), f"run {it}: {int((got[1] != first[1]).sum())} gradient elements differ"
+    assert np.isfinite(first[1]).all() and np.abs(first[1]).max() > 0
+
+
 @pytest.mark.parametrize("case,L,frames", [("base_sample_padded", 246000, 768), ("robust_masked", 480000, 1499)])
 def test_bf16_fine_tune_step_at_full_length(env, case, L, frames):
     """BASELINE configs[2] / configs[4] at their real sequence lengths on a 2-row batch: base (12 L / 768) at 2 x 246000
