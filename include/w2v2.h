@@ -163,7 +163,8 @@ int w2v2_ctc_loss(const float* logits_dev, int32_t B, int32_t T, int32_t V,
  *
  * w2v2_train_forward: Wav2Vec2ForCTC.call(training=True): Dropout(p) at every Dropout layer
  *   (feature_extractor.py:95; encoder.py:42-44,118,128,270; modeling.py:253) with masks from a
- *   counter-based hash of (seed, site, element) -- never stored, regenerated in the backward;
+ *   counter-based hash of (seed, site, element) -- regenerated in the backward (the bf16 attention keeps its
+ *   decisions as one bit per score for its own backward); the probability is realised to 2^-16;
  *   spec_mask_host (B*T bytes, or NULL): frames replaced by masked_spec_embed (spec_augment.py:119-127;
  *   the span sampling itself is host-side numpy in the reference and stays on the host here);
  *   sd_keep_host (num_layers floats of 0/1, or NULL): StochasticDepth's one Bernoulli draw per layer
@@ -335,7 +336,8 @@ int w2v2_op_attention_bwd(const float* qkv_dev, const int32_t* frame_len_dev, co
                           int32_t B, int32_t T, int32_t H, int32_t num_heads, float dropout_p,
                           uint64_t seed, uint32_t stream_id, void* stream);
 
-/* y = dropout(act(x)) [+ residual]: keep iff hash(seed, stream_id, index) >= p, kept values / (1 - p). */
+/* y = dropout(act(x)) [+ residual]: keep iff hash16(seed, stream_id, index) >= floor(p 2^16), kept values / (1 - p)
+ * (csrc/train.h, wav2vec2/variables.py::dropout_keep: the same integer function). */
 int w2v2_op_dropout(const float* x_dev, const float* residual_dev, float* y_dev, int64_t n, int32_t act,
                     float p, uint64_t seed, uint32_t stream_id, void* stream);
 
