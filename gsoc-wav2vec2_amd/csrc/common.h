@@ -58,6 +58,8 @@ Profiler* profiler_create();
 void profiler_destroy(Profiler*);
 void profiler_enable(Profiler*, bool on);
 void profiler_set_mask(Profiler*, unsigned family_mask);   // bit f = record family f; 0 = all
+void profiler_set_stride(Profiler*, int stride);           // every stride-th launch of a family gets the event pair
+int64_t profiler_seen(const Profiler*, int family);        // launches since the last reset, sampled or not
 bool profiler_enabled(const Profiler*);
 void profiler_reset(Profiler*);
 // returns a token (>=0) to pass to profiler_end, or -1 when disabled

@@ -45,6 +45,8 @@ struct ProfRec {
 struct Profiler {
     bool enabled = false;
     unsigned mask = 0xFFFFFFFFu;    // families that get an event pair
+    int stride = 1;                 // of a family's launches, every stride-th gets the pair (w2v2_profile_sampling)
+    int64_t seen[32] = {0};         // launches of each family since the last reset, sampled or not
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> pool;   // recycled events
 };
@@ -55,6 +57,7 @@ void profiler_reset(Profiler* p) {
         p->pool.push_back(r.e1);
     }
     p->recs.clear();
+    for (auto& n : p->seen) n = 0;
 }
 void profiler_destroy(Profiler* p) {
     if (!p) return;
@@ -75,8 +78,11 @@ static hipEvent_t prof_event(Profiler* p) {
     (void)hipEventCreate(&e);
     return e;
 }
+void profiler_set_stride(Profiler* p, int stride) { p->stride = stride < 1 ? 1 : stride; }
+int64_t profiler_seen(const Profiler* p, int family) { return p->seen[family & 31]; }
 int profiler_begin(Profiler* p, int family, double flops, double bytes, hipStream_t s) {
     if (!p || !p->enabled || !((p->mask >> family) & 1u)) return -1;
+    if ((p->seen[family & 31]++ % p->stride) != 0) return -1;
     ProfRec r{family, flops, bytes, prof_event(p), prof_event(p)};
     (void)hipEventRecord(r.e0, s);
     p->recs.push_back(r);
@@ -777,6 +783,16 @@ int w2v2_profile_enable(w2v2_model* m, int enable) {
 int w2v2_profile_families(w2v2_model* m, uint32_t family_mask) {
     W2V2_REQUIRE(m, "profile_families: null model");
     profiler_set_mask(m->prof, family_mask);
+    return W2V2_OK;
+}
+int w2v2_profile_sampling(w2v2_model* m, int32_t stride) {
+    W2V2_REQUIRE(m && stride >= 1, "profile_sampling: bad argument");
+    profiler_set_stride(m->prof, stride);
+    return W2V2_OK;
+}
+int w2v2_profile_seen(w2v2_model* m, int index, int64_t* launches) {
+    W2V2_REQUIRE(m && index >= 0 && index < FAM_COUNT && launches, "profile_seen: bad argument");
+    *launches = profiler_seen(m->prof, index);
     return W2V2_OK;
 }
 int w2v2_profile_num_families(void) { return FAM_COUNT; }

@@ -514,9 +514,10 @@ class TFKerasModel(Layer):
                                                N.current_stream()), "w2v2_copy_activation")
         return out
 
-    def profile(self, enable=True, families=None):
+    def profile(self, enable=True, families=None, stride=1):
         """Bracket kernel launches with HIP events; `families` (names as in profile_read) limits the
-        instrumentation to those kernel families, None = all."""
+        instrumentation to those kernel families, None = all; `stride` > 1 samples every stride-th launch of a family."""
+        N.check(self._lib.w2v2_profile_sampling(self._handle, int(stride)), "w2v2_profile_sampling")
         mask = 0
         if families:
             names = []
@@ -542,7 +543,9 @@ class TFKerasModel(Layer):
             ms, fl, by = C.c_double(), C.c_double(), C.c_double()
             N.check(self._lib.w2v2_profile_read(self._handle, i, C.byref(name), C.byref(n), C.byref(ms),
                                                 C.byref(fl), C.byref(by)), "w2v2_profile_read")
-            out[name.value.decode()] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
+            seen = C.c_int64()
+            N.check(self._lib.w2v2_profile_seen(self._handle, i, C.byref(seen)), "w2v2_profile_seen")
+            out[name.value.decode()] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value, issued=seen.value)
         return out
 
     def num_frames(self, num_samples):

@@ -219,6 +219,11 @@ int w2v2_profile_enable(w2v2_model* m, int enable);
  * an event pair costs ~7 us of stream time, so timing ONLY the dominant family keeps the timed region
  * of a benchmark within 1 % of the un-instrumented run. */
 int w2v2_profile_families(w2v2_model* m, uint32_t family_mask);
+/* Sampling: only every stride-th launch of a family gets the event pair (default 1 = every launch).  With a stride coprime to
+ * the number of launches per layer the samples rotate through all shapes; averages stay unbiased, the tax drops by the stride.
+ * w2v2_profile_seen: how many launches of the family were issued since the last reset, sampled or not. */
+int w2v2_profile_sampling(w2v2_model* m, int32_t stride);
+int w2v2_profile_seen(w2v2_model* m, int index, int64_t* launches);
 int w2v2_profile_num_families(void);
 int w2v2_profile_read(w2v2_model* m, int index, const char** name, int64_t* launches,
                       double* total_ms, double* flops, double* bytes);
