@@ -239,6 +239,24 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
     return 0.5f * x + 0.5f * fabsf(x) * erf_abs;             // 0.5 x (1 + sign(x) erf(|x| / sqrt 2))
 }
 
+// gelu_erf_fast on two values at once (v_pk_mul_f32 / v_pk_fma_f32 where the ISA has packed forms; rcp and exp2 stay scalar)
+using f32x2_t = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ f32x2_t gelu_erf_fast2(f32x2_t x) {
+    const f32x2_t ax = {fabsf(x[0]), fabsf(x[1])};
+    const f32x2_t z = ax * f32x2_t{0.70710678118654752440f, 0.70710678118654752440f};
+    const f32x2_t d = __builtin_elementwise_fma(f32x2_t{0.3275911f, 0.3275911f}, z, f32x2_t{1.0f, 1.0f});
+    const f32x2_t t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    f32x2_t q = __builtin_elementwise_fma(f32x2_t{1.061405429f, 1.061405429f}, t, f32x2_t{-1.453152027f, -1.453152027f});
+    q = __builtin_elementwise_fma(q, t, f32x2_t{1.421413741f, 1.421413741f});
+    q = __builtin_elementwise_fma(q, t, f32x2_t{-0.284496736f, -0.284496736f});
+    q = __builtin_elementwise_fma(q, t, f32x2_t{0.254829592f, 0.254829592f});
+    const f32x2_t zz = z * z * f32x2_t{-1.44269504088896340736f, -1.44269504088896340736f};
+    const f32x2_t e = {__builtin_amdgcn_exp2f(zz[0]), __builtin_amdgcn_exp2f(zz[1])};
+    const f32x2_t erf_abs = __builtin_elementwise_fma(-(q * t), e, f32x2_t{1.0f, 1.0f});
+    const f32x2_t half = {0.5f, 0.5f};
+    return __builtin_elementwise_fma(half * ax, erf_abs, half * x);
+}
+
 // act: 0 none, 1 exact GELU (erff), 2 tanh GELU, 3 exact GELU through gelu_erf_fast (element-wise kernels in precision mode 1)
 __device__ __forceinline__ float apply_act(float x, int act) {
     return act == 1 ? gelu_erf(x) : (act == 2 ? gelu_tanh(x) : (act == 3 ? gelu_erf_fast(x) : x));

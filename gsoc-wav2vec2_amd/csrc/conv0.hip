@@ -176,23 +176,8 @@ __global__ __launch_bounds__(256) void conv0_apply4_kernel(Conv0Args a, int tpr 
                 ya = __builtin_elementwise_fma(xx, f2{w[k][0], w[k][1]}, ya);
                 yb = __builtin_elementwise_fma(xx, f2{w[k][2], w[k][3]}, yb);
             }
-            auto gelu2 = [](f2 x) -> f2 {
-                const f2 ax = {fabsf(x[0]), fabsf(x[1])};
-                const f2 z = ax * f2{0.70710678118654752440f, 0.70710678118654752440f};
-                const f2 d = __builtin_elementwise_fma(f2{0.3275911f, 0.3275911f}, z, f2{1.0f, 1.0f});
-                const f2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-                f2 q = __builtin_elementwise_fma(f2{1.061405429f, 1.061405429f}, t, f2{-1.453152027f, -1.453152027f});
-                q = __builtin_elementwise_fma(q, t, f2{1.421413741f, 1.421413741f});
-                q = __builtin_elementwise_fma(q, t, f2{-0.284496736f, -0.284496736f});
-                q = __builtin_elementwise_fma(q, t, f2{0.254829592f, 0.254829592f});
-                const f2 zz = z * z * f2{-1.44269504088896340736f, -1.44269504088896340736f};
-                const f2 e = {__builtin_amdgcn_exp2f(zz[0]), __builtin_amdgcn_exp2f(zz[1])};
-                const f2 erf_abs = __builtin_elementwise_fma(-(q * t), e, f2{1.0f, 1.0f});
-                const f2 half = {0.5f, 0.5f};
-                return __builtin_elementwise_fma(half * ax, erf_abs, half * x);
-            };
-            ya = gelu2(__builtin_elementwise_fma(ya, f2{sc[0], sc[1]}, f2{sh[0], sh[1]}));
-            yb = gelu2(__builtin_elementwise_fma(yb, f2{sc[2], sc[3]}, f2{sh[2], sh[3]}));
+            ya = gelu_erf_fast2(__builtin_elementwise_fma(ya, f2{sc[0], sc[1]}, f2{sh[0], sh[1]}));
+            yb = gelu_erf_fast2(__builtin_elementwise_fma(yb, f2{sc[2], sc[3]}, f2{sh[2], sh[3]}));
             y = f32x4_c0{ya[0], ya[1], yb[0], yb[1]};
         } else {
 #pragma unroll

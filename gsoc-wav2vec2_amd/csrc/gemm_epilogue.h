@@ -34,7 +34,16 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16_t (&acc)[MT][NTL], fl
             for (int r = 0; r < 16; ++r) v[r] += bv;
             if (act == 1) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = FAST_GELU ? gelu_erf_fast(v[r]) : gelu_erf(v[r]);
+                for (int r = 0; r < 16; r += 2) {
+                    if (FAST_GELU) {
+                        const f32x2_t g = gelu_erf_fast2(f32x2_t{v[r], v[r + 1]});
+                        v[r] = g[0];
+                        v[r + 1] = g[1];
+                    } else {
+                        v[r] = gelu_erf(v[r]);
+                        v[r + 1] = gelu_erf(v[r + 1]);
+                    }
+                }
             } else if (act == 2) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = gelu_tanh(v[r]);
