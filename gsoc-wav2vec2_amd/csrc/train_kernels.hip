@@ -49,6 +49,23 @@ __device__ __forceinline__ float gelu_grad(float u, int act) {
     return 1.0f;
 }
 
+// gelu_grad(., 3) on two values at once (packed fp32 multiply / fma; rcp and exp2 stay scalar)
+__device__ __forceinline__ f32x2_t gelu_grad_fast2(f32x2_t u) {
+    const f32x2_t au = {fabsf(u[0]), fabsf(u[1])};
+    const f32x2_t z = au * f32x2_t{0.70710678118654752440f, 0.70710678118654752440f};
+    const f32x2_t d = __builtin_elementwise_fma(f32x2_t{0.3275911f, 0.3275911f}, z, f32x2_t{1.0f, 1.0f});
+    const f32x2_t t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    f32x2_t q = __builtin_elementwise_fma(f32x2_t{1.061405429f, 1.061405429f}, t, f32x2_t{-1.453152027f, -1.453152027f});
+    q = __builtin_elementwise_fma(q, t, f32x2_t{1.421413741f, 1.421413741f});
+    q = __builtin_elementwise_fma(q, t, f32x2_t{-0.284496736f, -0.284496736f});
+    q = __builtin_elementwise_fma(q, t, f32x2_t{0.254829592f, 0.254829592f});
+    const f32x2_t zz = z * z * f32x2_t{-1.44269504088896340736f, -1.44269504088896340736f};
+    const f32x2_t e = {__builtin_amdgcn_exp2f(zz[0]), __builtin_amdgcn_exp2f(zz[1])};        // exp(-u^2 / 2)
+    const f32x2_t herf = __builtin_elementwise_fma(-(q * t), e, f32x2_t{1.0f, 1.0f}) * f32x2_t{0.5f, 0.5f};
+    const f32x2_t cdf = {0.5f + copysignf(herf[0], u[0]), 0.5f + copysignf(herf[1], u[1])};
+    return __builtin_elementwise_fma(u * f32x2_t{0.39894228040143267794f, 0.39894228040143267794f}, e, cdf);
+}
+
 // y = dropout(act(x)) [+ res]           (act may be 0).  HBM-bound: 16 bytes per lane per access when the tensor allows.
 template <bool VEC>
 __global__ void dropout_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
@@ -60,7 +77,13 @@ __global__ void dropout_fwd_kernel(const float* __restrict__ x, const float* __r
         const int64_t nv = n >> 2;
         for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < nv; i += (int64_t)gridDim.x * EW_THREADS) {
             const float4 xv = reinterpret_cast<const float4*>(x)[i];
-            float v[4] = {apply_act(xv.x, act), apply_act(xv.y, act), apply_act(xv.z, act), apply_act(xv.w, act)};
+            float v[4];
+            if (act == 3) {
+                const f32x2_t a0 = gelu_erf_fast2(f32x2_t{xv.x, xv.y}), a1 = gelu_erf_fast2(f32x2_t{xv.z, xv.w});
+                v[0] = a0[0]; v[1] = a0[1]; v[2] = a1[0]; v[3] = a1[1];
+            } else {
+                v[0] = apply_act(xv.x, act); v[1] = apply_act(xv.y, act); v[2] = apply_act(xv.z, act); v[3] = apply_act(xv.w, act);
+            }
             if (p > 0.f) {
 #pragma unroll
                 for (int e = 0; e < 4; e += 2) {       // elements 4 i + e, + 1 share one hash word
@@ -109,7 +132,12 @@ __global__ void dropout_bwd_kernel(const float* __restrict__ u, const float* __r
             }
             if (act) {
                 const float4 uv = reinterpret_cast<const float4*>(u)[i];
-                g[0] *= gelu_grad(uv.x, act); g[1] *= gelu_grad(uv.y, act); g[2] *= gelu_grad(uv.z, act); g[3] *= gelu_grad(uv.w, act);
+                if (act == 3) {
+                    const f32x2_t d0 = gelu_grad_fast2(f32x2_t{uv.x, uv.y}), d1 = gelu_grad_fast2(f32x2_t{uv.z, uv.w});
+                    g[0] *= d0[0]; g[1] *= d0[1]; g[2] *= d1[0]; g[3] *= d1[1];
+                } else {
+                    g[0] *= gelu_grad(uv.x, act); g[1] *= gelu_grad(uv.y, act); g[2] *= gelu_grad(uv.z, act); g[3] *= gelu_grad(uv.w, act);
+                }
             }
             if (dx) reinterpret_cast<float4*>(dx)[i] = make_float4(g[0], g[1], g[2], g[3]);
             if (dx16) reinterpret_cast<uint2*>(dx16)[i] = make_uint2(pack_bf16_rne(g[0], g[1]), pack_bf16_rne(g[2], g[3]));
@@ -156,7 +184,12 @@ __global__ __launch_bounds__(256) void dropout_bwd_colsum_kernel(const float* __
             }
             if (act) {
                 const float4 uv = *reinterpret_cast<const float4*>(u + i);
-                g[0] *= gelu_grad(uv.x, act); g[1] *= gelu_grad(uv.y, act); g[2] *= gelu_grad(uv.z, act); g[3] *= gelu_grad(uv.w, act);
+                if (act == 3) {
+                    const f32x2_t d0 = gelu_grad_fast2(f32x2_t{uv.x, uv.y}), d1 = gelu_grad_fast2(f32x2_t{uv.z, uv.w});
+                    g[0] *= d0[0]; g[1] *= d0[1]; g[2] *= d1[0]; g[3] *= d1[1];
+                } else {
+                    g[0] *= gelu_grad(uv.x, act); g[1] *= gelu_grad(uv.y, act); g[2] *= gelu_grad(uv.z, act); g[3] *= gelu_grad(uv.w, act);
+                }
             }
             if (dx) *reinterpret_cast<float4*>(dx + i) = make_float4(g[0], g[1], g[2], g[3]);
             if (dx16) *reinterpret_cast<uint2*>(dx16 + i) = make_uint2(pack_bf16_rne(g[0], g[1]), pack_bf16_rne(g[2], g[3]));
