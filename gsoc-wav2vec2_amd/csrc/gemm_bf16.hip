@@ -322,6 +322,44 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
         const unsigned char* S = smem16 + buf * STAGE;
         // Fragment reads run one k-step ahead of the MFMAs that consume them: a 16-deep bf16 MFMA is only 32 cycles, so
         // an LDS round trip (~100+ cycles) in front of each group of 4 would otherwise be the critical path.
+        if constexpr (DMA && MT == 2 && NTL == 1) {
+            // The default instance (8 waves of 64 x 32) with hand-counted waits.  Left to the compiler, the first MFMA pair of a
+            // tile waited for the reads of steps 0 AND 1 (lgkmcnt(0) instead of 3), and the pair of step 2 for the reads of step 3
+            // issued just before it: ~200 cycles of stall per wave and tile that are not data dependencies.  The reads are inline
+            // asm, the waits are tied to the fragment registers ("+v") so that the MFMAs stay behind them; LDS operations complete
+            // in order, so the compiler's own (empty here) lgkmcnt bookkeeping is unaffected.
+            const unsigned S3 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)S;
+            bf16x8 fa0[2], fa1[2], fb[2];
+            auto rd = [&](int s, int slot) {
+                const unsigned aa0 = S3 + (unsigned)a_row[0] + (unsigned)(((2 * s + lh) ^ a_swz[0]) << 4);
+                const unsigned aa1 = S3 + (unsigned)a_row[1] + (unsigned)(((2 * s + lh) ^ a_swz[1]) << 4);
+                const unsigned ab = S3 + (unsigned)b_row[0] + (unsigned)(((2 * s + lh) ^ b_swz[0]) << 4);
+                asm volatile("ds_read_b128 %0, %1" : "=v"(fa0[slot]) : "v"(aa0));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(fa1[slot]) : "v"(aa1));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(fb[slot]) : "v"(ab));
+            };
+            auto mm = [&](int slot) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[slot], fb[slot], acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[slot], fb[slot], acc[1][0], 0, 0, 0);
+            };
+            static_assert(BK / 16 == 4, "four k-steps per tile");
+            rd(0, 0);
+            rd(1, 1);
+            asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa0[0]), "+v"(fa1[0]), "+v"(fb[0]));
+            mm(0);
+            __builtin_amdgcn_sched_barrier(0);      // (the MFMAs are free to sink below the later waits otherwise)
+            rd(2, 0);
+            asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa0[1]), "+v"(fa1[1]), "+v"(fb[1]));
+            mm(1);
+            __builtin_amdgcn_sched_barrier(0);
+            rd(3, 1);
+            asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa0[0]), "+v"(fa1[0]), "+v"(fb[0]));
+            mm(0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa0[1]), "+v"(fa1[1]), "+v"(fb[1]));
+            mm(1);
+            return;
+        }
         bf16x8 a[2][MT], b[2][NTL];
         auto read_frags = [&](int s, int slot) {
 #pragma unroll
