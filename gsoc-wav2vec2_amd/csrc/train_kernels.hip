@@ -700,8 +700,10 @@ int launch_dropout_bwd_colsum(const float* u, const float* dy, float* dx, uint16
 }
 
 static int ln_bwd_blocks(int64_t rows) {
+    // two blocks per CU: measured at 24576 x 768 -- 1024 blocks 45.8 / 49.4 us (without / with the dx column sums) + 12 us for
+    // the fold of twice as many partial rows, 512 blocks 41.0 / 47.2 + 7, 256 blocks 62 / 67
     int64_t b = (rows + 3) / 4;
-    return (int)(b > 1024 ? 1024 : b);
+    return (int)(b > 512 ? 512 : b);
 }
 int64_t ln_bwd_ws_floats(int64_t rows, int C) { return (int64_t)ln_bwd_blocks(rows) * 3 * C + 8; }
 
