@@ -7,6 +7,8 @@
 // HBM-bound: one read + one write of the row.  One wave64 per row; the row is
 // held in registers (float4 per lane per 256-channel chunk) so mean and the
 // centred variance are two in-register passes -- no E[x^2]-mean^2 cancellation.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace w2v2 {
@@ -121,9 +123,11 @@ int launch_layer_norm_x(Profiler* prof, const float* x, float* y, const float* g
     W2V2_REQUIRE(x && y && gamma && beta, "layer_norm: null operand");
     W2V2_REQUIRE(rows > 0 && C > 0 && C <= 2048, "layer_norm: rows=%lld C=%d unsupported (C <= 2048)",
                  (long long)rows, C);
-    // at most 8 blocks per CU resident (32 waves): beyond that each wave loops over rows
+    // 4 blocks per CU (16 waves), each wave looping over rows
     const int64_t want = (rows + 3) / 4;
-    dim3 grid((unsigned)(want < 256 * 8 ? want : 256 * 8)), block(256);
+    static int cap = -1;
+    if (cap < 0) { const char* e = getenv("W2V2_LN_BLOCKS"); cap = e ? atoi(e) : 256 * 4; }      // tuning knob: 512 / 1024 / 2048 / 4096 blocks -> 1.14 / 1.06 / 1.10 / 1.26 ms for the 25 LayerNorms of a base forward
+    dim3 grid((unsigned)(want < cap ? want : cap)), block(256);
     ProfScope ps(prof, FAM_LAYERNORM, 8.0 * rows * C, (y16 ? 10.0 : 8.0) * rows * C, s);
     if (C <= 256)
         hipLaunchKernelGGL(layer_norm_kernel<1>, grid, block, 0, s, x, y, y16, gamma, beta, rows, C, eps, act);

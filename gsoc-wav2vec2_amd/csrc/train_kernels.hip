@@ -9,6 +9,8 @@
 // Dropout masks are NOT stored: keep(seed, stream, index) is a counter-based hash (splitmix64), the same
 // integer function as wav2vec2/variables.py::dropout_keep, regenerated wherever the mask is needed
 // (forward, backward, and inside the attention kernels).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -20,8 +22,10 @@ namespace {
 constexpr int EW_THREADS = 256;
 
 inline unsigned ew_grid(int64_t n_vec) {
+    static int cap = -1;
+    if (cap < 0) { const char* e = getenv("W2V2_EW_BLOCKS"); cap = e ? atoi(e) : 16384; }      // tuning knob: 1024 / 2048 / 4096 / 16384 blocks -> 78.9 / 59.6 / 59.8 / 57.3 us per dropout_fwd launch (fine-tune step average)
     int64_t g = (n_vec + EW_THREADS - 1) / EW_THREADS;
-    return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));   // grid-stride beyond 4096 blocks
+    return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));   // grid-stride beyond `cap` blocks
 }
 
 __device__ __forceinline__ float gelu_grad(float u, int act) {
