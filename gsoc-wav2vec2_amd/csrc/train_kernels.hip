@@ -647,8 +647,8 @@ int launch_transpose(const float* x, float* y, int rows, int cols, int nbatch, h
 constexpr int COLSUM_CHUNK = 128;    // rows per stage-1 block
 
 int64_t colsum_ws_floats(int64_t rows, int cols) { return ((rows + COLSUM_CHUNK - 1) / COLSUM_CHUNK) * (int64_t)cols + 8; }
-// launch_dropout_bwd_colsum may cut its chunks down to 32 rows
-int64_t dropout_bwd_colsum_ws_floats(int64_t rows, int cols) { return ((rows + 31) / 32) * (int64_t)cols + 8; }
+// launch_dropout_bwd_colsum may cut its chunks down to 16 rows
+int64_t dropout_bwd_colsum_ws_floats(int64_t rows, int cols) { return ((rows + 15) / 16) * (int64_t)cols + 8; }
 
 int launch_colsum(const float* x, float* out, int64_t rows, int cols, float* ws, int accumulate, hipStream_t s) {
     W2V2_REQUIRE(x && out && rows > 0 && cols > 0, "colsum: bad argument");
@@ -690,11 +690,14 @@ int launch_dropout_bwd_colsum(const float* u, const float* dy, float* dx, uint16
         if (int e = launch_dropout_bwd_x(u, dy, dx, dx16, rows * cols, act, p, seed, stream_id, s)) return e;
         return launch_colsum(dx, colsum, rows, cols, ws, 0, s);
     }
-    // narrow tensors (cols = H: 3 column blocks) get shorter chunks so that the grid still covers the chip (>= ~2000 blocks);
+    // shorter chunks until the grid has `target` blocks (this HBM-bound kernel wants many small blocks; the fold of the partial
+    // rows grows with them);
     // ws: dropout_bwd_colsum_ws_floats(rows, cols) floats
+    static int target = -1;
+    if (target < 0) { const char* e = getenv("W2V2_DBC_BLOCKS"); target = e ? atoi(e) : 8192; }      // tuning knob: >= 2048 / 4096 / 8192 / 16384 blocks -> 20.4 / 18.8 / 17.8 / 18.9 ms (kernel + fold, 7 fine-tune steps)
     int chunk = COLSUM_CHUNK;
     const int colblocks = (cols + 255) / 256;
-    while (chunk > 32 && (rows + chunk - 1) / chunk * colblocks < 2048) chunk >>= 1;
+    while (chunk > 16 && (rows + chunk - 1) / chunk * colblocks < target) chunk >>= 1;
     const int nchunks = (int)((rows + chunk - 1) / chunk);
     hipLaunchKernelGGL(dropout_bwd_colsum_kernel, dim3(colblocks, nchunks), dim3(256), 0, s, u, dy, dx, dx16, ws, rows, cols,
                        chunk, act, p, seed, stream_id);
