@@ -107,7 +107,14 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a, AttnTrai
     auto issue_tile = [&](int tile, int buf) {
         float* S = smem + buf * STAGE;
         const int k0 = tile * KT;
-        for (int p = wave; p < 2 * NP; p += NW) {
+        // A FIXED number of pieces per wave, straight-line (pieces past the end wrap around and reload a piece another wave also
+        // loads -- same bytes, harmless): with a data-dependent trip count (`p = wave; p < 2 NP; p += NW`, wave in a VGPR) the
+        // loop is exec-masked control flow, after which the compiler's wait-count pass drains vmcnt(0) before the first LDS read
+        // of the tile -- i.e. this block waited for the NEXT tile's K / V before computing on the current one.
+        constexpr int PW = (2 * NP + NW - 1) / NW;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int p = (wave + i * NW) % (2 * NP);
             const bool isv = p >= NP;
             const int pp = isv ? p - NP : p;
             const int r = pp * RPP + p_row;                       // row inside the tile
@@ -133,7 +140,9 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a, AttnTrai
 
     for (int tile = 0; tile < ntiles; ++tile) {
         const int k0 = tile * KT, buf = tile & 1;
-        if (tile + 1 < ntiles) issue_tile(tile + 1, buf ^ 1);     // wave-uniform branch; no registers involved
+        // unconditional (the last iteration re-requests its own tile into the idle stage): behind a branch the compiler's wait-count
+        // pass drains vmcnt(0) before the first LDS read of the tile, i.e. DMA and compute no longer overlap inside a block
+        issue_tile(min(tile + 1, ntiles - 1), buf ^ 1);
         __builtin_amdgcn_sched_barrier(0);
         const float* Ks = smem + buf * STAGE;
         const float* Vs = Ks + KT * DH;
@@ -314,7 +323,10 @@ __device__ __forceinline__ void dma_tile_swz(const float* base, int64_t ld, int 
                                               float* dst, int wave, int lane, int piece0) {
     using Z = Swz<DH>;
     const int p_row = lane / Z::SPR, p_slot = lane % Z::SPR;
-    for (int p = wave; p < Z::NP; p += NW) {
+    constexpr int PW = (Z::NP + NW - 1) / NW;      // fixed, straight-line (see attention_kernel's issue_tile)
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        const int p = (wave + i * NW) % Z::NP;
         const int r = p * Z::RPP + p_row;
         const int row = min(r0 + r, T - 1);
         dma16(base + (int64_t)row * ld + col + ((p_slot ^ Z::f(r)) << 2), dst + (piece0 + p) * 256);
@@ -397,7 +409,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(AttnBwdArgs a, At
     __syncthreads();
     for (int tile = 0; tile < ntiles; ++tile) {
         const int k0 = tile * KT, buf = tile & 1;
-        if (tile + 1 < ntiles) issue(tile + 1, buf ^ 1);
+        issue(min(tile + 1, ntiles - 1), buf ^ 1);      // unconditional: see attention.hip (a branch here costs the DMA / compute overlap)
         __builtin_amdgcn_sched_barrier(0);
         const float* Ks = smem + buf * STAGE;
         const float* Vs = Ks + KT * DH;
@@ -517,7 +529,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(AttnBwdArgs a, A
     __syncthreads();
     for (int tile = 0; tile < ntiles; ++tile) {
         const int t0 = tile * KT, buf = tile & 1;
-        if (tile + 1 < ntiles) issue(tile + 1, buf ^ 1);
+        issue(min(tile + 1, ntiles - 1), buf ^ 1);      // unconditional: see attention.hip (a branch here costs the DMA / compute overlap)
         __builtin_amdgcn_sched_barrier(0);
         const float* Qs = smem + buf * STAGE;
         const float* Os = Qs + KT * DH;

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attention_bf16_kernel(Attn16Args a
     __syncthreads();                          // (carries the vmcnt(0) that retires the DMA)
     for (int tile = 0; tile < ntiles; ++tile) {
         const int k0 = tile * KT, buf = tile & 1;
-        if (tile + 1 < ntiles) issue(tile + 1, buf ^ 1);
+        issue(min(tile + 1, ntiles - 1), buf ^ 1);      // unconditional: see attention.hip (a branch here costs the DMA / compute overlap)
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char* Ks = smem_a16 + buf * STAGE;
         const unsigned char* Vs = Ks + IMG;
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256, 3) void attention_bf16_bwd_dq_kernel(Attn16Bwd
     __syncthreads();
     for (int tile = 0; tile < ntiles; ++tile) {
         const int k0 = tile * KT, buf = tile & 1;
-        if (tile + 1 < ntiles) issue(tile + 1, buf ^ 1);
+        issue(min(tile + 1, ntiles - 1), buf ^ 1);      // unconditional: see attention.hip (a branch here costs the DMA / compute overlap)
         uint32_t bits = 0;
         if (BITS) bits = tr.keep_bits[keep_word(bh, tile, lh, a.nqb) + q0 + li];     // (lands under the first MFMAs)
         __builtin_amdgcn_sched_barrier(0);
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
     __syncthreads();
     for (int tile = 0; tile < ntiles; ++tile) {
         const int t0 = tile * KT, buf = tile & 1;
-        if (tile + 1 < ntiles) issue(tile + 1, buf ^ 1);
+        issue(min(tile + 1, ntiles - 1), buf ^ 1);      // unconditional: see attention.hip (a branch here costs the DMA / compute overlap)
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char* Qs = smem_a16 + buf * STAGE;
         const unsigned char* Os = Qs + IMG;
