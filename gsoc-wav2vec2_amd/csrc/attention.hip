@@ -29,6 +29,10 @@
 namespace w2v2 {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+// LDS fragment reads go through this NATIVE vector type, not HIP's float4 struct: after a struct-typed LDS load the compiler's
+// wait-count pass assumes it may alias the LDS-DMA in flight and drains vmcnt(0) before the first read of every tile (measured:
+// the fp32 attention forward waited for the next tile's K / V before touching the current one, 6.05 ms per forward).
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 namespace {
 
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a, AttnTrai
     constexpr int STAGE = 2 * KT * DH;    // floats per buffer (K then V)
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (an SGPR: the DMA's LDS address is then provably wave-uniform)
     const int li = lane & 31, lh = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
     const int q0 = (blockIdx.x * NW + wave) * 32;
@@ -158,10 +162,10 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a, AttnTrai
             const int sw = (row >> SH) & SWM;
 #pragma unroll
             for (int j = 0; j < JD; ++j) {
-                const float4 kf = *reinterpret_cast<const float4*>(kp + (((2 * j + lh) ^ sw) << 2));
+                const f32x4 kf = *reinterpret_cast<const f32x4*>(kp + (((2 * j + lh) ^ sw) << 2));
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(kf, e), f4get(qf[j], e), s[kt], 0, 0, 0);
+                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], f4get(qf[j], e), s[kt], 0, 0, 0);
             }
         }
         // ---- mask + online softmax (lane owns query li; keys (r&3) + 8 (r>>2) + 4 lh) ----
@@ -421,12 +425,12 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(AttnBwdArgs a, At
             const int row = kt * 32 + li, sw = Z::f(row);
 #pragma unroll
             for (int j = 0; j < JD; ++j) {
-                const float4 kf = *reinterpret_cast<const float4*>(Ks + row * DH + (((2 * j + lh) ^ sw) << 2));
-                const float4 vf = *reinterpret_cast<const float4*>(Vs + row * DH + (((2 * j + lh) ^ sw) << 2));
+                const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + row * DH + (((2 * j + lh) ^ sw) << 2));
+                const f32x4 vf = *reinterpret_cast<const f32x4*>(Vs + row * DH + (((2 * j + lh) ^ sw) << 2));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(kf, e), f4get(qf[j], e), s, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(vf, e), f4get(dof[j], e), dp, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], f4get(qf[j], e), s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[e], f4get(dof[j], e), dp, 0, 0, 0);
                 }
             }
             // dS^T = P^T * (dP^T * keep/(1-p) - D);  P = exp(S - lse)
@@ -542,12 +546,12 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(AttnBwdArgs a, A
             const int row = qt * 32 + li, sw = Z::f(row);
 #pragma unroll
             for (int j = 0; j < JD; ++j) {
-                const float4 qv = *reinterpret_cast<const float4*>(Qs + row * DH + (((2 * j + lh) ^ sw) << 2));
-                const float4 ov = *reinterpret_cast<const float4*>(Os + row * DH + (((2 * j + lh) ^ sw) << 2));
+                const f32x4 qv = *reinterpret_cast<const f32x4*>(Qs + row * DH + (((2 * j + lh) ^ sw) << 2));
+                const f32x4 ov = *reinterpret_cast<const f32x4*>(Os + row * DH + (((2 * j + lh) ^ sw) << 2));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(qv, e), f4get(kf[j], e), s, 0, 0, 0);     // S[q][key]
-                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(ov, e), f4get(vf[j], e), dp, 0, 0, 0);   // dP[q][key]
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(qv[e], f4get(kf[j], e), s, 0, 0, 0);     // S[q][key]
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(ov[e], f4get(vf[j], e), dp, 0, 0, 0);   // dP[q][key]
                 }
             }
             // lane owns key column `key`; register r is query row qt*32 + (r&3) + 8 (r>>2) + 4 lh
