@@ -371,12 +371,21 @@ def test_bf16_training_shadows_do_not_change_results(env):
             res[flag] = dict(logits=logits.cpu().numpy(),
                              grads={n: tr.gradient(n) for n in ("lm_head/kernel", "encoder/layers/11/feed_forward/output_dense/kernel",
                                                                 "encoder/layers/0/attention/q_proj/kernel",
-                                                                "feature_projection/projection/kernel", "encoder/layer_norm/gamma")})
+                                                                "feature_projection/projection/kernel", "encoder/layer_norm/gamma")},
+                             biases={n: tr.gradient(n) for n in ("encoder/layers/11/feed_forward/output_dense/bias",
+                                                                 "encoder/layers/3/feed_forward/intermediate_dense/bias",
+                                                                 "encoder/layers/0/attention/q_proj/bias",
+                                                                 "encoder/layers/5/attention/out_proj/bias")})
     finally:
         os.environ.pop("W2V2_BF16_SHADOWS", None)
     assert np.array_equal(res["0"]["logits"], res["1"]["logits"])
     for n, g in res["0"]["grads"].items():
         assert np.array_equal(g, res["1"]["grads"][n]), n
+    # bias gradients are column sums taken by different kernels in the two modes (fused into the fp32 weight-gradient GEMM vs left by
+    # the producers of dY): equal up to fp32 summation order
+    for n, g in res["0"]["biases"].items():
+        g1 = res["1"]["biases"][n]
+        assert np.abs(g - g1).max() <= 2e-5 * max(np.abs(g).max(), 1e-6), (n, float(np.abs(g - g1).max()), float(np.abs(g).max()))
 
 
 def test_stage1_only_lm_head_trains(env):
