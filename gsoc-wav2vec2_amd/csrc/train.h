@@ -53,6 +53,49 @@ __device__ __forceinline__ uint32_t attention_drop_stride(int T) { return (uint3
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t stream, uint64_t idx, float p) {
     return dropout_keep32(dropout_key(seed, stream), (uint32_t)idx, dropout_threshold(p));
 }
+
+// derivative of the activations of apply_act (common.h); shared by the element-wise kernels and the GEMM training epilogue
+__device__ __forceinline__ float gelu_grad(float u, int act) {
+    if (act == 1) {   // d/du [0.5 u (1 + erf(u / sqrt 2))]
+        const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
+        return cdf + u * 0.39894228040143267794f * expf(-0.5f * u * u);
+    }
+    if (act == 2) {
+        const float c = 0.79788456080286535588f, k = 0.044715f;
+        const float t = tanhf(c * (u + k * u * u * u));
+        return 0.5f * (1.0f + t) + 0.5f * u * (1.0f - t * t) * c * (1.0f + 3.0f * k * u * u);
+    }
+    if (act == 3) {   // act 1 evaluated the fast way (precision mode 1): erf by Abramowitz-Stegun 7.1.26, one exponential shared with the density
+        const float z = fabsf(u) * 0.70710678118654752440f;
+        const float tt = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+        float q = fmaf(1.061405429f, tt, -1.453152027f);
+        q = fmaf(q, tt, 1.421413741f);
+        q = fmaf(q, tt, -0.284496736f);
+        q = fmaf(q, tt, 0.254829592f);
+        const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);      // exp(-u^2 / 2)
+        const float erf_abs = fmaf(-q * tt, e, 1.0f);
+        const float cdf = 0.5f + copysignf(0.5f * erf_abs, u);
+        return fmaf(u * 0.39894228040143267794f, e, cdf);
+    }
+    return 1.0f;
+}
+
+// gelu_grad(., 3) on two values at once (packed fp32 multiply / fma; rcp and exp2 stay scalar)
+__device__ __forceinline__ f32x2_t gelu_grad_fast2(f32x2_t u) {
+    const f32x2_t au = {fabsf(u[0]), fabsf(u[1])};
+    const f32x2_t z = au * f32x2_t{0.70710678118654752440f, 0.70710678118654752440f};
+    const f32x2_t d = __builtin_elementwise_fma(f32x2_t{0.3275911f, 0.3275911f}, z, f32x2_t{1.0f, 1.0f});
+    const f32x2_t t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    f32x2_t q = __builtin_elementwise_fma(f32x2_t{1.061405429f, 1.061405429f}, t, f32x2_t{-1.453152027f, -1.453152027f});
+    q = __builtin_elementwise_fma(q, t, f32x2_t{1.421413741f, 1.421413741f});
+    q = __builtin_elementwise_fma(q, t, f32x2_t{-0.284496736f, -0.284496736f});
+    q = __builtin_elementwise_fma(q, t, f32x2_t{0.254829592f, 0.254829592f});
+    const f32x2_t zz = z * z * f32x2_t{-1.44269504088896340736f, -1.44269504088896340736f};
+    const f32x2_t e = {__builtin_amdgcn_exp2f(zz[0]), __builtin_amdgcn_exp2f(zz[1])};        // exp(-u^2 / 2)
+    const f32x2_t herf = __builtin_elementwise_fma(-(q * t), e, f32x2_t{1.0f, 1.0f}) * f32x2_t{0.5f, 0.5f};
+    const f32x2_t cdf = {0.5f + copysignf(herf[0], u[0]), 0.5f + copysignf(herf[1], u[1])};
+    return __builtin_elementwise_fma(u * f32x2_t{0.39894228040143267794f, 0.39894228040143267794f}, e, cdf);
+}
 #endif
 
 // one 4096-element piece of one variable for the single-launch Adam: p = variable + offset, goff = its offset in the
@@ -78,13 +121,21 @@ int launch_transpose(const float* x, float* y, int rows, int cols, int nbatch, h
 int64_t colsum_ws_floats(int64_t rows, int cols);
 int64_t dropout_bwd_colsum_ws_floats(int64_t rows, int cols);      // scratch of launch_dropout_bwd_colsum
 int launch_colsum(const float* x, float* out, int64_t rows, int cols, float* ws, int accumulate, hipStream_t s);
+int launch_colsum_fold(const float* partial, float* out, int nrows, int cols, hipStream_t s);   // rows are per-block partial sums
 int64_t ln_bwd_ws_floats(int64_t rows, int C);
 int launch_ln_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma,
                   float* dbeta, int64_t rows, int C, float eps, float* ws, hipStream_t s);
+// dropout backward of the tensor in front of a residual add, folded into the LayerNorm backward that produces its gradient
+struct LnDropTail {
+    float p;
+    uint64_t seed;
+    uint32_t stream;
+};
 int launch_ln_bwd_x(const float* x, const float* gamma, const float* dy, float* dx, uint16_t* dx16 /* optional bf16 shadow */,
                     float* dgamma, float* dbeta, int64_t rows, int C, float eps, float* ws, hipStream_t s,
                     float* dxsum = nullptr /* optional: column sums of dx (C floats) */,
-                    const float* residual = nullptr /* optional: dx = LN-backward(dy) + residual */);
+                    const float* residual = nullptr /* optional: dx = LN-backward(dy) + residual */,
+                    const struct LnDropTail* tail = nullptr /* optional: dx16 / dxsum take dropout-backward(dx) instead of dx */);
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1, float b2,
                 float eps, hipStream_t s);
 int launch_spec_aug_fwd(const float* x, const uint8_t* mask, const float* embed, float* y, int64_t rows, int H, hipStream_t s);

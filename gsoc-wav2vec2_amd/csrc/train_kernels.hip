@@ -28,48 +28,6 @@ inline unsigned ew_grid(int64_t n_vec) {
     return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));   // grid-stride beyond `cap` blocks
 }
 
-__device__ __forceinline__ float gelu_grad(float u, int act) {
-    if (act == 1) {   // d/du [0.5 u (1 + erf(u / sqrt 2))]
-        const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
-        return cdf + u * 0.39894228040143267794f * expf(-0.5f * u * u);
-    }
-    if (act == 2) {
-        const float c = 0.79788456080286535588f, k = 0.044715f;
-        const float t = tanhf(c * (u + k * u * u * u));
-        return 0.5f * (1.0f + t) + 0.5f * u * (1.0f - t * t) * c * (1.0f + 3.0f * k * u * u);
-    }
-    if (act == 3) {   // act 1 evaluated the fast way (precision mode 1): erf by Abramowitz-Stegun 7.1.26, one exponential shared with the density
-        const float z = fabsf(u) * 0.70710678118654752440f;
-        const float tt = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-        float q = fmaf(1.061405429f, tt, -1.453152027f);
-        q = fmaf(q, tt, 1.421413741f);
-        q = fmaf(q, tt, -0.284496736f);
-        q = fmaf(q, tt, 0.254829592f);
-        const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);      // exp(-u^2 / 2)
-        const float erf_abs = fmaf(-q * tt, e, 1.0f);
-        const float cdf = 0.5f + copysignf(0.5f * erf_abs, u);
-        return fmaf(u * 0.39894228040143267794f, e, cdf);
-    }
-    return 1.0f;
-}
-
-// gelu_grad(., 3) on two values at once (packed fp32 multiply / fma; rcp and exp2 stay scalar)
-__device__ __forceinline__ f32x2_t gelu_grad_fast2(f32x2_t u) {
-    const f32x2_t au = {fabsf(u[0]), fabsf(u[1])};
-    const f32x2_t z = au * f32x2_t{0.70710678118654752440f, 0.70710678118654752440f};
-    const f32x2_t d = __builtin_elementwise_fma(f32x2_t{0.3275911f, 0.3275911f}, z, f32x2_t{1.0f, 1.0f});
-    const f32x2_t t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-    f32x2_t q = __builtin_elementwise_fma(f32x2_t{1.061405429f, 1.061405429f}, t, f32x2_t{-1.453152027f, -1.453152027f});
-    q = __builtin_elementwise_fma(q, t, f32x2_t{1.421413741f, 1.421413741f});
-    q = __builtin_elementwise_fma(q, t, f32x2_t{-0.284496736f, -0.284496736f});
-    q = __builtin_elementwise_fma(q, t, f32x2_t{0.254829592f, 0.254829592f});
-    const f32x2_t zz = z * z * f32x2_t{-1.44269504088896340736f, -1.44269504088896340736f};
-    const f32x2_t e = {__builtin_amdgcn_exp2f(zz[0]), __builtin_amdgcn_exp2f(zz[1])};        // exp(-u^2 / 2)
-    const f32x2_t herf = __builtin_elementwise_fma(-(q * t), e, f32x2_t{1.0f, 1.0f}) * f32x2_t{0.5f, 0.5f};
-    const f32x2_t cdf = {0.5f + copysignf(herf[0], u[0]), 0.5f + copysignf(herf[1], u[1])};
-    return __builtin_elementwise_fma(u * f32x2_t{0.39894228040143267794f, 0.39894228040143267794f}, e, cdf);
-}
-
 // y = dropout(act(x)) [+ res]           (act may be 0).  HBM-bound: 16 bytes per lane per access when the tensor allows.
 template <bool VEC>
 __global__ void dropout_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
@@ -372,14 +330,21 @@ __global__ __launch_bounds__(256) void colsum_final_wide_kernel(const float* __r
 // written as partial[block][2][C]; colsum_final reduces them.
 // DXSUM: also leave the column sums of dx (dx is the dY of the Dense layer in front of this LayerNorm: its bias gradient) as a
 // third group of C partials.
-template <int NV, bool DXSUM>
+// TAIL 2: dx is (plus the residual) the gradient of t1 = dropout(o) + x of the attention block: the dropout backward of the
+// out-projection's output rides along -- dx16 then receives bf16(dropout-backward(dx)) (the dY shadow of that Dense layer) and the
+// third partial group its column sums (the out-projection's bias gradient); dx itself is still written in fp32.
+template <int NV, int TAIL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ dy, float* __restrict__ dx,
-                                                     uint16_t* __restrict__ dx16 /* optional bf16 shadow of dx */,
+                                                     uint16_t* __restrict__ dx16 /* optional bf16 shadow of dx (TAIL 2: of its dropout backward) */,
                                                      float* __restrict__ partial, int64_t rows, int C, float eps,
-                                                     const float* __restrict__ res /* optional: dx = LN-backward + res */) {
+                                                     const float* __restrict__ res /* optional: dx = LN-backward + res */,
+                                                     float drop_p, uint64_t drop_seed, uint32_t drop_stream) {
     extern __shared__ float red[];   // 4 waves x NG x C
+    constexpr bool DXSUM = TAIL != 0;
     constexpr int NG = DXSUM ? 3 : 2;
+    const uint32_t dkey = TAIL == 2 ? dropout_key(drop_seed, drop_stream) : 0u, dthr = TAIL == 2 ? dropout_threshold(drop_p) : 0u;
+    const float dinv = (TAIL == 2 && drop_p > 0.f) ? 1.0f / (1.0f - drop_p) : 1.0f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float dg[NV][4], db[NV][4], ds[DXSUM ? NV : 1][4];
 #pragma unroll
@@ -468,6 +433,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
                         o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
                     }
                     *reinterpret_cast<float4*>(dxr + c) = o;
+                    if constexpr (TAIL == 2) {        // o -> dropout backward of o (the same pair-wise decisions as dropout_bwd_kernel)
+                        if (drop_p > 0.f) {
+                            const uint32_t pr = (uint32_t)(row * C + c) >> 1;
+                            const uint32_t w0 = dropout_word(dkey, pr), w1 = dropout_word(dkey, pr + 1);
+                            o.x = dropout_keep_lo(w0, dthr) ? o.x * dinv : 0.f;
+                            o.y = dropout_keep_hi(w0, dthr) ? o.y * dinv : 0.f;
+                            o.z = dropout_keep_lo(w1, dthr) ? o.z * dinv : 0.f;
+                            o.w = dropout_keep_hi(w1, dthr) ? o.w * dinv : 0.f;
+                        }
+                    }
                     if (dx16) *reinterpret_cast<uint2*>(dx16 + row * C + c) = make_uint2(pack_bf16_rne(o.x, o.y), pack_bf16_rne(o.z, o.w));
                     if constexpr (DXSUM) { ds[i][0] += o.x; ds[i][1] += o.y; ds[i][2] += o.z; ds[i][3] += o.w; }
                 }
@@ -482,6 +457,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
                         float o = rstd * (gv[i][e] - s1 - xv[i][e] * s2);
                         if (res) o += res[row * C + c];
                         dxr[c] = o;
+                        if constexpr (TAIL == 2) {
+                            if (drop_p > 0.f) o = dropout_keep32(dkey, (uint32_t)(row * C + c), dthr) ? o * dinv : 0.f;
+                        }
                         if (dx16) dx16[row * C + c] = (uint16_t)pack_bf16_rne(o, 0.f);
                         if constexpr (DXSUM) ds[i][e] += o;
                     }
@@ -650,6 +628,14 @@ int64_t colsum_ws_floats(int64_t rows, int cols) { return ((rows + COLSUM_CHUNK 
 // launch_dropout_bwd_colsum may cut its chunks down to 16 rows
 int64_t dropout_bwd_colsum_ws_floats(int64_t rows, int cols) { return ((rows + 15) / 16) * (int64_t)cols + 8; }
 
+// out[c] = sum over `nrows` rows of already-reduced partial rows (a producer's per-block column sums): one launch, fp64 accumulate
+int launch_colsum_fold(const float* partial, float* out, int nrows, int cols, hipStream_t s) {
+    W2V2_REQUIRE(partial && out && nrows > 0 && cols > 0, "colsum_fold: bad argument");
+    hipLaunchKernelGGL(colsum_final_wide_kernel, dim3((cols + 31) / 32), dim3(256), 0, s, partial, out, nrows, cols, (int64_t)cols, 0, nullptr, nullptr);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
 int launch_colsum(const float* x, float* out, int64_t rows, int cols, float* ws, int accumulate, hipStream_t s) {
     W2V2_REQUIRE(x && out && rows > 0 && cols > 0, "colsum: bad argument");
     const bool vec = (cols & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(ws)) & 15) == 0;
@@ -716,11 +702,13 @@ int64_t ln_bwd_ws_floats(int64_t rows, int C) { return (int64_t)ln_bwd_blocks(ro
 
 int launch_ln_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma,
                   float* dbeta, int64_t rows, int C, float eps, float* ws, hipStream_t s) {
-    return launch_ln_bwd_x(x, gamma, dy, dx, nullptr, dgamma, dbeta, rows, C, eps, ws, s, nullptr, nullptr);
+    return launch_ln_bwd_x(x, gamma, dy, dx, nullptr, dgamma, dbeta, rows, C, eps, ws, s, nullptr, nullptr, nullptr);
 }
 
 int launch_ln_bwd_x(const float* x, const float* gamma, const float* dy, float* dx, uint16_t* dx16, float* dgamma,
-                    float* dbeta, int64_t rows, int C, float eps, float* ws, hipStream_t s, float* dxsum, const float* residual) {
+                    float* dbeta, int64_t rows, int C, float eps, float* ws, hipStream_t s, float* dxsum, const float* residual,
+                    const LnDropTail* tail) {
+    W2V2_REQUIRE(!tail || (dx16 && dxsum && tail->p >= 0.f && tail->p < 1.f), "ln_bwd: the dropout tail needs its bf16 output and a column-sum target");
     W2V2_REQUIRE(x && gamma && dy && dx && dgamma && dbeta && ws, "ln_bwd: null operand");
     W2V2_REQUIRE(!residual || (C & 3) != 0 || (reinterpret_cast<uintptr_t>(residual) & 15) == 0, "ln_bwd: unaligned residual");
     W2V2_REQUIRE(!dx16 || ((C & 3) == 0 && (reinterpret_cast<uintptr_t>(dx16) & 7) == 0), "ln_bwd: the bf16 shadow needs C %% 4 == 0");
@@ -730,8 +718,15 @@ int launch_ln_bwd_x(const float* x, const float* gamma, const float* dy, float* 
     const size_t lds = (size_t)4 * ng * C * sizeof(float);
     auto go = [&](auto nv) {
         constexpr int NV = decltype(nv)::value;
-        if (dxsum) hipLaunchKernelGGL((ln_bwd_kernel<NV, true>), dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, dx16, ws, rows, C, eps, residual);
-        else hipLaunchKernelGGL((ln_bwd_kernel<NV, false>), dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, dx16, ws, rows, C, eps, residual);
+        if (tail)
+            hipLaunchKernelGGL((ln_bwd_kernel<NV, 2>), dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, dx16, ws, rows, C, eps, residual, tail->p,
+                               tail->seed, tail->stream);
+        else if (dxsum)
+            hipLaunchKernelGGL((ln_bwd_kernel<NV, 1>), dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, dx16, ws, rows, C, eps, residual, 0.f,
+                               (uint64_t)0, 0u);
+        else
+            hipLaunchKernelGGL((ln_bwd_kernel<NV, 0>), dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, dx16, ws, rows, C, eps, residual, 0.f,
+                               (uint64_t)0, 0u);
     };
     if (C <= 256) go(std::integral_constant<int, 1>{});
     else if (C <= 512) go(std::integral_constant<int, 2>{});

@@ -62,6 +62,7 @@ struct TrainState {
     // scratch
     float *gh[4] = {nullptr, nullptr, nullptr, nullptr}, *gf = nullptr, *g3h = nullptr, *at = nullptr,
           *slabs = nullptr, *red_ws = nullptr, *dvec = nullptr, *dummy = nullptr, *dwqkv = nullptr, *dwv_scratch = nullptr,
+          *ffn_colpart = nullptr,      // per-wave-tile column sums of du from the down-projection's data-gradient GEMM (-> b1 gradient)
           *attn_colpart = nullptr;     // per-block column sums of dqkv from the bf16 attention backward (-> q|k|v bias gradient)
     int64_t slab_floats = 0;
     // bf16 shadows of the gradient tensors that are the A operand of a data-gradient GEMM (precision mode 1): written by the
@@ -236,6 +237,7 @@ static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
     if (lw > rw) rw = lw;
     if (int e = t_alloc(t, &t->red_ws, rw + 16)) return e;
     if (int e = t_alloc(t, &t->dvec, (int64_t)B * c.num_heads * T)) return e;
+    if (int e = t_alloc(t, &t->ffn_colpart, (int64_t)gemm_train_colpart_rows((int)BT) * F)) return e;
     t->attn_colpart = nullptr;
     if (attention_bf16_supported((int)(H / c.num_heads)))
         if (int e = t_alloc(t, &t->attn_colpart, (int64_t)attention_colpart_rows(B, T) * 3 * H)) return e;
@@ -458,7 +460,8 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
     const bool attn16 = sh && attention_bf16_supported(H / c.num_heads);
     auto gemm = [&](const float* A, const uint16_t* A16, int64_t lda, int64_t strideA, const float* Bw, int64_t ldb, float* Cc,
                     uint16_t* C16, int64_t ldc, int64_t strideC, const float* bias, const float* res, int M, int N, int K,
-                    int nbatch, int act_) -> int {
+                    int nbatch, int act_, const GemmTrainEpi* epi = nullptr) -> int {
+        W2V2_REQUIRE(!epi || sh, "train_forward: a training epilogue without the bf16 shadows");
         if (w2v2_use_split_gemm(m, A, lda, strideA, ldb, M, N, K, nbatch)) {      // precision mode 2 (gemm_split.hip)
             const uint16_t* planes = nullptr;
             if (int e = w2v2_split_planes(m, Bw, K, N, s, &planes)) return e;
@@ -466,10 +469,12 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
         }
         if (!sh) return launch_gemm(pf, A, lda, strideA, Bw, ldb, Cc, ldc, strideC, bias, res, M, N, K, nbatch, act_, s);
         GemmShadows x;
-        x.A16 = A16; x.B16 = m->w16[Bw]; x.C16 = C16; x.ldb16 = K;
+        x.A16 = A16; x.B16 = m->w16[Bw]; x.C16 = C16; x.ldb16 = K; x.epi = epi;
         return launch_gemm_bf16_x(pf, A, lda, strideA, Bw, ldb, 0, Cc, ldc, strideC, bias, res, M, N, K, nbatch, act_, x, s);
     };
     auto S16 = [&](uint16_t* p16) -> uint16_t* { return sh ? p16 : nullptr; };
+    // can this Dense layer's GEMM take a training epilogue?  (shadows on => both operands stream as bf16: w2v2_ensure_shadows)
+    auto epi_ok = [&](int M, int N, int K) { return sh && K % 64 == 0 && gemm_train_epilogue_ok(M, N, K, N); };
     const int NC = c.num_conv_layers;
 
     // ---- frozen feature extractor: identical to inference (no dropout inside, feature_extractor.py:54-59) ----
@@ -575,10 +580,18 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
                                              H, c.num_heads, tr, s))
             return e;
         // o = ctx Wo + bo;  t1 = dropout(o) + x   (encoder.py:116-119)
-        if (int e = gemm(l.ctx, attn16 ? l.ctx16 : nullptr, H, 0, m->P(b + "/attention/out_proj/kernel"), H, m->t0, nullptr, H, 0,
-                         m->P(b + "/attention/out_proj/bias"), nullptr, (int)BT, H, H, 1, 0))
-            return e;
-        if (int e = launch_dropout_fwd(m->t0, x, l.t1, BT * H, 0, p, seed, layer_stream(i, 1), s)) return e;
+        if ((gemm_train_epilogue_sites() & 2) && attn16 && epi_ok((int)BT, H, H)) {         // dropout and the residual add ride in the GEMM's epilogue
+            GemmTrainEpi ep;
+            ep.mode = 1; ep.p = p; ep.seed = seed; ep.stream = layer_stream(i, 1);
+            if (int e = gemm(nullptr, l.ctx16, H, 0, m->P(b + "/attention/out_proj/kernel"), H, l.t1, nullptr, H, 0,
+                             m->P(b + "/attention/out_proj/bias"), x, (int)BT, H, H, 1, 0, &ep))
+                return e;
+        } else {
+            if (int e = gemm(l.ctx, attn16 ? l.ctx16 : nullptr, H, 0, m->P(b + "/attention/out_proj/kernel"), H, m->t0, nullptr, H, 0,
+                             m->P(b + "/attention/out_proj/bias"), nullptr, (int)BT, H, H, 1, 0))
+                return e;
+            if (int e = launch_dropout_fwd(m->t0, x, l.t1, BT * H, 0, p, seed, layer_stream(i, 1), s)) return e;
+        }
         // postnorm: t2 = LN1(t1) feeds the FFN and is its residual; prenorm: t2 = LN2(t1) feeds the FFN, t1 is the residual
         const char* ln_a = prenorm ? "/final_layer_norm" : "/layer_norm";
         if (int e = launch_layer_norm_x(pf, l.t1, l.t2, m->P(b + ln_a + "/gamma"), m->P(b + ln_a + "/beta"), BT, H, eps, 0, S16(l.t2_16), s)) return e;
@@ -586,11 +599,19 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
         float* ffn_out = prenorm ? m->hs[i + 1] : l.t3;
         if (l.keep != 0.f) {
             // u = t2 W1 + b1;  gd = dropout(GELU(u));  out = res + keep * (gd W2 + b2)   (encoder.py:127-130)
-            if (int e = gemm(l.t2, S16(l.t2_16), H, 0, m->P(b + "/feed_forward/intermediate_dense/kernel"), F, l.u, nullptr, F, 0,
-                             m->P(b + "/feed_forward/intermediate_dense/bias"), nullptr, (int)BT, F, H, 1, 0))
-                return e;
-            // (ffn16_only: every reader of gd -- this GEMM, and the down-projection's weight gradient -- streams the bf16 shadow)
-            if (int e = launch_dropout_fwd_x(l.u, nullptr, ffn16_only ? nullptr : l.gd, S16(l.gd16), BT * F, act_ew, p, seed, layer_stream(i, 2), s)) return e;
+            // (ffn16_only: every reader of gd -- the next GEMM, and the down-projection's weight gradient -- streams the bf16 shadow)
+            if ((gemm_train_epilogue_sites() & 1) && sh && epi_ok((int)BT, F, H)) {         // GELU and dropout ride in the epilogue; u is kept in fp32 for the backward
+                GemmTrainEpi ep;
+                ep.mode = 1; ep.act = act_ew; ep.p = p; ep.seed = seed; ep.stream = layer_stream(i, 2); ep.pre = l.u;
+                if (int e = gemm(l.t2, l.t2_16, H, 0, m->P(b + "/feed_forward/intermediate_dense/kernel"), F, ffn16_only ? nullptr : l.gd, l.gd16, F, 0,
+                                 m->P(b + "/feed_forward/intermediate_dense/bias"), nullptr, (int)BT, F, H, 1, 0, &ep))
+                    return e;
+            } else {
+                if (int e = gemm(l.t2, S16(l.t2_16), H, 0, m->P(b + "/feed_forward/intermediate_dense/kernel"), F, l.u, nullptr, F, 0,
+                                 m->P(b + "/feed_forward/intermediate_dense/bias"), nullptr, (int)BT, F, H, 1, 0))
+                    return e;
+                if (int e = launch_dropout_fwd_x(l.u, nullptr, ffn16_only ? nullptr : l.gd, S16(l.gd16), BT * F, act_ew, p, seed, layer_stream(i, 2), s)) return e;
+            }
             if (int e = gemm(ffn16_only ? nullptr : l.gd, S16(l.gd16), F, 0, m->P(b + "/feed_forward/output_dense/kernel"), H, ffn_out, nullptr, H, 0,
                              m->P(b + "/feed_forward/output_dense/bias"), ffn_res, (int)BT, H, F, 1, 0))
                 return e;
@@ -641,7 +662,8 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     const bool shb = m->precision == 1 && w2v2_shadows_enabled() && m->w16_valid;
     // A16: the producer's bf16 shadow of A (or null): with it both operands stream by LDS-DMA (gemm_bf16.hip source 5)
     auto gemm_dx = [&](const float* A, const uint16_t* A16, int64_t lda, const float* WT, const float* W, float* Cc, int64_t ldc,
-                       const float* res, int M, int N, int K, hipStream_t st, uint16_t* C16 = nullptr) -> int {
+                       const float* res, int M, int N, int K, hipStream_t st, uint16_t* C16 = nullptr, const GemmTrainEpi* epi = nullptr) -> int {
+        W2V2_REQUIRE(!epi || (shb && m->w16p.find(W) != m->w16p.end()), "train_backward: a training epilogue without the weight's bf16 shadow");
         // (C16: bf16 shadow of the result, only from the shadow branch -- callers ask for it only when `dx_shadowed(W)`)
         if (shb) {
             auto it = m->w16p.find(W);
@@ -651,6 +673,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
                 x.C16 = C16;
                 x.B16 = it->second;
                 x.ldb16 = K;
+                x.epi = epi;
                 return launch_gemm_bf16_x(m->prof, A, lda, 0, WT, N, 0, Cc, ldc, 0, nullptr, res, M, N, K, 1, 0, x, st);
             }
         }
@@ -775,6 +798,28 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         return W2V2_OK;
     };
 
+    // dgd = dY W2^T (the down-projection's data gradient), then du = dropout-backward(dgd) * GELU'(u) with its column sums (the
+    // up-projection's bias gradient).  Where du is wanted only as bf16 the second step rides in the GEMM's epilogue and dgd never
+    // reaches memory; otherwise the GEMM writes dgd to t->gf and the element-wise kernel follows.
+    auto ffn_hidden_grad = [&](int i, LayerSave& l, const std::string& b, const float* dy, const uint16_t* dy16, bool du16_only, float* gb1,
+                               bool* b1_done) -> int {
+        const float* W2 = m->P(b + "/feed_forward/output_dense/kernel");
+        *b1_done = false;
+        if ((gemm_train_epilogue_sites() & 4) && du16_only && dy16 && s16f && dx_shadowed(W2) && gemm_train_epilogue_ok((int)BT, F, H, F)) {
+            GemmTrainEpi ep;
+            ep.mode = 2; ep.act = act_ew; ep.p = p; ep.seed = seed; ep.stream = layer_stream(i, 2); ep.u = l.u;
+            ep.colpart = gb1 ? t->ffn_colpart : nullptr;
+            if (int e = gemm_dx(nullptr, dy16, H, l.W2T, W2, nullptr, F, nullptr, (int)BT, F, H, s, s16f, &ep)) return e;
+            if (gb1) {
+                if (int e = launch_colsum_fold(t->ffn_colpart, gb1, gemm_train_colpart_rows((int)BT), F, s)) return e;
+                *b1_done = true;
+            }
+            return W2V2_OK;
+        }
+        if (int e = gemm_dx(dy, dy16, H, l.W2T, W2, t->gf, F, nullptr, (int)BT, F, H, s)) return e;
+        return dropout_bwd_bias(l.u, t->gf, du16_only ? nullptr : t->gf, s16f, BT, F, act_ew, layer_stream(i, 2), gb1, b1_done);
+    };
+    static const bool fuse_do_tail = !getenv("W2V2_NO_DO_TAIL");
     bool dh16_valid = false;
     if (prenorm && s16h && (BT * H) % 4 == 0 && (reinterpret_cast<uintptr_t>(dh) & 15) == 0) {
         // the last layer's output gradient arrives in fp32 only: round it once so that its down-projection GEMMs stream shadows too
@@ -789,37 +834,44 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         float* dt1 = tmp3;
         // dh's bf16 shadow (written by the previous iteration's closing axpby into s16h, which is free again by then)
         const uint16_t* dh16 = dh16_valid ? s16h : nullptr;
+        bool bo_done = false;
+        float* const gbo = G(b + "/attention/out_proj/bias");
+        // (d_o is read only as bf16 when both of its GEMMs stream shadows and its column sums come from the producer: the
+        //  dropout backward that makes it then rides in the tail of the LayerNorm backward that produces dt1)
+        const bool do16_only = xs && t->x16_attn && s16h && H % 128 == 0 && (BT * H) % 4 == 0 && dx_shadowed(m->P(b + "/attention/out_proj/kernel"));
+        bool do_tail = do16_only && shb && fuse_do_tail;
+        const LnDropTail do_drop{p, seed, layer_stream(i, 1)};
         if (l.keep != 0.f) {
             W2V2_REQUIRE(!f16 || dh16, "train_backward: no bf16 shadow of the layer's output gradient");
             if (int e = weight_grad(m, f16 ? nullptr : l.gd, dh, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
                                     G(b + "/feed_forward/output_dense/bias"), s, (xs && dh16) ? l.gd16 : nullptr, dh16))
                 return e;
-            if (int e = gemm_dx(dh, dh16, H, l.W2T, m->P(b + "/feed_forward/output_dense/kernel"), t->gf, F, nullptr, (int)BT, F, H, s)) return e;
             bool b1_done = false;
             float* const gb1 = G(b + "/feed_forward/intermediate_dense/bias");
             // (f16: du is needed only as bf16 -- both consumers stream the shadow -- unless its fp32 column sums are still to be taken)
             const bool du16_only = f16 && (!gb1 || shb) && dx_shadowed(m->P(b + "/feed_forward/intermediate_dense/kernel"));
             float* const du = du16_only ? nullptr : t->gf;
-            if (int e = dropout_bwd_bias(l.u, t->gf, du, s16f, BT, F, act_ew, layer_stream(i, 2), gb1, &b1_done)) return e;
+            if (int e = ffn_hidden_grad(i, l, b, dh, dh16, du16_only, gb1, &b1_done)) return e;
             if (int e = weight_grad(m, l.t2, du, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
                                     b1_done ? nullptr : gb1, s, xs ? l.t2_16 : nullptr, s16f))
                 return e;
             if (int e = gemm_dx(du, s16f, F, l.W1T, m->P(b + "/feed_forward/intermediate_dense/kernel"), tmp, H, nullptr, (int)BT, H, F, s)) return e;
             float* dg2 = G(b + "/final_layer_norm/gamma");
             float* db2 = G(b + "/final_layer_norm/beta");
-            // dt1 = dh (residual) + LN2-backward(tmp), one pass
-            if (int e = launch_ln_bwd_x(l.t1, m->P(b + "/final_layer_norm/gamma"), tmp, dt1, nullptr, dg2 ? dg2 : t->dummy,
-                                        db2 ? db2 : t->dummy + H, BT, H, eps, t->red_ws, s, nullptr, dh))
+            // dt1 = dh (residual) + LN2-backward(tmp), one pass (+ d_o's shadow and column sums where nothing reads d_o in fp32;
+            // dh16 in s16h is dead by now)
+            if (int e = launch_ln_bwd_x(l.t1, m->P(b + "/final_layer_norm/gamma"), tmp, dt1, do_tail ? s16h : nullptr, dg2 ? dg2 : t->dummy,
+                                        db2 ? db2 : t->dummy + H, BT, H, eps, t->red_ws, s, do_tail ? (gbo ? gbo : t->dummy + 2 * H) : nullptr, dh,
+                                        do_tail ? &do_drop : nullptr))
                 return e;
+            bo_done = do_tail && gbo;
         } else {
             W2V2_HIP_CHECK(hipMemcpyAsync(dt1, dh, (size_t)BT * H * 4, hipMemcpyDeviceToDevice, s));
+            do_tail = false;
         }
         float* d_o = tmp;
-        bool bo_done = false;
-        float* const gbo = G(b + "/attention/out_proj/bias");
-        // (d_o is read only as bf16 when both of its GEMMs stream shadows and its column sums come from the producer)
-        const bool do16_only = xs && t->x16_attn && s16h && H % 128 == 0 && (BT * H) % 4 == 0 && dx_shadowed(m->P(b + "/attention/out_proj/kernel"));
-        if (int e = dropout_bwd_bias(nullptr, dt1, do16_only ? nullptr : d_o, s16h, BT, H, 0, layer_stream(i, 1), gbo, &bo_done)) return e;
+        if (!do_tail)
+            if (int e = dropout_bwd_bias(nullptr, dt1, do16_only ? nullptr : d_o, s16h, BT, H, 0, layer_stream(i, 1), gbo, &bo_done)) return e;
         if (int e = weight_grad(m, l.ctx, do16_only ? nullptr : d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), bo_done ? nullptr : gbo, s,
                                 (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h))
             return e;
@@ -862,14 +914,13 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
             if (int e = weight_grad(m, f16 ? nullptr : l.gd, dt3, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
                                     gb2 ? nullptr : G(b + "/feed_forward/output_dense/bias"), s, xs ? l.gd16 : nullptr, H % 4 == 0 ? s16h : nullptr))
                 return e;
-            if (int e = gemm_dx(dt3, H % 4 == 0 ? s16h : nullptr, H, l.W2T, m->P(b + "/feed_forward/output_dense/kernel"), t->gf, F, nullptr, (int)BT, F, H, s)) return e;
             // du = dgd * keep/(1-p) * GELU'(u)   (+ its column sums = the up-projection's bias gradient)
             bool b1_done = false;
             float* const gb1 = G(b + "/feed_forward/intermediate_dense/bias");
             // (f16: du is needed only as bf16 -- both consumers stream the shadow, the column sums come from the producer)
             const bool du16_only = f16 && (!gb1 || shb) && dx_shadowed(m->P(b + "/feed_forward/intermediate_dense/kernel"));
             float* const du = du16_only ? nullptr : t->gf;
-            if (int e = dropout_bwd_bias(l.u, t->gf, du, s16f, BT, F, act_ew, layer_stream(i, 2), gb1, &b1_done)) return e;
+            if (int e = ffn_hidden_grad(i, l, b, dt3, H % 4 == 0 ? s16h : nullptr, du16_only, gb1, &b1_done)) return e;
             if (int e = weight_grad(m, l.t2, du, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
                                     b1_done ? nullptr : gb1, s, xs ? l.t2_16 : nullptr, s16f))
                 return e;
@@ -882,16 +933,22 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         float* dt1 = tmp3;
         float* dg1 = G(b + "/layer_norm/gamma");
         float* db1 = G(b + "/layer_norm/beta");
-        if (int e = launch_ln_bwd(l.t1, m->P(b + "/layer_norm/gamma"), dt2, dt1, dg1 ? dg1 : t->dummy, db1 ? db1 : t->dummy + H, BT, H,
-                                  eps, t->red_ws, s))
-            return e;
         // t1 = dropout(o) + x,  o = ctx Wo + bo
         float* d_o = tmp;     // dt3 (and its shadow) is dead
         bool bo_done = false;
         float* const gbo = G(b + "/attention/out_proj/bias");
-        // (d_o is read only as bf16 when both of its GEMMs stream shadows and its column sums come from the producer)
+        // (d_o is read only as bf16 when both of its GEMMs stream shadows and its column sums come from the producer: the
+        //  dropout backward that makes it then rides in the tail of the LayerNorm backward that produces dt1)
         const bool do16_only = xs && t->x16_attn && s16h && H % 128 == 0 && (BT * H) % 4 == 0 && dx_shadowed(m->P(b + "/attention/out_proj/kernel"));
-        if (int e = dropout_bwd_bias(nullptr, dt1, do16_only ? nullptr : d_o, s16h, BT, H, 0, layer_stream(i, 1), gbo, &bo_done)) return e;
+        const bool do_tail = do16_only && shb && fuse_do_tail;
+        const LnDropTail do_drop{p, seed, layer_stream(i, 1)};
+        if (int e = launch_ln_bwd_x(l.t1, m->P(b + "/layer_norm/gamma"), dt2, dt1, do_tail ? s16h : nullptr, dg1 ? dg1 : t->dummy,
+                                    db1 ? db1 : t->dummy + H, BT, H, eps, t->red_ws, s, do_tail ? (gbo ? gbo : t->dummy + 2 * H) : nullptr, nullptr,
+                                    do_tail ? &do_drop : nullptr))
+            return e;
+        bo_done = do_tail && gbo;
+        if (!do_tail)
+            if (int e = dropout_bwd_bias(nullptr, dt1, do16_only ? nullptr : d_o, s16h, BT, H, 0, layer_stream(i, 1), gbo, &bo_done)) return e;
         if (int e = weight_grad(m, l.ctx, do16_only ? nullptr : d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), bo_done ? nullptr : gbo, s,
                                 (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h))
             return e;
