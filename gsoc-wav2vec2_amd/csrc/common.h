@@ -142,6 +142,9 @@ struct GemmShadows {
     // transposing LDS read ds_read_b64_tr_b16 (gemm_bf16.hip: gemm_bf16_tr_kernel).  No column sums in this form (they are sums
     // of the UNROUNDED gradient): `colsum` must be null.
     const uint16_t* B16p = nullptr;
+    // (that form only) the K dimension really has validK rows over all batches, K * nbatch >= validK > K * (nbatch - 1): rows past
+    // it are read as zero.  0 = K * nbatch.  Lets dW = X^T dY run over B T = 23984 rows (T = 1499) without a leftover-row pass.
+    int64_t validK = 0;
 };
 int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
                        int64_t strideB, float* C, int64_t ldc, int64_t strideC, const float* bias,

@@ -60,6 +60,8 @@ struct Gemm16Args {
     float* colsum;
     int64_t strideCS;
     GemmTrainEpiDev epi;   // training epilogue (EPI instances of the kernel only)
+    int64_t validK;        // tr form: rows of the K dimension that exist, over all batches (batch z owns [z K, (z + 1) K)); rows beyond
+                           // read as zero, so neither the row count nor its split into slabs has to be a multiple of the K tile
     int abl;      // timing ablations (W2V2_GEMM16_ABL, results are wrong by construction): 1 = no operand traffic in the K loop,
                   // 2 = no MFMAs, 4 = no epilogue
 };
@@ -525,6 +527,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
 // receives rows 0 .. 3 of column c).  A lane of a 32x32x16 MFMA needs column (lane % 32) and the 8 k rows 8 (lane / 32) .. + 7:
 // two such reads.  Same tile / stage / barrier structure as the forward LDS-DMA kernel (source 5).  No epilogue extras:
 // C (M, N) fp32 slabs, one per batch.
+__device__ __attribute__((aligned(16))) const uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};      // DMA source of the rows past validK
+
 template <int WM, int WN, int MINB>
 __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_tr_kernel(Gemm16Args g) {
     constexpr int BM = 128, BN = 128, NWV = WM * WN;
@@ -549,6 +553,11 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_tr_kernel(Gemm16A
     const uint16_t* __restrict__ Az = g.A16 + (int64_t)z * g.strideA + m0;
     const uint16_t* __restrict__ Bz = g.B16p + (int64_t)z * g.strideB + n0;
     const int nk = g.K / BK;
+    // rows of this batch that exist (a select on the source address, not a branch: control flow around the DMA issue makes the
+    // compiler drain vmcnt in front of the next LDS read)
+    const int64_t kleft = g.validK - (int64_t)z * g.K;
+    const uint16_t* const zsrc = reinterpret_cast<const uint16_t*>(g_zero16);
+    int prow[PP];
 
     // DMA: piece p of an image = rows 4p .. 4p+3; lane -> row 4p + lane / 16, 16-byte chunk lane % 16 (8 columns)
     const uint16_t* da[PP];
@@ -561,18 +570,23 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_tr_kernel(Gemm16A
         const int chunk = (lane & 15) ^ (4 * (row & 3));
         da[i] = Az + (int64_t)row * g.lda + 8 * chunk;
         db[i] = Bz + (int64_t)row * g.ldb + 8 * chunk;
+        prow[i] = row;
     }
     auto issue = [&](int kt, int buf) {
         unsigned char* S = smem16 + buf * STAGE;
         const int64_t k0 = (int64_t)kt * BK;
 #pragma unroll
-        for (int i = 0; i < PP; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(da[i] + k0 * g.lda),
+        for (int i = 0; i < PP; ++i) {
+            const uint16_t* src = k0 + prow[i] < kleft ? da[i] + k0 * g.lda : zsrc;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(S + (wave * PP + i) * 1024), 16, 0, 0);
+        }
 #pragma unroll
-        for (int i = 0; i < PP; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db[i] + k0 * g.ldb),
+        for (int i = 0; i < PP; ++i) {
+            const uint16_t* src = k0 + prow[i] < kleft ? db[i] + k0 * g.ldb : zsrc;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(S + IMG + (wave * PP + i) * 1024), 16, 0, 0);
+        }
     };
 
     // fragment addresses: group = lane / 16 -> column half (group & 1), k half = lane / 32; l = lane % 16 -> row l / 4, chunk l % 4
@@ -764,6 +778,9 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
     g.zmod = x.zmod; g.strideB16 = x.strideB16; g.strideC2 = x.strideC2; g.strideBias = x.strideBias; g.strideB2 = x.strideB2;
     g.colsum = x.transA ? x.colsum : nullptr; g.strideCS = x.strideCS;
     g.B16p = x.B16p;
+    g.validK = x.validK > 0 ? x.validK : (int64_t)K * nbatch;
+    W2V2_REQUIRE(x.validK == 0 || (x.transA && x.A16 && x.B16p && x.validK > (int64_t)K * (nbatch - 1) && x.validK <= (int64_t)K * nbatch),
+                 "gemm_bf16: validK is for the transposed-A shadow form, and every batch must own at least one existing row");
     g.epi = GemmTrainEpiDev{};
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("W2V2_GEMM16_ABL"); abl = e ? atoi(e) : 0; }
@@ -788,6 +805,7 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
             ProfScope ps(prof, FAM_GEMM_BF16, 2.0 * M * (double)N * K * nbatch, nbatch * (2.0 * K * ((double)M + N) + 4.0 * (double)M * N), s);
             return launch_tr16(g, nbatch, s);
         }
+        W2V2_REQUIRE(x.validK == 0, "gemm_bf16: validK needs the LDS-DMA weight-gradient form (both shadows, whole 128 x 128 tiles)");
         W2V2_REQUIRE(A && kfast && b32 && (M % 4 == 0) && (lda % 4 == 0) && (strideA % 4 == 0) &&
                          ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda >= M || x.overlapA),
                      "gemm_bf16: transposed A needs fp32 A and B, K %% 64 == 0, M %% 4 == 0 and 16-byte alignment");

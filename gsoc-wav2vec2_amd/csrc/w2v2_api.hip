@@ -846,6 +846,16 @@ int w2v2_op_gemm_bf16_at(const float* At, int64_t lda, int64_t strideA, const fl
     return launch_gemm_bf16_x(nullptr, At, lda, strideA, B, ldb, strideB, C, ldc, strideC, nullptr, nullptr, M, N, K, nbatch, 0, x,
                               reinterpret_cast<hipStream_t>(stream));
 }
+int w2v2_op_weight_grad_bf16(const uint16_t* x16, const uint16_t* dy16, float* slabs, int64_t rows, int32_t Kin, int32_t Nout,
+                             int32_t rows_per_slab, int32_t nslabs, void* stream) {
+    W2V2_REQUIRE(x16 && dy16 && slabs && rows > 0 && rows_per_slab > 0 && nslabs > 0 && Kin % 128 == 0 && Nout % 128 == 0 &&
+                     rows_per_slab % 64 == 0, "op_weight_grad_bf16: bad argument");
+    GemmShadows x;
+    x.transA = true; x.A16 = x16; x.B16p = dy16;
+    x.validK = rows == (int64_t)rows_per_slab * nslabs ? 0 : rows;
+    return launch_gemm_bf16_x(nullptr, nullptr, Kin, (int64_t)rows_per_slab * Kin, nullptr, Nout, (int64_t)rows_per_slab * Nout, slabs, Nout,
+                              (int64_t)Kin * Nout, nullptr, nullptr, Kin, Nout, rows_per_slab, nslabs, 0, x, reinterpret_cast<hipStream_t>(stream));
+}
 int w2v2_op_layer_norm(const float* x, float* y, const float* gamma, const float* beta, int64_t rows,
                        int32_t C, float eps, int32_t act, void* stream) {
     return launch_layer_norm(nullptr, x, y, gamma, beta, rows, C, eps, act, reinterpret_cast<hipStream_t>(stream));

@@ -334,6 +334,34 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
         while (cap > 1 && (tiles * cap > max_blocks || (int64_t)(cap + 2) * Kin * Nout > t->slab_floats)) --cap;
         // S must divide the number of kq-row units; if M / kq has no useful divisor (a prime, say), give up to 15 more
         // units to the leftover slab until one appears
+        // both bf16 shadows and whole 128 x 128 tiles: the LDS-DMA + transposing-read kernel; it has no fp32 dY in registers,
+        // so the bias gradient (a sum of the UNROUNDED dY) takes the column-sum pass below instead of riding along.  In this form
+        // the fp32 A / dY are not read at all (callers may pass null when nothing else needs them).
+        const bool tr_form = direct && A16 && dY16 && Kin % 128 == 0 && Nout % 128 == 0;
+        W2V2_REQUIRE(tr_form || (A && dY), "weight_grad: the fp32 operands are needed here (no bf16 shadows / shapes not whole 128-tiles)");
+        // That kernel reads rows past M as zero (GemmShadows::validK), so any M splits into S slabs of ceil(M / 64 / S) K tiles with
+        // no leftover pass: the last slab is merely short.
+        static const bool ragged = !getenv("W2V2_NO_RAGGED_DW");      // tuning knob: leftover rows on the tail kernel instead
+        if (tr_form && ragged && M % kq != 0) {
+            const int64_t units_all = (M + kq - 1) / kq;
+            int S = (int)(units_all < cap ? units_all : cap);
+            int64_t per = (units_all + S - 1) / S;
+            while (S > 1 && (int64_t)(S - 1) * per >= units_all) { --S; per = (units_all + S - 1) / S; }     // (no empty slab)
+            const int Kp = (int)(per * kq);
+            W2V2_REQUIRE(S == 1 || (int64_t)(S + 1) * Kin * Nout <= t->slab_floats, "weight_grad: slab scratch too small");
+            GemmShadows x;
+            x.transA = true; x.A16 = A16; x.B16p = dY16; x.validK = M;
+            if (int e = launch_gemm_bf16_x(m->prof, nullptr, Kin, (int64_t)Kp * Kin, nullptr, Nout, (int64_t)Kp * Nout, S == 1 ? dW : t->slabs, Nout,
+                                           (int64_t)Kin * Nout, nullptr, nullptr, Kin, Nout, Kp, S, 0, x, s))
+                return e;
+            if (S > 1)
+                if (int e = launch_colsum(t->slabs, dW, S, Kin * Nout, t->slabs + (int64_t)S * Kin * Nout, 0, s)) return e;
+            if (db) {
+                W2V2_REQUIRE(dY, "weight_grad: the bias gradient needs the fp32 dY");
+                if (int e = launch_colsum(dY, db, M, Nout, t->red_ws, 0, s)) return e;
+            }
+            return W2V2_OK;
+        }
         const int64_t units0 = M / kq;
         int64_t units = units0;
         int S = units0 > 0 ? 1 : 0;
@@ -350,11 +378,6 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
         W2V2_REQUIRE(nslabs == 1 || (int64_t)(nslabs + 1) * Kin * Nout <= t->slab_floats, "weight_grad: slab scratch too small");
         float* dst = nslabs == 1 ? dW : t->slabs;
         const int Kp = S ? Mq / S : 0;
-        // both bf16 shadows and whole 128 x 128 tiles: the LDS-DMA + transposing-read kernel; it has no fp32 dY in registers,
-        // so the bias gradient (a sum of the UNROUNDED dY) takes the column-sum pass below instead of riding along.  In this form
-        // the fp32 A / dY are not read at all (callers may pass null when nothing else needs them).
-        const bool tr_form = direct && A16 && dY16 && Kin % 128 == 0 && Nout % 128 == 0;
-        W2V2_REQUIRE(tr_form || (A && dY), "weight_grad: the fp32 operands are needed here (no bf16 shadows / shapes not whole 128-tiles)");
         if (S) {
             if (direct) {
                 GemmShadows x;

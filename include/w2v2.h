@@ -273,6 +273,14 @@ int w2v2_op_gemm_bf16_at(const float* At_dev, int64_t lda, int64_t strideA,
                          float* C_dev, int64_t ldc, int64_t strideC,
                          int32_t M, int32_t N, int32_t K, int32_t nbatch, void* stream);
 
+/* The same weight gradient from bf16 copies of both operands in their natural layouts: slab z (Kin, Nout) = X_z^T dY_z over rows
+ * [z rows_per_slab, (z + 1) rows_per_slab) of x16 (rows, Kin) and dy16 (rows, Nout), uint16 bf16 bit patterns, row-major.  `rows`
+ * need not fill the last slab (nor be a multiple of the 64-row K tile): rows past it count as zero, every slab must own at least
+ * one row.  Kin % 128 == 0, Nout % 128 == 0, rows_per_slab % 64 == 0, 16-byte aligned operands.  (The fine-tune step's dW GEMMs
+ * in W2V2_PRECISION_BF16: tf.GradientTape's kernel gradient of Dense, src/main.py:198.) */
+int w2v2_op_weight_grad_bf16(const uint16_t* x16_dev, const uint16_t* dy16_dev, float* slabs_dev,
+                             int64_t rows, int32_t Kin, int32_t Nout, int32_t rows_per_slab, int32_t nslabs, void* stream);
+
 /* y = LN(x) * gamma + beta over the last axis, optional GELU after
  * (tf.keras.layers.LayerNormalization(axis=-1); act as above). rows x C. */
 int w2v2_op_layer_norm(const float* x_dev, float* y_dev, const float* gamma_dev,

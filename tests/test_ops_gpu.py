@@ -248,6 +248,32 @@ def test_gemm_split_rejects_unsupported_shapes(env):
     assert lib.w2v2_op_gemm_split(N.ptr(A), 32, 0, N.ptr(B), N.ptr(out), 96, 0, None, None, 64, 96, 32, 1, 0, stream()) == -1   # N % 256
 
 
+@pytest.mark.parametrize("rows,Kin,Nout,per,S", [(512, 128, 256, 128, 4), (1499 * 2, 256, 128, 1024, 3), (23984, 128, 384, 12032, 2),
+                                                 (65, 128, 128, 64, 2), (37, 128, 128, 64, 1)])
+def test_weight_grad_bf16_ragged_rows(env, rows, Kin, Nout, per, S):
+    """dW = X^T dY from the bf16 copies of both operands (LDS-DMA + transposing LDS reads), S slabs of `per` rows: the row count
+    need not fill the last slab or be a multiple of the 64-row K tile (B T = 23984 at 16 x 480000 samples) -- rows past it count
+    as zero, whatever the memory behind the operands holds (here: NaN patterns)."""
+    lib, torch, dev = env
+    X, dY = rnd("wgX", (rows, Kin)), rnd("wgY", (rows, Nout), 0.3)
+    Xr, Yr = O.round_bf16(X), O.round_bf16(dY)
+    def dev16(a, pad_rows):      # bf16 bit patterns, followed by rows of NaN
+        bits = (a.view(np.uint32) >> 16).astype(np.uint16)
+        full = np.concatenate([bits, np.full((pad_rows, a.shape[1]), 0x7FC0, np.uint16)])
+        return torch.from_numpy(full.view(np.int16)).to(dev)
+    pad = per * S - rows
+    assert 0 <= pad < per
+    x16, y16 = dev16(Xr, pad), dev16(Yr, pad)
+    out = torch.full((S, Kin, Nout), float("nan"), device=dev)
+    N.check(lib.w2v2_op_weight_grad_bf16(N.ptr(x16), N.ptr(y16), N.ptr(out), rows, Kin, Nout, per, S, stream()))
+    got = out.cpu().numpy()
+    for z in range(S):
+        ref = Xr[z * per:(z + 1) * per].astype(np.float64).T @ Yr[z * per:(z + 1) * per].astype(np.float64)
+        assert H.max_err(got[z], ref) < 2e-5 * max(1.0, np.abs(ref).max()), z
+    # an empty slab is an error, not silent zeros
+    assert lib.w2v2_op_weight_grad_bf16(N.ptr(x16), N.ptr(y16), N.ptr(out), max(1, per * (S - 1)), Kin, Nout, per, S, stream()) == -1 or S == 1
+
+
 @pytest.mark.parametrize("rows,Kin,Nout,S", [(256, 128, 132, 1), (512, 768, 64, 4), (1024, 132, 256, 8)])
 def test_gemm_bf16_transposed_a_split_k(env, rows, Kin, Nout, S):
     """dW = X^T dY as the training step runs it in precision mode 1: X (rows, Kin) is passed as the TRANSPOSED A of the GEMM
