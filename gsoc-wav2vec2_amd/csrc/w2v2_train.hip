@@ -799,7 +799,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
                                 (xs && s16q) ? attn_in16 : nullptr, s16q))
             return e;
         if (only16)
-            if (int e = launch_colsum(t->attn_colpart, dbqkv, attention_colpart_rows(B, T), 3 * H, t->red_ws, 0, s)) return e;
+            if (int e = launch_colsum_fold(t->attn_colpart, dbqkv, attention_colpart_rows(B, T), 3 * H, s)) return e;
         const char* names[3] = {"q_proj", "k_proj", "v_proj"};
         if (H % 4 == 0) {
             float* gw3[3];
