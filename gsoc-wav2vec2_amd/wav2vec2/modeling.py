@@ -341,38 +341,56 @@ class TFKerasModel(Layer):
         return [("wav2vec2", [(n, a) for n, a in named if "/lm_head/" not in n]), ("dropout", []), ("lm_head", head)]
 
     def save_weights(self, path):
-        """`*.h5`: a Keras-layout HDF5 weight file written by the package's own HDF5 writer (wav2vec2/h5lite.py) -- the
-        container of the reference's `tf_model.h5` (modeling.py:26); `*.npz`: numpy archive keyed by TF variable names."""
+        """Keras' rule (`Model.save_weights`): a path ending in `.h5` / `.hdf5` / `.keras` is a Keras-layout HDF5 weight file,
+        written by the package's own HDF5 writer (wav2vec2/h5lite.py) -- the container of the reference's `tf_model.h5`
+        (modeling.py:26); any other path is the PREFIX of a TensorFlow checkpoint (`<path>.index` + `<path>.data-00000-of-00001`,
+        wav2vec2/tfckpt.py) -- what the reference's ModelCheckpoint writes to `.../tf_model` (training_utils.py:32-45).
+        `*.npz`: numpy archive keyed by TF variable names."""
         weights = self.get_weights()
         if path.endswith(".npz"):
             np.savez(path, **{V.tf_variable_name(n, self._prefix_with_head): a for n, a in weights.items()})
             return
-        from . import h5lite
-        h5lite.save_keras_weights(path, self._keras_layers(weights))
+        if path.endswith((".h5", ".hdf5", ".keras")):
+            from . import h5lite
+            h5lite.save_keras_weights(path, self._keras_layers(weights))
+            return
+        from . import tfckpt
+        # (checkpoint keys are variable names without the `:0` output suffix)
+        tfckpt.write_checkpoint(path, {V.tf_variable_name(n, self._prefix_with_head).rsplit(":", 1)[0]: a for n, a in weights.items()})
+
+    def _match_by_name(self, found, where):
+        """{our name: array} out of {TF variable name (possibly under extra leading scopes, possibly `:0`-suffixed): array}."""
+        bare = lambda k: k[:-2] if k.endswith(":0") else k        # HDF5 weight names carry the suffix, checkpoint keys do not
+        found = {bare(k): v for k, v in found.items()}
+        ours = {}
+        for n in self._specs:
+            tfn = bare(V.tf_variable_name(n, self._prefix_with_head))
+            hits = [k for k in found if k == tfn or k.endswith("/" + tfn)]
+            if not hits:
+                # a backbone file loaded into the CTC model (or the reverse): same variables under the other prefix
+                alt = bare(V.tf_variable_name(n, not self._prefix_with_head))
+                hits = [k for k in found if k == alt or k.endswith("/" + alt)]
+            if not hits:
+                raise KeyError(f"`{tfn}` not found in {where}")
+            ours[n] = found[hits[0]]
+        return ours
 
     def load_weights(self, path):
-        """Reads `tf_model.h5` (Keras HDF5 weight file; h5lite, no h5py needed) or a `.npz` of TF variable names.  Variables
-        are matched BY NAME (the TF variable names of convert_torch_to_tf.py:24-44), a missing one raises KeyError."""
+        """Reads `tf_model.h5` (Keras HDF5 weight file; h5lite, no h5py needed), a TensorFlow checkpoint prefix such as
+        `.../tf_model` (src/main.py:132; name-based or object-based, wav2vec2/tfckpt.py) or a `.npz` of TF variable names.
+        Variables are matched BY NAME (the TF variable names of convert_torch_to_tf.py:24-44), a missing one raises KeyError."""
         if path.endswith(".h5") and not os.path.exists(path) and os.path.exists(path[:-3] + ".npz"):
             path = path[:-3] + ".npz"
         if path.endswith(".npz"):
             with np.load(path) as z:
                 self.set_weights({k: z[k] for k in z.files})
             return
+        from . import tfckpt
+        if not os.path.isfile(path) and tfckpt.is_checkpoint(path):
+            self.set_weights(self._match_by_name(tfckpt.read_checkpoint(path), path + ".index"))
+            return
         from . import h5lite
-        found = h5lite.load_keras_weights(path)
-        ours = {}
-        for n in self._specs:
-            tfn = V.tf_variable_name(n, self._prefix_with_head)
-            hits = [k for k in found if k == tfn or k.endswith("/" + tfn)]
-            if not hits:
-                # a backbone file loaded into the CTC model (or the reverse): same variables under the other prefix
-                alt = V.tf_variable_name(n, not self._prefix_with_head)
-                hits = [k for k in found if k == alt or k.endswith("/" + alt)]
-            if not hits:
-                raise KeyError(f"`{tfn}` not found in {path}")
-            ours[n] = found[hits[0]]
-        self.set_weights(ours)
+        self.set_weights(self._match_by_name(h5lite.load_keras_weights(path), path))
 
     def save_pretrained(self, save_dir):
         """config.json + `tf_model.h5`, as reference modeling.py:22-27."""

@@ -281,6 +281,10 @@ int w2v2_op_gemm_bf16_at(const float* At_dev, int64_t lda, int64_t strideA,
 int w2v2_op_weight_grad_bf16(const uint16_t* x16_dev, const uint16_t* dy16_dev, float* slabs_dev,
                              int64_t rows, int32_t Kin, int32_t Nout, int32_t rows_per_slab, int32_t nslabs, void* stream);
 
+/* CRC-32C (Castagnoli; TFRecord and TensorFlow-checkpoint checksums, tensorflow/core/lib/hash/crc32c.h: crc32c::Extend) of `n` host
+ * bytes continuing from `crc` (0 to start).  Host-only helper for the package's checkpoint / record I/O: no device work. */
+uint32_t w2v2_crc32c_extend(uint32_t crc, const void* data_host, uint64_t n);
+
 /* y = LN(x) * gamma + beta over the last axis, optional GELU after
  * (tf.keras.layers.LayerNormalization(axis=-1); act as above). rows x C. */
 int w2v2_op_layer_norm(const float* x_dev, float* y_dev, const float* gamma_dev,

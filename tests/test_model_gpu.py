@@ -276,6 +276,41 @@ def test_end_to_end_decode(torch_mod):
     assert tok.decode(ids) == tok.decode(ref_ids)
 
 
+def test_tensorflow_checkpoint_prefix_roundtrip(torch_mod, tmp_path):
+    """`model.save_weights(".../tf_model")` / `model.load_weights(".../tf_model")` on a path without a suffix is a TensorFlow
+    checkpoint prefix (src/main.py:132, training_utils.py:32-45): `tf_model.index` + `tf_model.data-00000-of-00001`, keyed by the
+    TF variable names; an object-based file (Keras' own `save_weights`) is read through its object graph's variable names."""
+    import wav2vec2
+    from wav2vec2 import tfckpt
+    m, cfg = build("tiny_base")
+    g = H.golden("tiny_base")
+    ref = m(g["wave"]).numpy()
+    prefix = str(tmp_path / "ckpt_stage1" / "tf_model")
+    m.save_weights(prefix)
+    assert sorted(os.listdir(tmp_path / "ckpt_stage1")) == ["tf_model.data-00000-of-00001", "tf_model.index"]
+    names = tfckpt.BundleReader(prefix).keys()
+    assert "wav2vec2-ctc/wav2vec2/masked_spec_embed" in names and "wav2vec2-ctc/lm_head/kernel" in names
+    assert len(names) == len(V.variable_specs(cfg))
+    m2 = wav2vec2.Wav2Vec2ForCTC(cfg, input_shape=(1, 4000))
+    m2.load_weights(prefix)
+    assert np.array_equal(m2(g["wave"]).numpy(), ref)
+    # the same variables as an object-based checkpoint, with `:0`-less names under one more leading scope
+    obj = str(tmp_path / "obj" / "tf_model")
+    tfckpt.write_checkpoint(obj, {"tower/" + n: a for n, a in tfckpt.read_checkpoint(prefix).items()}, object_graph=True)
+    m3 = wav2vec2.Wav2Vec2ForCTC(cfg, input_shape=(1, 4000))
+    m3.load_weights(obj)
+    assert np.array_equal(m3(g["wave"]).numpy(), ref)
+    # the backbone loads the CTC model's checkpoint (other name prefix); a missing variable is a KeyError
+    bb = wav2vec2.Wav2Vec2Model(cfg, input_shape=(1, 4000))
+    bb.load_weights(prefix)
+    k = "encoder/layers/1/feed_forward/output_dense/kernel"
+    assert np.array_equal(bb.get_weights()[k], m.get_weights()[k])
+    part = {n: a for n, a in tfckpt.read_checkpoint(prefix).items() if not n.endswith("lm_head/bias")}
+    tfckpt.write_checkpoint(str(tmp_path / "part" / "tf_model"), part)
+    with pytest.raises(KeyError):
+        m3.load_weights(str(tmp_path / "part" / "tf_model"))
+
+
 def test_variables_and_persistence(torch_mod, tmp_path):
     import wav2vec2
     m, cfg = build("tiny_base")
