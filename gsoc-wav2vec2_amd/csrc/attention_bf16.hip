@@ -236,12 +236,15 @@ __global__ __launch_bounds__(NW * 64, 3) void attention_bf16_kernel(Attn16Args a
             // 1 / (1 - p) factor is applied once, with the final normalisation
             const uint32_t cbase = drop_row + (uint32_t)k0, thr1 = drop_thr - 1u;      // h >= thr  <=>  thr - 1 - h < 0 (16-bit h, thr)
             uint32_t bits = 0;                  // bit 16 kt + r = the keep decision of accumulator register r of sub-tile kt
+            // cbase is even (even row stride, k0 a multiple of 64), so pair = (cbase + col) / 2 = (cbase / 2 + 2 lh) + a
+            // compile-time constant: one multiply per tile, an add per hash word
+            const uint32_t pm0 = ((cbase >> 1) + 2u * (uint32_t)lh) * DROPOUT_FIB;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {      // registers r, r + 1 are keys 2j, 2j + 1 of an even-strided row: one hash word
-                    const uint32_t col = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const uint32_t w = dropout_word(drop_key, (cbase + col) >> 1);
+                    const uint32_t cpair = (uint32_t)(kt * 16 + ((r & 3) >> 1) + 4 * (r >> 2));      // (col - 4 lh) / 2
+                    const uint32_t w = dropout_word_premul(drop_key, pm0 + cpair * DROPOUT_FIB);
                     // all-ones / zero masks by integer arithmetic (sign of thr - 1 - h), applied with AND: no lane masks in SGPRs
                     const uint32_t me = (uint32_t)((int32_t)(thr1 - (w & 0xFFFFu)) >> 31), mo = (uint32_t)((int32_t)(thr1 - (w >> 16)) >> 31);
                     s[kt][r] = __uint_as_float(__float_as_uint(s[kt][r]) & me);

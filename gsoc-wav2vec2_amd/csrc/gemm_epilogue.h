@@ -150,11 +150,13 @@ __device__ __forceinline__ void gemm_epilogue_train(const f32x16_t (&acc)[MT][NT
                 }
             }
             // dropout (forward and backward are the same map): keep ? v / (1 - p) : 0
+            // (pair index = pbase + row offset * hp: pre-multiplied once, the per-register part is a small multiple of hp * FIB)
             const uint32_t pbase = pair0 + (uint32_t)(mt * 32 + 4 * lh) * hp + ((uint32_t)cl >> 1);
+            const uint32_t pm0 = (pbase + odd * hp) * DROPOUT_FIB, hpm = hp * DROPOUT_FIB;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const uint32_t ro = (uint32_t)r + odd;
-                const uint32_t w_self = dropout_word(key, pbase + ((ro & 3u) + 8u * (ro >> 2)) * hp);
+                // this lane hashes the row of register r + odd: row offset (r & 3) + odd + 8 (r >> 2)   (r even: no carry into bit 2)
+                const uint32_t w_self = dropout_word_premul(key, pm0 + (uint32_t)((r & 3) + 8 * (r >> 2)) * hpm);
                 const uint32_t w_peer = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w_self, 0xB1 /* quad_perm [1, 0, 3, 2] */, 0xF, 0xF, false);
                 const uint32_t w0 = odd ? w_peer : w_self, w1 = odd ? w_self : w_peer;     // rows of registers r, r + 1
                 const uint32_t h0 = odd ? (w0 >> 16) : (w0 & 0xFFFFu), h1 = odd ? (w1 >> 16) : (w1 & 0xFFFFu);

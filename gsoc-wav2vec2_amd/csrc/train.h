@@ -41,6 +41,10 @@ __device__ __forceinline__ uint32_t dropout_threshold(float p) {      // 16-bit 
 }
 // the hash word of element pair (2 pair, 2 pair + 1): low half decides the even element, high half the odd one
 __device__ __forceinline__ uint32_t dropout_word(uint32_t key, uint32_t pair) { return lowbias32(pair * 0x9E3779B1u ^ key); }
+// the same word from the pre-multiplied pair index (pair * 0x9E3779B1 mod 2^32): callers whose pair indices are `base + small
+// constant` pay the quarter-rate multiply once per base and an add per word (products distribute over the sum modulo 2^32)
+constexpr uint32_t DROPOUT_FIB = 0x9E3779B1u;
+__device__ __forceinline__ uint32_t dropout_word_premul(uint32_t key, uint32_t pair_times_fib) { return lowbias32(pair_times_fib ^ key); }
 __device__ __forceinline__ bool dropout_keep_lo(uint32_t w, uint32_t thr) { return (w & 0xFFFFu) >= thr; }
 __device__ __forceinline__ bool dropout_keep_hi(uint32_t w, uint32_t thr) { return (w >> 16) >= thr; }
 // general form (one hash per call): key and threshold hoisted by the caller, 32-bit index
