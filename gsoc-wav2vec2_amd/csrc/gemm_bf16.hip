@@ -741,7 +741,9 @@ int forced_cfg16() {
 
 // (the flat element index row * ldc + col is hashed as 32 bits: element-wise kernels and epilogue agree modulo 2^32)
 bool gemm_train_epilogue_ok(int M, int N, int K, int64_t ldc) {
-    return M > 0 && N > 64 && N % 2 == 0 && ldc == N && K % BK == 0;
+    // (M ldc < 2^32: the epilogue steps pair indices inside a sub-tile by addition, which equals the element-wise kernels'
+    //  "(index mod 2^32) >> 1" only while no index wraps)
+    return M > 0 && N > 64 && N % 2 == 0 && ldc == N && K % BK == 0 && (int64_t)M * ldc < ((int64_t)1 << 32);
 }
 // which Dense layers of the fine-tune step use it: bit 0 = FFN up-projection forward, 1 = attention out-projection forward,
 // 2 = FFN down-projection data gradient (tuning knob W2V2_GEMM_EPI).  Measured on the base fine-tune step (38.45 ms without): bit 2
