@@ -650,6 +650,9 @@ int launch_attention_fwd_bf16(const float* qkv, const uint16_t* qkv16, const int
     W2V2_REQUIRE(H / heads == DH && H % heads == 0, "attention_bf16: head size %d unsupported (64)", H / heads);
     W2V2_REQUIRE(ctx || ctx16, "attention_bf16: no output");
     W2V2_REQUIRE((int64_t)T * 3 * H < (1ll << 31), "attention_bf16: T x 3H too large for 32-bit row offsets");
+    // (the forward steps the hash's pair index inside a key tile by addition: equal to "(index mod 2^32) >> 1" while no index wraps)
+    W2V2_REQUIRE(!tr || tr->p <= 0.f || (int64_t)B * heads * T * (T + (T & 1)) < (1ll << 32),
+                 "attention_bf16: dropout over 2^32 or more attention probabilities is not supported");
     const uint16_t* q16 = nullptr;
     if (int e = shadow_or_scratch(qkv, qkv16, (int64_t)B * T * 3 * H, SCRATCH_QKV16, s, &q16)) return e;
     W2V2_REQUIRE(((reinterpret_cast<uintptr_t>(q16) | reinterpret_cast<uintptr_t>(ctx)) & 15) == 0 && (reinterpret_cast<uintptr_t>(ctx16) & 7) == 0,
