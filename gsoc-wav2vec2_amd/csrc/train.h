@@ -21,7 +21,7 @@ enum DropStream : uint32_t {
 //   w    = lowbias32(lo32(idx >> 1) * 0x9E3779B1 ^ k)   (Fibonacci pre-multiply spreads the sequential counter, then a
 //                                               bijective multiply-xorshift mixer; lagged mask correlations < 1e-3)
 //   keep = (idx odd ? w >> 16 : w & 0xFFFF) >= floor(p * 2^16)       -- the two 16-bit halves decide elements 2j and 2j + 1
-// The two quarter-rate 32-bit multiplies of the mixer are the expensive part on gfx950, so one hash word serves two
+// The mixer (two 32-bit multiplies at ~1.8 plain ops each, three xorshifts) is the expensive part, so one hash word serves two
 // elements; p is realised to 2^-16 (0.1 -> 0.1000061).  The index enters modulo 2^32 (a pattern repeats after 8.6e9
 // elements of one tensor).  Attention probabilities index their (B heads T, T) matrix with the row stride rounded up to
 // even (attention_drop_stride), so that a pair never straddles two query rows.  Same integer function as
@@ -42,7 +42,7 @@ __device__ __forceinline__ uint32_t dropout_threshold(float p) {      // 16-bit 
 // the hash word of element pair (2 pair, 2 pair + 1): low half decides the even element, high half the odd one
 __device__ __forceinline__ uint32_t dropout_word(uint32_t key, uint32_t pair) { return lowbias32(pair * 0x9E3779B1u ^ key); }
 // the same word from the pre-multiplied pair index (pair * 0x9E3779B1 mod 2^32): callers whose pair indices are `base + small
-// constant` pay the quarter-rate multiply once per base and an add per word (products distribute over the sum modulo 2^32)
+// constant` pay the multiply once per base and an add per word (products distribute over the sum modulo 2^32)
 constexpr uint32_t DROPOUT_FIB = 0x9E3779B1u;
 __device__ __forceinline__ uint32_t dropout_word_premul(uint32_t key, uint32_t pair_times_fib) { return lowbias32(pair_times_fib ^ key); }
 __device__ __forceinline__ bool dropout_keep_lo(uint32_t w, uint32_t thr) { return (w & 0xFFFFu) >= thr; }
