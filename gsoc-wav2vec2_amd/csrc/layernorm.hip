@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict
             sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
         }
         const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)C + eps);
-        float* yr = y + row * C;
+        float* yr = y ? y + row * C : nullptr;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = (i * 64 + lane) * 4;
@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict
                         if (c + e < C) hr[e] = (uint16_t)pack_bf16_rne(o[e], 0.f);
                 }
             }
+            if (!y) continue;       // bf16-only output: the consumer streams the shadow
             if (vec) {
                 *reinterpret_cast<float4*>(yr + c) = make_float4(o[0], o[1], o[2], o[3]);
             } else {
@@ -120,7 +121,7 @@ int launch_layer_norm(Profiler* prof, const float* x, float* y, const float* gam
 
 int launch_layer_norm_x(Profiler* prof, const float* x, float* y, const float* gamma, const float* beta, int64_t rows,
                         int C, float eps, int act, uint16_t* y16, hipStream_t s) {
-    W2V2_REQUIRE(x && y && gamma && beta, "layer_norm: null operand");
+    W2V2_REQUIRE(x && (y || y16) && gamma && beta, "layer_norm: null operand");
     W2V2_REQUIRE(rows > 0 && C > 0 && C <= 2048, "layer_norm: rows=%lld C=%d unsupported (C <= 2048)",
                  (long long)rows, C);
     // 4 blocks per CU (16 waves), each wave looping over rows
@@ -128,7 +129,7 @@ int launch_layer_norm_x(Profiler* prof, const float* x, float* y, const float* g
     static int cap = -1;
     if (cap < 0) { const char* e = getenv("W2V2_LN_BLOCKS"); cap = e ? atoi(e) : 256 * 4; }      // tuning knob: 512 / 1024 / 2048 / 4096 blocks -> 1.14 / 1.06 / 1.10 / 1.26 ms for the 25 LayerNorms of a base forward
     dim3 grid((unsigned)(want < cap ? want : cap)), block(256);
-    ProfScope ps(prof, FAM_LAYERNORM, 8.0 * rows * C, (y16 ? 10.0 : 8.0) * rows * C, s);
+    ProfScope ps(prof, FAM_LAYERNORM, 8.0 * rows * C, (4.0 + (y ? 4.0 : 0.0) + (y16 ? 2.0 : 0.0)) * rows * C, s);
     if (C <= 256)
         hipLaunchKernelGGL(layer_norm_kernel<1>, grid, block, 0, s, x, y, y16, gamma, beta, rows, C, eps, act);
     else if (C <= 512)

@@ -74,6 +74,7 @@ struct w2v2_model {
 // implemented in w2v2_api.hip
 bool w2v2_shadows_enabled();                                              // W2V2_BF16_SHADOWS != 0
 bool w2v2_conv_out_bf16_only(const w2v2_model* m, int i, bool sh);         // conv-stack output i is written only as bf16 this forward
+bool w2v2_conv_ln_bf16_only(const w2v2_model* m, int i, bool sh);          // LayerNorm-mode extractor: LN + GELU output i only as bf16
 bool w2v2_keep_activations();                                             // W2V2_KEEP_ACTIVATIONS == 1: also write the fp32 copies nothing reads
 int w2v2_ensure_shadows(w2v2_model* m, int B, int T, hipStream_t s);
 bool w2v2_pos_conv_bf16_ok(const w2v2_model* m);                          // precision 1 and a supported group shape

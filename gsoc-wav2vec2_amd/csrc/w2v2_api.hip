@@ -274,6 +274,16 @@ bool w2v2_conv_out_bf16_only(const w2v2_model* m, int i, bool sh) {
     return K % 64 == 0 && lda % 8 == 0 && strideA % 8 == 0;
 }
 
+// LayerNorm-mode extractor (robust / xlsr): conv i's LayerNorm + GELU output is written ONLY as bf16 when its one consumer, conv
+// i + 1's GEMM, streams the shadow (same alignment conditions as above; the GEMM's own fp32 output is the LayerNorm's input and stays)
+bool w2v2_conv_ln_bf16_only(const w2v2_model* m, int i, bool sh) {
+    const w2v2_config& c = m->cfg;
+    if (!sh || c.feature_extractor_norm_type != 1 || i + 1 >= c.num_conv_layers || w2v2_keep_activations()) return false;
+    const int64_t cin = c.filter_sizes[i], K = (int64_t)c.kernal_sizes[i + 1] * cin, lda = (int64_t)c.strides[i + 1] * cin;
+    const int64_t strideA = (int64_t)m->conv_T[i] * cin;
+    return K % 64 == 0 && lda % 8 == 0 && strideA % 8 == 0;
+}
+
 static int sh_alloc(std::vector<void*>& pool, uint16_t** out, int64_t n) {
     void* p = nullptr;
     W2V2_HIP_CHECK(hipMalloc(&p, (size_t)(n > 0 ? n : 1) * sizeof(uint16_t)));
@@ -619,14 +629,14 @@ int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const i
     // the fp32 copy is not written at all (w2v2_conv_out_bf16_only)
     m->acts_skipped.clear();
     for (int i = 0; i + 1 < NC; ++i)
-        if (w2v2_conv_out_bf16_only(m, i, sh)) m->acts_skipped.push_back("conv" + std::to_string(i));
+        if (w2v2_conv_out_bf16_only(m, i, sh) || w2v2_conv_ln_bf16_only(m, i, sh)) m->acts_skipped.push_back("conv" + std::to_string(i));
     if (int e = launch_conv0_x(pf, wave, fe(0, "/conv/kernel"), c.conv_bias ? fe(0, "/conv/bias") : nullptr,
                                fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"), w2v2_conv_out_bf16_only(m, 0, sh) ? nullptr : m->conv[0],
                                (sh && !layer_mode) ? m->conv16[0] : nullptr, m->conv0_ws, B, L, c.kernal_sizes[0], c.strides[0],
                                c.filter_sizes[0], 1e-5f, layer_mode ? 1 : 0, act_ew, s))
         return e;
     if (layer_mode)
-        if (int e = launch_layer_norm_x(pf, m->conv[0], m->conv[0], fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"),
+        if (int e = launch_layer_norm_x(pf, m->conv[0], w2v2_conv_ln_bf16_only(m, 0, sh) ? nullptr : m->conv[0], fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"),
                                         (int64_t)B * m->conv_T[0], c.filter_sizes[0], 1e-5f, act_ew, sh ? m->conv16[0] : nullptr, s))
             return e;
     for (int i = 1; i < NC; ++i) {
@@ -640,7 +650,7 @@ int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const i
                          layer_mode ? 0 : act))
             return e;
         if (layer_mode)
-            if (int e = launch_layer_norm_x(pf, m->conv[i], m->conv[i], fe(i, "/layer_norm/gamma"), fe(i, "/layer_norm/beta"),
+            if (int e = launch_layer_norm_x(pf, m->conv[i], w2v2_conv_ln_bf16_only(m, i, sh) ? nullptr : m->conv[i], fe(i, "/layer_norm/gamma"), fe(i, "/layer_norm/beta"),
                                             (int64_t)B * Tout, cout, 1e-5f, act_ew, o16, s))
                 return e;
     }

@@ -503,14 +503,14 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
     // ---- frozen feature extractor: identical to inference (no dropout inside, feature_extractor.py:54-59) ----
     m->acts_skipped.clear();                   // conv outputs written only as bf16: see w2v2_api.hip::w2v2_conv_out_bf16_only
     for (int i = 0; i + 1 < NC; ++i)
-        if (w2v2_conv_out_bf16_only(m, i, sh)) m->acts_skipped.push_back("conv" + std::to_string(i));
+        if (w2v2_conv_out_bf16_only(m, i, sh) || w2v2_conv_ln_bf16_only(m, i, sh)) m->acts_skipped.push_back("conv" + std::to_string(i));
     if (int e = launch_conv0_x(pf, wave, fe(0, "/conv/kernel"), c.conv_bias ? fe(0, "/conv/bias") : nullptr,
                                fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"), w2v2_conv_out_bf16_only(m, 0, sh) ? nullptr : m->conv[0],
                                (sh && !layer_mode) ? m->conv16[0] : nullptr, m->conv0_ws, B, L, c.kernal_sizes[0], c.strides[0],
                                c.filter_sizes[0], 1e-5f, layer_mode ? 1 : 0, act_ew, s))
         return e;
     if (layer_mode)
-        if (int e = launch_layer_norm_x(pf, m->conv[0], m->conv[0], fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"),
+        if (int e = launch_layer_norm_x(pf, m->conv[0], w2v2_conv_ln_bf16_only(m, 0, sh) ? nullptr : m->conv[0], fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"),
                                         (int64_t)B * m->conv_T[0], c.filter_sizes[0], 1e-5f, act_ew, sh ? m->conv16[0] : nullptr, s))
             return e;
     for (int i = 1; i < NC; ++i) {
@@ -523,7 +523,7 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
                          layer_mode ? 0 : act))
             return e;
         if (layer_mode)
-            if (int e = launch_layer_norm_x(pf, m->conv[i], m->conv[i], fe(i, "/layer_norm/gamma"), fe(i, "/layer_norm/beta"),
+            if (int e = launch_layer_norm_x(pf, m->conv[i], w2v2_conv_ln_bf16_only(m, i, sh) ? nullptr : m->conv[i], fe(i, "/layer_norm/gamma"), fe(i, "/layer_norm/beta"),
                                             (int64_t)B * Tout, cout, 1e-5f, act_ew, o16, s))
                 return e;
     }

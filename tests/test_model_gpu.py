@@ -157,12 +157,14 @@ def test_bf16_shadows_do_not_change_results(torch_mod, name):
     # stores nothing would read): same logits bit for bit, and the taps of those stages say so instead of returning stale data
     out = m(g["wave"], attention_mask=mask).numpy()
     assert np.array_equal(out, res["1"]["logits"])
-    if cfg.feature_extractor_norm_type == "group":
+    # (group-norm extractor: the conv GEMM's own output; LayerNorm extractor: the LayerNorm + GELU behind it; in either case only
+    #  when conv2's GEMM can stream the shadow: K = 3 x C_in a multiple of 64 -- not the 32-channel toy extractor)
+    if (cfg.kernal_sizes[2] * cfg.filter_sizes[1]) % 64 == 0:
         with pytest.raises(RuntimeError, match="only as bf16"):
             m.activation("conv1")
-        assert np.array_equal(m.activation(f"conv{len(cfg.kernal_sizes) - 1}"), res["1"][f"conv{len(cfg.kernal_sizes) - 1}"])
     else:
         assert np.array_equal(m.activation("conv1"), res["1"]["conv1"])
+    assert np.array_equal(m.activation(f"conv{len(cfg.kernal_sizes) - 1}"), res["1"][f"conv{len(cfg.kernal_sizes) - 1}"])
 
 
 @pytest.mark.parametrize("name", ["tiny_base", "base_sample_unpadded", "base_sample_padded", "robust_masked"])
