@@ -37,6 +37,7 @@ struct Conv0Args {
     uint16_t* out16;       // optional bf16 shadow of out (precision mode 1: layer 1's GEMM reads it)
     double* partial;       // (B, nchunks, 2, C)
     float* scale_shift;    // (B, 2, C)
+    const double* ln_const;   // MODE 3 (LayerNorm over channels): LN_CONST doubles, see conv0_ln_const_kernel
     int64_t L;
     int T0, K, stride, C, nchunks, norm_mode, act;
     float eps;
@@ -139,6 +140,48 @@ __global__ __launch_bounds__(256) void conv0_kernel(Conv0Args a) {
 using f32x4_c0 = __attribute__((ext_vector_type(4))) float;
 using u32x2_c0 = __attribute__((ext_vector_type(2))) unsigned;
 
+// MODE 3: LayerNorm over the C channels of each frame + activation (the robust / xlsr extractor, feature_extractor.py:40-47 with
+// layer norm).  A frame's channels are y_c = w_c . x + b_c over the SAME 10 samples x, so its moments over c need no pass over y:
+//   mean_c y = wbar . x + bbar,     var_c y = x^T Cw x + 2 cwb . x + varb
+// with wbar = mean_c w_c, Cw = mean_c (w_c - wbar)(w_c - wbar)^T (10 x 10), cwb = mean_c (w_c - wbar)(b_c - bbar), varb = var_c b:
+// 122 numbers of the layer's kernel (conv0_ln_const_kernel, fp64).  One thread per frame evaluates them in fp64 (65 FMAs, against
+// 5120 for the frame's taps) before the apply loop, and the un-normalised conv output -- 3.1 GB at 16 x 480000 -- is never
+// written or re-read.  Centred weights: the quadratic form has no cancellation to lose.
+constexpr int LN_CONST = 10 + 1 + 100 + 10 + 1;     // wbar | bbar | Cw | cwb | varb   (K = 10)
+
+__global__ __launch_bounds__(128) void conv0_ln_const_kernel(const float* __restrict__ kernel /* (10, C) */, const float* __restrict__ bias,
+                                                             double* __restrict__ out, int C) {
+    __shared__ double wbar[10], bbar;
+    const int t = threadIdx.x;
+    if (t < 10) {
+        double sum = 0.0;
+        for (int c = 0; c < C; ++c) sum += (double)kernel[t * C + c];
+        wbar[t] = sum / C;
+    } else if (t == 10) {
+        double sum = 0.0;
+        for (int c = 0; c < C; ++c) sum += bias ? (double)bias[c] : 0.0;
+        bbar = sum / C;
+    }
+    __syncthreads();
+    if (t < 10) out[t] = wbar[t];
+    if (t == 10) out[10] = bbar;
+    if (t < 100) {
+        const int i = t / 10, j = t % 10;
+        double sum = 0.0;
+        for (int c = 0; c < C; ++c) sum += ((double)kernel[i * C + c] - wbar[i]) * ((double)kernel[j * C + c] - wbar[j]);
+        out[11 + t] = sum / C;
+    } else if (t < 110) {
+        const int i = t - 100;
+        double sum = 0.0;
+        for (int c = 0; c < C; ++c) sum += ((double)kernel[i * C + c] - wbar[i]) * ((bias ? (double)bias[c] : 0.0) - bbar);
+        out[111 + i] = sum / C;
+    } else if (t == 110) {
+        double sum = 0.0;
+        for (int c = 0; c < C; ++c) { const double d = (bias ? (double)bias[c] : 0.0) - bbar; sum += d * d; }
+        out[121] = sum / C;
+    }
+}
+
 template <int MODE, int KT, int ST>
 __global__ __launch_bounds__(256) void conv0_apply4_kernel(Conv0Args a, int tpr /* lanes per frame = C / 4 */) {
     constexpr int TCB = TC;      // frames per block: 32 / 128 / 256 / 512 measured 0.644 / 0.638 / 0.655 / 0.711 ms against 0.627-0.635 for 64
@@ -158,13 +201,39 @@ __global__ __launch_bounds__(256) void conv0_apply4_kernel(Conv0Args a, int tpr 
         sc = *reinterpret_cast<const f32x4_c0*>(a.scale_shift + ((int64_t)b * 2 + 0) * a.C + c);
         sh = *reinterpret_cast<const f32x4_c0*>(a.scale_shift + ((int64_t)b * 2 + 1) * a.C + c);
     }
+    if (MODE == 3) {      // gamma / beta of this lane's channels
+        sc = *reinterpret_cast<const f32x4_c0*>(a.gamma + c);
+        sh = *reinterpret_cast<const f32x4_c0*>(a.beta + c);
+    }
     __syncthreads();
+    __shared__ float fr_mean[TC], fr_rstd[TC];
+    if (MODE == 3) {
+        static_assert(KT == 10 || MODE != 3, "the LayerNorm constants are laid out for 10 taps");
+        if ((int)threadIdx.x < nt) {
+            const float* xp = xs + threadIdx.x * ST;
+            const double* __restrict__ k = a.ln_const;
+            double x[KT > 0 ? KT : 1], mean = k[10], var = k[121];
+#pragma unroll
+            for (int i = 0; i < KT; ++i) x[i] = (double)xp[i];
+#pragma unroll
+            for (int i = 0; i < KT; ++i) {
+                mean = fma(k[i], x[i], mean);
+                double r = 2.0 * k[111 + i];
+#pragma unroll
+                for (int j = 0; j < KT; ++j) r = fma(k[11 + i * 10 + j], x[j], r);
+                var = fma(r, x[i], var);
+            }
+            fr_mean[threadIdx.x] = (float)mean;
+            fr_rstd[threadIdx.x] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)a.eps));
+        }
+        __syncthreads();
+    }
     float* __restrict__ orow = a.out ? a.out + ((int64_t)b * a.T0 + t0) * a.C + c : nullptr;
     uint16_t* __restrict__ orow16 = a.out16 ? a.out16 + ((int64_t)b * a.T0 + t0) * a.C + c : nullptr;
     for (int t = fp; t < nt; t += fpb) {
         const float* xp = xs + t * ST;
         f32x4_c0 y = bs;
-        if (MODE == 1 && a.act == 3) {
+        if (MODE == 1 && a.act == 3) {   // (MODE 3 takes the scalar path: its normalisation is per frame, not per channel)
             // bf16 mode: this stage writes half the bytes and becomes VALU-bound, so the taps, the normalisation and the GELU
             // (gelu_erf_fast, common.h) run two channels per instruction (v_pk_fma_f32 / v_pk_mul_f32)
             using f2 = __attribute__((ext_vector_type(2))) float;
@@ -189,6 +258,11 @@ __global__ __launch_bounds__(256) void conv0_apply4_kernel(Conv0Args a, int tpr 
             if (MODE == 1) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) y[j] = apply_act(fmaf(y[j], sc[j], sh[j]), a.act);
+            }
+            if (MODE == 3) {      // (same association as layer_norm_kernel: ((y - mean) rstd) gamma + beta)
+                const float mean = fr_mean[t], rstd = fr_rstd[t];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = apply_act((y[j] - mean) * rstd * sc[j] + sh[j], a.act);
             }
         }
         // nontemporal: 0.635 ms against 0.657 with plain stores (3.2 GB streamed once; tools/write_bw.hip: a bare 128-KiB-per-block
@@ -340,7 +414,7 @@ static inline int conv0_nchunks(int64_t L, int K, int stride) {
 int64_t conv0_ws_floats(int B, int64_t L, int K, int stride, int C) {
     if (L < K || stride <= 0) return 0;
     const int64_t nch = conv0_nchunks(L, K, stride);
-    return 2 * ((int64_t)B * nch * 2 * C) /* fp64 partials */ + (int64_t)B * 2 * C + 8;
+    return 2 * ((int64_t)B * nch * 2 * C) /* fp64 partials */ + (int64_t)B * 2 * C + 8 + 2 * LN_CONST /* LayerNorm-mode constants */;
 }
 
 int launch_conv0(Profiler* prof, const float* wave, const float* kernel, const float* bias,
@@ -355,7 +429,7 @@ int launch_conv0_x(Profiler* prof, const float* wave, const float* kernel, const
     W2V2_REQUIRE(wave && kernel && (out || out16), "conv0: null operand");
     W2V2_REQUIRE(B > 0 && C > 0 && K > 0 && K <= 32 && stride > 0 && L >= K,
                  "conv0: unsupported B=%d C=%d K=%d stride=%d L=%lld", B, C, K, stride, (long long)L);
-    W2V2_REQUIRE(norm_mode == 0 || norm_mode == 1, "conv0: bad norm_mode %d", norm_mode);
+    W2V2_REQUIRE(norm_mode >= 0 && norm_mode <= 2, "conv0: bad norm_mode %d", norm_mode);
     Conv0Args a;
     a.wave = wave; a.kernel = kernel; a.bias = bias; a.gamma = gamma; a.beta = beta; a.out = out; a.out16 = out16;
     a.L = L; a.K = K; a.stride = stride; a.C = C; a.eps = eps; a.norm_mode = norm_mode; a.act = act;
@@ -366,6 +440,32 @@ int launch_conv0_x(Profiler* prof, const float* wave, const float* kernel, const
     if (norm_mode == 1) {
         ProfScope ps(prof, FAM_CONV0_APPLY, flops, in_bytes + out_bytes, s);
         launch_mode<2>(a, B, s);
+        W2V2_HIP_CHECK(hipGetLastError());
+        return W2V2_OK;
+    }
+    if (norm_mode == 2) {       // conv -> LayerNorm over channels -> activation, one pass (conv0_apply4_kernel MODE 3)
+        W2V2_REQUIRE(ws && gamma && beta, "conv0: layer-norm mode needs workspace, gamma and beta");
+        const int tpr = C / 4;
+        const bool vec_ok = K == 10 && stride == 5 && C % 4 == 0 && tpr >= 1 && tpr <= 256 && 256 % tpr == 0 &&
+                            ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(kernel) | reinterpret_cast<uintptr_t>(bias) |
+                              reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0 &&
+                            (reinterpret_cast<uintptr_t>(out16) & 7) == 0;
+        if (!vec_ok) {          // other geometries: the plain conv, then the LayerNorm kernel in place
+            W2V2_REQUIRE(out, "conv0: this geometry needs the fp32 output buffer for its LayerNorm pass");
+            a.out16 = nullptr;
+            {
+                ProfScope ps(prof, FAM_CONV0_APPLY, flops, in_bytes + 4.0 * B * (double)a.T0 * C, s);
+                launch_mode<2>(a, B, s);
+            }
+            W2V2_HIP_CHECK(hipGetLastError());
+            return launch_layer_norm_x(prof, out, out, gamma, beta, (int64_t)B * a.T0, C, eps, act, out16, s);
+        }
+        double* kc = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(ws) + 7) & ~(uintptr_t)7);
+        a.ln_const = kc;
+        ProfScope ps(prof, FAM_CONV0_APPLY, flops, in_bytes + out_bytes, s);
+        hipLaunchKernelGGL(conv0_ln_const_kernel, dim3(1), dim3(128), 0, s, kernel, bias, kc, C);
+        const size_t lds = ((size_t)(TC - 1) * stride + K + 4) * sizeof(float);
+        hipLaunchKernelGGL((conv0_apply4_kernel<3, 10, 5>), dim3(a.nchunks, B), dim3(256), lds, s, a, tpr);
         W2V2_HIP_CHECK(hipGetLastError());
         return W2V2_OK;
     }

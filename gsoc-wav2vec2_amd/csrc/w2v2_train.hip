@@ -505,14 +505,11 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
     for (int i = 0; i + 1 < NC; ++i)
         if (w2v2_conv_out_bf16_only(m, i, sh) || w2v2_conv_ln_bf16_only(m, i, sh)) m->acts_skipped.push_back("conv" + std::to_string(i));
     if (int e = launch_conv0_x(pf, wave, fe(0, "/conv/kernel"), c.conv_bias ? fe(0, "/conv/bias") : nullptr,
-                               fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"), w2v2_conv_out_bf16_only(m, 0, sh) ? nullptr : m->conv[0],
-                               (sh && !layer_mode) ? m->conv16[0] : nullptr, m->conv0_ws, B, L, c.kernal_sizes[0], c.strides[0],
-                               c.filter_sizes[0], 1e-5f, layer_mode ? 1 : 0, act_ew, s))
+                               fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"),
+                               (w2v2_conv_out_bf16_only(m, 0, sh) || w2v2_conv_ln_bf16_only(m, 0, sh)) ? nullptr : m->conv[0],
+                               sh ? m->conv16[0] : nullptr, m->conv0_ws, B, L, c.kernal_sizes[0], c.strides[0],
+                               c.filter_sizes[0], 1e-5f, layer_mode ? 2 : 0, act_ew, s))      // (layer mode: conv + LayerNorm + GELU in one pass)
         return e;
-    if (layer_mode)
-        if (int e = launch_layer_norm_x(pf, m->conv[0], w2v2_conv_ln_bf16_only(m, 0, sh) ? nullptr : m->conv[0], fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"),
-                                        (int64_t)B * m->conv_T[0], c.filter_sizes[0], 1e-5f, act_ew, sh ? m->conv16[0] : nullptr, s))
-            return e;
     for (int i = 1; i < NC; ++i) {
         const int cin = c.filter_sizes[i - 1], cout = c.filter_sizes[i];
         const int Tin = m->conv_T[i - 1], Tout = m->conv_T[i];

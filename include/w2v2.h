@@ -297,8 +297,11 @@ int w2v2_op_layer_norm(const float* x_dev, float* y_dev, const float* gamma_dev,
  * (feature_extractor.py:31-47,54-59; tensorflow_addons.py:207-231).
  *   wave (B, L); kernel (K, 1, C); bias (C) or NULL; out (B, T0, C);
  *   stats_ws: caller scratch of w2v2_conv0_ws_floats(B, L, K, stride, C) floats.
- * norm_mode: 0 = group-norm+GELU, 1 = conv(+bias) only ("layer" configs
- * follow it with w2v2_op_layer_norm). */
+ * norm_mode: 0 = group-norm + activation, 1 = conv(+bias) only, 2 = conv -> LayerNormalization over the C channels of each frame
+ * -> activation in one pass (the "layer" configs, feature_extractor.py:40-50): a frame's channel mean and variance follow from
+ * its 10 input samples and a 10 x 10 moment matrix of the kernel, so the un-normalised conv output is never written.  Mode 2
+ * needs gamma, beta and stats_ws; geometries other than K = 10, stride 5, C % 4 == 0 run mode 1 + w2v2_op_layer_norm inside.
+ * act as in w2v2_op_layer_norm (modes 0 and 2). */
 int64_t w2v2_conv0_ws_floats(int32_t B, int64_t L, int32_t K, int32_t stride, int32_t C);
 int w2v2_op_conv0(const float* wave_dev, const float* kernel_dev, const float* bias_dev,
                   const float* gamma_dev, const float* beta_dev, float* out_dev,

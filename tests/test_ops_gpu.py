@@ -336,6 +336,33 @@ def test_conv0_groupnorm_gelu(env, B, L, Cn, K, S, bias):
     assert H.max_err(got, ref) < tol
 
 
+@pytest.mark.parametrize("B,L,Cn,S,bias", [(2, 3000, 512, 5, True), (1, 4005, 64, 5, False), (3, 400, 32, 5, True), (2, 1000, 48, 3, True)])
+def test_conv0_layernorm_gelu(env, B, L, Cn, S, bias):
+    """conv0 -> LayerNormalization over channels -> GELU in one pass (the robust / xlsr extractor, feature_extractor.py:40-50):
+    frame moments from the 10 input samples and the kernel's 10 x 10 moment matrix.  stride 3 takes the two-kernel fallback.
+    A loud frame next to silence (padding) checks that the variance form has nothing to cancel."""
+    lib, torch, dev = env
+    K = 10
+    x = V.hash_normal("l0x", B * L, 5).reshape(B, L)
+    x[:, L // 2:L // 2 + 200] *= 50.0
+    x[:, (3 * L) // 4:] = 0.0
+    w = rnd("l0w", (K, 1, Cn), 0.6)
+    bs = rnd("l0b", (Cn,)) if bias else None
+    g, b = 1 + rnd("l0g", (Cn,), 0.1), rnd("l0be", (Cn,), 0.1)
+    y = O.conv1d_valid(x.astype(np.float64)[:, :, None], w.astype(np.float64), S, None if bs is None else bs.astype(np.float64))
+    ref = O.gelu(O.layer_norm(y, g.astype(np.float64), b.astype(np.float64), 1e-5))
+    T0 = 1 + (L - K) // S
+    out = torch.full((B, T0, Cn), float("nan"), device=dev)
+    ws = torch.empty((int(lib.w2v2_conv0_ws_floats(B, L, K, S, Cn)),), device=dev)
+    N.check(lib.w2v2_op_conv0(N.ptr(dev_t(torch, dev, x)), N.ptr(dev_t(torch, dev, w)),
+                              N.ptr(dev_t(torch, dev, bs)) if bias else None, N.ptr(dev_t(torch, dev, g)),
+                              N.ptr(dev_t(torch, dev, b)), N.ptr(out), N.ptr(ws), B, L, K, S, Cn, 1e-5, 2, 1, stream()))
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    # frames of pure padding without a bias have zero variance: rsqrt(eps) = 316 multiplies the fp32 rounding of the taps
+    assert H.max_err(got, ref) < 2e-5 * max(1.0, np.abs(ref).max())
+
+
 def test_conv0_plain_mode(env):
     lib, torch, dev = env
     B, L, Cn = 2, 3000, 64
