@@ -10,6 +10,8 @@ python bench.py --precision bf16 --no-cpu-baseline > $O/bench_bf16_n1.json 2>/de
 python bench.py --mode train --precision bf16 --no-cpu-baseline > $O/bench_bf16_train_n1.json 2>/dev/null
 python bench.py --mode train --no-cpu-baseline > $O/bench_train_n1.json 2>/dev/null
 python bench.py --mode train --precision bf16 --model large-robust --batch 16 --samples 480000 --no-cpu-baseline --steps 8 --warmup 3 > $O/bench_large_robust_bf16_train_n1.json 2>/dev/null
+python bench.py --precision bf16 --model large-robust --batch 16 --samples 480000 --no-cpu-baseline --steps 8 --warmup 3 > $O/bench_large_robust_bf16_n1.json 2>/dev/null
+python bench.py --model large-robust --batch 16 --samples 246000 --no-cpu-baseline --steps 5 --warmup 2 > $O/bench_large_robust_fwd_n1.json 2>/dev/null
 for f in $O/bench_*.json; do echo "$(basename $f): $(grep -o '"ms_per_step": [0-9.]*' $f | head -1)"; done
 bash tools/prof_one.sh train_bf16 --mode train --precision bf16 --steps 5 --warmup 2
 bash tools/prof_one.sh train_lr_bf16 --mode train --precision bf16 --model large-robust --batch 16 --samples 480000 --steps 3 --warmup 1
