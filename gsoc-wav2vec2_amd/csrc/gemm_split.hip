@@ -87,7 +87,7 @@ struct SplitCfg {
     static constexpr int NPB = 3 * BN / PROWS / (NT / 64);           // DMA pieces per wave
     static constexpr int SUB = BK / 16;                              // k16 sub-steps per stage
     // 16-byte slot XOR: consecutive rows walk the 256-byte bank span once, then the slot index changes
-    static __device__ __forceinline__ int sw(int row) { return BK == 32 ? (row >> 2) & 3 : (row >> 3) & 1; }
+    static constexpr __device__ __host__ __forceinline__ int sw(int row) { return BK == 32 ? (row >> 2) & 3 : (row >> 3) & 1; }
 };
 
 template <int BK, int MINW>   // MINW: waves per SIMD the register budget must allow (HIP's second launch-bound)
@@ -96,7 +96,10 @@ __global__ __launch_bounds__(NT, MINW) void gemm_split_kernel(SplitArgs g) {
     constexpr int ROWB = Cf::ROWB, A_PLANE = Cf::A_PLANE, B_PLANE = Cf::B_PLANE, STAGE = Cf::STAGE, NA = Cf::NA, LPR = Cf::LPR,
                   PROWS = Cf::PROWS, NPB = Cf::NPB, SUB = Cf::SUB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_split[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // (readfirstlane: tells the compiler the wave index is uniform, so the B pieces' sources become scalar bases + one lane offset
+    //  instead of three 64-bit pointers per lane -- at 128 VGPRs this kernel was spilling 7 registers inside its K loop)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN, li = lane & 31, lh = lane >> 5;
 
     // XCD-aware tile order (gemm_f32.hip): each XCD walks a contiguous run of tiles, N fastest
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(NT, MINW) void gemm_split_kernel(SplitArgs g) {
         const int piece = wave * NPB + i, plane = piece / PPP, rb = (piece % PPP) * PROWS;
         // the planes are stored as LDS images (launch_split_weight): [k tile][plane][n][BK] with the slot XOR applied,
         // so a piece is 1 KiB of consecutive memory and the per-step advance is 3 N BK elements
-        b_src[i] = g.Bp + ((int64_t)plane * g.N + n0 + rb) * BK + lane * 8;
+        b_src[i] = g.Bp + ((int64_t)plane * g.N + n0 + rb) * BK;      // wave-uniform; the lane's 16 bytes are added at the issue
         b_lds[i] = 3 * A_PLANE + plane * B_PLANE + rb * ROWB;
     }
     const int64_t b_step = (int64_t)3 * g.N * BK;
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(NT, MINW) void gemm_split_kernel(SplitArgs g) {
         for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a_src[i] + kt * BK);
     };
     auto issue_piece = [&](int i, int kt, int buf) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + (int64_t)kt * b_step),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + (int64_t)kt * b_step + lane * 8),
                                          (__attribute__((address_space(3))) void*)(smem_split + buf * STAGE + b_lds[i]), 16, 0, 0);
     };
     auto store_a = [&](int buf) {
@@ -165,17 +168,17 @@ __global__ __launch_bounds__(NT, MINW) void gemm_split_kernel(SplitArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
 
-    int fa[MT], fb[NTL];       // fragment byte offsets inside a plane for k16 sub-step 0 (sub-step 1: slot ^ 2)
+    // fragment byte offsets inside a plane for k16 sub-step 0 (sub-step 1: slot ^ 2).  The swizzle has period 16 in the row, so
+    // the second 32-row fragment of a wave sits exactly 32 rows further: ONE per-lane offset per operand, the rest are immediates
+    // (two registers fewer in a kernel that sits on its 128-VGPR limit)
+    static_assert(Cf::sw(0) == Cf::sw(32) && Cf::sw(5) == Cf::sw(37) && Cf::sw(12) == Cf::sw(44), "swizzle period must divide 32");
+    const int fa0 = (wm * 64 + li) * ROWB + ((lh ^ Cf::sw(wm * 64 + li)) << 4);
+    const int fb0 = 3 * A_PLANE + (wn * 64 + li) * ROWB + ((lh ^ Cf::sw(wn * 64 + li)) << 4);
+    int fa[MT], fb[NTL];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int row = wm * 64 + mt * 32 + li;
-        fa[mt] = row * ROWB + ((lh ^ Cf::sw(row)) << 4);
-    }
+    for (int mt = 0; mt < MT; ++mt) fa[mt] = fa0 + mt * 32 * ROWB;
 #pragma unroll
-    for (int nt = 0; nt < NTL; ++nt) {
-        const int col = wn * 64 + nt * 32 + li;
-        fb[nt] = 3 * A_PLANE + col * ROWB + ((lh ^ Cf::sw(col)) << 4);
-    }
+    for (int nt = 0; nt < NTL; ++nt) fb[nt] = fb0 + nt * 32 * ROWB;
     // One tile step = 6 SUB groups of four MFMAs on stage `buf`.  The staging of the next step is threaded BETWEEN the
     // groups instead of bunched at the stage boundary (where all eight waves would stall on the same unit together and
     // leave the matrix pipe idle): group 0 is followed by the split + LDS store of the A slab already in registers,
