@@ -105,7 +105,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
     static_assert(NA >= 1 && NB >= 1 && MT >= 1 && NTL >= 1, "bad tile / wave grid");
     using bvec = typename FVec<PN>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (uniform: LDS-DMA destinations and piece indices become scalar)
     const int wm = wave / WN, wn = wave % WN, li = lane & 31, lh = lane >> 5;
 
     // XCD-aware tile order (see gemm_f32.hip): each XCD walks a contiguous run of tiles, N fastest
@@ -392,33 +393,42 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
         // (lane & 7) fetches logical slot (lane & 7) ^ swz(row).  Pieces are dealt round-robin to the waves.
         constexpr int NWV = WM * WN, PA = BM / 8, PB = BN / 8, PPA = PA / NWV, PPB = PB / NWV;
         static_assert(PA % NWV == 0 && PB % NWV == 0, "pieces must divide over the waves");
-        const uint16_t* da[PPA];
-        const uint16_t* db[PPB];
-        const uint16_t* A16p = g.A16 + (int64_t)z * g.strideA;
+        // sources as a wave-uniform tile base (scalar registers, advanced by the scalar unit) plus a 32-bit per-lane offset inside
+        // the tile: the DMA takes the `v_off, s[base]` form, and the K loop carries no 64-bit vector pointers or adds
+        uint32_t da[PPA], db[PPB];       // BYTE offsets from the tile bases (rows clamped to the matrix: < 128 ld x 2 < 2^31)
+        const uint16_t* const baseA = g.A16 + (int64_t)z * g.strideA + (int64_t)m0 * g.lda;
+        const uint16_t* const baseB = g.B16 + (int64_t)(g.zmod ? z % g.zmod : 0) * g.strideB16 + (int64_t)n0 * g.ldb16;
 #pragma unroll
         for (int i = 0; i < PPA; ++i) {
             const int r = (wave * PPA + i) * 8 + (lane >> 3);
-            int row = m0 + r;
-            row = row < g.M ? row : g.M - 1;
-            da[i] = A16p + (int64_t)row * g.lda + (((lane & 7) ^ swz(r)) << 3);
+            const int rc = m0 + r < g.M ? r : g.M - 1 - m0;
+            da[i] = 2u * ((uint32_t)((int64_t)rc * g.lda) + (uint32_t)(((lane & 7) ^ swz(r)) << 3));
         }
 #pragma unroll
         for (int i = 0; i < PPB; ++i) {
             const int r = (wave * PPB + i) * 8 + (lane >> 3);
-            int col = n0 + r;
-            col = col < g.N ? col : g.N - 1;
-            db[i] = g.B16 + (int64_t)(g.zmod ? z % g.zmod : 0) * g.strideB16 + (int64_t)col * g.ldb16 + (((lane & 7) ^ swz(r)) << 3);
+            const int rc = n0 + r < g.N ? r : g.N - 1 - n0;
+            db[i] = 2u * ((uint32_t)((int64_t)rc * g.ldb16) + (uint32_t)(((lane & 7) ^ swz(r)) << 3));
         }
+        // (the uniform half goes through readfirstlane: otherwise loop strength reduction turns base + k0 + offset back into a
+        //  per-lane 64-bit induction pointer and the loop's DMA falls out of the scalar-base form again)
+        auto uniform_ptr = [](const uint16_t* p) {
+            const uint64_t v = reinterpret_cast<uint64_t>(p);
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+            return reinterpret_cast<const unsigned char*>(((uint64_t)hi << 32) | lo);
+        };
         auto issue = [&](int kt, int buf) {
             unsigned char* S = smem16 + buf * STAGE;
             const int k0 = kt * BK;
+            const unsigned char* const ua = uniform_ptr(baseA + k0);
+            const unsigned char* const ub = uniform_ptr(baseB + k0);
 #pragma unroll
             for (int i = 0; i < PPA; ++i)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(da[i] + k0),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ua + da[i]),
                                                  (__attribute__((address_space(3))) void*)(S + (wave * PPA + i) * 1024), 16, 0, 0);
 #pragma unroll
             for (int i = 0; i < PPB; ++i)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db[i] + k0),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + db[i]),
                                                  (__attribute__((address_space(3))) void*)(S + BM * ROWB + (wave * PPB + i) * 1024), 16, 0, 0);
         };
         if constexpr (NS == 2) {
