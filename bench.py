@@ -48,6 +48,9 @@ from threadpoolctl import threadpool_limits
 from oracle import w2v2_oracle as O
 from wav2vec2 import variables as V
 from wav2vec2.config import Wav2Vec2Config
+pin = {pin!r}
+if pin:
+    os.sched_setaffinity(0, pin)                   # one disjoint set of physical cores (one NUMA node) per worker
 cfg = Wav2Vec2Config(); w = dict(np.load({weights!r}))
 x = V.hash_normal("bench/cpu", {L}, {seed}).reshape(1, {L})
 with threadpool_limits(limits={nt}):
@@ -57,8 +60,46 @@ with threadpool_limits(limits={nt}):
     t0 = time.time()
     for _ in range({reps}):
         O.ctc_forward(cfg, w, x)
-    print("CPU_WORKER_SPAN", t0, time.time(), flush=True)
+    print("CPU_WORKER_SPAN", t0, time.time(), len(os.sched_getaffinity(0)), flush=True)
 """
+
+
+def _core_sets(workers, width):
+    """`workers` disjoint lists of `width` logical CPUs, one hardware thread per PHYSICAL core, each list inside one NUMA
+    node (nodes filled round-robin so the workers spread over all memory channels), drawn from this process's allowed
+    CPUs.  Returns fewer lists than asked when the host has fewer whole sets; [] when the topology cannot be read."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return []
+
+    def read(path):
+        try:
+            with open(path) as f:
+                return f.read().strip()
+        except OSError:
+            return None
+
+    by_node, seen = {}, set()
+    for cpu in allowed:
+        base = f"/sys/devices/system/cpu/cpu{cpu}"
+        core, pkg = read(f"{base}/topology/core_id"), read(f"{base}/topology/physical_package_id")
+        if core is None:
+            return []
+        if (pkg, core) in seen:                        # an SMT sibling of a core already taken
+            continue
+        seen.add((pkg, core))
+        node = next((d[4:] for d in (os.listdir(base) if os.path.isdir(base) else []) if d.startswith("node") and d[4:].isdigit()), pkg)
+        by_node.setdefault(node, []).append(cpu)
+    pools = [by_node[k] for k in sorted(by_node, key=str)]
+    sets, progressed = [], True
+    while len(sets) < workers and progressed:
+        progressed = False
+        for pool in pools:
+            if len(sets) < workers and len(pool) >= width:
+                sets.append([pool.pop(0) for _ in range(width)])
+                progressed = True
+    return sets
 
 
 def _cpu_model():
@@ -141,7 +182,10 @@ def cpu_baseline(cfg, weights, L, wave_row0=None):
     legs["B=8"] = {"best_s": round(b8, 4), "median_s": round(m8, 4), "runs": runs8, "threads": nt8,
                    "audio_s_per_s_best": round(8 * L / SAMPLE_RATE / b8, 2), "audio_s_per_s_median": round(8 * L / SAMPLE_RATE / m8, 2)}
     # -- leg 3: fill the host: W concurrent single-utterance workers of the probed width, timed forwards started together
-    procs = int(os.environ.get("W2V2_CPU_WORKERS", 0)) or max(1, min(8, phys // best_nt))
+    procs = int(os.environ.get("W2V2_CPU_WORKERS", 0)) or max(1, min(16, phys // best_nt))
+    pins = _core_sets(procs, best_nt)                 # pinned: unpinned workers migrate and share memory channels
+    if pins:
+        procs = len(pins)
     reps = 3
     if procs > 1:
         children, tmp = [], None
@@ -150,7 +194,8 @@ def cpu_baseline(cfg, weights, L, wave_row0=None):
             tmp.close()
             np.savez(tmp.name, **weights)
             for i in range(procs):
-                code = _CPU_WORKER.format(root=ROOT, L=L, seed=i, nt=best_nt, reps=reps, weights=tmp.name)
+                code = _CPU_WORKER.format(root=ROOT, L=L, seed=i, nt=best_nt, reps=reps, weights=tmp.name,
+                                          pin=pins[i] if pins else None)
                 children.append(subprocess.Popen([sys.executable, "-c", code], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
                                                  stderr=subprocess.PIPE, text=True))
             deadline = time.perf_counter() + 150.0
@@ -171,10 +216,12 @@ def cpu_baseline(cfg, weights, L, wave_row0=None):
                 hit = [ln for ln in out.splitlines() if ln.startswith("CPU_WORKER_SPAN")]
                 if not hit:
                     raise RuntimeError(f"worker gave no timing: {err[-400:]}")
-                spans.append(tuple(float(v) for v in hit[0].split()[1:3]))
-            wall = max(e for _, e in spans) - min(b for b, _ in spans)
+                spans.append(tuple(float(v) for v in hit[0].split()[1:4]))
+            wall = max(s[1] for s in spans) - min(s[0] for s in spans)
             legs["aggregate"] = {"workers": procs, "threads_each": best_nt, "forwards_each": reps, "wall_s": round(wall, 3),
-                                 "audio_s_per_s": round(procs * reps * L / SAMPLE_RATE / wall, 2)}
+                                 "audio_s_per_s": round(procs * reps * L / SAMPLE_RATE / wall, 2),
+                                 "pinned": bool(pins), "cpus_per_worker_seen": sorted({int(s[2]) for s in spans}),
+                                 "pin_sets": [f"{p[0]}-{p[-1]}" for p in pins] if pins else None}
         except Exception as exc:                                       # noqa: BLE001 -- reported, not hidden
             legs["aggregate"] = {"workers": procs, "threads_each": best_nt, "error": repr(exc)[:300]}
         finally:
@@ -235,6 +282,22 @@ def measured_traffic():
     return None
 
 
+def self_launch(n):
+    """Re-run this command line under `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` (the form the
+    driver itself uses for N > 1); returns the launcher's exit code.  Ranks inherit stdout, so rank 0's JSON line is this
+    process's output."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -256,6 +319,11 @@ def main():
                          "(BASELINE configs[2] shape, fp32: forward + CTC + backward + gradient all-reduce + Adam)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU under
+        # torch.distributed.run, rendezvous on 127.0.0.1 at a free port) and pass rank 0's JSON line through.
+        raise SystemExit(self_launch(args.gpus))
+
     import torch
     import torch.distributed as dist
 
@@ -265,11 +333,12 @@ def main():
 
     world, rank, local_rank = D.env_world()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus must agree")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     D.init(backend="nccl", device=dev)        # RCCL; no-op for a single process
+    comm = D.describe()                       # what the process group itself reports (echoed in the JSON line)
 
     cfg = wav2vec2.Wav2Vec2Config() if args.model == "base" else wav2vec2.RobustWav2Vec2Config()
     weights = V.seeded_weights(cfg, seed=0)
@@ -399,6 +468,7 @@ def main():
             "dtype": {"fp32": "f32", "bf16": "bf16 operands, f32 accumulate (Dense / Conv1D); f32 elsewhere",
                       "bf16x3": "f32 operands as exact 3 x bf16 sums, 6 bf16 MFMA products per f32 product, f32 accumulate (Dense / Conv1D); f32 elsewhere"}[args.precision],
             "data": "synthetic",
+            "comm": comm,
             "config": {"workload": (f"wav2vec2-{args.model} {args.precision} forward-only, batch={B}x{L} samples per GPU"
                                     + (" (BASELINE configs[1])" if (args.model, B, L, args.precision) == ("base", 32, 246000, "fp32") else "")
                                     if args.mode == "forward" else

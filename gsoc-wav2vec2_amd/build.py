@@ -45,8 +45,17 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    if not force and not needs_build():
+def build(force=False, verbose=True, tuning=False):
+    """tuning=True builds lib/libw2v2_tuning.so with -DW2V2_TUNING: the same sources with the tuning knobs and timing
+    ablations readable from the environment (csrc/common.h: tune_int).  Only tools/ load it (W2V2_NATIVE_LIB); the
+    shipping library reads no environment variable."""
+    if tuning:
+        return _build(os.path.join(HERE, "build_tuning"), os.path.join(LIB_DIR, "libw2v2_tuning.so"), FLAGS + ["-DW2V2_TUNING"], True, verbose)
+    return _build(OBJ, LIB, FLAGS, force, verbose)
+
+
+def _build(OBJ, LIB, FLAGS, force, verbose):
+    if not force and LIB == globals()["LIB"] and not needs_build():
         return LIB
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
@@ -74,4 +83,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, tuning="--tuning" in sys.argv)

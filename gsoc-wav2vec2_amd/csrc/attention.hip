@@ -271,11 +271,7 @@ int launch_attn_nw(const AttnArgs& a, hipStream_t s) {
 // T=768, B=32, 12 heads: 4 waves (2 blocks/CU) 95 TF, 8 waves 93, 12 waves (3 per SIMD) 105.
 template <int DH>
 int launch_attn(const AttnArgs& a, hipStream_t s) {
-    static int forced = -2;
-    if (forced == -2) {
-        const char* e = getenv("W2V2_ATTN_NW");     // tuning knob, not part of the ABI
-        forced = e ? atoi(e) : -1;
-    }
+    const int forced = tune_int("W2V2_ATTN_NW", -1);
     const int cand[3] = {12, 8, 4};
     int best = 4;
     int64_t best_cost = INT64_MAX;

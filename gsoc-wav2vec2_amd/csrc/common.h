@@ -34,6 +34,16 @@ void set_error(const char* fmt, ...);
         }                                      \
     } while (0)
 
+// ---- tuning knobs -----------------------------------------------------------
+// The shipping library has NO environment reads: every knob is its measured default, folded at compile time.  The tools-only
+// build (`python build.py --tuning` -> lib/libw2v2_tuning.so, -DW2V2_TUNING) reads the same names from the environment for
+// the sweeps and timing ablations recorded under profiles/; tests and bench.py never load it.
+#ifdef W2V2_TUNING
+int tune_int(const char* name, int dflt);      // getenv + atoi, read on every call (w2v2_api.hip)
+#else
+constexpr int tune_int(const char*, int dflt) { return dflt; }
+#endif
+
 // ---- kernel families (one row each in profiles/ and in the roofline) ------
 enum Family {
     FAM_CONV0_STATS = 0,   // conv0 recompute + per-(sample,channel) sum/sumsq   (HBM: wave read)

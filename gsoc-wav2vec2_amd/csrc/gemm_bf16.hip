@@ -62,8 +62,11 @@ struct Gemm16Args {
     GemmTrainEpiDev epi;   // training epilogue (EPI instances of the kernel only)
     int64_t validK;        // tr form: rows of the K dimension that exist, over all batches (batch z owns [z K, (z + 1) K)); rows beyond
                            // read as zero, so neither the row count nor its split into slabs has to be a multiple of the K tile
-    int abl;      // timing ablations (W2V2_GEMM16_ABL, results are wrong by construction): 1 = no operand traffic in the K loop,
-                  // 2 = no MFMAs, 4 = no epilogue
+#ifdef W2V2_TUNING
+    unsigned long long* trace = nullptr;      // tools-only build: per-block phase stamps (tools/gemm16_trace.py), 32 words per block
+    int abl = 0;  // timing ablations of the tools-only build (W2V2_GEMM16_ABL, results are wrong by construction): 1 = no operand
+                  // traffic in the K loop, 2 = no MFMAs, 4 = no epilogue.  The shipping kernel has no such field and no such branches.
+#endif
 };
 
 // two fp32 -> one dword of two bf16, round to nearest even (gfx950 instruction; no builtin in ROCm 7.2)
@@ -123,6 +126,23 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
     const float* __restrict__ Bm = g.B + (g.zmod ? (int64_t)(z / g.zmod) * g.strideB2 + (int64_t)(z % g.zmod) * g.strideB
                                                  : (int64_t)z * g.strideB);
 
+#ifdef W2V2_TUNING
+    const int abl = g.abl;
+    unsigned long long* const trc = g.trace ? g.trace + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 32 : nullptr;
+    int trc_n = 2;
+    if (trc && tid == 0) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        trc[0] = ((unsigned long long)xcc << 32) | hwid;
+        trc[1] = wall_clock64();
+        trc[trc_n++] = clock64();
+    }
+#define W2V2_TRC() do { if (trc && tid == 0 && trc_n < 31) trc[trc_n++] = clock64(); } while (0)
+#else
+    constexpr int abl = 0;      // (the conditions below fold away: the DMA issue is unconditional in the shipping kernel)
+#define W2V2_TRC() do { } while (0)
+#endif
     const int nk = (g.K + BK - 1) / BK;
     const bool do_colsum = AT && g.colsum != nullptr && tm == 0;      // block-uniform
 
@@ -434,15 +454,18 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
         if constexpr (NS == 2) {
             issue(0, 0);
             __syncthreads();                    // carries the vmcnt(0) that retires the DMA
+            W2V2_TRC();
             for (int kt = 0; kt + 1 < nk; ++kt) {
                 const int cur = kt & 1;
-                if (!(g.abl & 1)) issue(kt + 1, cur ^ 1);
+                if (!(abl & 1)) issue(kt + 1, cur ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
-                if (!(g.abl & 2)) compute(cur);
+                if (!(abl & 2)) compute(cur);
                 __builtin_amdgcn_sched_barrier(0);
                 __syncthreads();
+                W2V2_TRC();
             }
             compute((nk - 1) & 1);
+            W2V2_TRC();
         } else {
             // Ring of NS stages, NS - 1 tiles in flight.  One MFMA block per tile step is only 512 cycles while an
             // L2 / HBM round trip under load is several thousand, so a single tile of prefetch leaves the loop
@@ -504,7 +527,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
     const int64_t tile_off = (int64_t)zo * g.strideC2 + (int64_t)zi * g.strideC + (int64_t)(m0 + wm * WTM) * g.ldc + (n0 + wn * WTN);
     // the operand images are dead once every wave has issued its last MFMA: the accumulators go out through wave-private
     // LDS patches so that every store writes whole 128-byte row segments (gemm_epilogue_lds)
-    if (g.abl & 4) {
+    if (abl & 4) {
         if (acc[0][0][0] == 12345.678f) g.C[0] = 1.f;       // keep the accumulators alive
         return;
     }
@@ -525,6 +548,13 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
                                  g.residual ? g.residual + tile_off : nullptr,
                                  g.bias ? g.bias + (g.zmod ? (int64_t)zi * g.strideBias : 0) + (n0 + wn * WTN) : nullptr,
                                  (int)g.ldc, g.M - (m0 + wm * WTM), g.N - (n0 + wn * WTN), g.act, li, lh);
+#ifdef W2V2_TUNING
+    if (trc && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (this wave's stores have left)
+        trc[trc_n++] = clock64();
+        trc[31] = (unsigned long long)trc_n;
+    }
+#endif
 }
 
 // ---- weight-gradient form dW = X^T dY with both operands by LDS-DMA and a TRANSPOSING LDS read ---------------------------
@@ -738,13 +768,14 @@ uint32_t host_dropout_key(uint64_t seed, uint32_t stream) {
     return (uint32_t)(z ^ (z >> 31));
 }
 
+#ifdef W2V2_TUNING
+}  // namespace
+unsigned long long* g_tune_trace = nullptr;      // set by w2v2_tune_set_trace (tuning_entry.hip)
+namespace {
+#endif
+
 int forced_cfg16() {
-    static int v = -2;
-    if (v == -2) {
-        const char* e = getenv("W2V2_GEMM16_CFG");   // tuning knob, not part of the ABI
-        v = e ? atoi(e) : -1;
-    }
-    return v;
+    return tune_int("W2V2_GEMM16_CFG", -1);
 }
 
 }  // namespace
@@ -760,9 +791,7 @@ bool gemm_train_epilogue_ok(int M, int N, int K, int64_t ldc) {
 // -0.38 ms, bit 0 -0.1 ms, bit 1 +0.34 ms (the H-wide GEMM is too short to hide the epilogue's hash and scattered residual reads):
 // default 5.
 int gemm_train_epilogue_sites() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("W2V2_GEMM_EPI"); v = e ? atoi(e) : 5; }
-    return v;
+    return tune_int("W2V2_GEMM_EPI", 5);
 }
 int gemm_train_colpart_rows(int M) { return (M + 127) / 128 * 2; }     // wave tiles of 64 rows, two per 128-row block
 
@@ -780,7 +809,6 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
     W2V2_REQUIRE((A || x.A16) && (B || x.B16 || x.B16p) && (C || x.C16), "gemm_bf16: null operand");
     W2V2_REQUIRE(M > 0 && N > 0 && K > 0 && nbatch > 0, "gemm_bf16: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, nbatch);
     W2V2_REQUIRE(lda >= 1 && ldb >= N && ldc >= N && ldc < (1 << 23), "gemm_bf16: bad leading dimensions");
-    static int dma = -1;
     W2V2_REQUIRE(act >= 0 && act <= 2, "gemm_bf16: bad activation %d", act);
     Gemm16Args g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.residual = residual;
@@ -794,9 +822,10 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
     W2V2_REQUIRE(x.validK == 0 || (x.transA && x.A16 && x.B16p && x.validK > (int64_t)K * (nbatch - 1) && x.validK <= (int64_t)K * nbatch),
                  "gemm_bf16: validK is for the transposed-A shadow form, and every batch must own at least one existing row");
     g.epi = GemmTrainEpiDev{};
-    static int abl = -1;
-    if (abl < 0) { const char* e = getenv("W2V2_GEMM16_ABL"); abl = e ? atoi(e) : 0; }
-    g.abl = abl;
+#ifdef W2V2_TUNING
+    g.abl = tune_int("W2V2_GEMM16_ABL", 0);
+    g.trace = g_tune_trace;
+#endif
     W2V2_REQUIRE(x.zmod >= 0 && (x.zmod == 0 || nbatch % x.zmod == 0), "gemm_bf16: batch %d is not a multiple of the inner batch %d", nbatch, x.zmod);
     const bool kfast = K % BK == 0;
     const bool a32 = A && (lda % 4 == 0) && (strideA % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
@@ -806,12 +835,11 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
     int src;
     // tuning knob: 0 = register-staged shadows (595 TF on the forward mix), 1 = LDS-DMA, 2 stages, 2 blocks/CU (617, default),
     // 2 = LDS-DMA 4-stage ring with three tiles in flight, 1 block/CU (513: deeper prefetch does not pay for half the waves)
-    if (dma < 0) { const char* e = getenv("W2V2_GEMM16_DMA"); dma = e ? atoi(e) : 1; }
+    const int dma = tune_int("W2V2_GEMM16_DMA", 1);
     if (x.transA) {
         // both bf16 shadows, whole 128 x 128 tiles, 16-byte aligned rows: LDS-DMA + transposing LDS reads (the fp32 operands are
         // not touched and may be null)
-        static int tr = -1;
-        if (tr < 0) { const char* e = getenv("W2V2_GEMM16_TR"); tr = e ? atoi(e) : 1; }      // tuning knob
+        const int tr = tune_int("W2V2_GEMM16_TR", 1);
         if (tr && kfast && C && x.A16 && x.B16p && !x.colsum && !x.overlapA && M % 128 == 0 && N % 128 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
             strideA % 8 == 0 && strideB % 8 == 0 && ((reinterpret_cast<uintptr_t>(x.A16) | reinterpret_cast<uintptr_t>(x.B16p)) & 15) == 0) {
             ProfScope ps(prof, FAM_GEMM_BF16, 2.0 * M * (double)N * K * nbatch, nbatch * (2.0 * K * ((double)M + N) + 4.0 * (double)M * N), s);

@@ -382,12 +382,7 @@ int launch_cfg(GemmArgs& g, bool fast, int nbatch, hipStream_t s) {
 }
 
 int forced_cfg() {
-    static int v = -2;
-    if (v == -2) {
-        const char* e = getenv("W2V2_GEMM_CFG");   // tuning knob, not part of the ABI
-        v = e ? atoi(e) : -1;
-    }
-    return v;
+    return tune_int("W2V2_GEMM_CFG", -1);
 }
 
 // ---- split-K for small problems (serving: B = 1) ------------------------------------------------------------------
@@ -493,8 +488,7 @@ int launch_gemm_ex(Profiler* prof, const float* A, int64_t lda, int64_t strideA,
         // The rows of that partial round are computed with 64x64 tiles instead (4x the blocks, a quarter of the time each).
         // Every output element still sums its K products in the same order, so results do not depend on the tiling
         // (a row's value is independent of its position in the batch: test_linearity_of_lm_head_at_full_size).
-        static int tail_knob = -1;
-        if (tail_knob < 0) { const char* e = getenv("W2V2_GEMM_TAIL"); tail_knob = e ? atoi(e) : 1; }     // tuning knob
+        const int tail_knob = tune_int("W2V2_GEMM_TAIL", 1);
         const int64_t tn = (N + 127) / 128, S = 512, r = tiles128 % S;
         if (tail_knob && fast && cfg == 7 && nbatch == 1 && tiles128 > S && r != 0 && 4 * r <= S) {
             const int64_t main_rows = ((tiles128 - r) / tn) * 128;

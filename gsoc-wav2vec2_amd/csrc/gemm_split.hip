@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
 // k extent of one LDS stage; fixed for the process because the weight planes are stored in that tiling
 int split_bk() {
     static int bk = -1;
-    if (bk < 0) { const char* e = getenv("W2V2_SPLIT_BK"); bk = (e && atoi(e) == 32) ? 32 : 16; }      // tuning knob, not part of the ABI
+    if (bk < 0) bk = tune_int("W2V2_SPLIT_BK", 16) == 32 ? 32 : 16;
     return bk;
 }
 
@@ -316,7 +316,7 @@ int launch_gemm_split(Profiler* prof, const float* A, int64_t lda, int64_t strid
     ProfScope ps(prof, FAM_GEMM_SPLIT, 2.0 * M * (double)N * K * nbatch,
                  nbatch * 4.0 * ((double)M * K + (double)M * N) + 6.0 * (double)K * N, s);
     static int order = -1;
-    if (order < 0) { const char* e = getenv("W2V2_SPLIT_ORDER"); order = e ? atoi(e) : 1; }
+    if (order < 0) order = tune_int("W2V2_SPLIT_ORDER", 1);
     g.order = order;
     const int bk = split_bk();
     const dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch);

@@ -127,7 +127,7 @@ int launch_layer_norm_x(Profiler* prof, const float* x, float* y, const float* g
     // 4 blocks per CU (16 waves), each wave looping over rows
     const int64_t want = (rows + 3) / 4;
     static int cap = -1;
-    if (cap < 0) { const char* e = getenv("W2V2_LN_BLOCKS"); cap = e ? atoi(e) : 256 * 4; }      // tuning knob: 512 / 1024 / 2048 / 4096 blocks -> 1.14 / 1.06 / 1.10 / 1.26 ms for the 25 LayerNorms of a base forward
+    if (cap < 0) cap = tune_int("W2V2_LN_BLOCKS", 256 * 4);      // 512 / 1024 / 2048 / 4096 blocks -> 1.14 / 1.06 / 1.10 / 1.26 ms for the 25 LayerNorms of a base forward
     dim3 grid((unsigned)(want < cap ? want : cap)), block(256);
     ProfScope ps(prof, FAM_LAYERNORM, 8.0 * rows * C, (4.0 + (y ? 4.0 : 0.0) + (y16 ? 2.0 : 0.0)) * rows * C, s);
     if (C <= 256)

@@ -29,6 +29,7 @@ struct w2v2_model {
     std::vector<float*> qkv_w, qkv_b;        // per layer (H, 3H), (3H)
     bool finalized = false;
     int precision = 0;                       // 0 fp32 MFMA, 1 bf16 operands / fp32 accumulate (w2v2_set_precision)
+    bool opt_shadows = true, opt_keep_acts = false;      // w2v2_set_option
     // activation workspace
     int ws_B = 0;
     int64_t ws_L = 0;
@@ -72,10 +73,10 @@ struct w2v2_model {
 
 
 // implemented in w2v2_api.hip
-bool w2v2_shadows_enabled();                                              // W2V2_BF16_SHADOWS != 0
+bool w2v2_shadows_enabled(const w2v2_model* m);                            // W2V2_OPT_BF16_SHADOWS (default on)
 bool w2v2_conv_out_bf16_only(const w2v2_model* m, int i, bool sh);         // conv-stack output i is written only as bf16 this forward
 bool w2v2_conv_ln_bf16_only(const w2v2_model* m, int i, bool sh);          // LayerNorm-mode extractor: LN + GELU output i only as bf16
-bool w2v2_keep_activations();                                             // W2V2_KEEP_ACTIVATIONS == 1: also write the fp32 copies nothing reads
+bool w2v2_keep_activations(const w2v2_model* m);                           // W2V2_OPT_KEEP_ACTIVATIONS: also write the fp32 copies nothing reads
 int w2v2_ensure_shadows(w2v2_model* m, int B, int T, hipStream_t s);
 bool w2v2_pos_conv_bf16_ok(const w2v2_model* m);                          // precision 1 and a supported group shape
 int w2v2_ensure_pos16(w2v2_model* m, int B, int T, hipStream_t s);       // kernel shadow + pack scratch     // allocate activation shadows, (re)build weight shadows

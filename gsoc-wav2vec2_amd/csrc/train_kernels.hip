@@ -23,7 +23,7 @@ constexpr int EW_THREADS = 256;
 
 inline unsigned ew_grid(int64_t n_vec) {
     static int cap = -1;
-    if (cap < 0) { const char* e = getenv("W2V2_EW_BLOCKS"); cap = e ? atoi(e) : 16384; }      // tuning knob: 1024 / 2048 / 4096 / 16384 blocks -> 78.9 / 59.6 / 59.8 / 57.3 us per dropout_fwd launch (fine-tune step average)
+    if (cap < 0) cap = tune_int("W2V2_EW_BLOCKS", 16384);      // 1024 / 2048 / 4096 / 16384 blocks -> 78.9 / 59.6 / 59.8 / 57.3 us per dropout_fwd launch (fine-tune step average)
     int64_t g = (n_vec + EW_THREADS - 1) / EW_THREADS;
     return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));   // grid-stride beyond `cap` blocks
 }
@@ -680,7 +680,7 @@ int launch_dropout_bwd_colsum(const float* u, const float* dy, float* dx, uint16
     // rows grows with them);
     // ws: dropout_bwd_colsum_ws_floats(rows, cols) floats
     static int target = -1;
-    if (target < 0) { const char* e = getenv("W2V2_DBC_BLOCKS"); target = e ? atoi(e) : 8192; }      // tuning knob: >= 2048 / 4096 / 8192 / 16384 blocks -> 20.4 / 18.8 / 17.8 / 18.9 ms (kernel + fold, 7 fine-tune steps)
+    if (target < 0) target = tune_int("W2V2_DBC_BLOCKS", 8192);      // >= 2048 / 4096 / 8192 / 16384 blocks -> 20.4 / 18.8 / 17.8 / 18.9 ms (kernel + fold, 7 fine-tune steps)
     int chunk = COLSUM_CHUNK;
     const int colblocks = (cols + 255) / 256;
     while (chunk > 16 && (rows + chunk - 1) / chunk * colblocks < target) chunk >>= 1;

@@ -248,27 +248,30 @@ int w2v2_ensure_workspace(w2v2_model* m, int B, int64_t L) {
 }
 
 // ---- bf16 shadows for the inference forward in precision mode 1 ------------------------------------------
-// W2V2_BF16_SHADOWS=0 turns them off (every GEMM then rounds its fp32 operands itself): same results bit for
-// bit, used by the tests to prove exactly that.
-bool w2v2_shadows_enabled() {
-    const char* e = getenv("W2V2_BF16_SHADOWS");      // read per call: tests flip it between two forwards
-    return !(e && atoi(e) == 0);
-}
+// w2v2_set_option(m, W2V2_OPT_BF16_SHADOWS, 0) turns them off (every GEMM then rounds its fp32 operands itself): same
+// results bit for bit, used by the tests to prove exactly that.
+bool w2v2_shadows_enabled(const w2v2_model* m) { return m->opt_shadows; }
 
 // Precision mode 1 with shadows: a conv-stack output whose only consumer is the next layer's GEMM (reading the bf16 shadow)
 // is written ONLY as bf16 -- 6.3 GB of fp32 stores per B = 32 x 246000 forward that nothing would read.  Stage taps of
-// those tensors (w2v2_copy_activation) then report an error; W2V2_KEEP_ACTIVATIONS=1 (read per call) keeps the fp32 copies.
-bool w2v2_keep_activations() {
-    const char* e = getenv("W2V2_KEEP_ACTIVATIONS");
-    return e && atoi(e) != 0;
+// those tensors (w2v2_copy_activation) then report an error; w2v2_set_option(m, W2V2_OPT_KEEP_ACTIVATIONS, 1) keeps the fp32 copies.
+bool w2v2_keep_activations(const w2v2_model* m) { return m->opt_keep_acts; }
+
+#ifdef W2V2_TUNING
+namespace w2v2 {
+int tune_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
 }
+}  // namespace w2v2
+#endif
 
 // Whether conv-stack output i (0 .. NC-2) may be written ONLY as bf16 in the coming forward: group-norm mode with shadows,
 // and layer i+1's GEMM is certain to take the bf16 shadow as its A operand (gemm_bf16.hip: K % 64 == 0 and 16-byte
 // aligned rows / batch strides) -- otherwise that GEMM reads the fp32 tensor and it must exist.
 bool w2v2_conv_out_bf16_only(const w2v2_model* m, int i, bool sh) {
     const w2v2_config& c = m->cfg;
-    if (!sh || c.feature_extractor_norm_type == 1 || i + 1 >= c.num_conv_layers || w2v2_keep_activations()) return false;
+    if (!sh || c.feature_extractor_norm_type == 1 || i + 1 >= c.num_conv_layers || w2v2_keep_activations(m)) return false;
     const int64_t cin = c.filter_sizes[i], K = (int64_t)c.kernal_sizes[i + 1] * cin, lda = (int64_t)c.strides[i + 1] * cin;
     const int64_t strideA = (int64_t)m->conv_T[i] * cin;
     return K % 64 == 0 && lda % 8 == 0 && strideA % 8 == 0;
@@ -278,7 +281,7 @@ bool w2v2_conv_out_bf16_only(const w2v2_model* m, int i, bool sh) {
 // i + 1's GEMM, streams the shadow (same alignment conditions as above; the GEMM's own fp32 output is the LayerNorm's input and stays)
 bool w2v2_conv_ln_bf16_only(const w2v2_model* m, int i, bool sh) {
     const w2v2_config& c = m->cfg;
-    if (!sh || c.feature_extractor_norm_type != 1 || i + 1 >= c.num_conv_layers || w2v2_keep_activations()) return false;
+    if (!sh || c.feature_extractor_norm_type != 1 || i + 1 >= c.num_conv_layers || w2v2_keep_activations(m)) return false;
     const int64_t cin = c.filter_sizes[i], K = (int64_t)c.kernal_sizes[i + 1] * cin, lda = (int64_t)c.strides[i + 1] * cin;
     const int64_t strideA = (int64_t)m->conv_T[i] * cin;
     return K % 64 == 0 && lda % 8 == 0 && strideA % 8 == 0;
@@ -572,6 +575,23 @@ int w2v2_set_precision(w2v2_model* m, int32_t mode) {
 }
 int w2v2_get_precision(const w2v2_model* m) { return m ? m->precision : W2V2_EINVAL; }
 
+int w2v2_set_option(w2v2_model* m, int32_t option, int32_t value) {
+    W2V2_REQUIRE(m, "set_option: null model");
+    switch (option) {
+        case W2V2_OPT_BF16_SHADOWS: m->opt_shadows = value != 0; return W2V2_OK;
+        case W2V2_OPT_KEEP_ACTIVATIONS: m->opt_keep_acts = value != 0; return W2V2_OK;
+        default: set_error("set_option: unknown option %d", option); return W2V2_EINVAL;
+    }
+}
+int w2v2_get_option(const w2v2_model* m, int32_t option) {
+    if (!m) return W2V2_EINVAL;
+    switch (option) {
+        case W2V2_OPT_BF16_SHADOWS: return m->opt_shadows ? 1 : 0;
+        case W2V2_OPT_KEEP_ACTIVATIONS: return m->opt_keep_acts ? 1 : 0;
+        default: return W2V2_EINVAL;
+    }
+}
+
 int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const int32_t* mask,
                  float* out, void* stream) {
     W2V2_REQUIRE(m && wave && out, "forward: null argument");
@@ -601,7 +621,7 @@ int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const i
     // Precision mode 1 with bf16 shadows: every producer of a GEMM operand also writes its nearest-even bf16 copy, the
     // GEMMs stream those (2 bytes per element, no conversion) and the weights come from (N, K) bf16 shadows.  `sh`
     // false = plain pointers everywhere: the GEMMs then round their fp32 operands themselves, with identical results.
-    const bool sh = m->precision == 1 && w2v2_shadows_enabled();
+    const bool sh = m->precision == 1 && w2v2_shadows_enabled(m);
     if (sh)
         if (int e = w2v2_ensure_shadows(m, B, T, s)) return e;
     const bool attn16 = sh && attention_bf16_supported(H / c.num_heads);
@@ -776,7 +796,7 @@ int w2v2_copy_activation(w2v2_model* m, const char* name, float* host_dst, int64
     for (const std::string& skipped : m->acts_skipped)
         if (skipped == name) {
             set_error("activation `%s` was written only as bf16 by the last forward (precision mode bf16: its one consumer reads the "
-                      "shadow); set W2V2_KEEP_ACTIVATIONS=1 to keep the fp32 copy", name);
+                      "shadow); w2v2_set_option(m, W2V2_OPT_KEEP_ACTIVATIONS, 1) keeps the fp32 copy", name);
             return W2V2_ESTATE;
         }
     W2V2_HIP_CHECK(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));

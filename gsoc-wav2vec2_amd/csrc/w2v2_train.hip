@@ -263,7 +263,7 @@ static int refresh_transposes(w2v2_model* m, hipStream_t s) {
     // never read: only lm_head's (N = 32: no shadow) and the flipped positional kernel are needed.  `transposes_full`
     // remembers whether the fp32 copies are current, for a later switch back to fp32 / bf16x3 on the same model.
     const w2v2_config& c = m->cfg;
-    bool need_full = !(m->precision == 1 && w2v2_shadows_enabled() && m->w16_valid);
+    bool need_full = !(m->precision == 1 && w2v2_shadows_enabled(m) && m->w16_valid);
     if (!need_full) {      // every kernel whose fp32 copy is skipped must really have its bf16 stand-in (shapes with N % 64 != 0 do not)
         auto has = [&](const float* w) { return m->w16p.find(w) != m->w16p.end(); };
         need_full = !has(m->P("feature_projection/projection/kernel"));
@@ -327,8 +327,7 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
         const int64_t tiles = (int64_t)((Kin + 127) / 128) * ((Nout + 127) / 128);
         // slabs cost a reduction pass each: the bf16 kernels are happiest with ONE block per resident slot (512),
         // the fp32 one wants ~4 to balance its long tiles (183.8 vs 189.4 ms)
-        static int dwb = -1;
-        if (dwb < 0) { const char* e = getenv("W2V2_DW_BLOCKS"); dwb = e ? atoi(e) : 512; }      // tuning knob: 512 -> 40.0 ms per step, 1024 -> 40.5, 256 -> 47.0 (base, 32 x 246000)
+        const int dwb = tune_int("W2V2_DW_BLOCKS", 512);      // 512 -> 40.0 ms per step, 1024 -> 40.5, 256 -> 47.0 (base, 32 x 246000)
         const int64_t max_blocks = direct ? dwb : 2048;
         int cap = 32;                                                   // most slabs worth having / that fit the scratch
         while (cap > 1 && (tiles * cap > max_blocks || (int64_t)(cap + 2) * Kin * Nout > t->slab_floats)) --cap;
@@ -341,7 +340,7 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
         W2V2_REQUIRE(tr_form || (A && dY), "weight_grad: the fp32 operands are needed here (no bf16 shadows / shapes not whole 128-tiles)");
         // That kernel reads rows past M as zero (GemmShadows::validK), so any M splits into S slabs of ceil(M / 64 / S) K tiles with
         // no leftover pass: the last slab is merely short.
-        static const bool ragged = !getenv("W2V2_NO_RAGGED_DW");      // tuning knob: leftover rows on the tail kernel instead
+        const bool ragged = !tune_int("W2V2_NO_RAGGED_DW", 0);      // (tuning build: 1 = leftover rows on the tail kernel instead)
         if (tr_form && ragged && M % kq != 0) {
             const int64_t units_all = (M + kq - 1) / kq;
             int S = (int)(units_all < cap ? units_all : cap);
@@ -443,6 +442,20 @@ int w2v2_set_trainable(w2v2_model* m, const char* prefix, int trainable) {
     return W2V2_OK;
 }
 
+int w2v2_set_trainable_flags(w2v2_model* m, const uint8_t* flags, int32_t n) {
+    W2V2_REQUIRE(m && flags, "set_trainable_flags: null argument");
+    W2V2_REQUIRE(n == (int32_t)m->params.size(), "set_trainable_flags: %d flags for %d variables", n, (int)m->params.size());
+    TrainState* t = get_state(m);
+    bool changed = false;
+    for (int32_t i = 0; i < n; ++i) {
+        const uint8_t f = flags[i] ? 1 : 0;
+        changed |= t->trainable[i] != f;
+        t->trainable[i] = f;
+    }
+    if (changed) t->adam_table_fresh = false;
+    return W2V2_OK;
+}
+
 int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const int32_t* mask,
                        const uint8_t* spec_mask_host, const float* sd_keep_host, float dropout_p,
                        uint64_t seed, float* logits_out, void* stream) {
@@ -477,7 +490,7 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
     // operand -- conv0, GEMM epilogues, LayerNorm, dropout, attention -- also writes the nearest-even bf16 copy, so the
     // forward GEMMs stream 2-byte operands by LDS-DMA instead of converting fp32 in registers.  The shadow buffers are
     // transient scratch (the backward works from the saved fp32 activations); results are bit-identical either way.
-    const bool sh = m->precision == 1 && w2v2_shadows_enabled();
+    const bool sh = m->precision == 1 && w2v2_shadows_enabled(m);
     if (sh)
         if (int e = w2v2_ensure_shadows(m, B, T, s)) return e;
     const bool attn16 = sh && attention_bf16_supported(H / c.num_heads);
@@ -679,7 +692,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     PrecisionScope precision(m->precision);
     // dX = dY W^T reads the fp32 transposed copy WT ([out][in]) as its B operand; in precision mode 1 with shadows the bf16
     // copy of W itself ([in][out] = (N, K) for this GEMM) is the B shadow -- no transpose needed.  Bit-identical results.
-    const bool shb = m->precision == 1 && w2v2_shadows_enabled() && m->w16_valid;
+    const bool shb = m->precision == 1 && w2v2_shadows_enabled(m) && m->w16_valid;
     // A16: the producer's bf16 shadow of A (or null): with it both operands stream by LDS-DMA (gemm_bf16.hip source 5)
     auto gemm_dx = [&](const float* A, const uint16_t* A16, int64_t lda, const float* WT, const float* W, float* Cc, int64_t ldc,
                        const float* res, int M, int N, int K, hipStream_t st, uint16_t* C16 = nullptr, const GemmTrainEpi* epi = nullptr) -> int {
@@ -839,7 +852,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         if (int e = gemm_dx(dy, dy16, H, l.W2T, W2, t->gf, F, nullptr, (int)BT, F, H, s)) return e;
         return dropout_bwd_bias(l.u, t->gf, du16_only ? nullptr : t->gf, s16f, BT, F, act_ew, layer_stream(i, 2), gb1, b1_done);
     };
-    static const bool fuse_do_tail = !getenv("W2V2_NO_DO_TAIL");
+    const bool fuse_do_tail = !tune_int("W2V2_NO_DO_TAIL", 0);
     bool dh16_valid = false;
     if (prenorm && s16h && (BT * H) % 4 == 0 && (reinterpret_cast<uintptr_t>(dh) & 15) == 0) {
         // the last layer's output gradient arrives in fp32 only: round it once so that its down-projection GEMMs stream shadows too

@@ -61,6 +61,9 @@ PROTOTYPES = {
     "w2v2_forward": (C.c_int, [_P, _P, _I32, _I64, _P, _P, _P]),
     "w2v2_ctc_loss": (C.c_int, [_P, _I32, _I32, _I32, _P, _I32, _P, _P, _I32, _P, _P, _P]),
     "w2v2_set_trainable": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "w2v2_set_trainable_flags": (C.c_int, [_P, _P, _I32]),
+    "w2v2_set_option": (C.c_int, [_P, _I32, _I32]),
+    "w2v2_get_option": (C.c_int, [_P, _I32]),
     "w2v2_train_forward": (C.c_int, [_P, _P, _I32, _I64, _P, _P, _P, C.c_float, C.c_uint64, _P, _P]),
     "w2v2_train_backward": (C.c_int, [_P, _P, _P]),
     "w2v2_grad_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I64)]),
@@ -120,7 +123,12 @@ def load(build_if_missing=True):
     # mapped when libw2v2.so is loaded, so that both sides share ONE runtime (device pointers,
     # streams); loading libw2v2.so first would pull in /opt/rocm's copy as a second runtime.
     import torch  # noqa: F401
-    if not os.path.exists(LIB_PATH) and build_if_missing:
+    override = os.environ.get("W2V2_NATIVE_LIB")      # tools/ only: the -DW2V2_TUNING build (build.py --tuning) for sweeps
+    if override:
+        path = override
+    else:
+        path = LIB_PATH
+    if not os.path.exists(LIB_PATH) and build_if_missing and not override:
         try:
             import importlib.util
             spec = importlib.util.spec_from_file_location("w2v2_build", os.path.join(_PKG_ROOT, "build.py"))
@@ -131,10 +139,10 @@ def load(build_if_missing=True):
             raise NativeLibraryError(
                 f"libw2v2.so is missing at {LIB_PATH} and could not be built with hipcc: {e}") from e
     try:
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path)
     except OSError as e:
         raise NativeLibraryError(
-            f"cannot load the HIP library {LIB_PATH}: {e}.  The MI355X path has no CPU fallback; "
+            f"cannot load the HIP library {path}: {e}.  The MI355X path has no CPU fallback; "
             "build it with `python gsoc-wav2vec2_amd/build.py`.") from e
     for name, (restype, argtypes) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError if the header and the library disagree

@@ -32,6 +32,22 @@ def init(backend="nccl", device=None):
     return world, rank
 
 
+def describe():
+    """What the process group itself reports: backend, world size, rank count per node, the RCCL version torch links
+    (backend "nccl" IS RCCL on ROCm).  A single un-launched process has no group: backend None, world size 1."""
+    import torch
+    import torch.distributed as dist
+    out = {"backend": None, "world_size": 1, "rccl_version": None, "launcher": "torch.distributed.run" if "RANK" in os.environ else "none"}
+    try:
+        out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:  # noqa: BLE001 -- a build without RCCL reports None
+        pass
+    if dist.is_available() and dist.is_initialized():
+        out["backend"] = dist.get_backend()
+        out["world_size"] = dist.get_world_size()
+    return out
+
+
 def shard_bounds(total_rows, world, rank):
     """Contiguous [lo, hi) slice of a global batch for `rank`; the first total % world ranks take one
     extra row (the reference keeps a fixed 32 rows per replica, src/main.py:41,156)."""
@@ -137,10 +153,33 @@ def all_reduce_range(buf, off, n, payload_dtype=None, async_op=False):
     """SUM all-reduce of buf[off : off + n] in place.  `payload_dtype` (e.g. torch.bfloat16) sends a down-cast copy and
     writes the up-cast sum back -- half the bytes over xGMI for the bf16 fine-tune configurations (180.4 MB
     instead of 360.8 MB for base).  Returns a callable that completes the operation (waits, and for a compressed payload
-    copies the result back)."""
+    copies the result back).
+
+    Accuracy of the compressed payload: the collective SUMs in the payload dtype, so with a bf16 payload every partial sum
+    of the ring is rounded to bf16 again -- relative error per element ~ 2^-9 for the down-cast plus up to ~ log2(world)
+    further roundings, i.e. ~1e-2 at 8 ranks (the two-rank bound is pinned in tests/test_dist_cpu.py).  That is the price
+    of halving the bytes; the default payload is fp32 (exact to fp32 summation order).
+
+    Transport: device buffers go straight to the backend (RCCL).  Under the `gloo` backend (the two-process-one-GPU test;
+    RCCL refuses two ranks on one device) a device range is staged through host memory on the CURRENT stream -- the copy
+    out is ordered behind whatever that stream waits for (the bucket event), the copy back is ordered before whatever
+    waits on it, so the stream / event protocol of Trainer.all_reduce_gradients is exercised unchanged."""
+    import torch
     import torch.distributed as dist
     view = buf[off:off + n]
-    if payload_dtype is None or payload_dtype == view.dtype:
+    compress = payload_dtype is not None and payload_dtype != view.dtype
+    if view.is_cuda and dist.get_backend() == "gloo":
+        host = (view.to(payload_dtype) if compress else view).cpu()      # synchronous D2H on the current stream
+        work = dist.all_reduce(host, op=dist.ReduceOp.SUM, async_op=async_op)
+        stream = torch.cuda.current_stream()
+
+        def finish_host():
+            if async_op:
+                work.wait()
+            with torch.cuda.stream(stream):
+                view.copy_(host.to(view.device, non_blocking=False))
+        return finish_host
+    if not compress:
         work = dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=async_op)
         return (work.wait if async_op else (lambda: None))
     small = view.to(payload_dtype)

@@ -214,13 +214,29 @@ class TFKerasModel(Layer):
             self.__dict__.update(backbone_attrs)
         attach(self, self._variables)
 
+    def _native_inventory(self):
+        """Variable names in the native library's own inventory order (w2v2_param_info)."""
+        if getattr(self, "_native_names", None) is None:
+            names = []
+            for i in range(self._lib.w2v2_num_params(self._handle)):
+                name, shape, rank = C.c_char_p(), (C.c_int64 * 4)(), C.c_int()
+                N.check(self._lib.w2v2_param_info(self._handle, i, C.byref(name), shape, C.byref(rank)), "w2v2_param_info")
+                names.append(name.value.decode())
+            if sorted(names) != sorted(self._specs):
+                raise RuntimeError("native variable inventory differs from wav2vec2.variables.variable_specs")
+            self._native_names = names
+        return self._native_names
+
     def _sync_trainable(self):
-        """Push the effective per-variable flags (own flag AND every layer above) to the native training state."""
-        for v in self._variables:
-            flag = v.trainable
-            if self._pushed_trainable.get(v.local_name, True) != flag:
-                N.check(self._lib.w2v2_set_trainable(self._handle, v.local_name.encode(), int(flag)), "w2v2_set_trainable")
-                self._pushed_trainable[v.local_name] = flag
+        """Push the effective per-variable flags (own flag AND every layer above) to the native training state: the whole
+        vector in ONE call (w2v2_set_trainable_flags), and only when some flag differs from what was pushed last -- an
+        inference-only model whose flags never leave the all-trainable default never creates the training state."""
+        flags = {v.local_name: bool(v.trainable) for v in self._variables}
+        if all(self._pushed_trainable.get(n, True) == f for n, f in flags.items()):
+            return
+        vec = (C.c_uint8 * len(flags))(*[int(flags[n]) for n in self._native_inventory()])
+        N.check(self._lib.w2v2_set_trainable_flags(self._handle, vec, len(flags)), "w2v2_set_trainable_flags")
+        self._pushed_trainable = flags
 
     def __del__(self):
         try:
@@ -324,6 +340,19 @@ class TFKerasModel(Layer):
         if precision not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(set(self.PRECISIONS))}, got {precision!r}")
         N.check(self._lib.w2v2_set_precision(self._handle, self.PRECISIONS[precision]), "w2v2_set_precision")
+
+    OPTIONS = {"bf16_shadows": 0, "keep_activations": 1}      # W2V2_OPT_* of include/w2v2.h
+
+    def set_option(self, name, value):
+        """Per-model switches of the bf16 precision mode (include/w2v2.h: w2v2_set_option): "bf16_shadows" (default on; off =
+        every GEMM rounds its fp32 operands itself, same bits, slower) and "keep_activations" (default off; on = stage outputs
+        that are normally written only as bf16 keep their fp32 copy so `activation(name)` can tap them)."""
+        if name not in self.OPTIONS:
+            raise KeyError(f"unknown option {name!r}; one of {sorted(self.OPTIONS)}")
+        N.check(self._lib.w2v2_set_option(self._handle, self.OPTIONS[name], int(bool(value))), "w2v2_set_option")
+
+    def get_option(self, name):
+        return bool(self._lib.w2v2_get_option(self._handle, self.OPTIONS[name]))
 
     @property
     def precision(self):

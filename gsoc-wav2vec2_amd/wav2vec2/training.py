@@ -13,6 +13,7 @@ draws on the host, and issues the collective.
 """
 
 import ctypes as C
+import warnings
 
 import numpy as np
 
@@ -66,10 +67,13 @@ class Trainer:
         self.dropout = cfg.dropout if dropout is None else dropout
         self.apply_spec_augment = cfg.apply_spec_augment if apply_spec_augment is None else apply_spec_augment
         world, rank = _world_rank()
+        self._world_rank_seen = (world, rank)             # what the seed below was derived from (checked again in `step`)
         self.base_seed = int(seed)
         self.seed = int(seed) * world + rank              # rank-aware: replicas draw independent masks
         self.iterations = 0                               # Keras optimizer.iterations
         self._rng = np.random.RandomState(self.seed & 0xFFFFFFFF)    # host RNG: spec-augment spans, stochastic depth
+        self._ranges_cache = {}                           # trainable set -> per-bucket send ranges (reduce_ranges)
+        self._layout_checked = False
         self.last = {}
         self.overlap_all_reduce = bool(overlap_all_reduce)   # per-bucket all-reduces under the backward (all_reduce_gradients)
         self.allreduce_dtype = allreduce_dtype
@@ -129,9 +133,23 @@ class Trainer:
         (the 4.2 M conv-stack elements in stage 2; everything but lm_head in stage 1) are zero on every rank and stay home.
         For wav2vec2-base in stage 2 that is the reference's 90,195,104-element payload (+ masked_spec_embed), 360.8 MB fp32."""
         m = self.model
-        layout, _ = D.flat_layout(m._specs)
-        trainable = {v.local_name for v in m.trainable_variables}
-        return [D.trainable_ranges(layout, bk, trainable) for bk in self.gradient_buckets()]
+        trainable = frozenset(v.local_name for v in m.trainable_variables)
+        hit = self._ranges_cache.get(trainable)
+        if hit is not None:
+            return hit
+        layout, total = D.flat_layout(m._specs)
+        if not self._layout_checked:
+            # the host-side layout arithmetic must BE the native flat buffer's layout: a drift would leave trainable slots
+            # unreduced or send frozen ones (checked once, against every slot the library reports)
+            for name, (off, n) in layout.items():
+                if self.gradient_slot(name) != (off, n):
+                    raise RuntimeError(f"gradient slot of `{name}`: host layout {(off, n)} != native {self.gradient_slot(name)}")
+            if total != self.grad_buffer().numel():
+                raise RuntimeError(f"flat gradient buffer: host layout {total} elements != native {self.grad_buffer().numel()}")
+            self._layout_checked = True
+        ranges = [D.trainable_ranges(layout, bk, trainable) for bk in self.gradient_buckets()]
+        self._ranges_cache = {trainable: ranges}          # (one entry: the trainable set changes between stages, not steps)
+        return ranges
 
     def all_reduce_gradients(self, force=False):
         """SUM over data-parallel ranks: the loss is pre-divided by the global batch (losses.py:45,
@@ -149,6 +167,11 @@ class Trainer:
         active = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)
         if not active:
             return
+        if _world_rank() != self._world_rank_seen:
+            warnings.warn(f"torch.distributed reports (world, rank) = {_world_rank()} but this Trainer derived its per-replica seed "
+                          f"from {self._world_rank_seen}: build the Trainer after init_process_group, or replicas share dropout / "
+                          "spec-augment masks", RuntimeWarning, stacklevel=2)
+            self._world_rank_seen = _world_rank()
         buf = self.grad_buffer()
         payload = torch.bfloat16 if self.allreduce_dtype == "bf16" else None
         ranges = self.reduce_ranges()
@@ -196,9 +219,10 @@ class Trainer:
         optimizer step count, Adam's moments, the hyper-parameters and the host RNG that draws spec-augment spans and
         stochastic-depth decisions.  The reference's per-epoch ModelCheckpoint (training_utils.py:38-45) is the analogue."""
         am, av = self._adam_views()
+        world, rank = _world_rank()
         return dict(iterations=int(self.iterations), learning_rate=float(self.learning_rate), beta_1=float(self.beta_1),
                     beta_2=float(self.beta_2), epsilon=float(self.epsilon), seed=int(self.seed), base_seed=int(self.base_seed),
-                    rng=self._rng.get_state(), adam_m=am.cpu().numpy(), adam_v=av.cpu().numpy())
+                    world_size=world, rank=rank, rng=self._rng.get_state(), adam_m=am.cpu().numpy(), adam_v=av.cpu().numpy())
 
     def load_state_dict(self, state, batch_shape=None):
         """Inverse of `state_dict`.  A state without moments (e.g. one written before any step) zeroes them, so stale
@@ -216,9 +240,22 @@ class Trainer:
         self.iterations = int(state["iterations"])
         for k in ("learning_rate", "beta_1", "beta_2", "epsilon"):
             setattr(self, k, float(state[k]))
-        self.seed = int(state["seed"])
-        self.base_seed = int(state.get("base_seed", self.seed))
-        self._rng.set_state(state["rng"])
+        # Randomness stays per REPLICA: the seed is re-derived for the rank that loads (a rank-0 checkpoint loaded on every
+        # rank must not give all replicas rank 0's dropout / spec-augment / stochastic-depth masks).  The saved host RNG
+        # state is adopted only by the replica that wrote it (exact resume); any other replica re-seeds from its own seed
+        # and the step count.
+        world, rank = _world_rank()
+        self._world_rank_seen = (world, rank)
+        saved_world, saved_rank = int(state.get("world_size", 1)), int(state.get("rank", 0))
+        self.base_seed = int(state.get("base_seed", state["seed"]))
+        if "base_seed" in state:
+            self.seed = self.base_seed * world + rank
+        else:                                             # a state from before base_seed existed: single-replica semantics
+            self.seed = int(state["seed"])
+        if (saved_world, saved_rank) == (world, rank) and self.seed == int(state["seed"]):
+            self._rng.set_state(state["rng"])
+        else:
+            self._rng = np.random.RandomState((self.seed * 1000003 + self.iterations) & 0xFFFFFFFF)
 
     # -- the step ------------------------------------------------------------------------------------
     def step(self, batch, labels, attention_mask=None):

@@ -130,6 +130,17 @@ int64_t w2v2_num_frames(const w2v2_model* m, int64_t num_samples);
 int w2v2_set_precision(w2v2_model* m, int32_t mode);
 int w2v2_get_precision(const w2v2_model* m);
 
+/* Per-model switches of the bf16 precision mode (no environment variable is read anywhere in the library):
+ *   W2V2_OPT_BF16_SHADOWS (default 1)      0 = no bf16 operand shadows: every GEMM rounds its fp32 operands itself.  Same
+ *                                          results bit for bit, slower; the parity tests flip it to prove exactly that.
+ *   W2V2_OPT_KEEP_ACTIVATIONS (default 0)  1 = also write the fp32 copies of stage outputs whose only reader streams the bf16
+ *                                          shadow, so w2v2_copy_activation can tap them (otherwise such a tap is an error).
+ * w2v2_get_option returns the value, or W2V2_EINVAL for an unknown option. */
+#define W2V2_OPT_BF16_SHADOWS 0
+#define W2V2_OPT_KEEP_ACTIVATIONS 1
+int w2v2_set_option(w2v2_model* m, int32_t option, int32_t value);
+int w2v2_get_option(const w2v2_model* m, int32_t option);
+
 /* ---- the hot path --------------------------------------------------------
  * Replaces Wav2Vec2ForCTC.call / Wav2Vec2Model.call at training=False
  * (modeling.py:169-209, 239-255).
@@ -174,6 +185,10 @@ int w2v2_ctc_loss(const float* logits_dev, int32_t B, int32_t T, int32_t V,
  * w2v2_adam_step: Keras Adam, p -= lr sqrt(1-b2^t)/(1-b1^t) m / (sqrt(v) + eps), then re-derives the
  *   tensors w2v2_finalize builds. */
 int w2v2_set_trainable(w2v2_model* m, const char* name_prefix, int trainable);
+/* The whole flag vector in one call: flags[i] != 0 marks variable i of the inventory (w2v2_param_info order) trainable;
+ * n must equal w2v2_num_params.  This is what `model.trainable = ...` / `layer.trainable = ...` push after walking the
+ * Keras-style layer tree (reference src/main.py:210,234-237 flips whole layers). */
+int w2v2_set_trainable_flags(w2v2_model* m, const uint8_t* flags, int32_t n);
 int w2v2_train_forward(w2v2_model* m, const float* wave_dev, int32_t B, int64_t L, const int32_t* mask_dev,
                        const uint8_t* spec_mask_host, const float* sd_keep_host, float dropout_p,
                        uint64_t seed, float* logits_dev, void* stream);

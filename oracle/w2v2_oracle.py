@@ -66,11 +66,28 @@ def round_bf16(x):
     return b.astype(np.uint32).view(np.float32).reshape(a.shape).astype(np.asarray(x).dtype)
 
 
-def _mm(a, b):
+# Error-budget switches (tests/bf16_error_budget.py): with GEMM_OPERANDS == "bf16", ROUND_STAGES limits the operand rounding
+# to the named contractions ("conv", "projection", "pos_conv", "qkv", "out_proj", "ffn1", "ffn2", "lm_head"; None = all of
+# them, the mode the parity tests use).  ATTENTION_OPERANDS == "bf16" additionally rounds q, k, v and the softmax
+# probabilities inside the attention core, which is what the build's bf16 attention kernel does (the reference-side
+# definition of the mode, `_mm` only, leaves the core in the working precision).
+ROUND_STAGES = None
+ATTENTION_OPERANDS = None
+
+
+def _mm(a, b, stage=None):
     """a @ b of one dense contraction, with the configured operand rounding."""
-    if GEMM_OPERANDS == "bf16":
+    if GEMM_OPERANDS == "bf16" and (ROUND_STAGES is None or stage in ROUND_STAGES):
         return round_bf16(a) @ round_bf16(b)
     return a @ b
+
+
+def _usable_cpus():
+    """CPUs this process may run on (a pinned CPU-baseline worker must not start a thread per core of the whole host)."""
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
 
 
 def _chunked(fn, x, min_elems=1 << 20):
@@ -81,11 +98,11 @@ def _chunked(fn, x, min_elems=1 << 20):
     if x.size < min_elems:
         return fn(x)
     flat = x.reshape(-1, x.shape[-1])
-    n = min(64, os.cpu_count() or 1, max(1, x.size // min_elems))
+    n = min(64, _usable_cpus(), max(1, x.size // min_elems))
     if n <= 1:
         return fn(x)
     if _POOL is None:
-        _POOL = ThreadPoolExecutor(max_workers=min(64, os.cpu_count() or 1))
+        _POOL = ThreadPoolExecutor(max_workers=min(64, _usable_cpus()))
     out = np.empty_like(flat)
     bounds = np.linspace(0, flat.shape[0], n + 1).astype(int)
 
@@ -160,7 +177,7 @@ def conv1d_valid(x, kernel, stride, bias=None):
     step = max(1, (32 << 20) // max(1, K * Cin * it))
     for b in range(B):
         for t0 in range(0, T_out, step):
-            y[b, t0:t0 + step] = (_mm(np.ascontiguousarray(win[b, t0:t0 + step]), w2) if x.shape[2] > 1
+            y[b, t0:t0 + step] = (_mm(np.ascontiguousarray(win[b, t0:t0 + step]), w2, "conv") if x.shape[2] > 1
                                    else np.ascontiguousarray(win[b, t0:t0 + step]) @ w2)   # layer 0 (C_in = 1) is not a GEMM in the build
     if bias is not None:
         y += bias
@@ -190,7 +207,7 @@ def feature_projection(config, w, x):
     (feature_extractor.py:92-95)."""
     x = layer_norm(x, w["feature_projection/layer_norm/gamma"],
                    w["feature_projection/layer_norm/beta"], config.layer_norm_eps)
-    return _mm(x, w["feature_projection/projection/kernel"]) + w["feature_projection/projection/bias"]
+    return _mm(x, w["feature_projection/projection/kernel"], "projection") + w["feature_projection/projection/bias"]
 
 
 def weight_norm_kernel(weight_v, weight_g):
@@ -220,7 +237,7 @@ def grouped_conv1d_same(x, kernel, bias, groups, padding):
             xg, shape=(B, T_out, K * cg), strides=(Tp * cg * it, cg * it, it), writeable=False)
         wg = kernel[:, :, g * og:(g + 1) * og].reshape(K * cg, og)
         for b in range(B):
-            y[b, :, g * og:(g + 1) * og] = _mm(np.ascontiguousarray(win[b]), wg)   # operand rounding as the Dense layers
+            y[b, :, g * og:(g + 1) * og] = _mm(np.ascontiguousarray(win[b]), wg, "pos_conv")   # operand rounding as the Dense layers
     return y + bias
 
 
@@ -250,20 +267,25 @@ def attention(config, w, base, x, add_mask):
     d = H // h
 
     def proj(name):
-        y = _mm(x, w[f"{base}/attention/{name}/kernel"]) + w[f"{base}/attention/{name}/bias"]
+        y = _mm(x, w[f"{base}/attention/{name}/kernel"], "qkv") + w[f"{base}/attention/{name}/bias"]
         return y.reshape(B, T, h, d).transpose(0, 2, 1, 3)            # (B, h, T, d)
 
     q = proj("q_proj") * x.dtype.type(d ** -0.5)
     k = proj("k_proj")
     v = proj("v_proj")
+    if ATTENTION_OPERANDS == "bf16":
+        q, k, v = round_bf16(q), round_bf16(k), round_bf16(v)
     s = q @ k.transpose(0, 1, 3, 2)                                   # (B, h, T, T)
     if add_mask is not None:
         s = s + add_mask
     s = s - s.max(axis=-1, keepdims=True)
     p = np.exp(s)
-    p = p / p.sum(axis=-1, keepdims=True)
-    ctx = (p @ v).transpose(0, 2, 1, 3).reshape(B, T, H)
-    return _mm(ctx, w[f"{base}/attention/out_proj/kernel"]) + w[f"{base}/attention/out_proj/bias"]
+    denom = p.sum(axis=-1, keepdims=True)
+    if ATTENTION_OPERANDS == "bf16":      # the kernel rounds the UN-normalised probabilities (operand of P V), sums them in fp32
+        ctx = ((round_bf16(p) @ v) / denom).transpose(0, 2, 1, 3).reshape(B, T, H)
+    else:
+        ctx = ((p / denom) @ v).transpose(0, 2, 1, 3).reshape(B, T, H)
+    return _mm(ctx, w[f"{base}/attention/out_proj/kernel"], "out_proj") + w[f"{base}/attention/out_proj/bias"]
 
 
 def transformer_layer(config, w, i, x, add_mask):
@@ -281,9 +303,9 @@ def transformer_layer(config, w, i, x, add_mask):
     res = x
     if pre:
         x = layer_norm(x, w[f"{base}/final_layer_norm/gamma"], w[f"{base}/final_layer_norm/beta"], eps)
-    x = gelu(_mm(x, w[f"{base}/feed_forward/intermediate_dense/kernel"])
+    x = gelu(_mm(x, w[f"{base}/feed_forward/intermediate_dense/kernel"], "ffn1")
              + w[f"{base}/feed_forward/intermediate_dense/bias"], config.is_gelu_approx)
-    x = _mm(x, w[f"{base}/feed_forward/output_dense/kernel"]) + w[f"{base}/feed_forward/output_dense/bias"]
+    x = _mm(x, w[f"{base}/feed_forward/output_dense/kernel"], "ffn2") + w[f"{base}/feed_forward/output_dense/bias"]
     x = res + x
     if not pre:
         x = layer_norm(x, w[f"{base}/final_layer_norm/gamma"], w[f"{base}/final_layer_norm/beta"], eps)
@@ -340,7 +362,7 @@ def ctc_forward(config, w, wave, attention_mask=None, taps=None, dtype=np.float3
     """Wav2Vec2ForCTC.call at inference (modeling.py:239-255): backbone ->
     (dropout: identity) -> lm_head Dense(H -> vocab).  Returns logits (B,T,V)."""
     h = model_forward(config, w, wave, attention_mask, taps, dtype)
-    return _mm(h, np.asarray(w["lm_head/kernel"], dtype=dtype)) + np.asarray(w["lm_head/bias"], dtype=dtype)
+    return _mm(h, np.asarray(w["lm_head/kernel"], dtype=dtype), "lm_head") + np.asarray(w["lm_head/bias"], dtype=dtype)
 
 
 # --------------------------------------------------------------------------

@@ -1,0 +1,134 @@
+"""The N = 2 data-parallel training step on DEVICE buffers (reference src/main.py:148-156,192,198-200 and
+src/wav2vec2/losses.py:45): two processes share the one GPU of the test box and drive the real `Trainer.step` -- training
+forward, CTC, backward with its per-bucket events, the communication stream, the trainable send ranges, Adam -- on a
+1 + 1 split of a 2-row batch with division_factor = 2.  RCCL refuses two ranks on one device, so the process group is
+`gloo` (device ranges are staged through host memory on the communication stream, wav2vec2/dist.py); everything in front
+of and behind the transport is the code that runs over RCCL on 8 GPUs.
+
+Asserted: the all-reduced gradients of both ranks equal the unsharded 2-row step's (and a whole-buffer all-reduce of the
+local gradients, bit for bit in fp32), frozen slots never travel, and the post-Adam weights equal the unsharded step's.
+"""
+
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import helpers as H
+from wav2vec2 import variables as V
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+L = 4000
+LABELS = np.array([[3, 4, 9, 0], [5, 5, 0, 0]], np.int32)
+CHECK = ["lm_head/kernel", "lm_head/bias", "encoder/layers/1/feed_forward/output_dense/kernel",
+         "encoder/layers/0/attention/q_proj/kernel", "encoder/layers/0/attention/q_proj/bias", "encoder/layer_norm/gamma",
+         "encoder/pos_conv_embed/conv/weight_v", "feature_projection/projection/kernel", "feature_projection/layer_norm/beta"]
+
+
+def _wave():
+    return V.hash_normal("dist_gpu/wave", 2 * L, 4).reshape(2, L)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _make_trainer(rows, payload, overlap):
+    import wav2vec2
+    cfg = H.case_config("tiny_base")
+    m = wav2vec2.Wav2Vec2ForCTC(cfg, input_shape=(rows, L))
+    m.set_weights(H.case_weights("tiny_base"))
+    m.freeze_feature_extractor()                                    # stage 2 of the reference (main.py:234-237)
+    loss = wav2vec2.CTCLoss(cfg, (rows, L), division_factor=2)      # the GLOBAL batch on every replica (losses.py:45)
+    tr = wav2vec2.Trainer(m, loss, learning_rate=1e-3, dropout=0.0, apply_spec_augment=False, seed=5,
+                          allreduce_dtype=payload, overlap_all_reduce=overlap)
+    return m, tr
+
+
+def _rank_main(rank, world, port, out_dir, payload, overlap):
+    for p in (ROOT, os.path.join(ROOT, "gsoc-wav2vec2_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from wav2vec2 import dist as D
+    torch.cuda.set_device(0)                                        # both ranks on the one GPU
+    D.init(backend="gloo")
+    assert D.describe()["world_size"] == 2 and D.describe()["backend"] == "gloo"
+    m, tr = _make_trainer(1, payload, overlap)
+    assert tr.seed == 5 * world + rank                              # per-replica randomness (MirroredStrategy replicas)
+    x, labels = _wave()[rank:rank + 1], LABELS[rank:rank + 1]
+    # -- the pieces of Trainer.step, with a look at the buffer in between
+    logits = tr.forward(x)
+    nll, grad = tr.loss.per_sample(labels, logits, with_grad=True)
+    tr.backward(grad)
+    torch.cuda.synchronize()
+    local = tr.grad_buffer().clone()
+    host = local.cpu()
+    dist.all_reduce(host)                                           # whole-buffer SUM of the local gradients
+    tr.backward(grad)                                               # enqueue the backward again ...
+    tr.all_reduce_gradients()                                       # ... and the per-bucket collectives right behind it
+    torch.cuda.synchronize()
+    reduced = tr.grad_buffer().cpu()
+    ranges = tr.reduce_ranges()
+    sent = torch.zeros(reduced.numel(), dtype=torch.bool)
+    for runs in ranges:
+        for off, n in runs:
+            sent[off:off + n] = True
+    # frozen slots stayed home: untouched local values (zero) there, and the payload is the trainable set
+    assert torch.equal(reduced[~sent], local.cpu()[~sent])
+    trainable = sum(int(np.prod(v.shape)) for v in m.trainable_variables)
+    assert trainable <= int(sent.sum()) < trainable + 4 * len(m.trainable_variables)
+    if payload == "fp32":
+        assert torch.equal(reduced[sent], host[sent]), "bucketed all-reduce != whole-buffer all-reduce"
+    else:
+        scale = float(host[sent].abs().max())
+        assert float((reduced[sent] - host[sent]).abs().max()) < 2e-2 * scale
+    grads = {n: tr.gradient(n) for n in CHECK}
+    tr.apply_gradients()
+    torch.cuda.synchronize()
+    weights = {n: m.get_weights()[n] for n in CHECK}
+    # -- and the step as one call on a fresh replica: same loss contribution, same update
+    m2, tr2 = _make_trainer(1, payload, overlap)
+    loss2 = float(tr2.step(x, labels))
+    w2 = m2.get_weights()
+    for n in CHECK:
+        assert np.array_equal(w2[n], weights[n]), n
+    t = torch.tensor([loss2], dtype=torch.float64)
+    dist.all_reduce(t)                                              # SUM of the per-replica losses = the global loss
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=np.array([float(t)]),
+             **{"g:" + n: g for n, g in grads.items()}, **{"w:" + n: w for n, w in weights.items()})
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("payload,overlap", [("fp32", True), ("bf16", True), ("fp32", False)])
+def test_two_ranks_on_one_gpu_drive_the_real_trainer(tmp_path, payload, overlap):
+    import torch
+    import torch.multiprocessing as mp
+    assert torch.cuda.is_available()
+    mp.spawn(_rank_main, args=(2, _free_port(), str(tmp_path), payload, overlap), nprocs=2, join=True)
+    # the unsharded reference: ONE process, both rows, the same division factor
+    m, tr = _make_trainer(2, "fp32", False)
+    loss = float(tr.step(_wave(), LABELS))
+    want_w = m.get_weights()
+    want_g = {n: tr.gradient(n) for n in CHECK}
+    got = [dict(np.load(tmp_path / f"rank{r}.npz")) for r in range(2)]
+    # (the first Adam step moves an element by ~lr sign(g): an element whose gradient is at the noise level may flip)
+    gtol, wtol = (2e-5, 5e-5) if payload == "fp32" else (2e-2, 2.1e-3)
+    for r in range(2):
+        assert abs(got[r]["loss"][0] - loss) < 1e-5 * abs(loss)
+        for n in CHECK:
+            g, w = got[r]["g:" + n], got[r]["w:" + n]
+            scale = max(1e-6, float(np.abs(want_g[n]).max()))
+            assert np.abs(g - want_g[n]).max() < gtol * scale, (n, float(np.abs(g - want_g[n]).max()), scale)
+            assert np.abs(w - want_w[n]).max() < wtol, (n, float(np.abs(w - want_w[n]).max()))
+    # both replicas hold the same weights after the step (what keeps data-parallel replicas in sync)
+    for n in CHECK:
+        assert np.array_equal(got[0]["w:" + n], got[1]["w:" + n]), n

@@ -357,11 +357,21 @@ def test_tfrecord_file_roundtrip_and_corruption(tmp_path):
 class _FakeLib:
     """Records what would be pushed to the native training state (no GPU here)."""
 
-    def __init__(self):
-        self.flags = {}
+    def __init__(self, names):
+        self.names = list(reversed(names))      # a native inventory order that differs from the host's: flags must follow IT
+        self.flags, self.calls = {}, 0
 
-    def w2v2_set_trainable(self, handle, name, flag):
-        self.flags[name.decode()] = bool(flag)
+    def w2v2_num_params(self, handle):
+        return len(self.names)
+
+    def w2v2_param_info(self, handle, i, name_ref, shape, rank_ref):
+        name_ref._obj.value = self.names[i].encode()
+        return 0
+
+    def w2v2_set_trainable_flags(self, handle, vec, n):
+        assert n == len(self.names)
+        self.flags = {name: bool(vec[i]) for i, name in enumerate(self.names)}
+        self.calls += 1
         return 0
 
 
@@ -371,8 +381,8 @@ def _graph_only_model(cls, config):
     m = object.__new__(cls)
     m.name = "wav2vec2-ctc" if cls._with_lm_head else "wav2vec2"
     m.config = config
-    m._lib, m._handle = _FakeLib(), None
     m._specs = V.variable_specs(config, with_lm_head=cls._with_lm_head)
+    m._lib, m._handle = _FakeLib(list(m._specs)), None
     m._variables = [M.Variable(m, n, s) for n, (s, _) in m._specs.items()]
     m._pushed_trainable = {}
     m._build_layers()
@@ -395,7 +405,7 @@ def test_reference_two_stage_freezing_runs_verbatim_on_the_layer_graph():
     model.layers[0].trainable = False
     assert [v.local_name for v in model.trainable_variables] == ["lm_head/kernel", "lm_head/bias"]
     assert model._lib.flags["masked_spec_embed"] is False and model._lib.flags["encoder/layers/11/attention/q_proj/kernel"] is False
-    assert "lm_head/kernel" not in model._lib.flags                  # never changed: stays trainable natively
+    assert model._lib.flags["lm_head/kernel"] is True and model._lib.calls == 1      # the whole vector, in ONE native call
 
     # ---- STAGE 2, src/main.py:232-237 verbatim ----
     model.trainable = True

@@ -80,10 +80,10 @@ ATOL_BF16_LOGITS = 0.10      # measured (round 2): 0.026-0.050 vs the rounded-op
 
 
 @pytest.mark.parametrize("name", ["tiny_base", "tiny_robust", "base_sample_unpadded", "robust_masked"])
-def test_bf16_precision_logits(torch_mod, name, monkeypatch):
-    monkeypatch.setenv("W2V2_KEEP_ACTIVATIONS", "1")      # the conv taps below: keep the fp32 copies this mode otherwise skips
+def test_bf16_precision_logits(torch_mod, name):
     g = H.golden(name)
     m, cfg = build(name)
+    m.set_option("keep_activations", True)      # the conv taps below: keep the fp32 copies this mode otherwise skips
     w = H.case_weights(name)
     mask = g.get("attention_mask")
     mask = None if mask is None else mask.astype(np.int32)
@@ -132,7 +132,7 @@ def test_bf16_precision_logits(torch_mod, name, monkeypatch):
 @pytest.mark.parametrize("name", ["tiny_robust", "base_sample_unpadded", "robust_masked"])
 def test_bf16_shadows_do_not_change_results(torch_mod, name):
     """The bf16 shadows (activations written by the producing kernels, weights transposed once) hold exactly what
-    the GEMM would round its fp32 operands to, so a forward with W2V2_BF16_SHADOWS=0 gives the same logits and
+    the GEMM would round its fp32 operands to, so a forward with the option "bf16_shadows" off gives the same logits and
     activations bit for bit."""
     g = H.golden(name)
     m, cfg = build(name)
@@ -141,16 +141,14 @@ def test_bf16_shadows_do_not_change_results(torch_mod, name):
     mask = None if mask is None else mask.astype(np.int32)
     taps = [f"conv{i}" for i in range(len(cfg.kernal_sizes))] + ["projection", "encoder_in", "layer0", "encoder_out"]
     res = {}
-    try:
-        os.environ["W2V2_KEEP_ACTIVATIONS"] = "1"
-        for flag in ("0", "1"):
-            os.environ["W2V2_BF16_SHADOWS"] = flag
-            out = m(g["wave"], attention_mask=mask).numpy()
-            res[flag] = {k: m.activation(k) for k in taps}
-            res[flag]["logits"] = out
-    finally:
-        os.environ.pop("W2V2_BF16_SHADOWS", None)
-        os.environ.pop("W2V2_KEEP_ACTIVATIONS", None)
+    m.set_option("keep_activations", True)
+    for flag in ("0", "1"):
+        m.set_option("bf16_shadows", flag == "1")
+        assert m.get_option("bf16_shadows") == (flag == "1")
+        out = m(g["wave"], attention_mask=mask).numpy()
+        res[flag] = {k: m.activation(k) for k in taps}
+        res[flag]["logits"] = out
+    m.set_option("keep_activations", False)
     for k in taps + ["logits"]:
         assert np.array_equal(res["0"][k], res["1"][k]), f"{k}: max diff {H.max_err(res['0'][k], res['1'][k]):.3e}"
     # default in this mode: conv-stack outputs whose only consumer reads the bf16 shadow are written ONLY as bf16 (no fp32
@@ -588,3 +586,63 @@ def test_layers_and_trainable_drive_the_native_training_state(torch_mod):
     assert np.array_equal(g2["lm_head/kernel"], g1["lm_head/kernel"])
     assert np.any(g2["encoder/layers/0/attention/q_proj/kernel"]) and np.any(g2["feature_projection/projection/kernel"])
     assert not any(np.any(a) for n, a in g2.items() if n.startswith("feature_extractor/"))
+
+
+# ---- round 3 additions ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["base", "robust"])
+def test_is_gelu_approx_model_level(torch_mod, kind):
+    """`is_gelu_approx=True` (reference config.py field; feature_extractor.py:58, encoder.py:127,181 pass it to tf.nn.gelu as
+    `approximate`): the whole model on the tanh form -- conv stack, positional conv and FFN -- against the oracle's
+    `approximate` branch, fp32, and it must differ from the exact-GELU model by far more than the tolerance."""
+    import dataclasses
+    import wav2vec2
+    cfg = dataclasses.replace(H.case_config(f"tiny_{kind}"), is_gelu_approx=True)
+    w = V.seeded_weights(cfg, seed=3)
+    x = V.hash_normal("gelu_approx/wave", 2 * 6000, 2).reshape(2, 6000)
+    mask = None
+    if cfg.is_robust:
+        mask = np.ones((2, 6000), np.int32)
+        mask[1, 4500:] = 0
+    m = wav2vec2.Wav2Vec2ForCTC(cfg, input_shape=x.shape)
+    m.set_weights(w)
+    got = m(x, attention_mask=mask).numpy()
+    ref = O.ctc_forward(cfg, w, x, mask)
+    err = H.max_err(got, ref)
+    exact_cfg = dataclasses.replace(cfg, is_gelu_approx=False)
+    gap = H.max_err(ref, O.ctc_forward(exact_cfg, w, x, mask))
+    print(f"tiny_{kind} tanh-GELU: max|hip - oracle| = {err:.3e}; exact-vs-tanh gap {gap:.3e}")
+    report(f"tiny_{kind}/gelu_approx_logits_vs_oracle", err)
+    assert err < H.ATOL_AIM and gap > 20 * err
+    # the bf16x3 mode evaluates the same epilogue function
+    m.set_precision("bf16x3")
+    assert H.max_err(m(x, attention_mask=mask).numpy(), ref) < H.ATOL_AIM
+    m.set_precision("fp32")
+
+
+def test_baseline_batch_fp32_forward_under_pytest(torch_mod):
+    """BASELINE configs[1] as a test, not only as a bench: base, fp32, B = 32 x 246000.  Rows 0-1 are the two waveforms of the
+    committed HF fixture (what bench.py places there), rows 2-31 seeded noise: the golden rows must match HF fp64 at the
+    fp32 bar inside the full batch, the batch must equal the same rows run as a pair bit for bit (a row's result does not
+    depend on its batch), and every row must be finite."""
+    import torch
+    g = H.golden("base_sample_padded")
+    Bn, L = 32, g["wave"].shape[1]
+    assert L == 246000
+    m, cfg = build("base_sample_padded")
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(99)
+    x = torch.randn((Bn, L), generator=gen, device=dev, dtype=torch.float32)
+    x[:2] = torch.from_numpy(g["wave"]).to(dev)
+    out = m(x)
+    assert tuple(out.shape) == (Bn, 768, cfg.vocab_size) and bool(torch.isfinite(out).all())
+    err = H.max_err(out[:2].cpu().numpy(), g["logits_f64"])
+    print(f"B = 32 x 246000: max|logits[:2] - HF fp64| = {err:.3e}")
+    report("base_sample_padded/logits_vs_hf_f64_in_b32_batch", err)
+    assert err < H.ATOL_AIM
+    pair = m(x[:2].contiguous())
+    assert torch.equal(pair, out[:2])
+    tail = m(x[30:].contiguous())
+    assert torch.equal(tail, out[30:])
+    del out, pair, tail, x
+    torch.cuda.empty_cache()

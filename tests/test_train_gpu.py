@@ -351,33 +351,29 @@ def test_bf16_precision_training_step(env, L, frames):
 def test_bf16_training_shadows_do_not_change_results(env):
     """The bf16 shadows of the training forward (LayerNorm / dropout / GEMM / attention producers, (N, K) weight
     shadows) carry exactly the values the GEMMs would round to: logits and every gradient are bit-identical with
-    W2V2_BF16_SHADOWS=0."""
-    import os
+    the model option "bf16_shadows" off."""
     import wav2vec2
     L = 20560
     labels = np.array([[5, 9, 9, 11, 0, 0], [7, 6, 0, 0, 0, 0]], np.int32)
     x = V.hash_normal("train/wave16s", 2 * L, 8).reshape(2, L)
     res = {}
-    try:
-        for flag in ("0", "1"):
-            os.environ["W2V2_BF16_SHADOWS"] = flag
-            m, cfg, w = build("base_sample_padded", L)
-            m.set_precision("bf16")
-            loss_fn = wav2vec2.CTCLoss(cfg, x.shape, division_factor=2)
-            tr = wav2vec2.Trainer(m, loss_fn, dropout=0.1, apply_spec_augment=False, seed=1)
-            logits = tr.forward(x, step_seed=7)
-            nll, dlog = loss_fn.per_sample(labels, logits, with_grad=True)
-            tr.backward(dlog)
-            res[flag] = dict(logits=logits.cpu().numpy(),
-                             grads={n: tr.gradient(n) for n in ("lm_head/kernel", "encoder/layers/11/feed_forward/output_dense/kernel",
-                                                                "encoder/layers/0/attention/q_proj/kernel",
-                                                                "feature_projection/projection/kernel", "encoder/layer_norm/gamma")},
-                             biases={n: tr.gradient(n) for n in ("encoder/layers/11/feed_forward/output_dense/bias",
-                                                                 "encoder/layers/3/feed_forward/intermediate_dense/bias",
-                                                                 "encoder/layers/0/attention/q_proj/bias",
-                                                                 "encoder/layers/5/attention/out_proj/bias")})
-    finally:
-        os.environ.pop("W2V2_BF16_SHADOWS", None)
+    for flag in ("0", "1"):
+        m, cfg, w = build("base_sample_padded", L)
+        m.set_precision("bf16")
+        m.set_option("bf16_shadows", flag == "1")
+        loss_fn = wav2vec2.CTCLoss(cfg, x.shape, division_factor=2)
+        tr = wav2vec2.Trainer(m, loss_fn, dropout=0.1, apply_spec_augment=False, seed=1)
+        logits = tr.forward(x, step_seed=7)
+        nll, dlog = loss_fn.per_sample(labels, logits, with_grad=True)
+        tr.backward(dlog)
+        res[flag] = dict(logits=logits.cpu().numpy(),
+                         grads={n: tr.gradient(n) for n in ("lm_head/kernel", "encoder/layers/11/feed_forward/output_dense/kernel",
+                                                            "encoder/layers/0/attention/q_proj/kernel",
+                                                            "feature_projection/projection/kernel", "encoder/layer_norm/gamma")},
+                         biases={n: tr.gradient(n) for n in ("encoder/layers/11/feed_forward/output_dense/bias",
+                                                             "encoder/layers/3/feed_forward/intermediate_dense/bias",
+                                                             "encoder/layers/0/attention/q_proj/bias",
+                                                             "encoder/layers/5/attention/out_proj/bias")})
     assert np.array_equal(res["0"]["logits"], res["1"]["logits"])
     for n, g in res["0"]["grads"].items():
         assert np.array_equal(g, res["1"]["grads"][n]), n

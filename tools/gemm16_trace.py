@@ -1,0 +1,80 @@
+#!/usr/bin/env python
+"""Per-block phase trace of the shadow-fed bf16 GEMM (tools-only build: `python gsoc-wav2vec2_amd/build.py --tuning`).
+
+    W2V2_NATIVE_LIB=gsoc-wav2vec2_amd/lib/libw2v2_tuning.so python tools/gemm16_trace.py [shape ...]
+
+For each base-model shape at B = 32 it launches the GEMM with the operands / outputs the forward uses (q|k|v: bf16 output only;
+out-projection / FFN down: fp32 output + residual; FFN up: GELU, bf16 only), once timed without the trace and once with it, and
+prints where a block's cycles go: entry -> first tile landed, every k step, last MFMA block, epilogue until its stores retire;
+plus how many blocks a CU ran and the spread of their start times."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gsoc-wav2vec2_amd"))
+os.environ.setdefault("W2V2_NATIVE_LIB", os.path.join(ROOT, "gsoc-wav2vec2_amd", "lib", "libw2v2_tuning.so"))
+import ctypes as C
+import numpy as np
+import torch
+from wav2vec2 import _native as N
+
+lib = N.load()
+P, I32, I64 = C.c_void_p, C.c_int32, C.c_int64
+lib.w2v2_tune_gemm16.restype = C.c_int
+lib.w2v2_tune_gemm16.argtypes = [P, I64, I64, P, P, P, I64, I64, P, P, I32, I32, I32, I32, I32, P]
+lib.w2v2_tune_set_trace.restype = C.c_int
+lib.w2v2_tune_set_trace.argtypes = [P]
+dev = torch.device("cuda:0")
+B = int(os.environ.get("TRACE_BATCH", 32)); BT = B * 768
+# name: M, N, K, lda, strideA, nbatch, act, fp32 out, bf16 out, residual
+SHAPES = {"qkv": (BT, 2304, 768, 768, 0, 1, 0, False, True, False), "out": (BT, 768, 768, 768, 0, 1, 0, True, False, True),
+          "ffn1": (BT, 3072, 768, 768, 0, 1, 1, False, True, False), "ffn2": (BT, 768, 3072, 3072, 0, 1, 0, True, False, True),
+          "conv1": (24599, 512, 1536, 1024, 49199 * 512, B, 1, False, True, False),
+          "conv4": (3074, 512, 1536, 1024, 6149 * 512, B, 1, False, True, False)}
+names = sys.argv[1:] or ["qkv", "out", "ffn1", "ffn2", "conv1"]
+for name in names:
+    M, Nn, K, lda, sA, nb, act, f32o, b16o, res = SHAPES[name]
+    a_elems = (nb - 1) * sA + (M - 1) * lda + K if sA else M * lda
+    A16 = torch.randn(a_elems, device=dev).to(torch.bfloat16)
+    B16 = (torch.randn(Nn, K, device=dev) * 0.05).to(torch.bfloat16)
+    Cf = torch.empty(nb * M * Nn, device=dev) if f32o else None
+    Ch = torch.empty(nb * M * Nn, device=dev, dtype=torch.bfloat16) if b16o else None
+    bias = torch.randn(Nn, device=dev)
+    R = torch.randn(nb * M * Nn, device=dev) if res else None
+    st = N.current_stream()
+
+    def run():
+        N.check(lib.w2v2_tune_gemm16(N.ptr(A16), lda, sA, N.ptr(B16), N.ptr(Cf), N.ptr(Ch), Nn, M * Nn, N.ptr(bias), N.ptr(R), M, Nn, K, nb, act, st))
+    lib.w2v2_tune_set_trace(None)
+    for _ in range(3): run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): run()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    tiles = ((M + 127) // 128) * ((Nn + 127) // 128) * nb
+    tr = torch.zeros(tiles * 32, dtype=torch.int64, device=dev)
+    lib.w2v2_tune_set_trace(tr.data_ptr())
+    e0.record(); run(); e1.record(); torch.cuda.synchronize()
+    ms_tr = e0.elapsed_time(e1)
+    lib.w2v2_tune_set_trace(None)
+    t = tr.cpu().numpy().reshape(tiles, 32)
+    cnt = int(t[0, 31]); nk = K // 64
+    assert cnt == 2 + 1 + 1 + (nk - 1) + 1 + 1, (cnt, nk)
+    clk = t[:, 2:cnt].astype(np.float64)
+    d = np.diff(clk, axis=1)            # [prologue, k-step 0 .. nk-2, last compute, epilogue]
+    q = lambda v: "%7.0f %7.0f %7.0f" % tuple(np.percentile(v, [10, 50, 90]))
+    total = clk[:, -1] - clk[:, 0]
+    print(f"== {name}: M={M} N={Nn} K={K} batch={nb}: {ms:.4f} ms = {2.0 * M * Nn * K * nb / ms / 1e9:.0f} TF (traced launch {ms_tr:.4f} ms); {tiles} tiles, {nk} k-steps")
+    print(f"   cycles per block (p10 / p50 / p90):  total {q(total)}")
+    print(f"   entry -> first tile landed          {q(d[:, 0])}")
+    steps = d[:, 1:nk]
+    print(f"   one k step (all steps pooled)       {q(steps.reshape(-1))}    sum over the loop {q(steps.sum(axis=1))}")
+    print(f"   per-step medians: " + " ".join("%.0f" % v for v in np.median(steps, axis=0)))
+    print(f"   last MFMA block                     {q(d[:, nk])}")
+    print(f"   epilogue until stores retired       {q(d[:, nk + 1])}")
+    hw = t[:, 0]
+    cu_key = ((hw >> 32) << 16) | ((hw & 0xFFFFFFFF) >> 8 & 0xF) | (((hw & 0xFFFFFFFF) >> 13 & 0x7) << 4) | (((hw & 0xFFFFFFFF) >> 12 & 1) << 7)
+    uniq, per_cu = np.unique(cu_key, return_counts=True)
+    wall = t[:, 1].astype(np.float64) * 10.0      # ns (100 MHz)
+    print(f"   {len(uniq)} distinct (xcc, se, sh, cu) ids; blocks per CU min / median / max {per_cu.min()} / {int(np.median(per_cu))} / {per_cu.max()}; "
+          f"block starts span {(wall.max() - wall.min()) / 1e3:.1f} us; ideal MFMA cycles per tile {nk * 8 * 32 * 2}")

@@ -13,7 +13,7 @@ mask = g.get("attention_mask"); mask = None if mask is None else mask.astype(np.
 taps = [f"conv{i}" for i in range(7)] + ["projection", "encoder_in"] + [f"layer{i}" for i in range(cfg.num_layers)]
 res = {}
 for flag in ("0", "1"):
-    os.environ["W2V2_BF16_SHADOWS"] = flag
+    m.set_option("bf16_shadows", flag == "1"); m.set_option("keep_activations", True)
     out = m(g["wave"], attention_mask=mask).numpy()
     res[flag] = {k: m.activation(k) for k in taps}
     res[flag]["logits"] = out
