@@ -156,6 +156,11 @@ struct GemmShadows {
     // it are read as zero.  0 = K * nbatch.  Lets dW = X^T dY run over B T = 23984 rows (T = 1499) without a leftover-row pass.
     int64_t validK = 0;
 };
+// 256 x 256 ping-pong form of the shadow-fed bf16 GEMM (gemm_bf16_pp.hip): same arithmetic, identical bits, for the large shapes
+bool gemm_bf16_pp_ok(int M, int N, int K, int64_t lda, int64_t ldb16, int64_t strideA);
+int launch_gemm_bf16_pp(const uint16_t* A16, int64_t lda, int64_t strideA, const uint16_t* B16, int64_t ldb16, float* C, uint16_t* C16,
+                        int64_t ldc, int64_t strideC, const float* bias, const float* residual, int M, int N, int K, int nbatch, int act,
+                        hipStream_t s);
 int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
                        int64_t strideB, float* C, int64_t ldc, int64_t strideC, const float* bias,
                        const float* residual, int M, int N, int K, int nbatch, int act, const GemmShadows& x,

@@ -872,6 +872,16 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
         g.epi.pre = t.pre; g.epi.u = t.u; g.epi.colpart = t.colpart;
         return t.mode == 1 ? launch_src16<5, 128, 128, 2, 4, 2, 1>(g, nbatch, s) : launch_src16<5, 128, 128, 2, 4, 2, 2>(g, nbatch, s);
     }
+    // large shapes, both operands from shadows: 256 x 256 tiles, two wave groups in ping-pong, half-tile ring (gemm_bf16_pp.hip).
+    // Same bits.  Taken when the tile count fills the 256 CUs without a badly underfilled last round (tuning build:
+    // W2V2_GEMM16_PP = 0 never, 2 whenever the operands allow it).
+    if (src == 5 && x.zmod == 0 && gemm_bf16_pp_ok(M, N, K, lda, g.ldb16, strideA)) {
+        const int pp = tune_int("W2V2_GEMM16_PP", 1);
+        const int64_t tiles = (int64_t)((M + 255) / 256) * ((N + 255) / 256) * nbatch;
+        const double fill = (double)tiles / (double)(((tiles + 255) / 256) * 256);      // how full the rounds of 256 blocks are
+        if (pp == 2 || (pp == 1 && N >= 256 && tiles >= 256 && fill >= 0.8))
+            return launch_gemm_bf16_pp(x.A16, lda, strideA, x.B16, g.ldb16, C, x.C16, ldc, strideC, bias, residual, M, N, K, nbatch, act, s);
+    }
     if (cfg == 2 && src == 1) return launch_src16<1, 256, 256, 2, 4, 1>(g, nbatch, s);   // tile study: 8 waves of 128x64
     if (N <= 64 && src == 5) return launch_src16<5, 128, 64, 2, 2, 2>(g, nbatch, s);     // narrow outputs (grouped conv: 48 | 64 columns)
     if (N <= 64 && src == 7) return launch_src16<7, 128, 64, 2, 2, 2>(g, nbatch, s);

@@ -59,6 +59,23 @@ for name in names:
     lib.w2v2_tune_set_trace(None)
     t = tr.cpu().numpy().reshape(tiles, 32)
     cnt = int(t[0, 31]); nk = K // 64
+    if cnt == 7:          # gemm_bf16_pp_kernel: entry, items 0-1 landed, end of the steady loop, end of the last two K tiles, stores retired
+        tiles = ((M + 255) // 256) * ((Nn + 255) // 256) * nb
+        t = t[:tiles]
+        clk = t[:, 2:7].astype(np.float64); d = np.diff(clk, axis=1)
+        q = lambda v: "%7.0f %7.0f %7.0f" % tuple(np.percentile(v, [10, 50, 90]))
+        print(f"== {name} [256x256 ping-pong]: M={M} N={Nn} K={K} batch={nb}: {ms:.4f} ms = {2.0 * M * Nn * K * nb / ms / 1e9:.0f} TF (traced launch {ms_tr:.4f} ms); {tiles} tiles, {nk} K tiles")
+        print(f"   cycles per block (p10 / p50 / p90):  total {q(clk[:, -1] - clk[:, 0])}")
+        print(f"   entry -> first two half-tiles landed {q(d[:, 0])}")
+        print(f"   steady loop ({nk - 2} K tiles)           {q(d[:, 1])}    per K tile {q(d[:, 1] / max(1, nk - 2))}   (ideal 2048)")
+        print(f"   last two K tiles                    {q(d[:, 2])}")
+        print(f"   epilogue until stores retired       {q(d[:, 3])}")
+        hw = t[:, 0]
+        cu_key = ((hw >> 32) << 16) | ((hw & 0xFFFFFFFF) >> 8 & 0xF) | (((hw & 0xFFFFFFFF) >> 13 & 0x7) << 4) | (((hw & 0xFFFFFFFF) >> 12 & 1) << 7)
+        uniq, per_cu = np.unique(cu_key, return_counts=True)
+        wall = t[:, 1].astype(np.float64) * 10.0
+        print(f"   {len(uniq)} distinct CU ids; blocks per CU min / median / max {per_cu.min()} / {int(np.median(per_cu))} / {per_cu.max()}; block starts span {(wall.max() - wall.min()) / 1e3:.1f} us")
+        continue
     assert cnt == 2 + 1 + 1 + (nk - 1) + 1 + 1, (cnt, nk)
     clk = t[:, 2:cnt].astype(np.float64)
     d = np.diff(clk, axis=1)            # [prologue, k-step 0 .. nk-2, last compute, epilogue]
