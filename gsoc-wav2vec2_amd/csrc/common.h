@@ -155,12 +155,14 @@ struct GemmShadows {
     // (that form only) the K dimension really has validK rows over all batches, K * nbatch >= validK > K * (nbatch - 1): rows past
     // it are read as zero.  0 = K * nbatch.  Lets dW = X^T dY run over B T = 23984 rows (T = 1499) without a leftover-row pass.
     int64_t validK = 0;
+    int force_kernel = 0;        // forward form with both shadows: 0 = by shape, 1 = the 128 x 128 kernel, 2 = the 128 x 256 software-pipelined one
 };
-// 256 x 256 ping-pong form of the shadow-fed bf16 GEMM (gemm_bf16_pp.hip): same arithmetic, identical bits, for the large shapes
-bool gemm_bf16_pp_ok(int M, int N, int K, int64_t lda, int64_t ldb16, int64_t strideA);
-int launch_gemm_bf16_pp(const uint16_t* A16, int64_t lda, int64_t strideA, const uint16_t* B16, int64_t ldb16, float* C, uint16_t* C16,
+// 128 x 256 software-pipelined form, two 4-wave blocks per CU (gemm_bf16_sw.hip): same arithmetic, identical bits
+bool gemm_bf16_sw_ok(int M, int N, int K, int64_t lda, int64_t ldb16, int64_t strideA);
+struct GemmTrainEpiDev;      // gemm_epilogue.h
+int launch_gemm_bf16_sw(const uint16_t* A16, int64_t lda, int64_t strideA, const uint16_t* B16, int64_t ldb16, float* C, uint16_t* C16,
                         int64_t ldc, int64_t strideC, const float* bias, const float* residual, int M, int N, int K, int nbatch, int act,
-                        hipStream_t s);
+                        hipStream_t s, const GemmTrainEpiDev* epi = nullptr);
 int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
                        int64_t strideB, float* C, int64_t ldc, int64_t strideC, const float* bias,
                        const float* residual, int M, int N, int K, int nbatch, int act, const GemmShadows& x,

@@ -774,6 +774,18 @@ unsigned long long* g_tune_trace = nullptr;      // set by w2v2_tune_set_trace (
 namespace {
 #endif
 
+// Which shadow-fed shapes take the 128 x 256 software-pipelined kernel (measured at B = 32, profiles/r03_gemm_bf16_study.md: it wins
+// 15-25 % on every model shape with N K >= 512 x 1024 and ties on the two smaller ones): whole 256-column tiles, at least 256 of
+// them (half of the chip's 512 block slots), a weight matrix of at least 512 K elements.  GemmShadows::force_kernel overrides
+// (1 = never, 2 = whenever the operands allow it: the op-level parity tests compare the two kernels bit for bit).
+bool use_sw_kernel(const GemmShadows& x, int M, int N, int K, int64_t lda, int64_t ldb16, int64_t strideA, int nbatch) {
+    if (x.zmod != 0 || x.force_kernel == 1 || !gemm_bf16_sw_ok(M, N, K, lda, ldb16, strideA)) return false;
+    if (x.force_kernel == 2) return true;
+    if (tune_int("W2V2_GEMM16_SW", 1) == 0) return false;
+    const int64_t tiles = (int64_t)((M + 127) / 128) * (N / 256) * nbatch;
+    return tiles >= 256 && (int64_t)N * K >= 512 * 1024;
+}
+
 int forced_cfg16() {
     return tune_int("W2V2_GEMM16_CFG", -1);
 }
@@ -870,18 +882,17 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
         g.epi.mode = t.mode; g.epi.act = t.act; g.epi.inv = t.p > 0.f ? 1.0f / (1.0f - t.p) : 1.0f;
         g.epi.key = host_dropout_key(t.seed, t.stream); g.epi.thr1 = (uint32_t)((double)t.p * 65536.0) - 1u;
         g.epi.pre = t.pre; g.epi.u = t.u; g.epi.colpart = t.colpart;
+        // (the 128 x 256 kernel has these instances too, but with 128 outputs per lane and two waves per SIMD the tails' scattered
+        //  fp32 reads of u and their hash / GELU' chains are exposed: 513 vs 325 us for the FFN data-gradient tail, 278 vs 251 for
+        //  the forward one -- profiles/r03_gemm_bf16_study.md; they are taken only when forced)
+        if (x.force_kernel == 2 && use_sw_kernel(x, M, N, K, lda, g.ldb16, strideA, nbatch))
+            return launch_gemm_bf16_sw(x.A16, lda, strideA, x.B16, g.ldb16, C, x.C16, ldc, strideC, bias, residual, M, N, K, nbatch, 0, s, &g.epi);
         return t.mode == 1 ? launch_src16<5, 128, 128, 2, 4, 2, 1>(g, nbatch, s) : launch_src16<5, 128, 128, 2, 4, 2, 2>(g, nbatch, s);
     }
-    // large shapes, both operands from shadows: 256 x 256 tiles, two wave groups in ping-pong, half-tile ring (gemm_bf16_pp.hip).
-    // Same bits.  Taken when the tile count fills the 256 CUs without a badly underfilled last round (tuning build:
-    // W2V2_GEMM16_PP = 0 never, 2 whenever the operands allow it).
-    if (src == 5 && x.zmod == 0 && gemm_bf16_pp_ok(M, N, K, lda, g.ldb16, strideA)) {
-        const int pp = tune_int("W2V2_GEMM16_PP", 1);
-        const int64_t tiles = (int64_t)((M + 255) / 256) * ((N + 255) / 256) * nbatch;
-        const double fill = (double)tiles / (double)(((tiles + 255) / 256) * 256);      // how full the rounds of 256 blocks are
-        if (pp == 2 || (pp == 1 && N >= 256 && tiles >= 256 && fill >= 0.8))
-            return launch_gemm_bf16_pp(x.A16, lda, strideA, x.B16, g.ldb16, C, x.C16, ldc, strideC, bias, residual, M, N, K, nbatch, act, s);
-    }
+    // both operands from shadows, enough tiles to fill the chip: 128 x 256 tiles, 4-wave software-pipelined blocks, two per CU
+    // (gemm_bf16_sw.hip).  Same bits as the kernels below.
+    if (src == 5 && use_sw_kernel(x, M, N, K, lda, g.ldb16, strideA, nbatch))
+        return launch_gemm_bf16_sw(x.A16, lda, strideA, x.B16, g.ldb16, C, x.C16, ldc, strideC, bias, residual, M, N, K, nbatch, act, s);
     if (cfg == 2 && src == 1) return launch_src16<1, 256, 256, 2, 4, 1>(g, nbatch, s);   // tile study: 8 waves of 128x64
     if (N <= 64 && src == 5) return launch_src16<5, 128, 64, 2, 2, 2>(g, nbatch, s);     // narrow outputs (grouped conv: 48 | 64 columns)
     if (N <= 64 && src == 7) return launch_src16<7, 128, 64, 2, 2, 2>(g, nbatch, s);

@@ -1,0 +1,483 @@
+// bf16 GEMM, 128 x 256 x 64 tiles, FOUR waves per block and TWO blocks per CU, every wave software-pipelined: the LDS reads of
+// the next quadrant's operands and the LDS-DMA of the stream ten 8-KiB items ahead are issued between the MFMAs of the current
+// quadrant.
+//
+// Why (profiles/r03_gemm_bf16_study.md): the 256 x 256 ping-pong kernel (gemm_bf16_pp.hip) runs its K loop at ~1.7 PF, but with
+// K = 512 ... 1536 a tile is only 8 ... 24 K tiles long and its prologue (3 k cycles) and epilogue (10 k cycles for a bf16-only
+// store, 16 k with GELU: ~20 VALU ops per output) run with the matrix pipe idle -- one block per CU, both waves of a SIMD in the
+// same tile.  Two independent blocks per CU put the epilogue of one under the K loop of the other, which needs (a) half the LDS
+// and registers per block: 4 waves of 128 x 64 outputs (128 accumulator VGPRs, 256 per wave at 2 waves / SIMD) and an 80-KiB
+// operand ring, and (b) a wave that keeps the matrix pipe busy ON ITS OWN while its neighbour is in an epilogue -- no load segment
+// that waits for a partner's MFMAs, but reads and DMA issue threaded through its own MFMA stream.
+//
+// Stream: per K tile six items of 8 KiB (64 image rows x 128 B) in the order they are read: A_0 | B_0a B_0b | B_1a B_1b | A_1
+// (A_i = rows 64 i .. 64 i + 63 of the tile; B_j = columns 64 w + 32 j .. + 31 of every wave w, halves a / b = waves 0-1 / 2-3).
+// Item s lives in ring slot s mod 10; it is requested as soon as item s - 10 has been read.  Quadrant order per K tile
+// (0,0) (0,1) (1,1) (1,0): each quadrant's MFMAs free exactly the registers the reads issued beside them refill (B_1 | A_1 |
+// next A_0 | next B_0, the last one k-step by k-step behind the MFMAs that consume the old values).
+// A phase = s_waitcnt vmcnt(N_q) + lgkmcnt(0) / s_barrier (4 waves) / DMA issue / 8 MFMAs with 4 or 8 ds_read_b128 between them.
+//
+// Same arithmetic as gemm_bf16_kernel (k ascending in 16-deep MFMA steps, same lane -> k assignment): identical bits.
+#include "common.h"
+#include "gemm_epilogue.h"
+
+namespace w2v2 {
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+constexpr int SW_BM = 128, SW_BN = 256, SW_BK = 64;
+constexpr int SW_ITEM = 8192, SW_SLOTS = 10, SW_LDS = SW_SLOTS * SW_ITEM;      // 80 KiB: two blocks per CU
+
+struct GemmSWArgs {
+    const uint16_t* A16;
+    const uint16_t* B16;       // (N, K) rows ldb16 apart
+    float* C;
+    uint16_t* C16;
+    const float* bias;
+    const float* residual;
+    int64_t lda, ldb16, ldc, strideA, strideC;
+    int M, N, K, act;
+    int tiles_m, tiles_n;
+    GemmTrainEpiDev epi;       // training epilogue (EPI instances only)
+#ifdef W2V2_TUNING
+    unsigned long long* trace;
+    int abl;
+#endif
+};
+
+__device__ __forceinline__ int sw_swz(int row) { return ((row >> 1) & 7) ^ ((row >> 4) & 1); }      // = gemm_bf16.hip's swz
+
+template <int OFF>
+__device__ __forceinline__ bf16x8 sw_read(unsigned addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+
+// one 1-KiB LDS-DMA piece: lanes fetch 16 B each from base + off (saddr form: scalar 64-bit base, 32-bit per-lane offset)
+// into LDS bytes [dst, dst + 1024).  M0 is written in the statement that uses it (the compiler does not preserve it for asm);
+// s_nop 0: one wait state between the SALU write of M0 and the LDS-DMA that reads it (the bases are SALU-computed from values
+// made uniform at kernel entry, long before any DMA).
+__device__ __forceinline__ void sw_dma(unsigned lds_dst, uint32_t off, const unsigned char* base) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(off), "s"(base) : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void sw_wait_vm() {
+    if constexpr (N >= 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int V>
+using IC = std::integral_constant<int, V>;
+
+// ---- bf16-only epilogue through LDS (see gemm_bf16_pp.hip: column-major image, ds_write_b64, transposing reads, 16-byte stores)
+__device__ __forceinline__ unsigned sw_cswz(int c) { return (unsigned)(((c & 3) << 2) | ((c >> 2) & 3)); }
+
+template <int ACT>
+__device__ __forceinline__ void sw_epilogue_bf16(const f32x16 (&acc)[4][2], uint16_t* __restrict__ C16, const float* __restrict__ bias, int ldc,
+                                                 unsigned wbase, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    const unsigned pre_w = ((sw_cswz(li) ^ (unsigned)lh) << 3);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const float bv = bias ? bias[nt * 32 + li] : 0.0f;
+        const unsigned colbase = wbase + (unsigned)(nt * 32 + li) * 256u;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            f32x16 v = acc[mt][nt];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += bv;
+            if constexpr (ACT == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2_t t = gelu_erf_fast2(f32x2_t{v[r], v[r + 1]});
+                    v[r] = t[0];
+                    v[r + 1] = t[1];
+                }
+            } else if constexpr (ACT == 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = gelu_tanh(v[r]);
+            }
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                u32x2 w;
+                w[0] = pack_bf16_rne(v[4 * gq], v[4 * gq + 1]);
+                w[1] = pack_bf16_rne(v[4 * gq + 2], v[4 * gq + 3]);
+                const unsigned a = colbase + ((unsigned)((mt * 8 + 2 * gq) << 3) ^ pre_w);
+                asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(w) : "memory");
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int q = lane >> 4, l = lane & 15;
+    const int cA = 8 * q + (l >> 2);
+    const unsigned rdA = wbase + (unsigned)cA * 256u, preA = ((unsigned)(l & 3) ^ sw_cswz(cA)) << 3;
+    const unsigned rdB = rdA + 4u * 256u, preB = ((unsigned)(l & 3) ^ sw_cswz(cA + 4)) << 3;
+    u32x2 lo[16], hi[16];
+    uint16_t* const dst = C16 + (int64_t)l * ldc + 8 * q;
+#define SW_RD4(G)                                                                                                            \
+    _Pragma("unroll") for (int t = 4 * (G); t < 4 * (G) + 4; ++t) {                                                          \
+        const unsigned R = (unsigned)(t >> 1), Hc = (unsigned)(t & 1);                                                       \
+        const unsigned a1 = rdA + Hc * 8192u + ((32u * R) ^ preA), a2 = rdB + Hc * 8192u + ((32u * R) ^ preB);               \
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[t]) : "v"(a1));                                                   \
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi[t]) : "v"(a2));                                                   \
+    }
+#define SW_ST4(G, WAIT)                                                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(%8)"                                                                                     \
+                 : "+v"(lo[4 * (G)]), "+v"(hi[4 * (G)]), "+v"(lo[4 * (G) + 1]), "+v"(hi[4 * (G) + 1]), "+v"(lo[4 * (G) + 2]),   \
+                   "+v"(hi[4 * (G) + 2]), "+v"(lo[4 * (G) + 3]), "+v"(hi[4 * (G) + 3])                                       \
+                 : "n"(WAIT));                                                                                               \
+    _Pragma("unroll") for (int t = 4 * (G); t < 4 * (G) + 4; ++t) {                                                          \
+        u32x4 o;                                                                                                             \
+        o[0] = lo[t][0]; o[1] = lo[t][1]; o[2] = hi[t][0]; o[3] = hi[t][1];                                                  \
+        *reinterpret_cast<u32x4*>(dst + (int64_t)(16 * (t >> 1)) * ldc + 32 * (t & 1)) = o;                                  \
+    }
+    SW_RD4(0)
+    SW_RD4(1)
+    SW_ST4(0, 8)
+    SW_RD4(2)
+    SW_ST4(1, 8)
+    SW_RD4(3)
+    SW_ST4(2, 8)
+    SW_ST4(3, 0)
+#undef SW_RD4
+#undef SW_ST4
+}
+
+template <bool TRACE, bool PRIO = true, int EPI = 0>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_sw_kernel(GemmSWArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sw_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = wc: the wave's 64-column group
+    const int li = lane & 31, lh = lane >> 5;
+
+    // XCD-aware tile order (gemm_f32.hip): each XCD walks a contiguous run of tiles, N fastest
+    const int nwg = g.tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
+    const int m0 = tm * SW_BM, n0 = tn * SW_BN;
+    const int z = blockIdx.z;
+    const int nk = g.K / SW_BK;
+#ifdef W2V2_TUNING
+    unsigned long long* const trc = (TRACE && g.trace) ? g.trace + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 32 : nullptr;
+    int trc_n = 2;
+    if (TRACE && trc && tid == 0) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        trc[0] = ((unsigned long long)xcc << 32) | hwid;
+        trc[1] = wall_clock64();
+        trc[trc_n++] = clock64();
+    }
+#define SW_TRC() do { if (TRACE && trc && tid == 0 && trc_n < 31) trc[trc_n++] = clock64(); } while (0)
+#else
+#define SW_TRC() do { } while (0)
+#endif
+
+    // ---- LDS-DMA sources.  An item is 64 image rows = 8 pieces of 1 KiB, two per wave: piece pc = image rows 8 pc .. 8 pc + 7,
+    // the lane at physical slot (lane & 7) of image row r fetches logical slot (lane & 7) ^ swz(r).  Per-lane byte offsets from a
+    // scalar base: A per half (rows clamped to the matrix, so a ragged last row tile re-reads row M - 1), B once (whole column tiles:
+    // the two halves and two column groups of B are scalar offsets of the base).
+    uint32_t offA[2][2], offB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wave * 2 + i) * 8 + (lane >> 3);                       // image row 0 .. 63
+        const uint32_t sl = (uint32_t)(((lane & 7) ^ sw_swz(r)) << 3);        // logical slot, in elements
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int ar = h * 64 + r;
+            ar = m0 + ar < g.M ? ar : g.M - 1 - m0;
+            offA[h][i] = 2u * ((uint32_t)((int64_t)ar * g.lda) + sl);
+        }
+        const int bc = (r >> 5) * 64 + (r & 31);                              // column of B_0a's image row r (B_1: + 32, half b: + 128)
+        offB[i] = 2u * ((uint32_t)((int64_t)bc * g.ldb16) + sl);
+    }
+    auto uniform_ptr = [](const uint16_t* p) {
+        const uint64_t v = reinterpret_cast<uint64_t>(p);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return reinterpret_cast<const unsigned char*>(((uint64_t)hi << 32) | lo);
+    };
+    const unsigned char* const baseA = uniform_ptr(g.A16 + (int64_t)z * g.strideA + (int64_t)m0 * g.lda);
+    const unsigned char* const baseB = uniform_ptr(g.B16 + (int64_t)n0 * g.ldb16);
+    const int64_t bstep32 = 64 * g.ldb16, bstep128 = 256 * g.ldb16;           // bytes: 32 / 128 columns of B
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)sw_smem;
+
+    // piece I (0 | 1) of this wave's share of stream item J (= item number mod 6) of K tile `ktile`, into ring slot `slot`
+    auto issue_piece = [&](auto Jc, auto Ic, int ktile, int slot) {
+        constexpr int J = decltype(Jc)::value, I = decltype(Ic)::value;
+        const unsigned dst = lds0 + (unsigned)slot * SW_ITEM + (unsigned)wave * 2048u + (unsigned)I * 1024u;
+        if constexpr (J == 0 || J == 5) {
+            sw_dma(dst, offA[J == 0 ? 0 : 1][I], baseA + (int64_t)ktile * (SW_BK * 2));
+        } else {
+            constexpr int HALF = (J == 2 || J == 4) ? 1 : 0, JB = (J >= 3) ? 1 : 0;      // waves 2-3 | columns + 32
+            sw_dma(dst, offB[I], baseB + (int64_t)ktile * (SW_BK * 2) + HALF * bstep128 + JB * bstep32);
+        }
+    };
+    auto issue = [&](auto Jc, int ktile, int slot) {
+        issue_piece(Jc, IC<0>{}, ktile, slot);
+        issue_piece(Jc, IC<1>{}, ktile, slot);
+    };
+
+    // ---- fragment reads.  Image row rho = 32 rb + li (A) or 32 (wave & 1) + li (B): swz(rho) = swz(li) for both, so one pair
+    // (x, y) serves every read: address = slot base + x + ((32 ks) ^ y) [+ 4096 for the second 32 rows].
+    const unsigned x0 = lds0 + (unsigned)li * 128u + 16u * (unsigned)(lh ^ (sw_swz(li) & 1)), y0 = (unsigned)(sw_swz(li) & 6) * 16u;
+    unsigned xk[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) xk[ks] = x0 + ((32u * ks) ^ y0);
+    const unsigned bwave = (unsigned)(wave & 1) * 4096u;           // this wave's 32 rows inside its B item
+
+    bf16x8 fa[2][2][4];      // [i: 64-row half][rb: 32-row block][ks]
+    bf16x8 fb[2][4];         // [j: 32-column half][ks]
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 zero = {};
+        fa[0][0][ks] = fa[0][1][ks] = fa[1][0][ks] = fa[1][1][ks] = fb[0][ks] = fb[1][ks] = zero;
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // ring bookkeeping (scalar): s0 = slot of item 6 kt (the K tile's A_0); slot of item 6 kt + j = (s0 + j) mod 10
+    auto slot_of = [](int s0, int j) { const int s = s0 + j; return s >= SW_SLOTS ? s - SW_SLOTS : s; };
+    auto rd_a = [&](auto Ic, auto KSc, int slot) {          // A_I, k step KS: both 32-row blocks
+        constexpr int I = decltype(Ic)::value, KS = decltype(KSc)::value;
+        const unsigned a = xk[KS] + (unsigned)slot * SW_ITEM;
+        fa[I][0][KS] = sw_read<0>(a);
+        fa[I][1][KS] = sw_read<4096>(a);
+    };
+    auto rd_b = [&](auto Jc, auto KSc, int slot) {          // B_J, k step KS (slot = this wave's half a | b)
+        constexpr int J = decltype(Jc)::value, KS = decltype(KSc)::value;
+        fb[J][KS] = sw_read<0>(xk[KS] + (unsigned)slot * SW_ITEM + bwave);
+    };
+    auto mm = [&](auto QIc, auto QJc, auto KSc) {
+        constexpr int QI = decltype(QIc)::value, QJ = decltype(QJc)::value, KS = decltype(KSc)::value;
+        acc[QI * 2][QJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[QI][0][KS], fb[QJ][KS], acc[QI * 2][QJ], 0, 0, 0);
+        acc[QI * 2 + 1][QJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[QI][1][KS], fb[QJ][KS], acc[QI * 2 + 1][QJ], 0, 0, 0);
+    };
+#define SW_TIE_ALL()                                                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                                           \
+                 : "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fa[0][0][2]), "+v"(fa[0][0][3]), "+v"(fa[0][1][0]), "+v"(fa[0][1][1]),  \
+                   "+v"(fa[0][1][2]), "+v"(fa[0][1][3]), "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fa[1][0][2]), "+v"(fa[1][0][3]),  \
+                   "+v"(fa[1][1][0]), "+v"(fa[1][1][1]), "+v"(fa[1][1][2]), "+v"(fa[1][1][3]), "+v"(fb[0][0]), "+v"(fb[0][1]),        \
+                   "+v"(fb[0][2]), "+v"(fb[0][3]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[1][2]), "+v"(fb[1][3])                     \
+                 :: "memory")
+
+    // One phase of K tile kt (s0 = ring slot of its item 0).  Q: quadrant; VM: vmcnt before the barrier (-1: none); NI: items to
+    // request (0 .. 2); READ: the items this phase reads exist.  What a phase requests is fixed by its position: the slots freed by
+    // the reads of the phase before it, i.e. items 6 kt + 11, 12 | 13, 14 | 15 | 16 for Q = 0 | 1 | 2 | 3.
+    auto phase = [&](auto Qc, auto VMc, auto NIc, auto READc, int s0, int kt) {
+        constexpr int Q = decltype(Qc)::value, VM = decltype(VMc)::value, NI = decltype(NIc)::value;
+        constexpr bool READ = decltype(READc)::value != 0;
+        sw_wait_vm<VM>();
+        SW_TIE_ALL();                                                 // reads issued during the previous phase (also: its slots are free)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // what this phase requests (two 1-KiB pieces per item and wave), threaded between the MFMA pairs below
+        constexpr int J1 = Q == 0 ? 5 : Q == 1 ? 1 : Q == 2 ? 3 : 4, J2 = Q == 0 ? 0 : 2;      // items 6 kt + 11, 12 | 13, 14 | 15 | 16
+        const int kt1 = Q == 0 ? kt + 1 : kt + 2, sl1 = slot_of(s0, Q == 0 ? 1 : Q == 1 ? 3 : Q == 2 ? 5 : 6), sl2 = slot_of(s0, Q == 0 ? 2 : 4);
+        const int half = wave >> 1;                                   // this wave's B item of a pair: a (waves 0-1) | b (waves 2-3)
+        // quadrant of this phase, and the registers its reads refill: Q0 (A_0, B_0) -> B_1 (items 3 | 4); Q1 (A_0, B_1) -> A_1 (item 5);
+        // Q2 (A_1, B_1) -> A_0 of the next K tile (item 6); Q3 (A_1, B_0) -> B_0 of the next K tile (items 7 | 8), k step by k step
+        // right behind the MFMAs that used the old values
+        constexpr int QI = (Q == 0 || Q == 1) ? 0 : 1, QJ = (Q == 0 || Q == 3) ? 0 : 1;
+        const int srd = slot_of(s0, Q == 0 ? 3 + half : Q == 1 ? 5 : Q == 2 ? 6 : 7 + half);
+        mm(IC<QI>{}, IC<QJ>{}, IC<0>{});
+        if constexpr (READ) {
+            if constexpr (Q == 0) { rd_b(IC<1>{}, IC<0>{}, srd); rd_b(IC<1>{}, IC<1>{}, srd); rd_b(IC<1>{}, IC<2>{}, srd); rd_b(IC<1>{}, IC<3>{}, srd); }
+            if constexpr (Q == 1) { rd_a(IC<1>{}, IC<0>{}, srd); rd_a(IC<1>{}, IC<1>{}, srd); rd_a(IC<1>{}, IC<2>{}, srd); rd_a(IC<1>{}, IC<3>{}, srd); }
+            if constexpr (Q == 2) { rd_a(IC<0>{}, IC<0>{}, srd); rd_a(IC<0>{}, IC<1>{}, srd); rd_a(IC<0>{}, IC<2>{}, srd); rd_a(IC<0>{}, IC<3>{}, srd); }
+            if constexpr (Q == 3) rd_b(IC<0>{}, IC<0>{}, srd);
+        }
+        if constexpr (NI >= 1) issue_piece(IC<J1>{}, IC<0>{}, kt1, sl1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(IC<QI>{}, IC<QJ>{}, IC<1>{});
+        if constexpr (READ && Q == 3) rd_b(IC<0>{}, IC<1>{}, srd);
+        if constexpr (NI >= 1) issue_piece(IC<J1>{}, IC<1>{}, kt1, sl1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(IC<QI>{}, IC<QJ>{}, IC<2>{});
+        if constexpr (READ && Q == 3) rd_b(IC<0>{}, IC<2>{}, srd);
+        if constexpr (NI >= 2) issue_piece(IC<J2>{}, IC<0>{}, kt + 2, sl2);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(IC<QI>{}, IC<QJ>{}, IC<3>{});
+        if constexpr (READ && Q == 3) rd_b(IC<0>{}, IC<3>{}, srd);
+        if constexpr (NI >= 2) issue_piece(IC<J2>{}, IC<1>{}, kt + 2, sl2);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue: ten items in flight; then the two read-only "phases" in front of K tile 0 (A_0, then B_0)
+    issue(IC<0>{}, 0, 0); issue(IC<1>{}, 0, 1); issue(IC<2>{}, 0, 2); issue(IC<3>{}, 0, 3); issue(IC<4>{}, 0, 4); issue(IC<5>{}, 0, 5);
+    issue(IC<0>{}, 1, 6); issue(IC<1>{}, 1, 7); issue(IC<2>{}, 1, 8); issue(IC<3>{}, 1, 9);
+    sw_wait_vm<18>();                                                 // item 0 (nine younger items of two pieces each may be in flight)
+    __builtin_amdgcn_s_barrier();
+    rd_a(IC<0>{}, IC<0>{}, 0); rd_a(IC<0>{}, IC<1>{}, 0); rd_a(IC<0>{}, IC<2>{}, 0); rd_a(IC<0>{}, IC<3>{}, 0);
+    sw_wait_vm<14>();                                                 // items 1, 2
+    SW_TIE_ALL();
+    __builtin_amdgcn_s_barrier();
+    {
+        const int sb = 1 + (wave >> 1);
+        rd_b(IC<0>{}, IC<0>{}, sb); rd_b(IC<0>{}, IC<1>{}, sb); rd_b(IC<0>{}, IC<2>{}, sb); rd_b(IC<0>{}, IC<3>{}, sb);
+    }
+    issue(IC<4>{}, 1, 0);                                             // item 10 (slot 0: every wave's A_0 reads retired before the barrier)
+
+    SW_TRC();
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);                // the K loop outranks the co-resident block's epilogue on this SIMD
+    // ---- K loop.  Steady state: a phase requests as many items as the previous phase read (slots freed), and waits until the items
+    // it reads itself have landed: 10 - reads(previous) - reads(this) younger items of two pieces each may stay in flight.
+    int s0 = 0, kt = 0;
+    for (; kt + 2 < nk; ++kt) {
+        phase(IC<0>{}, IC<12>{}, IC<2>{}, IC<1>{}, s0, kt);
+        phase(IC<1>{}, IC<14>{}, IC<2>{}, IC<1>{}, s0, kt);
+        phase(IC<2>{}, IC<16>{}, IC<1>{}, IC<1>{}, s0, kt);
+        phase(IC<3>{}, IC<14>{}, IC<1>{}, IC<1>{}, s0, kt);
+        s0 = s0 + 6 >= SW_SLOTS ? s0 + 6 - SW_SLOTS : s0 + 6;
+    }
+    SW_TRC();
+    // ---- the last two K tiles (items E - 12 .. E - 1): everything but the last item has been requested when they begin
+    phase(IC<0>{}, IC<12>{}, IC<1>{}, IC<1>{}, s0, kt);                // requests item E - 1 (A_1 of the last K tile)
+    phase(IC<1>{}, IC<12>{}, IC<0>{}, IC<1>{}, s0, kt);                // reads E - 7; E - 1 - (E - 7) = 6 younger
+    phase(IC<2>{}, IC<10>{}, IC<0>{}, IC<1>{}, s0, kt);                // reads E - 6
+    phase(IC<3>{}, IC<6>{}, IC<0>{}, IC<1>{}, s0, kt);                 // reads E - 5, E - 4
+    s0 = s0 + 6 >= SW_SLOTS ? s0 + 6 - SW_SLOTS : s0 + 6;
+    phase(IC<0>{}, IC<2>{}, IC<0>{}, IC<1>{}, s0, kt + 1);             // reads E - 3, E - 2
+    phase(IC<1>{}, IC<0>{}, IC<0>{}, IC<1>{}, s0, kt + 1);             // reads E - 1
+    phase(IC<2>{}, IC<-1>{}, IC<0>{}, IC<0>{}, s0, kt + 1);
+    phase(IC<3>{}, IC<-1>{}, IC<0>{}, IC<0>{}, s0, kt + 1);
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();                                     // every wave is done with the ring: the LDS is free for the epilogue
+    SW_TRC();
+#ifdef W2V2_TUNING
+    if (g.abl == 2) {
+        if (acc[0][0][0] == 12345.678f && acc[3][1][5] == 1.0f) g.C16[0] = 1;
+        return;
+    }
+#endif
+
+    // ---- epilogue: bias -> act -> + residual -> fp32 store and / or bf16 shadow
+    const int64_t tile_off = (int64_t)z * g.strideC + (int64_t)m0 * g.ldc + (n0 + wave * 64);
+    if constexpr (EPI != 0) {       // one batch, ldc == N (the launcher checks): fused element-wise tails of the fine-tune step
+        const int col0 = n0 + wave * 64;
+        // column sums: one partial row per 64-row wave tile of the 128 x 128 kernel (gemm_train_colpart_rows); a wave here owns
+        // both 64-row halves of its 128 rows, writes their sum to the first of the two rows and zero to the second
+        float* const cp = g.epi.colpart ? g.epi.colpart + (int64_t)(2 * tm) * g.N + col0 : nullptr;
+        if (EPI == 2 && cp && lh == 0) {
+            cp[g.N + li] = 0.0f;
+            cp[g.N + 32 + li] = 0.0f;
+        }
+        gemm_epilogue_train<4, 2, EPI>(acc, g.C ? g.C + tile_off : nullptr, g.C16 ? g.C16 + tile_off : nullptr,
+                                       g.residual ? g.residual + tile_off : nullptr, g.bias ? g.bias + col0 : nullptr,
+                                       g.epi.pre ? g.epi.pre + tile_off : nullptr, g.epi.u ? g.epi.u + tile_off : nullptr, cp, (int)g.ldc, g.M - m0,
+                                       g.N - col0, g.epi.act, (uint32_t)(((uint32_t)m0 * (uint32_t)g.ldc + (uint32_t)col0) >> 1), g.epi.key, g.epi.thr1,
+                                       g.epi.inv, li, lh);
+    } else
+    if (g.C16 && !g.C && !g.residual && g.M - m0 >= 128 && (g.ldc & 7) == 0) {
+        uint16_t* const c16 = g.C16 + tile_off;
+        const float* const bw = g.bias ? g.bias + (n0 + wave * 64) : nullptr;
+        const unsigned wb = lds0 + (unsigned)wave * 16384u;
+        if (g.act == 0) sw_epilogue_bf16<0>(acc, c16, bw, (int)g.ldc, wb, lane);
+        else if (g.act == 1) sw_epilogue_bf16<1>(acc, c16, bw, (int)g.ldc, wb, lane);
+        else sw_epilogue_bf16<2>(acc, c16, bw, (int)g.ldc, wb, lane);
+    } else {
+        gemm_epilogue<4, 2, true>(acc, g.C ? g.C + tile_off : nullptr, g.C16 ? g.C16 + tile_off : nullptr, g.residual ? g.residual + tile_off : nullptr,
+                                  g.bias ? g.bias + (n0 + wave * 64) : nullptr, (int)g.ldc, g.M - m0, g.N - (n0 + wave * 64), g.act, li, lh);
+    }
+#ifdef W2V2_TUNING
+    SW_TRC();
+    if (TRACE && trc && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        trc[trc_n++] = clock64();
+        trc[31] = (unsigned long long)trc_n;
+    }
+#endif
+#undef SW_TRC
+#undef SW_TIE_ALL
+}
+
+}  // namespace
+
+#ifdef W2V2_TUNING
+extern unsigned long long* g_tune_trace;
+#endif
+
+// Shapes: both operands as aligned bf16 shadows, whole 256-column tiles (B's per-lane offsets are shared by its four items),
+// K a multiple of 64 with at least 3 K tiles, any M.
+bool gemm_bf16_sw_ok(int M, int N, int K, int64_t lda, int64_t ldb16, int64_t strideA) {
+    return M >= 1 && N >= 256 && N % 256 == 0 && K % 64 == 0 && K >= 192 && lda % 8 == 0 && ldb16 % 8 == 0 && strideA % 8 == 0 &&
+           128 * lda < (1 << 29) && 256 * ldb16 < (1 << 29);
+}
+
+namespace {
+template <int EPI>
+int launch_sw_epi(GemmSWArgs& g, hipStream_t s) {
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set) {
+        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_sw_kernel<false, true, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_sw_kernel<false, true, EPI>), dim3(g.tiles_m * g.tiles_n), dim3(256), SW_LDS, s, g);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+}  // namespace
+
+int launch_gemm_bf16_sw(const uint16_t* A16, int64_t lda, int64_t strideA, const uint16_t* B16, int64_t ldb16, float* C, uint16_t* C16,
+                        int64_t ldc, int64_t strideC, const float* bias, const float* residual, int M, int N, int K, int nbatch, int act,
+                        hipStream_t s, const GemmTrainEpiDev* epi) {
+    W2V2_REQUIRE(A16 && B16 && (C || C16) && gemm_bf16_sw_ok(M, N, K, lda, ldb16, strideA), "gemm_bf16_sw: unsupported operands");
+    GemmSWArgs g;
+    g.A16 = A16; g.B16 = B16; g.C = C; g.C16 = C16; g.bias = bias; g.residual = residual;
+    g.lda = lda; g.ldb16 = ldb16; g.ldc = ldc; g.strideA = strideA; g.strideC = strideC;
+    g.M = M; g.N = N; g.K = K; g.act = act;
+    g.tiles_m = (M + SW_BM - 1) / SW_BM;
+    g.tiles_n = N / SW_BN;
+    g.epi = GemmTrainEpiDev{};
+    if (epi && epi->mode) {
+        W2V2_REQUIRE(nbatch == 1 && ldc == N && act == 0, "gemm_bf16_sw: the training epilogue needs one batch, ldc == N and no GEMM activation");
+        g.epi = *epi;
+#ifdef W2V2_TUNING
+        g.trace = nullptr; g.abl = 0;
+#endif
+        return epi->mode == 1 ? launch_sw_epi<1>(g, s) : launch_sw_epi<2>(g, s);
+    }
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set) {
+        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_sw_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS));
+#ifdef W2V2_TUNING
+        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_sw_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS));
+        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_sw_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS));
+#endif
+        attr_set = true;
+    }
+    dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch);
+#ifdef W2V2_TUNING
+    g.trace = g_tune_trace;
+    g.abl = tune_int("W2V2_PP_ABL", 0);
+    if (g.trace) {
+        hipLaunchKernelGGL(gemm_bf16_sw_kernel<true>, grid, dim3(256), SW_LDS, s, g);
+        W2V2_HIP_CHECK(hipGetLastError());
+        return W2V2_OK;
+    }
+    if (!tune_int("W2V2_PP_PRIO", 1)) {
+        hipLaunchKernelGGL((gemm_bf16_sw_kernel<false, false>), grid, dim3(256), SW_LDS, s, g);
+        W2V2_HIP_CHECK(hipGetLastError());
+        return W2V2_OK;
+    }
+#endif
+    hipLaunchKernelGGL(gemm_bf16_sw_kernel<false>, grid, dim3(256), SW_LDS, s, g);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
+}  // namespace w2v2

@@ -7,6 +7,8 @@
 // wave-uniform base (no 64-bit multiply-add per element), and exact GELU uses a 5-coefficient erf.
 #pragma once
 
+#include <utility>
+
 #include "common.h"
 #include "train.h"
 
@@ -103,6 +105,18 @@ struct GemmTrainEpiDev {
     float* colpart;            // MODE 2, optional: (ceil(M / wave-tile rows)) x N
 };
 
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>).  The element function below is ~100
+// instructions per accumulator block; left as a `#pragma unroll` loop over MT = 4 blocks hipcc declines to unroll it and indexes the
+// accumulators through scratch (576 B per lane in the 128 x 256 kernel's instances).
+template <class F, int... I>
+__device__ __forceinline__ void static_for_seq(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_seq(f, std::make_integer_sequence<int, N>{});
+}
+
 template <int MT, int NTL, int MODE>
 __device__ __forceinline__ void gemm_epilogue_train(const f32x16_t (&acc)[MT][NTL], float* __restrict__ C, uint16_t* __restrict__ C16,
                                                     const float* __restrict__ R, const float* __restrict__ bias, float* __restrict__ pre,
@@ -111,14 +125,14 @@ __device__ __forceinline__ void gemm_epilogue_train(const f32x16_t (&acc)[MT][NT
                                                     sub-tile's first element >> 1 */, uint32_t key, uint32_t thr1, float inv, int li, int lh) {
     const bool interior = rows_left >= MT * 32 && cols_left >= NTL * 32;
     const uint32_t odd = (uint32_t)li & 1u, hp = (uint32_t)ldc >> 1;
-#pragma unroll
-    for (int nt = 0; nt < NTL; ++nt) {
+    static_for<NTL>([&](auto NTc) {
+        constexpr int nt = decltype(NTc)::value;
         const int cl = nt * 32 + li;
         const bool col_ok = cl < cols_left;
         const float bv = (MODE == 1 && bias && col_ok) ? bias[cl] : 0.0f;
         float csum = 0.0f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+        static_for<MT>([&](auto MTc) {
+            constexpr int mt = decltype(MTc)::value;
             f32x16_t v = acc[mt][nt];
             const int off0 = (mt * 32 + 4 * lh) * ldc + cl;   // register r adds ((r & 3) + 8 (r >> 2)) * ldc
             bool ok[16];
@@ -193,12 +207,12 @@ __device__ __forceinline__ void gemm_epilogue_train(const f32x16_t (&acc)[MT][NT
                     if (MODE == 2) csum += v[r];
                 }
             }
-        }
+        });
         if (MODE == 2 && colpart) {
             csum += __shfl_xor(csum, 32);
             if (lh == 0 && col_ok) colpart[cl] = csum;
         }
-    }
+    });
 }
 
 #endif

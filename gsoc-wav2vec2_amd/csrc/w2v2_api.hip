@@ -855,6 +855,18 @@ int w2v2_op_gemm_bf16(const float* A, int64_t lda, int64_t strideA, const float*
     return launch_gemm_bf16(nullptr, A, lda, strideA, B, ldb, 0, C, ldc, strideC, bias, residual, M, N, K, nbatch, act,
                             reinterpret_cast<hipStream_t>(stream));
 }
+int w2v2_op_gemm_bf16_shadows(const uint16_t* A16, int64_t lda, int64_t strideA, const uint16_t* B16, float* C, uint16_t* C16, int64_t ldc,
+                              int64_t strideC, const float* bias, const float* residual, int32_t M, int32_t N, int32_t K, int32_t nbatch,
+                              int32_t act, int32_t variant, void* stream) {
+    W2V2_REQUIRE(A16 && B16 && (C || C16), "op_gemm_bf16_shadows: null operand");
+    W2V2_REQUIRE(variant >= 0 && variant <= 2, "op_gemm_bf16_shadows: variant %d (0 by shape, 1 = 128 x 128 tiles, 2 = 128 x 256 software-pipelined)", variant);
+    W2V2_REQUIRE(variant != 2 || gemm_bf16_sw_ok(M, N, K, lda, K, strideA),
+                 "op_gemm_bf16_shadows: variant 2 needs N %% 256 == 0, K %% 64 == 0, K >= 192 and 16-byte aligned rows");
+    GemmShadows x;
+    x.A16 = A16; x.B16 = B16; x.C16 = C16; x.ldb16 = K; x.force_kernel = variant;
+    return launch_gemm_bf16_x(nullptr, nullptr, lda, strideA, nullptr, N, 0, C, ldc, strideC, bias, residual, M, N, K, nbatch, act, x,
+                              reinterpret_cast<hipStream_t>(stream));
+}
 int w2v2_op_gemm_split(const float* A, int64_t lda, int64_t strideA, const float* B, float* C, int64_t ldc, int64_t strideC,
                        const float* bias, const float* residual, int32_t M, int32_t N, int32_t K, int32_t nbatch, int32_t act,
                        void* stream) {

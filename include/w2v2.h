@@ -272,6 +272,16 @@ int w2v2_op_gemm_bf16(const float* A_dev, int64_t lda, int64_t strideA,
                       const float* bias_dev, const float* residual_dev,
                       int32_t M, int32_t N, int32_t K, int32_t nbatch, int32_t act, void* stream);
 
+/* The same contraction fed from bf16 SHADOWS, the form the model's forward and data-gradient GEMMs run in precision mode bf16:
+ *   A16 (M, K) bf16 rows lda elements apart (overlapping rows = strided Conv1D, batch stride strideA), B16 = the (N, K) bf16
+ *   shadow of the (K, N) kernel; C fp32 and / or C16 bf16 (either may be NULL).  Both operands stream HBM / L2 -> LDS by DMA.
+ * variant: 0 = the kernel the library would pick for the shape, 1 = the 128 x 128-tile kernel (gemm_bf16.hip), 2 = the 128 x 256
+ * software-pipelined kernel with two 4-wave blocks per CU (gemm_bf16_sw.hip; needs N % 256 == 0, K % 64 == 0, K >= 192).  All
+ * variants produce identical bits (tests/test_ops_gpu.py). */
+int w2v2_op_gemm_bf16_shadows(const uint16_t* A16_dev, int64_t lda, int64_t strideA, const uint16_t* B16_nk_dev, float* C_dev,
+                              uint16_t* C16_dev, int64_t ldc, int64_t strideC, const float* bias_dev, const float* residual_dev,
+                              int32_t M, int32_t N, int32_t K, int32_t nbatch, int32_t act, int32_t variant, void* stream);
+
 /* C_z = act(A_z B + bias) + residual_z with fp32 operands split exactly into three bf16 terms each and six bf16 MFMA
  * products per fp32 product (W2V2_PRECISION_BF16X3's GEMM; B dense (K, N), split into planes inside the call).
  * N % 256 == 0, K % 32 == 0, lda % 4 == 0, 16-byte aligned A. */

@@ -162,6 +162,94 @@ def test_gemm_bf16_transpose_detecting(env):
     assert np.array_equal(out.cpu().numpy(), B)
 
 
+def _bf16_bits(torch, t):
+    """fp32 tensor -> its nearest-even bf16 copy (the shadow a producer kernel would write), as a device bf16 tensor."""
+    return t.to(torch.bfloat16).contiguous()
+
+
+@pytest.mark.parametrize("M,N_,K,act,use_bias,use_res,f32_out,b16_out", [
+    (128, 256, 192, 0, False, False, True, True),        # smallest shape the software-pipelined kernel takes (3 K tiles)
+    (300, 512, 448, 1, True, False, False, True),        # ragged rows, GELU, bf16-only output (the LDS-staged epilogue on full row tiles)
+    (257, 768, 768, 0, True, True, True, False),         # fp32 output + residual (out-projection / FFN down form)
+    (1000, 2304, 768, 2, True, False, True, True),       # tanh GELU, both outputs
+    (640, 768, 3072, 0, True, True, True, True),         # long K
+    (130, 256, 256, 1, True, False, False, True)])
+def test_gemm_bf16_shadow_kernels_agree_bit_for_bit(env, M, N_, K, act, use_bias, use_res, f32_out, b16_out):
+    """The shadow-fed form of the bf16 GEMM (both operands already bf16, streamed HBM / L2 -> LDS by DMA) has two kernels:
+    128 x 128 tiles (gemm_bf16.hip) and 128 x 256 software-pipelined 4-wave blocks (gemm_bf16_sw.hip).  Same products, same
+    ascending k order, same lane -> k assignment: identical bits in the fp32 AND the bf16 output, and both equal to exact
+    products of the bf16 operands up to fp32 accumulation order."""
+    lib, torch, dev = env
+    A, B = rnd("As16", (M, K)), rnd("Bs16", (K, N_), 0.2)
+    bias = rnd("biass16", (N_,)) if use_bias else None
+    res = rnd("ress16", (M, N_)) if use_res else None
+    ref = O.round_bf16(A).astype(np.float64) @ O.round_bf16(B).astype(np.float64)
+    if use_bias:
+        ref = ref + bias
+    if act:
+        ref = O.gelu(ref, approximate=(act == 2))
+    if use_res:
+        ref = ref + res
+    A16 = _bf16_bits(torch, dev_t(torch, dev, A))
+    B16 = _bf16_bits(torch, dev_t(torch, dev, np.ascontiguousarray(B.T)))      # (N, K): the weight shadow's layout
+    tb = dev_t(torch, dev, bias) if use_bias else None
+    tr = dev_t(torch, dev, res) if use_res else None
+    outs = {}
+    for variant in (1, 2, 0):
+        Cf = torch.full((M, N_), float("nan"), device=dev) if f32_out else None
+        Ch = torch.zeros((M, N_), device=dev, dtype=torch.bfloat16) if b16_out else None
+        N.check(lib.w2v2_op_gemm_bf16_shadows(N.ptr(A16), K, 0, N.ptr(B16), N.ptr(Cf), N.ptr(Ch), N_, 0, N.ptr(tb), N.ptr(tr), M, N_, K, 1, act,
+                                              variant, stream()), "w2v2_op_gemm_bf16_shadows")
+        torch.cuda.synchronize()
+        outs[variant] = (Cf, Ch)
+    for variant in (2, 0):
+        if f32_out:
+            assert torch.equal(outs[1][0], outs[variant][0]), f"fp32 output: variant {variant} differs from the 128 x 128 kernel"
+        if b16_out:
+            assert torch.equal(outs[1][1].view(torch.int16), outs[variant][1].view(torch.int16)), f"bf16 output: variant {variant} differs"
+    scale = max(1.0, np.abs(ref).max())
+    if f32_out:
+        got = outs[2][0].cpu().numpy()
+        assert np.isfinite(got).all() and H.max_err(got, ref) < 2e-5 * scale
+    if b16_out:
+        got = outs[2][1].float().cpu().numpy()
+        assert H.max_err(got, O.round_bf16(ref.astype(np.float32))) <= 2.0 ** -7 * scale      # one bf16 step where the fp32 sums straddle a tie
+
+
+def test_gemm_bf16_shadows_transpose_detecting_and_batched_conv(env):
+    """(a) A = I against an asymmetric bf16-exact B on the software-pipelined kernel: a swapped k pairing, half-tile or C map
+    cannot pass; (b) a strided Conv1D as an overlapping-row batched GEMM (lda < K, per-sample stride, ragged last row tile)."""
+    lib, torch, dev = env
+    n = 256
+    A = np.eye(n, dtype=np.float32)
+    Bm = ((np.arange(n)[:, None] % 16) * 16 + (np.arange(n)[None, :] % 13) + 1).astype(np.float32)   # < 256: exact in bf16
+    Bm *= np.where(np.arange(n)[:, None] > np.arange(n)[None, :], 1.0, -1.0).astype(np.float32)
+    A16 = _bf16_bits(torch, dev_t(torch, dev, A))
+    B16 = _bf16_bits(torch, dev_t(torch, dev, np.ascontiguousarray(Bm.T)))
+    out = torch.empty((n, n), device=dev)
+    N.check(lib.w2v2_op_gemm_bf16_shadows(N.ptr(A16), n, 0, N.ptr(B16), N.ptr(out), None, n, 0, None, None, n, n, n, 1, 0, 2, stream()))
+    assert np.array_equal(out.cpu().numpy(), Bm)
+    Tin, Cin, Cout, k, st, Bn = 611, 128, 256, 3, 2, 3
+    x, w = rnd("xs16", (Bn, Tin, Cin)), rnd("ws16", (k, Cin, Cout), 0.1)
+    bias = rnd("cbs16", (Cout,))
+    ref = O.gelu(O.conv1d_valid(O.round_bf16(x).astype(np.float64), O.round_bf16(w).astype(np.float64), st, bias.astype(np.float64)))
+    Tout = 1 + (Tin - k) // st
+    x16 = _bf16_bits(torch, dev_t(torch, dev, x))
+    w16 = _bf16_bits(torch, dev_t(torch, dev, np.ascontiguousarray(w.reshape(k * Cin, Cout).T)))
+    tb = dev_t(torch, dev, bias)
+    got = {}
+    for variant in (1, 2):
+        o = torch.full((Bn, Tout, Cout), float("nan"), device=dev)
+        N.check(lib.w2v2_op_gemm_bf16_shadows(N.ptr(x16), st * Cin, Tin * Cin, N.ptr(w16), N.ptr(o), None, Cout, Tout * Cout, N.ptr(tb), None,
+                                              Tout, Cout, k * Cin, Bn, 1, variant, stream()))
+        got[variant] = o
+    assert torch.equal(got[1], got[2])
+    assert H.max_err(got[2].cpu().numpy(), ref) < 3e-5 * max(1.0, np.abs(ref).max())
+    # variant 2 on a shape the kernel does not take is an error, not a silent fallback
+    assert lib.w2v2_op_gemm_bf16_shadows(N.ptr(x16), st * Cin, Tin * Cin, N.ptr(w16), N.ptr(got[1]), None, Cout, Tout * Cout, None, None,
+                                         Tout, Cout, k * Cin, Bn, 0, 3, stream()) == -1
+
+
 @pytest.mark.parametrize("Tin,Cin,Cout,k,s,B", [(203, 64, 96, 3, 2, 3), (101, 32, 32, 2, 2, 2), (49199 // 16, 512, 512, 3, 2, 1)])
 def test_strided_conv_as_overlapping_gemm_bf16(env, Tin, Cin, Cout, k, s, B):
     lib, torch, dev = env

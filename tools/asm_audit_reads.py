@@ -19,12 +19,12 @@ def regs_of(tok):
         if m.group(1): s.update(range(int(m.group(1)), int(m.group(2)) + 1))
         else: s.add(int(m.group(3)))
     return s
-kernel, pending, in_asm, bad, nreads, scratch = None, {}, False, 0, 0, 0
+kernel, pending, in_asm, bad, nreads, scratch, order = None, {}, False, 0, 0, 0, []
 for ln, line in enumerate(text, 1):
     t = line.strip()
     m = re.match(r"^(_Z\w+):", t)
     if m:
-        kernel, pending = m.group(1), {}
+        kernel, pending, order = m.group(1), {}, []
     if t.startswith(";;#ASMSTART"): in_asm = True; continue
     if t.startswith(";;#ASMEND"): in_asm = False; continue
     if not t or t.startswith(";") or t.startswith("."): continue
@@ -32,11 +32,17 @@ for ln, line in enumerate(text, 1):
     if in_asm:
         if t.startswith("ds_read"):
             dst = t.split()[1].rstrip(",")
-            for r in regs_of(dst): pending[r] = ln
+            order.append((ln, regs_of(dst)))
             nreads += 1
-        elif "lgkmcnt(0)" in t:
-            pending = {}
-        continue          # (a counted wait retires the oldest reads only: everything stays pending, conservatively)
+        elif t.startswith("ds_write"):
+            order.append((ln, set()))          # counts in lgkmcnt, owns no destination
+        else:
+            m2 = re.search(r"lgkmcnt\((\d+)\)", t)
+            if m2:                               # LDS operations retire in order: all but the N youngest are done
+                n = int(m2.group(1))
+                order = order[len(order) - n:] if n else []
+        pending = {r: l0 for l0, rs in order for r in rs}
+        continue
     if pending:
         ops = t.split(None, 1)
         touched = regs_of(ops[1]) if len(ops) > 1 else set()

@@ -1,23 +1,20 @@
 #!/usr/bin/env python
-"""A/B of the two shadow-fed bf16 GEMM kernels through the tools-only build: gemm_bf16_kernel (128 x 128, W2V2_GEMM16_PP=0)
-against gemm_bf16_pp_kernel (256 x 256 ping-pong, W2V2_GEMM16_PP=2): bitwise comparison of the fp32 and bf16 outputs on ragged
-and model shapes, then interleaved timing on the B = 32 model shapes (knobs: W2V2_PP_D, W2V2_PP_PRIO).
+"""A/B of the two shadow-fed bf16 GEMM kernels through the product op w2v2_op_gemm_bf16_shadows: variant 1 (gemm_bf16_kernel,
+128 x 128 tiles) against variant 2 (gemm_bf16_sw_kernel, 128 x 256 software-pipelined, two 4-wave blocks per CU): bitwise
+comparison of the fp32 and bf16 outputs on ragged and model shapes, then interleaved timing on the B = 32 model shapes.
 
-    python tools/gemm16_pp_check.py [--time-only] [--d 4,5,6]"""
+    python tools/gemm16_ab.py [--time-only]            (W2V2_NATIVE_LIB selects the tools-only build for knob sweeps)"""
 import os, sys, argparse
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "gsoc-wav2vec2_amd"))
-os.environ.setdefault("W2V2_NATIVE_LIB", os.path.join(ROOT, "gsoc-wav2vec2_amd", "lib", "libw2v2_tuning.so"))
 import ctypes as C
 import torch
 from wav2vec2 import _native as N
-ap = argparse.ArgumentParser(); ap.add_argument("--time-only", action="store_true"); ap.add_argument("--d", default="5"); ap.add_argument("--prio", default="1")
+ap = argparse.ArgumentParser(); ap.add_argument("--time-only", action="store_true"); ap.add_argument("--prio", default="1")
 ap.add_argument("--iters", type=int, default=20)
 args = ap.parse_args()
 lib = N.load()
 P, I32, I64 = C.c_void_p, C.c_int32, C.c_int64
-lib.w2v2_tune_gemm16.restype = C.c_int
-lib.w2v2_tune_gemm16.argtypes = [P, I64, I64, P, P, P, I64, I64, P, P, I32, I32, I32, I32, I32, P]
 dev = torch.device("cuda:0")
 
 def make(M, Nn, K, lda, sA, nb, f32o, b16o, res, seed=0):
@@ -31,10 +28,9 @@ def make(M, Nn, K, lda, sA, nb, f32o, b16o, res, seed=0):
 
 def run(pp, t, M, Nn, K, lda, sA, nb, act, f32o, b16o):
     A16, B16, bias, R = t
-    os.environ["W2V2_GEMM16_PP"] = str(pp)
     Cf = torch.full((nb * M * Nn,), float("nan"), device=dev) if f32o else None
     Ch = torch.zeros(nb * M * Nn, device=dev, dtype=torch.bfloat16) if b16o else None
-    N.check(lib.w2v2_tune_gemm16(N.ptr(A16), lda, sA, N.ptr(B16), N.ptr(Cf), N.ptr(Ch), Nn, M * Nn, N.ptr(bias), N.ptr(R), M, Nn, K, nb, act, N.current_stream()))
+    N.check(lib.w2v2_op_gemm_bf16_shadows(N.ptr(A16), lda, sA, N.ptr(B16), N.ptr(Cf), N.ptr(Ch), Nn, M * Nn, N.ptr(bias), N.ptr(R), M, Nn, K, nb, act, pp, N.current_stream()))
     torch.cuda.synchronize()
     return Cf, Ch
 
@@ -42,24 +38,24 @@ if not args.time_only:
     # (M, N, K, lda, strideA, batch, act, fp32 out, bf16 out, residual)
     cases = [(256, 256, 256, 256, 0, 1, 0, True, True, False), (512, 768, 768, 768, 0, 1, 1, True, True, True), (300, 260, 384, 384, 0, 1, 0, True, False, True),
              (1000, 520, 512, 512, 0, 1, 1, False, True, False), (257, 1, 256, 256, 0, 1, 0, True, True, False), (2459, 512, 1536, 1024, 4919 * 512, 3, 1, True, True, False),
-             (768 * 4, 2304, 768, 768, 0, 1, 0, False, True, False), (768 * 2, 768, 3072, 3072, 0, 1, 0, True, False, True)]
-    for d in args.d.split(","):
-        os.environ["W2V2_PP_D"] = d
+             (768 * 4, 2304, 768, 768, 0, 1, 0, False, True, False), (768 * 2, 768, 3072, 3072, 0, 1, 0, True, False, True),
+             (130, 256, 192, 192, 0, 1, 0, True, True, False), (1000, 512, 448, 448, 0, 2, 1, False, True, False)]
+    for d in ("-",):
         for c in cases:
             M, Nn, K, lda, sA, nb, act, f32o, b16o, res = c
             t = make(M, Nn, K, lda, sA, nb, f32o, b16o, res)
             ok = True
             for rep in range(3):
-                c0, h0 = run(0, t, M, Nn, K, lda, sA, nb, act, f32o, b16o)
-                c1, h1 = run(2, t, M, Nn, K, lda, sA, nb, act, f32o, b16o)
+                c0, h0 = run(1, t, M, Nn, K, lda, sA, nb, act, f32o, b16o)
+                c1, h1 = run(2 if Nn % 256 == 0 and K % 64 == 0 and K >= 192 else 0, t, M, Nn, K, lda, sA, nb, act, f32o, b16o)
                 same = (c0 is None or torch.equal(c0, c1)) and (h0 is None or torch.equal(h0.view(torch.int16), h1.view(torch.int16)))
                 fin = (c1 is None or bool(torch.isfinite(c1).all()))
                 ok &= same and fin
                 if not same:
                     dc = float((c0 - c1).abs().max()) if c0 is not None else float((h0.float() - h1.float()).abs().max())
-                    print(f"   MISMATCH D={d} {c}: max diff {dc:.3e}")
+                    print(f"   MISMATCH {c}: max diff {dc:.3e}")
                     break
-            print(f"D={d} M={M} N={Nn} K={K} batch={nb} act={act} f32={f32o} bf16={b16o} res={res}: {'identical bits x3' if ok else 'DIFFERENT'}")
+            print(f"M={M} N={Nn} K={K} batch={nb} act={act} f32={f32o} bf16={b16o} res={res}: {'identical bits x3' if ok else 'DIFFERENT'}")
 
 B = 32; BT = B * 768
 SHAPES = {"qkv": (BT, 2304, 768, 768, 0, 1, 0, False, True, False), "out": (BT, 768, 768, 768, 0, 1, 0, True, False, True),
@@ -75,23 +71,25 @@ def timeit(fn, iters):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
-print(f"{'shape':8s} {'old 128x128':>14s}  " + "  ".join(f"pp D={d} prio={p}" for d in args.d.split(",") for p in args.prio.split(",")))
+print(f"{'shape':8s} {'128x128':>14s}  " + "  ".join(f"128x256 sw (prio {p})" for p in args.prio.split(",")))
 for name, (M, Nn, K, lda, sA, nb, act, f32o, b16o, res) in SHAPES.items():
     A16, B16, bias, R = make(M, Nn, K, lda, sA, nb, f32o, b16o, res)
     Cf = torch.empty(nb * M * Nn, device=dev) if f32o else None
     Ch = torch.empty(nb * M * Nn, device=dev, dtype=torch.bfloat16) if b16o else None
     st = N.current_stream()
+    variant = [1]
     def call():
-        N.check(lib.w2v2_tune_gemm16(N.ptr(A16), lda, sA, N.ptr(B16), N.ptr(Cf), N.ptr(Ch), Nn, M * Nn, N.ptr(bias), N.ptr(R), M, Nn, K, nb, act, st))
+        N.check(lib.w2v2_op_gemm_bf16_shadows(N.ptr(A16), lda, sA, N.ptr(B16), N.ptr(Cf), N.ptr(Ch), Nn, M * Nn, N.ptr(bias), N.ptr(R), M, Nn, K, nb, act, variant[0], st))
     fl = 2.0 * M * Nn * K * nb
-    os.environ["W2V2_GEMM16_PP"] = "0"
+    variant[0] = 1
     t0 = timeit(call, args.iters)
     cols = []
-    for d in args.d.split(","):
+    for d in ("-",):
         for p in args.prio.split(","):
-            os.environ.update(W2V2_GEMM16_PP="2", W2V2_PP_D=d, W2V2_PP_PRIO=p)
+            os.environ.update(W2V2_PP_PRIO=p)
+            variant[0] = 2
             t1 = timeit(call, args.iters)
             cols.append(f"{t1 * 1e3:7.1f} us {fl / t1 / 1e9:5.0f} TF")
-    os.environ["W2V2_GEMM16_PP"] = "0"
+    variant[0] = 1
     t0b = timeit(call, args.iters)
     print(f"{name:8s} {min(t0, t0b) * 1e3:7.1f} us {fl / min(t0, t0b) / 1e9:5.0f} TF  " + "  ".join(cols))

@@ -18,8 +18,6 @@ from wav2vec2 import _native as N
 
 lib = N.load()
 P, I32, I64 = C.c_void_p, C.c_int32, C.c_int64
-lib.w2v2_tune_gemm16.restype = C.c_int
-lib.w2v2_tune_gemm16.argtypes = [P, I64, I64, P, P, P, I64, I64, P, P, I32, I32, I32, I32, I32, P]
 lib.w2v2_tune_set_trace.restype = C.c_int
 lib.w2v2_tune_set_trace.argtypes = [P]
 dev = torch.device("cuda:0")
@@ -29,6 +27,7 @@ SHAPES = {"qkv": (BT, 2304, 768, 768, 0, 1, 0, False, True, False), "out": (BT, 
           "ffn1": (BT, 3072, 768, 768, 0, 1, 1, False, True, False), "ffn2": (BT, 768, 3072, 3072, 0, 1, 0, True, False, True),
           "conv1": (24599, 512, 1536, 1024, 49199 * 512, B, 1, False, True, False),
           "conv4": (3074, 512, 1536, 1024, 6149 * 512, B, 1, False, True, False)}
+VARIANT = int(os.environ.get("TRACE_VARIANT", 0))      # 0 by shape, 1 = 128 x 128, 2 = 128 x 256 software-pipelined
 names = sys.argv[1:] or ["qkv", "out", "ffn1", "ffn2", "conv1"]
 for name in names:
     M, Nn, K, lda, sA, nb, act, f32o, b16o, res = SHAPES[name]
@@ -42,7 +41,7 @@ for name in names:
     st = N.current_stream()
 
     def run():
-        N.check(lib.w2v2_tune_gemm16(N.ptr(A16), lda, sA, N.ptr(B16), N.ptr(Cf), N.ptr(Ch), Nn, M * Nn, N.ptr(bias), N.ptr(R), M, Nn, K, nb, act, st))
+        N.check(lib.w2v2_op_gemm_bf16_shadows(N.ptr(A16), lda, sA, N.ptr(B16), N.ptr(Cf), N.ptr(Ch), Nn, M * Nn, N.ptr(bias), N.ptr(R), M, Nn, K, nb, act, VARIANT, st))
     lib.w2v2_tune_set_trace(None)
     for _ in range(3): run()
     torch.cuda.synchronize()
@@ -59,6 +58,32 @@ for name in names:
     lib.w2v2_tune_set_trace(None)
     t = tr.cpu().numpy().reshape(tiles, 32)
     cnt = int(t[0, 31]); nk = K // 64
+    if cnt == 8:          # gemm_bf16_sw_kernel: entry, prologue done, steady loop done, tail done + barrier, epilogue issued, stores retired
+        tiles = ((M + 127) // 128) * (Nn // 256) * nb
+        t = t[:tiles]
+        clk = t[:, 2:8].astype(np.float64); d = np.diff(clk, axis=1)
+        q = lambda v: "%7.0f %7.0f %7.0f" % tuple(np.percentile(v, [10, 50, 90]))
+        print(f"== {name} [128x256 software-pipelined, 2 blocks / CU]: {ms:.4f} ms = {2.0 * M * Nn * K * nb / ms / 1e9:.0f} TF; {tiles} tiles, {nk} K tiles")
+        for lab, col in (("entry -> A_0, B_0 of K tile 0 in registers", 0), (f"steady loop ({nk - 2} K tiles)", 1), ("last two K tiles + barrier", 2),
+                         ("epilogue until stores issued", 3), ("stores retired (vmcnt 0)", 4)):
+            print(f"   {lab:44s} {q(d[:, col])}" + (f"   per K tile {q(d[:, col] / (nk - 2))} (1024 = the pipe to itself)" if col == 1 else ""))
+        print(f"   total {q(clk[:, -1] - clk[:, 0])}")
+        hw = t[:, 0]
+        cu_key = ((hw >> 32) << 16) | ((hw & 0xFFFFFFFF) >> 8 & 0xF) | (((hw & 0xFFFFFFFF) >> 13 & 0x7) << 4) | (((hw & 0xFFFFFFFF) >> 12 & 1) << 7)
+        uniq, per_cu = np.unique(cu_key, return_counts=True)
+        print(f"   {len(uniq)} distinct CU ids; blocks per CU min / median / max {per_cu.min()} / {int(np.median(per_cu))} / {per_cu.max()}")
+        continue
+    if cnt == 10:         # gemm_bf16_pp_kernel with the LDS-staged bf16 epilogue: + barrier passed, LDS written, stores issued
+        tiles = ((M + 255) // 256) * ((Nn + 255) // 256) * nb
+        t = t[:tiles]
+        clk = t[:, 2:10].astype(np.float64); d = np.diff(clk, axis=1)
+        q = lambda v: "%7.0f %7.0f %7.0f" % tuple(np.percentile(v, [10, 50, 90]))
+        print(f"== {name} [256x256 ping-pong, LDS-staged epilogue]: {ms:.4f} ms = {2.0 * M * Nn * K * nb / ms / 1e9:.0f} TF; {tiles} tiles, {nk} K tiles")
+        for lab, col in (("entry -> first half-tiles landed", 0), (f"steady loop ({nk - 2} K tiles)", 1), ("last two K tiles", 2), ("final barrier", 3),
+                         ("bias / act / cvt + LDS writes", 4), ("tr reads + store issue", 5), ("stores retired (vmcnt 0)", 6)):
+            print(f"   {lab:36s} {q(d[:, col])}")
+        print(f"   total {q(clk[:, -1] - clk[:, 0])}")
+        continue
     if cnt == 7:          # gemm_bf16_pp_kernel: entry, items 0-1 landed, end of the steady loop, end of the last two K tiles, stores retired
         tiles = ((M + 255) // 256) * ((Nn + 255) // 256) * nb
         t = t[:tiles]
