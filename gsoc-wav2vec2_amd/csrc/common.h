@@ -110,25 +110,7 @@ int launch_gemm_split(Profiler* prof, const float* A, int64_t lda, int64_t strid
 // tensor -- exactly what the kernel would round to itself -- so using one changes speed, never results.
 //   A16: same shape / strides (in elements) as A;   B16: B TRANSPOSED, [N][K] with row stride ldb16 (0 = K);
 //   C16: bf16 copy of the output for the consumer GEMM (C itself may then be null: the fp32 store is skipped).
-// Training epilogue of the bf16 GEMM (gemm_epilogue.h: gemm_epilogue_train), for the fine-tune step's Dense layers whose output
-// goes straight through an element-wise dropout kernel.  Only the LDS-DMA form takes it (both operands from shadows, one batch,
-// ldc == N even): ask gemm_train_epilogue_ok() first and fall back to the separate kernel otherwise.
-struct GemmTrainEpi {
-    int mode = 0;                 // 1 forward: [pre = acc + bias] -> act -> dropout -> + residual -> C / C16
-                                  // 2 backward: dropout-backward(acc) * act'(u) -> C / C16 (+ colpart: per-64-row column sums)
-    int act = 0;                  // activation of the element function (0 | 1 | 2 | 3); the GEMM's own `act` must be 0
-    float p = 0.f;
-    uint64_t seed = 0;
-    uint32_t stream = 0;
-    float* pre = nullptr;         // mode 1, optional: fp32 pre-activations (ldc)
-    const float* u = nullptr;     // mode 2: the forward's pre-activations (ldc)
-    float* colpart = nullptr;     // mode 2, optional: gemm_train_colpart_rows(M) x N floats
-};
-bool gemm_train_epilogue_ok(int M, int N, int K, int64_t ldc);
-int gemm_train_colpart_rows(int M);
-int gemm_train_epilogue_sites();
 struct GemmShadows {
-    const GemmTrainEpi* epi = nullptr;
     const uint16_t* A16 = nullptr;
     const uint16_t* B16 = nullptr;
     uint16_t* C16 = nullptr;
@@ -159,10 +141,9 @@ struct GemmShadows {
 };
 // 128 x 256 software-pipelined form, two 4-wave blocks per CU (gemm_bf16_sw.hip): same arithmetic, identical bits
 bool gemm_bf16_sw_ok(int M, int N, int K, int64_t lda, int64_t ldb16, int64_t strideA);
-struct GemmTrainEpiDev;      // gemm_epilogue.h
 int launch_gemm_bf16_sw(const uint16_t* A16, int64_t lda, int64_t strideA, const uint16_t* B16, int64_t ldb16, float* C, uint16_t* C16,
                         int64_t ldc, int64_t strideC, const float* bias, const float* residual, int M, int N, int K, int nbatch, int act,
-                        hipStream_t s, const GemmTrainEpiDev* epi = nullptr);
+                        hipStream_t s);
 int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
                        int64_t strideB, float* C, int64_t ldc, int64_t strideC, const float* bias,
                        const float* residual, int M, int N, int K, int nbatch, int act, const GemmShadows& x,

@@ -59,7 +59,6 @@ struct Gemm16Args {
     // (the bias gradient: B = dY is already in registers while it is staged, so the sums cost 8 adds per patch column)
     float* colsum;
     int64_t strideCS;
-    GemmTrainEpiDev epi;   // training epilogue (EPI instances of the kernel only)
     int64_t validK;        // tr form: rows of the K dimension that exist, over all batches (batch z owns [z K, (z + 1) K)); rows beyond
                            // read as zero, so neither the row count nor its split into slabs has to be a multiple of the K tile
 #ifdef W2V2_TUNING
@@ -91,7 +90,7 @@ template <> struct FVec<2> { using type = f32x2; };
 // then goes on the per-lane SOURCE address, as in gemm_f32.hip), 7 = fp32 with A TRANSPOSED in memory ((K, M), the
 // activation itself in a weight-gradient GEMM  dW = X^T dY): A takes B's register-transposing path, no transposed copy.  Shadows hold exactly the values the fp32 path would round to, so all five
 // produce bit-identical results.
-template <int SRC, int BM, int BN, int WM, int WN, int MINB, int EPI = 0>
+template <int SRC, int BM, int BN, int WM, int WN, int MINB>
 __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args g) {
     constexpr bool FAST = SRC >= 1, A16 = SRC == 2 || (SRC >= 4 && SRC <= 6), B16 = SRC == 3 || (SRC >= 4 && SRC <= 6);
     constexpr bool DMA = SRC == 5 || SRC == 6;      // both shadows, LDS-DMA staging (no registers, no ds_write)
@@ -534,16 +533,6 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
     // Epilogue forms measured in round 2 (profiles/r02_gemm_bf16_study.md): these row-major C/D blocks with dword stores
     // (2 rows x 128 B per instruction) beat both C^T accumulators with 16-byte stores straight from registers (32 rows x 32 B:
     // 532 vs 613 TF on the forward mix) and C^T through wave-private LDS patches (whole 128-byte segments, 16 B per lane: 586).
-    if constexpr (EPI != 0) {       // one batch, ldc == N (launch_gemm_bf16_x checks)
-        const int row0 = m0 + wm * WTM, col0 = n0 + wn * WTN;
-        gemm_epilogue_train<MT, NTL, EPI>(acc, g.C ? g.C + tile_off : nullptr, g.C16 ? g.C16 + tile_off : nullptr,
-                                          g.residual ? g.residual + tile_off : nullptr, g.bias ? g.bias + col0 : nullptr,
-                                          g.epi.pre ? g.epi.pre + tile_off : nullptr, g.epi.u ? g.epi.u + tile_off : nullptr,
-                                          g.epi.colpart ? g.epi.colpart + (int64_t)(row0 / WTM) * g.N + col0 : nullptr, (int)g.ldc,
-                                          g.M - row0, g.N - col0, g.epi.act, (uint32_t)(((uint32_t)row0 * (uint32_t)g.ldc + (uint32_t)col0) >> 1),
-                                          g.epi.key, g.epi.thr1, g.epi.inv, li, lh);
-        return;
-    }
     gemm_epilogue<MT, NTL, true>(acc, g.C ? g.C + tile_off : nullptr, g.C16 ? g.C16 + tile_off : nullptr,
                                  g.residual ? g.residual + tile_off : nullptr,
                                  g.bias ? g.bias + (g.zmod ? (int64_t)zi * g.strideBias : 0) + (n0 + wn * WTN) : nullptr,
@@ -729,19 +718,19 @@ int launch_tr16(Gemm16Args& g, int nbatch, hipStream_t s) {
     return W2V2_OK;
 }
 
-template <int SRC, int BM, int BN, int WM, int WN, int MINB, int EPI = 0>
+template <int SRC, int BM, int BN, int WM, int WN, int MINB>
 int launch_src16(Gemm16Args& g, int nbatch, hipStream_t s) {
     constexpr size_t LDS = (SRC == 6 ? 4 : 2) * (BM + BN) * ROWB;
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
     static std::atomic<bool> attr_set{false};   // (idempotent call; atomic so concurrent host threads agree on the flag)
     if (!attr_set) {
-        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<SRC, BM, BN, WM, WN, MINB, EPI>),
+        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<SRC, BM, BN, WM, WN, MINB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
         attr_set = true;
     }
     dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch), block(WM * WN * 64);
-    hipLaunchKernelGGL((gemm_bf16_kernel<SRC, BM, BN, WM, WN, MINB, EPI>), grid, block, LDS, s, g);
+    hipLaunchKernelGGL((gemm_bf16_kernel<SRC, BM, BN, WM, WN, MINB>), grid, block, LDS, s, g);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -758,14 +747,6 @@ int launch_cfg16(Gemm16Args& g, int src, int nbatch, hipStream_t s) {
         case 7: return launch_src16<7, BM, BN, WM, WN, MINB>(g, nbatch, s);
         default: return launch_src16<0, BM, BN, WM, WN, MINB>(g, nbatch, s);
     }
-}
-
-// dropout_key (train.h) on the host: the key is loop-invariant, so the kernel argument carries it
-uint32_t host_dropout_key(uint64_t seed, uint32_t stream) {
-    uint64_t z = (seed ^ ((uint64_t)stream * 0x9E3779B97F4A7C15ULL)) + 0x9E3779B97F4A7C15ULL;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    return (uint32_t)(z ^ (z >> 31));
 }
 
 #ifdef W2V2_TUNING
@@ -791,21 +772,6 @@ int forced_cfg16() {
 }
 
 }  // namespace
-
-// (the flat element index row * ldc + col is hashed as 32 bits: element-wise kernels and epilogue agree modulo 2^32)
-bool gemm_train_epilogue_ok(int M, int N, int K, int64_t ldc) {
-    // (M ldc < 2^32: the epilogue steps pair indices inside a sub-tile by addition, which equals the element-wise kernels'
-    //  "(index mod 2^32) >> 1" only while no index wraps)
-    return M > 0 && N > 64 && N % 2 == 0 && ldc == N && K % BK == 0 && (int64_t)M * ldc < ((int64_t)1 << 32);
-}
-// which Dense layers of the fine-tune step use it: bit 0 = FFN up-projection forward, 1 = attention out-projection forward,
-// 2 = FFN down-projection data gradient (tuning knob W2V2_GEMM_EPI).  Measured on the base fine-tune step (38.45 ms without): bit 2
-// -0.38 ms, bit 0 -0.1 ms, bit 1 +0.34 ms (the H-wide GEMM is too short to hide the epilogue's hash and scattered residual reads):
-// default 5.
-int gemm_train_epilogue_sites() {
-    return tune_int("W2V2_GEMM_EPI", 5);
-}
-int gemm_train_colpart_rows(int M) { return (M + 127) / 128 * 2; }     // wave tiles of 64 rows, two per 128-row block
 
 int launch_gemm_bf16(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
                      int64_t strideB, float* C, int64_t ldc, int64_t strideC, const float* bias,
@@ -833,7 +799,6 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
     g.validK = x.validK > 0 ? x.validK : (int64_t)K * nbatch;
     W2V2_REQUIRE(x.validK == 0 || (x.transA && x.A16 && x.B16p && x.validK > (int64_t)K * (nbatch - 1) && x.validK <= (int64_t)K * nbatch),
                  "gemm_bf16: validK is for the transposed-A shadow form, and every batch must own at least one existing row");
-    g.epi = GemmTrainEpiDev{};
 #ifdef W2V2_TUNING
     g.abl = tune_int("W2V2_GEMM16_ABL", 0);
     g.trace = g_tune_trace;
@@ -873,22 +838,6 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
                  nbatch * (abytes * (double)M * K + (C ? 4.0 : 0.0) * (double)M * N + (x.C16 ? 2.0 : 0.0) * (double)M * N) +
                      bbytes * (double)K * N, s);
     int cfg = forced_cfg16();
-    if (x.epi && x.epi->mode) {
-        const GemmTrainEpi& t = *x.epi;
-        W2V2_REQUIRE(src == 5 && N > 64 && nbatch == 1 && x.zmod == 0 && act == 0 && gemm_train_epilogue_ok(M, N, K, ldc),
-                     "gemm_bf16: the training epilogue needs both operands as aligned bf16 shadows, one batch and ldc == N (ask gemm_train_epilogue_ok)");
-        W2V2_REQUIRE((t.mode == 1 || t.mode == 2) && t.act >= 0 && t.act <= 3 && t.p >= 0.f && t.p < 1.f && (t.mode == 1 || !t.act || t.u) &&
-                         (t.mode == 2 || !t.colpart), "gemm_bf16: bad training epilogue");
-        g.epi.mode = t.mode; g.epi.act = t.act; g.epi.inv = t.p > 0.f ? 1.0f / (1.0f - t.p) : 1.0f;
-        g.epi.key = host_dropout_key(t.seed, t.stream); g.epi.thr1 = (uint32_t)((double)t.p * 65536.0) - 1u;
-        g.epi.pre = t.pre; g.epi.u = t.u; g.epi.colpart = t.colpart;
-        // (the 128 x 256 kernel has these instances too, but with 128 outputs per lane and two waves per SIMD the tails' scattered
-        //  fp32 reads of u and their hash / GELU' chains are exposed: 513 vs 325 us for the FFN data-gradient tail, 278 vs 251 for
-        //  the forward one -- profiles/r03_gemm_bf16_study.md; they are taken only when forced)
-        if (x.force_kernel == 2 && use_sw_kernel(x, M, N, K, lda, g.ldb16, strideA, nbatch))
-            return launch_gemm_bf16_sw(x.A16, lda, strideA, x.B16, g.ldb16, C, x.C16, ldc, strideC, bias, residual, M, N, K, nbatch, 0, s, &g.epi);
-        return t.mode == 1 ? launch_src16<5, 128, 128, 2, 4, 2, 1>(g, nbatch, s) : launch_src16<5, 128, 128, 2, 4, 2, 2>(g, nbatch, s);
-    }
     // both operands from shadows, enough tiles to fill the chip: 128 x 256 tiles, 4-wave software-pipelined blocks, two per CU
     // (gemm_bf16_sw.hip).  Same bits as the kernels below.
     if (src == 5 && use_sw_kernel(x, M, N, K, lda, g.ldb16, strideA, nbatch))

@@ -43,7 +43,6 @@ struct GemmSWArgs {
     int64_t lda, ldb16, ldc, strideA, strideC;
     int M, N, K, act;
     int tiles_m, tiles_n;
-    GemmTrainEpiDev epi;       // training epilogue (EPI instances only)
 #ifdef W2V2_TUNING
     unsigned long long* trace;
     int abl;
@@ -149,7 +148,7 @@ __device__ __forceinline__ void sw_epilogue_bf16(const f32x16 (&acc)[4][2], uint
 #undef SW_ST4
 }
 
-template <bool TRACE, bool PRIO = true, int EPI = 0>
+template <bool TRACE, bool PRIO = true>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_sw_kernel(GemmSWArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sw_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -367,21 +366,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_sw_kernel(GemmSWArgs g) {
 
     // ---- epilogue: bias -> act -> + residual -> fp32 store and / or bf16 shadow
     const int64_t tile_off = (int64_t)z * g.strideC + (int64_t)m0 * g.ldc + (n0 + wave * 64);
-    if constexpr (EPI != 0) {       // one batch, ldc == N (the launcher checks): fused element-wise tails of the fine-tune step
-        const int col0 = n0 + wave * 64;
-        // column sums: one partial row per 64-row wave tile of the 128 x 128 kernel (gemm_train_colpart_rows); a wave here owns
-        // both 64-row halves of its 128 rows, writes their sum to the first of the two rows and zero to the second
-        float* const cp = g.epi.colpart ? g.epi.colpart + (int64_t)(2 * tm) * g.N + col0 : nullptr;
-        if (EPI == 2 && cp && lh == 0) {
-            cp[g.N + li] = 0.0f;
-            cp[g.N + 32 + li] = 0.0f;
-        }
-        gemm_epilogue_train<4, 2, EPI>(acc, g.C ? g.C + tile_off : nullptr, g.C16 ? g.C16 + tile_off : nullptr,
-                                       g.residual ? g.residual + tile_off : nullptr, g.bias ? g.bias + col0 : nullptr,
-                                       g.epi.pre ? g.epi.pre + tile_off : nullptr, g.epi.u ? g.epi.u + tile_off : nullptr, cp, (int)g.ldc, g.M - m0,
-                                       g.N - col0, g.epi.act, (uint32_t)(((uint32_t)m0 * (uint32_t)g.ldc + (uint32_t)col0) >> 1), g.epi.key, g.epi.thr1,
-                                       g.epi.inv, li, lh);
-    } else
     if (g.C16 && !g.C && !g.residual && g.M - m0 >= 128 && (g.ldc & 7) == 0) {
         uint16_t* const c16 = g.C16 + tile_off;
         const float* const bw = g.bias ? g.bias + (n0 + wave * 64) : nullptr;
@@ -418,23 +402,9 @@ bool gemm_bf16_sw_ok(int M, int N, int K, int64_t lda, int64_t ldb16, int64_t st
            128 * lda < (1 << 29) && 256 * ldb16 < (1 << 29);
 }
 
-namespace {
-template <int EPI>
-int launch_sw_epi(GemmSWArgs& g, hipStream_t s) {
-    static std::atomic<bool> attr_set{false};
-    if (!attr_set) {
-        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_sw_kernel<false, true, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm_bf16_sw_kernel<false, true, EPI>), dim3(g.tiles_m * g.tiles_n), dim3(256), SW_LDS, s, g);
-    W2V2_HIP_CHECK(hipGetLastError());
-    return W2V2_OK;
-}
-}  // namespace
-
 int launch_gemm_bf16_sw(const uint16_t* A16, int64_t lda, int64_t strideA, const uint16_t* B16, int64_t ldb16, float* C, uint16_t* C16,
                         int64_t ldc, int64_t strideC, const float* bias, const float* residual, int M, int N, int K, int nbatch, int act,
-                        hipStream_t s, const GemmTrainEpiDev* epi) {
+                        hipStream_t s) {
     W2V2_REQUIRE(A16 && B16 && (C || C16) && gemm_bf16_sw_ok(M, N, K, lda, ldb16, strideA), "gemm_bf16_sw: unsupported operands");
     GemmSWArgs g;
     g.A16 = A16; g.B16 = B16; g.C = C; g.C16 = C16; g.bias = bias; g.residual = residual;
@@ -442,15 +412,6 @@ int launch_gemm_bf16_sw(const uint16_t* A16, int64_t lda, int64_t strideA, const
     g.M = M; g.N = N; g.K = K; g.act = act;
     g.tiles_m = (M + SW_BM - 1) / SW_BM;
     g.tiles_n = N / SW_BN;
-    g.epi = GemmTrainEpiDev{};
-    if (epi && epi->mode) {
-        W2V2_REQUIRE(nbatch == 1 && ldc == N && act == 0, "gemm_bf16_sw: the training epilogue needs one batch, ldc == N and no GEMM activation");
-        g.epi = *epi;
-#ifdef W2V2_TUNING
-        g.trace = nullptr; g.abl = 0;
-#endif
-        return epi->mode == 1 ? launch_sw_epi<1>(g, s) : launch_sw_epi<2>(g, s);
-    }
     static std::atomic<bool> attr_set{false};
     if (!attr_set) {
         W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_sw_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS));

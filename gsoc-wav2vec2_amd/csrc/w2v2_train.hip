@@ -62,7 +62,6 @@ struct TrainState {
     // scratch
     float *gh[4] = {nullptr, nullptr, nullptr, nullptr}, *gf = nullptr, *g3h = nullptr, *at = nullptr,
           *slabs = nullptr, *red_ws = nullptr, *dvec = nullptr, *dummy = nullptr, *dwqkv = nullptr, *dwv_scratch = nullptr,
-          *ffn_colpart = nullptr,      // per-wave-tile column sums of du from the down-projection's data-gradient GEMM (-> b1 gradient)
           *attn_colpart = nullptr;     // per-block column sums of dqkv from the bf16 attention backward (-> q|k|v bias gradient)
     int64_t slab_floats = 0;
     // bf16 shadows of the gradient tensors that are the A operand of a data-gradient GEMM (precision mode 1): written by the
@@ -237,7 +236,6 @@ static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
     if (lw > rw) rw = lw;
     if (int e = t_alloc(t, &t->red_ws, rw + 16)) return e;
     if (int e = t_alloc(t, &t->dvec, (int64_t)B * c.num_heads * T)) return e;
-    if (int e = t_alloc(t, &t->ffn_colpart, (int64_t)gemm_train_colpart_rows((int)BT) * F)) return e;
     t->attn_colpart = nullptr;
     if (attention_bf16_supported((int)(H / c.num_heads)))
         if (int e = t_alloc(t, &t->attn_colpart, (int64_t)attention_colpart_rows(B, T) * 3 * H)) return e;
@@ -496,8 +494,7 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
     const bool attn16 = sh && attention_bf16_supported(H / c.num_heads);
     auto gemm = [&](const float* A, const uint16_t* A16, int64_t lda, int64_t strideA, const float* Bw, int64_t ldb, float* Cc,
                     uint16_t* C16, int64_t ldc, int64_t strideC, const float* bias, const float* res, int M, int N, int K,
-                    int nbatch, int act_, const GemmTrainEpi* epi = nullptr) -> int {
-        W2V2_REQUIRE(!epi || sh, "train_forward: a training epilogue without the bf16 shadows");
+                    int nbatch, int act_) -> int {
         if (w2v2_use_split_gemm(m, A, lda, strideA, ldb, M, N, K, nbatch)) {      // precision mode 2 (gemm_split.hip)
             const uint16_t* planes = nullptr;
             if (int e = w2v2_split_planes(m, Bw, K, N, s, &planes)) return e;
@@ -505,12 +502,10 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
         }
         if (!sh) return launch_gemm(pf, A, lda, strideA, Bw, ldb, Cc, ldc, strideC, bias, res, M, N, K, nbatch, act_, s);
         GemmShadows x;
-        x.A16 = A16; x.B16 = m->w16[Bw]; x.C16 = C16; x.ldb16 = K; x.epi = epi;
+        x.A16 = A16; x.B16 = m->w16[Bw]; x.C16 = C16; x.ldb16 = K;
         return launch_gemm_bf16_x(pf, A, lda, strideA, Bw, ldb, 0, Cc, ldc, strideC, bias, res, M, N, K, nbatch, act_, x, s);
     };
     auto S16 = [&](uint16_t* p16) -> uint16_t* { return sh ? p16 : nullptr; };
-    // can this Dense layer's GEMM take a training epilogue?  (shadows on => both operands stream as bf16: w2v2_ensure_shadows)
-    auto epi_ok = [&](int M, int N, int K) { return sh && K % 64 == 0 && gemm_train_epilogue_ok(M, N, K, N); };
     const int NC = c.num_conv_layers;
 
     // ---- frozen feature extractor: identical to inference (no dropout inside, feature_extractor.py:54-59) ----
@@ -613,18 +608,11 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
                                              H, c.num_heads, tr, s))
             return e;
         // o = ctx Wo + bo;  t1 = dropout(o) + x   (encoder.py:116-119)
-        if ((gemm_train_epilogue_sites() & 2) && attn16 && epi_ok((int)BT, H, H)) {         // dropout and the residual add ride in the GEMM's epilogue
-            GemmTrainEpi ep;
-            ep.mode = 1; ep.p = p; ep.seed = seed; ep.stream = layer_stream(i, 1);
-            if (int e = gemm(nullptr, l.ctx16, H, 0, m->P(b + "/attention/out_proj/kernel"), H, l.t1, nullptr, H, 0,
-                             m->P(b + "/attention/out_proj/bias"), x, (int)BT, H, H, 1, 0, &ep))
-                return e;
-        } else {
-            if (int e = gemm(l.ctx, attn16 ? l.ctx16 : nullptr, H, 0, m->P(b + "/attention/out_proj/kernel"), H, m->t0, nullptr, H, 0,
-                             m->P(b + "/attention/out_proj/bias"), nullptr, (int)BT, H, H, 1, 0))
-                return e;
-            if (int e = launch_dropout_fwd(m->t0, x, l.t1, BT * H, 0, p, seed, layer_stream(i, 1), s)) return e;
-        }
+        // (dropout + residual as their own pass: folded into this GEMM's epilogue they were measured slower, study section 12 / r03)
+        if (int e = gemm(l.ctx, attn16 ? l.ctx16 : nullptr, H, 0, m->P(b + "/attention/out_proj/kernel"), H, m->t0, nullptr, H, 0,
+                         m->P(b + "/attention/out_proj/bias"), nullptr, (int)BT, H, H, 1, 0))
+            return e;
+        if (int e = launch_dropout_fwd(m->t0, x, l.t1, BT * H, 0, p, seed, layer_stream(i, 1), s)) return e;
         // postnorm: t2 = LN1(t1) feeds the FFN and is its residual; prenorm: t2 = LN2(t1) feeds the FFN, t1 is the residual
         const char* ln_a = prenorm ? "/final_layer_norm" : "/layer_norm";
         if (int e = launch_layer_norm_x(pf, l.t1, l.t2, m->P(b + ln_a + "/gamma"), m->P(b + ln_a + "/beta"), BT, H, eps, 0, S16(l.t2_16), s)) return e;
@@ -633,18 +621,10 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
         if (l.keep != 0.f) {
             // u = t2 W1 + b1;  gd = dropout(GELU(u));  out = res + keep * (gd W2 + b2)   (encoder.py:127-130)
             // (ffn16_only: every reader of gd -- the next GEMM, and the down-projection's weight gradient -- streams the bf16 shadow)
-            if ((gemm_train_epilogue_sites() & 1) && sh && epi_ok((int)BT, F, H)) {         // GELU and dropout ride in the epilogue; u is kept in fp32 for the backward
-                GemmTrainEpi ep;
-                ep.mode = 1; ep.act = act_ew; ep.p = p; ep.seed = seed; ep.stream = layer_stream(i, 2); ep.pre = l.u;
-                if (int e = gemm(l.t2, l.t2_16, H, 0, m->P(b + "/feed_forward/intermediate_dense/kernel"), F, ffn16_only ? nullptr : l.gd, l.gd16, F, 0,
-                                 m->P(b + "/feed_forward/intermediate_dense/bias"), nullptr, (int)BT, F, H, 1, 0, &ep))
-                    return e;
-            } else {
-                if (int e = gemm(l.t2, S16(l.t2_16), H, 0, m->P(b + "/feed_forward/intermediate_dense/kernel"), F, l.u, nullptr, F, 0,
-                                 m->P(b + "/feed_forward/intermediate_dense/bias"), nullptr, (int)BT, F, H, 1, 0))
-                    return e;
-                if (int e = launch_dropout_fwd_x(l.u, nullptr, ffn16_only ? nullptr : l.gd, S16(l.gd16), BT * F, act_ew, p, seed, layer_stream(i, 2), s)) return e;
-            }
+            if (int e = gemm(l.t2, S16(l.t2_16), H, 0, m->P(b + "/feed_forward/intermediate_dense/kernel"), F, l.u, nullptr, F, 0,
+                             m->P(b + "/feed_forward/intermediate_dense/bias"), nullptr, (int)BT, F, H, 1, 0))
+                return e;
+            if (int e = launch_dropout_fwd_x(l.u, nullptr, ffn16_only ? nullptr : l.gd, S16(l.gd16), BT * F, act_ew, p, seed, layer_stream(i, 2), s)) return e;
             if (int e = gemm(ffn16_only ? nullptr : l.gd, S16(l.gd16), F, 0, m->P(b + "/feed_forward/output_dense/kernel"), H, ffn_out, nullptr, H, 0,
                              m->P(b + "/feed_forward/output_dense/bias"), ffn_res, (int)BT, H, F, 1, 0))
                 return e;
@@ -695,8 +675,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     const bool shb = m->precision == 1 && w2v2_shadows_enabled(m) && m->w16_valid;
     // A16: the producer's bf16 shadow of A (or null): with it both operands stream by LDS-DMA (gemm_bf16.hip source 5)
     auto gemm_dx = [&](const float* A, const uint16_t* A16, int64_t lda, const float* WT, const float* W, float* Cc, int64_t ldc,
-                       const float* res, int M, int N, int K, hipStream_t st, uint16_t* C16 = nullptr, const GemmTrainEpi* epi = nullptr) -> int {
-        W2V2_REQUIRE(!epi || (shb && m->w16p.find(W) != m->w16p.end()), "train_backward: a training epilogue without the weight's bf16 shadow");
+                       const float* res, int M, int N, int K, hipStream_t st, uint16_t* C16 = nullptr) -> int {
         // (C16: bf16 shadow of the result, only from the shadow branch -- callers ask for it only when `dx_shadowed(W)`)
         if (shb) {
             auto it = m->w16p.find(W);
@@ -706,7 +685,6 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
                 x.C16 = C16;
                 x.B16 = it->second;
                 x.ldb16 = K;
-                x.epi = epi;
                 return launch_gemm_bf16_x(m->prof, A, lda, 0, WT, N, 0, Cc, ldc, 0, nullptr, res, M, N, K, 1, 0, x, st);
             }
         }
@@ -831,24 +809,13 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         return W2V2_OK;
     };
 
-    // dgd = dY W2^T (the down-projection's data gradient), then du = dropout-backward(dgd) * GELU'(u) with its column sums (the
-    // up-projection's bias gradient).  Where du is wanted only as bf16 the second step rides in the GEMM's epilogue and dgd never
-    // reaches memory; otherwise the GEMM writes dgd to t->gf and the element-wise kernel follows.
+    // dgd = dY W2^T (the down-projection's data gradient) into t->gf, then du = dropout-backward(dgd) * GELU'(u) with its column sums
+    // (the up-projection's bias gradient) as one element-wise pass.  (In round 2 that pass rode in the GEMM's epilogue; with the GEMM
+    // on the 128 x 256 kernel the separate pass at the HBM roofline is faster: profiles/r03_gemm_bf16_study.md.)
     auto ffn_hidden_grad = [&](int i, LayerSave& l, const std::string& b, const float* dy, const uint16_t* dy16, bool du16_only, float* gb1,
                                bool* b1_done) -> int {
         const float* W2 = m->P(b + "/feed_forward/output_dense/kernel");
         *b1_done = false;
-        if ((gemm_train_epilogue_sites() & 4) && du16_only && dy16 && s16f && dx_shadowed(W2) && gemm_train_epilogue_ok((int)BT, F, H, F)) {
-            GemmTrainEpi ep;
-            ep.mode = 2; ep.act = act_ew; ep.p = p; ep.seed = seed; ep.stream = layer_stream(i, 2); ep.u = l.u;
-            ep.colpart = gb1 ? t->ffn_colpart : nullptr;
-            if (int e = gemm_dx(nullptr, dy16, H, l.W2T, W2, nullptr, F, nullptr, (int)BT, F, H, s, s16f, &ep)) return e;
-            if (gb1) {
-                if (int e = launch_colsum_fold(t->ffn_colpart, gb1, gemm_train_colpart_rows((int)BT), F, s)) return e;
-                *b1_done = true;
-            }
-            return W2V2_OK;
-        }
         if (int e = gemm_dx(dy, dy16, H, l.W2T, W2, t->gf, F, nullptr, (int)BT, F, H, s)) return e;
         return dropout_bwd_bias(l.u, t->gf, du16_only ? nullptr : t->gf, s16f, BT, F, act_ew, layer_stream(i, 2), gb1, b1_done);
     };
