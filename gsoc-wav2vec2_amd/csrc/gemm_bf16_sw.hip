@@ -148,7 +148,98 @@ __device__ __forceinline__ void sw_epilogue_bf16(const f32x16 (&acc)[4][2], uint
 #undef SW_ST4
 }
 
-template <bool TRACE, bool PRIO = true>
+// ---- fp32 epilogue through LDS (outputs that stay fp32: the residual stream, the data gradients).  From registers a lane writes
+// 128 single dwords (2 rows x 128 B per store instruction) and reads the residual the same way; here the wave's tile goes through its
+// 16 KiB of LDS in two halves of 64 rows as a row-major fp32 image (ds_write_b32: 32 consecutive dwords per half-wave), comes back
+// as 16 bytes of one row per lane (ds_read_b128, 4 whole 256-byte rows per instruction), and residual loads, fp32 stores (16 B per
+// lane) and the optional bf16 shadow (8 B per lane) all move whole rows.  Same element arithmetic in the same order as
+// gemm_epilogue: (acc + bias) -> act -> + residual.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+template <int ACT>
+__device__ __forceinline__ void sw_epilogue_f32(const f32x16 (&acc)[4][2], float* __restrict__ C, uint16_t* __restrict__ C16,
+                                                const float* __restrict__ R, const float* __restrict__ bias, int ldc, unsigned wbase, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    const unsigned wr0 = wbase + (unsigned)(4 * lh) * 256u + (unsigned)li * 4u;      // register r adds ((r & 3) + 8 (r >> 2)) rows
+    const int row_l = lane >> 4, ch = lane & 15;                                     // read side: row 4 t + row_l, 16-byte chunk ch
+    const unsigned rd0 = wbase + (unsigned)row_l * 256u + (unsigned)ch * 16u;
+    float bv[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) bv[nt] = bias ? bias[nt * 32 + li] : 0.0f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (h == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // (the first half's reads have retired)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh) {
+                f32x16 v = acc[2 * h + mh][nt];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += bv[nt];
+                if constexpr (ACT == 1) {
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2_t t = gelu_erf_fast2(f32x2_t{v[r], v[r + 1]});
+                        v[r] = t[0];
+                        v[r + 1] = t[1];
+                    }
+                } else if constexpr (ACT == 2) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = gelu_tanh(v[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned a = wr0 + (unsigned)(mh * 32 + (r & 3) + 8 * (r >> 2)) * 256u + (unsigned)nt * 128u;
+                    asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v[r]) : "memory");
+                }
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int64_t rbase = (int64_t)(64 * h + row_l) * ldc + 4 * ch;
+        // 16 reads of 4 rows each, in groups of four: residual loads (counted by the compiler) go out beside the LDS reads
+#define SW_F32_GROUP(TG)                                                                                                          \
+    {                                                                                                                             \
+        f32x4 x0, x1, x2, x3;                                                                                                     \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x0) : "v"(rd0), "n"((4 * (TG) + 0) * 1024));                          \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x1) : "v"(rd0), "n"((4 * (TG) + 1) * 1024));                          \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x2) : "v"(rd0), "n"((4 * (TG) + 2) * 1024));                          \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x3) : "v"(rd0), "n"((4 * (TG) + 3) * 1024));                          \
+        f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0, r2 = r0, r3 = r0;                                                               \
+        if (R) {                                                                                                                  \
+            r0 = *reinterpret_cast<const f32x4*>(R + rbase + (int64_t)(4 * (4 * (TG) + 0)) * ldc);                                \
+            r1 = *reinterpret_cast<const f32x4*>(R + rbase + (int64_t)(4 * (4 * (TG) + 1)) * ldc);                                \
+            r2 = *reinterpret_cast<const f32x4*>(R + rbase + (int64_t)(4 * (4 * (TG) + 2)) * ldc);                                \
+            r3 = *reinterpret_cast<const f32x4*>(R + rbase + (int64_t)(4 * (4 * (TG) + 3)) * ldc);                                \
+        }                                                                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));                                            \
+        SW_F32_OUT(x0, r0, 4 * (TG) + 0)                                                                                          \
+        SW_F32_OUT(x1, r1, 4 * (TG) + 1)                                                                                          \
+        SW_F32_OUT(x2, r2, 4 * (TG) + 2)                                                                                          \
+        SW_F32_OUT(x3, r3, 4 * (TG) + 3)                                                                                          \
+    }
+#define SW_F32_OUT(X, RR, T)                                                                                                      \
+    {                                                                                                                             \
+        const f32x4 o = R ? (X) + (RR) : (X);                                                                                     \
+        const int64_t off = rbase + (int64_t)(4 * (T)) * ldc;                                                                     \
+        if (C) *reinterpret_cast<f32x4*>(C + off) = o;                                                                            \
+        if (C16) {                                                                                                                \
+            u32x2 pk;                                                                                                             \
+            pk[0] = pack_bf16_rne(o[0], o[1]);                                                                                    \
+            pk[1] = pack_bf16_rne(o[2], o[3]);                                                                                    \
+            *reinterpret_cast<u32x2*>(C16 + off) = pk;                                                                            \
+        }                                                                                                                         \
+    }
+        SW_F32_GROUP(0)
+        SW_F32_GROUP(1)
+        SW_F32_GROUP(2)
+        SW_F32_GROUP(3)
+#undef SW_F32_GROUP
+#undef SW_F32_OUT
+    }
+}
+
+// EK: the epilogue this instance carries (one per instance: with all of them inlined into one kernel their pointers and strides stay
+// live across the K loop and the allocator starts parking registers in scratch): 0 = from registers (ragged row tiles, odd strides),
+// 1 + act = bf16-only output through LDS, 4 + act = fp32 output (+ residual, + bf16 shadow) through LDS.
+template <bool TRACE, bool PRIO = true, int EK = 0>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_sw_kernel(GemmSWArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sw_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -366,16 +457,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_sw_kernel(GemmSWArgs g) {
 
     // ---- epilogue: bias -> act -> + residual -> fp32 store and / or bf16 shadow
     const int64_t tile_off = (int64_t)z * g.strideC + (int64_t)m0 * g.ldc + (n0 + wave * 64);
-    if (g.C16 && !g.C && !g.residual && g.M - m0 >= 128 && (g.ldc & 7) == 0) {
-        uint16_t* const c16 = g.C16 + tile_off;
-        const float* const bw = g.bias ? g.bias + (n0 + wave * 64) : nullptr;
-        const unsigned wb = lds0 + (unsigned)wave * 16384u;
-        if (g.act == 0) sw_epilogue_bf16<0>(acc, c16, bw, (int)g.ldc, wb, lane);
-        else if (g.act == 1) sw_epilogue_bf16<1>(acc, c16, bw, (int)g.ldc, wb, lane);
-        else sw_epilogue_bf16<2>(acc, c16, bw, (int)g.ldc, wb, lane);
+    const bool whole = g.M - m0 >= 128;                               // (block-uniform; ragged last row tiles take the register epilogue)
+    const float* const bw = g.bias ? g.bias + (n0 + wave * 64) : nullptr;
+    const unsigned wb = lds0 + (unsigned)wave * 16384u;
+    if (EK >= 1 && EK <= 3 && whole) {
+        sw_epilogue_bf16<EK - 1>(acc, g.C16 + tile_off, bw, (int)g.ldc, wb, lane);
+    } else if (EK >= 4 && whole) {
+        sw_epilogue_f32<EK - 4>(acc, g.C + tile_off, g.C16 ? g.C16 + tile_off : nullptr, g.residual ? g.residual + tile_off : nullptr, bw, (int)g.ldc, wb,
+                                lane);
     } else {
         gemm_epilogue<4, 2, true>(acc, g.C ? g.C + tile_off : nullptr, g.C16 ? g.C16 + tile_off : nullptr, g.residual ? g.residual + tile_off : nullptr,
-                                  g.bias ? g.bias + (n0 + wave * 64) : nullptr, (int)g.ldc, g.M - m0, g.N - (n0 + wave * 64), g.act, li, lh);
+                                  bw, (int)g.ldc, g.M - m0, g.N - (n0 + wave * 64), g.act, li, lh);
     }
 #ifdef W2V2_TUNING
     SW_TRC();
@@ -387,6 +479,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_sw_kernel(GemmSWArgs g) {
 #endif
 #undef SW_TRC
 #undef SW_TIE_ALL
+}
+
+template <bool TRACE, int EK>
+int launch_sw(GemmSWArgs& g, dim3 grid, hipStream_t s) {
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set) {
+        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_sw_kernel<TRACE, true, EK>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_sw_kernel<TRACE, true, EK>), grid, dim3(256), SW_LDS, s, g);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
 }
 
 }  // namespace
@@ -412,33 +516,23 @@ int launch_gemm_bf16_sw(const uint16_t* A16, int64_t lda, int64_t strideA, const
     g.M = M; g.N = N; g.K = K; g.act = act;
     g.tiles_m = (M + SW_BM - 1) / SW_BM;
     g.tiles_n = N / SW_BN;
-    static std::atomic<bool> attr_set{false};
-    if (!attr_set) {
-        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_sw_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS));
-#ifdef W2V2_TUNING
-        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_sw_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS));
-        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_sw_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS));
-#endif
-        attr_set = true;
-    }
+    // which epilogue: bf16-only and fp32 outputs go through LDS when the strides allow 16-byte row pieces
+    const int ek = (C16 && !C && !residual && ldc % 8 == 0) ? 1 + act : (C && ldc % 4 == 0 && (!C16 || ldc % 4 == 0)) ? 4 + act : 0;
     dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch);
 #ifdef W2V2_TUNING
     g.trace = g_tune_trace;
     g.abl = tune_int("W2V2_PP_ABL", 0);
-    if (g.trace) {
-        hipLaunchKernelGGL(gemm_bf16_sw_kernel<true>, grid, dim3(256), SW_LDS, s, g);
-        W2V2_HIP_CHECK(hipGetLastError());
-        return W2V2_OK;
-    }
-    if (!tune_int("W2V2_PP_PRIO", 1)) {
-        hipLaunchKernelGGL((gemm_bf16_sw_kernel<false, false>), grid, dim3(256), SW_LDS, s, g);
-        W2V2_HIP_CHECK(hipGetLastError());
-        return W2V2_OK;
-    }
+    if (g.trace) return launch_sw<true, 0>(g, grid, s);          // (the traced instance keeps the register epilogue)
 #endif
-    hipLaunchKernelGGL(gemm_bf16_sw_kernel<false>, grid, dim3(256), SW_LDS, s, g);
-    W2V2_HIP_CHECK(hipGetLastError());
-    return W2V2_OK;
+    switch (ek) {
+        case 1: return launch_sw<false, 1>(g, grid, s);
+        case 2: return launch_sw<false, 2>(g, grid, s);
+        case 3: return launch_sw<false, 3>(g, grid, s);
+        case 4: return launch_sw<false, 4>(g, grid, s);
+        case 5: return launch_sw<false, 5>(g, grid, s);
+        case 6: return launch_sw<false, 6>(g, grid, s);
+        default: return launch_sw<false, 0>(g, grid, s);
+    }
 }
 
 }  // namespace w2v2
