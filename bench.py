@@ -266,17 +266,22 @@ def golden_rows(L):
     return wave, logits
 
 
-def measured_traffic():
-    """HBM bytes per GEMM launch from the committed rocprofv3 --pmc summary of this same command
-    (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction; tools/prof_summary.py)."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
+def measured_traffic(precision="fp32", mode="forward"):
+    """HBM bytes per launch of the dominant GEMM family, from the committed rocprofv3 --pmc summaries of this same command
+    (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction: tools/prof_summary.py for fp32, tools/pmc_bench.sh
+    for the bf16 family: launch-weighted mean over its kernels).  Committed numbers, not measured in this run."""
     try:
-        with open(path) as f:
-            js = json.load(f)
-        hits = [v for k, v in js.items() if "gemm_f32" in k]
-        if hits:
-            v = max(hits, key=lambda e: e.get("launches", 0))       # the 128x128 kernel, not the small-problem variant
-            return round(v["fetch_corrected_bytes"] + v["write_bytes"])
+        if precision == "fp32":
+            with open(os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")) as f:
+                js = json.load(f)
+            hits = [v for k, v in js.items() if "gemm_f32" in k]
+            if hits:
+                v = max(hits, key=lambda e: e.get("launches", 0))       # the 128x128 kernel, not the small-problem variant
+                return round(v["fetch_corrected_bytes"] + v["write_bytes"])
+        elif precision == "bf16":
+            with open(os.path.join(ROOT, "profiles", "hbm_traffic_bf16.json")) as f:
+                js = json.load(f)[mode]
+            return round(js["fetch_corrected_bytes_per_launch"] + js["write_bytes_per_launch"])
     except (OSError, ValueError, KeyError):
         pass
     return None
@@ -485,11 +490,12 @@ def main():
             peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16x3": round(PEAK_BF16_MFMA_TFLOPS / 6, 1)}[args.precision]
             res["roofline"] = {
                 "kernel": ("gemm_f32_dma_kernel (fp32 MFMA 32x32x2, LDS-DMA staged: conv1-6 implicit GEMM + all Dense layers)" if args.precision == "fp32"
-                           else "gemm_bf16_kernel (bf16 MFMA 32x32x16; operands from bf16 shadows or fp32 rounded on the way into LDS: conv1-6 + all Dense)"
+                           else "gemm_bf16 family (bf16 MFMA 32x32x16, operands from bf16 shadows by LDS-DMA: gemm_bf16_sw_kernel 128x256 software-pipelined "
+                                "for the large shapes, gemm_bf16_kernel 128x128 for the rest, gemm_bf16_tr_kernel for weight gradients: conv1-6 + all Dense)"
                            if args.precision == "bf16" else
                            "gemm_split_kernel (fp32 GEMM as 6 bf16 MFMA 32x32x16 products of exact 3-term operand splits; peak = bf16 dense peak / 6)"),
                 "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": measured_traffic() if args.precision == "fp32" else None,
+                "frac": round(ach / peak, 4), "traffic": measured_traffic(args.precision, args.mode) if (args.model, B, L) == ("base", 32, 246000) else None,
                 "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
                 "launches_per_step": gm.get("issued", gm["launches"]) // max(1, args.steps),
                 "avg_launch_ms": round(gm["ms"] / max(1, gm["launches"]), 4),

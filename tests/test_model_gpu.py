@@ -76,10 +76,16 @@ def test_logits_match_golden(torch_mod, name):
 # output by ulp_bf16(x) * |w| ~ 6e-3, and every later layer re-rounds the difference.  So the model-level bar is
 # bf16-sized, and the bit-level claim is made where inputs are identical: the GEMM itself (test_ops_gpu.py) and
 # each conv layer fed with the build's own previous activation (below).
-ATOL_BF16_LOGITS = 0.10      # measured (round 2): 0.026-0.050 vs the rounded-operand oracle, 0.043-0.072 vs HF fp64
+# Where the error comes from (profiles/r03_bf16_error_budget.md, the oracle in fp64 with ONE contraction family rounded at a time, on
+# the BASELINE-size fixture): conv stack 4.3e-2, out-projection 3.5e-2, FFN up 3.4e-2, FFN down 2.9e-2, attention core 2.7e-2,
+# q|k|v 2.4e-2, lm_head 1.8e-2, projection 1.2e-2 -- independent contributions that add up (root-sum-square 8.2e-2) to the 7.8e-2 ... 8.4e-2
+# the oracle itself shows with everything rounded.  No single stage pays for it: the figure is the mode's definition.
+# Bars = 1.5 x the measured values of rounds 2-3 (max |logits - HF fp64|, max |logits - rounded-operand oracle|):
+BF16_LOGIT_BARS = {"tiny_base": (0.105, 0.042), "tiny_robust": (0.088, 0.063), "base_sample_unpadded": (0.109, 0.066),
+                   "robust_masked": (0.067, 0.042), "base_sample_padded": (0.155, 0.10)}      # measured padded: 0.084 ... 0.103 vs HF fp64
 
 
-@pytest.mark.parametrize("name", ["tiny_base", "tiny_robust", "base_sample_unpadded", "robust_masked"])
+@pytest.mark.parametrize("name", ["tiny_base", "tiny_robust", "base_sample_unpadded", "robust_masked", "base_sample_padded"])
 def test_bf16_precision_logits(torch_mod, name):
     g = H.golden(name)
     m, cfg = build(name)
@@ -98,8 +104,12 @@ def test_bf16_precision_logits(torch_mod, name):
     report(f"{name}/bf16_logits_vs_rounded_oracle", err)
     report(f"{name}/bf16_logits_vs_hf_f64", cost)
     assert np.isfinite(got).all()
-    assert err < ATOL_BF16_LOGITS and cost < ATOL_BF16_LOGITS
+    bar_hf, bar_oracle = BF16_LOGIT_BARS[name]
+    assert err < bar_oracle and cost < bar_hf, (err, cost)
     assert H.max_err(got, fp32) > 1e-5     # the mode really changes the arithmetic
+    if name == "base_sample_padded":       # the BASELINE-size fixture adds the model-level numbers; the teacher-forced stage checks
+        m.set_precision("fp32")            # below run on the four smaller cases (fp64 oracle convolutions over 2 x 246000 samples)
+        return
     # teacher-forced conv stack: same fp32 input => same bf16 operands => only the accumulation order differs
     acts = [m.activation(f"conv{i}") for i in range(len(cfg.kernal_sizes))]
     for i in range(1, len(cfg.kernal_sizes)):
@@ -129,7 +139,7 @@ def test_bf16_precision_logits(torch_mod, name):
     assert np.array_equal(m(g["wave"], attention_mask=mask).numpy(), fp32)
 
 
-@pytest.mark.parametrize("name", ["tiny_robust", "base_sample_unpadded", "robust_masked"])
+@pytest.mark.parametrize("name", ["tiny_robust", "base_sample_unpadded", "robust_masked", "base_sample_padded"])
 def test_bf16_shadows_do_not_change_results(torch_mod, name):
     """The bf16 shadows (activations written by the producing kernels, weights transposed once) hold exactly what
     the GEMM would round its fp32 operands to, so a forward with the option "bf16_shadows" off gives the same logits and

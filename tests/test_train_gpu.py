@@ -667,9 +667,9 @@ def test_bf16_fine_tune_step_at_full_length(env, case, L, frames):
     (T = 768) and large-robust (24 L / 1024, prenorm, LayerNorm convs, attention mask) at 2 x 480000 (T = 1499), precision
     mode bf16, dropout 0.1 + spec-augment, conv stack frozen.  Checker: the torch-autograd oracle (pinned to HF by
     tests/test_train_oracle_golden.py) with bf16-rounded Dense / Conv1D operands, one layer's T x T tensors alive at a time.
-    Bars are bf16-sized and self-declared (the reference has no mixed precision): logits 0.08 abs, NLL 0.2 %, every
-    gradient within 4 % of its max|g| and 0.5 % on average.  Measured (round 2): logits 3.4e-2 / 3.6e-2, NLL 4e-4 relative,
-    worst gradient 1.6 % / 1.4 % of max|g|, worst mean error 0.23 % / 0.13 % (base / large)."""
+    Bars are bf16-sized and self-declared (the reference has no mixed precision), 1.5 x the measured values: logits 0.054 abs,
+    NLL 0.2 %, every gradient within 3.2 % of its max|g| and 0.35 % on average.  Measured (rounds 2-3): logits 3.4e-2 / 3.6e-2, NLL
+    4e-4 relative, worst gradient 1.1-2.1 % of max|g|, worst mean error 0.23 % / 0.13 % (base / large)."""
     import time
     import wav2vec2
     m, cfg, w = build(case, L)
@@ -695,7 +695,7 @@ def test_bf16_fine_tune_step_at_full_length(env, case, L, frames):
     print(f"{case}: oracle took {time.time() - t0:.1f} s")
     err = H.max_err(logits.cpu().numpy(), ref_logits)
     print(f"{case}: bf16 training logits vs rounded-operand oracle {err:.3e}; nll {nll.cpu().numpy()} vs {ref_nll}")
-    assert err < 0.08
+    assert err < 0.054
     assert np.allclose(nll.cpu().numpy(), ref_nll, rtol=2e-3)
     worst, worst_mean = ("", 0.0), ("", 0.0)
     for name, gref in ref_grads.items():
@@ -712,7 +712,7 @@ def test_bf16_fine_tune_step_at_full_length(env, case, L, frames):
         if d.mean() / scale > worst_mean[1]:
             worst_mean = (name, d.mean() / scale)
     print(f"{case}: worst gradient max-error / max|g| {worst}, worst mean-error / max|g| {worst_mean}")
-    assert worst[1] < 4e-2 and worst_mean[1] < 5e-3
+    assert worst[1] < 3.2e-2 and worst_mean[1] < 3.5e-3
 
 
 def test_new_trainer_is_a_fresh_optimizer(env):

@@ -42,6 +42,22 @@ for k in sorted(acc):
     if "SQ_WAVE_CYCLES" in c:
         d.append("wave-cycle split: waiting (s_waitcnt / barrier) %.2f, issue-stalled %.2f, issuing %.2f" % tuple(c.get(x, 0) / c["SQ_WAVE_CYCLES"] for x in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")))
     lines += [""] + ["* " + x for x in d] + [""]
+# family aggregate: launch-weighted mean over the matching kernels (what bench.py's roofline.traffic quotes)
+import json
+tot = {"launches": 0, "fetch": 0.0, "write": 0.0, "kernels": {}}
+for k in sorted(acc):
+    c = {n: v[0] / max(v[1], 1) for n, v in acc[k].items()}
+    n = max(v[1] for v in acc[k].values())
+    f, w = 2 * c.get("FETCH_SIZE", 0.0) * 1024, c.get("WRITE_SIZE", 0.0) * 1024
+    tot["kernels"][k] = {"launches_per_pass": n, "fetch_corrected_bytes": f, "write_bytes": w}
+    tot["launches"] += n; tot["fetch"] += f * n; tot["write"] += w * n
+if tot["launches"]:
+    js = {"tag": tag, "launches_per_pass": tot["launches"], "fetch_corrected_bytes_per_launch": tot["fetch"] / tot["launches"],
+          "write_bytes_per_launch": tot["write"] / tot["launches"], "kernels": tot["kernels"],
+          "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE (KiB) x 2 = the gfx950 correction of MI355X_MICROARCH.md"}
+    json.dump(js, open(f"{O}/pmc_{tag}.json", "w"), indent=1)
+    lines.append(f"Family aggregate: {tot['launches']} launches per pass, {js['fetch_corrected_bytes_per_launch'] / 1e6:.1f} MB fetched (corrected) + "
+                 f"{js['write_bytes_per_launch'] / 1e6:.1f} MB written per launch")
 open(f"{O}/pmc_{tag}.md", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 PY
