@@ -144,6 +144,9 @@ bool gemm_bf16_sw_ok(int M, int N, int K, int64_t lda, int64_t ldb16, int64_t st
 int launch_gemm_bf16_sw(const uint16_t* A16, int64_t lda, int64_t strideA, const uint16_t* B16, int64_t ldb16, float* C, uint16_t* C16,
                         int64_t ldc, int64_t strideC, const float* bias, const float* residual, int M, int N, int K, int nbatch, int act,
                         hipStream_t s);
+bool gemm_bf16_swtr_ok(int M, int N, int K, int64_t lda, int64_t ldb, int64_t strideA, int64_t strideB);
+int launch_gemm_bf16_swtr(const uint16_t* A16, int64_t lda, int64_t strideA, const uint16_t* B16, int64_t ldb, int64_t strideB, float* C,
+                          int64_t ldc, int64_t strideC, int M, int N, int K, int nbatch, hipStream_t s);
 int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
                        int64_t strideB, float* C, int64_t ldc, int64_t strideC, const float* bias,
                        const float* residual, int M, int N, int K, int nbatch, int act, const GemmShadows& x,

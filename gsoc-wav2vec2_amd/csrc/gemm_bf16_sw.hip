@@ -35,12 +35,12 @@ constexpr int SW_ITEM = 8192, SW_SLOTS = 10, SW_LDS = SW_SLOTS * SW_ITEM;      /
 
 struct GemmSWArgs {
     const uint16_t* A16;
-    const uint16_t* B16;       // (N, K) rows ldb16 apart
+    const uint16_t* B16;       // (N, K) rows ldb16 apart; transposed form: (K, N) rows ldb16 apart, batch stride strideB
     float* C;
     uint16_t* C16;
     const float* bias;
     const float* residual;
-    int64_t lda, ldb16, ldc, strideA, strideC;
+    int64_t lda, ldb16, ldc, strideA, strideC, strideB;
     int M, N, K, act;
     int tiles_m, tiles_n;
 #ifdef W2V2_TUNING
@@ -239,23 +239,43 @@ __device__ __forceinline__ void sw_epilogue_f32(const f32x16 (&acc)[4][2], float
 // EK: the epilogue this instance carries (one per instance: with all of them inlined into one kernel their pointers and strides stay
 // live across the K loop and the allocator starts parking registers in scratch): 0 = from registers (ragged row tiles, odd strides),
 // 1 + act = bf16-only output through LDS, 4 + act = fp32 output (+ residual, + bf16 shadow) through LDS.
-template <bool TRACE, bool PRIO = true, int EK = 0>
+// TR = the weight-gradient form dW = X^T dY: A16 is X (K, M) and B16 is dY (K, N), both with the contraction index as the SLOW
+// dimension.  Items are then 64 k rows x 128 B (A_i: 64 m; B_j a | b: the 32 n of two waves side by side), copied as they lie in
+// memory, and the k-contiguous MFMA fragments come out of the transposing LDS read ds_read_b64_tr_b16 (two per fragment), exactly
+// as in gemm_bf16_tr_kernel -- same products, same order, identical bits.  Everything else (stream, ring, phases) is shared.
+__device__ __forceinline__ int sw_swzk(int row) { return ((row >> 1) & 1) << 1; }      // 16-byte slot swizzle of a k-major image row
+
+template <int OFF>
+__device__ __forceinline__ u32x2 sw_read_tr(unsigned addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+
+template <bool TRACE, bool PRIO = true, int EK = 0, bool TR = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_sw_kernel(GemmSWArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sw_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = wc: the wave's 64-column group
     const int li = lane & 31, lh = lane >> 5;
 
-    // XCD-aware tile order (gemm_f32.hip): each XCD walks a contiguous run of tiles, N fastest
+    // XCD-aware tile order.  Blocks go to the 8 XCDs round-robin in dispatch order (x fastest, then z); the remap runs over the whole
+    // (batch, tile) space so that every XCD owns ONE contiguous run of it whatever the tile count modulo 8 is, and inside a batch the
+    // SHORTER grid dimension is the fastest index: a run then covers an r x c patch of tiles that share r + c operand panels in
+    // that XCD's L2 instead of 1 + r c (forward shapes: N is the short side; weight gradients 768 x 3072: M).
     const int nwg = g.tiles_m * g.tiles_n;
-    int bid = blockIdx.x;
+    int bid, z;
     {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int total = nwg * (int)gridDim.z;
+        int lin = (int)blockIdx.x + nwg * (int)blockIdx.z;
+        const int q = total >> 3, r = total & 7, xcd = lin & 7, idx = lin >> 3;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        z = lin / nwg;
+        bid = lin - z * nwg;
     }
-    const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
+    const bool m_fast = g.tiles_m < g.tiles_n;
+    const int tm = m_fast ? bid % g.tiles_m : bid / g.tiles_n, tn = m_fast ? bid / g.tiles_m : bid % g.tiles_n;
     const int m0 = tm * SW_BM, n0 = tn * SW_BN;
-    const int z = blockIdx.z;
     const int nk = g.K / SW_BK;
 #ifdef W2V2_TUNING
     unsigned long long* const trc = (TRACE && g.trace) ? g.trace + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 32 : nullptr;
@@ -281,24 +301,32 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_sw_kernel(GemmSWArgs g) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int r = (wave * 2 + i) * 8 + (lane >> 3);                       // image row 0 .. 63
-        const uint32_t sl = (uint32_t)(((lane & 7) ^ sw_swz(r)) << 3);        // logical slot, in elements
+        if constexpr (TR) {
+            // image row = k; the 128 bytes of a row are 64 m of A (one run) or 32 n of each of two waves of B (two runs 64 columns apart)
+            const uint32_t ls = (uint32_t)((lane & 7) ^ sw_swzk(r));          // logical 16-byte slot
+            offA[0][i] = offA[1][i] = 2u * ((uint32_t)((int64_t)r * g.lda) + ls * 8u);
+            offB[i] = 2u * ((uint32_t)((int64_t)r * g.ldb16) + (ls >> 2) * 64u + (ls & 3u) * 8u);
+        } else {
+            const uint32_t sl = (uint32_t)(((lane & 7) ^ sw_swz(r)) << 3);    // logical slot, in elements
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            int ar = h * 64 + r;
-            ar = m0 + ar < g.M ? ar : g.M - 1 - m0;
-            offA[h][i] = 2u * ((uint32_t)((int64_t)ar * g.lda) + sl);
+            for (int h = 0; h < 2; ++h) {
+                int ar = h * 64 + r;
+                ar = m0 + ar < g.M ? ar : g.M - 1 - m0;
+                offA[h][i] = 2u * ((uint32_t)((int64_t)ar * g.lda) + sl);
+            }
+            const int bc = (r >> 5) * 64 + (r & 31);                          // column of B_0a's image row r (B_1: + 32, half b: + 128)
+            offB[i] = 2u * ((uint32_t)((int64_t)bc * g.ldb16) + sl);
         }
-        const int bc = (r >> 5) * 64 + (r & 31);                              // column of B_0a's image row r (B_1: + 32, half b: + 128)
-        offB[i] = 2u * ((uint32_t)((int64_t)bc * g.ldb16) + sl);
     }
     auto uniform_ptr = [](const uint16_t* p) {
         const uint64_t v = reinterpret_cast<uint64_t>(p);
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
         return reinterpret_cast<const unsigned char*>(((uint64_t)hi << 32) | lo);
     };
-    const unsigned char* const baseA = uniform_ptr(g.A16 + (int64_t)z * g.strideA + (int64_t)m0 * g.lda);
-    const unsigned char* const baseB = uniform_ptr(g.B16 + (int64_t)n0 * g.ldb16);
-    const int64_t bstep32 = 64 * g.ldb16, bstep128 = 256 * g.ldb16;           // bytes: 32 / 128 columns of B
+    const unsigned char* const baseA = uniform_ptr(TR ? g.A16 + (int64_t)z * g.strideA + m0 : g.A16 + (int64_t)z * g.strideA + (int64_t)m0 * g.lda);
+    const unsigned char* const baseB = uniform_ptr(TR ? g.B16 + (int64_t)z * g.strideB + n0 : g.B16 + (int64_t)n0 * g.ldb16);
+    const int64_t bstep32 = TR ? 64 : 64 * g.ldb16, bstep128 = TR ? 256 : 256 * g.ldb16;      // bytes: 32 / 128 columns of B
+    const int64_t kstepA = TR ? 2 * SW_BK * g.lda : 2 * SW_BK, kstepB = TR ? 2 * SW_BK * g.ldb16 : 2 * SW_BK;      // bytes per K tile
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)sw_smem;
 
     // piece I (0 | 1) of this wave's share of stream item J (= item number mod 6) of K tile `ktile`, into ring slot `slot`
@@ -306,10 +334,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_sw_kernel(GemmSWArgs g) {
         constexpr int J = decltype(Jc)::value, I = decltype(Ic)::value;
         const unsigned dst = lds0 + (unsigned)slot * SW_ITEM + (unsigned)wave * 2048u + (unsigned)I * 1024u;
         if constexpr (J == 0 || J == 5) {
-            sw_dma(dst, offA[J == 0 ? 0 : 1][I], baseA + (int64_t)ktile * (SW_BK * 2));
+            sw_dma(dst, offA[J == 0 ? 0 : 1][I], baseA + (int64_t)ktile * kstepA + ((TR && J == 5) ? 128 : 0));
         } else {
             constexpr int HALF = (J == 2 || J == 4) ? 1 : 0, JB = (J >= 3) ? 1 : 0;      // waves 2-3 | columns + 32
-            sw_dma(dst, offB[I], baseB + (int64_t)ktile * (SW_BK * 2) + HALF * bstep128 + JB * bstep32);
+            sw_dma(dst, offB[I], baseB + (int64_t)ktile * kstepB + HALF * bstep128 + JB * bstep32);
         }
     };
     auto issue = [&](auto Jc, int ktile, int slot) {
@@ -325,12 +353,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_sw_kernel(GemmSWArgs g) {
     for (int ks = 0; ks < 4; ++ks) xk[ks] = x0 + ((32u * ks) ^ y0);
     const unsigned bwave = (unsigned)(wave & 1) * 4096u;           // this wave's 32 rows inside its B item
 
+    // transposed form: a lane supplies the address of 4 consecutive columns (8 B) of k row 8 lh + l16 / 4 (+ 4 for the second
+    // read) and receives 4 k of column 16 grp + l16; slot swizzle = sw_swzk(row) = a per-lane constant (rows step by multiples of 4)
+    const int l16 = lane & 15, grp = (lane >> 4) & 1;
+    const unsigned xtr = lds0 + (unsigned)(8 * lh + (l16 >> 2)) * 128u + (unsigned)(((2 * grp + ((l16 >> 1) & 1)) ^ (2 * ((l16 >> 3) & 1))) << 4) +
+                         8u * (unsigned)(l16 & 1);
     bf16x8 fa[2][2][4];      // [i: 64-row half][rb: 32-row block][ks]
     bf16x8 fb[2][4];         // [j: 32-column half][ks]
+    u32x2 tal[2][2][4], tah[2][2][4], tbl[2][4], tbh[2][4];      // transposed form: the two 4-k halves of each fragment
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         const bf16x8 zero = {};
+        const u32x2 z2 = {0u, 0u};
         fa[0][0][ks] = fa[0][1][ks] = fa[1][0][ks] = fa[1][1][ks] = fb[0][ks] = fb[1][ks] = zero;
+        tal[0][0][ks] = tal[0][1][ks] = tal[1][0][ks] = tal[1][1][ks] = tah[0][0][ks] = tah[0][1][ks] = tah[1][0][ks] = tah[1][1][ks] = z2;
+        tbl[0][ks] = tbl[1][ks] = tbh[0][ks] = tbh[1][ks] = z2;
     }
     f32x16 acc[4][2];
 #pragma unroll
@@ -344,26 +381,57 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_sw_kernel(GemmSWArgs g) {
     auto slot_of = [](int s0, int j) { const int s = s0 + j; return s >= SW_SLOTS ? s - SW_SLOTS : s; };
     auto rd_a = [&](auto Ic, auto KSc, int slot) {          // A_I, k step KS: both 32-row blocks
         constexpr int I = decltype(Ic)::value, KS = decltype(KSc)::value;
-        const unsigned a = xk[KS] + (unsigned)slot * SW_ITEM;
-        fa[I][0][KS] = sw_read<0>(a);
-        fa[I][1][KS] = sw_read<4096>(a);
+        if constexpr (TR) {
+            const unsigned a = xtr + (unsigned)slot * SW_ITEM;
+            tal[I][0][KS] = sw_read_tr<KS * 2048>(a);
+            tah[I][0][KS] = sw_read_tr<KS * 2048 + 512>(a);
+            tal[I][1][KS] = sw_read_tr<KS * 2048 + 64>(a);
+            tah[I][1][KS] = sw_read_tr<KS * 2048 + 576>(a);
+        } else {
+            const unsigned a = xk[KS] + (unsigned)slot * SW_ITEM;
+            fa[I][0][KS] = sw_read<0>(a);
+            fa[I][1][KS] = sw_read<4096>(a);
+        }
     };
     auto rd_b = [&](auto Jc, auto KSc, int slot) {          // B_J, k step KS (slot = this wave's half a | b)
         constexpr int J = decltype(Jc)::value, KS = decltype(KSc)::value;
-        fb[J][KS] = sw_read<0>(xk[KS] + (unsigned)slot * SW_ITEM + bwave);
+        if constexpr (TR) {
+            const unsigned a = xtr + (unsigned)slot * SW_ITEM + (unsigned)(wave & 1) * 64u;
+            tbl[J][KS] = sw_read_tr<KS * 2048>(a);
+            tbh[J][KS] = sw_read_tr<KS * 2048 + 512>(a);
+        } else {
+            fb[J][KS] = sw_read<0>(xk[KS] + (unsigned)slot * SW_ITEM + bwave);
+        }
     };
     auto mm = [&](auto QIc, auto QJc, auto KSc) {
         constexpr int QI = decltype(QIc)::value, QJ = decltype(QJc)::value, KS = decltype(KSc)::value;
-        acc[QI * 2][QJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[QI][0][KS], fb[QJ][KS], acc[QI * 2][QJ], 0, 0, 0);
-        acc[QI * 2 + 1][QJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[QI][1][KS], fb[QJ][KS], acc[QI * 2 + 1][QJ], 0, 0, 0);
+        if constexpr (TR) {
+            union J8 { u32x2 h[2]; bf16x8 v; } a0, a1, b;
+            a0.h[0] = tal[QI][0][KS]; a0.h[1] = tah[QI][0][KS];
+            a1.h[0] = tal[QI][1][KS]; a1.h[1] = tah[QI][1][KS];
+            b.h[0] = tbl[QJ][KS]; b.h[1] = tbh[QJ][KS];
+            acc[QI * 2][QJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.v, b.v, acc[QI * 2][QJ], 0, 0, 0);
+            acc[QI * 2 + 1][QJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v, b.v, acc[QI * 2 + 1][QJ], 0, 0, 0);
+        } else {
+            acc[QI * 2][QJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[QI][0][KS], fb[QJ][KS], acc[QI * 2][QJ], 0, 0, 0);
+            acc[QI * 2 + 1][QJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[QI][1][KS], fb[QJ][KS], acc[QI * 2 + 1][QJ], 0, 0, 0);
+        }
     };
-#define SW_TIE_ALL()                                                                                                              \
-    asm volatile("s_waitcnt lgkmcnt(0)"                                                                                           \
-                 : "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fa[0][0][2]), "+v"(fa[0][0][3]), "+v"(fa[0][1][0]), "+v"(fa[0][1][1]),  \
-                   "+v"(fa[0][1][2]), "+v"(fa[0][1][3]), "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fa[1][0][2]), "+v"(fa[1][0][3]),  \
-                   "+v"(fa[1][1][0]), "+v"(fa[1][1][1]), "+v"(fa[1][1][2]), "+v"(fa[1][1][3]), "+v"(fb[0][0]), "+v"(fb[0][1]),        \
-                   "+v"(fb[0][2]), "+v"(fb[0][3]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[1][2]), "+v"(fb[1][3])                     \
-                 :: "memory")
+#define SW_TIE24(P, X, Y)                                                                                                           \
+    asm volatile(P : "+v"(X[0][0][0]), "+v"(X[0][0][1]), "+v"(X[0][0][2]), "+v"(X[0][0][3]), "+v"(X[0][1][0]), "+v"(X[0][1][1]),            \
+                 "+v"(X[0][1][2]), "+v"(X[0][1][3]), "+v"(X[1][0][0]), "+v"(X[1][0][1]), "+v"(X[1][0][2]), "+v"(X[1][0][3]),                \
+                 "+v"(X[1][1][0]), "+v"(X[1][1][1]), "+v"(X[1][1][2]), "+v"(X[1][1][3]), "+v"(Y[0][0]), "+v"(Y[0][1]),                      \
+                 "+v"(Y[0][2]), "+v"(Y[0][3]), "+v"(Y[1][0]), "+v"(Y[1][1]), "+v"(Y[1][2]), "+v"(Y[1][3]) :: "memory")
+    // wait for every fragment read in flight and pin the fragment registers behind the wait (the MFMAs cannot move above it)
+#define SW_TIE_ALL()                                                                                                                \
+    do {                                                                                                                            \
+        if constexpr (TR) {                                                                                                         \
+            SW_TIE24("s_waitcnt lgkmcnt(0)", tal, tbl);                                                                             \
+            SW_TIE24("", tah, tbh);                                                                                                 \
+        } else {                                                                                                                    \
+            SW_TIE24("s_waitcnt lgkmcnt(0)", fa, fb);                                                                               \
+        }                                                                                                                           \
+    } while (0)
 
     // One phase of K tile kt (s0 = ring slot of its item 0).  Q: quadrant; VM: vmcnt before the barrier (-1: none); NI: items to
     // request (0 .. 2); READ: the items this phase reads exist.  What a phase requests is fixed by its position: the slots freed by
@@ -460,9 +528,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_sw_kernel(GemmSWArgs g) {
     const bool whole = g.M - m0 >= 128;                               // (block-uniform; ragged last row tiles take the register epilogue)
     const float* const bw = g.bias ? g.bias + (n0 + wave * 64) : nullptr;
     const unsigned wb = lds0 + (unsigned)wave * 16384u;
-    if (EK >= 1 && EK <= 3 && whole) {
+    if (!TR && EK >= 1 && EK <= 3 && whole) {
         sw_epilogue_bf16<EK - 1>(acc, g.C16 + tile_off, bw, (int)g.ldc, wb, lane);
-    } else if (EK >= 4 && whole) {
+    } else if (!TR && EK >= 4 && whole) {
         sw_epilogue_f32<EK - 4>(acc, g.C + tile_off, g.C16 ? g.C16 + tile_off : nullptr, g.residual ? g.residual + tile_off : nullptr, bw, (int)g.ldc, wb,
                                 lane);
     } else {
@@ -479,6 +547,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_sw_kernel(GemmSWArgs g) {
 #endif
 #undef SW_TRC
 #undef SW_TIE_ALL
+#undef SW_TIE24
 }
 
 template <bool TRACE, int EK>
@@ -506,13 +575,41 @@ bool gemm_bf16_sw_ok(int M, int N, int K, int64_t lda, int64_t ldb16, int64_t st
            128 * lda < (1 << 29) && 256 * ldb16 < (1 << 29);
 }
 
+// Weight-gradient form: C_z (M, N) = A16_z^T B16_z with A16 (K, M) rows lda apart and B16 (K, N) rows ldb apart, K rows per batch.
+bool gemm_bf16_swtr_ok(int M, int N, int K, int64_t lda, int64_t ldb, int64_t strideA, int64_t strideB) {
+    return M >= 128 && M % 128 == 0 && N >= 256 && N % 256 == 0 && K % 64 == 0 && K >= 192 && lda % 8 == 0 && ldb % 8 == 0 && strideA % 8 == 0 &&
+           strideB % 8 == 0 && 64 * lda < (1 << 29) && 64 * ldb < (1 << 29);
+}
+
+int launch_gemm_bf16_swtr(const uint16_t* A16, int64_t lda, int64_t strideA, const uint16_t* B16, int64_t ldb, int64_t strideB, float* C,
+                          int64_t ldc, int64_t strideC, int M, int N, int K, int nbatch, hipStream_t s) {
+    W2V2_REQUIRE(A16 && B16 && C && gemm_bf16_swtr_ok(M, N, K, lda, ldb, strideA, strideB), "gemm_bf16_swtr: unsupported operands");
+    GemmSWArgs g;
+    g.A16 = A16; g.B16 = B16; g.C = C; g.C16 = nullptr; g.bias = nullptr; g.residual = nullptr;
+    g.lda = lda; g.ldb16 = ldb; g.ldc = ldc; g.strideA = strideA; g.strideC = strideC; g.strideB = strideB;
+    g.M = M; g.N = N; g.K = K; g.act = 0;
+    g.tiles_m = M / SW_BM;
+    g.tiles_n = N / SW_BN;
+#ifdef W2V2_TUNING
+    g.trace = nullptr; g.abl = 0;
+#endif
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set) {
+        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_sw_kernel<false, true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_sw_kernel<false, true, 0, true>), dim3(g.tiles_m * g.tiles_n, 1, nbatch), dim3(256), SW_LDS, s, g);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
 int launch_gemm_bf16_sw(const uint16_t* A16, int64_t lda, int64_t strideA, const uint16_t* B16, int64_t ldb16, float* C, uint16_t* C16,
                         int64_t ldc, int64_t strideC, const float* bias, const float* residual, int M, int N, int K, int nbatch, int act,
                         hipStream_t s) {
     W2V2_REQUIRE(A16 && B16 && (C || C16) && gemm_bf16_sw_ok(M, N, K, lda, ldb16, strideA), "gemm_bf16_sw: unsupported operands");
     GemmSWArgs g;
     g.A16 = A16; g.B16 = B16; g.C = C; g.C16 = C16; g.bias = bias; g.residual = residual;
-    g.lda = lda; g.ldb16 = ldb16; g.ldc = ldc; g.strideA = strideA; g.strideC = strideC;
+    g.lda = lda; g.ldb16 = ldb16; g.ldc = ldc; g.strideA = strideA; g.strideC = strideC; g.strideB = 0;
     g.M = M; g.N = N; g.K = K; g.act = act;
     g.tiles_m = (M + SW_BM - 1) / SW_BM;
     g.tiles_n = N / SW_BN;

@@ -921,11 +921,14 @@ uint32_t w2v2_crc32c_extend(uint32_t crc, const void* data, uint64_t n) {
     return c ^ 0xFFFFFFFFu;
 }
 int w2v2_op_weight_grad_bf16(const uint16_t* x16, const uint16_t* dy16, float* slabs, int64_t rows, int32_t Kin, int32_t Nout,
-                             int32_t rows_per_slab, int32_t nslabs, void* stream) {
+                             int32_t rows_per_slab, int32_t nslabs, int32_t variant, void* stream) {
     W2V2_REQUIRE(x16 && dy16 && slabs && rows > 0 && rows_per_slab > 0 && nslabs > 0 && Kin % 128 == 0 && Nout % 128 == 0 &&
-                     rows_per_slab % 64 == 0, "op_weight_grad_bf16: bad argument");
+                     rows_per_slab % 64 == 0 && variant >= 0 && variant <= 2, "op_weight_grad_bf16: bad argument");
+    W2V2_REQUIRE(variant != 2 || (rows == (int64_t)rows_per_slab * nslabs &&
+                                  gemm_bf16_swtr_ok(Kin, Nout, rows_per_slab, Kin, Nout, (int64_t)rows_per_slab * Kin, (int64_t)rows_per_slab * Nout)),
+                 "op_weight_grad_bf16: variant 2 needs whole slabs, Nout %% 256 == 0 and at least 192 rows per slab");
     GemmShadows x;
-    x.transA = true; x.A16 = x16; x.B16p = dy16;
+    x.transA = true; x.A16 = x16; x.B16p = dy16; x.force_kernel = variant;
     x.validK = rows == (int64_t)rows_per_slab * nslabs ? 0 : rows;
     return launch_gemm_bf16_x(nullptr, nullptr, Kin, (int64_t)rows_per_slab * Kin, nullptr, Nout, (int64_t)rows_per_slab * Nout, slabs, Nout,
                               (int64_t)Kin * Nout, nullptr, nullptr, Kin, Nout, rows_per_slab, nslabs, 0, x, reinterpret_cast<hipStream_t>(stream));

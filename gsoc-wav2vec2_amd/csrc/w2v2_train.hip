@@ -322,7 +322,10 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
         // B T = 23984): the first Mq = kq floor(M / kq) rows go through the fast path in S equal slabs, S a divisor of
         // Mq / kq, and the R = M - Mq < kq leftover rows form one more slab on the guarded kernel (0.2 % of the work).
         // (Before this, such an M fell back to ONE guarded GEMM over all rows: 256 tiles, K = 23984.)
-        const int64_t tiles = (int64_t)((Kin + 127) / 128) * ((Nout + 127) / 128);
+        // (tiles as the kernel that will run counts them: with both bf16 shadows, whole rows and Nout % 256 == 0 the weight gradient
+        //  takes the 128 x 256 software-pipelined kernel, which has half as many tiles to spread over the 512 block slots)
+        const bool wide_tiles = direct && A16 && dY16 && Kin % 128 == 0 && Nout % 256 == 0 && M % kq == 0;
+        const int64_t tiles = (int64_t)((Kin + 127) / 128) * (wide_tiles ? Nout / 256 : (Nout + 127) / 128);
         // slabs cost a reduction pass each: the bf16 kernels are happiest with ONE block per resident slot (512),
         // the fp32 one wants ~4 to balance its long tiles (183.8 vs 189.4 ms)
         const int dwb = tune_int("W2V2_DW_BLOCKS", 512);      // 512 -> 40.0 ms per step, 1024 -> 40.5, 256 -> 47.0 (base, 32 x 246000)

@@ -302,9 +302,12 @@ int w2v2_op_gemm_bf16_at(const float* At_dev, int64_t lda, int64_t strideA,
  * [z rows_per_slab, (z + 1) rows_per_slab) of x16 (rows, Kin) and dy16 (rows, Nout), uint16 bf16 bit patterns, row-major.  `rows`
  * need not fill the last slab (nor be a multiple of the 64-row K tile): rows past it count as zero, every slab must own at least
  * one row.  Kin % 128 == 0, Nout % 128 == 0, rows_per_slab % 64 == 0, 16-byte aligned operands.  (The fine-tune step's dW GEMMs
- * in W2V2_PRECISION_BF16: tf.GradientTape's kernel gradient of Dense, src/main.py:198.) */
+ * in W2V2_PRECISION_BF16: tf.GradientTape's kernel gradient of Dense, src/main.py:198.)
+ * variant: 0 = the kernel the library would pick, 1 = the 128 x 128-tile transposing-read kernel, 2 = the 128 x 256 software-pipelined
+ * kernel in its transposed form (whole slabs, Nout % 256 == 0, >= 192 rows per slab); identical bits. */
 int w2v2_op_weight_grad_bf16(const uint16_t* x16_dev, const uint16_t* dy16_dev, float* slabs_dev,
-                             int64_t rows, int32_t Kin, int32_t Nout, int32_t rows_per_slab, int32_t nslabs, void* stream);
+                             int64_t rows, int32_t Kin, int32_t Nout, int32_t rows_per_slab, int32_t nslabs, int32_t variant,
+                             void* stream);
 
 /* CRC-32C (Castagnoli; TFRecord and TensorFlow-checkpoint checksums, tensorflow/core/lib/hash/crc32c.h: crc32c::Extend) of `n` host
  * bytes continuing from `crc` (0 to start).  Host-only helper for the package's checkpoint / record I/O: no device work. */

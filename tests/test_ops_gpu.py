@@ -353,13 +353,41 @@ def test_weight_grad_bf16_ragged_rows(env, rows, Kin, Nout, per, S):
     assert 0 <= pad < per
     x16, y16 = dev16(Xr, pad), dev16(Yr, pad)
     out = torch.full((S, Kin, Nout), float("nan"), device=dev)
-    N.check(lib.w2v2_op_weight_grad_bf16(N.ptr(x16), N.ptr(y16), N.ptr(out), rows, Kin, Nout, per, S, stream()))
+    N.check(lib.w2v2_op_weight_grad_bf16(N.ptr(x16), N.ptr(y16), N.ptr(out), rows, Kin, Nout, per, S, 0, stream()))
     got = out.cpu().numpy()
     for z in range(S):
         ref = Xr[z * per:(z + 1) * per].astype(np.float64).T @ Yr[z * per:(z + 1) * per].astype(np.float64)
         assert H.max_err(got[z], ref) < 2e-5 * max(1.0, np.abs(ref).max()), z
     # an empty slab is an error, not silent zeros
-    assert lib.w2v2_op_weight_grad_bf16(N.ptr(x16), N.ptr(y16), N.ptr(out), max(1, per * (S - 1)), Kin, Nout, per, S, stream()) == -1 or S == 1
+    assert lib.w2v2_op_weight_grad_bf16(N.ptr(x16), N.ptr(y16), N.ptr(out), max(1, per * (S - 1)), Kin, Nout, per, S, 0, stream()) == -1 or S == 1
+
+
+@pytest.mark.parametrize("rows,Kin,Nout,S", [(192, 128, 256, 1), (1024, 768, 768, 4), (1536, 256, 2304, 3), (2048, 3072, 768, 2)])
+def test_weight_grad_bf16_kernels_agree_bit_for_bit(env, rows, Kin, Nout, S):
+    """dW = X^T dY from the bf16 copies of both operands has two kernels: 128 x 128 tiles (gemm_bf16_tr_kernel) and the 128 x 256
+    software-pipelined kernel in its transposed form (k-major items, ds_read_b64_tr_b16 fragments).  Identical bits per slab, both
+    equal to the exact products of the bf16 operands up to fp32 accumulation order; an asymmetric pattern catches a swapped
+    operand, k half or column group."""
+    lib, torch, dev = env
+    X, dY = rnd("wg2X", (rows, Kin)), rnd("wg2Y", (rows, Nout), 0.3)
+    X[:, 5] += 3.0; dY[:, Nout - 7] -= 2.0                        # mark one row of dW^T and one column
+    Xr, Yr = O.round_bf16(X), O.round_bf16(dY)
+    x16 = torch.from_numpy((Xr.view(np.uint32) >> 16).astype(np.uint16).view(np.int16)).to(dev)
+    y16 = torch.from_numpy((Yr.view(np.uint32) >> 16).astype(np.uint16).view(np.int16)).to(dev)
+    per = rows // S
+    outs = {}
+    for variant in (1, 2, 0):
+        out = torch.full((S, Kin, Nout), float("nan"), device=dev)
+        N.check(lib.w2v2_op_weight_grad_bf16(N.ptr(x16), N.ptr(y16), N.ptr(out), rows, Kin, Nout, per, S, variant, stream()), "w2v2_op_weight_grad_bf16")
+        torch.cuda.synchronize()
+        outs[variant] = out
+    assert torch.equal(outs[1], outs[2]) and torch.equal(outs[1], outs[0])
+    got = outs[2].cpu().numpy()
+    for z in range(S):
+        ref = Xr[z * per:(z + 1) * per].astype(np.float64).T @ Yr[z * per:(z + 1) * per].astype(np.float64)
+        assert H.max_err(got[z], ref) < 2e-5 * max(1.0, np.abs(ref).max()), z
+    # variant 2 cannot take ragged rows: an error, not a silent fallback
+    assert lib.w2v2_op_weight_grad_bf16(N.ptr(x16), N.ptr(y16), N.ptr(outs[0]), rows - 8, Kin, Nout, per, S, 2, stream()) == -1
 
 
 @pytest.mark.parametrize("rows,Kin,Nout,S", [(256, 128, 132, 1), (512, 768, 64, 4), (1024, 132, 256, 8)])
