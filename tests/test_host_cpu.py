@@ -462,3 +462,40 @@ def test_from_pretrained_download_failure_is_the_reference_error(monkeypatch):
     with pytest.raises(ValueError, match="Couldn't download model weights from https://huggingface.co/no-such-org/no-such-model"):
         wav2vec2.Wav2Vec2ForCTC.from_pretrained("no-such-org/no-such-model")
     assert hasattr(wav2vec2.Wav2Vec2ForCTC, "push_to_hub")
+
+
+def test_bench_self_launch_builds_the_driver_command(monkeypatch):
+    """`python bench.py --gpus N` without a launcher re-runs itself under torch.distributed.run (one rank per GPU, rendezvous on
+    127.0.0.1 at a free port) with its own arguments: the form the driver uses for N > 1, so a plain `--gpus 8` cannot fail at
+    argument parsing."""
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1", "--precision", "bf16", "--mode", "train"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as exc:
+        bench.main()
+    assert exc.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    i = cmd.index(os.path.join(root, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "3", "--warmup", "1", "--precision", "bf16", "--mode", "train"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # under the launcher (WORLD_SIZE set) it does NOT spawn again: it goes on to the device check
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    seen.clear()
+    with pytest.raises((SystemExit, AssertionError, RuntimeError)):
+        bench.main()
+    assert "cmd" not in seen

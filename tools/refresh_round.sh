@@ -1,18 +1,23 @@
 #!/bin/bash
-# End-of-round evidence on the GPU box (through gpurun, from the repo root): the full -m gpu suite, the bench lines of every
-# reported configuration, and rocprofv3 kernel stats of the two fine-tune steps.  Everything lands under gpurun_out/final/.
+# End-of-round evidence on the GPU box (through gpurun, from the repo root): the full -m gpu suite, smoke(), the bench lines of every
+# reported configuration, and rocprofv3 kernel stats of the forward benches and the two fine-tune steps.  Everything lands under
+# gpurun_out/final/; tools/collect_profiles.py copies the summaries into profiles/ with the round's prefix.
 set -u
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/final; mkdir -p $O; cd $R
 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1; tail -3 $O/gpu_tests.log
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -6 $O/smoke.log
 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
 python bench.py --precision bf16 --no-cpu-baseline > $O/bench_bf16_n1.json 2>/dev/null
+python bench.py --precision bf16x3 --no-cpu-baseline > $O/bench_bf16x3_n1.json 2>/dev/null
 python bench.py --mode train --precision bf16 --no-cpu-baseline > $O/bench_bf16_train_n1.json 2>/dev/null
 python bench.py --mode train --no-cpu-baseline > $O/bench_train_n1.json 2>/dev/null
 python bench.py --mode train --precision bf16 --model large-robust --batch 16 --samples 480000 --no-cpu-baseline --steps 8 --warmup 3 > $O/bench_large_robust_bf16_train_n1.json 2>/dev/null
 python bench.py --precision bf16 --model large-robust --batch 16 --samples 480000 --no-cpu-baseline --steps 8 --warmup 3 > $O/bench_large_robust_bf16_n1.json 2>/dev/null
 python bench.py --model large-robust --batch 16 --samples 246000 --no-cpu-baseline --steps 5 --warmup 2 > $O/bench_large_robust_fwd_n1.json 2>/dev/null
-for f in $O/bench_*.json; do echo "$(basename $f): $(grep -o '"ms_per_step": [0-9.]*' $f | head -1)"; done
+for f in $O/bench_*.json; do echo "$(basename $f): $(grep -o '"ms_per_step": [0-9.]*' $f | head -1) $(grep -o '"frac": [0-9.]*' $f | head -1)"; done
+bash tools/prof_one.sh fwd_f32
+bash tools/prof_one.sh fwd_bf16 --precision bf16
 bash tools/prof_one.sh train_bf16 --mode train --precision bf16 --steps 5 --warmup 2
 bash tools/prof_one.sh train_lr_bf16 --mode train --precision bf16 --model large-robust --batch 16 --samples 480000 --steps 3 --warmup 1
-cp gpurun_out/stats_train_bf16.md gpurun_out/stats_train_lr_bf16.md $O/ 2>/dev/null
+cp gpurun_out/stats_fwd_f32.md gpurun_out/stats_fwd_bf16.md gpurun_out/stats_train_bf16.md gpurun_out/stats_train_lr_bf16.md $O/ 2>/dev/null
