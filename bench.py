@@ -42,15 +42,17 @@ PEAK_HBM_GBS = 8000.0
 
 _CPU_WORKER = r"""
 import os, sys, time
+pin = {pin!r}
+if pin:
+    os.sched_setaffinity(0, pin)                   # one disjoint set of physical cores (one NUMA node) per worker -- BEFORE numpy is
+for v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):      # imported: the BLAS creates its worker threads at load
+    os.environ[v] = str({nt})                      # time, and only threads created after the call inherit the affinity
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "gsoc-wav2vec2_amd"))
 import numpy as np
 from threadpoolctl import threadpool_limits
 from oracle import w2v2_oracle as O
 from wav2vec2 import variables as V
 from wav2vec2.config import Wav2Vec2Config
-pin = {pin!r}
-if pin:
-    os.sched_setaffinity(0, pin)                   # one disjoint set of physical cores (one NUMA node) per worker
 cfg = Wav2Vec2Config(); w = dict(np.load({weights!r}))
 x = V.hash_normal("bench/cpu", {L}, {seed}).reshape(1, {L})
 with threadpool_limits(limits={nt}):

