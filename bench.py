@@ -67,9 +67,11 @@ with threadpool_limits(limits={nt}):
 
 
 def _core_sets(workers, width):
-    """`workers` disjoint lists of `width` logical CPUs, one hardware thread per PHYSICAL core, each list inside one NUMA
-    node (nodes filled round-robin so the workers spread over all memory channels), drawn from this process's allowed
-    CPUs.  Returns fewer lists than asked when the host has fewer whole sets; [] when the topology cannot be read."""
+    """`workers` disjoint lists of logical CPUs covering `width` PHYSICAL cores each -- every allowed hardware thread of those
+    cores, so a worker's BLAS threads and its element-wise pool threads (oracle: one pool thread per usable CPU) each find a
+    hardware thread; pinned to one thread per core the two pools fought over 16 CPUs and the leg ran 4x slower than unpinned --
+    each list inside one NUMA node (nodes filled round-robin so the workers spread over all memory channels), drawn from this
+    process's allowed CPUs.  Returns fewer lists than asked when the host has fewer whole sets; [] when the topology cannot be read."""
     try:
         allowed = sorted(os.sched_getaffinity(0))
     except (AttributeError, OSError):
@@ -82,26 +84,40 @@ def _core_sets(workers, width):
         except OSError:
             return None
 
-    by_node, seen = {}, set()
+    by_node, threads = {}, {}
     for cpu in allowed:
         base = f"/sys/devices/system/cpu/cpu{cpu}"
         core, pkg = read(f"{base}/topology/core_id"), read(f"{base}/topology/physical_package_id")
         if core is None:
             return []
-        if (pkg, core) in seen:                        # an SMT sibling of a core already taken
+        if (pkg, core) in threads:                     # an SMT sibling of a core already listed: it travels with that core
+            threads[(pkg, core)].append(cpu)
             continue
-        seen.add((pkg, core))
+        threads[(pkg, core)] = [cpu]
         node = next((d[4:] for d in (os.listdir(base) if os.path.isdir(base) else []) if d.startswith("node") and d[4:].isdigit()), pkg)
-        by_node.setdefault(node, []).append(cpu)
+        by_node.setdefault(node, []).append((pkg, core))
     pools = [by_node[k] for k in sorted(by_node, key=str)]
     sets, progressed = [], True
     while len(sets) < workers and progressed:
         progressed = False
         for pool in pools:
             if len(sets) < workers and len(pool) >= width:
-                sets.append([pool.pop(0) for _ in range(width)])
+                sets.append(sorted(c for _ in range(width) for c in threads[pool.pop(0)]))
                 progressed = True
     return sets
+
+
+def _ranges(cpus):
+    """[0, 1, 2, 128, 129, 130] -> '0-2,128-130'"""
+    out, cpus = [], sorted(cpus)
+    i = 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else f"{cpus[i]}-{cpus[j]}")
+        i = j + 1
+    return ",".join(out)
 
 
 def _cpu_model():
@@ -223,7 +239,7 @@ def cpu_baseline(cfg, weights, L, wave_row0=None):
             legs["aggregate"] = {"workers": procs, "threads_each": best_nt, "forwards_each": reps, "wall_s": round(wall, 3),
                                  "audio_s_per_s": round(procs * reps * L / SAMPLE_RATE / wall, 2),
                                  "pinned": bool(pins), "cpus_per_worker_seen": sorted({int(s[2]) for s in spans}),
-                                 "pin_sets": [f"{p[0]}-{p[-1]}" for p in pins] if pins else None}
+                                 "pin_sets": [_ranges(p) for p in pins] if pins else None}
         except Exception as exc:                                       # noqa: BLE001 -- reported, not hidden
             legs["aggregate"] = {"workers": procs, "threads_each": best_nt, "error": repr(exc)[:300]}
         finally:
@@ -313,6 +329,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="rows per GPU")
     ap.add_argument("--samples", type=int, default=246000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="run only the CPU leg (no GPU needed) and print its object")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra bf16x3 measurement printed beside the headline")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--model", choices=["base", "large-robust"], default="base",
@@ -325,6 +342,16 @@ def main():
                     help="forward = BASELINE configs[1] (the headline metric); train = one CTC fine-tune step "
                          "(BASELINE configs[2] shape, fp32: forward + CTC + backward + gradient all-reduce + Adam)")
     args = ap.parse_args()
+
+    if args.cpu_baseline_only:
+        # the cpu_baseline object alone (host cores only; the same call the N = 1 fp32 forward line makes after its timed region)
+        sys.path.insert(0, os.path.join(ROOT, "gsoc-wav2vec2_amd"))
+        import wav2vec2
+        from wav2vec2 import variables as V
+        cfg = wav2vec2.Wav2Vec2Config()
+        gold_wave, _ = golden_rows(args.samples)
+        print(json.dumps({"cpu_baseline": cpu_baseline(cfg, V.seeded_weights(cfg, seed=0), args.samples, None if gold_wave is None else gold_wave[0])}))
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU under

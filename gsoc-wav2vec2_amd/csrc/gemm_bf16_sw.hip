@@ -165,6 +165,30 @@ __device__ __forceinline__ void sw_epilogue_f32(const f32x16 (&acc)[4][2], float
     float bv[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) bv[nt] = bias ? bias[nt * 32 + li] : 0.0f;
+    // The residual rows of a half (16 loads of 16 bytes per lane) are requested BEFORE that half's trip through LDS -- those of the
+    // second half while the first half's rows are still being read back -- so their HBM latency runs under the LDS traffic.  (First
+    // version: four loads at a time beside the four LDS reads that needed them; a phase trace of the FFN down-projection showed the
+    // epilogue at 27 k cycles with the block alone on its CU: eight exposed round trips.)  Asm loads (scalar base + one 32-bit lane
+    // offset) so that they stay where they are written, retired by counted waits: vmcnt is in order on gfx950, and what may still be
+    // in flight behind the four loads a group needs are the later loads already requested and at least one store per row group
+    // already written.  Order: 8 loads | first half's LDS writes | 8 loads | row groups 0, 1 | the second half's 16 loads | groups 2, 3
+    // | second half's LDS writes | its four groups -> 12, 12, 28, 28 requests may stay in flight for the first half's groups, 20 for
+    // each of the second's.  (More loads up front made the allocator spill load destinations -- which the compiler then stores
+    // before they have landed; tools/scratch_scan.sh guards the instance against that.)
+    f32x4 rr[2][16];
+    const unsigned rrow = ((unsigned)row_l * (unsigned)ldc + 4u * (unsigned)ch) * 4u;     // byte offset inside the wave's tile (< 2^32: ldc < 2^23)
+    const uint64_t rbits = reinterpret_cast<uint64_t>(R);
+    const char* const Rs = reinterpret_cast<const char*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(rbits >> 32)) << 32) |
+                                                         (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)rbits));   // (R is wave-uniform; the builtin returns int: no sign extension into the high word)
+#define SW_F32_RES(H, T0, T1)                                                                                                     \
+    if (R) {                                                                                                                      \
+        _Pragma("unroll") for (int t = (T0); t < (T1); ++t)                                                                       \
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rr[H][t]) : "v"(rrow), "s"(Rs + (size_t)(64 * (H) + 4 * t) * (size_t)ldc * 4u) : "memory"); \
+    }
+    asm volatile("" : "+v"(bv[0]), "+v"(bv[1]));      // (the bias has landed before the counted loads start: the compiler's own wait for it would drain them)
+    constexpr int EARLY = ACT == 0 ? 8 : 0;      // (an activation's temporaries leave no room for loads in flight next to all 128 accumulators)
+    SW_F32_RES(0, 0, EARLY)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         if (h == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // (the first half's reads have retired)
@@ -192,9 +216,13 @@ __device__ __forceinline__ void sw_epilogue_f32(const f32x16 (&acc)[4][2], float
                     asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v[r]) : "memory");
                 }
             }
+        if (h == 0) {
+            SW_F32_RES(0, EARLY, 16)
+            __builtin_amdgcn_sched_barrier(0);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const int64_t rbase = (int64_t)(64 * h + row_l) * ldc + 4 * ch;
-        // 16 reads of 4 rows each, in groups of four: residual loads (counted by the compiler) go out beside the LDS reads
+        // 16 reads of 4 rows each, in groups of four
 #define SW_F32_GROUP(TG)                                                                                                          \
     {                                                                                                                             \
         f32x4 x0, x1, x2, x3;                                                                                                     \
@@ -202,22 +230,23 @@ __device__ __forceinline__ void sw_epilogue_f32(const f32x16 (&acc)[4][2], float
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x1) : "v"(rd0), "n"((4 * (TG) + 1) * 1024));                          \
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x2) : "v"(rd0), "n"((4 * (TG) + 2) * 1024));                          \
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x3) : "v"(rd0), "n"((4 * (TG) + 3) * 1024));                          \
-        f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0, r2 = r0, r3 = r0;                                                               \
-        if (R) {                                                                                                                  \
-            r0 = *reinterpret_cast<const f32x4*>(R + rbase + (int64_t)(4 * (4 * (TG) + 0)) * ldc);                                \
-            r1 = *reinterpret_cast<const f32x4*>(R + rbase + (int64_t)(4 * (4 * (TG) + 1)) * ldc);                                \
-            r2 = *reinterpret_cast<const f32x4*>(R + rbase + (int64_t)(4 * (4 * (TG) + 2)) * ldc);                                \
-            r3 = *reinterpret_cast<const f32x4*>(R + rbase + (int64_t)(4 * (4 * (TG) + 3)) * ldc);                                \
-        }                                                                                                                         \
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));                                            \
-        SW_F32_OUT(x0, r0, 4 * (TG) + 0)                                                                                          \
-        SW_F32_OUT(x1, r1, 4 * (TG) + 1)                                                                                          \
-        SW_F32_OUT(x2, r2, 4 * (TG) + 2)                                                                                          \
-        SW_F32_OUT(x3, r3, 4 * (TG) + 3)                                                                                          \
+        if (R) {                                                                                                                  \
+            if (h == 0 && (TG) < 2)                                                                                               \
+                asm volatile("s_waitcnt vmcnt(12)" : "+v"(rr[h][4 * (TG) + 0]), "+v"(rr[h][4 * (TG) + 1]), "+v"(rr[h][4 * (TG) + 2]), "+v"(rr[h][4 * (TG) + 3])); \
+            else if (h == 0)                                                                                                      \
+                asm volatile("s_waitcnt vmcnt(28)" : "+v"(rr[h][4 * (TG) + 0]), "+v"(rr[h][4 * (TG) + 1]), "+v"(rr[h][4 * (TG) + 2]), "+v"(rr[h][4 * (TG) + 3])); \
+            else                                                                                                                  \
+                asm volatile("s_waitcnt vmcnt(20)" : "+v"(rr[h][4 * (TG) + 0]), "+v"(rr[h][4 * (TG) + 1]), "+v"(rr[h][4 * (TG) + 2]), "+v"(rr[h][4 * (TG) + 3])); \
+        }                                                                                                                         \
+        SW_F32_OUT(x0, 4 * (TG) + 0)                                                                                              \
+        SW_F32_OUT(x1, 4 * (TG) + 1)                                                                                              \
+        SW_F32_OUT(x2, 4 * (TG) + 2)                                                                                              \
+        SW_F32_OUT(x3, 4 * (TG) + 3)                                                                                              \
     }
-#define SW_F32_OUT(X, RR, T)                                                                                                      \
+#define SW_F32_OUT(X, T)                                                                                                          \
     {                                                                                                                             \
-        const f32x4 o = R ? (X) + (RR) : (X);                                                                                     \
+        const f32x4 o = R ? (X) + rr[h][T] : (X);                                                                                 \
         const int64_t off = rbase + (int64_t)(4 * (T)) * ldc;                                                                     \
         if (C) *reinterpret_cast<f32x4*>(C + off) = o;                                                                            \
         if (C16) {                                                                                                                \
@@ -229,11 +258,16 @@ __device__ __forceinline__ void sw_epilogue_f32(const f32x16 (&acc)[4][2], float
     }
         SW_F32_GROUP(0)
         SW_F32_GROUP(1)
+        if (h == 0) {
+            SW_F32_RES(1, 0, 16)
+            __builtin_amdgcn_sched_barrier(0);
+        }
         SW_F32_GROUP(2)
         SW_F32_GROUP(3)
 #undef SW_F32_GROUP
 #undef SW_F32_OUT
     }
+#undef SW_F32_RES
 }
 
 // EK: the epilogue this instance carries (one per instance: with all of them inlined into one kernel their pointers and strides stay
@@ -619,7 +653,15 @@ int launch_gemm_bf16_sw(const uint16_t* A16, int64_t lda, int64_t strideA, const
 #ifdef W2V2_TUNING
     g.trace = g_tune_trace;
     g.abl = tune_int("W2V2_PP_ABL", 0);
-    if (g.trace) return launch_sw<true, 0>(g, grid, s);          // (the traced instance keeps the register epilogue)
+    if (g.trace) {                                               // traced instances of the epilogues the model's large shapes use
+        if (tune_int("W2V2_TRACE_EPI", 1) == 0) return launch_sw<true, 0>(g, grid, s);
+        switch (ek) {
+            case 1: return launch_sw<true, 1>(g, grid, s);
+            case 2: return launch_sw<true, 2>(g, grid, s);
+            case 4: return launch_sw<true, 4>(g, grid, s);
+            default: return launch_sw<true, 0>(g, grid, s);
+        }
+    }
 #endif
     switch (ek) {
         case 1: return launch_sw<false, 1>(g, grid, s);

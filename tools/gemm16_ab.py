@@ -60,7 +60,8 @@ if not args.time_only:
 B = 32; BT = B * 768
 SHAPES = {"qkv": (BT, 2304, 768, 768, 0, 1, 0, False, True, False), "out": (BT, 768, 768, 768, 0, 1, 0, True, False, True),
           "ffn1": (BT, 3072, 768, 768, 0, 1, 1, False, True, False), "ffn2": (BT, 768, 3072, 3072, 0, 1, 0, True, False, True),
-          "qkv_dx": (BT, 768, 2304, 2304, 0, 1, 0, True, True, False),
+          "qkv_dx": (BT, 768, 2304, 2304, 0, 1, 0, True, True, False), "ffn1_dx": (BT, 768, 3072, 3072, 0, 1, 0, True, True, False),
+          "ffn2_dx": (BT, 3072, 768, 768, 0, 1, 0, True, False, False),
           "conv1": (24599, 512, 1536, 1024, 49199 * 512, B, 1, False, True, False), "conv3": (6149, 512, 1536, 1024, 12299 * 512, B, 1, False, True, False),
           "conv5": (1537, 512, 1024, 1024, 3074 * 512, B, 1, False, True, False), "proj": (BT, 768, 512, 512, 0, 1, 0, True, False, False)}
 def timeit(fn, iters):
@@ -71,7 +72,7 @@ def timeit(fn, iters):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
-print(f"{'shape':8s} {'128x128':>14s}  " + "  ".join(f"128x256 sw (prio {p})" for p in args.prio.split(",")))
+print(f"{'shape':8s} {'128x128':>16s} {'128x256 sw':>18s} {'auto (row split)':>18s}   auto == 128x128 bits")
 for name, (M, Nn, K, lda, sA, nb, act, f32o, b16o, res) in SHAPES.items():
     A16, B16, bias, R = make(M, Nn, K, lda, sA, nb, f32o, b16o, res)
     Cf = torch.empty(nb * M * Nn, device=dev) if f32o else None
@@ -81,15 +82,18 @@ for name, (M, Nn, K, lda, sA, nb, act, f32o, b16o, res) in SHAPES.items():
     def call():
         N.check(lib.w2v2_op_gemm_bf16_shadows(N.ptr(A16), lda, sA, N.ptr(B16), N.ptr(Cf), N.ptr(Ch), Nn, M * Nn, N.ptr(bias), N.ptr(R), M, Nn, K, nb, act, variant[0], st))
     fl = 2.0 * M * Nn * K * nb
-    variant[0] = 1
-    t0 = timeit(call, args.iters)
-    cols = []
-    for d in ("-",):
-        for p in args.prio.split(","):
-            os.environ.update(W2V2_PP_PRIO=p)
-            variant[0] = 2
-            t1 = timeit(call, args.iters)
-            cols.append(f"{t1 * 1e3:7.1f} us {fl / t1 / 1e9:5.0f} TF")
-    variant[0] = 1
-    t0b = timeit(call, args.iters)
-    print(f"{name:8s} {min(t0, t0b) * 1e3:7.1f} us {fl / min(t0, t0b) / 1e9:5.0f} TF  " + "  ".join(cols))
+    ts = {}
+    for rep in range(2):
+        for v in (1, 2, 0):
+            variant[0] = v
+            t = timeit(call, args.iters)
+            ts[v] = min(ts.get(v, 1e9), t)
+    outs = {}
+    for v in (1, 0):
+        variant[0] = v
+        if Cf is not None: Cf.fill_(float("nan"))
+        call(); torch.cuda.synchronize()
+        outs[v] = (Cf.clone() if Cf is not None else None, Ch.clone() if Ch is not None else None)
+    same = all(a is None or torch.equal(a.view(torch.int32 if a.dtype == torch.float32 else torch.int16), b.view(torch.int32 if b.dtype == torch.float32 else torch.int16))
+               for a, b in zip(outs[1], outs[0]))
+    print(f"{name:8s} " + " ".join(f"{ts[v] * 1e3:7.1f} us {fl / ts[v] / 1e9:5.0f} TF" for v in (1, 2, 0)) + f"   {'identical' if same else 'DIFFERENT'}")
