@@ -120,6 +120,26 @@ def _ranges(cpus):
     return ",".join(out)
 
 
+def _cpu_quota():
+    """CPUs' worth of time this container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited.  The MI355X boxes
+    expose 256 logical CPUs but run the job under a 16-CPU quota: more runnable threads than that are throttled, which is why
+    OpenBLAS "gets slower" past 16 threads there and why concurrent workers do not add throughput."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = float(f.read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def _cpu_model():
     model, phys = "unknown CPU", set()
     try:
@@ -165,6 +185,8 @@ def cpu_baseline(cfg, weights, L, wave_row0=None):
     ncpu = os.cpu_count() or 1
     model, phys = _cpu_model()
     phys = phys or max(1, ncpu // 2)
+    quota = _cpu_quota()
+    usable = phys if quota is None else max(1, min(phys, int(quota)))      # cores' worth of CPU time this job can actually burn
     rows = [V.hash_normal("bench/cpu", L, i) for i in range(8)]
     if wave_row0 is not None:
         rows[0] = np.asarray(wave_row0, np.float32)
@@ -200,7 +222,7 @@ def cpu_baseline(cfg, weights, L, wave_row0=None):
     legs["B=8"] = {"best_s": round(b8, 4), "median_s": round(m8, 4), "runs": runs8, "threads": nt8,
                    "audio_s_per_s_best": round(8 * L / SAMPLE_RATE / b8, 2), "audio_s_per_s_median": round(8 * L / SAMPLE_RATE / m8, 2)}
     # -- leg 3: fill the host: W concurrent single-utterance workers of the probed width, timed forwards started together
-    procs = int(os.environ.get("W2V2_CPU_WORKERS", 0)) or max(1, min(16, phys // best_nt))
+    procs = int(os.environ.get("W2V2_CPU_WORKERS", 0)) or max(1, min(16, usable // best_nt))
     pins = _core_sets(procs, best_nt)                 # pinned: unpinned workers migrate and share memory channels
     if pins:
         procs = len(pins)
@@ -252,7 +274,9 @@ def cpu_baseline(cfg, weights, L, wave_row0=None):
                 except OSError:
                     pass
     else:
-        legs["aggregate"] = {"workers": 1, "note": f"{phys} physical cores / {best_nt} BLAS threads leaves room for one worker only"}
+        legs["aggregate"] = {"workers": 1, "note": f"{usable} usable cores ({phys} physical, cgroup quota {quota}) / {best_nt} BLAS threads leaves room for one "
+                                                   "worker only: concurrent workers would share the same quota (measured on this pool: 8 pinned workers x 16 "
+                                                   "threads = 21.4 audio-s/s against 21.4 for one)"}
     cands = [(legs["B=1"]["audio_s_per_s_best"], best_nt, "B=1"), (legs["B=8"]["audio_s_per_s_best"], nt8, "B=8")]
     if "audio_s_per_s" in legs["aggregate"]:
         cands.append((legs["aggregate"]["audio_s_per_s"], procs * best_nt, "aggregate"))
@@ -265,7 +289,7 @@ def cpu_baseline(cfg, weights, L, wave_row0=None):
         "sample": f"CPU restatement of the reference path (numpy oracle; TensorFlow not run), wav2vec2-base fp32, L = {L}: "
                   f"value = best leg ({which}); legs: B=1 and B=8 best / median of 5 after 1 warm-up, plus an aggregate of "
                   f"concurrent single-utterance workers; BLAS width probed {sorted(probe)} -> {best_nt}",
-        "cpu_model": model, "host_cpus": ncpu, "physical_cores": phys,
+        "cpu_model": model, "host_cpus": ncpu, "physical_cores": phys, "cgroup_cpu_quota": quota,
         "blas_probe_s": {str(k): round(v, 4) for k, v in probe.items()},
         "legs": legs,
         "reference_published": "1.10 (TF jit) / 2.58 (TF eager) / 3.71 (ONNX) audio-s/s at L = 50000, B = 1, Colab CPU (BASELINE.md section 1)",

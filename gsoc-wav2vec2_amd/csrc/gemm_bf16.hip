@@ -830,13 +830,15 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
         const int tr = tune_int("W2V2_GEMM16_TR", 1);
         if (tr && kfast && C && x.A16 && x.B16p && !x.colsum && !x.overlapA && M % 128 == 0 && N % 128 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
             strideA % 8 == 0 && strideB % 8 == 0 && ((reinterpret_cast<uintptr_t>(x.A16) | reinterpret_cast<uintptr_t>(x.B16p)) & 15) == 0) {
-            ProfScope ps(prof, FAM_GEMM_BF16, 2.0 * M * (double)N * K * nbatch, nbatch * (2.0 * K * ((double)M + N) + 4.0 * (double)M * N), s);
+            const double krows = (double)K * nbatch + 64.0 * x.kextra;          // rows of the K dimension over all slabs
+            ProfScope ps(prof, FAM_GEMM_BF16, 2.0 * M * (double)N * krows, 2.0 * krows * ((double)M + N) + nbatch * 4.0 * (double)M * N, s);
             // every row exists and the columns fill 256-wide tiles: the 128 x 256 software-pipelined kernel in its transposed form
             // (gemm_bf16_sw.hip); identical bits.  Ragged row counts (validK) stay on the kernel below, which reads rows past the end as zero.
-            const bool whole = x.validK == 0 || x.validK == (int64_t)K * nbatch;
+            const bool whole = x.validK == 0 || x.validK == (int64_t)K * nbatch + 64 * x.kextra;
             if (x.force_kernel != 1 && whole && gemm_bf16_swtr_ok(M, N, K, lda, ldb, strideA, strideB) &&
                 (x.force_kernel == 2 || tune_int("W2V2_GEMM16_SW", 1) != 0))
-                return launch_gemm_bf16_swtr(x.A16, lda, strideA, x.B16p, ldb, strideB, C, ldc, strideC, M, N, K, nbatch, s);
+                return launch_gemm_bf16_swtr(x.A16, lda, strideA, x.B16p, ldb, strideB, C, ldc, strideC, M, N, K, nbatch, s, x.kextra);
+            W2V2_REQUIRE(x.kextra == 0, "gemm_bf16: uneven slabs (kextra) are a feature of the 128 x 256 transposed kernel");
             return launch_tr16(g, nbatch, s);
         }
         W2V2_REQUIRE(x.validK == 0, "gemm_bf16: validK needs the LDS-DMA weight-gradient form (both shadows, whole 128 x 128 tiles)");

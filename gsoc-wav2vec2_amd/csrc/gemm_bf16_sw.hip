@@ -41,6 +41,7 @@ struct GemmSWArgs {
     const float* bias;
     const float* residual;
     int64_t lda, ldb16, ldc, strideA, strideC, strideB;
+    int kextra = 0;            // transposed form: batches z < kextra run one K tile more; batch z starts min(z, kextra) K tiles after z K rows
     int M, N, K, act;
     int tiles_m, tiles_n;
 #ifdef W2V2_TUNING
@@ -310,7 +311,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_sw_kernel(GemmSWArgs g) {
     const bool m_fast = g.tiles_m < g.tiles_n;
     const int tm = m_fast ? bid % g.tiles_m : bid / g.tiles_n, tn = m_fast ? bid / g.tiles_m : bid % g.tiles_n;
     const int m0 = tm * SW_BM, n0 = tn * SW_BN;
-    const int nk = g.K / SW_BK;
+    const int zk = TR ? (z < g.kextra ? z : g.kextra) : 0;                  // K tiles the earlier (longer) slabs pushed this one back by
+    const int nk = g.K / SW_BK + ((TR && z < g.kextra) ? 1 : 0);
 #ifdef W2V2_TUNING
     unsigned long long* const trc = (TRACE && g.trace) ? g.trace + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 32 : nullptr;
     int trc_n = 2;
@@ -357,8 +359,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_sw_kernel(GemmSWArgs g) {
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
         return reinterpret_cast<const unsigned char*>(((uint64_t)hi << 32) | lo);
     };
-    const unsigned char* const baseA = uniform_ptr(TR ? g.A16 + (int64_t)z * g.strideA + m0 : g.A16 + (int64_t)z * g.strideA + (int64_t)m0 * g.lda);
-    const unsigned char* const baseB = uniform_ptr(TR ? g.B16 + (int64_t)z * g.strideB + n0 : g.B16 + (int64_t)n0 * g.ldb16);
+    const unsigned char* const baseA = uniform_ptr(TR ? g.A16 + (int64_t)z * g.strideA + (int64_t)zk * SW_BK * g.lda + m0
+                                                      : g.A16 + (int64_t)z * g.strideA + (int64_t)m0 * g.lda);
+    const unsigned char* const baseB = uniform_ptr(TR ? g.B16 + (int64_t)z * g.strideB + (int64_t)zk * SW_BK * g.ldb16 + n0 : g.B16 + (int64_t)n0 * g.ldb16);
     const int64_t bstep32 = TR ? 64 : 64 * g.ldb16, bstep128 = TR ? 256 : 256 * g.ldb16;      // bytes: 32 / 128 columns of B
     const int64_t kstepA = TR ? 2 * SW_BK * g.lda : 2 * SW_BK, kstepB = TR ? 2 * SW_BK * g.ldb16 : 2 * SW_BK;      // bytes per K tile
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)sw_smem;
@@ -616,12 +619,14 @@ bool gemm_bf16_swtr_ok(int M, int N, int K, int64_t lda, int64_t ldb, int64_t st
 }
 
 int launch_gemm_bf16_swtr(const uint16_t* A16, int64_t lda, int64_t strideA, const uint16_t* B16, int64_t ldb, int64_t strideB, float* C,
-                          int64_t ldc, int64_t strideC, int M, int N, int K, int nbatch, hipStream_t s) {
+                          int64_t ldc, int64_t strideC, int M, int N, int K, int nbatch, hipStream_t s, int kextra) {
     W2V2_REQUIRE(A16 && B16 && C && gemm_bf16_swtr_ok(M, N, K, lda, ldb, strideA, strideB), "gemm_bf16_swtr: unsupported operands");
+    W2V2_REQUIRE(kextra >= 0 && kextra < nbatch && (kextra == 0 || (strideA == (int64_t)K * lda && strideB == (int64_t)K * ldb)),
+                 "gemm_bf16_swtr: uneven slabs need back-to-back slabs (strides = K rows) and kextra < batch");
     GemmSWArgs g;
     g.A16 = A16; g.B16 = B16; g.C = C; g.C16 = nullptr; g.bias = nullptr; g.residual = nullptr;
     g.lda = lda; g.ldb16 = ldb; g.ldc = ldc; g.strideA = strideA; g.strideC = strideC; g.strideB = strideB;
-    g.M = M; g.N = N; g.K = K; g.act = 0;
+    g.M = M; g.N = N; g.K = K; g.act = 0; g.kextra = kextra;
     g.tiles_m = M / SW_BM;
     g.tiles_n = N / SW_BN;
 #ifdef W2V2_TUNING

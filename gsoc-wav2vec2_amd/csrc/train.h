@@ -111,16 +111,25 @@ struct AdamChunk {
 };
 int launch_adam_multi(const AdamChunk* chunks_dev, int nchunks, const float* grads, float* m, float* v, float lr_t, float b1,
                       float b2, float eps, hipStream_t s);
+// bf16-stored inputs of the element-wise dropout kernels (precision mode 1 keeps the FFN pre-activation u and the gradient of the
+// FFN hidden activation only as bf16): a16 stands in for x (forward) / u (backward), b16 for dy (backward; it may be the dx16 the
+// call writes -- in place); round_in = the fp32 inputs are rounded to bf16 on the way in (the shadow-free path of the same mode,
+// which must produce the same bits).
+struct EwBf16 {
+    const uint16_t* a16 = nullptr;
+    const uint16_t* b16 = nullptr;
+    int round_in = 0;
+};
 int launch_dropout_fwd_x(const float* x, const float* res, float* y, uint16_t* y16 /* optional bf16 shadow */, int64_t n, int act,
-                         float p, uint64_t seed, uint32_t stream_id, hipStream_t s);
+                         float p, uint64_t seed, uint32_t stream_id, hipStream_t s, const EwBf16& in = EwBf16{});
 int launch_dropout_fwd(const float* x, const float* res, float* y, int64_t n, int act, float p,
                        uint64_t seed, uint32_t stream_id, hipStream_t s);
 int launch_dropout_bwd(const float* u, const float* dy, float* dx, int64_t n, int act, float p,
                        uint64_t seed, uint32_t stream_id, hipStream_t s);
 int launch_dropout_bwd_x(const float* u, const float* dy, float* dx, uint16_t* dx16 /* optional bf16 shadow */, int64_t n, int act,
-                         float p, uint64_t seed, uint32_t stream_id, hipStream_t s);
+                         float p, uint64_t seed, uint32_t stream_id, hipStream_t s, const EwBf16& in = EwBf16{});
 int launch_dropout_bwd_colsum(const float* u, const float* dy, float* dx, uint16_t* dx16, float* colsum, int64_t rows, int cols,
-                              int act, float p, uint64_t seed, uint32_t stream_id, float* ws, hipStream_t s);
+                              int act, float p, uint64_t seed, uint32_t stream_id, float* ws, hipStream_t s, const EwBf16& in = EwBf16{});
 int launch_transpose(const float* x, float* y, int rows, int cols, int nbatch, hipStream_t s);
 int64_t colsum_ws_floats(int64_t rows, int cols);
 int64_t dropout_bwd_colsum_ws_floats(int64_t rows, int cols);      // scratch of launch_dropout_bwd_colsum

@@ -28,23 +28,46 @@ inline unsigned ew_grid(int64_t n_vec) {
     return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));   // grid-stride beyond `cap` blocks
 }
 
+// Inputs kept as bf16 (precision mode 1: the FFN pre-activation u and the gradient of its activation are stored as bf16 only --
+// EwBf16 in train.h): four consecutive elements starting at element index e, from the bf16 copy when there is one (8 bytes),
+// else from the fp32 tensor (16 bytes), rounded to bf16 on the way in when `round_in` (the shadow-free path of the same mode).
+__device__ __forceinline__ float bf16_round_trip(float v) { return __uint_as_float(pack_bf16_rne(v, 0.f) << 16); }
+__device__ __forceinline__ void load4_maybe_bf16(const float* x, const uint16_t* x16, int64_t e, int round_in, float (&v)[4]) {
+    if (x16) {
+        const uint2 w = *reinterpret_cast<const uint2*>(x16 + e);
+        v[0] = __uint_as_float(w.x << 16); v[1] = __uint_as_float(w.x & 0xFFFF0000u);
+        v[2] = __uint_as_float(w.y << 16); v[3] = __uint_as_float(w.y & 0xFFFF0000u);
+    } else {
+        const float4 f = *reinterpret_cast<const float4*>(x + e);
+        v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+        if (round_in) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = bf16_round_trip(v[k]);
+        }
+    }
+}
+__device__ __forceinline__ float load1_maybe_bf16(const float* x, const uint16_t* x16, int64_t e, int round_in) {
+    if (x16) return __uint_as_float((uint32_t)x16[e] << 16);
+    return round_in ? bf16_round_trip(x[e]) : x[e];
+}
+
 // y = dropout(act(x)) [+ res]           (act may be 0).  HBM-bound: 16 bytes per lane per access when the tensor allows.
 template <bool VEC>
 __global__ void dropout_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                    float* __restrict__ y, uint16_t* __restrict__ y16 /* optional bf16 shadow of y */, int64_t n,
-                                   int act, float p, uint64_t seed, uint32_t stream) {
+                                   int act, float p, uint64_t seed, uint32_t stream, const uint16_t* __restrict__ x16, int round_in) {
     const float inv = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     const uint32_t key = dropout_key(seed, stream), thr = dropout_threshold(p);
     if (VEC) {
         const int64_t nv = n >> 2;
         for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < nv; i += (int64_t)gridDim.x * EW_THREADS) {
-            const float4 xv = reinterpret_cast<const float4*>(x)[i];
-            float v[4];
+            float xv[4], v[4];
+            load4_maybe_bf16(x, x16, 4 * i, round_in, xv);
             if (act == 3) {
-                const f32x2_t a0 = gelu_erf_fast2(f32x2_t{xv.x, xv.y}), a1 = gelu_erf_fast2(f32x2_t{xv.z, xv.w});
+                const f32x2_t a0 = gelu_erf_fast2(f32x2_t{xv[0], xv[1]}), a1 = gelu_erf_fast2(f32x2_t{xv[2], xv[3]});
                 v[0] = a0[0]; v[1] = a0[1]; v[2] = a1[0]; v[3] = a1[1];
             } else {
-                v[0] = apply_act(xv.x, act); v[1] = apply_act(xv.y, act); v[2] = apply_act(xv.z, act); v[3] = apply_act(xv.w, act);
+                v[0] = apply_act(xv[0], act); v[1] = apply_act(xv[1], act); v[2] = apply_act(xv[2], act); v[3] = apply_act(xv[3], act);
             }
             if (p > 0.f) {
 #pragma unroll
@@ -63,7 +86,7 @@ __global__ void dropout_fwd_kernel(const float* __restrict__ x, const float* __r
         }
     } else {
         for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS) {
-            float v = apply_act(x[i], act);
+            float v = apply_act(load1_maybe_bf16(x, x16, i, round_in), act);
             if (p > 0.f) v = dropout_keep32(key, (uint32_t)i, thr) ? v * inv : 0.0f;
             v = res ? v + res[i] : v;
             if (y) y[i] = v;
@@ -73,17 +96,18 @@ __global__ void dropout_fwd_kernel(const float* __restrict__ x, const float* __r
 }
 
 // dx = dy * keep/(1-p) * act'(u)
+// (dy16 may be dx16: every element is read once, then written, by the same lane)
 template <bool VEC>
 __global__ void dropout_bwd_kernel(const float* __restrict__ u, const float* __restrict__ dy,
-                                   float* __restrict__ dx, uint16_t* __restrict__ dx16 /* optional bf16 shadow of dx */, int64_t n, int act,
-                                   float p, uint64_t seed, uint32_t stream) {
+                                   float* __restrict__ dx, uint16_t* dx16 /* optional bf16 shadow of dx */, int64_t n, int act,
+                                   float p, uint64_t seed, uint32_t stream, const uint16_t* __restrict__ u16, const uint16_t* dy16, int round_in) {
     const float inv = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     const uint32_t key = dropout_key(seed, stream), thr = dropout_threshold(p);
     if (VEC) {
         const int64_t nv = n >> 2;
         for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < nv; i += (int64_t)gridDim.x * EW_THREADS) {
-            const float4 gv = reinterpret_cast<const float4*>(dy)[i];
-            float g[4] = {gv.x, gv.y, gv.z, gv.w};
+            float g[4];
+            load4_maybe_bf16(dy, dy16, 4 * i, round_in, g);
             if (p > 0.f) {
 #pragma unroll
                 for (int e = 0; e < 4; e += 2) {
@@ -93,12 +117,13 @@ __global__ void dropout_bwd_kernel(const float* __restrict__ u, const float* __r
                 }
             }
             if (act) {
-                const float4 uv = reinterpret_cast<const float4*>(u)[i];
+                float uv[4];
+                load4_maybe_bf16(u, u16, 4 * i, round_in, uv);
                 if (act == 3) {
-                    const f32x2_t d0 = gelu_grad_fast2(f32x2_t{uv.x, uv.y}), d1 = gelu_grad_fast2(f32x2_t{uv.z, uv.w});
+                    const f32x2_t d0 = gelu_grad_fast2(f32x2_t{uv[0], uv[1]}), d1 = gelu_grad_fast2(f32x2_t{uv[2], uv[3]});
                     g[0] *= d0[0]; g[1] *= d0[1]; g[2] *= d1[0]; g[3] *= d1[1];
                 } else {
-                    g[0] *= gelu_grad(uv.x, act); g[1] *= gelu_grad(uv.y, act); g[2] *= gelu_grad(uv.z, act); g[3] *= gelu_grad(uv.w, act);
+                    g[0] *= gelu_grad(uv[0], act); g[1] *= gelu_grad(uv[1], act); g[2] *= gelu_grad(uv[2], act); g[3] *= gelu_grad(uv[3], act);
                 }
             }
             if (dx) reinterpret_cast<float4*>(dx)[i] = make_float4(g[0], g[1], g[2], g[3]);
@@ -106,9 +131,9 @@ __global__ void dropout_bwd_kernel(const float* __restrict__ u, const float* __r
         }
     } else {
         for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS) {
-            float g = dy[i];
+            float g = load1_maybe_bf16(dy, dy16, i, round_in);
             if (p > 0.f) g = dropout_keep32(key, (uint32_t)i, thr) ? g * inv : 0.0f;
-            if (act) g *= gelu_grad(u[i], act);
+            if (act) g *= gelu_grad(load1_maybe_bf16(u, u16, i, round_in), act);
             if (dx) dx[i] = g;
             if (dx16) dx16[i] = (uint16_t)pack_bf16_rne(g, 0.f);
         }
@@ -120,9 +145,10 @@ __global__ void dropout_bwd_kernel(const float* __restrict__ u, const float* __r
 // dropout_bwd_kernel; the loop is the column-sum kernel's: 64 float4 column groups x 4 row lanes per block, 128-row chunks,
 // partial[chunk][cols] folded by colsum_final_wide.  Needs cols % 4 == 0 and 16-byte aligned tensors.
 __global__ __launch_bounds__(256) void dropout_bwd_colsum_kernel(const float* __restrict__ u, const float* __restrict__ dy,
-                                                                 float* __restrict__ dx, uint16_t* __restrict__ dx16,
+                                                                 float* __restrict__ dx, uint16_t* dx16,
                                                                  float* __restrict__ partial, int64_t rows, int cols, int rows_per_chunk,
-                                                                 int act, float p, uint64_t seed, uint32_t stream) {
+                                                                 int act, float p, uint64_t seed, uint32_t stream,
+                                                                 const uint16_t* __restrict__ u16, const uint16_t* dy16, int round_in) {
     __shared__ float4 red[4][64];
     const float inv = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     const uint32_t key = dropout_key(seed, stream), thr = dropout_threshold(p);
@@ -134,8 +160,8 @@ __global__ __launch_bounds__(256) void dropout_bwd_colsum_kernel(const float* __
     if (c < cols) {
         for (int64_t r = r0 + ry; r < r1; r += 4) {
             const int64_t i = r * cols + c;
-            const float4 gv = *reinterpret_cast<const float4*>(dy + i);
-            float g[4] = {gv.x, gv.y, gv.z, gv.w};
+            float g[4];
+            load4_maybe_bf16(dy, dy16, i, round_in, g);
             if (p > 0.f) {
 #pragma unroll
                 for (int e = 0; e < 4; e += 2) {       // i = r cols + c is a multiple of 4
@@ -145,12 +171,13 @@ __global__ __launch_bounds__(256) void dropout_bwd_colsum_kernel(const float* __
                 }
             }
             if (act) {
-                const float4 uv = *reinterpret_cast<const float4*>(u + i);
+                float uv[4];
+                load4_maybe_bf16(u, u16, i, round_in, uv);
                 if (act == 3) {
-                    const f32x2_t d0 = gelu_grad_fast2(f32x2_t{uv.x, uv.y}), d1 = gelu_grad_fast2(f32x2_t{uv.z, uv.w});
+                    const f32x2_t d0 = gelu_grad_fast2(f32x2_t{uv[0], uv[1]}), d1 = gelu_grad_fast2(f32x2_t{uv[2], uv[3]});
                     g[0] *= d0[0]; g[1] *= d0[1]; g[2] *= d1[0]; g[3] *= d1[1];
                 } else {
-                    g[0] *= gelu_grad(uv.x, act); g[1] *= gelu_grad(uv.y, act); g[2] *= gelu_grad(uv.z, act); g[3] *= gelu_grad(uv.w, act);
+                    g[0] *= gelu_grad(uv[0], act); g[1] *= gelu_grad(uv[1], act); g[2] *= gelu_grad(uv[2], act); g[3] *= gelu_grad(uv[3], act);
                 }
             }
             if (dx) *reinterpret_cast<float4*>(dx + i) = make_float4(g[0], g[1], g[2], g[3]);
@@ -574,14 +601,16 @@ int launch_dropout_fwd(const float* x, const float* res, float* y, int64_t n, in
 }
 
 int launch_dropout_fwd_x(const float* x, const float* res, float* y, uint16_t* y16, int64_t n, int act, float p,
-                         uint64_t seed, uint32_t stream_id, hipStream_t s) {
-    W2V2_REQUIRE(x && (y || y16) && n > 0 && p >= 0.f && p < 1.f, "dropout_fwd: bad argument");      // (y may be null: bf16 result only)
+                         uint64_t seed, uint32_t stream_id, hipStream_t s, const EwBf16& in) {
+    W2V2_REQUIRE((x || in.a16) && (y || y16) && n > 0 && p >= 0.f && p < 1.f, "dropout_fwd: bad argument");      // (y may be null: bf16 result only)
     const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res)) & 15) == 0 &&
-                     (reinterpret_cast<uintptr_t>(y16) & 7) == 0;
+                     ((reinterpret_cast<uintptr_t>(y16) | reinterpret_cast<uintptr_t>(in.a16)) & 7) == 0;
     if (vec)
-        hipLaunchKernelGGL(dropout_fwd_kernel<true>, dim3(ew_grid(n >> 2)), dim3(EW_THREADS), 0, s, x, res, y, y16, n, act, p, seed, stream_id);
+        hipLaunchKernelGGL(dropout_fwd_kernel<true>, dim3(ew_grid(n >> 2)), dim3(EW_THREADS), 0, s, x, res, y, y16, n, act, p, seed, stream_id, in.a16,
+                           in.round_in);
     else
-        hipLaunchKernelGGL(dropout_fwd_kernel<false>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, s, x, res, y, y16, n, act, p, seed, stream_id);
+        hipLaunchKernelGGL(dropout_fwd_kernel<false>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, s, x, res, y, y16, n, act, p, seed, stream_id, in.a16,
+                           in.round_in);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -592,14 +621,16 @@ int launch_dropout_bwd(const float* u, const float* dy, float* dx, int64_t n, in
 }
 
 int launch_dropout_bwd_x(const float* u, const float* dy, float* dx, uint16_t* dx16, int64_t n, int act, float p,
-                         uint64_t seed, uint32_t stream_id, hipStream_t s) {
-    W2V2_REQUIRE(dy && (dx || dx16) && n > 0 && p >= 0.f && p < 1.f && (act == 0 || u), "dropout_bwd: bad argument");   // (dx may be null)
+                         uint64_t seed, uint32_t stream_id, hipStream_t s, const EwBf16& in) {
+    W2V2_REQUIRE((dy || in.b16) && (dx || dx16) && n > 0 && p >= 0.f && p < 1.f && (act == 0 || u || in.a16), "dropout_bwd: bad argument");   // (dx may be null)
     const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0 &&
-                     (reinterpret_cast<uintptr_t>(dx16) & 7) == 0;
+                     ((reinterpret_cast<uintptr_t>(dx16) | reinterpret_cast<uintptr_t>(in.a16) | reinterpret_cast<uintptr_t>(in.b16)) & 7) == 0;
     if (vec)
-        hipLaunchKernelGGL(dropout_bwd_kernel<true>, dim3(ew_grid(n >> 2)), dim3(EW_THREADS), 0, s, u, dy, dx, dx16, n, act, p, seed, stream_id);
+        hipLaunchKernelGGL(dropout_bwd_kernel<true>, dim3(ew_grid(n >> 2)), dim3(EW_THREADS), 0, s, u, dy, dx, dx16, n, act, p, seed, stream_id, in.a16,
+                           in.b16, in.round_in);
     else
-        hipLaunchKernelGGL(dropout_bwd_kernel<false>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, s, u, dy, dx, dx16, n, act, p, seed, stream_id);
+        hipLaunchKernelGGL(dropout_bwd_kernel<false>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, s, u, dy, dx, dx16, n, act, p, seed, stream_id, in.a16,
+                           in.b16, in.round_in);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -666,14 +697,15 @@ int launch_colsum(const float* x, float* out, int64_t rows, int cols, float* ws,
 // layer dx is the output gradient of).  ws: dropout_bwd_colsum_ws_floats(rows, cols) floats.  Falls back to the two separate passes when
 // the tensors do not allow 16-byte accesses.
 int launch_dropout_bwd_colsum(const float* u, const float* dy, float* dx, uint16_t* dx16, float* colsum, int64_t rows, int cols,
-                              int act, float p, uint64_t seed, uint32_t stream_id, float* ws, hipStream_t s) {
-    W2V2_REQUIRE(dy && (dx || dx16) && colsum && ws && rows > 0 && cols > 0 && p >= 0.f && p < 1.f && (act == 0 || u), "dropout_bwd_colsum: bad argument");
+                              int act, float p, uint64_t seed, uint32_t stream_id, float* ws, hipStream_t s, const EwBf16& in) {
+    W2V2_REQUIRE((dy || in.b16) && (dx || dx16) && colsum && ws && rows > 0 && cols > 0 && p >= 0.f && p < 1.f && (act == 0 || u || in.a16),
+                 "dropout_bwd_colsum: bad argument");
     const bool vec = (cols & 3) == 0 && ((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) |
                                            reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(colsum)) & 15) == 0 &&
-                     (reinterpret_cast<uintptr_t>(dx16) & 7) == 0;
+                     ((reinterpret_cast<uintptr_t>(dx16) | reinterpret_cast<uintptr_t>(in.a16) | reinterpret_cast<uintptr_t>(in.b16)) & 7) == 0;
     if (!vec) {
         W2V2_REQUIRE(dx, "dropout_bwd_colsum: a bf16-only result needs cols %% 4 == 0 and 16-byte aligned tensors");
-        if (int e = launch_dropout_bwd_x(u, dy, dx, dx16, rows * cols, act, p, seed, stream_id, s)) return e;
+        if (int e = launch_dropout_bwd_x(u, dy, dx, dx16, rows * cols, act, p, seed, stream_id, s, in)) return e;
         return launch_colsum(dx, colsum, rows, cols, ws, 0, s);
     }
     // shorter chunks until the grid has `target` blocks (this HBM-bound kernel wants many small blocks; the fold of the partial
@@ -686,7 +718,7 @@ int launch_dropout_bwd_colsum(const float* u, const float* dy, float* dx, uint16
     while (chunk > 16 && (rows + chunk - 1) / chunk * colblocks < target) chunk >>= 1;
     const int nchunks = (int)((rows + chunk - 1) / chunk);
     hipLaunchKernelGGL(dropout_bwd_colsum_kernel, dim3(colblocks, nchunks), dim3(256), 0, s, u, dy, dx, dx16, ws, rows, cols,
-                       chunk, act, p, seed, stream_id);
+                       chunk, act, p, seed, stream_id, in.a16, in.b16, in.round_in);
     hipLaunchKernelGGL(colsum_final_wide_kernel, dim3((cols + 31) / 32), dim3(256), 0, s, ws, colsum, nchunks, cols, (int64_t)cols, 0);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;

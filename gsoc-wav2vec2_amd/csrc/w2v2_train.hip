@@ -71,6 +71,7 @@ struct TrainState {
     int64_t cs_floats = 0;
     bool forward_done = false;
     bool ffn16_only = false;                      // the last forward wrote dropout(GELU(u)) only as bf16 (no fp32 l.gd)
+    bool u16_only = false;                        // ... and the FFN pre-activation u only as bf16 (in the first half of l.u's storage)
     bool x16_valid = false, x16_attn = false;     // the last forward wrote the per-layer bf16 shadows (/ ctx16 from the bf16 attention)
     // gradient buckets for overlapping the data-parallel all-reduce with the backward: completion order
     //   0 = lm_head, 1 .. N = encoder layers N-1 .. 0, N+1 = everything in front of layer 0 in the flat buffer
@@ -362,6 +363,29 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
             }
             return W2V2_OK;
         }
+        // Whole rows on the 128 x 256 transposed kernel: ANY slab count works there (GemmShadows::kextra: the first M / 64 mod S slabs
+        // run one K tile more), so take as many slabs as fit the block slots -- 7 x 72 tiles = 504 blocks for the FFN matrices where
+        // the divisor rule below stops at 6 x 72 = 432 (a sixth of the chip idle while the longest CUs run two 64-K-tile blocks).
+        if (wide_tiles && tr_form && tune_int("W2V2_DW_UNEVEN", 1) != 0) {
+            const int64_t units_all = M / kq;
+            const int S = (int)std::min<int64_t>(cap, units_all / 3);      // (a slab is at least three K tiles: the kernel's pipeline depth)
+            if (S >= 1) {
+                const int64_t q = units_all / S;
+                const int Kp = (int)(q * kq);
+                GemmShadows x;
+                x.transA = true; x.A16 = A16; x.B16p = dY16; x.kextra = (int)(units_all % S);
+                if (int e = launch_gemm_bf16_x(m->prof, nullptr, Kin, (int64_t)Kp * Kin, nullptr, Nout, (int64_t)Kp * Nout, S == 1 ? dW : t->slabs, Nout,
+                                               (int64_t)Kin * Nout, nullptr, nullptr, Kin, Nout, Kp, S, 0, x, s))
+                    return e;
+                if (S > 1)
+                    if (int e = launch_colsum(t->slabs, dW, S, Kin * Nout, t->slabs + (int64_t)S * Kin * Nout, 0, s)) return e;
+                if (db) {
+                    W2V2_REQUIRE(dY, "weight_grad: the bias gradient needs the fp32 dY");
+                    if (int e = launch_colsum(dY, db, M, Nout, t->red_ws, 0, s)) return e;
+                }
+                return W2V2_OK;
+            }
+        }
         const int64_t units0 = M / kq;
         int64_t units = units0;
         int S = units0 > 0 ? 1 : 0;
@@ -588,6 +612,13 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
     // the transposing-read form, whole 128-tiles) and the plain bf16 copies of the FFN kernels for the data gradients
     const bool ffn16_only = sh && m->w16_valid && F % 128 == 0 && H % 128 == 0 && (BT * F) % 4 == 0 && !m->w16p.empty();
     t->ffn16_only = ffn16_only;
+    // Precision mode 1 keeps the FFN pre-activation u = t2 W1 + b1 as bf16 (what a mixed_bfloat16 Dense hands to its activation): on
+    // the shadow path the up-projection writes ONLY the bf16 copy (its bf16 epilogue; 302 MB of fp32 stores per layer gone at B = 32)
+    // and GELU + dropout, GELU' in the backward read that; the shadow-free path of the mode rounds the fp32 u on the way into the
+    // same kernels, so both paths agree bit for bit.
+    const bool u16_only = ffn16_only && tune_int("W2V2_U16", 1) != 0;
+    t->u16_only = u16_only;
+    const int u_round = m->precision == 1 ? 1 : 0;
     for (int i = 0; i < c.num_layers; ++i) {
         const std::string b = "encoder/layers/" + std::to_string(i);
         LayerSave& l = t->layers[i];
@@ -624,10 +655,15 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
         if (l.keep != 0.f) {
             // u = t2 W1 + b1;  gd = dropout(GELU(u));  out = res + keep * (gd W2 + b2)   (encoder.py:127-130)
             // (ffn16_only: every reader of gd -- the next GEMM, and the down-projection's weight gradient -- streams the bf16 shadow)
-            if (int e = gemm(l.t2, S16(l.t2_16), H, 0, m->P(b + "/feed_forward/intermediate_dense/kernel"), F, l.u, nullptr, F, 0,
+            uint16_t* const u16 = u16_only ? reinterpret_cast<uint16_t*>(l.u) : nullptr;
+            if (int e = gemm(l.t2, S16(l.t2_16), H, 0, m->P(b + "/feed_forward/intermediate_dense/kernel"), F, u16_only ? nullptr : l.u, u16, F, 0,
                              m->P(b + "/feed_forward/intermediate_dense/bias"), nullptr, (int)BT, F, H, 1, 0))
                 return e;
-            if (int e = launch_dropout_fwd_x(l.u, nullptr, ffn16_only ? nullptr : l.gd, S16(l.gd16), BT * F, act_ew, p, seed, layer_stream(i, 2), s)) return e;
+            EwBf16 uin;
+            uin.a16 = u16; uin.round_in = u_round;
+            if (int e = launch_dropout_fwd_x(u16_only ? nullptr : l.u, nullptr, ffn16_only ? nullptr : l.gd, S16(l.gd16), BT * F, act_ew, p, seed,
+                                             layer_stream(i, 2), s, uin))
+                return e;
             if (int e = gemm(ffn16_only ? nullptr : l.gd, S16(l.gd16), F, 0, m->P(b + "/feed_forward/output_dense/kernel"), H, ffn_out, nullptr, H, 0,
                              m->P(b + "/feed_forward/output_dense/bias"), ffn_res, (int)BT, H, F, 1, 0))
                 return e;
@@ -729,13 +765,13 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     // registers to sum for the bias gradient: the PRODUCER of each dY leaves its column sums instead (dropout backward,
     // LayerNorm backward), and weight_grad is called without a bias target.  `bias_from_producer` says that happened.
     auto dropout_bwd_bias = [&](const float* u, const float* dy, float* dx, uint16_t* dx16, int64_t rows, int cols, int act_, uint32_t stream_id,
-                                float* bias_grad, bool* bias_done) -> int {
+                                float* bias_grad, bool* bias_done, const EwBf16& in = EwBf16{}) -> int {
         *bias_done = false;
         if (shb && bias_grad) {
             *bias_done = true;
-            return launch_dropout_bwd_colsum(u, dy, dx, dx16, bias_grad, rows, cols, act_, p, seed, stream_id, t->red_ws, s);
+            return launch_dropout_bwd_colsum(u, dy, dx, dx16, bias_grad, rows, cols, act_, p, seed, stream_id, t->red_ws, s, in);
         }
-        return launch_dropout_bwd_x(u, dy, dx, dx16, rows * cols, act_, p, seed, stream_id, s);
+        return launch_dropout_bwd_x(u, dy, dx, dx16, rows * cols, act_, p, seed, stream_id, s, in);
     };
     W2V2_HIP_CHECK(hipMemsetAsync(t->grads, 0, (size_t)t->gtotal * 4, s));
     if (int e = refresh_transposes(m, s)) return e;
@@ -819,8 +855,18 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
                                bool* b1_done) -> int {
         const float* W2 = m->P(b + "/feed_forward/output_dense/kernel");
         *b1_done = false;
+        EwBf16 in;
+        in.round_in = m->precision == 1 ? 1 : 0;
+        if (t->u16_only) {
+            // the forward kept u only as bf16; the gradient of the hidden activation is written only as bf16 too (the data-gradient
+            // GEMM's bf16 epilogue, into the buffer du's shadow will occupy) and GELU' x dropout-backward runs on it in place
+            W2V2_REQUIRE(s16f && dx_shadowed(W2), "train_backward: the forward kept u as bf16 only, which needs the shadow path for the down-projection's data gradient");
+            if (int e = gemm_dx(dy, dy16, H, l.W2T, W2, nullptr, F, nullptr, (int)BT, F, H, s, s16f)) return e;
+            in.a16 = reinterpret_cast<const uint16_t*>(l.u); in.b16 = s16f;
+            return dropout_bwd_bias(nullptr, nullptr, du16_only ? nullptr : t->gf, s16f, BT, F, act_ew, layer_stream(i, 2), gb1, b1_done, in);
+        }
         if (int e = gemm_dx(dy, dy16, H, l.W2T, W2, t->gf, F, nullptr, (int)BT, F, H, s)) return e;
-        return dropout_bwd_bias(l.u, t->gf, du16_only ? nullptr : t->gf, s16f, BT, F, act_ew, layer_stream(i, 2), gb1, b1_done);
+        return dropout_bwd_bias(l.u, t->gf, du16_only ? nullptr : t->gf, s16f, BT, F, act_ew, layer_stream(i, 2), gb1, b1_done, in);
     };
     const bool fuse_do_tail = !tune_int("W2V2_NO_DO_TAIL", 0);
     bool dh16_valid = false;

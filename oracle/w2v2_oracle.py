@@ -83,11 +83,21 @@ def _mm(a, b, stage=None):
 
 
 def _usable_cpus():
-    """CPUs this process may run on (a pinned CPU-baseline worker must not start a thread per core of the whole host)."""
+    """CPUs this process can keep busy: its affinity mask (a pinned CPU-baseline worker must not start a thread per core of the
+    whole host), capped by the container's cgroup CPU quota (the MI355X boxes show 256 CPUs under a 16-CPU quota: 64 runnable
+    pool threads there only get each other throttled)."""
     try:
-        return max(1, len(os.sched_getaffinity(0)))
+        n = max(1, len(os.sched_getaffinity(0)))
     except (AttributeError, OSError):
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def _chunked(fn, x, min_elems=1 << 20):

@@ -21,7 +21,8 @@ from wav2vec2 import variables as V
 # Operand rounding of the Dense contractions, mirroring oracle/w2v2_oracle.py::GEMM_OPERANDS.  "bf16": both
 # operands of every Dense are rounded to bfloat16 in the forward with a straight-through gradient, so autograd
 # yields dX = dY . bf16(W)^T and dW = bf16(X)^T . dY; the build additionally rounds dY in its backward GEMMs
-# (W2V2_PRECISION_BF16), which is why bf16 gradients are compared at a bf16-sized tolerance.
+# (W2V2_PRECISION_BF16), which is why bf16 gradients are compared at a bf16-sized tolerance.  The same mode stores the FFN
+# pre-activation as bf16 (rounded below, straight-through) and, in the backward, the gradient of the FFN hidden activation.
 GEMM_OPERANDS = None
 
 
@@ -125,7 +126,9 @@ def train_forward(config, w, wave, attention_mask=None, p=0.0, seed=0, spec_mask
         if keep_l != 0.0:
             f_in = _ln(x, w[f"{b}/final_layer_norm/gamma"], w[f"{b}/final_layer_norm/beta"], eps) if pre else x
             u = _mm(f_in, w[f"{b}/feed_forward/intermediate_dense/kernel"]) + w[f"{b}/feed_forward/intermediate_dense/bias"]
-            g = _drop(_gelu(u), p, seed, V.layer_stream(i, 2))
+            # (W2V2_PRECISION_BF16 keeps this pre-activation as bf16 in the training step, as a mixed_bfloat16 Dense hands it to its
+            #  activation: GELU and, through the straight-through rounding, GELU' see the rounded value)
+            g = _drop(_gelu(_r(u)), p, seed, V.layer_stream(i, 2))
             f = _mm(g, w[f"{b}/feed_forward/output_dense/kernel"]) + w[f"{b}/feed_forward/output_dense/bias"]
             x = x + keep_l * f
         if not pre:

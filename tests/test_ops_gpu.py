@@ -390,6 +390,35 @@ def test_weight_grad_bf16_kernels_agree_bit_for_bit(env, rows, Kin, Nout, S):
     assert lib.w2v2_op_weight_grad_bf16(N.ptr(x16), N.ptr(y16), N.ptr(outs[0]), rows - 8, Kin, Nout, per, S, 2, stream()) == -1
 
 
+@pytest.mark.parametrize("q,e,Kin,Nout,S", [(3, 1, 128, 256, 2), (5, 4, 768, 768, 7), (4, 2, 256, 2304, 3)])
+def test_weight_grad_bf16_uneven_slabs(env, q, e, Kin, Nout, S):
+    """The training step cuts the B T rows of dW = X^T dY into as many slabs as fill the chip's block slots, whatever the row count's
+    divisors: the first e slabs run one 64-row K tile more than the others (GemmShadows::kextra, 128 x 256 transposed kernel).  Every
+    slab must equal the exact product over ITS rows (a slab that started at the wrong row cannot), and the slabs must add up to the
+    whole product."""
+    lib, torch, dev = env
+    rows = 64 * (S * q + e)
+    X, dY = rnd("wg3X", (rows, Kin)), rnd("wg3Y", (rows, Nout), 0.3)
+    X[:, 3] += 2.0; dY[:, Nout - 5] -= 1.5
+    X *= (1.0 + np.arange(rows, dtype=np.float32) / rows)[:, None]            # rows differ in scale: a shifted slab shows
+    Xr, Yr = O.round_bf16(X), O.round_bf16(dY)
+    x16 = torch.from_numpy((Xr.view(np.uint32) >> 16).astype(np.uint16).view(np.int16)).to(dev)
+    y16 = torch.from_numpy((Yr.view(np.uint32) >> 16).astype(np.uint16).view(np.int16)).to(dev)
+    out = torch.full((S, Kin, Nout), float("nan"), device=dev)
+    N.check(lib.w2v2_op_weight_grad_bf16(N.ptr(x16), N.ptr(y16), N.ptr(out), rows, Kin, Nout, 64 * q, S, 2, stream()), "w2v2_op_weight_grad_bf16")
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    start = 0
+    for z in range(S):
+        n = 64 * (q + (1 if z < e else 0))
+        ref = Xr[start:start + n].astype(np.float64).T @ Yr[start:start + n].astype(np.float64)
+        assert np.isfinite(got[z]).all() and H.max_err(got[z], ref) < 2e-5 * max(1.0, np.abs(ref).max()), z
+        start += n
+    assert start == rows
+    # e >= S is not a split this form describes
+    assert lib.w2v2_op_weight_grad_bf16(N.ptr(x16), N.ptr(y16), N.ptr(out), 64 * (S * q + S), Kin, Nout, 64 * q, S, 2, stream()) == -1
+
+
 @pytest.mark.parametrize("rows,Kin,Nout,S", [(256, 128, 132, 1), (512, 768, 64, 4), (1024, 132, 256, 8)])
 def test_gemm_bf16_transposed_a_split_k(env, rows, Kin, Nout, S):
     """dW = X^T dY as the training step runs it in precision mode 1: X (rows, Kin) is passed as the TRANSPOSED A of the GEMM
