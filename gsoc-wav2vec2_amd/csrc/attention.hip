@@ -685,13 +685,13 @@ int launch_attention_train(Profiler* prof, const float* qkv, const int32_t* fram
 
 int launch_attention_train_x(Profiler* prof, const float* qkv, const uint16_t* qkv16, const int32_t* frame_len, float* ctx, uint16_t* ctx16,
                              int B, int T, int H, int heads, const AttnTrain& tr, hipStream_t s) {
-    W2V2_REQUIRE((qkv || qkv16) && ctx && tr.lse, "attention_train: null operand");
+    W2V2_REQUIRE((qkv || qkv16) && (ctx || ctx16) && tr.lse, "attention_train: null operand");
     W2V2_REQUIRE(B > 0 && T > 0 && heads > 0 && H % heads == 0 && tr.p >= 0.f && tr.p < 1.f, "attention_train: bad sizes");
     const int dh = H / heads;
     ProfScope ps(prof, FAM_ATTENTION, 4.0 * B * (double)heads * T * (double)T * dh, 4.0 * B * (double)T * 4.0 * H, s);
     if (gemm_get_precision() == 1 && attention_bf16_supported(dh))
         return launch_attention_fwd_bf16(qkv, qkv16, frame_len, ctx, ctx16, B, T, H, heads, &tr, s);
-    W2V2_REQUIRE(qkv, "attention_train: the fp32 kernels need the fp32 qkv");
+    W2V2_REQUIRE(qkv && ctx, "attention_train: the fp32 kernels need the fp32 qkv and write the fp32 ctx");
     AttnArgs a{qkv, frame_len, ctx, B, T, H, heads, 1.0f / sqrtf((float)dh)};
     W2V2_REQUIRE(!ctx16, "attention_train: a bf16 shadow output needs the bf16 kernel (precision 1, head size 64)");
     switch (dh) {
@@ -705,16 +705,17 @@ int launch_attention_train_x(Profiler* prof, const float* qkv, const uint16_t* q
 
 int launch_attention_bwd(Profiler* prof, const float* qkv, const int32_t* frame_len, const float* ctx,
                          const float* dctx, float* dqkv, float* dvec_ws, int B, int T, int H, int heads,
-                         const AttnTrain& tr, hipStream_t s, uint16_t* dqkv16, const uint16_t* qkv16, const uint16_t* dctx16, float* colpart) {
-    W2V2_REQUIRE((qkv || qkv16) && ctx && dctx && (dqkv || dqkv16) && dvec_ws && tr.lse, "attention_bwd: null operand");
+                         const AttnTrain& tr, hipStream_t s, uint16_t* dqkv16, const uint16_t* qkv16, const uint16_t* dctx16, float* colpart,
+                         const uint16_t* ctx16) {
+    W2V2_REQUIRE((qkv || qkv16) && (ctx || ctx16) && (dctx || dctx16) && (dqkv || dqkv16) && dvec_ws && tr.lse, "attention_bwd: null operand");
     W2V2_REQUIRE(B > 0 && T > 0 && heads > 0 && H % heads == 0, "attention_bwd: bad sizes");
     const int dh = H / heads;
     ProfScope ps(prof, FAM_ATTENTION, 10.0 * B * (double)heads * T * (double)T * dh, 4.0 * B * (double)T * 8.0 * H, s);
     if (gemm_get_precision() == 1 && attention_bf16_supported(dh)) {
-        // (D = rowsum(dO o O) is computed by the dQ kernel from the fp32 ctx / dctx)
-        return launch_attention_bwd_bf16(qkv, qkv16, frame_len, dctx, dctx16, dvec_ws, dqkv, dqkv16, B, T, H, heads, tr, s, colpart, ctx);
+        // (D = rowsum(dO o O) is computed by the dQ kernel from the bf16 values of dO and O, whichever form they arrive in)
+        return launch_attention_bwd_bf16(qkv, qkv16, frame_len, dctx, dctx16, dvec_ws, dqkv, dqkv16, B, T, H, heads, tr, s, colpart, ctx, ctx16);
     }
-    W2V2_REQUIRE(qkv && dqkv && !colpart, "attention_bwd: the fp32 kernels need the fp32 qkv / dqkv and leave no column sums");
+    W2V2_REQUIRE(qkv && dqkv && ctx && dctx && !colpart, "attention_bwd: the fp32 kernels need the fp32 qkv / ctx / dctx / dqkv and leave no column sums");
     AttnBwdArgs a{qkv, frame_len, dctx, dvec_ws, dqkv, B, T, H, heads, 1.0f / sqrtf((float)dh)};
     W2V2_REQUIRE(!dqkv16, "attention_bwd: a bf16 shadow of dqkv is only written by the bf16 kernels (head size 64, precision mode 1)");
     switch (dh) {

@@ -311,9 +311,9 @@ struct Attn16BwdArgs {
     const uint16_t* qkv16;  // (B, T, 3H)
     const int32_t* frame_len;
     const uint16_t* do16;   // (B, T, H) bf16 shadow of dO
-    float* dvec;            // (B, heads, T): D = rowsum(dO o O); written by the dQ kernel when o32 / do32 are given, else an input
-    const float* o32;       // optional fp32 O and dO (B, T, H): the dQ kernel then computes D itself (no separate pass over both)
-    const float* do32;
+    float* dvec;            // (B, heads, T): D = rowsum(dO o O); written by the dQ kernel when o16 / o32 is given, else an input
+    const uint16_t* o16;    // optional O (B, T, H) as bf16 (the forward's ctx shadow) or as fp32 (rounded to bf16 on the way in): the dQ
+    const float* o32;       // kernel then computes D itself from bf16(dO) and bf16(O) -- the same bits from either form
     float* dqkv;            // (B, T, 3H); may be null when dqkv16 is given
     uint16_t* dqkv16;       // optional bf16 shadow of dqkv (the A operand of the q|k|v data-gradient GEMM)
     float* colpart;         // optional (B nqb, 3H): per-block column sums of dqkv over the block's valid rows (-> the q|k|v bias gradient)
@@ -377,17 +377,28 @@ __global__ __launch_bounds__(256, 3) void attention_bf16_bwd_dq_kernel(Attn16Bwd
     const int64_t sidx = (int64_t)bh * a.T + qr;
     const float nlse = -tr.lse[sidx] * LOG2E;
     float dv;
-    if (a.o32) {         // D = sum_d dO O of this query: each lane half takes its 32 d, fp32
+    if (a.o16 || a.o32) {         // D = sum_d dO O of this query: each lane half takes its 32 d; bf16 values (dO: the fragments just loaded), fp32 sums
         const int64_t r0 = ((int64_t)b * a.T + qr) * a.H + head * DH + 8 * lh;
         float acc = 0.f;
 #pragma unroll
-        for (int st = 0; st < 4; ++st)
+        for (int st = 0; st < 4; ++st) {
+            u32x4 ow;
+            if (a.o16) {
+                ow = *reinterpret_cast<const u32x4*>(a.o16 + r0 + 16 * st);
+            } else {
+                const f32x4 o0 = *reinterpret_cast<const f32x4*>(a.o32 + r0 + 16 * st), o1 = *reinterpret_cast<const f32x4*>(a.o32 + r0 + 16 * st + 4);
+                ow = u32x4{pack_bf16(o0[0], o0[1]), pack_bf16(o0[2], o0[3]), pack_bf16(o1[0], o1[1]), pack_bf16(o1[2], o1[3])};
+            }
+            const u32x4 gw = dof[st];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const f32x4 ov = *reinterpret_cast<const f32x4*>(a.o32 + r0 + 16 * st + 4 * j);
-                const f32x4 gv = *reinterpret_cast<const f32x4*>(a.do32 + r0 + 16 * st + 4 * j);
-                acc += (ov[0] * gv[0] + ov[1] * gv[1]) + (ov[2] * gv[2] + ov[3] * gv[3]);
+                const float oa = __uint_as_float(ow[2 * j] << 16), ob = __uint_as_float(ow[2 * j] & 0xFFFF0000u);
+                const float oc = __uint_as_float(ow[2 * j + 1] << 16), od = __uint_as_float(ow[2 * j + 1] & 0xFFFF0000u);
+                const float ga = __uint_as_float(gw[2 * j] << 16), gb = __uint_as_float(gw[2 * j] & 0xFFFF0000u);
+                const float gc = __uint_as_float(gw[2 * j + 1] << 16), gd = __uint_as_float(gw[2 * j + 1] & 0xFFFF0000u);
+                acc += (oa * ga + ob * gb) + (oc * gc + od * gd);
             }
+        }
         dv = acc + __shfl_xor(acc, 32, 64);
         if (qok && lh == 0) a.dvec[sidx] = dv;      // (the dK/dV kernel, launched next, reads it)
     } else {
@@ -669,11 +680,12 @@ int launch_attention_fwd_bf16(const float* qkv, const uint16_t* qkv16, const int
     return W2V2_OK;
 }
 
-// dvec: (B, heads, T) scratch for D = rowsum(dO o O).  With `ctx` (fp32 O) and the fp32 `dctx` the dQ kernel computes it;
-// otherwise it must already hold D.  qkv16 / dctx16: bf16 shadows (null: made here from the fp32 tensors).
+// dvec: (B, heads, T) scratch for D = rowsum(dO o O).  With `ctx16` (the forward's bf16 O) or `ctx` (fp32 O, rounded to bf16 on the
+// way in) the dQ kernel computes it from the bf16 values of dO and O; otherwise it must already hold D.  qkv16 / dctx16: bf16 shadows
+// (null: made here from the fp32 tensors).
 int launch_attention_bwd_bf16(const float* qkv, const uint16_t* qkv16, const int32_t* frame_len, const float* dctx, const uint16_t* dctx16,
                               float* dvec, float* dqkv, uint16_t* dqkv16, int B, int T, int H, int heads, const AttnTrain& tr,
-                              hipStream_t s, float* colpart, const float* ctx) {
+                              hipStream_t s, float* colpart, const float* ctx, const uint16_t* ctx16) {
     W2V2_REQUIRE(dqkv || dqkv16, "attention_bwd_bf16: no output");
     W2V2_REQUIRE(H / heads == DH && H % heads == 0, "attention_bwd_bf16: head size %d unsupported (64)", H / heads);
     W2V2_REQUIRE((int64_t)T * 3 * H < (1ll << 31), "attention_bwd_bf16: T x 3H too large for 32-bit row offsets");
@@ -684,11 +696,9 @@ int launch_attention_bwd_bf16(const float* qkv, const uint16_t* qkv16, const int
                      (reinterpret_cast<uintptr_t>(dqkv16) & 7) == 0,
                  "attention_bwd_bf16: unaligned operand");
     const int nqb = (T + NW * 32 - 1) / (NW * 32);
-    const bool fuse_d = ctx && dctx;
-    W2V2_REQUIRE(!fuse_d || ((reinterpret_cast<uintptr_t>(ctx) | reinterpret_cast<uintptr_t>(dctx)) & 15) == 0, "attention_bwd_bf16: unaligned ctx / dctx");
+    W2V2_REQUIRE(((reinterpret_cast<uintptr_t>(ctx) | reinterpret_cast<uintptr_t>(ctx16)) & 15) == 0, "attention_bwd_bf16: unaligned ctx");
     W2V2_REQUIRE(dvec, "attention_bwd_bf16: null dvec");
-    Attn16BwdArgs a{q16, frame_len, do16, dvec, fuse_d ? ctx : nullptr, fuse_d ? dctx : nullptr, dqkv, dqkv16, colpart, B, T, H, heads,
-                    nqb, nqb * heads * B};
+    Attn16BwdArgs a{q16, frame_len, do16, dvec, ctx16, ctx16 ? nullptr : ctx, dqkv, dqkv16, colpart, B, T, H, heads, nqb, nqb * heads * B};
     const bool bits = tr.keep_bits && tr.p > 0.f;
     size_t lds_q = 2 * 2 * IMG, lds_kv = 2 * (2 * IMG + 2 * KT * 4 + (bits ? NW * 2 * (KT + 4) * 4 : 0));
     if (colpart) {

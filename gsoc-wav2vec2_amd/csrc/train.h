@@ -181,7 +181,8 @@ int launch_attention_fwd_bf16(const float* qkv, const uint16_t* qkv16, const int
 // bias gradient.  dqkv may be null when dqkv16 is given.
 int launch_attention_bwd_bf16(const float* qkv, const uint16_t* qkv16, const int32_t* frame_len, const float* dctx, const uint16_t* dctx16,
                               float* dvec, float* dqkv, uint16_t* dqkv16 /* optional bf16 shadow */, int B, int T, int H, int heads,
-                              const AttnTrain& tr, hipStream_t s, float* colpart = nullptr, const float* ctx = nullptr /* fp32 O: D computed inside */);
+                              const AttnTrain& tr, hipStream_t s, float* colpart = nullptr, const float* ctx = nullptr /* fp32 O: D computed inside */,
+                              const uint16_t* ctx16 = nullptr /* ... or its bf16 copy (the forward's shadow): same D */);
 int attention_colpart_rows(int B, int T);
 int launch_attention_train_x(Profiler* prof, const float* qkv, const uint16_t* qkv16, const int32_t* frame_len, float* ctx, uint16_t* ctx16,
                              int B, int T, int H, int heads, const AttnTrain& tr, hipStream_t s);
@@ -192,7 +193,8 @@ int launch_attention_train(Profiler* prof, const float* qkv, const int32_t* fram
 int launch_attention_bwd(Profiler* prof, const float* qkv, const int32_t* frame_len, const float* ctx,
                          const float* dctx, float* dqkv, float* dvec_ws, int B, int T, int H, int heads,
                          const AttnTrain& tr, hipStream_t s, uint16_t* dqkv16 = nullptr /* bf16 shadow of dqkv (bf16 kernels only) */,
-                         const uint16_t* qkv16 = nullptr, const uint16_t* dctx16 = nullptr, float* colpart = nullptr /* see launch_attention_bwd_bf16 */);
+                         const uint16_t* qkv16 = nullptr, const uint16_t* dctx16 = nullptr, float* colpart = nullptr /* see launch_attention_bwd_bf16 */,
+                         const uint16_t* ctx16 = nullptr /* bf16 kernels: ctx / dctx may then be null (O and dO are read as bf16 only) */);
 
 // positional conv, training variants (posconv.hip)
 int launch_pos_conv_ex(Profiler* prof, const float* x, const float* wg, const float* bias,

@@ -71,6 +71,7 @@ struct TrainState {
     int64_t cs_floats = 0;
     bool forward_done = false;
     bool ffn16_only = false;                      // the last forward wrote dropout(GELU(u)) only as bf16 (no fp32 l.gd)
+    bool ctx16_only = false;                      // ... and the attention output only as bf16 (no fp32 l.ctx: the backward reads O and dO as bf16)
     bool u16_only = false;                        // ... and the FFN pre-activation u only as bf16 (in the first half of l.u's storage)
     bool x16_valid = false, x16_attn = false;     // the last forward wrote the per-layer bf16 shadows (/ ctx16 from the bf16 attention)
     // gradient buckets for overlapping the data-parallel all-reduce with the backward: completion order
@@ -619,6 +620,10 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
     const bool u16_only = ffn16_only && tune_int("W2V2_U16", 1) != 0;
     t->u16_only = u16_only;
     const int u_round = m->precision == 1 ? 1 : 0;
+    // The attention output O: its readers are the out-projection GEMM and that GEMM's weight gradient (both stream the bf16 shadow)
+    // and D = rowsum(dO o O) of the attention backward, which is defined on the bf16 values -- no fp32 copy is written.
+    const bool ctx16_only = ffn16_only && attn16 && tune_int("W2V2_CTX16", 1) != 0;
+    t->ctx16_only = ctx16_only;
     for (int i = 0; i < c.num_layers; ++i) {
         const std::string b = "encoder/layers/" + std::to_string(i);
         LayerSave& l = t->layers[i];
@@ -638,7 +643,7 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
                          nullptr, (int)BT, 3 * H, H, 1, 0))
             return e;
         AttnTrain tr{p, seed, layer_stream(i, 0), l.lse, attn16 ? l.keep_bits : nullptr};
-        if (int e = launch_attention_train_x(pf, attn16 ? nullptr : l.qkv, attn16 ? l.qkv16 : nullptr, flen, l.ctx, attn16 ? l.ctx16 : nullptr, B, T,
+        if (int e = launch_attention_train_x(pf, attn16 ? nullptr : l.qkv, attn16 ? l.qkv16 : nullptr, flen, ctx16_only ? nullptr : l.ctx, attn16 ? l.ctx16 : nullptr, B, T,
                                              H, c.num_heads, tr, s))
             return e;
         // o = ctx Wo + bo;  t1 = dropout(o) + x   (encoder.py:116-119)
@@ -921,17 +926,20 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         float* d_o = tmp;
         if (!do_tail)
             if (int e = dropout_bwd_bias(nullptr, dt1, do16_only ? nullptr : d_o, s16h, BT, H, 0, layer_stream(i, 1), gbo, &bo_done)) return e;
-        if (int e = weight_grad(m, l.ctx, do16_only ? nullptr : d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), bo_done ? nullptr : gbo, s,
+        if (int e = weight_grad(m, t->ctx16_only ? nullptr : l.ctx, do16_only ? nullptr : d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), bo_done ? nullptr : gbo, s,
                                 (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h))
             return e;
         float* dctx = tmp2;
         // (the bf16 attention backward reads dctx and q | k | v as bf16: the GEMM leaves the dctx shadow, the forward left qkv16)
         uint16_t* const dctx16 = (s16q && dx_shadowed(m->P(b + "/attention/out_proj/kernel"))) ? t->dy16_ctx : nullptr;
-        if (int e = gemm_dx(do16_only ? nullptr : d_o, s16h, H, l.WoT, m->P(b + "/attention/out_proj/kernel"), dctx, H, nullptr, (int)BT, H, H, s, dctx16)) return e;
+        // (c16: the forward kept O only as bf16 -- dctx is then written only as bf16 too and the backward reads both as bf16)
+        const bool c16 = t->ctx16_only;
+        W2V2_REQUIRE(!c16 || (dctx16 && xs && t->x16_attn), "train_backward: the forward kept the attention output as bf16 only, which needs the shadow paths");
+        if (int e = gemm_dx(do16_only ? nullptr : d_o, s16h, H, l.WoT, m->P(b + "/attention/out_proj/kernel"), c16 ? nullptr : dctx, H, nullptr, (int)BT, H, H, s, dctx16)) return e;
         AttnTrain tr{p, seed, layer_stream(i, 0), l.lse, t->x16_attn ? l.keep_bits : nullptr};
         const bool q16 = dqkv16_only(i, l.a16);
-        if (int e = launch_attention_bwd(pf, t->x16_attn ? nullptr : l.qkv, flen, l.ctx, dctx, q16 ? nullptr : t->g3h, t->dvec, B, T, H, c.num_heads, tr,
-                                         s, s16q, t->x16_attn ? l.qkv16 : nullptr, dctx16, q16 ? t->attn_colpart : nullptr))
+        if (int e = launch_attention_bwd(pf, t->x16_attn ? nullptr : l.qkv, flen, c16 ? nullptr : l.ctx, c16 ? nullptr : dctx, q16 ? nullptr : t->g3h, t->dvec, B, T, H, c.num_heads, tr,
+                                         s, s16q, t->x16_attn ? l.qkv16 : nullptr, dctx16, q16 ? t->attn_colpart : nullptr, c16 ? l.ctx16 : nullptr))
             return e;
         if (int e = qkv_weight_grad(b, l.a, l.a16, q16)) return e;
         if (int e = gemm_dx(q16 ? nullptr : t->g3h, s16q, 3 * H, l.WqkvT, m->qkv_w[i], tmp, H, nullptr, (int)BT, H, 3 * H, s)) return e;
@@ -998,18 +1006,20 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         bo_done = do_tail && gbo;
         if (!do_tail)
             if (int e = dropout_bwd_bias(nullptr, dt1, do16_only ? nullptr : d_o, s16h, BT, H, 0, layer_stream(i, 1), gbo, &bo_done)) return e;
-        if (int e = weight_grad(m, l.ctx, do16_only ? nullptr : d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), bo_done ? nullptr : gbo, s,
+        if (int e = weight_grad(m, t->ctx16_only ? nullptr : l.ctx, do16_only ? nullptr : d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), bo_done ? nullptr : gbo, s,
                                 (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h))
             return e;
         float* dctx = tmp2;   // dt2 is dead
         // (the bf16 attention backward reads dctx and q | k | v as bf16: the GEMM leaves the dctx shadow, the forward left qkv16)
         uint16_t* const dctx16 = (s16q && dx_shadowed(m->P(b + "/attention/out_proj/kernel"))) ? t->dy16_ctx : nullptr;
-        if (int e = gemm_dx(do16_only ? nullptr : d_o, s16h, H, l.WoT, m->P(b + "/attention/out_proj/kernel"), dctx, H, nullptr, (int)BT, H, H, s, dctx16)) return e;
+        const bool c16 = t->ctx16_only;
+        W2V2_REQUIRE(!c16 || (dctx16 && xs && t->x16_attn), "train_backward: the forward kept the attention output as bf16 only, which needs the shadow paths");
+        if (int e = gemm_dx(do16_only ? nullptr : d_o, s16h, H, l.WoT, m->P(b + "/attention/out_proj/kernel"), c16 ? nullptr : dctx, H, nullptr, (int)BT, H, H, s, dctx16)) return e;
         AttnTrain tr{p, seed, layer_stream(i, 0), l.lse, t->x16_attn ? l.keep_bits : nullptr};
         const uint16_t* const hs16_i = m->hs16.size() > (size_t)i ? m->hs16[i] : nullptr;
         const bool q16 = dqkv16_only(i, hs16_i);
-        if (int e = launch_attention_bwd(pf, t->x16_attn ? nullptr : l.qkv, flen, l.ctx, dctx, q16 ? nullptr : t->g3h, t->dvec, B, T, H, c.num_heads, tr,
-                                         s, s16q, t->x16_attn ? l.qkv16 : nullptr, dctx16, q16 ? t->attn_colpart : nullptr))
+        if (int e = launch_attention_bwd(pf, t->x16_attn ? nullptr : l.qkv, flen, c16 ? nullptr : l.ctx, c16 ? nullptr : dctx, q16 ? nullptr : t->g3h, t->dvec, B, T, H, c.num_heads, tr,
+                                         s, s16q, t->x16_attn ? l.qkv16 : nullptr, dctx16, q16 ? t->attn_colpart : nullptr, c16 ? l.ctx16 : nullptr))
             return e;
         if (int e = qkv_weight_grad(b, m->hs[i], hs16_i, q16)) return e;
         // dx = dqkv Wqkv^T + dt1 (residual)
