@@ -715,7 +715,11 @@ int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const i
         if (int e = gemm(attn_in, attn_in16, H, 0, m->qkv_w[i], 3 * H, attn16 ? nullptr : m->qkv, attn16 ? m->qkv16 : nullptr, 3 * H, 0, m->qkv_b[i],
                          nullptr, (int)BT, 3 * H, H, 1, 0))
             return e;
-        if (int e = launch_attention_x(pf, attn16 ? nullptr : m->qkv, attn16 ? m->qkv16 : nullptr, flen, m->ctx, B, T, H, c.num_heads,
+        // (the attention output's one reader is the out-projection GEMM; when that is certain to stream the bf16 shadow -- K = H a
+        //  multiple of 64, rows 16-byte aligned: gemm_bf16.hip -- the fp32 copy is not written: 75 MB per layer at B = 32)
+        const auto wo16 = m->w16.find(m->P(b + "/attention/out_proj/kernel"));
+        const bool ctx16_only = attn16 && H % 64 == 0 && wo16 != m->w16.end() && wo16->second != nullptr;
+        if (int e = launch_attention_x(pf, attn16 ? nullptr : m->qkv, attn16 ? m->qkv16 : nullptr, flen, ctx16_only ? nullptr : m->ctx, B, T, H, c.num_heads,
                                        attn16 ? m->ctx16 : nullptr, s))
             return e;
         // out projection + residual (encoder.py:31,117-119)
