@@ -114,7 +114,11 @@ int64_t w2v2_num_frames(const w2v2_model* m, int64_t num_samples);
  *                        ask for (mixed precision; variables, optimizer state and activations stay fp32).
  *                        Attention (head size 64) takes bf16 q, k, v and probabilities on the same pipe with
  *                        fp32 scores / softmax / accumulation; the grouped positional conv runs as one batched
- *                        GEMM with bf16-rounded input and kernel.
+ *                        GEMM with bf16-rounded input and kernel.  In the TRAINING step of this mode four tensors that sit
+ *                        between two roundings are also stored as bf16 (as a mixed_bfloat16 Dense would hand them on): the
+ *                        FFN pre-activation (GELU and GELU' see bf16(u)), the gradient of the FFN hidden activation, the
+ *                        attention output and its gradient (D = rowsum(dO o O) is taken from the bf16 values).  The
+ *                        residual stream, LayerNorm inputs / outputs and every gradient of them stay fp32.
  *   W2V2_PRECISION_BF16X3  fp32 results from the bf16 matrix cores (forward, and the data-gradient GEMMs of the
  *                        training step): every fp32 operand is written
  *                        exactly as a sum of three bf16 terms and each fp32 product is evaluated as the six bf16 x bf16
