@@ -278,7 +278,11 @@ __device__ __forceinline__ void sw_epilogue_f32(const f32x16 (&acc)[4][2], float
 // dimension.  Items are then 64 k rows x 128 B (A_i: 64 m; B_j a | b: the 32 n of two waves side by side), copied as they lie in
 // memory, and the k-contiguous MFMA fragments come out of the transposing LDS read ds_read_b64_tr_b16 (two per fragment), exactly
 // as in gemm_bf16_tr_kernel -- same products, same order, identical bits.  Everything else (stream, ring, phases) is shared.
-__device__ __forceinline__ int sw_swzk(int row) { return ((row >> 1) & 1) << 1; }      // 16-byte slot swizzle of a k-major image row
+// 16-byte slot swizzle of a k-major image row.  A transposing read moves 32 lanes x 8 B per LDS pass: four k rows (128 B apart) x
+// two 32-byte column runs.  Rows r and r + 2 would land on the same banks (LDS is 256 B wide: row parity is the only row bit in
+// the bank index), so rows 2, 3 (mod 4) swap the two 64-byte halves of their 128 bytes -- slot ^= 4.  (First version: slot ^= 2,
+// which only permuted the runs inside a half: PMC showed half of the LDS cycles of this form as bank conflicts.)
+__device__ __forceinline__ int sw_swzk(int row) { return ((row >> 1) & 1) << 2; }
 
 template <int OFF>
 __device__ __forceinline__ u32x2 sw_read_tr(unsigned addr) {
@@ -393,8 +397,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_sw_kernel(GemmSWArgs g) {
     // transposed form: a lane supplies the address of 4 consecutive columns (8 B) of k row 8 lh + l16 / 4 (+ 4 for the second
     // read) and receives 4 k of column 16 grp + l16; slot swizzle = sw_swzk(row) = a per-lane constant (rows step by multiples of 4)
     const int l16 = lane & 15, grp = (lane >> 4) & 1;
-    const unsigned xtr = lds0 + (unsigned)(8 * lh + (l16 >> 2)) * 128u + (unsigned)(((2 * grp + ((l16 >> 1) & 1)) ^ (2 * ((l16 >> 3) & 1))) << 4) +
+    const unsigned xtr = lds0 + (unsigned)(8 * lh + (l16 >> 2)) * 128u + (unsigned)(((2 * grp + ((l16 >> 1) & 1)) ^ (4 * ((l16 >> 3) & 1))) << 4) +
                          8u * (unsigned)(l16 & 1);
+    const unsigned xtr1 = xtr ^ 64u;      // the other 64-byte half of the row (A: the second 32 m; B: the odd wave's 32 n): XOR, because the swizzle swaps halves
     bf16x8 fa[2][2][4];      // [i: 64-row half][rb: 32-row block][ks]
     bf16x8 fb[2][4];         // [j: 32-column half][ks]
     u32x2 tal[2][2][4], tah[2][2][4], tbl[2][4], tbh[2][4];      // transposed form: the two 4-k halves of each fragment
@@ -419,11 +424,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_sw_kernel(GemmSWArgs g) {
     auto rd_a = [&](auto Ic, auto KSc, int slot) {          // A_I, k step KS: both 32-row blocks
         constexpr int I = decltype(Ic)::value, KS = decltype(KSc)::value;
         if constexpr (TR) {
-            const unsigned a = xtr + (unsigned)slot * SW_ITEM;
+            const unsigned a = xtr + (unsigned)slot * SW_ITEM, a1 = xtr1 + (unsigned)slot * SW_ITEM;
             tal[I][0][KS] = sw_read_tr<KS * 2048>(a);
             tah[I][0][KS] = sw_read_tr<KS * 2048 + 512>(a);
-            tal[I][1][KS] = sw_read_tr<KS * 2048 + 64>(a);
-            tah[I][1][KS] = sw_read_tr<KS * 2048 + 576>(a);
+            tal[I][1][KS] = sw_read_tr<KS * 2048>(a1);
+            tah[I][1][KS] = sw_read_tr<KS * 2048 + 512>(a1);
         } else {
             const unsigned a = xk[KS] + (unsigned)slot * SW_ITEM;
             fa[I][0][KS] = sw_read<0>(a);
@@ -433,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_sw_kernel(GemmSWArgs g) {
     auto rd_b = [&](auto Jc, auto KSc, int slot) {          // B_J, k step KS (slot = this wave's half a | b)
         constexpr int J = decltype(Jc)::value, KS = decltype(KSc)::value;
         if constexpr (TR) {
-            const unsigned a = xtr + (unsigned)slot * SW_ITEM + (unsigned)(wave & 1) * 64u;
+            const unsigned a = ((wave & 1) ? xtr1 : xtr) + (unsigned)slot * SW_ITEM;
             tbl[J][KS] = sw_read_tr<KS * 2048>(a);
             tbh[J][KS] = sw_read_tr<KS * 2048 + 512>(a);
         } else {

@@ -499,3 +499,39 @@ def test_bench_self_launch_builds_the_driver_command(monkeypatch):
     with pytest.raises((SystemExit, AssertionError, RuntimeError)):
         bench.main()
     assert "cmd" not in seen
+
+
+def test_bench_cpu_baseline_topology_helpers(tmp_path, monkeypatch):
+    """The CPU-baseline leg of bench.py sizes itself to what the host really grants: worker pin sets are disjoint, cover WHOLE cores
+    (every hardware thread of a core travels with it) and stay inside this process's affinity mask; a cgroup CPU quota is read from
+    cpu.max and caps the worker count (the MI355X boxes show 256 CPUs under a 16-CPU quota)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench._ranges([0, 1, 2, 128, 129, 131]) == "0-2,128-129,131" and bench._ranges([7]) == "7"
+    allowed = set(os.sched_getaffinity(0))
+    sets = bench._core_sets(2, 1)
+    flat = [c for s in sets for c in s]
+    assert len(flat) == len(set(flat)) and set(flat) <= allowed            # disjoint, inside the mask
+    for s in sets:
+        assert s == sorted(s) and len(s) >= 1
+    assert bench._core_sets(10 ** 6, 1) == bench._core_sets(len(bench._core_sets(10 ** 6, 1)), 1)      # asks beyond the host: fewer sets, no error
+    q = bench._cpu_quota()
+    assert q is None or q > 0
+    # cgroup v2 file format: "<quota> <period>" or "max <period>"
+    real_open = open
+
+    def fake_open(path, *a, **k):
+        if path == "/sys/fs/cgroup/cpu.max":
+            return real_open(tmp_path / "cpu.max", *a, **k)
+        return real_open(path, *a, **k)
+    (tmp_path / "cpu.max").write_text("1600000 100000\n")
+    monkeypatch.setattr("builtins.open", fake_open)
+    assert bench._cpu_quota() == 16.0
+    (tmp_path / "cpu.max").write_text("max 100000\n")
+    assert bench._cpu_quota() is None
+    from oracle import w2v2_oracle as O
+    (tmp_path / "cpu.max").write_text("200000 100000\n")
+    assert O._usable_cpus() == min(2, len(allowed))
