@@ -141,6 +141,9 @@ struct GemmShadows {
     // and every slab starts where the previous one ends -- K dimension = 64 (nbatch K / 64 + kextra) rows, strideA / strideB = K rows.
     // Lets the rows be cut into ANY number of slabs (7 x 72 tiles = 504 of the 512 block slots instead of 6 x 72 = 432).
     int kextra = 0;
+    // ... and when validK ends inside the last K tile of the last slab, that kernel takes the ragged form too IF the caller keeps the
+    // row of B16p just past the end (row validK) all-zero: the missing rows are then read from there (and from A's last row).
+    bool b_zero_row = false;
     int force_kernel = 0;        // forward form with both shadows: 0 = by shape, 1 = the 128 x 128 kernel, 2 = the 128 x 256 software-pipelined one
 };
 // 128 x 256 software-pipelined form, two 4-wave blocks per CU (gemm_bf16_sw.hip): same arithmetic, identical bits
@@ -150,7 +153,7 @@ int launch_gemm_bf16_sw(const uint16_t* A16, int64_t lda, int64_t strideA, const
                         hipStream_t s);
 bool gemm_bf16_swtr_ok(int M, int N, int K, int64_t lda, int64_t ldb, int64_t strideA, int64_t strideB);
 int launch_gemm_bf16_swtr(const uint16_t* A16, int64_t lda, int64_t strideA, const uint16_t* B16, int64_t ldb, int64_t strideB, float* C,
-                          int64_t ldc, int64_t strideC, int M, int N, int K, int nbatch, hipStream_t s, int kextra = 0);
+                          int64_t ldc, int64_t strideC, int M, int N, int K, int nbatch, hipStream_t s, int kextra = 0, int krag = 0);
 int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t strideA, const float* B, int64_t ldb,
                        int64_t strideB, float* C, int64_t ldc, int64_t strideC, const float* bias,
                        const float* residual, int M, int N, int K, int nbatch, int act, const GemmShadows& x,

@@ -808,7 +808,8 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
     g.colsum = x.transA ? x.colsum : nullptr; g.strideCS = x.strideCS;
     g.B16p = x.B16p;
     g.validK = x.validK > 0 ? x.validK : (int64_t)K * nbatch;
-    W2V2_REQUIRE(x.validK == 0 || (x.transA && x.A16 && x.B16p && x.validK > (int64_t)K * (nbatch - 1) && x.validK <= (int64_t)K * nbatch),
+    W2V2_REQUIRE(x.validK == 0 || (x.transA && x.A16 && x.B16p && x.validK > (int64_t)K * (nbatch - 1) + 64 * x.kextra &&
+                                   x.validK <= (int64_t)K * nbatch + 64 * x.kextra),
                  "gemm_bf16: validK is for the transposed-A shadow form, and every batch must own at least one existing row");
 #ifdef W2V2_TUNING
     g.abl = tune_int("W2V2_GEMM16_ABL", 0);
@@ -834,10 +835,13 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
             ProfScope ps(prof, FAM_GEMM_BF16, 2.0 * M * (double)N * krows, 2.0 * krows * ((double)M + N) + nbatch * 4.0 * (double)M * N, s);
             // every row exists and the columns fill 256-wide tiles: the 128 x 256 software-pipelined kernel in its transposed form
             // (gemm_bf16_sw.hip); identical bits.  Ragged row counts (validK) stay on the kernel below, which reads rows past the end as zero.
-            const bool whole = x.validK == 0 || x.validK == (int64_t)K * nbatch + 64 * x.kextra;
-            if (x.force_kernel != 1 && whole && gemm_bf16_swtr_ok(M, N, K, lda, ldb, strideA, strideB) &&
+            const int64_t krows_all = (int64_t)K * nbatch + 64 * x.kextra;
+            const bool whole = x.validK == 0 || x.validK == krows_all;
+            // (rows missing only from the last K tile, and a zero row promised behind B: the same kernel, ragged form)
+            const int krag = (!whole && x.b_zero_row && x.validK > krows_all - 64 && x.validK < krows_all) ? (int)(x.validK - (krows_all - 64)) : 0;
+            if (x.force_kernel != 1 && (whole || krag > 0) && gemm_bf16_swtr_ok(M, N, K, lda, ldb, strideA, strideB) &&
                 (x.force_kernel == 2 || tune_int("W2V2_GEMM16_SW", 1) != 0))
-                return launch_gemm_bf16_swtr(x.A16, lda, strideA, x.B16p, ldb, strideB, C, ldc, strideC, M, N, K, nbatch, s, x.kextra);
+                return launch_gemm_bf16_swtr(x.A16, lda, strideA, x.B16p, ldb, strideB, C, ldc, strideC, M, N, K, nbatch, s, x.kextra, krag);
             W2V2_REQUIRE(x.kextra == 0, "gemm_bf16: uneven slabs (kextra) are a feature of the 128 x 256 transposed kernel");
             return launch_tr16(g, nbatch, s);
         }

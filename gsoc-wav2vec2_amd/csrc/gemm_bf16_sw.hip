@@ -42,6 +42,8 @@ struct GemmSWArgs {
     const float* residual;
     int64_t lda, ldb16, ldc, strideA, strideC, strideB;
     int kextra = 0;            // transposed form: batches z < kextra run one K tile more; batch z starts min(z, kextra) K tiles after z K rows
+    int krag = 0;              // transposed form: rows that exist in the LAST K tile of the LAST batch (0 = all 64).  Rows past them are read
+                               // from A's last existing row (finite) and from B's row just past the end, which the caller keeps all-zero
     int M, N, K, act;
     int tiles_m, tiles_n;
 #ifdef W2V2_TUNING
@@ -317,6 +319,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_sw_kernel(GemmSWArgs g) {
     const int m0 = tm * SW_BM, n0 = tn * SW_BN;
     const int zk = TR ? (z < g.kextra ? z : g.kextra) : 0;                  // K tiles the earlier (longer) slabs pushed this one back by
     const int nk = g.K / SW_BK + ((TR && z < g.kextra) ? 1 : 0);
+    const int kt_rag = (TR && g.krag > 0 && z == (int)gridDim.z - 1) ? nk - 1 : -1;      // the K tile whose tail rows do not exist (block-uniform)
 #ifdef W2V2_TUNING
     unsigned long long* const trc = (TRACE && g.trace) ? g.trace + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 32 : nullptr;
     int trc_n = 2;
@@ -338,6 +341,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_sw_kernel(GemmSWArgs g) {
     // scalar base: A per half (rows clamped to the matrix, so a ragged last row tile re-reads row M - 1), B once (whole column tiles:
     // the two halves and two column groups of B are scalar offsets of the base).
     uint32_t offA[2][2], offB[2];
+    uint32_t offAr[2] = {0u, 0u}, offBr[2] = {0u, 0u};      // transposed form, ragged last K tile: rows clamped as GemmSWArgs::krag says
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int r = (wave * 2 + i) * 8 + (lane >> 3);                       // image row 0 .. 63
@@ -346,6 +350,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_sw_kernel(GemmSWArgs g) {
             const uint32_t ls = (uint32_t)((lane & 7) ^ sw_swzk(r));          // logical 16-byte slot
             offA[0][i] = offA[1][i] = 2u * ((uint32_t)((int64_t)r * g.lda) + ls * 8u);
             offB[i] = 2u * ((uint32_t)((int64_t)r * g.ldb16) + (ls >> 2) * 64u + (ls & 3u) * 8u);
+            const int ra = r < g.krag ? r : g.krag - 1, rb = r < g.krag ? r : g.krag;      // (the LDS position stays row r's: only the source moves)
+            offAr[i] = 2u * ((uint32_t)((int64_t)ra * g.lda) + ls * 8u);
+            offBr[i] = 2u * ((uint32_t)((int64_t)rb * g.ldb16) + (ls >> 2) * 64u + (ls & 3u) * 8u);
         } else {
             const uint32_t sl = (uint32_t)(((lane & 7) ^ sw_swz(r)) << 3);    // logical slot, in elements
 #pragma unroll
@@ -375,10 +382,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_sw_kernel(GemmSWArgs g) {
         constexpr int J = decltype(Jc)::value, I = decltype(Ic)::value;
         const unsigned dst = lds0 + (unsigned)slot * SW_ITEM + (unsigned)wave * 2048u + (unsigned)I * 1024u;
         if constexpr (J == 0 || J == 5) {
-            sw_dma(dst, offA[J == 0 ? 0 : 1][I], baseA + (int64_t)ktile * kstepA + ((TR && J == 5) ? 128 : 0));
+            const uint32_t off = (TR && ktile == kt_rag) ? offAr[I] : offA[J == 0 ? 0 : 1][I];
+            sw_dma(dst, off, baseA + (int64_t)ktile * kstepA + ((TR && J == 5) ? 128 : 0));
         } else {
             constexpr int HALF = (J == 2 || J == 4) ? 1 : 0, JB = (J >= 3) ? 1 : 0;      // waves 2-3 | columns + 32
-            sw_dma(dst, offB[I], baseB + (int64_t)ktile * kstepB + HALF * bstep128 + JB * bstep32);
+            const uint32_t off = (TR && ktile == kt_rag) ? offBr[I] : offB[I];
+            sw_dma(dst, off, baseB + (int64_t)ktile * kstepB + HALF * bstep128 + JB * bstep32);
         }
     };
     auto issue = [&](auto Jc, int ktile, int slot) {
@@ -624,14 +633,16 @@ bool gemm_bf16_swtr_ok(int M, int N, int K, int64_t lda, int64_t ldb, int64_t st
 }
 
 int launch_gemm_bf16_swtr(const uint16_t* A16, int64_t lda, int64_t strideA, const uint16_t* B16, int64_t ldb, int64_t strideB, float* C,
-                          int64_t ldc, int64_t strideC, int M, int N, int K, int nbatch, hipStream_t s, int kextra) {
+                          int64_t ldc, int64_t strideC, int M, int N, int K, int nbatch, hipStream_t s, int kextra, int krag) {
     W2V2_REQUIRE(A16 && B16 && C && gemm_bf16_swtr_ok(M, N, K, lda, ldb, strideA, strideB), "gemm_bf16_swtr: unsupported operands");
     W2V2_REQUIRE(kextra >= 0 && kextra < nbatch && (kextra == 0 || (strideA == (int64_t)K * lda && strideB == (int64_t)K * ldb)),
                  "gemm_bf16_swtr: uneven slabs need back-to-back slabs (strides = K rows) and kextra < batch");
     GemmSWArgs g;
     g.A16 = A16; g.B16 = B16; g.C = C; g.C16 = nullptr; g.bias = nullptr; g.residual = nullptr;
     g.lda = lda; g.ldb16 = ldb; g.ldc = ldc; g.strideA = strideA; g.strideC = strideC; g.strideB = strideB;
-    g.M = M; g.N = N; g.K = K; g.act = 0; g.kextra = kextra;
+    W2V2_REQUIRE(krag >= 0 && krag < 64 && (krag == 0 || nbatch == 1 || (strideA == (int64_t)K * lda && strideB == (int64_t)K * ldb)),
+                 "gemm_bf16_swtr: a ragged last K tile needs back-to-back slabs and 0 < rows < 64");
+    g.M = M; g.N = N; g.K = K; g.act = 0; g.kextra = kextra; g.krag = krag;
     g.tiles_m = M / SW_BM;
     g.tiles_n = N / SW_BN;
 #ifdef W2V2_TUNING

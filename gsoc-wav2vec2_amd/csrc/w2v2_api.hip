@@ -927,18 +927,25 @@ uint32_t w2v2_crc32c_extend(uint32_t crc, const void* data, uint64_t n) {
 int w2v2_op_weight_grad_bf16(const uint16_t* x16, const uint16_t* dy16, float* slabs, int64_t rows, int32_t Kin, int32_t Nout,
                              int32_t rows_per_slab, int32_t nslabs, int32_t variant, void* stream) {
     W2V2_REQUIRE(x16 && dy16 && slabs && rows > 0 && rows_per_slab > 0 && nslabs > 0 && Kin % 128 == 0 && Nout % 128 == 0 &&
-                     rows_per_slab % 64 == 0 && variant >= 0 && variant <= 2, "op_weight_grad_bf16: bad argument");
-    // variant 2 also takes uneven slabs: rows = rows_per_slab nslabs + 64 e with 0 <= e < nslabs gives the first e slabs 64 rows more
-    // (GemmShadows::kextra -- how the training step cuts B T rows into any number of slabs)
-    const int64_t over = rows - (int64_t)rows_per_slab * nslabs;
-    const bool uneven = variant == 2 && over > 0 && over % 64 == 0 && over / 64 < nslabs;
-    W2V2_REQUIRE(variant != 2 || ((over == 0 || uneven) &&
-                                  gemm_bf16_swtr_ok(Kin, Nout, rows_per_slab, Kin, Nout, (int64_t)rows_per_slab * Kin, (int64_t)rows_per_slab * Nout)),
-                 "op_weight_grad_bf16: variant 2 needs whole (or 64-row uneven) slabs, Nout %% 256 == 0 and at least 192 rows per slab");
+                     rows_per_slab % 64 == 0 && variant >= 0 && variant <= 3, "op_weight_grad_bf16: bad argument");
+    // variants 2 and 3 also take uneven slabs: with u = ceil(rows / 64) K tiles in all, u - nslabs (rows_per_slab / 64) = e, 0 <= e < nslabs,
+    // gives the first e slabs one K tile more (GemmShadows::kextra -- how the training step cuts B T rows into any number of slabs).
+    // variant 3 additionally promises that row `rows` of dy16 exists and is all-zero, which lets the last K tile be short.
+    const bool sw = variant == 2 || variant == 3;
+    const int64_t units = (rows + 63) / 64, over_units = units - (int64_t)(rows_per_slab / 64) * nslabs;
+    const bool shape_ok = sw && over_units >= 0 && over_units < nslabs && (rows % 64 == 0 || variant == 3) && (over_units == 0 || nslabs > 1);
+    W2V2_REQUIRE(!sw || (shape_ok && gemm_bf16_swtr_ok(Kin, Nout, rows_per_slab, Kin, Nout, (int64_t)rows_per_slab * Kin, (int64_t)rows_per_slab * Nout)),
+                 "op_weight_grad_bf16: variants 2 / 3 need whole 64-row K tiles (variant 3: a zero row behind dy16 instead), at most one extra K tile "
+                 "per slab, Nout %% 256 == 0 and at least 192 rows per slab");
     GemmShadows x;
-    x.transA = true; x.A16 = x16; x.B16p = dy16; x.force_kernel = variant;
-    x.kextra = uneven ? (int)(over / 64) : 0;
-    x.validK = (over == 0 || uneven) ? 0 : rows;
+    x.transA = true; x.A16 = x16; x.B16p = dy16; x.force_kernel = sw ? 2 : variant;
+    if (sw) {
+        x.kextra = (int)over_units;
+        x.validK = rows % 64 == 0 ? 0 : rows;
+        x.b_zero_row = variant == 3;
+    } else {
+        x.validK = rows == (int64_t)rows_per_slab * nslabs ? 0 : rows;
+    }
     return launch_gemm_bf16_x(nullptr, nullptr, Kin, (int64_t)rows_per_slab * Kin, nullptr, Nout, (int64_t)rows_per_slab * Nout, slabs, Nout,
                               (int64_t)Kin * Nout, nullptr, nullptr, Kin, Nout, rows_per_slab, nslabs, 0, x, reinterpret_cast<hipStream_t>(stream));
 }

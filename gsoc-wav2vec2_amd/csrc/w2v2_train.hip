@@ -242,13 +242,17 @@ static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
     if (attention_bf16_supported((int)(H / c.num_heads)))
         if (int e = t_alloc(t, &t->attn_colpart, (int64_t)attention_colpart_rows(B, T) * 3 * H)) return e;
     {
-        float* raw = nullptr;                   // (BT, H) + (BT, F) + (BT, 3H) bf16, each 16-byte aligned
+        // (BT + 1, H) + (BT + 1, F) + (BT + 1, 3H) + (BT, H) bf16, each 16-byte aligned.  Row BT of the first three is never written
+        // and stays zero: the weight-gradient GEMMs read a short last K tile's missing rows from there (weight_grad: dy16_zero_row).
+        float* raw = nullptr;
         auto up8 = [](int64_t n) { return (n + 7) & ~(int64_t)7; };
-        if (int e = t_alloc(t, &raw, (2 * up8(BT * H) + up8(BT * F) + up8(BT * 3 * H)) / 2 + 16)) return e;
+        const int64_t words = (up8((BT + 1) * H) + up8((BT + 1) * F) + up8((BT + 1) * 3 * H) + up8(BT * H)) / 2 + 16;
+        if (int e = t_alloc(t, &raw, words)) return e;
+        W2V2_HIP_CHECK(hipMemset(raw, 0, (size_t)words * 4));
         t->dy16_h = reinterpret_cast<uint16_t*>(raw);
-        t->dy16_f = t->dy16_h + up8(BT * H);
-        t->dy16_3h = t->dy16_f + up8(BT * F);
-        t->dy16_ctx = t->dy16_3h + up8(BT * 3 * H);      // dctx as the bf16 attention backward reads it
+        t->dy16_f = t->dy16_h + up8((BT + 1) * H);
+        t->dy16_3h = t->dy16_f + up8((BT + 1) * F);
+        t->dy16_ctx = t->dy16_3h + up8((BT + 1) * 3 * H);      // dctx as the bf16 attention backward reads it
     }
     t->B = B;
     t->L = L;
@@ -310,8 +314,10 @@ static bool is_trainable(w2v2_model* m, const std::string& name) {
 
 // dW (Kin x Nout) = A^T (Kin x M) dY (M x Nout), db = column sums of dY.  A is (M x Kin) row-major.
 // A16 / dY16: bf16 shadows of A and dY (row-major, same shapes) or null: with both, the fast slabs read half the bytes
+// dy16_zero_row: the caller keeps row M of dY16 all-zero (TrainState's dY shadows are allocated that way) -- a row count that is not a
+// multiple of 64 can then take the 128 x 256 kernel's ragged form instead of the 128 x 128 kernel
 static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, int Kin, int Nout, float* dW,
-                       float* db, hipStream_t s, const uint16_t* A16 = nullptr, const uint16_t* dY16 = nullptr) {
+                       float* db, hipStream_t s, const uint16_t* A16 = nullptr, const uint16_t* dY16 = nullptr, bool dy16_zero_row = false) {
     TrainState* t = m->train;
     bool fused_bias = false;
     if (dW) {
@@ -326,7 +332,7 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
         // (Before this, such an M fell back to ONE guarded GEMM over all rows: 256 tiles, K = 23984.)
         // (tiles as the kernel that will run counts them: with both bf16 shadows, whole rows and Nout % 256 == 0 the weight gradient
         //  takes the 128 x 256 software-pipelined kernel, which has half as many tiles to spread over the 512 block slots)
-        const bool wide_tiles = direct && A16 && dY16 && Kin % 128 == 0 && Nout % 256 == 0 && M % kq == 0;
+        const bool wide_tiles = direct && A16 && dY16 && Kin % 128 == 0 && Nout % 256 == 0 && (M % kq == 0 || (dy16_zero_row && M > kq));
         const int64_t tiles = (int64_t)((Kin + 127) / 128) * (wide_tiles ? Nout / 256 : (Nout + 127) / 128);
         // slabs cost a reduction pass each: the bf16 kernels are happiest with ONE block per resident slot (512),
         // the fp32 one wants ~4 to balance its long tiles (183.8 vs 189.4 ms)
@@ -341,6 +347,30 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
         // the fp32 A / dY are not read at all (callers may pass null when nothing else needs them).
         const bool tr_form = direct && A16 && dY16 && Kin % 128 == 0 && Nout % 128 == 0;
         W2V2_REQUIRE(tr_form || (A && dY), "weight_grad: the fp32 operands are needed here (no bf16 shadows / shapes not whole 128-tiles)");
+        // The 128 x 256 transposed kernel: ANY slab count works there (GemmShadows::kextra: the first ceil(M / 64) mod S slabs run one
+        // K tile more; a short last K tile reads its missing rows from the zero row behind dY16), so take as many slabs as fit the block slots -- 7 x 72 tiles = 504 blocks for the FFN matrices where
+        // the divisor rule below stops at 6 x 72 = 432 (a sixth of the chip idle while the longest CUs run two 64-K-tile blocks).
+        if (wide_tiles && tr_form && tune_int("W2V2_DW_UNEVEN", 1) != 0) {
+            const int64_t units_all = (M + kq - 1) / kq;                   // (the last unit may be short: GemmShadows::b_zero_row)
+            const int S = (int)std::min<int64_t>(cap, units_all / 3);      // (a slab is at least three K tiles: the kernel's pipeline depth)
+            if (S >= 1) {
+                const int64_t q = units_all / S;
+                const int Kp = (int)(q * kq);
+                GemmShadows x;
+                x.transA = true; x.A16 = A16; x.B16p = dY16; x.kextra = (int)(units_all % S);
+                if (M % kq != 0) { x.validK = M; x.b_zero_row = true; }
+                if (int e = launch_gemm_bf16_x(m->prof, nullptr, Kin, (int64_t)Kp * Kin, nullptr, Nout, (int64_t)Kp * Nout, S == 1 ? dW : t->slabs, Nout,
+                                               (int64_t)Kin * Nout, nullptr, nullptr, Kin, Nout, Kp, S, 0, x, s))
+                    return e;
+                if (S > 1)
+                    if (int e = launch_colsum(t->slabs, dW, S, Kin * Nout, t->slabs + (int64_t)S * Kin * Nout, 0, s)) return e;
+                if (db) {
+                    W2V2_REQUIRE(dY, "weight_grad: the bias gradient needs the fp32 dY");
+                    if (int e = launch_colsum(dY, db, M, Nout, t->red_ws, 0, s)) return e;
+                }
+                return W2V2_OK;
+            }
+        }
         // That kernel reads rows past M as zero (GemmShadows::validK), so any M splits into S slabs of ceil(M / 64 / S) K tiles with
         // no leftover pass: the last slab is merely short.
         const bool ragged = !tune_int("W2V2_NO_RAGGED_DW", 0);      // (tuning build: 1 = leftover rows on the tail kernel instead)
@@ -363,29 +393,6 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
                 if (int e = launch_colsum(dY, db, M, Nout, t->red_ws, 0, s)) return e;
             }
             return W2V2_OK;
-        }
-        // Whole rows on the 128 x 256 transposed kernel: ANY slab count works there (GemmShadows::kextra: the first M / 64 mod S slabs
-        // run one K tile more), so take as many slabs as fit the block slots -- 7 x 72 tiles = 504 blocks for the FFN matrices where
-        // the divisor rule below stops at 6 x 72 = 432 (a sixth of the chip idle while the longest CUs run two 64-K-tile blocks).
-        if (wide_tiles && tr_form && tune_int("W2V2_DW_UNEVEN", 1) != 0) {
-            const int64_t units_all = M / kq;
-            const int S = (int)std::min<int64_t>(cap, units_all / 3);      // (a slab is at least three K tiles: the kernel's pipeline depth)
-            if (S >= 1) {
-                const int64_t q = units_all / S;
-                const int Kp = (int)(q * kq);
-                GemmShadows x;
-                x.transA = true; x.A16 = A16; x.B16p = dY16; x.kextra = (int)(units_all % S);
-                if (int e = launch_gemm_bf16_x(m->prof, nullptr, Kin, (int64_t)Kp * Kin, nullptr, Nout, (int64_t)Kp * Nout, S == 1 ? dW : t->slabs, Nout,
-                                               (int64_t)Kin * Nout, nullptr, nullptr, Kin, Nout, Kp, S, 0, x, s))
-                    return e;
-                if (S > 1)
-                    if (int e = launch_colsum(t->slabs, dW, S, Kin * Nout, t->slabs + (int64_t)S * Kin * Nout, 0, s)) return e;
-                if (db) {
-                    W2V2_REQUIRE(dY, "weight_grad: the bias gradient needs the fp32 dY");
-                    if (int e = launch_colsum(dY, db, M, Nout, t->red_ws, 0, s)) return e;
-                }
-                return W2V2_OK;
-            }
         }
         const int64_t units0 = M / kq;
         int64_t units = units0;
@@ -828,7 +835,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         float* dWqkv = t->dwqkv;
         float* dbqkv = dWqkv + (int64_t)3 * H * H;
         if (int e = weight_grad(m, attn_in, only16 ? nullptr : t->g3h, (int)BT, H, 3 * H, dWqkv, only16 ? nullptr : dbqkv, s,
-                                (xs && s16q) ? attn_in16 : nullptr, s16q))
+                                (xs && s16q) ? attn_in16 : nullptr, s16q, s16q != nullptr))
             return e;
         if (only16)
             if (int e = launch_colsum_fold(t->attn_colpart, dbqkv, attention_colpart_rows(B, T), 3 * H, s)) return e;
@@ -898,7 +905,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         if (l.keep != 0.f) {
             W2V2_REQUIRE(!f16 || dh16, "train_backward: no bf16 shadow of the layer's output gradient");
             if (int e = weight_grad(m, f16 ? nullptr : l.gd, dh, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
-                                    G(b + "/feed_forward/output_dense/bias"), s, (xs && dh16) ? l.gd16 : nullptr, dh16))
+                                    G(b + "/feed_forward/output_dense/bias"), s, (xs && dh16) ? l.gd16 : nullptr, dh16, dh16 != nullptr && dh16 == s16h))
                 return e;
             bool b1_done = false;
             float* const gb1 = G(b + "/feed_forward/intermediate_dense/bias");
@@ -907,7 +914,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
             float* const du = du16_only ? nullptr : t->gf;
             if (int e = ffn_hidden_grad(i, l, b, dh, dh16, du16_only, gb1, &b1_done)) return e;
             if (int e = weight_grad(m, l.t2, du, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
-                                    b1_done ? nullptr : gb1, s, xs ? l.t2_16 : nullptr, s16f))
+                                    b1_done ? nullptr : gb1, s, xs ? l.t2_16 : nullptr, s16f, s16f != nullptr))
                 return e;
             if (int e = gemm_dx(du, s16f, F, l.W1T, m->P(b + "/feed_forward/intermediate_dense/kernel"), tmp, H, nullptr, (int)BT, H, F, s)) return e;
             float* dg2 = G(b + "/final_layer_norm/gamma");
@@ -927,7 +934,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         if (!do_tail)
             if (int e = dropout_bwd_bias(nullptr, dt1, do16_only ? nullptr : d_o, s16h, BT, H, 0, layer_stream(i, 1), gbo, &bo_done)) return e;
         if (int e = weight_grad(m, t->ctx16_only ? nullptr : l.ctx, do16_only ? nullptr : d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), bo_done ? nullptr : gbo, s,
-                                (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h))
+                                (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h, s16h != nullptr))
             return e;
         float* dctx = tmp2;
         // (the bf16 attention backward reads dctx and q | k | v as bf16: the GEMM leaves the dctx shadow, the forward left qkv16)
@@ -969,7 +976,8 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         if (l.keep != 0.f) {
             // t3 = t2 + f,  f = gd W2 + b2
             if (int e = weight_grad(m, f16 ? nullptr : l.gd, dt3, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
-                                    gb2 ? nullptr : G(b + "/feed_forward/output_dense/bias"), s, xs ? l.gd16 : nullptr, H % 4 == 0 ? s16h : nullptr))
+                                    gb2 ? nullptr : G(b + "/feed_forward/output_dense/bias"), s, xs ? l.gd16 : nullptr, H % 4 == 0 ? s16h : nullptr,
+                                    s16h != nullptr))
                 return e;
             // du = dgd * keep/(1-p) * GELU'(u)   (+ its column sums = the up-projection's bias gradient)
             bool b1_done = false;
@@ -979,7 +987,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
             float* const du = du16_only ? nullptr : t->gf;
             if (int e = ffn_hidden_grad(i, l, b, dt3, H % 4 == 0 ? s16h : nullptr, du16_only, gb1, &b1_done)) return e;
             if (int e = weight_grad(m, l.t2, du, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
-                                    b1_done ? nullptr : gb1, s, xs ? l.t2_16 : nullptr, s16f))
+                                    b1_done ? nullptr : gb1, s, xs ? l.t2_16 : nullptr, s16f, s16f != nullptr))
                 return e;
             // dt2 = du W1^T + dt3 (the residual branch)
             if (int e = gemm_dx(du, s16f, F, l.W1T, m->P(b + "/feed_forward/intermediate_dense/kernel"), dt2, H, dt3, (int)BT, H, F, s)) return e;
@@ -1007,7 +1015,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         if (!do_tail)
             if (int e = dropout_bwd_bias(nullptr, dt1, do16_only ? nullptr : d_o, s16h, BT, H, 0, layer_stream(i, 1), gbo, &bo_done)) return e;
         if (int e = weight_grad(m, t->ctx16_only ? nullptr : l.ctx, do16_only ? nullptr : d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), bo_done ? nullptr : gbo, s,
-                                (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h))
+                                (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h, s16h != nullptr))
             return e;
         float* dctx = tmp2;   // dt2 is dead
         // (the bf16 attention backward reads dctx and q | k | v as bf16: the GEMM leaves the dctx shadow, the forward left qkv16)

@@ -308,9 +308,12 @@ int w2v2_op_gemm_bf16_at(const float* At_dev, int64_t lda, int64_t strideA,
  * one row.  Kin % 128 == 0, Nout % 128 == 0, rows_per_slab % 64 == 0, 16-byte aligned operands.  (The fine-tune step's dW GEMMs
  * in W2V2_PRECISION_BF16: tf.GradientTape's kernel gradient of Dense, src/main.py:198.)
  * variant: 0 = the kernel the library would pick, 1 = the 128 x 128-tile transposing-read kernel, 2 = the 128 x 256 software-pipelined
- * kernel in its transposed form (whole slabs, Nout % 256 == 0, >= 192 rows per slab); identical bits.  Variant 2 also takes UNEVEN
- * slabs, the form the training step uses to cut B T rows into any number of slabs: rows = rows_per_slab nslabs + 64 e with
- * 0 < e < nslabs gives each of the first e slabs 64 rows more, slab z then starting at row z rows_per_slab + 64 min(z, e). */
+ * kernel in its transposed form (whole 64-row K tiles, Nout % 256 == 0, >= 192 rows per slab); identical bits.  Variant 2 also takes
+ * UNEVEN slabs, the form the training step uses to cut B T rows into any number of slabs: rows = rows_per_slab nslabs + 64 e with
+ * 0 < e < nslabs gives each of the first e slabs 64 rows more, slab z then starting at row z rows_per_slab + 64 min(z, e).
+ * Variant 3 = variant 2 plus the caller's promise that dy16 has one more row, index `rows`, holding zeros: `rows` may then end
+ * inside the last K tile (its missing rows are read from that zero row and from x16's last row) -- what the training step does
+ * with its own dY shadows at B T = 23984 (480000-sample utterances). */
 int w2v2_op_weight_grad_bf16(const uint16_t* x16_dev, const uint16_t* dy16_dev, float* slabs_dev,
                              int64_t rows, int32_t Kin, int32_t Nout, int32_t rows_per_slab, int32_t nslabs, int32_t variant,
                              void* stream);

@@ -419,6 +419,41 @@ def test_weight_grad_bf16_uneven_slabs(env, q, e, Kin, Nout, S):
     assert lib.w2v2_op_weight_grad_bf16(N.ptr(x16), N.ptr(y16), N.ptr(out), 64 * (S * q + S), Kin, Nout, 64 * q, S, 2, stream()) == -1
 
 
+@pytest.mark.parametrize("rows,Kin,Nout,S", [(3 * 64 + 1, 128, 256, 1), (23 * 64 + 48, 768, 768, 4), (14 * 64 + 63, 256, 2304, 3), (374 * 64 + 48, 1024, 1024, 16)])
+def test_weight_grad_bf16_ragged_last_k_tile(env, rows, Kin, Nout, S):
+    """B T need not be a multiple of the 64-row K tile (T = 1499 at 480000 samples: B T = 23984).  With an all-zero row kept behind
+    dy16 the 128 x 256 transposed kernel reads the last tile's missing rows from there (and from x16's last row, which must not leak
+    into the result): variant 3.  Per slab it must equal the exact product over its own rows, and -- on slab boundaries both kernels
+    can express -- carry the bits of the 128 x 128 kernel, which reads missing rows as zero by address select."""
+    lib, torch, dev = env
+    X, dY = rnd("wg4X", (rows, Kin)), rnd("wg4Y", (rows + 1, Nout), 0.3)
+    X[-1] = 1000.0                                   # the row the kernel re-reads for the missing ones: a leak would be loud
+    dY[-1] = 0.0                                     # the promised zero row
+    Xr, Yr = O.round_bf16(X), O.round_bf16(dY)
+    x16 = torch.from_numpy((Xr.view(np.uint32) >> 16).astype(np.uint16).view(np.int16)).to(dev)
+    y16 = torch.from_numpy((Yr.view(np.uint32) >> 16).astype(np.uint16).view(np.int16)).to(dev)
+    units = (rows + 63) // 64
+    q, e = units // S, units % S
+    out3 = torch.full((S, Kin, Nout), float("nan"), device=dev)
+    N.check(lib.w2v2_op_weight_grad_bf16(N.ptr(x16), N.ptr(y16), N.ptr(out3), rows, Kin, Nout, 64 * q, S, 3, stream()), "w2v2_op_weight_grad_bf16")
+    torch.cuda.synchronize()
+    got = out3.cpu().numpy()
+    start = 0
+    for z in range(S):
+        n = min(64 * (q + (1 if z < e else 0)), rows - start)
+        ref = Xr[start:start + n].astype(np.float64).T @ Yr[start:start + n].astype(np.float64)
+        assert np.isfinite(got[z]).all() and H.max_err(got[z], ref) < 2e-5 * max(1.0, np.abs(ref).max()), z
+        start += n
+    assert start == rows
+    if e == 0:          # even slabs: the 128 x 128 kernel (rows past the end read as zero) must give the same bits
+        out1 = torch.full((S, Kin, Nout), float("nan"), device=dev)
+        N.check(lib.w2v2_op_weight_grad_bf16(N.ptr(x16), N.ptr(y16), N.ptr(out1), rows, Kin, Nout, 64 * q, S, 1, stream()), "w2v2_op_weight_grad_bf16")
+        torch.cuda.synchronize()
+        assert torch.equal(out1, out3)
+    # without the promise (variant 2) ragged rows are refused
+    assert lib.w2v2_op_weight_grad_bf16(N.ptr(x16), N.ptr(y16), N.ptr(out3), rows, Kin, Nout, 64 * q, S, 2, stream()) == -1
+
+
 @pytest.mark.parametrize("rows,Kin,Nout,S", [(256, 128, 132, 1), (512, 768, 64, 4), (1024, 132, 256, 8)])
 def test_gemm_bf16_transposed_a_split_k(env, rows, Kin, Nout, S):
     """dW = X^T dY as the training step runs it in precision mode 1: X (rows, Kin) is passed as the TRANSPOSED A of the GEMM
