@@ -933,9 +933,6 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         float* d_o = tmp;
         if (!do_tail)
             if (int e = dropout_bwd_bias(nullptr, dt1, do16_only ? nullptr : d_o, s16h, BT, H, 0, layer_stream(i, 1), gbo, &bo_done)) return e;
-        if (int e = weight_grad(m, t->ctx16_only ? nullptr : l.ctx, do16_only ? nullptr : d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), bo_done ? nullptr : gbo, s,
-                                (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h, s16h != nullptr))
-            return e;
         float* dctx = tmp2;
         // (the bf16 attention backward reads dctx and q | k | v as bf16: the GEMM leaves the dctx shadow, the forward left qkv16)
         uint16_t* const dctx16 = (s16q && dx_shadowed(m->P(b + "/attention/out_proj/kernel"))) ? t->dy16_ctx : nullptr;
@@ -947,6 +944,11 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         const bool q16 = dqkv16_only(i, l.a16);
         if (int e = launch_attention_bwd(pf, t->x16_attn ? nullptr : l.qkv, flen, c16 ? nullptr : l.ctx, c16 ? nullptr : dctx, q16 ? nullptr : t->g3h, t->dvec, B, T, H, c.num_heads, tr,
                                          s, s16q, t->x16_attn ? l.qkv16 : nullptr, dctx16, q16 ? t->attn_colpart : nullptr, c16 ? l.ctx16 : nullptr))
+            return e;
+        // (the out-projection's weight gradient runs here, not before its data gradient: the attention backward has just read O, so
+        //  the GEMM finds it in the Infinity Cache instead of streaming it from HBM cold; d_o / its shadow are untouched until below)
+        if (int e = weight_grad(m, t->ctx16_only ? nullptr : l.ctx, do16_only ? nullptr : d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), bo_done ? nullptr : gbo, s,
+                                (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h, s16h != nullptr))
             return e;
         if (int e = qkv_weight_grad(b, l.a, l.a16, q16)) return e;
         if (int e = gemm_dx(q16 ? nullptr : t->g3h, s16q, 3 * H, l.WqkvT, m->qkv_w[i], tmp, H, nullptr, (int)BT, H, 3 * H, s)) return e;
@@ -1014,9 +1016,6 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         bo_done = do_tail && gbo;
         if (!do_tail)
             if (int e = dropout_bwd_bias(nullptr, dt1, do16_only ? nullptr : d_o, s16h, BT, H, 0, layer_stream(i, 1), gbo, &bo_done)) return e;
-        if (int e = weight_grad(m, t->ctx16_only ? nullptr : l.ctx, do16_only ? nullptr : d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), bo_done ? nullptr : gbo, s,
-                                (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h, s16h != nullptr))
-            return e;
         float* dctx = tmp2;   // dt2 is dead
         // (the bf16 attention backward reads dctx and q | k | v as bf16: the GEMM leaves the dctx shadow, the forward left qkv16)
         uint16_t* const dctx16 = (s16q && dx_shadowed(m->P(b + "/attention/out_proj/kernel"))) ? t->dy16_ctx : nullptr;
@@ -1028,6 +1027,9 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         const bool q16 = dqkv16_only(i, hs16_i);
         if (int e = launch_attention_bwd(pf, t->x16_attn ? nullptr : l.qkv, flen, c16 ? nullptr : l.ctx, c16 ? nullptr : dctx, q16 ? nullptr : t->g3h, t->dvec, B, T, H, c.num_heads, tr,
                                          s, s16q, t->x16_attn ? l.qkv16 : nullptr, dctx16, q16 ? t->attn_colpart : nullptr, c16 ? l.ctx16 : nullptr))
+            return e;
+        if (int e = weight_grad(m, t->ctx16_only ? nullptr : l.ctx, do16_only ? nullptr : d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), bo_done ? nullptr : gbo, s,
+                                (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h, s16h != nullptr))
             return e;
         if (int e = qkv_weight_grad(b, m->hs[i], hs16_i, q16)) return e;
         // dx = dqkv Wqkv^T + dt1 (residual)
