@@ -173,7 +173,9 @@ def _bf16_bits(torch, t):
     (257, 768, 768, 0, True, True, True, False),         # fp32 output + residual (out-projection / FFN down form)
     (1000, 2304, 768, 2, True, False, True, True),       # tanh GELU, both outputs
     (640, 768, 3072, 0, True, True, True, True),         # long K
-    (130, 256, 256, 1, True, False, False, True)])
+    (130, 256, 256, 1, True, False, False, True),
+    (8192 + 128, 768, 768, 0, True, True, True, True)])  # 25-MB outputs: tile pointers whose low word has bit 31 set (a sign-extended
+                                                         # scalar base of the residual prefetch faulted from M = 8192 on)
 def test_gemm_bf16_shadow_kernels_agree_bit_for_bit(env, M, N_, K, act, use_bias, use_res, f32_out, b16_out):
     """The shadow-fed form of the bf16 GEMM (both operands already bf16, streamed HBM / L2 -> LDS by DMA) has two kernels:
     128 x 128 tiles (gemm_bf16.hip) and 128 x 256 software-pipelined 4-wave blocks (gemm_bf16_sw.hip).  Same products, same
