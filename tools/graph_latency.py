@@ -8,6 +8,7 @@ import torch
 import wav2vec2
 torch.cuda.set_device(0)
 m = wav2vec2.Wav2Vec2ForCTC(wav2vec2.Wav2Vec2Config())
+m.set_precision(sys.argv[1] if len(sys.argv) > 1 else "fp32")
 for L in (50000, 246000):
     x = torch.randn(1, L, device="cuda")
     for _ in range(3): ref = m(x)                       # warm-up: workspace allocation, function attributes
