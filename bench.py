@@ -308,25 +308,59 @@ def golden_rows(L):
     return wave, logits
 
 
-def measured_traffic(precision="fp32", mode="forward"):
-    """HBM bytes per launch of the dominant GEMM family, from the committed rocprofv3 --pmc summaries of this same command
-    (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction: tools/prof_summary.py for fp32, tools/pmc_bench.sh
-    for the bf16 family: launch-weighted mean over its kernels).  Committed numbers, not measured in this run."""
+def _sha16(path):
+    import hashlib
     try:
+        with open(path, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+KERNEL_SOURCES = {"fp32": ("gemm_f32.hip", "gemm_epilogue.h"), "bf16": ("gemm_bf16.hip", "gemm_bf16_sw.hip", "gemm_epilogue.h")}
+
+
+def kernel_source_hash(precision):
+    """sha256 (first 16 hex digits) over the kernel sources of the dominant GEMM family: the key a committed PMC figure is valid for."""
+    import hashlib
+    h = hashlib.sha256()
+    for fn in KERNEL_SOURCES.get(precision, ()):
+        try:
+            with open(os.path.join(ROOT, "gsoc-wav2vec2_amd", "csrc", fn), "rb") as f:
+                h.update(f.read())
+        except OSError:
+            return None
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(precision="fp32", mode="forward"):
+    """HBM bytes per launch of the dominant GEMM family from the committed rocprofv3 --pmc summaries of this same command
+    (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction; tools/pmc_traffic.sh writes them together with the
+    round and the hash of the kernel sources they were measured on).  PMC counters cannot be collected from inside the run, so this
+    is a STORED figure: returned with its provenance, and refused (None, with the reason) when the kernel sources have changed
+    since it was measured -- a stale number is never printed as if it were current."""
+    out = {"bytes": None, "source": None}
+    try:
+        fn = "hbm_traffic_latest.json" if precision == "fp32" else "hbm_traffic_bf16.json"
+        with open(os.path.join(ROOT, "profiles", fn)) as f:
+            js = json.load(f)
+        meta = js.get("_meta", {})
+        want = kernel_source_hash(precision)
+        if meta.get("kernel_source_sha16") != want:
+            out["source"] = (f"profiles/{fn} was measured on kernel sources {meta.get('kernel_source_sha16')} (round {meta.get('round')}); "
+                             f"the sources are now {want}: stale, not printed -- rerun tools/pmc_traffic.sh")
+            return out
         if precision == "fp32":
-            with open(os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")) as f:
-                js = json.load(f)
             hits = [v for k, v in js.items() if "gemm_f32" in k]
-            if hits:
-                v = max(hits, key=lambda e: e.get("launches", 0))       # the 128x128 kernel, not the small-problem variant
-                return round(v["fetch_corrected_bytes"] + v["write_bytes"])
-        elif precision == "bf16":
-            with open(os.path.join(ROOT, "profiles", "hbm_traffic_bf16.json")) as f:
-                js = json.load(f)[mode]
-            return round(js["fetch_corrected_bytes_per_launch"] + js["write_bytes_per_launch"])
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+            v = max(hits, key=lambda e: e.get("launches", 0))       # the 128x128 kernel, not the small-problem variant
+            out["bytes"] = round(v["fetch_corrected_bytes"] + v["write_bytes"])
+        else:
+            v = js[mode]
+            out["bytes"] = round(v["fetch_corrected_bytes_per_launch"] + v["write_bytes_per_launch"])
+        out["source"] = f"committed PMC profile profiles/{fn} (round {meta.get('round')}, kernel sources {want}); not measured in this run"
+    except (OSError, ValueError, KeyError) as exc:
+        out["source"] = f"no usable PMC profile: {exc!r}"
+    return out
 
 
 def self_launch(n):
@@ -345,6 +379,248 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+PEAK_CLOCK_MHZ = 2400.0           # MI355X_MICROARCH.md: the clock the peak figures are quoted at
+
+
+def clock_under_load(ctx, model, x, amask):
+    """Shader clock while this workload's forward runs, measured live: a one-wave probe kernel (w2v2_clock_probe, csrc/clock_probe.hip)
+    on a side stream samples the shader-cycle counter and the constant-rate wall clock over a window inside an (untimed) forward on
+    the main stream.  MI355X clocks to its power budget, so the 2.4 GHz behind the nominal peak is not what the MFMA GEMMs run at;
+    `frac_clock_adjusted` = achieved / (peak x measured clock / 2400).  The idle figure (probe alone) is printed beside it."""
+    import ctypes as C
+    torch = ctx["torch"]
+    from wav2vec2 import _native as N
+    lib = N.load()
+    side = torch.cuda.Stream()
+    buf = torch.zeros(8, dtype=torch.int64, device=ctx["dev"])
+    khz = C.c_int32()
+
+    def mhz(t):
+        v = t.cpu().tolist()
+        dc, dw = v[2] - v[0], v[3] - v[1]
+        return (dc / dw * khz.value / 1000.0, dw * 1e3 / khz.value) if dw > 0 else (None, 0.0)
+
+    try:
+        torch.cuda.synchronize()
+        time.sleep(0.05)
+        N.check(lib.w2v2_clock_probe(C.c_void_p(side.cuda_stream), 5000, C.c_void_p(buf[:4].data_ptr()), C.byref(khz)), "w2v2_clock_probe")
+        torch.cuda.synchronize()
+        idle, _ = mhz(buf[:4])
+        model(x, attention_mask=amask)                          # re-warm, then the probed forward
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model(x, attention_mask=amask)                          # enqueue only (asynchronous)
+        t_enq = time.perf_counter() - t0
+        N.check(lib.w2v2_clock_probe(C.c_void_p(side.cuda_stream), 25000, C.c_void_p(buf[4:].data_ptr()), C.byref(khz)), "w2v2_clock_probe")
+        torch.cuda.synchronize()
+        busy, window_us = mhz(buf[4:])
+        return {"clock_mhz_under_load": round(busy, 1) if busy else None, "clock_mhz_idle": round(idle, 1) if idle else None,
+                "clock_method": f"live: one-wave probe kernel on a side stream, d(s_memtime) / d(s_memrealtime) over a {window_us / 1e3:.1f} ms window "
+                                f"inside one untimed forward of this workload (enqueue took {1e3 * t_enq:.1f} ms); cross-check by PMC "
+                                "(GRBM_GUI_ACTIVE / 8 XCDs / kernel duration) in profiles/"}
+    except Exception as exc:                                    # noqa: BLE001 -- a side measurement never costs the line
+        return {"clock_mhz_under_load": None, "clock_error": repr(exc)[:200]}
+
+
+FAMILY_OF = {"fp32": "gemm_f32", "bf16": "gemm_bf16", "bf16x3": "gemm_split"}
+PEAK_OF = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16x3": round(PEAK_BF16_MFMA_TFLOPS / 6, 1)}
+KERNEL_OF = {
+    "fp32": "gemm_f32_dma_kernel (fp32 MFMA 32x32x2, LDS-DMA staged: conv1-6 implicit GEMM + all Dense layers)",
+    "bf16": "gemm_bf16 family (bf16 MFMA 32x32x16, operands from bf16 shadows by LDS-DMA: gemm_bf16_sw_kernel 128x256 software-pipelined "
+            "for the large shapes, gemm_bf16_kernel 128x128 for the rest, gemm_bf16_tr_kernel for weight gradients: conv1-6 + all Dense)",
+    "bf16x3": "gemm_split_kernel (fp32 GEMM as 6 bf16 MFMA 32x32x16 products of exact 3-term operand splits; peak = bf16 dense peak / 6)",
+}
+DTYPE_OF = {"fp32": "f32", "bf16": "bf16 operands, f32 accumulate (Dense / Conv1D); f32 elsewhere",
+            "bf16x3": "f32 operands as exact 3 x bf16 sums, 6 bf16 MFMA products per f32 product, f32 accumulate (Dense / Conv1D); f32 elsewhere"}
+MATRIX_FAMILIES = ("gemm_f32", "gemm_bf16", "gemm_split", "pos_conv", "attention", "conv0_apply")
+
+
+def make_labels(B, rank):
+    """labels (B, 256) int32, first 24..200 entries uniform in [1, 31], rest 0."""
+    import numpy as np
+    rs = np.random.RandomState(7 + rank)
+    labels = np.zeros((B, 256), np.int32)
+    for b in range(B):
+        n = rs.randint(24, 201)
+        labels[b, :n] = rs.randint(1, 32, size=n)
+    return labels
+
+
+def run_leg(ctx, spec, model=None):
+    """Time one workload: `warmup` untimed steps, then exactly `steps` steps between barrier + synchronize on both sides, MAX over
+    ranks.  spec: model ("base" | "large-robust"), precision, mode ("forward" | "train"), B (rows per GPU), L, steps, warmup, profile.
+    Returns (numbers, model, last output).  A training leg on more than one rank runs the bucketed RCCL gradient all-reduce inside
+    every timed step (Trainer.step) and is then timed again WITHOUT it to report the exposed communication time."""
+    torch, D, W, dev, world, rank = ctx["torch"], ctx["D"], ctx["W"], ctx["dev"], ctx["world"], ctx["rank"]
+    cfg = W.Wav2Vec2Config() if spec["model"] == "base" else W.RobustWav2Vec2Config()
+    B, L, mode, precision = spec["B"], spec["L"], spec["mode"], spec["precision"]
+    steps, warmup, do_prof = spec["steps"], spec["warmup"], spec.get("profile", True)
+    T = cfg.num_frames(L)
+    if model is None:
+        model = W.Wav2Vec2ForCTC(cfg, input_shape=(B, L))       # random-init weights from the seeded generator (seed 0)
+    model.set_precision(precision)
+    family = FAMILY_OF[precision]
+
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    x = torch.randn((B, L), generator=gen, device=dev, dtype=torch.float32)   # resident in HBM
+    # Parity inside the timed workload (SURVEY 8d C2): rows 0-1 of every rank's batch are the two waveforms of the committed
+    # HF fixture, so the logits the timed forward produces for them are checked against HF-PyTorch fp64.
+    gold_wave, gold_logits = (None, None)
+    if spec["model"] == "base" and mode == "forward" and B >= 2:
+        gold_wave, gold_logits = golden_rows(L)
+        if gold_wave is not None:
+            x[:2] = torch.from_numpy(gold_wave).to(dev)
+    amask = torch.ones((B, L), device=dev, dtype=torch.int32) if cfg.is_robust else None   # robust models take a mask
+
+    def barrier():
+        D.barrier(sync_device=torch.cuda.synchronize)
+
+    trainer = None
+    if mode == "train":
+        labels_dev = torch.from_numpy(make_labels(B, rank)).to(dev)
+        model.freeze_feature_extractor()                      # stage 2 of the reference (main.py:234-237)
+        trainer = W.Trainer(model, W.CTCLoss(cfg, (B, L), division_factor=world * B), learning_rate=1e-4, seed=rank)
+
+        def step(all_reduce=True):
+            return trainer.step(x, labels_dev, attention_mask=amask, all_reduce=all_reduce)
+    else:
+        def step(all_reduce=True):
+            return model(x, attention_mask=amask)
+
+    out = None
+    for _ in range(warmup):
+        out = step()
+    barrier()
+    # Timed region: HIP events bracket ONLY the dominant kernel family (the roofline object), and of that family every
+    # EVENT_STRIDE-th launch: an event pair costs ~7 us of stream time (all ~150 GEMM launches of a bf16 fine-tune step:
+    # +0.9 ms = 2.3 % on `value`, measured).  The stride is coprime to the launches per step of every configuration, so over the
+    # timed steps the samples rotate through all shapes equally and the flop-weighted average is the family's.
+    if do_prof:
+        model.profile(True, families=[family], stride=EVENT_STRIDE)
+    model.profile_reset()                                      # (also clears the kernel-launch counters)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = model.profile_read()
+    model.profile(False)
+    elapsed = D.max_over_ranks(elapsed, device=dev)            # the slowest rank defines the step
+    res = {"elapsed": elapsed, "ms_per_step": 1e3 * elapsed / steps, "B": B, "L": L, "T": T, "cfg": cfg, "x": x, "amask": amask,
+           "family": family, "prof": prof if do_prof else {}, "gold_wave": gold_wave,
+           "kernel_launches_per_step": {k: v["kernels"] // steps for k, v in prof.items() if v["kernels"]},
+           "op_calls_per_step": {k: v["issued"] // steps for k, v in prof.items() if v["issued"]}}
+
+    # -- the gradient collective, measured (N > 1 training legs): the same steps without it, and the collective alone
+    if trainer is not None:
+        payload, buckets, colls = trainer.all_reduce_payload()
+        ar = {"payload_bytes": payload, "buckets": buckets, "collectives_per_step": colls, "payload_dtype": trainer.allreduce_dtype,
+              "op": "SUM all-reduce of the trainable slots of the flat gradient buffer, one per bucket (lm_head, encoder layers N-1 .. 0, front) "
+                    "on a communication stream behind that bucket's completion event, under the rest of the backward (Trainer.all_reduce_gradients)",
+              "backend": ctx["comm"]["backend"], "world_size": world}
+        if world > 1:
+            for _ in range(1):
+                step(all_reduce=False)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                step(all_reduce=False)
+            barrier()
+            e_no = D.max_over_ranks(time.perf_counter() - t1, device=dev)
+            trainer.overlap_all_reduce = False                 # the collective alone: all buckets back to back on the calling stream
+            trainer.all_reduce_gradients()
+            barrier()
+            reps = 3
+            t2 = time.perf_counter()
+            for _ in range(reps):
+                trainer.all_reduce_gradients()
+            barrier()
+            e_ar = D.max_over_ranks(time.perf_counter() - t2, device=dev) / reps
+            trainer.overlap_all_reduce = True
+            ar.update({"ms_per_step_without_collective": round(1e3 * e_no / steps, 3),
+                       "exposed_ms": round(1e3 * (elapsed - e_no) / steps, 3),
+                       "standalone_ms": round(1e3 * e_ar, 3),
+                       "busbw_GBps": round(payload * 2 * (world - 1) / world / e_ar / 1e9, 1),
+                       "algbw_GBps": round(payload / e_ar / 1e9, 1),
+                       "busbw_note": "payload x 2 (N - 1) / N / standalone time (ring all-reduce convention); xGMI: 7 links x ~153 GB/s per GPU"})
+        else:
+            ar["note"] = "one rank: no collective is issued (SUM over one replica is the identity); the N > 1 lines carry exposed_ms / busbw"
+        res["allreduce"] = ar
+
+    # -- per-family breakdown: two extra, untimed steps with every family instrumented
+    if do_prof:
+        model.profile(True)
+        model.profile_reset()
+        for _ in range(2):
+            out = step()
+        barrier()
+        res["prof_all"] = model.profile_read()
+        model.profile(False)
+    if mode == "train":
+        assert bool(torch.isfinite(out).all()), "training loss is not finite"
+        res["final_loss"] = round(float(out), 4)
+    else:
+        assert tuple(out.shape) == (B, T, cfg.vocab_size) and bool(torch.isfinite(out).all())
+    if gold_logits is not None:
+        # `out` is the output of the last TIMED-configuration forward (per-family instrumentation does not change results)
+        err = float((out[:2].double().cpu() - torch.from_numpy(gold_logits).double()).abs().max())
+        bar = 1e-3 if precision in ("fp32", "bf16x3") else 0.15
+        assert err < bar, f"rank {rank}: max |logits - HF fp64| = {err:.3e} exceeds {bar}"
+        res["logit_err"] = D.max_over_ranks(err, device=dev)
+    return res, model, out
+
+
+def roofline_of(res, spec, steps):
+    """The `roofline` object of a leg: algorithmic FLOPs of the event-bracketed launches of the dominant GEMM family / their HIP-event time."""
+    gm = res["prof"].get(res["family"])
+    if not gm or gm["ms"] <= 0:
+        return None
+    precision = spec["precision"]
+    ach, peak = gm["flops"] / (gm["ms"] * 1e-3) / 1e12, PEAK_OF[precision]
+    return {"kernel": KERNEL_OF[precision], "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "launches_per_step": gm["issued"] // max(1, steps),
+            "kernel_launches_per_step": gm["kernels"] // max(1, steps),
+            "launches_note": "launches_per_step = op-level GEMM calls; kernel_launches_per_step = kernels enqueued for them (a call whose last "
+                             "round of tiles is underfilled runs a main + a tail-tile kernel): the count a rocprofv3 kernel trace shows",
+            "avg_launch_ms": round(gm["ms"] / max(1, gm["launches"]), 4),
+            "traffic_algorithmic": round(gm["bytes"] / max(1, gm["launches"])),
+            "traffic_algorithmic_note": "compulsory HBM bytes per op-level call (A + B + C once each), mean over the bracketed launches",
+            "event_sampling": f"every {EVENT_STRIDE}th launch of the family bracketed ({gm['launches']} of {gm['issued']})"}
+
+
+def families_of(res, world, steps):
+    """Per-family ms / step from the two instrumented steps, with `share` of the TIMED step (so the shares plus `unattributed`
+    add to 1: launch gaps, host time and anything un-instrumented show up instead of being normalised away)."""
+    pa = res.get("prof_all") or {}
+    step_ms = res["ms_per_step"]
+    fam = {k: {"ms_per_step": round(v["ms"] / 2, 3), "share": round(v["ms"] / 2 / step_ms, 4),
+               "kernel_launches_per_step": v["kernels"] // 2,
+               "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0,
+               "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0.0}
+           for k, v in pa.items() if v["launches"] > 0}
+    attributed = sum(v["ms"] for v in pa.values()) / 2
+    flops_step = sum(v["flops"] for k, v in pa.items() if k in MATRIX_FAMILIES) / 2
+    return fam, round(step_ms - attributed, 3), sum(v["kernels"] for v in pa.values()) // 2, flops_step
+
+
+def side_object(ctx, spec, res, label):
+    """One BASELINE configuration measured beside the headline, as a self-contained object of the JSON line."""
+    world = ctx["world"]
+    B, L, steps = res["B"], res["L"], spec["steps"]
+    fam, unattr, kernels, flops_step = families_of(res, world, steps)
+    obj = {"workload": label, "n_gpus": world, "global_batch": world * B, "samples": L, "frames": res["T"], "steps": steps, "warmup": spec["warmup"],
+           "ms_per_step": round(res["ms_per_step"], 3), "value": round(world * B * L / SAMPLE_RATE * steps / res["elapsed"], 2),
+           "unit": "audio-seconds/s", "dtype": DTYPE_OF[spec["precision"]], "roofline": roofline_of(res, spec, steps),
+           "families": fam, "unattributed_ms": unattr, "kernel_launches_per_step": kernels,
+           "matrix_tflops": round(flops_step * world / (res["ms_per_step"] * 1e-3) / 1e12, 2)}
+    if "final_loss" in res:
+        obj["final_loss"] = res["final_loss"]
+    if "allreduce" in res:
+        obj["allreduce"] = res["allreduce"]
+    return obj
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -355,6 +631,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="run only the CPU leg (no GPU needed) and print its object")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra bf16x3 measurement printed beside the headline")
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip the other BASELINE configurations measured beside the headline (configs[2] bf16 fine-tune step, configs[3] "
+                         "large-robust fp32 forward, configs[4] large bf16 fine-tune step at 480000 samples)")
+    ap.add_argument("--side-shrink", type=int, default=1, help="(tests) divide the side legs' per-GPU batch by this factor")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--model", choices=["base", "large-robust"], default="base",
                     help="base = wav2vec2-base (the headline); large-robust = 24L/1024d prenorm, LayerNorm convs, conv bias, "
@@ -365,6 +645,9 @@ def main():
     ap.add_argument("--mode", choices=["forward", "train"], default="forward",
                     help="forward = BASELINE configs[1] (the headline metric); train = one CTC fine-tune step "
                          "(BASELINE configs[2] shape, fp32: forward + CTC + backward + gradient all-reduce + Adam)")
+    ap.add_argument("--backend", default=os.environ.get("W2V2_BENCH_BACKEND", "nccl"),
+                    help="process-group backend: nccl (= RCCL, the default and the only one a result may be quoted on); gloo exists so the "
+                         "N > 1 code path can be exercised by two processes on ONE GPU, which RCCL refuses (tests/test_dist_gpu.py)")
     args = ap.parse_args()
 
     if args.cpu_baseline_only:
@@ -382,6 +665,9 @@ def main():
         # torch.distributed.run, rendezvous on 127.0.0.1 at a free port) and pass rank 0's JSON line through.
         raise SystemExit(self_launch(args.gpus))
 
+    t_start = time.perf_counter()
+    import gc
+
     import torch
     import torch.distributed as dist
 
@@ -393,93 +679,19 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus must agree")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    D.init(backend="nccl", device=dev)        # RCCL; no-op for a single process
-    comm = D.describe()                       # what the process group itself reports (echoed in the JSON line)
+    local_dev = local_rank % torch.cuda.device_count() if args.backend != "nccl" else local_rank     # (gloo test: ranks may share a GPU)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    D.init(backend=args.backend, device=dev)      # nccl = RCCL; no-op for a single un-launched process
+    comm = D.describe()                           # what the process group itself reports (echoed in the JSON line)
+    ctx = {"torch": torch, "D": D, "W": wav2vec2, "dev": dev, "world": world, "rank": rank, "comm": comm}
 
-    cfg = wav2vec2.Wav2Vec2Config() if args.model == "base" else wav2vec2.RobustWav2Vec2Config()
-    weights = V.seeded_weights(cfg, seed=0)
-    model = wav2vec2.Wav2Vec2ForCTC(cfg, input_shape=(args.batch, args.samples))
-    model.set_weights(weights)
-    model.set_precision(args.precision)
-    gemm_family = {"fp32": "gemm_f32", "bf16": "gemm_bf16", "bf16x3": "gemm_split"}[args.precision]
-    B, L = args.batch, args.samples
-    T = cfg.num_frames(L)
-
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-    x = torch.randn((B, L), generator=gen, device=dev, dtype=torch.float32)   # resident in HBM
-    # Parity inside the timed workload: rows 0-1 of every rank's batch are the two waveforms of the committed
-    # HF fixture, so the logits the timed forward produces for them are checked against HF-PyTorch fp64.
-    gold_wave, gold_logits = (None, None)
-    if args.model == "base" and args.mode == "forward" and B >= 2:
-        gold_wave, gold_logits = golden_rows(L)
-        if gold_wave is not None:
-            x[:2] = torch.from_numpy(gold_wave).to(dev)
-    amask = torch.ones((B, L), device=dev, dtype=torch.int32) if cfg.is_robust else None   # robust models take a mask
-
-    def barrier():
-        D.barrier(sync_device=torch.cuda.synchronize)
-
-    if args.mode == "train":
-        # labels (B, 256) int32, first 24..200 entries uniform in [1, 31], rest 0
-        import numpy as np
-        rs = np.random.RandomState(7 + rank)
-        labels = np.zeros((B, 256), np.int32)
-        for b in range(B):
-            n = rs.randint(24, 201)
-            labels[b, :n] = rs.randint(1, 32, size=n)
-        labels_dev = torch.from_numpy(labels).to(dev)
-        model.freeze_feature_extractor()                      # stage 2 of the reference (main.py:234-237)
-        trainer = wav2vec2.Trainer(model, wav2vec2.CTCLoss(cfg, (B, L), division_factor=world * B), learning_rate=1e-4, seed=rank)
-
-        def step():
-            return trainer.step(x, labels_dev, attention_mask=amask)
-    else:
-        def step():
-            return model(x, attention_mask=amask)
-
-    for _ in range(args.warmup):
-        out = step()
-    barrier()
-    # Timed region: HIP events bracket ONLY the dominant kernel family (the roofline object), and of that family every
-    # EVENT_STRIDE-th launch: an event pair costs ~7 us of stream time (all ~150 GEMM launches of a bf16 fine-tune step:
-    # +0.9 ms = 2.3 % on `value`, measured).  The stride is coprime to the launches per step of every configuration, so over the
-    # timed steps the samples rotate through all shapes equally and the flop-weighted average is the family's.
-    if not args.no_profile:
-        model.profile(True, families=[gemm_family], stride=EVENT_STRIDE)
-        model.profile_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = model.profile_read() if not args.no_profile else {}
-    model.profile(False)
-    # Per-family breakdown: two extra, untimed steps with every family instrumented.
-    prof_all = {}
-    if not args.no_profile:
-        model.profile(True)
-        model.profile_reset()
-        for _ in range(2):
-            out = step()
-        barrier()
-        prof_all = model.profile_read()
-        model.profile(False)
-    if args.mode == "train":
-        assert bool(torch.isfinite(out).all()), "training loss is not finite"
-    else:
-        assert tuple(out.shape) == (B, T, cfg.vocab_size) and bool(torch.isfinite(out).all())
-    logit_err = None
-    if gold_logits is not None:
-        # `out` is the output of the last TIMED-configuration forward (per-family instrumentation does not change results)
-        logit_err = float((out[:2].double().cpu() - torch.from_numpy(gold_logits).double()).abs().max())
-        bar = 1e-3 if args.precision in ("fp32", "bf16x3") else 0.15
-        assert logit_err < bar, f"rank {rank}: max |logits - HF fp64| = {logit_err:.3e} exceeds {bar}"
-        logit_err = D.max_over_ranks(logit_err, device=dev)
-
-    elapsed = D.max_over_ranks(elapsed, device=dev)      # the slowest rank defines the step
+    spec = {"model": args.model, "precision": args.precision, "mode": args.mode, "B": args.batch, "L": args.samples,
+            "steps": args.steps, "warmup": args.warmup, "profile": not args.no_profile}
+    res, model, out = run_leg(ctx, spec)
+    cfg, B, L, T, x, amask = res["cfg"], res["B"], res["L"], res["T"], res["x"], res["amask"]
+    elapsed, prof, logit_err, gold_wave = res["elapsed"], res["prof"], res.get("logit_err"), res["gold_wave"]
+    gemm_family = res["family"]
 
     # Beside the headline (never as it): the same workload in precision mode "bf16x3" -- fp32-level results from the bf16
     # matrix cores.  Single-process forward runs of the fp32 configuration only; timed after the headline.
@@ -521,9 +733,14 @@ def main():
         except Exception as exc:                               # noqa: BLE001
             alt = {"precision": "bf16x3", "error": repr(exc)}
 
+    clk_probe = None
+    if rank == 0 and args.mode == "forward" and not args.no_profile:
+        clk_probe = clock_under_load(ctx, model, x, amask)
+
+    line = None
     if rank == 0:
         audio_s = world * B * L / SAMPLE_RATE * args.steps
-        res = {
+        line = {
             "metric": f"audio-seconds/s (wav2vec2-{args.model} forward, {L}-sample pad)" if args.mode == "forward"
                       else f"audio-seconds/s (wav2vec2-{args.model} CTC fine-tune step, {L}-sample pad)",
             "value": round(audio_s / elapsed, 2),
@@ -535,8 +752,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16": "bf16 operands, f32 accumulate (Dense / Conv1D); f32 elsewhere",
-                      "bf16x3": "f32 operands as exact 3 x bf16 sums, 6 bf16 MFMA products per f32 product, f32 accumulate (Dense / Conv1D); f32 elsewhere"}[args.precision],
+            "dtype": DTYPE_OF[args.precision],
             "data": "synthetic",
             "comm": comm,
             "config": {"workload": (f"wav2vec2-{args.model} {args.precision} forward-only, batch={B}x{L} samples per GPU"
@@ -549,52 +765,88 @@ def main():
                        "global_batch": world * B, "samples": L, "frames": T, "parallelism": f"dp{world}"},
         }
         if prof:
-            gm = prof[gemm_family]
-            ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
-            # bf16x3: the algorithmic (fp32-product) rate is bounded by the bf16 pipe / 6 products
-            peak = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16x3": round(PEAK_BF16_MFMA_TFLOPS / 6, 1)}[args.precision]
-            res["roofline"] = {
-                "kernel": ("gemm_f32_dma_kernel (fp32 MFMA 32x32x2, LDS-DMA staged: conv1-6 implicit GEMM + all Dense layers)" if args.precision == "fp32"
-                           else "gemm_bf16 family (bf16 MFMA 32x32x16, operands from bf16 shadows by LDS-DMA: gemm_bf16_sw_kernel 128x256 software-pipelined "
-                                "for the large shapes, gemm_bf16_kernel 128x128 for the rest, gemm_bf16_tr_kernel for weight gradients: conv1-6 + all Dense)"
-                           if args.precision == "bf16" else
-                           "gemm_split_kernel (fp32 GEMM as 6 bf16 MFMA 32x32x16 products of exact 3-term operand splits; peak = bf16 dense peak / 6)"),
-                "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": measured_traffic(args.precision, args.mode) if (args.model, B, L) == ("base", 32, 246000) else None,
-                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
-                "launches_per_step": gm.get("issued", gm["launches"]) // max(1, args.steps),
-                "avg_launch_ms": round(gm["ms"] / max(1, gm["launches"]), 4),
-                "event_sampling": f"every {EVENT_STRIDE}th launch of the family bracketed ({gm['launches']} of {gm.get('issued', gm['launches'])})",
-            }
-            tot = sum(v["ms"] for v in prof_all.values())
-            res["families"] = {
-                k: {"ms_per_step": round(v["ms"] / 2, 3),
-                    "share": round(v["ms"] / tot, 4) if tot > 0 else 0.0,
-                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0,
-                    "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0.0}
-                for k, v in prof_all.items() if v["launches"] > 0}
-            res["families_note"] = "per-family breakdown from 2 extra untimed steps with every family instrumented"
+            roof = roofline_of(res, spec, args.steps)
+            if (args.model, B, L) == ("base", 32, 246000) and args.precision in ("fp32", "bf16"):
+                tr = measured_traffic(args.precision, args.mode)
+                roof["traffic"], roof["traffic_source"] = tr["bytes"], tr["source"]
+            else:
+                roof["traffic"], roof["traffic_source"] = None, "no PMC profile is kept for this configuration"
+            roof["traffic_unit"] = "HBM bytes per kernel launch of the family (rocprofv3 PMC FETCH_SIZE x 2 + WRITE_SIZE, separate passes)"
+            clk = clk_probe
+            if clk:
+                roof.update(clk)
+                if clk.get("clock_mhz_under_load"):
+                    adj = roof["peak"] * clk["clock_mhz_under_load"] / PEAK_CLOCK_MHZ
+                    roof["peak_at_measured_clock"] = round(adj, 1)
+                    roof["frac_clock_adjusted"] = round(roof["achieved"] / adj, 4)
+            line["roofline"] = roof
+            fam, unattr, kernels, flops_step = families_of(res, world, args.steps)
+            line["families"] = fam
+            line["unattributed_ms"] = unattr
+            line["kernel_launches_per_step"] = kernels
+            line["families_note"] = ("per-family breakdown from 2 extra untimed steps with every family instrumented; share = family ms / the TIMED "
+                                     "ms_per_step, unattributed_ms = the rest (launch gaps, host time, un-instrumented work)")
             # whole-forward algorithmic rate: 235.56 GFLOP per 246000-sample utterance scales with T
-            flops_step = sum(v["flops"] for k, v in prof_all.items() if k in ("gemm_f32", "gemm_bf16", "gemm_split", "pos_conv", "attention", "conv0_apply")) / 2
-            res["forward_tflops"] = round(flops_step * world / (elapsed / args.steps) / 1e12, 2)
+            line["forward_tflops"] = round(flops_step * world / (elapsed / args.steps) / 1e12, 2)
         if logit_err is not None:
-            res["max_abs_logit_err"] = logit_err
-            res["logit_err_note"] = ("rows 0-1 of the timed batch = tests/golden/base_sample_padded.npz (sample.wav normalised + zero-padded to "
-                                     f"{L}, and a noise row); max |logits - HF-PyTorch fp64 logits| over both rows, max over ranks; bar "
-                                     + ("1e-3 (BASELINE.json; the reference's TF-vs-HF bar)" if args.precision != "bf16" else "0.15 (bf16 mode, self-declared)"))
+            line["max_abs_logit_err"] = logit_err
+            line["logit_err_note"] = ("rows 0-1 of the timed batch = tests/golden/base_sample_padded.npz (sample.wav normalised + zero-padded to "
+                                      f"{L}, and a noise row); max |logits - HF-PyTorch fp64 logits| over both rows, max over ranks; bar "
+                                      + ("1e-3 (BASELINE.json; the reference's TF-vs-HF bar)" if args.precision != "bf16" else "0.15 (bf16 mode, self-declared)"))
         if alt:
-            res["bf16x3"] = alt
-        if args.mode == "train":
-            res["final_loss"] = round(float(out), 4)
+            line["bf16x3"] = alt
+        if "final_loss" in res:
+            line["final_loss"] = res["final_loss"]
+        if "allreduce" in res:
+            line["allreduce"] = res["allreduce"]
+
+    # ---- the other BASELINE configurations, measured by this same command beside the headline (every rank takes part: the two
+    # training legs run the bucketed RCCL gradient all-reduce when N > 1).  Each leg is guarded: a failure is reported in its
+    # object and never costs the headline line.
+    headline_default = (args.model, args.precision, args.mode, args.batch, args.samples) == ("base", "fp32", "forward", 32, 246000)
+    if headline_default and not args.no_side:
+        del model, out, x, amask, res
+        gc.collect()
+        k = max(1, args.side_shrink)
+        legs = [("configs2_train_bf16", {"model": "base", "precision": "bf16", "mode": "train", "B": 32 // k, "L": 246000, "steps": 5, "warmup": 2},
+                 "BASELINE configs[2] per-GPU shard: wav2vec2-base CTC fine-tune step, bf16 contractions (conv stack frozen, dropout 0.1, "
+                 "spec-augment, Adam, fp32 variables / optimizer state), 32 x 246000 per GPU (global batch 256 at 8 GPUs)"),
+                ("configs3_large_fwd_f32", {"model": "large-robust", "precision": "fp32", "mode": "forward", "B": 16 // k, "L": 246000, "steps": 5, "warmup": 2},
+                 "BASELINE configs[3]: wav2vec2-large-robust (24L / 1024d, prenorm, LayerNorm convs, attention mask) fp32 forward, 16 x 246000 on 1 GPU"),
+                ("configs4_large_train_bf16", {"model": "large-robust", "precision": "bf16", "mode": "train", "B": 16 // k, "L": 480000, "steps": 3, "warmup": 1},
+                 "BASELINE configs[4] per-GPU shard: large (24L / 1024d; xlsr-53 is run as the robust architecture, SURVEY 8d) bf16 CTC fine-tune "
+                 "step, 16 x 480000 per GPU (global batch 128 at 8 GPUs)")]
+        keep = None                                            # the large model is built once and serves configs[3] and [4]
+        for name, sp, label in legs:
+            sp["profile"] = not args.no_profile
+            t_leg = time.perf_counter()
+            try:
+                reuse = keep if sp["model"] == "large-robust" else None
+                r, m2, o2 = run_leg(ctx, sp, model=reuse)
+                obj = side_object(ctx, sp, r, label) if rank == 0 else None
+                keep = m2 if sp["model"] == "large-robust" else None
+                del r, o2, m2
+            except Exception as exc:                           # noqa: BLE001 -- reported, the headline still prints
+                obj = {"workload": label, "error": repr(exc)[:400]}
+                keep = None
+            gc.collect()
+            if rank == 0:
+                obj["leg_wall_s"] = round(time.perf_counter() - t_leg, 1)
+                line[name] = obj
+        del keep
+        gc.collect()
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.mode == "forward" and args.model == "base" and args.precision == "fp32":
             try:
-                res["cpu_baseline"] = cpu_baseline(cfg, weights, L, None if gold_wave is None else gold_wave[0])
-                if res["cpu_baseline"]["value"]:
-                    res["gpu_over_cpu"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
+                line["cpu_baseline"] = cpu_baseline(cfg, V.seeded_weights(cfg, seed=0), L, None if gold_wave is None else gold_wave[0])
+                if line["cpu_baseline"]["value"]:
+                    line["gpu_over_cpu"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
             except Exception as exc:                           # noqa: BLE001 -- the GPU line must still be printed
-                res["cpu_baseline"] = {"value": None, "unit": "audio-seconds/s", "cores": 0, "kind": "port",
-                                       "sample": f"CPU baseline failed: {exc!r}"}
-        print(json.dumps(res), flush=True)
+                line["cpu_baseline"] = {"value": None, "unit": "audio-seconds/s", "cores": 0, "kind": "port",
+                                        "sample": f"CPU baseline failed: {exc!r}"}
+        line["bench_wall_s"] = round(time.perf_counter() - t_start, 1)
+        print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -261,7 +261,7 @@ int launch_attn_nw(const AttnArgs& a, hipStream_t s) {
     }
     const int qb = NW * 32;
     dim3 grid((a.T + qb - 1) / qb, a.heads, a.B), block(NW * 64);
-    hipLaunchKernelGGL((attention_kernel<DH, NW>), grid, block, lds, s, a, AttnTrain{0.f, 0, 0, nullptr});
+    W2V2_LAUNCH((attention_kernel<DH, NW>), grid, block, lds, s, a, AttnTrain{0.f, 0, 0, nullptr});
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -612,7 +612,7 @@ int launch_attn_train_impl(const AttnArgs& a, const AttnTrain& tr, hipStream_t s
         attr_set = true;
     }
     dim3 grid((a.T + NW * 32 - 1) / (NW * 32), a.heads, a.B), block(NW * 64);
-    hipLaunchKernelGGL((attention_kernel<DH, NW, true>), grid, block, lds, s, a, tr);
+    W2V2_LAUNCH((attention_kernel<DH, NW, true>), grid, block, lds, s, a, tr);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -628,7 +628,7 @@ int launch_attn_train(const AttnArgs& a, const AttnTrain& tr, hipStream_t s) {
 
 template <int DH>
 int launch_attn_bwd(const AttnBwdArgs& a, const AttnTrain& tr, const float* ctx, float* dvec, hipStream_t s) {
-    hipLaunchKernelGGL(attn_dvec_kernel<DH>, dim3((unsigned)((int64_t)a.B * a.T)), dim3(256), 0, s, ctx, a.d_o, dvec,
+    W2V2_LAUNCH(attn_dvec_kernel<DH>, dim3((unsigned)((int64_t)a.B * a.T)), dim3(256), 0, s, ctx, a.d_o, dvec,
                        a.B, a.T, a.H, a.heads);
     const size_t lds_q = (size_t)2 * 2 * KT * DH * sizeof(float);
     const size_t lds_kv = (size_t)2 * (2 * KT * DH + 2 * KT) * sizeof(float);
@@ -637,8 +637,8 @@ int launch_attn_bwd(const AttnBwdArgs& a, const AttnTrain& tr, const float* ctx,
     W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_dkv_kernel<DH>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv));
     dim3 grid((a.T + 127) / 128, a.heads, a.B), block(256);
-    hipLaunchKernelGGL(attention_bwd_dq_kernel<DH>, grid, block, lds_q, s, a, tr);
-    hipLaunchKernelGGL(attention_bwd_dkv_kernel<DH>, grid, block, lds_kv, s, a, tr);
+    W2V2_LAUNCH(attention_bwd_dq_kernel<DH>, grid, block, lds_q, s, a, tr);
+    W2V2_LAUNCH(attention_bwd_dkv_kernel<DH>, grid, block, lds_kv, s, a, tr);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }

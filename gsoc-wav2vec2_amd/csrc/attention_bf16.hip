@@ -673,9 +673,9 @@ int launch_attention_fwd_bf16(const float* qkv, const uint16_t* qkv16, const int
     const size_t lds = 2 * 2 * IMG;
     dim3 grid(a.nwork), block(NW * 64);
     if (tr)
-        hipLaunchKernelGGL(attention_bf16_kernel<true>, grid, block, lds, s, a, *tr);
+        W2V2_LAUNCH(attention_bf16_kernel<true>, grid, block, lds, s, a, *tr);
     else
-        hipLaunchKernelGGL(attention_bf16_kernel<false>, grid, block, lds, s, a, AttnTrain{0.f, 0, 0, nullptr});
+        W2V2_LAUNCH(attention_bf16_kernel<false>, grid, block, lds, s, a, AttnTrain{0.f, 0, 0, nullptr});
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -707,11 +707,11 @@ int launch_attention_bwd_bf16(const float* qkv, const uint16_t* qkv16, const int
     }
     dim3 grid(a.nwork), block(256);
     if (bits) {
-        hipLaunchKernelGGL(attention_bf16_bwd_dq_kernel<true>, grid, block, lds_q, s, a, tr);
-        hipLaunchKernelGGL(attention_bf16_bwd_dkv_kernel<true>, grid, block, lds_kv, s, a, tr);
+        W2V2_LAUNCH(attention_bf16_bwd_dq_kernel<true>, grid, block, lds_q, s, a, tr);
+        W2V2_LAUNCH(attention_bf16_bwd_dkv_kernel<true>, grid, block, lds_kv, s, a, tr);
     } else {
-        hipLaunchKernelGGL(attention_bf16_bwd_dq_kernel<false>, grid, block, lds_q, s, a, tr);
-        hipLaunchKernelGGL(attention_bf16_bwd_dkv_kernel<false>, grid, block, lds_kv, s, a, tr);
+        W2V2_LAUNCH(attention_bf16_bwd_dq_kernel<false>, grid, block, lds_q, s, a, tr);
+        W2V2_LAUNCH(attention_bf16_bwd_dkv_kernel<false>, grid, block, lds_kv, s, a, tr);
     }
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;

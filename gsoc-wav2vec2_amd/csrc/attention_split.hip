@@ -292,7 +292,7 @@ int launch_attention_split(const float* qkv, const int32_t* frame_len, float* ct
         attr_set = true;
     }
     dim3 grid((T + NW * 32 - 1) / (NW * 32), heads, B), block(NT);
-    hipLaunchKernelGGL(attention_split_kernel, grid, block, lds, s, a);
+    W2V2_LAUNCH(attention_split_kernel, grid, block, lds, s, a);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }

@@ -55,10 +55,28 @@ enum Family {
     FAM_POSCONV,           // grouped positional conv, MFMA 16x16x4 f32          (MFMA f32)
     FAM_ATTENTION,         // fused QK^T-softmax-PV, MFMA 32x32x2 f32            (MFMA f32)
     FAM_CTC,               // CTC alpha/beta                                     (latency)
-    FAM_MISC,              // frame lengths, weight-norm regroup, packing
+    FAM_MISC,              // frame lengths, weight-norm regroup, packing, spec-augment, residual adds, transposes
+    // training-step-only families (train_kernels.hip, shadow.hip): HBM-bound element-wise passes and reductions
+    FAM_DROPOUT,           // dropout forward / backward (+ GELU / GELU', + fused column sums)   (HBM / VALU)
+    FAM_REDUCE,            // column sums: bias gradients, weight-gradient slab folds            (HBM)
+    FAM_LN_BWD,            // LayerNorm backward (+ its partial-sum fold)                        (HBM)
+    FAM_OPTIMIZER,         // Adam (one launch over a chunk table) + the weight-shadow refresh   (HBM)
     FAM_COUNT
 };
 const char* family_name(int f);
+
+// Kernel launches actually enqueued, per family (an op-level call may enqueue several kernels: main + tail tiles, a partial
+// and a final reduction ...).  Every launch in csrc/ goes through W2V2_LAUNCH; the family is the innermost live ProfScope's
+// (FAM_MISC outside any).  Process-wide counters, cleared by profiler_reset; read by w2v2_profile_kernel_launches.
+extern thread_local int tl_launch_family;
+void note_kernel_launch();
+int64_t kernel_launches(int family);
+void kernel_launches_reset();
+#define W2V2_LAUNCH(...)                  \
+    do {                                  \
+        ::w2v2::note_kernel_launch();     \
+        hipLaunchKernelGGL(__VA_ARGS__);  \
+    } while (0)
 
 // A launch record sink.  When `enabled`, every launch wrapper brackets its
 // kernel with an event pair on the launch stream and logs algorithmic
@@ -81,11 +99,24 @@ struct ProfScope {
     Profiler* p;
     int tok;
     hipStream_t s;
+    int outer_family;
     ProfScope(Profiler* p_, int family, double flops, double bytes, hipStream_t s_)
-        : p(p_), tok(p_ ? profiler_begin(p_, family, flops, bytes, s_) : -1), s(s_) {}
+        : p(p_), tok(p_ ? profiler_begin(p_, family, flops, bytes, s_) : -1), s(s_), outer_family(tl_launch_family) {
+        tl_launch_family = family;
+    }
     ~ProfScope() {
+        tl_launch_family = outer_family;
         if (tok >= 0) profiler_end(p, tok, s);
     }
+};
+
+// The profiler of the model whose training step is running on this thread: the training-only kernels (train_kernels.hip,
+// shadow.hip) take no Profiler argument; their launchers read it from here (null outside w2v2_train_* / w2v2_adam_step).
+extern thread_local Profiler* tl_step_prof;
+struct StepProfScope {
+    Profiler* outer;
+    explicit StepProfScope(Profiler* p) : outer(tl_step_prof) { tl_step_prof = p; }
+    ~StepProfScope() { tl_step_prof = outer; }
 };
 
 // ---- operator launchers (defined one per .hip file) ------------------------

@@ -394,14 +394,14 @@ void launch_mode(const Conv0Args& a, int B, hipStream_t s) {
                         (reinterpret_cast<uintptr_t>(a.out16) & 7) == 0;
     if constexpr (MODE != 0) {
         if (vec_ok) {
-            hipLaunchKernelGGL((conv0_apply4_kernel<MODE, 10, 5>), grid, block, lds, s, a, tpr);
+            W2V2_LAUNCH((conv0_apply4_kernel<MODE, 10, 5>), grid, block, lds, s, a, tpr);
             return;
         }
     }
     if (a.K == 10 && a.stride == 5)
-        hipLaunchKernelGGL((conv0_kernel<MODE, 10, 5>), grid, block, lds, s, a);
+        W2V2_LAUNCH((conv0_kernel<MODE, 10, 5>), grid, block, lds, s, a);
     else
-        hipLaunchKernelGGL((conv0_kernel<MODE, 0, 0>), grid, block, lds, s, a);
+        W2V2_LAUNCH((conv0_kernel<MODE, 0, 0>), grid, block, lds, s, a);
 }
 
 }  // namespace
@@ -463,9 +463,9 @@ int launch_conv0_x(Profiler* prof, const float* wave, const float* kernel, const
         double* kc = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(ws) + 7) & ~(uintptr_t)7);
         a.ln_const = kc;
         ProfScope ps(prof, FAM_CONV0_APPLY, flops, in_bytes + out_bytes, s);
-        hipLaunchKernelGGL(conv0_ln_const_kernel, dim3(1), dim3(128), 0, s, kernel, bias, kc, C);
+        W2V2_LAUNCH(conv0_ln_const_kernel, dim3(1), dim3(128), 0, s, kernel, bias, kc, C);
         const size_t lds = ((size_t)(TC - 1) * stride + K + 4) * sizeof(float);
-        hipLaunchKernelGGL((conv0_apply4_kernel<3, 10, 5>), dim3(a.nchunks, B), dim3(256), lds, s, a, tpr);
+        W2V2_LAUNCH((conv0_apply4_kernel<3, 10, 5>), dim3(a.nchunks, B), dim3(256), lds, s, a, tpr);
         W2V2_HIP_CHECK(hipGetLastError());
         return W2V2_OK;
     }
@@ -480,17 +480,17 @@ int launch_conv0_x(Profiler* prof, const float* wave, const float* kernel, const
             const int nblk = (a.T0 + GFR - 1) / GFR;
             const size_t lds = ((size_t)(GFR - 1) * stride + GK + 4) * sizeof(float);
             if (lds <= 60 * 1024) {
-                hipLaunchKernelGGL(conv0_gram_kernel, dim3(nblk, B), dim3(256), lds, s, a, nblk);
-                hipLaunchKernelGGL(conv0_gram_finalize_kernel, dim3(B), dim3(256), 0, s, a, nblk);
+                W2V2_LAUNCH(conv0_gram_kernel, dim3(nblk, B), dim3(256), lds, s, a, nblk);
+                W2V2_LAUNCH(conv0_gram_finalize_kernel, dim3(B), dim3(256), 0, s, a, nblk);
             } else {
                 launch_mode<0>(a, B, s);
                 const int64_t n = (int64_t)B * C;
-                hipLaunchKernelGGL(conv0_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, B);
+                W2V2_LAUNCH(conv0_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, B);
             }
         } else {
             launch_mode<0>(a, B, s);
             const int64_t n = (int64_t)B * C;
-            hipLaunchKernelGGL(conv0_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, B);
+            W2V2_LAUNCH(conv0_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, B);
         }
     }
     {

@@ -325,8 +325,8 @@ int launch_ctc(Profiler* prof, const float* logits, int B, int T, int V, const i
     });
     W2V2_HIP_CHECK(attr_err);
     ProfScope ps(prof, FAM_CTC, 30.0 * B * (double)T * a.S_max, 4.0 * B * (double)T * V * (grad ? 2 : 1), s);
-    hipLaunchKernelGGL(ctc_kernel, dim3(B, grad ? 2 : 1), dim3(CTC_THREADS), lds, s, a);
-    if (grad) hipLaunchKernelGGL(ctc_grad_kernel, dim3(T, B), dim3(64), (size_t)V * sizeof(unsigned long long), s, a);
+    W2V2_LAUNCH(ctc_kernel, dim3(B, grad ? 2 : 1), dim3(CTC_THREADS), lds, s, a);
+    if (grad) W2V2_LAUNCH(ctc_grad_kernel, dim3(T, B), dim3(64), (size_t)V * sizeof(unsigned long long), s, a);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -347,8 +347,8 @@ int launch_frame_lengths(Profiler* prof, const int32_t* mask, int32_t* frame_len
     const int vec = (L % 4 == 0) && (reinterpret_cast<uintptr_t>(mask) & 15) == 0;
     int64_t chunks = (L + 8191) / 8192;                       // >= 32 loads per lane before another block is worth it
     chunks = chunks < 1 ? 1 : (chunks > 128 ? 128 : chunks);
-    hipLaunchKernelGGL(mask_sum_kernel, dim3((unsigned)chunks, B), dim3(256), 0, s, mask, frame_len, L, vec);
-    hipLaunchKernelGGL(frame_len_finish_kernel, dim3((B + 63) / 64), dim3(64), 0, s, frame_len, B, la);
+    W2V2_LAUNCH(mask_sum_kernel, dim3((unsigned)chunks, B), dim3(256), 0, s, mask, frame_len, L, vec);
+    W2V2_LAUNCH(frame_len_finish_kernel, dim3((B + 63) / 64), dim3(64), 0, s, frame_len, B, la);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }

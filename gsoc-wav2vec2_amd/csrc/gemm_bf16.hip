@@ -724,7 +724,7 @@ int launch_tr16(Gemm16Args& g, int nbatch, hipStream_t s) {
         attr_set = true;
     }
     dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch);
-    hipLaunchKernelGGL((gemm_bf16_tr_kernel<2, 4, 2>), grid, dim3(512), LDS, s, g);
+    W2V2_LAUNCH((gemm_bf16_tr_kernel<2, 4, 2>), grid, dim3(512), LDS, s, g);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -741,7 +741,7 @@ int launch_src16(Gemm16Args& g, int nbatch, hipStream_t s) {
         attr_set = true;
     }
     dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch), block(WM * WN * 64);
-    hipLaunchKernelGGL((gemm_bf16_kernel<SRC, BM, BN, WM, WN, MINB>), grid, block, LDS, s, g);
+    W2V2_LAUNCH((gemm_bf16_kernel<SRC, BM, BN, WM, WN, MINB>), grid, block, LDS, s, g);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -846,6 +846,8 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
             return launch_tr16(g, nbatch, s);
         }
         W2V2_REQUIRE(x.validK == 0, "gemm_bf16: validK needs the LDS-DMA weight-gradient form (both shadows, whole 128 x 128 tiles)");
+        // (the generic transposed-A path below contracts exactly K * nbatch rows: an operand set that asks for more would be cut short silently)
+        W2V2_REQUIRE(x.kextra == 0 && !x.b_zero_row, "gemm_bf16: uneven slabs (kextra) / the zero row behind B need the LDS-DMA weight-gradient form");
         W2V2_REQUIRE(A && kfast && b32 && (M % 4 == 0) && (lda % 4 == 0) && (strideA % 4 == 0) &&
                          ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (lda >= M || x.overlapA),
                      "gemm_bf16: transposed A needs fp32 A and B, K %% 64 == 0, M %% 4 == 0 and 16-byte alignment");

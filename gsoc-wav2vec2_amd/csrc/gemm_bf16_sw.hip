@@ -236,11 +236,11 @@ __device__ __forceinline__ void sw_epilogue_f32(const f32x16 (&acc)[4][2], float
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));                                            \
         if (R) {                                                                                                                  \
             if (h == 0 && (TG) < 2)                                                                                               \
-                asm volatile("s_waitcnt vmcnt(12)" : "+v"(rr[h][4 * (TG) + 0]), "+v"(rr[h][4 * (TG) + 1]), "+v"(rr[h][4 * (TG) + 2]), "+v"(rr[h][4 * (TG) + 3])); \
+                asm volatile("s_waitcnt vmcnt(12)" : "+v"(rr[h][4 * (TG) + 0]), "+v"(rr[h][4 * (TG) + 1]), "+v"(rr[h][4 * (TG) + 2]), "+v"(rr[h][4 * (TG) + 3]) : : "memory"); \
             else if (h == 0)                                                                                                      \
-                asm volatile("s_waitcnt vmcnt(28)" : "+v"(rr[h][4 * (TG) + 0]), "+v"(rr[h][4 * (TG) + 1]), "+v"(rr[h][4 * (TG) + 2]), "+v"(rr[h][4 * (TG) + 3])); \
+                asm volatile("s_waitcnt vmcnt(28)" : "+v"(rr[h][4 * (TG) + 0]), "+v"(rr[h][4 * (TG) + 1]), "+v"(rr[h][4 * (TG) + 2]), "+v"(rr[h][4 * (TG) + 3]) : : "memory"); \
             else                                                                                                                  \
-                asm volatile("s_waitcnt vmcnt(20)" : "+v"(rr[h][4 * (TG) + 0]), "+v"(rr[h][4 * (TG) + 1]), "+v"(rr[h][4 * (TG) + 2]), "+v"(rr[h][4 * (TG) + 3])); \
+                asm volatile("s_waitcnt vmcnt(20)" : "+v"(rr[h][4 * (TG) + 0]), "+v"(rr[h][4 * (TG) + 1]), "+v"(rr[h][4 * (TG) + 2]), "+v"(rr[h][4 * (TG) + 3]) : : "memory"); \
         }                                                                                                                         \
         SW_F32_OUT(x0, 4 * (TG) + 0)                                                                                              \
         SW_F32_OUT(x1, 4 * (TG) + 1)                                                                                              \
@@ -608,7 +608,7 @@ int launch_sw(GemmSWArgs& g, dim3 grid, hipStream_t s) {
         W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_sw_kernel<TRACE, true, EK>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_sw_kernel<TRACE, true, EK>), grid, dim3(256), SW_LDS, s, g);
+    W2V2_LAUNCH((gemm_bf16_sw_kernel<TRACE, true, EK>), grid, dim3(256), SW_LDS, s, g);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -653,7 +653,7 @@ int launch_gemm_bf16_swtr(const uint16_t* A16, int64_t lda, int64_t strideA, con
         W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_sw_kernel<false, true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_sw_kernel<false, true, 0, true>), dim3(g.tiles_m * g.tiles_n, 1, nbatch), dim3(256), SW_LDS, s, g);
+    W2V2_LAUNCH((gemm_bf16_sw_kernel<false, true, 0, true>), dim3(g.tiles_m * g.tiles_n, 1, nbatch), dim3(256), SW_LDS, s, g);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -669,7 +669,12 @@ int launch_gemm_bf16_sw(const uint16_t* A16, int64_t lda, int64_t strideA, const
     g.tiles_m = (M + SW_BM - 1) / SW_BM;
     g.tiles_n = N / SW_BN;
     // which epilogue: bf16-only and fp32 outputs go through LDS when the strides allow 16-byte row pieces
-    const int ek = (C16 && !C && !residual && ldc % 8 == 0) ? 1 + act : (C && ldc % 4 == 0 && (!C16 || ldc % 4 == 0)) ? 4 + act : 0;
+    // (they issue 16-byte stores to C / C16 and 16-byte residual loads at z * strideC + row * ldc + 4 | 8 j: the bases and the batch
+    //  stride must keep that alignment too, else the register epilogue -- ek 0, element-wise accesses -- takes the tile)
+    auto al = [](const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
+    const bool lds16 = C16 && !C && !residual && ldc % 8 == 0 && strideC % 8 == 0 && al(C16, 16);
+    const bool lds32 = C && ldc % 4 == 0 && strideC % 4 == 0 && al(C, 16) && (!residual || al(residual, 16)) && (!C16 || al(C16, 8));
+    const int ek = lds16 ? 1 + act : lds32 ? 4 + act : 0;
     dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch);
 #ifdef W2V2_TUNING
     g.trace = g_tune_trace;

@@ -354,7 +354,7 @@ int launch_dma(GemmArgs& g, int nbatch, hipStream_t s) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f32_dma_kernel<WM, WN, MINW, BKT, BM, BN>), grid, block, lds, s, g);
+    W2V2_LAUNCH((gemm_f32_dma_kernel<WM, WN, MINW, BKT, BM, BN>), grid, block, lds, s, g);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -374,9 +374,9 @@ int launch_cfg(GemmArgs& g, bool fast, int nbatch, hipStream_t s) {
     }
     dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch), block(C_::NT);
     if (fast)
-        hipLaunchKernelGGL((gemm_f32_kernel<true, BM, BN, WM, WN, MINW>), grid, block, C_::LDS, s, g);
+        W2V2_LAUNCH((gemm_f32_kernel<true, BM, BN, WM, WN, MINW>), grid, block, C_::LDS, s, g);
     else
-        hipLaunchKernelGGL((gemm_f32_kernel<false, BM, BN, WM, WN, MINW>), grid, block, C_::LDS, s, g);
+        W2V2_LAUNCH((gemm_f32_kernel<false, BM, BN, WM, WN, MINW>), grid, block, C_::LDS, s, g);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -470,7 +470,7 @@ int launch_gemm_ex(Profiler* prof, const float* A, int64_t lda, int64_t strideA,
             const int64_t n4 = (int64_t)M * N / 4;
             int64_t blocks = (n4 + 255) / 256;
             blocks = blocks > 2048 ? 2048 : blocks;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ws, C, bias, residual, M, N, ldc, S, act);
+            W2V2_LAUNCH(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ws, C, bias, residual, M, N, ldc, S, act);
             W2V2_HIP_CHECK(hipGetLastError());
             return W2V2_OK;
         }

@@ -293,9 +293,9 @@ int launch_split_weight(const float* w, uint16_t* planes, int K, int N, hipStrea
     W2V2_REQUIRE(w && planes && K > 0 && N > 0, "split_weight: bad argument");
     W2V2_REQUIRE(K % 32 == 0 && N % BN == 0, "split_weight: needs K %% 32 == 0 and N %% 256 == 0");
     if (split_bk() == 32)
-        hipLaunchKernelGGL(split_weight_kernel<32>, dim3((N + 63) / 64, (K + 63) / 64), dim3(256), 0, s, w, planes, K, N);
+        W2V2_LAUNCH(split_weight_kernel<32>, dim3((N + 63) / 64, (K + 63) / 64), dim3(256), 0, s, w, planes, K, N);
     else
-        hipLaunchKernelGGL(split_weight_kernel<16>, dim3((N + 63) / 64, (K + 63) / 64), dim3(256), 0, s, w, planes, K, N);
+        W2V2_LAUNCH(split_weight_kernel<16>, dim3((N + 63) / 64, (K + 63) / 64), dim3(256), 0, s, w, planes, K, N);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -327,7 +327,7 @@ int launch_gemm_split(Profiler* prof, const float* A, int64_t lda, int64_t strid
             W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<32, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
             attr_set = true;
         }
-        hipLaunchKernelGGL((gemm_split_kernel<32, 2>), grid, dim3(NT), LDS, s, g);
+        W2V2_LAUNCH((gemm_split_kernel<32, 2>), grid, dim3(NT), LDS, s, g);
     } else {
         constexpr size_t LDS = 2 * SplitCfg<16>::STAGE;
         static std::atomic<bool> attr_set{false};   // (idempotent call; atomic so concurrent host threads agree on the flag)
@@ -335,7 +335,7 @@ int launch_gemm_split(Profiler* prof, const float* A, int64_t lda, int64_t strid
             W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_kernel<16, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
             attr_set = true;
         }
-        hipLaunchKernelGGL((gemm_split_kernel<16, 4>), grid, dim3(NT), LDS, s, g);
+        W2V2_LAUNCH((gemm_split_kernel<16, 4>), grid, dim3(NT), LDS, s, g);
     }
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;

@@ -131,13 +131,13 @@ int launch_layer_norm_x(Profiler* prof, const float* x, float* y, const float* g
     dim3 grid((unsigned)(want < cap ? want : cap)), block(256);
     ProfScope ps(prof, FAM_LAYERNORM, 8.0 * rows * C, (4.0 + (y ? 4.0 : 0.0) + (y16 ? 2.0 : 0.0)) * rows * C, s);
     if (C <= 256)
-        hipLaunchKernelGGL(layer_norm_kernel<1>, grid, block, 0, s, x, y, y16, gamma, beta, rows, C, eps, act);
+        W2V2_LAUNCH(layer_norm_kernel<1>, grid, block, 0, s, x, y, y16, gamma, beta, rows, C, eps, act);
     else if (C <= 512)
-        hipLaunchKernelGGL(layer_norm_kernel<2>, grid, block, 0, s, x, y, y16, gamma, beta, rows, C, eps, act);
+        W2V2_LAUNCH(layer_norm_kernel<2>, grid, block, 0, s, x, y, y16, gamma, beta, rows, C, eps, act);
     else if (C <= 1024)
-        hipLaunchKernelGGL(layer_norm_kernel<4>, grid, block, 0, s, x, y, y16, gamma, beta, rows, C, eps, act);
+        W2V2_LAUNCH(layer_norm_kernel<4>, grid, block, 0, s, x, y, y16, gamma, beta, rows, C, eps, act);
     else
-        hipLaunchKernelGGL(layer_norm_kernel<8>, grid, block, 0, s, x, y, y16, gamma, beta, rows, C, eps, act);
+        W2V2_LAUNCH(layer_norm_kernel<8>, grid, block, 0, s, x, y, y16, gamma, beta, rows, C, eps, act);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }

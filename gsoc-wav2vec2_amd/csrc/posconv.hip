@@ -186,7 +186,7 @@ int launch_pos(const PosArgs& a, hipStream_t s) {
     }
     W2V2_REQUIRE(lds <= 160 * 1024, "pos_conv: K=%d needs %zu B of LDS (> 160 KiB)", a.K, lds);
     dim3 grid((a.T + PBM - 1) / PBM, a.groups, a.B), block(256);
-    hipLaunchKernelGGL(pos_conv_kernel<CG>, grid, block, lds, s, a);
+    W2V2_LAUNCH(pos_conv_kernel<CG>, grid, block, lds, s, a);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -343,7 +343,7 @@ int launch_dw(const PosDwArgs& a, hipStream_t s) {
         attr_set = true;
     }
     dim3 grid((a.K + DW_TAPS - 1) / DW_TAPS, a.groups), block(256);
-    hipLaunchKernelGGL(pos_conv_dw_kernel<CG>, grid, block, lds, s, a);
+    W2V2_LAUNCH(pos_conv_dw_kernel<CG>, grid, block, lds, s, a);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -356,7 +356,7 @@ int launch_weight_norm_regroup(Profiler* prof, const float* wv, const float* wg,
     W2V2_REQUIRE(K > 0 && groups > 0 && H % groups == 0 && cg == H / groups,
                  "weight_norm: bad shape K=%d cg=%d H=%d groups=%d", K, cg, H, groups);
     ProfScope ps(prof, FAM_MISC, 3.0 * K * cg * H, 8.0 * K * cg * H, s);
-    hipLaunchKernelGGL(weight_norm_regroup_kernel, dim3(K), dim3(256), 0, s, wv, wg, out, K, cg, H, groups);
+    W2V2_LAUNCH(weight_norm_regroup_kernel, dim3(K), dim3(256), 0, s, wv, wg, out, K, cg, H, groups);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -395,7 +395,7 @@ namespace w2v2 {
 
 int launch_pos_conv_flip_regroup(const float* wg, float* wg_t, int K, int cg, int groups, hipStream_t s) {
     W2V2_REQUIRE(wg && wg_t && K > 0 && cg > 0 && groups > 0, "pos_conv_flip: bad argument");
-    hipLaunchKernelGGL(flip_regroup_kernel, dim3(1024), dim3(256), 0, s, wg, wg_t, K, cg, groups);
+    W2V2_LAUNCH(flip_regroup_kernel, dim3(1024), dim3(256), 0, s, wg, wg_t, K, cg, groups);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -423,7 +423,7 @@ int launch_pos_conv_dw(Profiler* prof, const float* xz, const float* dc, float* 
 int launch_weight_norm_bwd(const float* wv, const float* wgain, const float* dwg, float* dwv, float* dwgain,
                            int K, int cg, int H, int groups, hipStream_t s) {
     W2V2_REQUIRE(wv && wgain && dwg && dwv && dwgain && K > 0 && cg == H / groups, "weight_norm_bwd: bad argument");
-    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(K), dim3(256), 0, s, wv, wgain, dwg, dwv, dwgain, K, cg, H, groups);
+    W2V2_LAUNCH(weight_norm_bwd_kernel, dim3(K), dim3(256), 0, s, wv, wgain, dwg, dwv, dwgain, K, cg, H, groups);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -525,7 +525,7 @@ int launch_pos_conv_bf16(Profiler* prof, const float* x, const uint16_t* w16, co
         const int64_t total = (int64_t)B * groups * Tp * (cg / 4);
         int64_t blocks = (total + 255) / 256;
         blocks = blocks > 8192 ? 8192 : blocks;
-        hipLaunchKernelGGL(pos_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, frame_len, pack16, masked_res ? xz_ws : nullptr, B, T,
+        W2V2_LAUNCH(pos_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, frame_len, pack16, masked_res ? xz_ws : nullptr, B, T,
                            H, groups, Tp, pad_left);
     }
     const float* res = add_residual ? (masked_res ? xz_ws : x) : nullptr;
@@ -545,7 +545,7 @@ int launch_pos_conv_bf16(Profiler* prof, const float* x, const uint16_t* w16, co
         const int64_t n4 = (int64_t)B * T * H / 4;
         int64_t blocks = (n4 + 255) / 256;
         blocks = blocks > 8192 ? 8192 : blocks;
-        hipLaunchKernelGGL(pos_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pre_act, res, y, n4, act);
+        W2V2_LAUNCH(pos_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pre_act, res, y, n4, act);
         W2V2_HIP_CHECK(hipGetLastError());
         return W2V2_OK;
     }
@@ -574,7 +574,7 @@ int launch_pos_conv_dw_bf16(Profiler* prof, const float* xz, const float* dc, fl
         const int64_t total = (int64_t)B * groups * Tp * (cg / 4);
         int64_t blocks = (total + 255) / 256;
         blocks = blocks > 8192 ? 8192 : blocks;
-        hipLaunchKernelGGL(pos_pack32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, xz, pack32, B, T, H, groups, Tp, K / 2);
+        W2V2_LAUNCH(pos_pack32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, xz, pack32, B, T, H, groups, Tp, K / 2);
     }
     GemmShadows gx;
     gx.transA = true;

@@ -103,8 +103,8 @@ static int launch_qkv(bool pack, float* packed_w, float* packed_b, float* const 
     for (int j = 0; j < 3; ++j) { a.w[j] = w[j]; a.b[j] = b[j]; bits |= reinterpret_cast<uintptr_t>(w[j]); }
     W2V2_REQUIRE((bits & 15) == 0, "qkv_pack: unaligned buffer");
     const int blocks = (int)(((int64_t)H * H / 4 + 255) / 256);
-    if (pack) hipLaunchKernelGGL(qkv_pack_kernel<true>, dim3(blocks < 256 ? blocks : 256, 3), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(qkv_pack_kernel<false>, dim3(blocks < 256 ? blocks : 256, 3), dim3(256), 0, s, a);
+    if (pack) W2V2_LAUNCH(qkv_pack_kernel<true>, dim3(blocks < 256 ? blocks : 256, 3), dim3(256), 0, s, a);
+    else W2V2_LAUNCH(qkv_pack_kernel<false>, dim3(blocks < 256 ? blocks : 256, 3), dim3(256), 0, s, a);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -163,14 +163,15 @@ int stream_scratch_release() {
 int launch_to_bf16(const float* x, uint16_t* y, int64_t n, hipStream_t s) {
     W2V2_REQUIRE(x && y && n > 0, "to_bf16: bad argument");
     W2V2_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0, "to_bf16: unaligned buffer");
-    hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, x, y, n);
+    W2V2_LAUNCH(to_bf16_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, x, y, n);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
 
 int launch_weight_shadows_multi(const ShadowJob* jobs_dev, int njobs, hipStream_t s) {
     W2V2_REQUIRE(jobs_dev && njobs > 0, "weight_shadows_multi: bad argument");
-    hipLaunchKernelGGL(weight_shadows_multi_kernel, dim3((unsigned)njobs), dim3(256), 0, s, jobs_dev);
+    ProfScope ps(tl_step_prof, FAM_OPTIMIZER, 0.0, 0.0, s);      // (the per-step refresh of the bf16 weight copies rides with the optimizer)
+    W2V2_LAUNCH(weight_shadows_multi_kernel, dim3((unsigned)njobs), dim3(256), 0, s, jobs_dev);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -181,7 +182,7 @@ int launch_transpose_to_bf16(const float* w, uint16_t* wt, int K, int N, hipStre
 
 int launch_transpose_to_bf16_batched(const float* w, uint16_t* wt, int K, int N, int nbatch, hipStream_t s) {
     W2V2_REQUIRE(w && wt && K > 0 && N > 0 && nbatch > 0, "transpose_to_bf16: bad argument");
-    hipLaunchKernelGGL(transpose_to_bf16_kernel, dim3((N + 63) / 64, (K + 63) / 64, nbatch), dim3(256), 0, s, w, wt, K, N);
+    W2V2_LAUNCH(transpose_to_bf16_kernel, dim3((N + 63) / 64, (K + 63) / 64, nbatch), dim3(256), 0, s, w, wt, K, N);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }

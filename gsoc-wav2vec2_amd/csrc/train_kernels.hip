@@ -603,13 +603,14 @@ int launch_dropout_fwd(const float* x, const float* res, float* y, int64_t n, in
 int launch_dropout_fwd_x(const float* x, const float* res, float* y, uint16_t* y16, int64_t n, int act, float p,
                          uint64_t seed, uint32_t stream_id, hipStream_t s, const EwBf16& in) {
     W2V2_REQUIRE((x || in.a16) && (y || y16) && n > 0 && p >= 0.f && p < 1.f, "dropout_fwd: bad argument");      // (y may be null: bf16 result only)
+    ProfScope ps(tl_step_prof, FAM_DROPOUT, 0.0, (double)n * ((x ? 4.0 : 2.0) + (res ? 4.0 : 0.0) + (y ? 4.0 : 0.0) + (y16 ? 2.0 : 0.0)), s);
     const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res)) & 15) == 0 &&
                      ((reinterpret_cast<uintptr_t>(y16) | reinterpret_cast<uintptr_t>(in.a16)) & 7) == 0;
     if (vec)
-        hipLaunchKernelGGL(dropout_fwd_kernel<true>, dim3(ew_grid(n >> 2)), dim3(EW_THREADS), 0, s, x, res, y, y16, n, act, p, seed, stream_id, in.a16,
+        W2V2_LAUNCH(dropout_fwd_kernel<true>, dim3(ew_grid(n >> 2)), dim3(EW_THREADS), 0, s, x, res, y, y16, n, act, p, seed, stream_id, in.a16,
                            in.round_in);
     else
-        hipLaunchKernelGGL(dropout_fwd_kernel<false>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, s, x, res, y, y16, n, act, p, seed, stream_id, in.a16,
+        W2V2_LAUNCH(dropout_fwd_kernel<false>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, s, x, res, y, y16, n, act, p, seed, stream_id, in.a16,
                            in.round_in);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
@@ -623,13 +624,14 @@ int launch_dropout_bwd(const float* u, const float* dy, float* dx, int64_t n, in
 int launch_dropout_bwd_x(const float* u, const float* dy, float* dx, uint16_t* dx16, int64_t n, int act, float p,
                          uint64_t seed, uint32_t stream_id, hipStream_t s, const EwBf16& in) {
     W2V2_REQUIRE((dy || in.b16) && (dx || dx16) && n > 0 && p >= 0.f && p < 1.f && (act == 0 || u || in.a16), "dropout_bwd: bad argument");   // (dx may be null)
+    ProfScope ps(tl_step_prof, FAM_DROPOUT, 0.0, (double)n * ((dy ? 4.0 : 2.0) + (act ? (u ? 4.0 : 2.0) : 0.0) + (dx ? 4.0 : 0.0) + (dx16 ? 2.0 : 0.0)), s);
     const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0 &&
                      ((reinterpret_cast<uintptr_t>(dx16) | reinterpret_cast<uintptr_t>(in.a16) | reinterpret_cast<uintptr_t>(in.b16)) & 7) == 0;
     if (vec)
-        hipLaunchKernelGGL(dropout_bwd_kernel<true>, dim3(ew_grid(n >> 2)), dim3(EW_THREADS), 0, s, u, dy, dx, dx16, n, act, p, seed, stream_id, in.a16,
+        W2V2_LAUNCH(dropout_bwd_kernel<true>, dim3(ew_grid(n >> 2)), dim3(EW_THREADS), 0, s, u, dy, dx, dx16, n, act, p, seed, stream_id, in.a16,
                            in.b16, in.round_in);
     else
-        hipLaunchKernelGGL(dropout_bwd_kernel<false>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, s, u, dy, dx, dx16, n, act, p, seed, stream_id, in.a16,
+        W2V2_LAUNCH(dropout_bwd_kernel<false>, dim3(ew_grid(n)), dim3(EW_THREADS), 0, s, u, dy, dx, dx16, n, act, p, seed, stream_id, in.a16,
                            in.b16, in.round_in);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
@@ -640,15 +642,17 @@ int launch_dw_tail_bf16(const uint16_t* A16, int64_t lda, const uint16_t* B16, i
                      (reinterpret_cast<uintptr_t>(A16) & 15) == 0 && (reinterpret_cast<uintptr_t>(B16) & 7) == 0 &&
                      (reinterpret_cast<uintptr_t>(dst) & 15) == 0,
                  "dw_tail_bf16: bad argument");
-    hipLaunchKernelGGL(dw_tail_bf16_kernel, dim3((Nout / 4 + 255) / 256, Kin / 8), dim3(256), 0, s, A16, lda, B16, ldb, dst, R, Kin, Nout);
+    ProfScope ps(tl_step_prof, FAM_GEMM_BF16, 2.0 * R * (double)Kin * Nout, 2.0 * R * ((double)Kin + Nout) + 4.0 * (double)Kin * Nout, s);
+    W2V2_LAUNCH(dw_tail_bf16_kernel, dim3((Nout / 4 + 255) / 256, Kin / 8), dim3(256), 0, s, A16, lda, B16, ldb, dst, R, Kin, Nout);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
 
 int launch_transpose(const float* x, float* y, int rows, int cols, int nbatch, hipStream_t s) {
     W2V2_REQUIRE(x && y && rows > 0 && cols > 0 && nbatch > 0, "transpose: bad argument");
+    ProfScope ps(tl_step_prof, FAM_MISC, 0.0, 8.0 * rows * (double)cols * nbatch, s);
     dim3 grid((cols + 31) / 32, (rows + 31) / 32, nbatch);
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, x, y, rows, cols);
+    W2V2_LAUNCH(transpose_kernel, grid, dim3(256), 0, s, x, y, rows, cols);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -662,21 +666,23 @@ int64_t dropout_bwd_colsum_ws_floats(int64_t rows, int cols) { return ((rows + 1
 // out[c] = sum over `nrows` rows of already-reduced partial rows (a producer's per-block column sums): one launch, fp64 accumulate
 int launch_colsum_fold(const float* partial, float* out, int nrows, int cols, hipStream_t s) {
     W2V2_REQUIRE(partial && out && nrows > 0 && cols > 0, "colsum_fold: bad argument");
-    hipLaunchKernelGGL(colsum_final_wide_kernel, dim3((cols + 31) / 32), dim3(256), 0, s, partial, out, nrows, cols, (int64_t)cols, 0, nullptr, nullptr);
+    ProfScope ps(tl_step_prof, FAM_REDUCE, 0.0, 4.0 * (nrows + 1.0) * cols, s);
+    W2V2_LAUNCH(colsum_final_wide_kernel, dim3((cols + 31) / 32), dim3(256), 0, s, partial, out, nrows, cols, (int64_t)cols, 0, nullptr, nullptr);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
 
 int launch_colsum(const float* x, float* out, int64_t rows, int cols, float* ws, int accumulate, hipStream_t s) {
     W2V2_REQUIRE(x && out && rows > 0 && cols > 0, "colsum: bad argument");
+    ProfScope ps(tl_step_prof, FAM_REDUCE, 0.0, 4.0 * (rows + 1.0) * cols, s);
     const bool vec = (cols & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(ws)) & 15) == 0;
     const int per_block = vec ? 4 * EW_THREADS : EW_THREADS;
     if (rows <= 64) {   // few rows (split-K slabs): one pass, fp64 accumulate, no scratch
         if (vec)
-            hipLaunchKernelGGL(colsum_final_kernel<true>, dim3((cols + per_block - 1) / per_block), dim3(EW_THREADS), 0, s, x, out,
+            W2V2_LAUNCH(colsum_final_kernel<true>, dim3((cols + per_block - 1) / per_block), dim3(EW_THREADS), 0, s, x, out,
                                (int)rows, cols, (int64_t)cols, accumulate);
         else
-            hipLaunchKernelGGL(colsum_final_kernel<false>, dim3((cols + per_block - 1) / per_block), dim3(EW_THREADS), 0, s, x, out,
+            W2V2_LAUNCH(colsum_final_kernel<false>, dim3((cols + per_block - 1) / per_block), dim3(EW_THREADS), 0, s, x, out,
                                (int)rows, cols, (int64_t)cols, accumulate);
         W2V2_HIP_CHECK(hipGetLastError());
         return W2V2_OK;
@@ -685,10 +691,10 @@ int launch_colsum(const float* x, float* out, int64_t rows, int cols, float* ws,
     const int nchunks = (int)((rows + COLSUM_CHUNK - 1) / COLSUM_CHUNK);
     dim3 grid(vec ? (cols + 255) / 256 : (cols + per_block - 1) / per_block, nchunks);
     if (vec)
-        hipLaunchKernelGGL(colsum_partial_kernel<true>, grid, dim3(EW_THREADS), 0, s, x, ws, rows, cols, COLSUM_CHUNK);
+        W2V2_LAUNCH(colsum_partial_kernel<true>, grid, dim3(EW_THREADS), 0, s, x, ws, rows, cols, COLSUM_CHUNK);
     else
-        hipLaunchKernelGGL(colsum_partial_kernel<false>, grid, dim3(EW_THREADS), 0, s, x, ws, rows, cols, COLSUM_CHUNK);
-    hipLaunchKernelGGL(colsum_final_wide_kernel, dim3((cols + 31) / 32), dim3(256), 0, s, ws, out, nchunks, cols, (int64_t)cols, accumulate);
+        W2V2_LAUNCH(colsum_partial_kernel<false>, grid, dim3(EW_THREADS), 0, s, x, ws, rows, cols, COLSUM_CHUNK);
+    W2V2_LAUNCH(colsum_final_wide_kernel, dim3((cols + 31) / 32), dim3(256), 0, s, ws, out, nchunks, cols, (int64_t)cols, accumulate);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -700,6 +706,8 @@ int launch_dropout_bwd_colsum(const float* u, const float* dy, float* dx, uint16
                               int act, float p, uint64_t seed, uint32_t stream_id, float* ws, hipStream_t s, const EwBf16& in) {
     W2V2_REQUIRE((dy || in.b16) && (dx || dx16) && colsum && ws && rows > 0 && cols > 0 && p >= 0.f && p < 1.f && (act == 0 || u || in.a16),
                  "dropout_bwd_colsum: bad argument");
+    ProfScope ps(tl_step_prof, FAM_DROPOUT, 0.0,
+                 (double)rows * cols * ((dy ? 4.0 : 2.0) + (act ? (u ? 4.0 : 2.0) : 0.0) + (dx ? 4.0 : 0.0) + (dx16 ? 2.0 : 0.0)), s);
     const bool vec = (cols & 3) == 0 && ((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) |
                                            reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(colsum)) & 15) == 0 &&
                      ((reinterpret_cast<uintptr_t>(dx16) | reinterpret_cast<uintptr_t>(in.a16) | reinterpret_cast<uintptr_t>(in.b16)) & 7) == 0;
@@ -717,9 +725,9 @@ int launch_dropout_bwd_colsum(const float* u, const float* dy, float* dx, uint16
     const int colblocks = (cols + 255) / 256;
     while (chunk > 16 && (rows + chunk - 1) / chunk * colblocks < target) chunk >>= 1;
     const int nchunks = (int)((rows + chunk - 1) / chunk);
-    hipLaunchKernelGGL(dropout_bwd_colsum_kernel, dim3(colblocks, nchunks), dim3(256), 0, s, u, dy, dx, dx16, ws, rows, cols,
+    W2V2_LAUNCH(dropout_bwd_colsum_kernel, dim3(colblocks, nchunks), dim3(256), 0, s, u, dy, dx, dx16, ws, rows, cols,
                        chunk, act, p, seed, stream_id, in.a16, in.b16, in.round_in);
-    hipLaunchKernelGGL(colsum_final_wide_kernel, dim3((cols + 31) / 32), dim3(256), 0, s, ws, colsum, nchunks, cols, (int64_t)cols, 0);
+    W2V2_LAUNCH(colsum_final_wide_kernel, dim3((cols + 31) / 32), dim3(256), 0, s, ws, colsum, nchunks, cols, (int64_t)cols, 0);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -745,26 +753,27 @@ int launch_ln_bwd_x(const float* x, const float* gamma, const float* dy, float* 
     W2V2_REQUIRE(!residual || (C & 3) != 0 || (reinterpret_cast<uintptr_t>(residual) & 15) == 0, "ln_bwd: unaligned residual");
     W2V2_REQUIRE(!dx16 || ((C & 3) == 0 && (reinterpret_cast<uintptr_t>(dx16) & 7) == 0), "ln_bwd: the bf16 shadow needs C %% 4 == 0");
     W2V2_REQUIRE(rows > 0 && C > 0 && C <= 1024, "ln_bwd: rows=%lld C=%d unsupported (C <= 1024)", (long long)rows, C);
+    ProfScope ps(tl_step_prof, FAM_LN_BWD, 0.0, (double)rows * C * (12.0 + (residual ? 4.0 : 0.0) + (dx16 ? 2.0 : 0.0)), s);
     const int nb = ln_bwd_blocks(rows);
     const int ng = dxsum ? 3 : 2;
     const size_t lds = (size_t)4 * ng * C * sizeof(float);
     auto go = [&](auto nv) {
         constexpr int NV = decltype(nv)::value;
         if (tail)
-            hipLaunchKernelGGL((ln_bwd_kernel<NV, 2>), dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, dx16, ws, rows, C, eps, residual, tail->p,
+            W2V2_LAUNCH((ln_bwd_kernel<NV, 2>), dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, dx16, ws, rows, C, eps, residual, tail->p,
                                tail->seed, tail->stream);
         else if (dxsum)
-            hipLaunchKernelGGL((ln_bwd_kernel<NV, 1>), dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, dx16, ws, rows, C, eps, residual, 0.f,
+            W2V2_LAUNCH((ln_bwd_kernel<NV, 1>), dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, dx16, ws, rows, C, eps, residual, 0.f,
                                (uint64_t)0, 0u);
         else
-            hipLaunchKernelGGL((ln_bwd_kernel<NV, 0>), dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, dx16, ws, rows, C, eps, residual, 0.f,
+            W2V2_LAUNCH((ln_bwd_kernel<NV, 0>), dim3(nb), dim3(256), lds, s, x, gamma, dy, dx, dx16, ws, rows, C, eps, residual, 0.f,
                                (uint64_t)0, 0u);
     };
     if (C <= 256) go(std::integral_constant<int, 1>{});
     else if (C <= 512) go(std::integral_constant<int, 2>{});
     else go(std::integral_constant<int, 4>{});
     // partial is (nb, ng C): dgamma = column sums of its first C columns, dbeta of the next C [, the sums of dx of the last C]
-    hipLaunchKernelGGL(colsum_final_wide_kernel, dim3((C + 31) / 32, ng), dim3(256), 0, s, ws, dgamma, nb, C, (int64_t)ng * C, 0, dbeta, dxsum);
+    W2V2_LAUNCH(colsum_final_wide_kernel, dim3((C + 31) / 32, ng), dim3(256), 0, s, ws, dgamma, nb, C, (int64_t)ng * C, 0, dbeta, dxsum);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -772,7 +781,8 @@ int launch_ln_bwd_x(const float* x, const float* gamma, const float* dy, float* 
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1, float b2,
                 float eps, hipStream_t s) {
     W2V2_REQUIRE(p && g && m && v && n > 0, "adam: bad argument");
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, s, p, g, m, v, n, lr_t, b1, b2, eps);
+    ProfScope ps(tl_step_prof, FAM_OPTIMIZER, 0.0, 28.0 * n, s);
+    W2V2_LAUNCH(adam_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, s, p, g, m, v, n, lr_t, b1, b2, eps);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -780,21 +790,24 @@ int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float l
 int launch_adam_multi(const AdamChunk* chunks_dev, int nchunks, const float* grads, float* m, float* v, float lr_t, float b1,
                       float b2, float eps, hipStream_t s) {
     W2V2_REQUIRE(chunks_dev && nchunks > 0 && grads && m && v, "adam_multi: bad argument");
-    hipLaunchKernelGGL(adam_multi_kernel, dim3(nchunks), dim3(EW_THREADS), 0, s, chunks_dev, grads, m, v, lr_t, b1, b2, eps);
+    ProfScope ps(tl_step_prof, FAM_OPTIMIZER, 0.0, 28.0 * 4096.0 * nchunks, s);
+    W2V2_LAUNCH(adam_multi_kernel, dim3(nchunks), dim3(EW_THREADS), 0, s, chunks_dev, grads, m, v, lr_t, b1, b2, eps);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
 
 int launch_spec_aug_fwd(const float* x, const uint8_t* mask, const float* embed, float* y, int64_t rows, int H, hipStream_t s) {
     W2V2_REQUIRE(x && mask && embed && y && rows > 0 && H > 0, "spec_aug_fwd: bad argument");
-    hipLaunchKernelGGL(spec_aug_fwd_kernel, dim3(ew_grid(rows * H)), dim3(EW_THREADS), 0, s, x, mask, embed, y, rows, H);
+    ProfScope ps(tl_step_prof, FAM_MISC, 0.0, 8.0 * rows * H, s);
+    W2V2_LAUNCH(spec_aug_fwd_kernel, dim3(ew_grid(rows * H)), dim3(EW_THREADS), 0, s, x, mask, embed, y, rows, H);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
 
 int launch_spec_aug_bwd(const float* dy, const uint8_t* mask, float* dx, float* dmasked, int64_t rows, int H, hipStream_t s) {
     W2V2_REQUIRE(dy && mask && dx && dmasked && rows > 0 && H > 0, "spec_aug_bwd: bad argument");
-    hipLaunchKernelGGL(spec_aug_bwd_kernel, dim3(ew_grid(rows * H)), dim3(EW_THREADS), 0, s, dy, mask, dx, dmasked, rows, H);
+    ProfScope ps(tl_step_prof, FAM_MISC, 0.0, 8.0 * rows * H, s);
+    W2V2_LAUNCH(spec_aug_bwd_kernel, dim3(ew_grid(rows * H)), dim3(EW_THREADS), 0, s, dy, mask, dx, dmasked, rows, H);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -807,22 +820,24 @@ int launch_axpby(const float* a, const float* b, float* y, int64_t n, float alph
 // it was asked for and the operands do not allow that path, so a caller never consumes a shadow that was not written)
 int launch_axpby_x(const float* a, const float* b, float* y, uint16_t* y16, int64_t n, float alpha, float beta, hipStream_t s) {
     W2V2_REQUIRE(a && y && n > 0, "axpby: bad argument");
+    ProfScope ps(tl_step_prof, FAM_MISC, 0.0, (double)n * (8.0 + (b ? 4.0 : 0.0) + (y16 ? 2.0 : 0.0)), s);
     const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 &&
                      (reinterpret_cast<uintptr_t>(y16) & 7) == 0;
     if (vec) {
-        hipLaunchKernelGGL(axpby4_kernel, dim3(ew_grid(n >> 2)), dim3(EW_THREADS), 0, s, a, b, y, y16, n >> 2, alpha, beta);
+        W2V2_LAUNCH(axpby4_kernel, dim3(ew_grid(n >> 2)), dim3(EW_THREADS), 0, s, a, b, y, y16, n >> 2, alpha, beta);
         W2V2_HIP_CHECK(hipGetLastError());
         return W2V2_OK;
     }
     W2V2_REQUIRE(!y16, "axpby: the bf16 shadow needs n %% 4 == 0 and 16-byte aligned operands");
-    hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, s, a, b, y, n, alpha, beta);
+    W2V2_LAUNCH(axpby_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, s, a, b, y, n, alpha, beta);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
 
 int launch_mask_rows(const float* x, const int32_t* frame_len, float* y, int B, int T, int H, hipStream_t s) {
     W2V2_REQUIRE(x && frame_len && y && B > 0 && T > 0 && H > 0, "mask_rows: bad argument");
-    hipLaunchKernelGGL(mask_rows_kernel, dim3(ew_grid((int64_t)B * T * H)), dim3(EW_THREADS), 0, s, x, frame_len, y, B, T, H);
+    ProfScope ps(tl_step_prof, FAM_MISC, 0.0, 8.0 * B * (double)T * H, s);
+    W2V2_LAUNCH(mask_rows_kernel, dim3(ew_grid((int64_t)B * T * H)), dim3(EW_THREADS), 0, s, x, frame_len, y, B, T, H);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }

@@ -34,8 +34,24 @@ void set_error(const char* fmt, ...) {
 
 const char* family_name(int f) {
     static const char* names[FAM_COUNT] = {"conv0_stats", "conv0_apply", "gemm_f32", "gemm_bf16", "gemm_split", "layer_norm",
-                                           "pos_conv",    "attention",   "ctc",      "misc"};
+                                           "pos_conv",    "attention",   "ctc",      "misc",      "dropout",    "reduce",
+                                           "layer_norm_bwd", "optimizer"};
     return (f >= 0 && f < FAM_COUNT) ? names[f] : "?";
+}
+
+// ---- kernel-launch counters (common.h: W2V2_LAUNCH) ---------------------------
+thread_local int tl_launch_family = FAM_MISC;
+thread_local Profiler* tl_step_prof = nullptr;
+static std::atomic<int64_t> g_kernel_launches[FAM_COUNT];
+void note_kernel_launch() {
+    const int f = tl_launch_family;
+    g_kernel_launches[(f >= 0 && f < FAM_COUNT) ? f : FAM_MISC].fetch_add(1, std::memory_order_relaxed);
+}
+int64_t kernel_launches(int family) {
+    return (family >= 0 && family < FAM_COUNT) ? g_kernel_launches[family].load(std::memory_order_relaxed) : 0;
+}
+void kernel_launches_reset() {
+    for (auto& n : g_kernel_launches) n.store(0, std::memory_order_relaxed);
 }
 
 // ---- profiler ---------------------------------------------------------------
@@ -60,6 +76,7 @@ void profiler_reset(Profiler* p) {
     }
     p->recs.clear();
     for (auto& n : p->seen) n = 0;
+    kernel_launches_reset();
 }
 void profiler_destroy(Profiler* p) {
     if (!p) return;
@@ -834,6 +851,12 @@ int w2v2_profile_read(w2v2_model* m, int index, const char** name, int64_t* laun
     W2V2_REQUIRE(m && index >= 0 && index < FAM_COUNT && launches && total_ms && flops && bytes, "profile_read: bad argument");
     if (name) *name = family_name(index);
     return profiler_read(m->prof, index, launches, total_ms, flops, bytes);
+}
+int w2v2_profile_kernel_launches(w2v2_model* m, int index, int64_t* launches) {
+    W2V2_REQUIRE(m && launches, "profile_kernel_launches: null argument");
+    W2V2_REQUIRE(index >= 0 && index < FAM_COUNT, "profile_kernel_launches: bad family index %d", index);
+    *launches = kernel_launches(index);
+    return W2V2_OK;
 }
 int w2v2_profile_reset(w2v2_model* m) {
     W2V2_REQUIRE(m, "profile_reset: null model");

@@ -249,6 +249,7 @@ static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
         const int64_t words = (up8((BT + 1) * H) + up8((BT + 1) * F) + up8((BT + 1) * 3 * H) + up8(BT * H)) / 2 + 16;
         if (int e = t_alloc(t, &raw, words)) return e;
         W2V2_HIP_CHECK(hipMemset(raw, 0, (size_t)words * 4));
+        W2V2_HIP_CHECK(hipDeviceSynchronize());      // (a device memset may return before it ran, and the step's stream need not be a blocking one)
         t->dy16_h = reinterpret_cast<uint16_t*>(raw);
         t->dy16_f = t->dy16_h + up8((BT + 1) * H);
         t->dy16_3h = t->dy16_f + up8((BT + 1) * F);
@@ -500,6 +501,7 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
     }
     const w2v2_config& c = m->cfg;
     PrecisionScope precision(m->precision);
+    StepProfScope step_prof(m->prof);          // the training-only kernels' launchers find the profiler here (common.h)
     const int64_t Tll = w2v2_num_frames(m, L);
     W2V2_REQUIRE(Tll >= 1, "train_forward: input too short");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -655,7 +657,7 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
             return e;
         // o = ctx Wo + bo;  t1 = dropout(o) + x   (encoder.py:116-119)
         // (dropout + residual as their own pass: folded into this GEMM's epilogue they were measured slower, study section 12 / r03)
-        if (int e = gemm(l.ctx, attn16 ? l.ctx16 : nullptr, H, 0, m->P(b + "/attention/out_proj/kernel"), H, m->t0, nullptr, H, 0,
+        if (int e = gemm(ctx16_only ? nullptr : l.ctx, attn16 ? l.ctx16 : nullptr, H, 0, m->P(b + "/attention/out_proj/kernel"), H, m->t0, nullptr, H, 0,
                          m->P(b + "/attention/out_proj/bias"), nullptr, (int)BT, H, H, 1, 0))
             return e;
         if (int e = launch_dropout_fwd(m->t0, x, l.t1, BT * H, 0, p, seed, layer_stream(i, 1), s)) return e;
@@ -721,6 +723,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     }
     const w2v2_config& c = m->cfg;
     PrecisionScope precision(m->precision);
+    StepProfScope step_prof(m->prof);          // the training-only kernels' launchers find the profiler here (common.h)
     // dX = dY W^T reads the fp32 transposed copy WT ([out][in]) as its B operand; in precision mode 1 with shadows the bf16
     // copy of W itself ([in][out] = (N, K) for this GEMM) is the B shadow -- no transpose needed.  Bit-identical results.
     const bool shb = m->precision == 1 && w2v2_shadows_enabled(m) && m->w16_valid;
@@ -752,6 +755,15 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     uint16_t* const s16h = shb ? t->dy16_h : nullptr;
     uint16_t* const s16f = shb ? t->dy16_f : nullptr;
     uint16_t* const s16q = (shb && attention_bf16_supported(dhead)) ? t->dy16_3h : nullptr;
+    if (shb && ((int64_t)t->B * t->T) % 64 != 0) {
+        // Ragged row count: the weight-gradient GEMMs read the missing rows of their last K tile from the zero row behind each dY
+        // shadow.  Re-assert the invariant on THIS stream every backward (three rows, a few KB): nothing may have padded into them.
+        hipStream_t st0 = reinterpret_cast<hipStream_t>(stream);
+        const int64_t BT0 = (int64_t)t->B * t->T;
+        W2V2_HIP_CHECK(hipMemsetAsync(t->dy16_h + BT0 * c.hidden_size, 0, (size_t)c.hidden_size * 2, st0));
+        W2V2_HIP_CHECK(hipMemsetAsync(t->dy16_f + BT0 * c.intermediate_size, 0, (size_t)c.intermediate_size * 2, st0));
+        W2V2_HIP_CHECK(hipMemsetAsync(t->dy16_3h + BT0 * 3 * c.hidden_size, 0, (size_t)3 * c.hidden_size * 2, st0));
+    }
     const bool xs = shb && t->x16_valid;             // X shadows of the forward are there for the weight-gradient GEMMs
     // the forward kept the FFN hidden activations only as bf16: the backward must then run entirely on the shadow paths
     const bool f16 = t->ffn16_only;
@@ -1237,6 +1249,7 @@ int w2v2_adam_step(w2v2_model* m, float lr, float beta1, float beta2, float eps,
         return W2V2_ESTATE;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    StepProfScope step_prof(m->prof);
     // Keras: lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t);  p -= lr_t * m / (sqrt(v) + eps)
     const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
     if (!t->adam_table_fresh) {

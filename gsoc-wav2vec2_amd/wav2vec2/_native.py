@@ -86,7 +86,9 @@ PROTOTYPES = {
     "w2v2_profile_families": (C.c_int, [_P, C.c_uint32]),
     "w2v2_profile_sampling": (C.c_int, [_P, C.c_int32]),
     "w2v2_profile_seen": (C.c_int, [_P, C.c_int, C.POINTER(_I64)]),
+    "w2v2_profile_kernel_launches": (C.c_int, [_P, C.c_int, C.POINTER(_I64)]),
     "w2v2_profile_num_families": (C.c_int, []),
+    "w2v2_clock_probe": (C.c_int, [_P, _I32, _P, C.POINTER(_I32)]),
     "w2v2_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(_I64),
                                     C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "w2v2_profile_reset": (C.c_int, [_P]),

@@ -74,6 +74,8 @@ def max_over_ranks(value, device="cpu"):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return float(value)
+    if dist.get_backend() == "gloo":
+        device = "cpu"                          # (the two-processes-on-one-GPU tests: keep the scalar off the device)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

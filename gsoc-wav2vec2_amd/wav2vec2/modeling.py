@@ -582,7 +582,9 @@ class TFKerasModel(Layer):
         N.check(self._lib.w2v2_profile_reset(self._handle), "w2v2_profile_reset")
 
     def profile_read(self):
-        """{family: dict(launches, ms, flops, bytes)} over the recorded launches."""
+        """{family: dict(launches, ms, flops, bytes, issued, kernels)}: event-bracketed launches with their time and algorithmic
+        work; `issued` = op-level calls since the last reset (sampled or not); `kernels` = kernel launches actually enqueued for
+        the family since the last reset (process-wide; what a rocprofv3 kernel trace counts)."""
         out = {}
         for i in range(self._lib.w2v2_profile_num_families()):
             name = C.c_char_p()
@@ -592,7 +594,10 @@ class TFKerasModel(Layer):
                                                 C.byref(fl), C.byref(by)), "w2v2_profile_read")
             seen = C.c_int64()
             N.check(self._lib.w2v2_profile_seen(self._handle, i, C.byref(seen)), "w2v2_profile_seen")
-            out[name.value.decode()] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value, issued=seen.value)
+            kern = C.c_int64()
+            N.check(self._lib.w2v2_profile_kernel_launches(self._handle, i, C.byref(kern)), "w2v2_profile_kernel_launches")
+            out[name.value.decode()] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value, issued=seen.value,
+                                            kernels=kern.value)
         return out
 
     def num_frames(self, num_samples):

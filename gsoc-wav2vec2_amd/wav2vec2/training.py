@@ -258,10 +258,21 @@ class Trainer:
             self._rng = np.random.RandomState((self.seed * 1000003 + self.iterations) & 0xFFFFFFFF)
 
     # -- the step ------------------------------------------------------------------------------------
-    def step(self, batch, labels, attention_mask=None):
+    def step(self, batch, labels, attention_mask=None, all_reduce=True):
+        """One fine-tune step.  `all_reduce=False` skips the data-parallel gradient collective (each replica then applies its
+        own gradients): a MEASUREMENT switch -- bench.py times the step with and without it to report the exposed
+        communication time -- never the training semantics of the reference (main.py:156,192)."""
         logits = self.forward(batch, attention_mask)
         nll, grad = self.loss.per_sample(labels, logits, with_grad=True)     # grad already / division_factor
         self.backward(grad)
-        self.all_reduce_gradients()
+        if all_reduce:
+            self.all_reduce_gradients()
         self.apply_gradients()
         return (nll / self.loss.division_factor).sum()
+
+    def all_reduce_payload(self):
+        """(bytes sent per step and replica, number of non-empty buckets, number of collectives) of `all_reduce_gradients`."""
+        ranges = self.reduce_ranges()
+        elems = sum(n for runs in ranges for _, n in runs)
+        return (elems * (2 if self.allreduce_dtype == "bf16" else 4), sum(1 for runs in ranges if runs),
+                sum(len(runs) for runs in ranges))

@@ -243,10 +243,22 @@ int w2v2_profile_families(w2v2_model* m, uint32_t family_mask);
  * w2v2_profile_seen: how many launches of the family were issued since the last reset, sampled or not. */
 int w2v2_profile_sampling(w2v2_model* m, int32_t stride);
 int w2v2_profile_seen(w2v2_model* m, int index, int64_t* launches);
+/* KERNEL launches enqueued for the family since the last w2v2_profile_reset, by any model of the process: an op-level call
+ * counted by w2v2_profile_seen may enqueue several kernels (main + tail-tile kernels of one GEMM, partial + final reductions);
+ * this is the count a rocprofv3 --kernel-trace of the same steps shows.  Counted whether or not profiling is enabled. */
+int w2v2_profile_kernel_launches(w2v2_model* m, int index, int64_t* launches);
 int w2v2_profile_num_families(void);
 int w2v2_profile_read(w2v2_model* m, int index, const char** name, int64_t* launches,
                       double* total_ms, double* flops, double* bytes);
 int w2v2_profile_reset(w2v2_model* m);
+
+/* Shader-clock probe (measurement aid; no reference counterpart).  Enqueues on `stream` a one-wave kernel that samples the
+ * shader-cycle counter and the constant-rate wall clock, spins `spin_us` microseconds of wall time (0 < spin_us <= 200000) and
+ * samples both again into dev_out4 = {cycles0, wall0, cycles1, wall1} (device memory, 4 x uint64).  *wall_clock_khz receives the
+ * wall counter's rate.  Shader MHz while it ran = (cycles1 - cycles0) / (wall1 - wall0) * wall_clock_khz / 1000.  Launched on
+ * a side stream while a workload runs on another, it reports the clock the chip holds UNDER that workload (MI355X clocks to its
+ * power budget), which bench.py prints beside the nominal-peak roofline fraction. */
+int w2v2_clock_probe(void* stream, int32_t spin_us, uint64_t* dev_out4, int32_t* wall_clock_khz);
 
 /* ---- individual operators (each is one hot-path kernel family) -----------
  * Exposed so every kernel is parity-tested on its own against the oracle. */

@@ -75,7 +75,7 @@ def tap_stride(name):
     return {"conv0": 997, "conv1": 499, "conv2": 251, "conv3": 127, "conv4": 61, "conv5": 31}.get(name, 1)
 
 
-def run_case(name, c, seed, x, mask, labels, out_dir, full_taps):
+def run_case(name, c, seed, x, mask, labels, out_dir, full_taps, conv_taps=True):
     print(f"[{name}] B={x.shape[0]} L={x.shape[1]} ...", flush=True)
     res = {"wave": x}
     if mask is not None:
@@ -97,7 +97,7 @@ def run_case(name, c, seed, x, mask, labels, out_dir, full_taps):
             res["last_hidden"] = out.last_hidden_state.float().numpy()[:, ::1 if full_taps else 13]
             # per-layer conv taps (strided in time)
             h = xt[:, None, :]
-            for i, layer in enumerate(hf.wav2vec2.feature_extractor.conv_layers):
+            for i, layer in enumerate(hf.wav2vec2.feature_extractor.conv_layers if conv_taps else ()):
                 with torch.no_grad():
                     h = layer(h)
                 if i < 6:
@@ -216,6 +216,32 @@ def main():
         m[0, -1000:] = 0
         m[1, -132:] = 0
         run_case("robust_masked", c, 0, x, m, None, out_dir, False)
+
+    if want("robust_full_246000"):
+        # BASELINE configs[3] shape: large-robust at 246000 samples, ragged mask (one full row, one row with 100000 padded
+        # samples) -- the input recipe of tests/test_model_gpu.py::test_large_robust_full_length (weights seed 5)
+        c = RobustWav2Vec2Config()
+        L = 246000
+        x = V.hash_normal("robust/full", 2 * L, 6).reshape(2, L)
+        m = np.ones((2, L), np.int32)
+        m[1, 146000:] = 0
+        run_case("robust_full_246000", c, 5, (x * m).astype(np.float32), m, None, out_dir, False, conv_taps=False)
+
+    if want("robust_long_480000"):
+        # BASELINE configs[4] input length: 480000 samples -> T = 1499 frames, large-robust, last 70001 samples masked
+        c = RobustWav2Vec2Config()
+        L = 480000
+        x = V.hash_normal("robust/long", L, 8).reshape(1, L)
+        m = np.ones((1, L), np.int32)
+        m[0, -70001:] = 0
+        run_case("robust_long_480000", c, 5, (x * m).astype(np.float32), m, None, out_dir, False, conv_taps=False)
+
+    if want("base_long_480000"):
+        # the input of tests/test_model_gpu.py::test_long_form_480000 (base, seed-0 weights, no mask)
+        c = Wav2Vec2Config()
+        L = 480000
+        x = V.hash_normal("long/wave", L, 7).reshape(1, L)
+        run_case("base_long_480000", c, 0, x.astype(np.float32), None, None, out_dir, False, conv_taps=False)
 
 
 if __name__ == "__main__":

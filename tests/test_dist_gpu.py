@@ -132,3 +132,38 @@ def test_two_ranks_on_one_gpu_drive_the_real_trainer(tmp_path, payload, overlap)
     # both replicas hold the same weights after the step (what keeps data-parallel replicas in sync)
     for n in CHECK:
         assert np.array_equal(got[0]["w:" + n], got[1]["w:" + n]), n
+
+
+def test_bench_two_ranks_report_every_baseline_config_with_the_collective():
+    """The one command the driver runs, at N = 2: `bench.py --gpus 2` self-launches two ranks under torch.distributed.run and its
+    single JSON line must carry, beside the headline, BASELINE configs[2] / [3] / [4] -- the two training legs with the bucketed
+    gradient all-reduce INSIDE their timed steps and the measured `allreduce` object (payload, buckets, step time without the
+    collective, exposed time, standalone time, bus bandwidth).  The test box has one GPU and RCCL refuses two ranks on one device, so
+    the group is gloo here (`--backend gloo`; the default and the only quotable backend is nccl = RCCL); the side legs run at an
+    eighth of their batch to keep the test short.  Everything else is the code path of the driver's 8-GPU run."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+           "--side-shrink", "8", "--no-cpu-baseline", "--no-alt"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    js = json.loads(lines[0])
+    assert js["n_gpus"] == 2 and js["comm"]["backend"] == "gloo" and js["comm"]["world_size"] == 2
+    assert js["config"]["global_batch"] == 64 and js["roofline"]["frac"] > 0
+    for key, train in (("configs2_train_bf16", True), ("configs3_large_fwd_f32", False), ("configs4_large_train_bf16", True)):
+        leg = js[key]
+        assert "error" not in leg, leg
+        assert leg["n_gpus"] == 2 and leg["ms_per_step"] > 0 and leg["value"] > 0
+        assert leg["roofline"]["frac"] > 0 and leg["roofline"]["kernel_launches_per_step"] >= leg["roofline"]["launches_per_step"]
+        shares = sum(v["share"] for v in leg["families"].values())
+        assert 0.3 < shares < 1.3, shares                   # shares are of the TIMED step: they need not add to 1
+        if train:
+            ar = leg["allreduce"]
+            assert ar["world_size"] == 2 and ar["buckets"] >= 13 and ar["payload_bytes"] > 0
+            assert ar["ms_per_step_without_collective"] > 0 and ar["standalone_ms"] > 0 and ar["busbw_GBps"] > 0
+            assert np.isfinite(leg["final_loss"])
+    assert js["configs2_train_bf16"]["allreduce"]["payload_bytes"] == 4 * (90195104 + 768)      # SURVEY 8e: 360.8 MB fp32 for base

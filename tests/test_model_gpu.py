@@ -434,6 +434,18 @@ def test_large_robust_full_length_vs_oracle(torch_mod):
     err = H.max_err(got, ref)
     report("robust_full_246000/logits_vs_oracle_f32", err)
     assert err < H.ATOL_AIM
+    # ... and against HF-PyTorch fp64 on the same input (tests/golden/make_golden.py::robust_full_246000; the reference's robust recipe
+    # tests/test_wav2vec2.py:58-62,85-91 at the BASELINE length), which also pins the ORACLE at this shape (round 3 pinned it at T = 145 only)
+    g = H.golden("robust_full_246000")
+    assert np.array_equal(g["wave"], x) and np.array_equal(g["attention_mask"], mask)
+    err_hf, oracle_hf = H.max_err(got, g["logits_f64"]), H.max_err(ref, g["logits_f64"])
+    print(f"robust_full_246000: max|logits - HF fp64| = {err_hf:.3e}; oracle vs HF fp64 {oracle_hf:.3e}; HF fp32 vs fp64 {H.max_err(g['logits_f32'], g['logits_f64']):.3e}")
+    report("robust_full_246000/logits_vs_hf_f64", err_hf)
+    report("robust_full_246000/oracle_vs_hf_f64", oracle_hf)
+    assert err_hf < H.ATOL_AIM and oracle_hf < H.ATOL_AIM
+    for tap in ("conv6", "encoder_in", "layer0"):
+        e = H.max_err(H.tap_view(tap, m.activation(tap), False), g[tap])
+        assert e < H.ATOL_AIM * max(1.0, float(np.abs(g[tap]).max())), f"{tap}: {e:.3e}"
 
 
 def test_long_form_480000_vs_oracle(torch_mod):
@@ -447,6 +459,114 @@ def test_long_form_480000_vs_oracle(torch_mod):
     err = H.max_err(got, ref)
     report("base_480000/logits_vs_oracle_f32", err)
     assert err < H.ATOL_AIM
+    g = H.golden("base_long_480000")                          # HF-PyTorch fp64 on the same input (make_golden.py::base_long_480000)
+    assert np.array_equal(g["wave"], x)
+    err_hf, oracle_hf = H.max_err(got, g["logits_f64"]), H.max_err(ref, g["logits_f64"])
+    print(f"base_long_480000: max|logits - HF fp64| = {err_hf:.3e}; oracle vs HF fp64 {oracle_hf:.3e}")
+    report("base_480000/logits_vs_hf_f64", err_hf)
+    assert err_hf < H.ATOL_AIM and oracle_hf < H.ATOL_AIM
+
+
+def test_large_robust_long_form_480000_vs_hf(torch_mod):
+    """BASELINE configs[4] model and length: wav2vec2-large-robust at 480000 samples (T = 1499) with the last 70001 samples masked,
+    against HF-PyTorch fp64 on the same input (tests/golden/make_golden.py::robust_long_480000; weights seed 5)."""
+    import wav2vec2
+    from wav2vec2.config import RobustWav2Vec2Config
+    cfg = RobustWav2Vec2Config()
+    g = H.golden("robust_long_480000")
+    L = 480000
+    mask = np.ones((1, L), np.int32)
+    mask[0, -70001:] = 0
+    x = (V.hash_normal("robust/long", L, 8).reshape(1, L) * mask).astype(np.float32)
+    assert np.array_equal(g["wave"], x) and np.array_equal(g["attention_mask"], mask)
+    m = wav2vec2.Wav2Vec2ForCTC(cfg, input_shape=(1, L))
+    m.set_weights(V.seeded_weights(cfg, seed=5))
+    got = m(x, attention_mask=mask).numpy()
+    assert got.shape == (1, 1499, 32) and np.isfinite(got).all()
+    err = H.max_err(got, g["logits_f64"])
+    print(f"robust_long_480000: max|logits - HF fp64| = {err:.3e}; HF fp32 vs fp64 {H.max_err(g['logits_f32'], g['logits_f64']):.3e}")
+    report("robust_long_480000/logits_vs_hf_f64", err)
+    assert err < H.ATOL_AIM
+    for tap in ("conv6", "encoder_in", "layer0"):
+        e = H.max_err(H.tap_view(tap, m.activation(tap), False), g[tap])
+        assert e < H.ATOL_AIM * max(1.0, float(np.abs(g[tap]).max())), f"{tap}: {e:.3e}"
+    m.set_precision("bf16x3")
+    err3 = H.max_err(m(x, attention_mask=mask).numpy(), g["logits_f64"])
+    report("robust_long_480000/bf16x3_logits_vs_hf_f64", err3)
+    assert err3 < H.ATOL_AIM
+
+
+def _greedy(logits):
+    """Greedy CTC path per frame and its collapsed label string (processor.decode's rule: merge repeats, drop pad 0)."""
+    ids = logits.argmax(-1)
+    outs = []
+    for row in ids:
+        keep = np.concatenate([[True], row[1:] != row[:-1]])
+        outs.append([int(v) for v in row[keep] if v != 0])
+    return ids, outs
+
+
+def test_bf16_mode_keeps_the_decoded_output(torch_mod):
+    """What a user of precision mode bf16 sees (processor.decode, processor.py:71-89; the reference demands string-equal decodes in
+    fp32, tests/test_wav2vec2.py:159-170): on both rows of the BASELINE-size fixture the greedy frame labels of the bf16 forward agree
+    with the fp32 forward's on >= 99 % of the frames whose fp32 top-2 margin exceeds the mode's logit error (0.2), and the CTC NLL
+    of a fixed labelling moves by <= 2e-3 relative.  (Random-init weights give near-uniform posteriors -- many frames have top-2
+    margins below the bf16 logit error, so unlike a trained checkpoint the raw agreement is not 100 %; the margin-gated form is the
+    meaningful statement.  Raw figures are reported and floor-checked.)"""
+    import wav2vec2
+    g = H.golden("base_sample_padded")
+    m, cfg = build("base_sample_padded")
+    x = g["wave"]
+    f32 = m(x).numpy()
+    m.set_precision("bf16")
+    b16 = m(x).numpy()
+    ids32, str32 = _greedy(f32)
+    ids16, str16 = _greedy(b16)
+    ids64, _ = _greedy(g["logits_f64"])
+    srt = np.sort(f32, axis=-1)
+    margin = srt[..., -1] - srt[..., -2]
+    raw = float((ids32 == ids16).mean())
+    sure = margin > 0.2
+    gated = float((ids32 == ids16)[sure].mean())
+    print(f"bf16 vs fp32 greedy ids: raw agreement {raw:.4f}; on the {sure.mean():.3f} of frames with fp32 margin > 0.2: {gated:.4f}; "
+          f"fp32 vs HF fp64 agreement {float((ids32 == ids64).mean()):.4f}; collapsed lengths {[len(s) for s in str32]} vs {[len(s) for s in str16]}")
+    report("base_sample_padded/bf16_greedy_agreement_raw", raw)
+    report("base_sample_padded/bf16_greedy_agreement_margin_gated", gated)
+    assert float((ids32 == ids64).mean()) > 0.999            # fp32 itself decodes as HF fp64 does
+    assert gated >= 0.99
+    assert raw >= 0.93
+    # CTC NLL of the fixture's labelling under both logits
+    loss = wav2vec2.CTCLoss(cfg, x.shape)
+    n32 = loss.per_sample(g["labels"], torch_mod.from_numpy(f32).cuda()).cpu().numpy()
+    n16 = loss.per_sample(g["labels"], torch_mod.from_numpy(b16).cuda()).cpu().numpy()
+    rel = float(np.abs(n16 - n32).max() / np.abs(n32).max())
+    print(f"CTC NLL fp32 {n32} bf16 {n16}: relative difference {rel:.2e}")
+    report("base_sample_padded/bf16_ctc_nll_rel", rel)
+    assert rel <= 2e-3
+
+
+def test_configs3_full_batch_rows_do_not_depend_on_the_batch(torch_mod):
+    """BASELINE configs[3] at its full per-GPU batch: large-robust fp32 forward, 16 x 246000.  Rows 0-1 are the HF fixture's two
+    rows (ragged mask), rows 2-15 seeded noise: the fixture rows must match HF fp64 at the fp32 bar INSIDE the 16-row batch and be
+    bit-identical to the 2-row forward's logits (every output row sums its products in the same order whatever the tiling)."""
+    import wav2vec2
+    from wav2vec2.config import RobustWav2Vec2Config
+    cfg = RobustWav2Vec2Config()
+    g = H.golden("robust_full_246000")
+    L, B = 246000, 16
+    x = V.hash_normal("configs3/noise", B * L, 11).reshape(B, L).astype(np.float32)
+    mask = np.ones((B, L), np.int32)
+    x[:2], mask[:2] = g["wave"], g["attention_mask"]
+    m = wav2vec2.Wav2Vec2ForCTC(cfg, input_shape=(B, L))
+    m.set_weights(V.seeded_weights(cfg, seed=5))
+    full = m(x, attention_mask=mask).numpy()
+    assert full.shape == (B, 768, 32) and np.isfinite(full).all()
+    err = H.max_err(full[:2], g["logits_f64"])
+    report("configs3_full_batch/rows01_vs_hf_f64", err)
+    assert err < H.ATOL_AIM
+    two = m(x[:2], attention_mask=mask[:2]).numpy()
+    assert np.array_equal(two, full[:2])
+    assert np.array_equal(m(x, attention_mask=mask).numpy(), full)          # and the batch reproduces itself
 
 
 def test_load_hf_state_dict_roundtrip(torch_mod):

@@ -715,6 +715,36 @@ def test_bf16_fine_tune_step_at_full_length(env, case, L, frames):
     assert worst[1] < 3.2e-2 and worst_mean[1] < 3.5e-3
 
 
+def test_configs2_full_batch_bf16_step(env):
+    """BASELINE configs[2] at its full per-GPU batch: base, bf16, 32 x 246000, dropout 0.1 + spec-augment, conv stack frozen.
+    Properties that need no oracle at this size: the loss and every gradient are finite; the step is bit-reproducible (same seeds,
+    twice: identical logits and flat gradient buffer); and rows 0-1 of the 32-row training forward equal the 2-row training forward's
+    logits bit for bit (dropout masks are counters of (seed, site, element index), rows are independent, and every output row
+    sums its products in the same order whatever slab / tile routing B T = 24576 rows take)."""
+    import wav2vec2
+    B, L = 32, 246000
+    m, cfg, w = build("base_sample_padded", L)
+    m.set_precision("bf16")
+    T = cfg.num_frames(L)
+    x = V.hash_normal("configs2/wave", B * L, 12).reshape(B, L).astype(np.float32)
+    labels = _ragged_labels(B, 256, 24, 200, 6)
+    loss_fn = wav2vec2.CTCLoss(cfg, x.shape, division_factor=B)
+    tr = wav2vec2.Trainer(m, loss_fn, dropout=0.1, apply_spec_augment=False, seed=1)
+    spec = compute_mask_indices((B, T), 0.05, 10, rng=np.random.RandomState(4))
+    runs = []
+    for _ in range(2):
+        logits = tr.forward(x, spec_mask=spec, step_seed=42)
+        nll, dlog = loss_fn.per_sample(labels, logits, with_grad=True)
+        tr.backward(dlog)
+        runs.append((logits.cpu().numpy().copy(), tr.grad_buffer().cpu().numpy().copy(), nll.cpu().numpy().copy()))
+    assert np.isfinite(runs[0][0]).all() and np.isfinite(runs[0][1]).all() and np.isfinite(runs[0][2]).all()
+    assert np.abs(runs[0][1]).max() > 0
+    assert np.array_equal(runs[0][0], runs[1][0]), "logits differ between two identical steps"
+    assert np.array_equal(runs[0][1], runs[1][1]), f"{int((runs[0][1] != runs[1][1]).sum())} gradient elements differ"
+    two = tr.forward(x[:2], spec_mask=spec[:2], step_seed=42).cpu().numpy()
+    assert np.array_equal(two, runs[0][0][:2]), f"rows 0-1 of the full batch differ from the 2-row forward by {H.max_err(two, runs[0][0][:2]):.3e}"
+
+
 def test_new_trainer_is_a_fresh_optimizer(env):
     """The reference builds a new Adam for stage 2 (src/main.py:213,240): iteration 0 AND zero moments.  The moments live in
     the model's native state, so a second Trainer on a used model must reset them; `reset_optimizer=False` adopts them."""

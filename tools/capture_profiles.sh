@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 cd /tmp
-B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-alt"
+B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-alt --no-side"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_fwd_f32   -- $B                                > $O/prof_fwd_f32.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_fwd_bf16  -- $B --precision bf16               > $O/prof_fwd_bf16.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_fwd_bf16x3 -- $B --precision bf16x3            > $O/prof_fwd_bf16x3.log 2>&1

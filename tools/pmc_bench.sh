@@ -8,7 +8,7 @@ mkdir -p $O; cd /tmp
 SETS=("SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "FETCH_SIZE" "WRITE_SIZE")
 i=0
 for set in "${SETS[@]}"; do
-  timeout 400 rocprofv3 --pmc $set --output-format csv -d $O/pmcb_${tag}_$i -- python $R/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-alt > $O/pmcb_${tag}_$i.log 2>&1 || echo "set $i ($set) failed: $(tail -2 $O/pmcb_${tag}_$i.log)"
+  timeout 400 rocprofv3 --pmc $set --output-format csv -d $O/pmcb_${tag}_$i -- python $R/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-alt --no-side > $O/pmcb_${tag}_$i.log 2>&1 || echo "set $i ($set) failed: $(tail -2 $O/pmcb_${tag}_$i.log)"
   i=$((i+1))
 done
 cd $R

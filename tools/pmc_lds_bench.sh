@@ -2,7 +2,7 @@
 # LDS bank-conflict share per kernel over one short bench.py run (all kernels, not one family): tools/pmc_lds_bench.sh <bench args...>
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O; cd /tmp
-timeout 400 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES --output-format csv -d $O/pmcl -- python $R/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-alt > $O/pmcl.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES --output-format csv -d $O/pmcl -- python $R/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-side --no-profile --no-alt > $O/pmcl.log 2>&1
 python - <<PY
 import csv, glob, collections, re
 acc = collections.defaultdict(lambda: collections.defaultdict(float))

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/final; mkdir -p $O; cd $R
 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1; tail -3 $O/gpu_tests.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -6 $O/smoke.log
-python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
+python bench.py --steps 20 --warmup 5 > $O/bench_n1.json 2> $O/bench_n1.err
 python bench.py --precision bf16 --no-cpu-baseline > $O/bench_bf16_n1.json 2>/dev/null
 python bench.py --precision bf16x3 --no-cpu-baseline > $O/bench_bf16x3_n1.json 2>/dev/null
 python bench.py --mode train --precision bf16 --no-cpu-baseline > $O/bench_bf16_train_n1.json 2>/dev/null
