@@ -382,11 +382,12 @@ def self_launch(n):
 PEAK_CLOCK_MHZ = 2400.0           # MI355X_MICROARCH.md: the clock the peak figures are quoted at
 
 
-def clock_under_load(ctx, model, x, amask):
-    """Shader clock while this workload's forward runs, measured live: a one-wave probe kernel (w2v2_clock_probe, csrc/clock_probe.hip)
-    on a side stream samples the shader-cycle counter and the constant-rate wall clock over a window inside an (untimed) forward on
-    the main stream.  MI355X clocks to its power budget, so the 2.4 GHz behind the nominal peak is not what the MFMA GEMMs run at;
-    `frac_clock_adjusted` = achieved / (peak x measured clock / 2400).  The idle figure (probe alone) is printed beside it."""
+def clock_under_load(ctx, run_step, window_us):
+    """Shader clock while a workload runs, measured live: a one-wave probe kernel (w2v2_clock_probe, csrc/clock_probe.hip) on a side
+    stream samples the shader-cycle counter (s_memtime: one tick per shader cycle) and the constant-rate wall clock over a window
+    inside one untimed step of the workload on the main stream.  MI355X clocks to its power budget, so the 2.4 GHz behind the nominal
+    peak need not be what a kernel mix runs at; `frac_clock_adjusted` = achieved / (peak x measured clock / 2400).  The idle figure
+    (probe alone) is printed beside it."""
     import ctypes as C
     torch = ctx["torch"]
     from wav2vec2 import _native as N
@@ -406,20 +407,30 @@ def clock_under_load(ctx, model, x, amask):
         N.check(lib.w2v2_clock_probe(C.c_void_p(side.cuda_stream), 5000, C.c_void_p(buf[:4].data_ptr()), C.byref(khz)), "w2v2_clock_probe")
         torch.cuda.synchronize()
         idle, _ = mhz(buf[:4])
-        model(x, attention_mask=amask)                          # re-warm, then the probed forward
+        run_step()                                              # re-warm, then the probed step
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        model(x, attention_mask=amask)                          # enqueue only (asynchronous)
+        run_step()                                              # enqueue only (asynchronous)
         t_enq = time.perf_counter() - t0
-        N.check(lib.w2v2_clock_probe(C.c_void_p(side.cuda_stream), 25000, C.c_void_p(buf[4:].data_ptr()), C.byref(khz)), "w2v2_clock_probe")
+        N.check(lib.w2v2_clock_probe(C.c_void_p(side.cuda_stream), int(window_us), C.c_void_p(buf[4:].data_ptr()), C.byref(khz)), "w2v2_clock_probe")
         torch.cuda.synchronize()
-        busy, window_us = mhz(buf[4:])
+        busy, got_us = mhz(buf[4:])
         return {"clock_mhz_under_load": round(busy, 1) if busy else None, "clock_mhz_idle": round(idle, 1) if idle else None,
-                "clock_method": f"live: one-wave probe kernel on a side stream, d(s_memtime) / d(s_memrealtime) over a {window_us / 1e3:.1f} ms window "
-                                f"inside one untimed forward of this workload (enqueue took {1e3 * t_enq:.1f} ms); cross-check by PMC "
+                "clock_method": f"live: one-wave probe kernel on a side stream, d(s_memtime) / d(s_memrealtime) over a {got_us / 1e3:.1f} ms window "
+                                f"inside one untimed step of this workload (its enqueue took {1e3 * t_enq:.1f} ms); cross-check by PMC "
                                 "(GRBM_GUI_ACTIVE / 8 XCDs / kernel duration) in profiles/"}
     except Exception as exc:                                    # noqa: BLE001 -- a side measurement never costs the line
         return {"clock_mhz_under_load": None, "clock_error": repr(exc)[:200]}
+
+
+def add_clock(roof, clk):
+    if roof is None or not clk:
+        return
+    roof.update(clk)
+    if clk.get("clock_mhz_under_load"):
+        adj = roof["peak"] * clk["clock_mhz_under_load"] / PEAK_CLOCK_MHZ
+        roof["peak_at_measured_clock"] = round(adj, 1)
+        roof["frac_clock_adjusted"] = round(roof["achieved"] / adj, 4)
 
 
 FAMILY_OF = {"fp32": "gemm_f32", "bf16": "gemm_bf16", "bf16x3": "gemm_split"}
@@ -557,6 +568,9 @@ def run_leg(ctx, spec, model=None):
         barrier()
         res["prof_all"] = model.profile_read()
         model.profile(False)
+    if do_prof and rank == 0:
+        # the probed window: 40 % of a step, started right after the step's enqueue (long enough to average over many kernels)
+        res["clock"] = clock_under_load(ctx, lambda: step(all_reduce=False), max(2000, min(60000, int(400 * res["ms_per_step"]))))
     if mode == "train":
         assert bool(torch.isfinite(out).all()), "training loss is not finite"
         res["final_loss"] = round(float(out), 4)
@@ -614,6 +628,7 @@ def side_object(ctx, spec, res, label):
            "unit": "audio-seconds/s", "dtype": DTYPE_OF[spec["precision"]], "roofline": roofline_of(res, spec, steps),
            "families": fam, "unattributed_ms": unattr, "kernel_launches_per_step": kernels,
            "matrix_tflops": round(flops_step * world / (res["ms_per_step"] * 1e-3) / 1e12, 2)}
+    add_clock(obj["roofline"], res.get("clock"))
     if "final_loss" in res:
         obj["final_loss"] = res["final_loss"]
     if "allreduce" in res:
@@ -733,10 +748,6 @@ def main():
         except Exception as exc:                               # noqa: BLE001
             alt = {"precision": "bf16x3", "error": repr(exc)}
 
-    clk_probe = None
-    if rank == 0 and args.mode == "forward" and not args.no_profile:
-        clk_probe = clock_under_load(ctx, model, x, amask)
-
     line = None
     if rank == 0:
         audio_s = world * B * L / SAMPLE_RATE * args.steps
@@ -772,13 +783,7 @@ def main():
             else:
                 roof["traffic"], roof["traffic_source"] = None, "no PMC profile is kept for this configuration"
             roof["traffic_unit"] = "HBM bytes per kernel launch of the family (rocprofv3 PMC FETCH_SIZE x 2 + WRITE_SIZE, separate passes)"
-            clk = clk_probe
-            if clk:
-                roof.update(clk)
-                if clk.get("clock_mhz_under_load"):
-                    adj = roof["peak"] * clk["clock_mhz_under_load"] / PEAK_CLOCK_MHZ
-                    roof["peak_at_measured_clock"] = round(adj, 1)
-                    roof["frac_clock_adjusted"] = round(roof["achieved"] / adj, 4)
+            add_clock(roof, res.get("clock"))
             line["roofline"] = roof
             fam, unattr, kernels, flops_step = families_of(res, world, args.steps)
             line["families"] = fam

@@ -21,6 +21,8 @@
 // The scale d^-0.5 = 2^-3 is folded into the exponent (scores stay unscaled in the accumulators): scaling by a power
 // of two commutes with every rounding involved, so the results are those of pre-scaled q.
 // Blocks are mapped so that the query blocks of one (sample, head) run on the same XCD and share K / V in its L2.
+#include <type_traits>
+
 #include "common.h"
 #include "train.h"
 
@@ -65,8 +67,23 @@ __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast
 __device__ __forceinline__ int swz(int row) { return 4 * ((row >> 1) & 1) + ((row >> 2) & 3); }
 
 // Keep-bit words of the attention-probability dropout (AttnTrain::keep_bits): word [bh][key tile][lh][query], query padded
-// to whole 128-row blocks (Tq = 128 nqb), key tiles padded to Tq / 64; bit 16 kt + r of the word of (query q, key tile, lh) is
-// the decision for key  64 tile + 32 kt + (r & 3) + 8 (r >> 2) + 4 lh  -- the forward lane's accumulator register order.
+// to whole 128-row blocks (Tq = 128 nqb), key tiles padded to Tq / 64.  A lane of the forward holds 32 scores of its query per key
+// tile, accumulator register r of sub-tile kt = key  64 tile + 32 kt + (r & 3) + 8 (r >> 2) + 4 lh; registers (2j, 2j + 1) are the
+// even / odd element of ONE hash word and one packed bf16 pair.  Pair p = 8 kt + j owns bit p (even element, register 2j) and bit
+// 16 + p (odd element, register 2j + 1): the packed keep mask of the pair (0xFFFF per kept half, train.h) ANDed with
+// (1 << p) | (1 << (16 + p)) is the pair's contribution, and  (word << (15 - p))  puts both decisions on the sign bits of the two
+// 16-bit halves again (keep_pair_mask).
+__device__ __forceinline__ constexpr int keep_bit(int kt, int r) { return (r & 1) * 16 + 8 * kt + (r >> 1); }
+__device__ __forceinline__ uint32_t keep_pair_mask(uint32_t bits, int pair) {      // packed 0xFFFF / 0 masks of pair `pair`
+    w2v2_short2 d = __builtin_bit_cast(w2v2_short2, bits << (15 - pair));
+    d = d >> 15;
+    return __builtin_bit_cast(uint32_t, d);
+}
+__device__ __forceinline__ float keep_f32(float v, uint32_t bits, int bit) {         // v where `bit` of bits is set, else +0
+    // v_bfe_i32 (a 1-bit signed field = all ones / zero) + v_and: written with the builtin because the generic shift form is folded
+    // back into test + compare + select (three instructions) by the optimiser
+    return __uint_as_float(__float_as_uint(v) & (uint32_t)__builtin_amdgcn_sbfe((int)bits, (unsigned)bit, 1u));
+}
 __device__ __forceinline__ int64_t keep_word(int bh, int tile, int lh, int nqb) {
     const int Tq = nqb * NW * 32;
     return (((int64_t)bh * (Tq / KT) + tile) * 2 + lh) * Tq;
@@ -175,6 +192,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attention_bf16_kernel(Attn16Args a
     float m_run = -INFINITY, l_run = 0.f;     // running max (of the UNSCALED scores) and sum
     // dropout hash inputs hoisted out of the tile loop: element index = ((b h + head) T + q) T + key, modulo 2^32
     const uint32_t drop_key = TRAIN ? dropout_key(tr.seed, tr.stream) : 0u, drop_thr = TRAIN ? dropout_threshold(tr.p) : 0u;
+    const uint32_t thr1s_pk = dropout_thr1s_pk(drop_thr);
     const uint32_t drop_row = (uint32_t)(((uint64_t)bh * a.T + (uint64_t)min(q0 + li, a.T - 1)) * attention_drop_stride(a.T));
     const int xr = swz(li);                   // swizzle of this lane's fragment rows (sub * 32 + li: the sub-tile does not change it)
 
@@ -219,55 +237,67 @@ __global__ __launch_bounds__(NW * 64, 3) void attention_bf16_kernel(Attn16Args a
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * C2);   // exp2(-inf) = 0 on the first tile
+        // exponent = s C2 - m C2 as ONE fused multiply-add (round 4; before: (s - m) * C2, two instructions per score).  The product
+        // s C2 is exact inside the FMA; what is rounded is m C2, once per row: a relative error of 2^-24 |m C2| in every probability
+        // of the row -- 1e-6 at |m| = 100, against the 2^-9 the bf16 rounding of P commits next -- and the SAME factor in the row sum,
+        // so it cancels in the normalised output.  (A fully masked row, |m C2| = 1.4e4, would see 1e-3: such a row has no valid key
+        // and its output is discarded by the caller's mask.)
+        const float mc = -m_new * C2;
         float rs = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f((s[kt][r] - m_new) * C2);   // subtract first: exact for nearby values even at |m| = 1e4 (masked rows)
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], C2, mc));
                 s[kt][r] = p;
                 rs += p;
             }
         rs += __shfl_xor(rs, 32, 64);
         l_run = l_run * alpha + rs;
         m_run = m_new;
-        if (TRAIN && tr.p > 0.f) {
-            // attention-probability dropout (encoder.py:42-44): the row sum above uses the un-dropped p; the
-            // 1 / (1 - p) factor is applied once, with the final normalisation
-            const uint32_t cbase = drop_row + (uint32_t)k0, thr1 = drop_thr - 1u;      // h >= thr  <=>  thr - 1 - h < 0 (16-bit h, thr)
-            uint32_t bits = 0;                  // bit 16 kt + r = the keep decision of accumulator register r of sub-tile kt
-            // cbase is even (even row stride, k0 a multiple of 64), so pair = (cbase + col) / 2 = (cbase / 2 + 2 lh) + a
-            // compile-time constant: one multiply per tile, an add per hash word
-            const uint32_t pm0 = ((cbase >> 1) + 2u * (uint32_t)lh) * DROPOUT_FIB;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {      // registers r, r + 1 are keys 2j, 2j + 1 of an even-strided row: one hash word
-                    const uint32_t cpair = (uint32_t)(kt * 16 + ((r & 3) >> 1) + 4 * (r >> 2));      // (col - 4 lh) / 2
-                    const uint32_t w = dropout_word_premul(drop_key, pm0 + cpair * DROPOUT_FIB);
-                    // all-ones / zero masks by integer arithmetic (sign of thr - 1 - h), applied with AND: no lane masks in SGPRs
-                    const uint32_t me = (uint32_t)((int32_t)(thr1 - (w & 0xFFFFu)) >> 31), mo = (uint32_t)((int32_t)(thr1 - (w >> 16)) >> 31);
-                    s[kt][r] = __uint_as_float(__float_as_uint(s[kt][r]) & me);
-                    s[kt][r + 1] = __uint_as_float(__float_as_uint(s[kt][r + 1]) & mo);
-                    bits |= (me & (1u << (16 * kt + r))) | (mo & (2u << (16 * kt + r)));
-                }
-            if (tr.keep_bits) tr.keep_bits[keep_word(bh, tile, lh, a.nqb) + q0 + li] = bits;
-        }
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
 
         // ---- O^T += V^T P^T: 8 MFMAs; B = the packed accumulator registers, A = transposing reads of the V image ----
+        // Attention-probability dropout (encoder.py:42-44) is applied to the PACKED pairs: registers (2j, 2j + 1) of a sub-tile are keys
+        // (2i, 2i + 1) of an even-strided row = the two halves of one hash word = one packed bf16 pair, so a word's two decisions
+        // (train.h::dropout_keep_mask_pk: two packed 16-bit instructions) mask the pair with one AND and enter the keep word with one
+        // AND-OR.  (Round 3 masked the fp32 values one by one: extract, subtract, shift, AND, AND-OR per ELEMENT -- with the hash 60 % of
+        // this VALU-bound loop.)  The row sum above uses the un-dropped p; 1 / (1 - p) is applied once, with the final normalisation.
+        // cbase = drop_row + k0 is even (even row stride, k0 a multiple of 64), so pair = (cbase + col) / 2 = (cbase / 2 + 2 lh) + a
+        // compile-time constant: one multiply per tile, an add per hash word
+        const uint32_t pm0 = (((drop_row + (uint32_t)k0) >> 1) + 2u * (uint32_t)lh) * DROPOUT_FIB;
+        uint32_t bits = 0;
+        auto pv = [&](auto dropping) {          // (two instances chosen by ONE wave-uniform branch per tile: a test inside the loops became 16 branches)
+            constexpr bool DROP = decltype(dropping)::value;
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const bf16x8 pb = pack_acc(s[kt], h);
+                for (int h = 0; h < 2; ++h) {
+                    u32x4 pw;
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Vs, tro, kt, h, dt), pb, o[dt], 0, 0, 0);
-            }
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = 8 * h + 2 * j;              // registers r, r + 1: keys 2i, 2i + 1
+                        pw[j] = pack_bf16(s[kt][r], s[kt][r + 1]);
+                        if (DROP) {
+                            const uint32_t cpair = (uint32_t)(kt * 16 + ((r & 3) >> 1) + 4 * (r >> 2));      // (col - 4 lh) / 2
+                            const uint32_t km = dropout_keep_mask_pk(dropout_word_premul(drop_key, pm0 + cpair * DROPOUT_FIB), thr1s_pk);
+                            pw[j] &= km;
+                            bits |= km & ((1u << (8 * kt + (r >> 1))) | (1u << (16 + 8 * kt + (r >> 1))));
+                        }
+                    }
+                    const bf16x8 pb = as_bf16x8(pw);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Vs, tro, kt, h, dt), pb, o[dt], 0, 0, 0);
+                }
+        };
+        const bool drop = TRAIN && drop_thr != 0u;
+        if (drop) pv(std::true_type{});
+        else pv(std::false_type{});
+        if (drop && tr.keep_bits) tr.keep_bits[keep_word(bh, tile, lh, a.nqb) + q0 + li] = bits;
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();        // everyone is done with `buf`; the DMA into the other stage has landed
     }
@@ -276,7 +306,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attention_bf16_kernel(Attn16Args a
     const int q = q0 + li;
     if (TRAIN && q < a.T && lh == 0) tr.lse[(int64_t)bh * a.T + q] = m_run * SCALE + logf(l_run);
     if (q < a.T) {
-        const float inv = ((TRAIN && tr.p > 0.f) ? 1.0f / (1.0f - tr.p) : 1.0f) / l_run;
+        const float inv = ((TRAIN && drop_thr != 0u) ? 1.0f / (1.0f - tr.p) : 1.0f) / l_run;
         const int64_t o0 = ((int64_t)b * a.T + q) * a.H + head * DH + 4 * lh;
         if (a.ctx) {
             float* op = a.ctx + o0;
@@ -404,9 +434,9 @@ __global__ __launch_bounds__(256, 3) void attention_bf16_bwd_dq_kernel(Attn16Bwd
     } else {
         dv = a.dvec[sidx];
     }
-    const float inv = tr.p > 0.f ? 1.0f / (1.0f - tr.p) : 1.0f;
-    const uint64_t rowbase = (uint64_t)sidx * attention_drop_stride(a.T);
     const uint32_t drop_key = dropout_key(tr.seed, tr.stream), drop_thr = dropout_threshold(tr.p);
+    const float inv = drop_thr != 0u ? 1.0f / (1.0f - tr.p) : 1.0f;
+    const uint64_t rowbase = (uint64_t)sidx * attention_drop_stride(a.T);
     const int xr = swz(li);
 
     f32x16 dq[2];
@@ -451,8 +481,8 @@ __global__ __launch_bounds__(256, 3) void attention_bf16_bwd_dq_kernel(Attn16Bwd
             for (int r = 0; r < 16; ++r) {
                 const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], C2, nlse));
                 float g = dp[r];
-                if (BITS) g = (bits & (1u << (16 * kt + r))) ? g : 0.f;
-                else if (tr.p > 0.f) g = dropout_keep32(drop_key, cbase + (uint32_t)((r & 3) + 8 * (r >> 2)), drop_thr) ? g : 0.f;
+                if (BITS) g = keep_f32(g, bits, keep_bit(kt, r));
+                else if (drop_thr != 0u) g = dropout_keep32(drop_key, cbase + (uint32_t)((r & 3) + 8 * (r >> 2)), drop_thr) ? g : 0.f;
                 s[r] = pv * fmaf(g, inv, -dv);
             }
             // dQ^T[d][q] += sum_key K^T[d][key] dS^T[key][q]
@@ -509,7 +539,8 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
     // (li & 3) + 4 (li >> 3) of the forward lane half (li >> 2) & 1
     const int Tq = a.nqb * NW * 32;
     const uint32_t* __restrict__ kbits = BITS ? tr.keep_bits + keep_word(bh, c0 / KT, 0, a.nqb) : nullptr;
-    const int kb_half = (li >> 2) & 1, kb_bit = 16 * ((c0 >> 5) & 1) + (li & 3) + 4 * (li >> 3);
+    const int kb_half = (li >> 2) & 1, kb_bit = keep_bit((c0 >> 5) & 1, (li & 3) + 4 * (li >> 3));
+    const int kb_shift = 31 - kb_bit;       // (word << kb_shift) >> 31 = all ones where this lane's key was kept
 
     TileDma dma;
     dma.init(wave, lane);
@@ -537,7 +568,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
     u32x4 kf[4], vf[4];
     load_col_frags(kf, base + kr * ld + a.H + 8 * lh);
     load_col_frags(vf, base + kr * ld + 2 * a.H + 8 * lh);
-    const float inv = tr.p > 0.f ? 1.0f / (1.0f - tr.p) : 1.0f;
+    const float inv = drop_thr != 0u ? 1.0f / (1.0f - tr.p) : 1.0f;
     const uint32_t drop_col = (uint32_t)((uint64_t)bh * a.T * attention_drop_stride(a.T)) + (uint32_t)kr;
     const int xr = swz(li);
 
@@ -571,19 +602,29 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
             // lane owns key column `key`; register r is query row qt*32 + (r&3) + 8 (r>>2) + 4 lh
             // (columns of keys >= T are clamped duplicates whose results are never stored, so only the QUERY bound
             // needs masking, and only on the last tile)
-            const bool qtail = t0 + KT > a.T;
             uint32_t didx = drop_col + (uint32_t)(t0 + qt * 32 + 4 * lh) * attention_drop_stride(a.T);   // ((bh T + q) T + key) mod 2^32
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ql = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float pv = __builtin_amdgcn_exp2f(fmaf(Ls[ql], -LOG2E, fmaf(s[r], C2, kmask)));
-                if (qtail) pv = t0 + ql < a.T ? pv : 0.f;
-                float g = dp[r], pd = pv;
-                if (BITS || tr.p > 0.f) {
-                    const bool keep = BITS ? ((Ws[ql] >> kb_bit) & 1u) != 0u
-                                           : dropout_keep32(drop_key, didx + (uint32_t)((r & 3) + 8 * (r >> 2)) * attention_drop_stride(a.T), drop_thr);
+                s[r] = __builtin_amdgcn_exp2f(fmaf(Ls[ql], -LOG2E, fmaf(s[r], C2, kmask)));      // P[q][key]
+            }
+            if (t0 + KT > a.T) {          // the last tile only (wave-uniform): query rows past T contribute nothing
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = t0 + qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh < a.T ? s[r] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ql = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float pv = s[r];
+                float g = dp[r], pd = pv * inv;
+                if (BITS) {             // one arithmetic shift turns this lane's bit of the row's keep word into a mask for both values
+                    const uint32_t km = (uint32_t)((int32_t)(Ws[ql] << kb_shift) >> 31);
+                    g = __uint_as_float(__float_as_uint(g) & km);
+                    pd = __uint_as_float(__float_as_uint(pd) & km);
+                } else if (drop_thr != 0u) {
+                    const bool keep = dropout_keep32(drop_key, didx + (uint32_t)((r & 3) + 8 * (r >> 2)) * attention_drop_stride(a.T), drop_thr);
                     g = keep ? g : 0.f;
-                    pd = keep ? pv * inv : 0.f;
+                    pd = keep ? pd : 0.f;
                 }
                 dp[r] = pd;                                    // Pd[q][key]
                 s[r] = pv * fmaf(g, inv, -Ls[KT + ql]);        // dS[q][key]

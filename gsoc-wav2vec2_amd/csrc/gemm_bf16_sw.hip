@@ -49,8 +49,27 @@ struct GemmSWArgs {
 #ifdef W2V2_TUNING
     unsigned long long* trace;
     int abl;
+    int nt;                    // W2V2_SW_NT: see SW_NT_DEFAULT
 #endif
 };
+
+// Output stores of the LDS-staged epilogues with the non-temporal hint (tools-only knob W2V2_SW_NT).  Idea: C / C16 are consumed by a
+// LATER kernel and never fit the 4-MB L2 of an XCD at B = 32, while the weight panel B16 (3.5-4.7 MB for the wide shapes) is re-read by
+// every row tile -- plain stores allocate in L2 and evict it (PMC round 3: q|k|v fetched 218 MB for 41 MB of operands).  Measured in
+// round 4 (profiles/r04_ab_sw_nt.txt, arms interleaved on one box): op level within +-0.7 % on every shape (q|k|v 91.6 vs 90.9 us,
+// FFN up 141.7 vs 141.9), bf16 forward 10.88 vs 10.86-10.91 ms, fine-tune step 33.15-33.19 vs 33.22-33.24 ms -- no gain: the refetched
+// B panel comes from the Infinity Cache fast enough to hide under the ring's ten-item prefetch.  Default: plain stores.
+constexpr int SW_NT_DEFAULT = 0;
+#ifdef W2V2_TUNING
+#define SW_NT(g) ((g).nt != 0)
+#else
+#define SW_NT(g) (SW_NT_DEFAULT != 0)
+#endif
+template <typename V>
+__device__ __forceinline__ void sw_store(V* p, const V& v, bool nt) {
+    if (nt) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
 
 __device__ __forceinline__ int sw_swz(int row) { return ((row >> 1) & 7) ^ ((row >> 4) & 1); }      // = gemm_bf16.hip's swz
 
@@ -81,7 +100,7 @@ using IC = std::integral_constant<int, V>;
 __device__ __forceinline__ unsigned sw_cswz(int c) { return (unsigned)(((c & 3) << 2) | ((c >> 2) & 3)); }
 
 template <int ACT>
-__device__ __forceinline__ void sw_epilogue_bf16(const f32x16 (&acc)[4][2], uint16_t* __restrict__ C16, const float* __restrict__ bias, int ldc,
+__device__ __forceinline__ void sw_epilogue_bf16(const bool nt, const f32x16 (&acc)[4][2], uint16_t* __restrict__ C16, const float* __restrict__ bias, int ldc,
                                                  unsigned wbase, int lane) {
     const int li = lane & 31, lh = lane >> 5;
     const unsigned pre_w = ((sw_cswz(li) ^ (unsigned)lh) << 3);
@@ -137,7 +156,7 @@ __device__ __forceinline__ void sw_epilogue_bf16(const f32x16 (&acc)[4][2], uint
     _Pragma("unroll") for (int t = 4 * (G); t < 4 * (G) + 4; ++t) {                                                          \
         u32x4 o;                                                                                                             \
         o[0] = lo[t][0]; o[1] = lo[t][1]; o[2] = hi[t][0]; o[3] = hi[t][1];                                                  \
-        *reinterpret_cast<u32x4*>(dst + (int64_t)(16 * (t >> 1)) * ldc + 32 * (t & 1)) = o;                                  \
+        sw_store(reinterpret_cast<u32x4*>(dst + (int64_t)(16 * (t >> 1)) * ldc + 32 * (t & 1)), o, nt);                      \
     }
     SW_RD4(0)
     SW_RD4(1)
@@ -159,7 +178,7 @@ __device__ __forceinline__ void sw_epilogue_bf16(const f32x16 (&acc)[4][2], uint
 // gemm_epilogue: (acc + bias) -> act -> + residual.
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 template <int ACT>
-__device__ __forceinline__ void sw_epilogue_f32(const f32x16 (&acc)[4][2], float* __restrict__ C, uint16_t* __restrict__ C16,
+__device__ __forceinline__ void sw_epilogue_f32(const bool nt, const f32x16 (&acc)[4][2], float* __restrict__ C, uint16_t* __restrict__ C16,
                                                 const float* __restrict__ R, const float* __restrict__ bias, int ldc, unsigned wbase, int lane) {
     const int li = lane & 31, lh = lane >> 5;
     const unsigned wr0 = wbase + (unsigned)(4 * lh) * 256u + (unsigned)li * 4u;      // register r adds ((r & 3) + 8 (r >> 2)) rows
@@ -251,12 +270,12 @@ __device__ __forceinline__ void sw_epilogue_f32(const f32x16 (&acc)[4][2], float
     {                                                                                                                             \
         const f32x4 o = R ? (X) + rr[h][T] : (X);                                                                                 \
         const int64_t off = rbase + (int64_t)(4 * (T)) * ldc;                                                                     \
-        if (C) *reinterpret_cast<f32x4*>(C + off) = o;                                                                            \
+        if (C) sw_store(reinterpret_cast<f32x4*>(C + off), o, nt);                                                                \
         if (C16) {                                                                                                                \
             u32x2 pk;                                                                                                             \
             pk[0] = pack_bf16_rne(o[0], o[1]);                                                                                    \
             pk[1] = pack_bf16_rne(o[2], o[3]);                                                                                    \
-            *reinterpret_cast<u32x2*>(C16 + off) = pk;                                                                            \
+            sw_store(reinterpret_cast<u32x2*>(C16 + off), pk, nt);                                                                \
         }                                                                                                                         \
     }
         SW_F32_GROUP(0)
@@ -580,9 +599,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_sw_kernel(GemmSWArgs g) {
     const float* const bw = g.bias ? g.bias + (n0 + wave * 64) : nullptr;
     const unsigned wb = lds0 + (unsigned)wave * 16384u;
     if (!TR && EK >= 1 && EK <= 3 && whole) {
-        sw_epilogue_bf16<EK - 1>(acc, g.C16 + tile_off, bw, (int)g.ldc, wb, lane);
+        sw_epilogue_bf16<EK - 1>(SW_NT(g), acc, g.C16 + tile_off, bw, (int)g.ldc, wb, lane);
     } else if (!TR && EK >= 4 && whole) {
-        sw_epilogue_f32<EK - 4>(acc, g.C + tile_off, g.C16 ? g.C16 + tile_off : nullptr, g.residual ? g.residual + tile_off : nullptr, bw, (int)g.ldc, wb,
+        sw_epilogue_f32<EK - 4>(SW_NT(g), acc, g.C + tile_off, g.C16 ? g.C16 + tile_off : nullptr, g.residual ? g.residual + tile_off : nullptr, bw, (int)g.ldc, wb,
                                 lane);
     } else {
         gemm_epilogue<4, 2, true>(acc, g.C ? g.C + tile_off : nullptr, g.C16 ? g.C16 + tile_off : nullptr, g.residual ? g.residual + tile_off : nullptr,
@@ -646,7 +665,7 @@ int launch_gemm_bf16_swtr(const uint16_t* A16, int64_t lda, int64_t strideA, con
     g.tiles_m = M / SW_BM;
     g.tiles_n = N / SW_BN;
 #ifdef W2V2_TUNING
-    g.trace = nullptr; g.abl = 0;
+    g.trace = nullptr; g.abl = 0; g.nt = 0;
 #endif
     static std::atomic<bool> attr_set{false};
     if (!attr_set) {
@@ -679,6 +698,7 @@ int launch_gemm_bf16_sw(const uint16_t* A16, int64_t lda, int64_t strideA, const
 #ifdef W2V2_TUNING
     g.trace = g_tune_trace;
     g.abl = tune_int("W2V2_PP_ABL", 0);
+    g.nt = tune_int("W2V2_SW_NT", SW_NT_DEFAULT);
     if (g.trace) {                                               // traced instances of the epilogues the model's large shapes use
         if (tune_int("W2V2_TRACE_EPI", 1) == 0) return launch_sw<true, 0>(g, grid, s);
         switch (ek) {

@@ -45,12 +45,30 @@ __device__ __forceinline__ uint32_t dropout_word(uint32_t key, uint32_t pair) { 
 // constant` pay the multiply once per base and an add per word (products distribute over the sum modulo 2^32)
 constexpr uint32_t DROPOUT_FIB = 0x9E3779B1u;
 __device__ __forceinline__ uint32_t dropout_word_premul(uint32_t key, uint32_t pair_times_fib) { return lowbias32(pair_times_fib ^ key); }
-__device__ __forceinline__ bool dropout_keep_lo(uint32_t w, uint32_t thr) { return (w & 0xFFFFu) >= thr; }
-__device__ __forceinline__ bool dropout_keep_hi(uint32_t w, uint32_t thr) { return (w >> 16) >= thr; }
+// The decision reads a 16-bit half as a SIGNED number: keep  <=>  int16(half) >= thr - 2^15  <=>  (half ^ 0x8000) >= thr  (round 4;
+// before: half >= thr -- the same probability, the top bit of the uniform half flipped).  In this form the decisions of BOTH halves of a
+// word come out of two packed 16-bit instructions (dropout_keep_mask_pk below), which is what the bf16 attention forward -- VALU-bound,
+// 60 % of it this hash and its bookkeeping -- needs.  Same function on the host: wav2vec2/variables.py::dropout_hash.
+__device__ __forceinline__ bool dropout_keep_lo(uint32_t w, uint32_t thr) { return ((w & 0xFFFFu) ^ 0x8000u) >= thr; }
+__device__ __forceinline__ bool dropout_keep_hi(uint32_t w, uint32_t thr) { return ((w >> 16) ^ 0x8000u) >= thr; }
 // general form (one hash per call): key and threshold hoisted by the caller, 32-bit index
 __device__ __forceinline__ bool dropout_keep32(uint32_t key, uint32_t idx, uint32_t thr) {
     const uint32_t w = dropout_word(key, idx >> 1);
-    return ((idx & 1u) ? (w >> 16) : (w & 0xFFFFu)) >= thr;
+    return (((idx & 1u) ? (w >> 16) : (w & 0xFFFFu)) ^ 0x8000u) >= thr;
+}
+// Both decisions of a word at once, as a mask: 0xFFFF in the half whose element is KEPT, 0 in the other.  thr1s_pk = dropout_thr1s_pk(thr)
+// holds int16(thr - 2^15 - 1) in both halves (thr >= 1): keep  <=>  thr - 2^15 - 1 - int16(half) < 0, a saturating packed subtract
+// (v_pk_sub_i16 clamp: the difference overflows 16 bits) and a packed arithmetic shift (v_pk_ashrrev_i16).  The mask has the layout
+// of a packed bf16 pair (even element low, odd element high): P pairs are masked AFTER v_cvt_pk_bf16_f32 with one AND.
+typedef short w2v2_short2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t dropout_thr1s_pk(uint32_t thr) {
+    const uint32_t t = (thr - 32769u) & 0xFFFFu;
+    return t | (t << 16);
+}
+__device__ __forceinline__ uint32_t dropout_keep_mask_pk(uint32_t w, uint32_t thr1s_pk) {
+    w2v2_short2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(w2v2_short2, thr1s_pk), __builtin_bit_cast(w2v2_short2, w));
+    d = d >> 15;
+    return __builtin_bit_cast(uint32_t, d);
 }
 // row stride of the attention-probability index space: T rounded up to even
 __device__ __forceinline__ uint32_t attention_drop_stride(int T) { return (uint32_t)(T + (T & 1)); }

@@ -270,9 +270,11 @@ def dropout_hash(seed, stream, n, start=0):
 
 
 def dropout_keep(seed, stream, n, p):
-    """Boolean keep mask: element kept iff its 16-bit hash value >= floor(p * 2^16) (then scaled by 1 / (1 - p))."""
+    """Boolean keep mask: element kept iff its 16-bit hash value, read as a signed number, >= floor(p * 2^16) - 2^15 -- i.e.
+    (value ^ 0x8000) >= floor(p * 2^16) -- then scaled by 1 / (1 - p).  (csrc/train.h: the signed form lets the device take both
+    decisions of a hash word with two packed 16-bit instructions.)"""
     thr = np.uint32(min(int(float(np.float32(p)) * 65536.0), 0xFFFF))
-    return dropout_hash(seed, stream, n) >= thr
+    return (dropout_hash(seed, stream, n) ^ np.uint32(0x8000)) >= thr
 
 
 def attention_keep(seed, stream, rows, T, p):
