@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
             for (int r = 0; r < 16; ++r) {
                 const int ql = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const float pv = s[r];
-                float g = dp[r], pd = pv * inv;
+                float g = dp[r], pd = pv;             // (Pd's factor 1 / (1 - p) multiplies dV once, at the end -- as the forward does with O)
                 if (BITS) {             // one arithmetic shift turns this lane's bit of the row's keep word into a mask for both values
                     const uint32_t km = (uint32_t)((int32_t)(Ws[ql] << kb_shift) >> 31);
                     g = __uint_as_float(__float_as_uint(g) & km);
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
             for (int g = 0; g < 4; ++g) {
                 // S was the UNSCALED score, so dS is the gradient of the scaled one: dK = scale * dS^T Q
                 const f32x4 kv = f32x4{dk[d][4 * g] * SCALE, dk[d][4 * g + 1] * SCALE, dk[d][4 * g + 2] * SCALE, dk[d][4 * g + 3] * SCALE};
-                const f32x4 vv = f32x4{dvv[d][4 * g], dvv[d][4 * g + 1], dvv[d][4 * g + 2], dvv[d][4 * g + 3]};
+                const f32x4 vv = f32x4{dvv[d][4 * g] * inv, dvv[d][4 * g + 1] * inv, dvv[d][4 * g + 2] * inv, dvv[d][4 * g + 3] * inv};
                 if (a.dqkv) {
                     *reinterpret_cast<f32x4*>(a.dqkv + k0 + 32 * d + 8 * g) = kv;
                     *reinterpret_cast<f32x4*>(a.dqkv + k0 + a.H + 32 * d + 8 * g) = vv;
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
     if (a.colpart) {
         float* cp = a.colpart + ((int64_t)b * a.nqb + kb) * ld + head * DH;
         block_colsum(dk, kok, SCALE, reinterpret_cast<float*>(smem_a16), tid, cp + a.H);
-        block_colsum(dvv, kok, 1.0f, reinterpret_cast<float*>(smem_a16), tid, cp + 2 * a.H);
+        block_colsum(dvv, kok, inv, reinterpret_cast<float*>(smem_a16), tid, cp + 2 * a.H);
     }
 }
 
