@@ -501,31 +501,12 @@ int launch_gemm_ex(Profiler* prof, const float* A, int64_t lda, int64_t strideA,
                 t.C = g.C + main_rows * ldc;
                 t.residual = g.residual ? g.residual + main_rows * ldc : nullptr;
                 t.M = M - (int)main_rows;
-                // Long K (the FFN down-projection, K = 3072): the 64 x 64 tiles of the leftover rows run one 32 x 32 accumulator per wave,
-                // two waves per SIMD, MFMA pipe 47 % busy (profiles/r03_gemm_f32_pmc.md: 166 us for an eighth of the rows of a 930-us
-                // GEMM).  Round 4: the SAME 128 x 128 kernel over those rows with K split in four -- r x 4 = 512 blocks, the full
-                // occupancy of the main launch, 24 k-steps each -- into four slabs that splitk_reduce_kernel folds with the
-                // epilogue (bias -> act -> + residual).  The leftover rows then sum their K products in another order than the
-                // rows of the main launch (four partial sums of 768 products, added in slab order): fp32 rounding noise (1e-6
-                // relative) between row positions in the batch, deterministic from run to run.  Short K (768: 6 k-steps per slab)
-                // does not pay for the fold and keeps the 64 x 64 tiles.
-                const int ts = tune_int("W2V2_GEMM_TAIL_SPLITK", 4);
-                if (ts > 1 && K >= 1536 && K % (ts * BK) == 0 && r * ts <= S && (ldc % 4) == 0 && N % 4 == 0 &&
-                    ((reinterpret_cast<uintptr_t>(t.C) | reinterpret_cast<uintptr_t>(t.residual) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0) {
-                    void* raw = nullptr;
-                    if (int e = stream_scratch(SCRATCH_SPLITK, s, (size_t)ts * t.M * N * sizeof(float), &raw)) return e;
-                    float* ws = reinterpret_cast<float*>(raw);
-                    GemmArgs p = t;
-                    p.C = ws; p.bias = nullptr; p.residual = nullptr; p.act = 0;
-                    p.K = K / ts; p.strideA = K / ts; p.strideB = (int64_t)(K / ts) * ldb; p.ldc = N; p.strideC = (int64_t)t.M * N;
-                    if (int e = launch_dma<2, 4, 2>(p, ts, s)) return e;
-                    const int64_t n4 = (int64_t)t.M * N / 4;
-                    int64_t blocks = (n4 + 255) / 256;
-                    blocks = blocks > 2048 ? 2048 : blocks;
-                    W2V2_LAUNCH(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ws, t.C, bias, t.residual, t.M, N, ldc, ts, act);
-                    W2V2_HIP_CHECK(hipGetLastError());
-                    return W2V2_OK;
-                }
+                // (Round 4 measured the alternative the round-3 review asked for -- the leftover rows of the K = 3072 members on the 128 x 128
+                //  kernel, K split four ways into slabs folded by splitk_reduce_kernel: 512 blocks at full occupancy, 24 k-steps each.
+                //  Forward 62.38 / 62.44 ms against 62.32 / 62.47 with the 64 x 64 tiles, arms interleaved on one box, two-way split
+                //  62.8-62.9 (profiles/r04_ab_gemm_tail_splitk.txt): a quarter-length K loop pays prologue + epilogue + the fold of 25 MB
+                //  of slabs, which is what the small tiles lose to their single accumulator per wave.  Not kept: it also gave up the
+                //  bit-for-bit independence of a row from its position in the batch.)
                 return launch_dma<2, 2, 2, 32, 64, 64>(t, 1, s);
             }
         }

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "train.h"
 
 namespace w2v2 {
 namespace {
@@ -112,7 +113,110 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict
     }
 }
 
+
+// t1 = dropout(a) + res;  y = LayerNorm(t1)  in ONE pass (training forward, encoder.py:116-119 / 122-124: "x + drop(attn)" followed by
+// the layer's next LayerNorm).  Round 4: as two kernels the row was written by the dropout pass and read again by the LayerNorm
+// (414 MB of traffic per layer at B = 32; now 339).  Same element arithmetic in the same order as dropout_fwd_kernel (keep ? a / (1 - p)
+// : 0, then + res) and layer_norm_kernel, so the results are bit-identical to the two-kernel form.  C % 4 == 0, 16-byte aligned rows.
+using ln_f32x4 = __attribute__((ext_vector_type(4))) float;
+template <int NV>
+__global__ __launch_bounds__(256) void layer_norm_drop_kernel(const float* __restrict__ a, const float* __restrict__ res, float* __restrict__ t1,
+                                                              float* __restrict__ y, uint16_t* __restrict__ y16, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int64_t rows, int C, float eps, float p, uint64_t seed,
+                                                              uint32_t stream) {
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float inv = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    const uint32_t key = dropout_key(seed, stream), thr = dropout_threshold(p);
+    const ln_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    ln_f32x4 gv[NV], bv[NV], va[NV], vr[NV], v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        gv[i] = c < C ? *reinterpret_cast<const ln_f32x4*>(gamma + c) : zero;
+        bv[i] = c < C ? *reinterpret_cast<const ln_f32x4*>(beta + c) : zero;
+        va[i] = c < C ? *reinterpret_cast<const ln_f32x4*>(a + row * C + c) : zero;
+        vr[i] = c < C ? *reinterpret_cast<const ln_f32x4*>(res + row * C + c) : zero;
+    }
+    while (true) {
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            ln_f32x4 e = va[i];
+            if (p > 0.f && c < C) {
+                const uint32_t pair = (uint32_t)((uint64_t)row * (uint64_t)C + (uint64_t)c) >> 1;      // (index mod 2^32) >> 1, as dropout_fwd_kernel
+                const uint32_t w0 = dropout_word(key, pair), w1 = dropout_word(key, pair + 1u);
+                e[0] = dropout_keep_lo(w0, thr) ? e[0] * inv : 0.0f;
+                e[1] = dropout_keep_hi(w0, thr) ? e[1] * inv : 0.0f;
+                e[2] = dropout_keep_lo(w1, thr) ? e[2] * inv : 0.0f;
+                e[3] = dropout_keep_hi(w1, thr) ? e[3] * inv : 0.0f;
+            }
+            v[i] = e + vr[i];
+            if (c < C) *reinterpret_cast<ln_f32x4*>(t1 + row * C + c) = v[i];
+            sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+        // the next row's loads go out now, into the registers just consumed: they are in flight under the two reductions and the stores
+        const int64_t next = row + stride;
+        const bool more = next < rows;
+        const int64_t nrow = more ? next : row;          // (unconditional: the last trip re-reads its own row)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            va[i] = c < C ? *reinterpret_cast<const ln_f32x4*>(a + nrow * C + c) : zero;
+            vr[i] = c < C ? *reinterpret_cast<const ln_f32x4*>(res + nrow * C + c) : zero;
+        }
+        const float mean = wave_sum(sum) / (float)C;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            const ln_f32x4 d = c < C ? v[i] - mean : zero;
+            v[i] = d;
+            sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)C + eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c >= C) continue;
+            ln_f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = v[i][k] * rstd * gv[i][k] + bv[i][k];
+            if (y16) *reinterpret_cast<uint2*>(y16 + row * C + c) = make_uint2(pack_bf16_rne(o[0], o[1]), pack_bf16_rne(o[2], o[3]));
+            if (y) *reinterpret_cast<ln_f32x4*>(y + row * C + c) = o;
+        }
+        if (!more) break;
+        row = next;
+    }
+}
+
 }  // namespace
+
+// (the index enters the dropout hash modulo 2^32, exactly as in dropout_fwd_kernel; callers keep rows * C below 2^32 or accept the
+//  wrap, as there)
+int launch_layer_norm_drop(Profiler* prof, const float* a, const float* res, float* t1, float* y, uint16_t* y16, const float* gamma,
+                           const float* beta, int64_t rows, int C, float eps, float p, uint64_t seed, uint32_t stream, hipStream_t s) {
+    W2V2_REQUIRE(a && res && t1 && (y || y16) && gamma && beta, "layer_norm_drop: null operand");
+    W2V2_REQUIRE(rows > 0 && C > 0 && C <= 2048 && (C & 3) == 0 && p >= 0.f && p < 1.f, "layer_norm_drop: rows=%lld C=%d p=%f unsupported", (long long)rows, C, p);
+    W2V2_REQUIRE(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(t1) | reinterpret_cast<uintptr_t>(y) |
+                   reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0 && (reinterpret_cast<uintptr_t>(y16) & 7) == 0,
+                 "layer_norm_drop: unaligned operand");
+    const int64_t want = (rows + 3) / 4;
+    const int cap = tune_int("W2V2_LN_BLOCKS", 256 * 4);
+    dim3 grid((unsigned)(want < cap ? want : cap)), block(256);
+    ProfScope ps(prof, FAM_LAYERNORM, 8.0 * rows * C, (12.0 + (y ? 4.0 : 0.0) + (y16 ? 2.0 : 0.0)) * rows * C, s);
+    // (two instances only: hipcc 7.2 crashes in its machine-copy-propagation pass on the <2> instance of this kernel, and the encoder widths
+    //  this pass serves are 768 / 1024; narrower rows -- the tiny test configurations -- leave the upper lanes of the <4> instance idle)
+    if (C <= 1024)
+        W2V2_LAUNCH(layer_norm_drop_kernel<4>, grid, block, 0, s, a, res, t1, y, y16, gamma, beta, rows, C, eps, p, seed, stream);
+    else
+        W2V2_LAUNCH(layer_norm_drop_kernel<8>, grid, block, 0, s, a, res, t1, y, y16, gamma, beta, rows, C, eps, p, seed, stream);
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
 
 int launch_layer_norm(Profiler* prof, const float* x, float* y, const float* gamma,
                       const float* beta, int64_t rows, int C, float eps, int act, hipStream_t s) {

@@ -148,6 +148,10 @@ int launch_dropout_bwd_x(const float* u, const float* dy, float* dx, uint16_t* d
                          float p, uint64_t seed, uint32_t stream_id, hipStream_t s, const EwBf16& in = EwBf16{});
 int launch_dropout_bwd_colsum(const float* u, const float* dy, float* dx, uint16_t* dx16, float* colsum, int64_t rows, int cols,
                               int act, float p, uint64_t seed, uint32_t stream_id, float* ws, hipStream_t s, const EwBf16& in = EwBf16{});
+// t1 = dropout(a) + res and y (/ y16) = LayerNorm(t1) in one pass (layernorm.hip); bit-identical to launch_dropout_fwd + launch_layer_norm_x
+int launch_layer_norm_drop(Profiler* prof, const float* a, const float* res, float* t1, float* y, uint16_t* y16 /* optional bf16 shadow */,
+                           const float* gamma, const float* beta, int64_t rows, int C, float eps, float p, uint64_t seed, uint32_t stream,
+                           hipStream_t s);
 int launch_transpose(const float* x, float* y, int rows, int cols, int nbatch, hipStream_t s);
 int64_t colsum_ws_floats(int64_t rows, int cols);
 int64_t dropout_bwd_colsum_ws_floats(int64_t rows, int cols);      // scratch of launch_dropout_bwd_colsum

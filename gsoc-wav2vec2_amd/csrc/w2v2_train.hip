@@ -660,10 +660,17 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
         if (int e = gemm(ctx16_only ? nullptr : l.ctx, attn16 ? l.ctx16 : nullptr, H, 0, m->P(b + "/attention/out_proj/kernel"), H, m->t0, nullptr, H, 0,
                          m->P(b + "/attention/out_proj/bias"), nullptr, (int)BT, H, H, 1, 0))
             return e;
-        if (int e = launch_dropout_fwd(m->t0, x, l.t1, BT * H, 0, p, seed, layer_stream(i, 1), s)) return e;
         // postnorm: t2 = LN1(t1) feeds the FFN and is its residual; prenorm: t2 = LN2(t1) feeds the FFN, t1 is the residual
         const char* ln_a = prenorm ? "/final_layer_norm" : "/layer_norm";
-        if (int e = launch_layer_norm_x(pf, l.t1, l.t2, m->P(b + ln_a + "/gamma"), m->P(b + ln_a + "/beta"), BT, H, eps, 0, S16(l.t2_16), s)) return e;
+        // (round 4: dropout + residual + LayerNorm as one pass over the row -- t1 is written once and not read back)
+        if (H % 4 == 0 && tune_int("W2V2_LN_DROP", 1) != 0) {
+            if (int e = launch_layer_norm_drop(pf, m->t0, x, l.t1, l.t2, S16(l.t2_16), m->P(b + ln_a + "/gamma"), m->P(b + ln_a + "/beta"), BT, H, eps, p,
+                                               seed, layer_stream(i, 1), s))
+                return e;
+        } else {
+            if (int e = launch_dropout_fwd(m->t0, x, l.t1, BT * H, 0, p, seed, layer_stream(i, 1), s)) return e;
+            if (int e = launch_layer_norm_x(pf, l.t1, l.t2, m->P(b + ln_a + "/gamma"), m->P(b + ln_a + "/beta"), BT, H, eps, 0, S16(l.t2_16), s)) return e;
+        }
         const float* ffn_res = prenorm ? l.t1 : l.t2;
         float* ffn_out = prenorm ? m->hs[i + 1] : l.t3;
         if (l.keep != 0.f) {
@@ -1293,6 +1300,10 @@ int w2v2_op_attention_bwd(const float* qkv, const int32_t* frame_len, const floa
     AttnTrain tr{p, seed, stream_id, const_cast<float*>(lse)};
     return launch_attention_bwd(nullptr, qkv, frame_len, ctx, dctx, dqkv, dvec_ws, B, T, H, heads, tr,
                                 reinterpret_cast<hipStream_t>(stream));
+}
+int w2v2_op_layer_norm_dropout(const float* x, const float* residual, float* t1, float* y, uint16_t* y16, const float* gamma, const float* beta,
+                               int64_t rows, int32_t C, float eps, float p, uint64_t seed, uint32_t stream_id, void* stream) {
+    return launch_layer_norm_drop(nullptr, x, residual, t1, y, y16, gamma, beta, rows, C, eps, p, seed, stream_id, reinterpret_cast<hipStream_t>(stream));
 }
 int w2v2_op_dropout(const float* x, const float* residual, float* y, int64_t n, int32_t act, float p,
                     uint64_t seed, uint32_t stream_id, void* stream) {

@@ -80,6 +80,7 @@ PROTOTYPES = {
     "w2v2_op_attention_train": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, C.c_float, C.c_uint64, C.c_uint32, _P]),
     "w2v2_op_attention_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, C.c_float, C.c_uint64, C.c_uint32, _P]),
     "w2v2_op_dropout": (C.c_int, [_P, _P, _P, _I64, _I32, C.c_float, C.c_uint64, C.c_uint32, _P]),
+    "w2v2_op_layer_norm_dropout": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, C.c_float, C.c_float, C.c_uint64, C.c_uint32, _P]),
     "w2v2_activation_info": (C.c_int, [_P, C.c_char_p, C.POINTER(_I64)]),
     "w2v2_copy_activation": (C.c_int, [_P, C.c_char_p, _P, _I64, _P]),
     "w2v2_profile_enable": (C.c_int, [_P, C.c_int]),

@@ -405,10 +405,17 @@ int w2v2_op_attention_bwd(const float* qkv_dev, const int32_t* frame_len_dev, co
                           int32_t B, int32_t T, int32_t H, int32_t num_heads, float dropout_p,
                           uint64_t seed, uint32_t stream_id, void* stream);
 
-/* y = dropout(act(x)) [+ residual]: keep iff hash16(seed, stream_id, index) >= floor(p 2^16), kept values / (1 - p)
- * (csrc/train.h, wav2vec2/variables.py::dropout_keep: the same integer function). */
+/* y = dropout(act(x)) [+ residual]: keep iff (hash16(seed, stream_id, index) ^ 0x8000) >= floor(p 2^16) -- the 16-bit value read as
+ * a signed number --, kept values / (1 - p)  (csrc/train.h, wav2vec2/variables.py::dropout_keep: the same integer function). */
 int w2v2_op_dropout(const float* x_dev, const float* residual_dev, float* y_dev, int64_t n, int32_t act,
                     float p, uint64_t seed, uint32_t stream_id, void* stream);
+
+/* t1 = dropout(x) + residual  and  y = LayerNorm(t1) over the last axis (C % 4 == 0), one pass over the rows: the training forward's
+ * "x + drop(attn(x))" followed by the layer's next LayerNorm (encoder.py:116-124).  Bit-identical to w2v2_op_dropout (act 0) followed by
+ * w2v2_op_layer_norm (act 0) on the same operands; y16_dev (optional) receives the nearest-even bf16 copy of y. */
+int w2v2_op_layer_norm_dropout(const float* x_dev, const float* residual_dev, float* t1_dev, float* y_dev, uint16_t* y16_dev,
+                               const float* gamma_dev, const float* beta_dev, int64_t rows, int32_t C, float eps, float p, uint64_t seed,
+                               uint32_t stream_id, void* stream);
 
 #ifdef __cplusplus
 }

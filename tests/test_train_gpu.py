@@ -60,6 +60,34 @@ def test_dropout_hash_matches_host(env, n, p, stream):
         assert abs(keep.mean() - (1 - p)) < 0.02
 
 
+@pytest.mark.parametrize("rows,Cn,p", [(37, 768, 0.1), (3001, 1024, 0.1), (9, 64, 0.5), (130, 768, 0.0), (5000, 1280, 0.1)])
+def test_layer_norm_dropout_fused_equals_the_two_kernels(env, rows, Cn, p):
+    """t1 = dropout(x) + residual, y = LayerNorm(t1) in one pass (layernorm.hip::layer_norm_drop_kernel, the training forward's
+    encoder.py:116-124) against (a) the two separate operators, bit for bit -- fp32 y, the bf16 copy and t1 -- and (b) the host's
+    keep mask + a float64 LayerNorm."""
+    lib, torch, dev = env
+    x, res = rnd("ldx", (rows, Cn), 2.0), rnd("ldr", (rows, Cn))
+    g, b = 1 + rnd("ldg", (Cn,), 0.3), rnd("ldb", (Cn,), 0.2)
+    seed, stream = C.c_uint64(0xC0FFEE1234), 21
+    xd, rd, gd, bd = (dev_t(torch, dev, a) for a in (x, res, g, b))
+    t1a = torch.empty((rows, Cn), device=dev)
+    N.check(lib.w2v2_op_dropout(N.ptr(xd), N.ptr(rd), N.ptr(t1a), rows * Cn, 0, p, seed, stream, N.current_stream()))
+    ya = torch.empty((rows, Cn), device=dev)
+    N.check(lib.w2v2_op_layer_norm(N.ptr(t1a), N.ptr(ya), N.ptr(gd), N.ptr(bd), rows, Cn, 1e-5, 0, N.current_stream()))
+    t1b, yb = torch.empty((rows, Cn), device=dev), torch.empty((rows, Cn), device=dev)
+    y16 = torch.empty((rows, Cn), device=dev, dtype=torch.bfloat16)
+    N.check(lib.w2v2_op_layer_norm_dropout(N.ptr(xd), N.ptr(rd), N.ptr(t1b), N.ptr(yb), N.ptr(y16), N.ptr(gd), N.ptr(bd), rows, Cn, 1e-5, p,
+                                           seed, stream, N.current_stream()))
+    assert torch.equal(t1a, t1b) and torch.equal(ya, yb)
+    assert torch.equal(y16, yb.to(torch.bfloat16))                       # nearest-even, as torch rounds
+    keep = V.dropout_keep(0xC0FFEE1234, stream, rows * Cn, p).reshape(rows, Cn)
+    t1 = np.where(keep, x.astype(np.float64) / (1 - np.float64(np.float32(p))), 0) + res
+    mu, var = t1.mean(-1, keepdims=True), t1.var(-1, keepdims=True)
+    ref = (t1 - mu) / np.sqrt(var + 1e-5) * g + b
+    assert H.max_err(t1b.cpu().numpy(), t1) < 2e-6 * max(1.0, np.abs(t1).max())
+    assert H.max_err(yb.cpu().numpy(), ref) < 2e-5
+
+
 @pytest.mark.parametrize("rows,Cn", [(37, 512), (130, 768), (9, 64), (5, 50), (3000, 768)])
 def test_layer_norm_backward(env, rows, Cn):
     lib, torch, dev = env
