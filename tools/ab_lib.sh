@@ -1,0 +1,17 @@
+#!/bin/bash
+# End-to-end A/B of two builds of the library on one box, arms interleaved:  tools/ab_lib.sh <tag> <libA.so> <libB.so> <reps> <bench args ...>
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O
+tag=$1; A=$2; B=$3; reps=$4; shift 4
+out=$O/abl_$tag.txt; echo "# A = $A, B = $B, bench.py $*" > $out
+for rep in $(seq 1 $reps); do
+  for arm in A B; do
+    lib=$A; [ $arm = B ] && lib=$B
+    line=$(W2V2_NATIVE_LIB=$R/$lib python $R/bench.py "$@" --no-cpu-baseline --no-side --no-alt 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); f=d.get('families',{})
+print(d['ms_per_step'], d['roofline']['achieved'], ' '.join(f'{k}={v[\"ms_per_step\"]}' for k,v in f.items()))")
+    echo "$arm rep $rep: $line" >> $out
+  done
+done
+cat $out
