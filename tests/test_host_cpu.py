@@ -535,3 +535,31 @@ def test_bench_cpu_baseline_topology_helpers(tmp_path, monkeypatch):
     from oracle import w2v2_oracle as O
     (tmp_path / "cpu.max").write_text("200000 100000\n")
     assert O._usable_cpus() == min(2, len(allowed))
+
+
+def test_counted_wait_kernels_have_no_scratch():
+    """Build gate for the kernels whose correctness rests on hand-counted `s_waitcnt vmcnt(N)` (gemm_bf16_sw.hip: the LDS-DMA ring and the
+    fp32 epilogue's early residual loads): if the register allocator spilled an asm-loaded destination, the compiler would store it
+    before it has landed and the counts would no longer describe what is in flight.  hipcc cross-compiles for gfx950 on the CPU box, so the
+    gate runs in the CPU suite: every instance of that file must report ScratchSize 0.  (Round-3 advisor finding; the GPU suite's
+    bit-for-bit variant tests are the other half.)"""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "gsoc-wav2vec2_amd", "csrc", "gemm_bf16_sw.hip")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-c", src, "-o", os.devnull,
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    names, scratch = [], []
+    for line in r.stderr.splitlines():
+        if "Function Name:" in line:
+            names.append(line.split("Function Name:")[1].split("[")[0].strip())
+        elif "ScratchSize [bytes/lane]:" in line:
+            scratch.append(int(line.split("ScratchSize [bytes/lane]:")[1].split("[")[0].strip()))
+    assert names and len(names) == len(scratch)
+    bad = [(n, s) for n, s in zip(names, scratch) if "gemm_bf16_sw_kernel" in n and s != 0]
+    assert sum("gemm_bf16_sw_kernel" in n for n in names) >= 7, names
+    assert not bad, bad
