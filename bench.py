@@ -697,7 +697,19 @@ def main():
     local_dev = local_rank % torch.cuda.device_count() if args.backend != "nccl" else local_rank     # (gloo test: ranks may share a GPU)
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    D.init(backend=args.backend, device=dev)      # nccl = RCCL; no-op for a single un-launched process
+    # RCCL prints a version banner ("RCCL version : ...", five lines) on the process's stdout when its communicator is created: keep
+    # stdout for the ONE JSON line -- file descriptor 1 points at stderr while the group comes up (init is eager with device_id) and
+    # through a first barrier
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        D.init(backend=args.backend, device=dev)      # nccl = RCCL; no-op for a single un-launched process
+        D.barrier(sync_device=torch.cuda.synchronize)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
     comm = D.describe()                           # what the process group itself reports (echoed in the JSON line)
     ctx = {"torch": torch, "D": D, "W": wav2vec2, "dev": dev, "world": world, "rank": rank, "comm": comm}
 

@@ -526,6 +526,12 @@ int launch_gemm_ex(Profiler* prof, const float* A, int64_t lda, int64_t strideA,
         case 12: if (fast && g.N >= 256) return launch_dma<4, 4, 1, 32, 256, 256>(g, nbatch, s); return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
         case 13: if (fast && g.N >= 128) return launch_dma<4, 2, 1, 32, 256, 128>(g, nbatch, s); return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
         case 8: if (fast) return launch_dma<4, 4, 1>(g, nbatch, s); return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
+#ifdef W2V2_TUNING
+        // round-4 tile study (tools-only build): wider tiles at BK = 16, two blocks per CU -- 25 % less LDS-DMA per flop than 128 x 128 x 32
+        case 17: if (fast && g.N >= 256) return launch_dma<2, 4, 2, 16, 128, 256>(g, nbatch, s); return launch_dma<2, 4, 2>(g, nbatch, s);
+        case 18: if (fast && g.N >= 128) return launch_dma<4, 2, 2, 16, 256, 128>(g, nbatch, s); return launch_dma<2, 4, 2>(g, nbatch, s);
+        case 19: if (fast && g.N >= 256) return launch_dma<2, 4, 2, 32, 128, 256>(g, nbatch, s); return launch_dma<2, 4, 2>(g, nbatch, s);
+#endif
         default: return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
     }
 }
