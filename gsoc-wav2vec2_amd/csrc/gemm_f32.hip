@@ -511,6 +511,16 @@ int launch_gemm_ex(Profiler* prof, const float* A, int64_t lda, int64_t strideA,
             }
         }
     }
+    // Wide tiles for the well-filled shapes (round 4, profiles/r04_gemm_f32_tile_study.txt): 256 x 128 x 16, 8 waves of 64 x 64 (4 x 2), still
+    // two blocks per CU (48 KiB of LDS each, 118 VGPRs) -- 25 % less LDS-DMA per flop and a third fewer fragment reads per MFMA than
+    // 128 x 128 x 32, the same flops per barrier.  Measured per shape against the default: conv1 132.6 vs 130.4 TF, conv2 131.1 vs 130.5,
+    // q|k|v 129.3 vs 127.4, FFN up 126.5 vs 125.3; it LOSES where its tile count quantises (N = 768: 99-104 vs 115-121; conv3-6 with their
+    // 4-8 % row padding), so it takes only GEMMs with >= 3 full rounds of tiles and <= 2.5 % padded rows.  Every output element still sums
+    // its K products in ascending order two at a time: the same bits as the 128 x 128 kernel.
+    if (cfg == 7 && fast && tune_int("W2V2_GEMM_WIDE", 1) != 0 && N % 128 == 0) {
+        const int64_t tm256 = (M + 255) / 256, tiles256 = tm256 * (N / 128) * nbatch;
+        if (tiles256 >= 1536 && (tm256 * 256 - M) * 40 <= M) return launch_dma<4, 2, 2, 16, 256, 128>(g, nbatch, s);
+    }
     switch (cfg) {
         case 16: if (fast) return launch_dma<2, 2, 2, 32, 64, 64>(g, nbatch, s); return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
         case 14: if (fast) return launch_dma<2, 3, 2, 32, 128, 96>(g, nbatch, s); return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
