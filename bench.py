@@ -351,9 +351,9 @@ def measured_traffic(precision="fp32", mode="forward"):
                              f"the sources are now {want}: stale, not printed -- rerun tools/pmc_traffic.sh")
             return out
         if precision == "fp32":
-            hits = [v for k, v in js.items() if "gemm_f32" in k]
-            v = max(hits, key=lambda e: e.get("launches", 0))       # the 128x128 kernel, not the small-problem variant
-            out["bytes"] = round(v["fetch_corrected_bytes"] + v["write_bytes"])
+            hits = [v for k, v in js.items() if "gemm_f32" in k and v.get("launches")]
+            n = sum(v["launches"] for v in hits)                    # launch-weighted mean over the family's kernels (256x128, 128x128, 64x64 tail tiles)
+            out["bytes"] = round(sum(v["launches"] * (v["fetch_corrected_bytes"] + v["write_bytes"]) for v in hits) / n)
         else:
             v = js[mode]
             out["bytes"] = round(v["fetch_corrected_bytes_per_launch"] + v["write_bytes_per_launch"])
@@ -436,7 +436,8 @@ def add_clock(roof, clk):
 FAMILY_OF = {"fp32": "gemm_f32", "bf16": "gemm_bf16", "bf16x3": "gemm_split"}
 PEAK_OF = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16x3": round(PEAK_BF16_MFMA_TFLOPS / 6, 1)}
 KERNEL_OF = {
-    "fp32": "gemm_f32_dma_kernel (fp32 MFMA 32x32x2, LDS-DMA staged: conv1-6 implicit GEMM + all Dense layers)",
+    "fp32": "gemm_f32_dma_kernel (fp32 MFMA 32x32x2, LDS-DMA staged, 256x128x16 tiles for the well-filled shapes, 128x128x32 for the rest, 64x64 "
+            "for underfilled last rounds: conv1-6 implicit GEMM + all Dense layers)",
     "bf16": "gemm_bf16 family (bf16 MFMA 32x32x16, operands from bf16 shadows by LDS-DMA: gemm_bf16_sw_kernel 128x256 software-pipelined "
             "for the large shapes, gemm_bf16_kernel 128x128 for the rest, gemm_bf16_tr_kernel for weight gradients: conv1-6 + all Dense)",
     "bf16x3": "gemm_split_kernel (fp32 GEMM as 6 bf16 MFMA 32x32x16 products of exact 3-term operand splits; peak = bf16 dense peak / 6)",
