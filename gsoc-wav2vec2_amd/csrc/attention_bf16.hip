@@ -377,7 +377,10 @@ __device__ __forceinline__ void block_colsum(const f32x16 (&acc)[2], bool row_ok
 // ---- dQ: block = 4 waves x 32 queries; streams 64-key tiles of K and V ----
 template <bool BITS>       // BITS: the forward left its keep decisions in tr.keep_bits (p > 0)
 __global__ __launch_bounds__(256, 3) void attention_bf16_bwd_dq_kernel(Attn16BwdArgs a, AttnTrain tr) {
-    constexpr int STAGE = 2 * IMG;
+    // K image, V image [, one keep word per lane and wave: DMA'd with the tile, one tile ahead -- round 4; round 3 loaded the word from
+    // HBM at the top of the tile that uses it, and the wait-count pass's vmcnt(0) in front of the transposing reads made every tile
+    // wait for that load]
+    constexpr int STAGE = 2 * IMG + (BITS ? NW * 64 * 4 : 0);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_a16[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int work = xcd_work(blockIdx.x, a.nwork);
@@ -398,6 +401,9 @@ __global__ __launch_bounds__(256, 3) void attention_bf16_bwd_dq_kernel(Attn16Bwd
         unsigned char* S = smem_a16 + buf * STAGE;
         dma.issue(base + a.H, ld, tile * KT, a.T, S, wave);
         dma.issue(base + 2 * a.H, ld, tile * KT, a.T, S + IMG, wave);
+        if (BITS)           // this lane's keep word of the tile: 4 bytes per lane, lane-linear into the wave's 256-byte slot
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tr.keep_bits + keep_word(bh, tile, lh, a.nqb) + q0 + li),
+                                             (__attribute__((address_space(3))) void*)(S + 2 * IMG + wave * 256), 4, 0, 0);
     };
     issue(0, 0);
 
@@ -450,11 +456,11 @@ __global__ __launch_bounds__(256, 3) void attention_bf16_bwd_dq_kernel(Attn16Bwd
     for (int tile = 0; tile < ntiles; ++tile) {
         const int k0 = tile * KT, buf = tile & 1;
         issue(min(tile + 1, ntiles - 1), buf ^ 1);      // unconditional: see attention.hip (a branch here costs the DMA / compute overlap)
-        uint32_t bits = 0;
-        if (BITS) bits = tr.keep_bits[keep_word(bh, tile, lh, a.nqb) + q0 + li];     // (lands under the first MFMAs)
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char* Ks = smem_a16 + buf * STAGE;
         const unsigned char* Vs = Ks + IMG;
+        uint32_t bits = 0;
+        if (BITS) bits = reinterpret_cast<const uint32_t*>(Ks + 2 * IMG)[wave * 64 + lane];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             f32x16 s, dp;
@@ -741,7 +747,7 @@ int launch_attention_bwd_bf16(const float* qkv, const uint16_t* qkv16, const int
     W2V2_REQUIRE(dvec, "attention_bwd_bf16: null dvec");
     Attn16BwdArgs a{q16, frame_len, do16, dvec, ctx16, ctx16 ? nullptr : ctx, dqkv, dqkv16, colpart, B, T, H, heads, nqb, nqb * heads * B};
     const bool bits = tr.keep_bits && tr.p > 0.f;
-    size_t lds_q = 2 * 2 * IMG, lds_kv = 2 * (2 * IMG + 2 * KT * 4 + (bits ? NW * 2 * (KT + 4) * 4 : 0));
+    size_t lds_q = 2 * (2 * IMG + (bits ? NW * 64 * 4 : 0)), lds_kv = 2 * (2 * IMG + 2 * KT * 4 + (bits ? NW * 2 * (KT + 4) * 4 : 0));
     if (colpart) {
         if (lds_q < (size_t)COLSUM_LDS) lds_q = COLSUM_LDS;
         if (lds_kv < (size_t)COLSUM_LDS) lds_kv = COLSUM_LDS;
