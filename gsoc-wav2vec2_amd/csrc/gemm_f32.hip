@@ -517,9 +517,10 @@ int launch_gemm_ex(Profiler* prof, const float* A, int64_t lda, int64_t strideA,
     // q|k|v 129.3 vs 127.4, FFN up 126.5 vs 125.3; it LOSES where its tile count quantises (N = 768: 99-104 vs 115-121; conv3-6 with their
     // 4-8 % row padding), so it takes only GEMMs with >= 3 full rounds of tiles and <= 2.5 % padded rows.  Every output element still sums
     // its K products in ascending order two at a time: the same bits as the 128 x 128 kernel.
-    if (cfg == 7 && fast && tune_int("W2V2_GEMM_WIDE", 1) != 0 && N % 128 == 0) {
+    const int wide_min = tune_int("W2V2_GEMM_WIDE", 1536);      // fewest 256 x 128 tiles that take the wide kernel (0: never)
+    if (cfg == 7 && fast && wide_min > 0 && N % 128 == 0) {
         const int64_t tm256 = (M + 255) / 256, tiles256 = tm256 * (N / 128) * nbatch;
-        if (tiles256 >= 1536 && (tm256 * 256 - M) * 40 <= M) return launch_dma<4, 2, 2, 16, 256, 128>(g, nbatch, s);
+        if (tiles256 >= wide_min && (tm256 * 256 - M) * 40 <= M) return launch_dma<4, 2, 2, 16, 256, 128>(g, nbatch, s);
     }
     switch (cfg) {
         case 16: if (fast) return launch_dma<2, 2, 2, 32, 64, 64>(g, nbatch, s); return launch_cfg<128, 128, 2, 2, 2>(g, fast, nbatch, s);
