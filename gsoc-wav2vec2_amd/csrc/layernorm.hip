@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict
 // (414 MB of traffic per layer at B = 32; now 339).  Same element arithmetic in the same order as dropout_fwd_kernel (keep ? a / (1 - p)
 // : 0, then + res) and layer_norm_kernel, so the results are bit-identical to the two-kernel form.  C % 4 == 0, 16-byte aligned rows.
 using ln_f32x4 = __attribute__((ext_vector_type(4))) float;
-template <int NV>
+template <int NV, bool DROP>      // DROP = false: plain LayerNorm of `a` (res, t1, p unused) -- the same row loop, serving launch_layer_norm_x
 __global__ __launch_bounds__(256) void layer_norm_drop_kernel(const float* __restrict__ a, const float* __restrict__ res, float* __restrict__ t1,
                                                               float* __restrict__ y, uint16_t* __restrict__ y16, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, int64_t rows, int C, float eps, float p, uint64_t seed,
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void layer_norm_drop_kernel(const float* __res
         gv[i] = c < C ? *reinterpret_cast<const ln_f32x4*>(gamma + c) : zero;
         bv[i] = c < C ? *reinterpret_cast<const ln_f32x4*>(beta + c) : zero;
         va[i] = c < C ? *reinterpret_cast<const ln_f32x4*>(a + row * C + c) : zero;
-        vr[i] = c < C ? *reinterpret_cast<const ln_f32x4*>(res + row * C + c) : zero;
+        vr[i] = (DROP && c < C) ? *reinterpret_cast<const ln_f32x4*>(res + row * C + c) : zero;
     }
     while (true) {
         float sum = 0.f;
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void layer_norm_drop_kernel(const float* __res
         for (int i = 0; i < NV; ++i) {
             const int c = (i * 64 + lane) * 4;
             ln_f32x4 e = va[i];
-            if (p > 0.f && c < C) {
+            if (DROP && p > 0.f && c < C) {
                 const uint32_t pair = (uint32_t)((uint64_t)row * (uint64_t)C + (uint64_t)c) >> 1;      // (index mod 2^32) >> 1, as dropout_fwd_kernel
                 const uint32_t w0 = dropout_word(key, pair), w1 = dropout_word(key, pair + 1u);
                 e[0] = dropout_keep_lo(w0, thr) ? e[0] * inv : 0.0f;
@@ -154,8 +154,8 @@ __global__ __launch_bounds__(256) void layer_norm_drop_kernel(const float* __res
                 e[2] = dropout_keep_lo(w1, thr) ? e[2] * inv : 0.0f;
                 e[3] = dropout_keep_hi(w1, thr) ? e[3] * inv : 0.0f;
             }
-            v[i] = e + vr[i];
-            if (c < C) *reinterpret_cast<ln_f32x4*>(t1 + row * C + c) = v[i];
+            v[i] = DROP ? e + vr[i] : e;
+            if (DROP && c < C) *reinterpret_cast<ln_f32x4*>(t1 + row * C + c) = v[i];
             sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
         // the next row's loads go out now, into the registers just consumed: they are in flight under the two reductions and the stores
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void layer_norm_drop_kernel(const float* __res
         for (int i = 0; i < NV; ++i) {
             const int c = (i * 64 + lane) * 4;
             va[i] = c < C ? *reinterpret_cast<const ln_f32x4*>(a + nrow * C + c) : zero;
-            vr[i] = c < C ? *reinterpret_cast<const ln_f32x4*>(res + nrow * C + c) : zero;
+            if (DROP) vr[i] = c < C ? *reinterpret_cast<const ln_f32x4*>(res + nrow * C + c) : zero;
         }
         const float mean = wave_sum(sum) / (float)C;
         float sq = 0.f;
@@ -211,9 +211,9 @@ int launch_layer_norm_drop(Profiler* prof, const float* a, const float* res, flo
     // (two instances only: hipcc 7.2 crashes in its machine-copy-propagation pass on the <2> instance of this kernel, and the encoder widths
     //  this pass serves are 768 / 1024; narrower rows -- the tiny test configurations -- leave the upper lanes of the <4> instance idle)
     if (C <= 1024)
-        W2V2_LAUNCH(layer_norm_drop_kernel<4>, grid, block, 0, s, a, res, t1, y, y16, gamma, beta, rows, C, eps, p, seed, stream);
+        W2V2_LAUNCH((layer_norm_drop_kernel<4, true>), grid, block, 0, s, a, res, t1, y, y16, gamma, beta, rows, C, eps, p, seed, stream);
     else
-        W2V2_LAUNCH(layer_norm_drop_kernel<8>, grid, block, 0, s, a, res, t1, y, y16, gamma, beta, rows, C, eps, p, seed, stream);
+        W2V2_LAUNCH((layer_norm_drop_kernel<8, true>), grid, block, 0, s, a, res, t1, y, y16, gamma, beta, rows, C, eps, p, seed, stream);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -234,6 +234,19 @@ int launch_layer_norm_x(Profiler* prof, const float* x, float* y, const float* g
     if (cap < 0) cap = tune_int("W2V2_LN_BLOCKS", 256 * 4);      // 512 / 1024 / 2048 / 4096 blocks -> 1.14 / 1.06 / 1.10 / 1.26 ms for the 25 LayerNorms of a base forward
     dim3 grid((unsigned)(want < cap ? want : cap)), block(256);
     ProfScope ps(prof, FAM_LAYERNORM, 8.0 * rows * C, (4.0 + (y ? 4.0 : 0.0) + (y16 ? 2.0 : 0.0)) * rows * C, s);
+    // Round 4: plain rows (no activation, C % 4 == 0, C > 512, 16-byte aligned) take the row loop of the fused dropout kernel, whose next
+    // row is loaded into the registers just consumed: 6.2 TB/s measured there against 4.8 for layer_norm_kernel's copy-forward prefetch.
+    // Same element arithmetic in the same order: bit-identical.
+    if (tune_int("W2V2_LN_V2", 1) != 0 && act == 0 && (C & 3) == 0 && C > 512 &&
+        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(y16) & 7) == 0) {
+        if (C <= 1024)
+            W2V2_LAUNCH((layer_norm_drop_kernel<4, false>), grid, block, 0, s, x, nullptr, nullptr, y, y16, gamma, beta, rows, C, eps, 0.f, (uint64_t)0, 0u);
+        else
+            W2V2_LAUNCH((layer_norm_drop_kernel<8, false>), grid, block, 0, s, x, nullptr, nullptr, y, y16, gamma, beta, rows, C, eps, 0.f, (uint64_t)0, 0u);
+        W2V2_HIP_CHECK(hipGetLastError());
+        return W2V2_OK;
+    }
     if (C <= 256)
         W2V2_LAUNCH(layer_norm_kernel<1>, grid, block, 0, s, x, y, y16, gamma, beta, rows, C, eps, act);
     else if (C <= 512)
