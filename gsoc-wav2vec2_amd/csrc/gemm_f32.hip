@@ -507,15 +507,6 @@ int launch_gemm_ex(Profiler* prof, const float* A, int64_t lda, int64_t strideA,
                 //  62.8-62.9 (profiles/r04_ab_gemm_tail_splitk.txt): a quarter-length K loop pays prologue + epilogue + the fold of 25 MB
                 //  of slabs, which is what the small tiles lose to their single accumulator per wave.  Not kept: it also gave up the
                 //  bit-for-bit independence of a row from its position in the batch.)
-#ifdef W2V2_TUNING
-                // round-4 study: leftover-row tiles with TWO accumulators per wave (64 x 128 / 128 x 64, 4 waves) instead of one
-                switch (tune_int("W2V2_GEMM_TAILCFG", 0)) {
-                    case 1: if (N % 128 == 0) return launch_dma<2, 2, 2, 32, 64, 128>(t, 1, s); break;
-                    case 2: return launch_dma<2, 2, 2, 32, 128, 64>(t, 1, s);
-                    case 3: if (N % 128 == 0) return launch_dma<2, 2, 2, 16, 64, 128>(t, 1, s); break;
-                    default: break;
-                }
-#endif
                 return launch_dma<2, 2, 2, 32, 64, 64>(t, 1, s);
             }
         }
