@@ -746,6 +746,8 @@ def main():
                     ach, pk = gs["flops"] / (gs["ms"] * 1e-3) / 1e12, round(PEAK_BF16_MFMA_TFLOPS / 6, 1)
                     roof = {"kernel": "gemm_split_kernel", "bound": "mfma", "achieved": round(ach, 2), "peak": pk, "unit": "TFLOP/s (fp32-equivalent)",
                             "frac": round(ach / pk, 4), "launches": gs["launches"], "note": "peak = bf16 dense MFMA peak / 6 products"}
+                    # the clock this mode runs at (the bf16 matrix pipe draws more power than the fp32 one: the chip throttles)
+                    add_clock(roof, clock_under_load(ctx, lambda: model(x, attention_mask=amask), max(2000, int(400 * 1e3 * e3 / args.steps))))
         finally:
             model.set_precision("fp32")
         return {"precision": "bf16x3 (fp32 operands as exact 3 x bf16 sums, 6 bf16 MFMA products per fp32 product, fp32 accumulate)",
