@@ -661,7 +661,7 @@ int launch_attention_x(Profiler* prof, const float* qkv, const uint16_t* qkv16, 
     W2V2_REQUIRE(qkv && ctx, "attention: null operand");
     AttnArgs a{qkv, frame_len, ctx, B, T, H, heads, 1.0f / sqrtf((float)dh)};
     W2V2_REQUIRE(!ctx16, "attention: a bf16 shadow output needs the bf16 kernel (precision 1, head size 64)");
-    if (gemm_get_precision() == 2 && attention_split_supported(dh) && H % 4 == 0 &&
+    if (gemm_get_precision() == 2 && tune_int("W2V2_SPLIT_ATTN", 1) != 0 && attention_split_supported(dh) && H % 4 == 0 &&
         ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(ctx)) & 15) == 0)
         return launch_attention_split(qkv, frame_len, ctx, B, T, H, heads, s);     // fp32-level results, bf16 matrix cores
     switch (dh) {

@@ -384,6 +384,7 @@ int w2v2_ensure_shadows(w2v2_model* m, int B, int T, hipStream_t s) {
 
 bool w2v2_use_split_gemm(const w2v2_model* m, const float* A, int64_t lda, int64_t strideA, int64_t ldb, int M, int N, int K, int nbatch) {
     if (m->precision != W2V2_PRECISION_BF16X3 || ldb != N || N % 256 != 0) return false;
+    if (tune_int("W2V2_SPLIT_GEMM", 1) == 0) return false;      // (tools-only: tools/nll_drift_probe.py separates the GEMMs from the attention)
     // (below ~half a wave of 128 x 256 tiles the fp32 path's small tiles and split-K serve a single utterance better)
     const int64_t split_tiles = (int64_t)((M + 127) / 128) * (N / 256) * nbatch;
     return split_tiles >= 128 && gemm_split_supported(A, lda, strideA, M, N, K);
