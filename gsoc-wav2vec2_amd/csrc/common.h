@@ -137,6 +137,19 @@ int launch_gemm_split(Profiler* prof, const float* A, int64_t lda, int64_t strid
                       int64_t strideC, const float* bias, const float* residual, int M, int N, int K, int nbatch, int act,
                       hipStream_t s);
 
+// ... and with BOTH operands pre-split (gemm_split_sw.hip): the activation as three row-major bf16 planes `planeA` elements apart
+// (written by its producer; launch_split_planes is the unfused form), the weight as that kernel's LDS images (launch_split_weight_sw,
+// 3 N K elements); the result as fp32 (C, + residual) or as the three planes of (acc + bias -> act) for the next GEMM (C16, planeC).
+bool gemm_split_sw_ok(const uint16_t* A16, int64_t planeA, int64_t lda, int64_t strideA, int M, int N, int K);
+int launch_split_weight_sw(const float* w, uint16_t* img, int K, int N, hipStream_t s);
+int launch_split_planes(const float* x, uint16_t* planes, int64_t plane, int64_t n, hipStream_t s);
+int launch_gemm_split_sw(Profiler* prof, const uint16_t* A16, int64_t planeA, int64_t lda, int64_t strideA, const uint16_t* Bimg, float* C,
+                         uint16_t* C16, int64_t planeC, int64_t ldc, int64_t strideC, const float* bias, const float* residual, int M, int N,
+                         int K, int nbatch, int act, hipStream_t s);
+
+// selftest.hip: counts the float patterns on which erf_select / tanh_select differ from the device library's erff / tanhf
+int launch_check_select_forms(unsigned long long* mismatches_dev /* [2] */, hipStream_t s);
+
 // Optional bf16 shadows of the operands (precision mode 1).  A shadow holds nearest-even bf16 roundings of the fp32
 // tensor -- exactly what the kernel would round to itself -- so using one changes speed, never results.
 //   A16: same shape / strides (in elements) as A;   B16: B TRANSPOSED, [N][K] with row stride ldb16 (0 = K);
@@ -279,6 +292,47 @@ __device__ __forceinline__ float gelu_erf(float x) {
     // tf.nn.gelu(approximate=False): 0.5 x (1 + erf(x / sqrt(2)))
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
+// The device library's erff (ROCm 7.2 ocml, __ocml_erf_f32) without its branch: the |x| < 1 polynomial and the 1 - exp(-q(|x|))
+// form are BOTH evaluated -- the same operations in the same order as the library's two arms -- and the result selected, so every
+// input gives the library's bits (tools/erf_exhaustive.hip compares all 2^32 patterns on the GPU; tests/test_ops_gpu.py runs it).
+// In a wave of 64 GELU inputs both arms execute anyway; what the select form removes is the control flow, which around 128
+// accumulator registers makes the allocator spill (gemm_split_sw.hip: 570 bytes of scratch per lane with the branch, 0 without).
+__device__ __forceinline__ float erf_select(float x) {
+    const float ax = fabsf(x), t = x * x;
+    float p = __builtin_fmaf(t, -0x1.268bc2p-11f, 0x1.420828p-8f);
+    p = __builtin_fmaf(t, p, -0x1.b5937p-6f);
+    p = __builtin_fmaf(t, p, 0x1.ce077cp-4f);
+    p = __builtin_fmaf(t, p, -0x1.81266p-2f);
+    p = __builtin_fmaf(t, p, 0x1.06ebap-3f);
+    const float small = __builtin_fmaf(ax, p, ax);
+    float q = __builtin_fmaf(ax, 0x1.1d3156p-16f, -0x1.8d129p-12f);
+    q = __builtin_fmaf(ax, q, 0x1.f9a6d2p-9f);
+    q = __builtin_fmaf(ax, q, -0x1.8c3164p-6f);
+    q = __builtin_fmaf(ax, q, 0x1.b4e9c8p-4f);
+    q = __builtin_fmaf(ax, q, 0x1.4515fap-1f);
+    q = __builtin_fmaf(ax, q, 0x1.078e5p-3f);
+    q = __builtin_fmaf(ax, q, ax);
+    const float large = 1.0f - expf(-q);
+    return copysignf(ax < 1.0f ? small : large, x);
+}
+// ... and the library's tanhf the same way (|x| < 0.625: odd polynomial; else 1 - 2 / (exp(2 |x|) + 1))
+__device__ __forceinline__ float tanh_select(float x) {
+    const float ax = fabsf(x), t = x * x;
+    float p = __builtin_fmaf(t, -0x1.758e7ap-8f, 0x1.521192p-6f);
+    p = __builtin_fmaf(t, p, -0x1.b8389cp-5f);
+    p = __builtin_fmaf(t, p, 0x1.110704p-3f);
+    p = __builtin_fmaf(t, p, -0x1.555532p-2f);
+    const float small = __builtin_fmaf(t, ax * p, ax);
+    const float large = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(expf(ax * 2.0f) + 1.0f), 1.0f);
+    return copysignf(ax < 0.625f ? small : large, x);
+}
+__device__ __forceinline__ float gelu_tanh_select(float x) {     // == gelu_tanh(x), bit for bit
+    const float c = 0.79788456080286535588f;  // sqrt(2/pi)
+    return 0.5f * x * (1.0f + tanh_select(c * (x + 0.044715f * x * x * x)));
+}
+__device__ __forceinline__ float gelu_erf_select(float x) {      // == gelu_erf(x), bit for bit
+    return 0.5f * x * (1.0f + erf_select(x * 0.70710678118654752440f));
+}
 __device__ __forceinline__ float gelu_tanh(float x) {
     const float c = 0.79788456080286535588f;  // sqrt(2/pi)
     return 0.5f * x * (1.0f + tanhf(c * (x + 0.044715f * x * x * x)));
@@ -326,6 +380,38 @@ __device__ __forceinline__ unsigned pack_bf16_rne(float lo, float hi) {
     unsigned r;
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
+}
+// exact three-term bf16 split of fp32 values (precision mode bf16x3): x = p0 + p1 + p2 with p0 = bf16(x), p1 = bf16(x - p0),
+// p2 = x - p0 - p1 -- both subtractions are exact in fp32 and the last remainder fits bf16's 8 significant bits.
+// Four values -> one dword pair per plane (element 0 in the low half of dword 0).
+using f32x4_t = __attribute__((ext_vector_type(4))) float;
+using u32x2_t = __attribute__((ext_vector_type(2))) unsigned;
+__device__ __forceinline__ void split3_pack4(const f32x4_t& x, u32x2_t& p0, u32x2_t& p1, u32x2_t& p2) {
+    p0[0] = pack_bf16_rne(x[0], x[1]);
+    p0[1] = pack_bf16_rne(x[2], x[3]);
+    f32x4_t r;
+    r[0] = x[0] - __uint_as_float(p0[0] << 16);
+    r[1] = x[1] - __uint_as_float(p0[0] & 0xffff0000u);
+    r[2] = x[2] - __uint_as_float(p0[1] << 16);
+    r[3] = x[3] - __uint_as_float(p0[1] & 0xffff0000u);
+    p1[0] = pack_bf16_rne(r[0], r[1]);
+    p1[1] = pack_bf16_rne(r[2], r[3]);
+    r[0] -= __uint_as_float(p1[0] << 16);
+    r[1] -= __uint_as_float(p1[0] & 0xffff0000u);
+    r[2] -= __uint_as_float(p1[1] << 16);
+    r[3] -= __uint_as_float(p1[1] & 0xffff0000u);
+    p2[0] = pack_bf16_rne(r[0], r[1]);
+    p2[1] = pack_bf16_rne(r[2], r[3]);
+}
+// one value -> its three bf16 bit patterns
+__device__ __forceinline__ void split3_one(float x, uint16_t& p0, uint16_t& p1, uint16_t& p2) {
+    const unsigned h0 = pack_bf16_rne(x, 0.f) & 0xffffu;
+    const float r1 = x - __uint_as_float(h0 << 16);
+    const unsigned h1 = pack_bf16_rne(r1, 0.f) & 0xffffu;
+    const float r2 = r1 - __uint_as_float(h1 << 16);
+    p0 = (uint16_t)h0;
+    p1 = (uint16_t)h1;
+    p2 = (uint16_t)(pack_bf16_rne(r2, 0.f) & 0xffffu);
 }
 // wave64 all-reduce sum via DPP/shuffles
 __device__ __forceinline__ float wave_sum(float v) {

@@ -58,41 +58,8 @@ using IC = std::integral_constant<int, V>;
 // ---- bf16-only epilogue through LDS (see gemm_bf16_pp.hip: column-major image, ds_write_b64, transposing reads, 16-byte stores)
 __device__ __forceinline__ unsigned sw_cswz(int c) { return (unsigned)(((c & 3) << 2) | ((c >> 2) & 3)); }
 
-template <int ACT>
-__device__ __forceinline__ void sw_epilogue_bf16(const bool nt, const f32x16 (&acc)[4][2], uint16_t* __restrict__ C16, const float* __restrict__ bias, int ldc,
-                                                 unsigned wbase, int lane) {
-    const int li = lane & 31, lh = lane >> 5;
-    const unsigned pre_w = ((sw_cswz(li) ^ (unsigned)lh) << 3);
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const float bv = bias ? bias[nt * 32 + li] : 0.0f;
-        const unsigned colbase = wbase + (unsigned)(nt * 32 + li) * 256u;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            f32x16 v = acc[mt][nt];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] += bv;
-            if constexpr (ACT == 1) {
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const f32x2_t t = gelu_erf_fast2(f32x2_t{v[r], v[r + 1]});
-                    v[r] = t[0];
-                    v[r + 1] = t[1];
-                }
-            } else if constexpr (ACT == 2) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = gelu_tanh(v[r]);
-            }
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                u32x2 w;
-                w[0] = pack_bf16_rne(v[4 * gq], v[4 * gq + 1]);
-                w[1] = pack_bf16_rne(v[4 * gq + 2], v[4 * gq + 3]);
-                const unsigned a = colbase + ((unsigned)((mt * 8 + 2 * gq) << 3) ^ pre_w);
-                asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(w) : "memory");
-            }
-        }
-    }
+// the wave's 128 x 64 bf16 image (column-major, written by ds_write_b64 as below) -> global rows of C16: transposing reads, 16-byte stores
+__device__ __forceinline__ void sw_image_store(const bool nt, uint16_t* __restrict__ C16, int ldc, unsigned wbase, int lane) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int q = lane >> 4, l = lane & 15;
     const int cA = 8 * q + (l >> 2);
@@ -129,6 +96,44 @@ __device__ __forceinline__ void sw_epilogue_bf16(const bool nt, const f32x16 (&a
 #undef SW_ST4
 }
 
+template <int ACT>
+__device__ __forceinline__ void sw_epilogue_bf16(const bool nt, const f32x16 (&acc)[4][2], uint16_t* __restrict__ C16, const float* __restrict__ bias, int ldc,
+                                                 unsigned wbase, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    const unsigned pre_w = ((sw_cswz(li) ^ (unsigned)lh) << 3);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const float bv = bias ? bias[nt * 32 + li] : 0.0f;
+        const unsigned colbase = wbase + (unsigned)(nt * 32 + li) * 256u;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            f32x16 v = acc[mt][nt];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += bv;
+            if constexpr (ACT == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2_t t = gelu_erf_fast2(f32x2_t{v[r], v[r + 1]});
+                    v[r] = t[0];
+                    v[r + 1] = t[1];
+                }
+            } else if constexpr (ACT == 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = gelu_tanh(v[r]);
+            }
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                u32x2 w;
+                w[0] = pack_bf16_rne(v[4 * gq], v[4 * gq + 1]);
+                w[1] = pack_bf16_rne(v[4 * gq + 2], v[4 * gq + 3]);
+                const unsigned a = colbase + ((unsigned)((mt * 8 + 2 * gq) << 3) ^ pre_w);
+                asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(w) : "memory");
+            }
+        }
+    }
+    sw_image_store(nt, C16, ldc, wbase, lane);
+}
+
 // ---- fp32 epilogue through LDS (outputs that stay fp32: the residual stream, the data gradients).  From registers a lane writes
 // 128 single dwords (2 rows x 128 B per store instruction) and reads the residual the same way; here the wave's tile goes through its
 // 16 KiB of LDS in two halves of 64 rows as a row-major fp32 image (ds_write_b32: 32 consecutive dwords per half-wave), comes back
@@ -136,7 +141,7 @@ __device__ __forceinline__ void sw_epilogue_bf16(const bool nt, const f32x16 (&a
 // lane) and the optional bf16 shadow (8 B per lane) all move whole rows.  Same element arithmetic in the same order as
 // gemm_epilogue: (acc + bias) -> act -> + residual.
 using f32x4 = __attribute__((ext_vector_type(4))) float;
-template <int ACT>
+template <int ACT, bool FASTG = true>
 __device__ __forceinline__ void sw_epilogue_f32(const bool nt, const f32x16 (&acc)[4][2], float* __restrict__ C, uint16_t* __restrict__ C16,
                                                 const float* __restrict__ R, const float* __restrict__ bias, int ldc, unsigned wbase, int lane) {
     const int li = lane & 31, lh = lane >> 5;
@@ -180,7 +185,10 @@ __device__ __forceinline__ void sw_epilogue_f32(const bool nt, const f32x16 (&ac
                 f32x16 v = acc[2 * h + mh][nt];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] += bv[nt];
-                if constexpr (ACT == 1) {
+                if constexpr (ACT == 1 && !FASTG) {      // (the fp32-grade split GEMM: erff, as the fp32 path)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = gelu_erf(v[r]);
+                } else if constexpr (ACT == 1) {
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
                         const f32x2_t t = gelu_erf_fast2(f32x2_t{v[r], v[r + 1]});
@@ -193,8 +201,8 @@ __device__ __forceinline__ void sw_epilogue_f32(const bool nt, const f32x16 (&ac
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const unsigned a = wr0 + (unsigned)(mh * 32 + (r & 3) + 8 * (r >> 2)) * 256u + (unsigned)nt * 128u;
-                    asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v[r]) : "memory");
+                    // (the row / column-half displacement as the instruction's offset field: one address register for all 128 writes)
+                    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(wr0), "v"(v[r]), "n"((mh * 32 + (r & 3) + 8 * (r >> 2)) * 256 + nt * 128) : "memory");
                 }
             }
         if (h == 0) {
@@ -249,6 +257,51 @@ __device__ __forceinline__ void sw_epilogue_f32(const bool nt, const f32x16 (&ac
 #undef SW_F32_OUT
     }
 #undef SW_F32_RES
+}
+
+// ---- three-plane epilogue (precision mode bf16x3: the consumer GEMM streams its activation as three bf16 planes whose sum is the
+// fp32 value EXACTLY -- gemm_split_sw.hip; that kernel applies the activation before it calls this).  acc + bias in place, then
+// plane p = bf16(rest), rest -= plane p (exact in fp32), each plane through the wave's LDS image like sw_epilogue_bf16.  An LDS pipe executes one wave's
+// operations in order and the image is the wave's own, so a pass's writes cannot overtake the previous pass's reads.
+__device__ __forceinline__ void sw_epilogue_planes(const bool nt, f32x16 (&acc)[4][2], uint16_t* __restrict__ C16, int64_t plane, const float* __restrict__ bias,
+                                                   int ldc, unsigned wbase, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    const unsigned pre_w = ((sw_cswz(li) ^ (unsigned)lh) << 3);
+    if (bias) {
+#pragma unroll
+        for (int nt_ = 0; nt_ < 2; ++nt_) {
+            const float bv = bias[nt_ * 32 + li];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt_][r] += bv;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int nt_ = 0; nt_ < 2; ++nt_) {
+            const unsigned colbase = wbase + (unsigned)(nt_ * 32 + li) * 256u;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    u32x2 w;
+                    w[0] = pack_bf16_rne(acc[mt][nt_][4 * gq], acc[mt][nt_][4 * gq + 1]);
+                    w[1] = pack_bf16_rne(acc[mt][nt_][4 * gq + 2], acc[mt][nt_][4 * gq + 3]);
+                    const unsigned a = colbase + ((unsigned)((mt * 8 + 2 * gq) << 3) ^ pre_w);
+                    asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(w) : "memory");
+                    if (p < 2) {
+                        acc[mt][nt_][4 * gq] -= __uint_as_float(w[0] << 16);
+                        acc[mt][nt_][4 * gq + 1] -= __uint_as_float(w[0] & 0xffff0000u);
+                        acc[mt][nt_][4 * gq + 2] -= __uint_as_float(w[1] << 16);
+                        acc[mt][nt_][4 * gq + 3] -= __uint_as_float(w[1] & 0xffff0000u);
+                    }
+                }
+            }
+        }
+        sw_image_store(nt, C16 + (int64_t)p * plane, ldc, wbase, lane);
+    }
 }
 
 }  // namespace

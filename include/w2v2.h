@@ -306,6 +306,27 @@ int w2v2_op_gemm_split(const float* A_dev, int64_t lda, int64_t strideA, const f
                        const float* bias_dev, const float* residual_dev,
                        int32_t M, int32_t N, int32_t K, int32_t nbatch, int32_t act, void* stream);
 
+/* The same contraction with BOTH operands pre-split, the form the model's forward GEMMs run in precision mode bf16x3
+ * (gemm_split_sw.hip: software-pipelined 128 x 256 tiles, operands HBM / L2 -> LDS by DMA):
+ *   w2v2_op_split_planes   x (n fp32) -> three bf16 planes, plane p at planes + p * plane_stride: x = p0 + p1 + p2 exactly
+ *                          (what the producing kernels of the model write next to / instead of their fp32 output);
+ *   w2v2_op_split_weight   Bm (K, N) fp32 -> the kernel's weight images, 3 K N bf16 (done once per variable update);
+ *   w2v2_op_gemm_split_planes   A as planes (rows lda elements apart, overlapping rows = strided Conv1D, batch stride strideA,
+ *                          planes planeA elements apart), B as images; the result as fp32 C (+ residual) or -- C NULL -- as the
+ *                          three planes of act(A B + bias) at C16 + p * planeC for the next GEMM.  N % 256 == 0, K % 64 == 0,
+ *                          lda % 8 == 0, 16-byte aligned planes. */
+int w2v2_op_split_planes(const float* x_dev, uint16_t* planes_dev, int64_t plane_stride, int64_t n, void* stream);
+int w2v2_op_split_weight(const float* B_dev, uint16_t* images_dev, int32_t K, int32_t N, void* stream);
+int w2v2_op_gemm_split_planes(const uint16_t* A16_dev, int64_t planeA, int64_t lda, int64_t strideA, const uint16_t* B_images_dev,
+                              float* C_dev, uint16_t* C16_dev, int64_t planeC, int64_t ldc, int64_t strideC,
+                              const float* bias_dev, const float* residual_dev,
+                              int32_t M, int32_t N, int32_t K, int32_t nbatch, int32_t act, void* stream);
+
+/* Self-check of the branch-free GELU forms the bf16x3 GEMM epilogues use (csrc/common.h: erf_select, tanh_select): evaluates them
+ * and the device library's erff / tanhf on all 2^32 float bit patterns; mismatches_dev[0] / [1] receive the number of patterns whose
+ * results differ in any bit (NaNs compare equal).  Both must be 0: the forms are drop-in for the fp32 path's GELU. */
+int w2v2_op_check_select_forms(uint64_t* mismatches_dev, void* stream);
+
 /* The weight-gradient form of the same GEMM: C_z (M, N) = A_z^T B_z with A given TRANSPOSED, (K, M) fp32 row-major with
  * row stride lda (>= M), and per-batch strides on A, B and C (split-K: batch z covers rows [z K, (z+1) K) of both
  * operands and writes slab z).  bf16-rounded operands, fp32 accumulation.  K % 64 == 0, M % 4 == 0, N % 4 == 0. */
