@@ -65,6 +65,11 @@ enum Family {
 };
 const char* family_name(int f);
 
+// plane formats of the pre-split GEMM operands (gemm_split_sw.hip): three bf16 planes, x = p0 + p1 + p2 exactly (precision mode
+// bf16x3), or two fp16 planes of x S (precision mode f16x2; helpers further down)
+enum PlaneFmt { PF_BF16X3 = 0, PF_F16X2 = 1 };
+constexpr int plane_count(int fmt) { return fmt == PF_F16X2 ? 2 : 3; }
+
 // Kernel launches actually enqueued, per family (an op-level call may enqueue several kernels: main + tail tiles, a partial
 // and a final reduction ...).  Every launch in csrc/ goes through W2V2_LAUNCH; the family is the innermost live ProfScope's
 // (FAM_MISC outside any).  Process-wide counters, cleared by profiler_reset; read by w2v2_profile_kernel_launches.
@@ -137,15 +142,17 @@ int launch_gemm_split(Profiler* prof, const float* A, int64_t lda, int64_t strid
                       int64_t strideC, const float* bias, const float* residual, int M, int N, int K, int nbatch, int act,
                       hipStream_t s);
 
-// ... and with BOTH operands pre-split (gemm_split_sw.hip): the activation as three row-major bf16 planes `planeA` elements apart
-// (written by its producer; launch_split_planes is the unfused form), the weight as that kernel's LDS images (launch_split_weight_sw,
-// 3 N K elements); the result as fp32 (C, + residual) or as the three planes of (acc + bias -> act) for the next GEMM (C16, planeC).
+// ... and with BOTH operands pre-split (gemm_split_sw.hip), in plane format `fmt` (PlaneFmt below: three bf16 planes = precision mode
+// bf16x3, two fp16 planes = precision mode f16x2): the activation as row-major planes `planeA` elements apart (written by its
+// producer; launch_split_planes is the unfused form), the weight as that kernel's LDS images (launch_split_weight_sw: plane_count x N x K
+// elements; the f16x2 format also needs two scratch words, whose second is the `out_scale` the GEMM reads); the result as fp32 (C,
+// + residual) or as the planes of (acc + bias -> act) for the next GEMM (C16, planeC).  range_flag: sticky overflow flag of f16x2.
 bool gemm_split_sw_ok(const uint16_t* A16, int64_t planeA, int64_t lda, int64_t strideA, int M, int N, int K);
-int launch_split_weight_sw(const float* w, uint16_t* img, int K, int N, hipStream_t s);
-int launch_split_planes(const float* x, uint16_t* planes, int64_t plane, int64_t n, hipStream_t s);
-int launch_gemm_split_sw(Profiler* prof, const uint16_t* A16, int64_t planeA, int64_t lda, int64_t strideA, const uint16_t* Bimg, float* C,
-                         uint16_t* C16, int64_t planeC, int64_t ldc, int64_t strideC, const float* bias, const float* residual, int M, int N,
-                         int K, int nbatch, int act, hipStream_t s);
+int launch_split_weight_sw(const float* w, uint16_t* img, int K, int N, int fmt, void* scratch, hipStream_t s);
+int launch_split_planes(const float* x, uint16_t* planes, int64_t plane, int64_t n, int fmt, int* range_flag, hipStream_t s);
+int launch_gemm_split_sw(Profiler* prof, int fmt, const uint16_t* A16, int64_t planeA, int64_t lda, int64_t strideA, const uint16_t* Bimg,
+                         const float* out_scale, float* C, uint16_t* C16, int64_t planeC, int64_t ldc, int64_t strideC, const float* bias,
+                         const float* residual, int M, int N, int K, int nbatch, int act, int* range_flag, hipStream_t s);
 
 // selftest.hip: counts the float patterns on which erf_select / tanh_select differ from the device library's erff / tanhf
 int launch_check_select_forms(unsigned long long* mismatches_dev /* [2] */, hipStream_t s);
@@ -412,6 +419,58 @@ __device__ __forceinline__ void split3_one(float x, uint16_t& p0, uint16_t& p1, 
     p0 = (uint16_t)h0;
     p1 = (uint16_t)h1;
     p2 = (uint16_t)(pack_bf16_rne(r2, 0.f) & 0xffffu);
+}
+// ---- precision mode f16x2: fp32 values as TWO fp16 terms of x S (S a power of two): h0 = fp16(x S), h1 = fp16(x S - h0); the
+// subtraction is exact and h0 + h1 carries 22 significant bits of x S (fp16 keeps its subnormals on gfx950, in the conversion and in
+// the MFMA -- tools/mfma_power_probe.hip -- so below |x S| = 2^-3 the error is absolute, <= 2^-25).  A product keeps a0 b0 + a0 b1 +
+// a1 b0: three MFMA products instead of bf16x3's six, at an error of ~2^-22 per product, which after K >= 64 products is below what
+// the fp32 accumulation itself commits (gemm_split_sw.hip).  |x S| > 65504 saturates; the producers report it (`ovf`).
+constexpr float F16X2_ACT_SCALE = 16.0f;       // activations: full precision for 2^-7 <= |x| < 4094
+constexpr float F16X2_MAX = 65504.0f;
+using h2_t = __attribute__((ext_vector_type(2))) _Float16;
+__device__ __forceinline__ unsigned pack_f16_rne(float lo, float hi) {
+    const h2_t v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void split2h_pack4(const f32x4_t& x, float s, u32x2_t& p0, u32x2_t& p1, bool& ovf) {
+    f32x4_t y;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float t = x[i] * s;
+        ovf |= !(fabsf(t) <= F16X2_MAX);
+        y[i] = __builtin_amdgcn_fmed3f(t, -F16X2_MAX, F16X2_MAX);
+    }
+    const h2_t a = {(_Float16)y[0], (_Float16)y[1]}, b = {(_Float16)y[2], (_Float16)y[3]};
+    p0[0] = __builtin_bit_cast(unsigned, a);
+    p0[1] = __builtin_bit_cast(unsigned, b);
+    p1[0] = pack_f16_rne(y[0] - (float)a[0], y[1] - (float)a[1]);
+    p1[1] = pack_f16_rne(y[2] - (float)b[0], y[3] - (float)b[1]);
+}
+__device__ __forceinline__ void split2h_one(float x, float s, uint16_t& p0, uint16_t& p1, bool& ovf) {
+    const float t = x * s;
+    ovf |= !(fabsf(t) <= F16X2_MAX);
+    const float y = __builtin_amdgcn_fmed3f(t, -F16X2_MAX, F16X2_MAX);
+    const _Float16 h = (_Float16)y;
+    p0 = __builtin_bit_cast(uint16_t, h);
+    p1 = __builtin_bit_cast(uint16_t, (_Float16)(y - (float)h));
+}
+// four values -> their planes at p, p + plane, (p + 2 plane); `ovf` only moves in the fp16 format
+__device__ __forceinline__ void store_planes4(uint16_t* __restrict__ p, int64_t plane, int fmt, const f32x4_t& v, bool& ovf) {
+    u32x2_t p0, p1, p2;
+    if (fmt == PF_F16X2) {
+        split2h_pack4(v, F16X2_ACT_SCALE, p0, p1, ovf);
+        *reinterpret_cast<u32x2_t*>(p) = p0;
+        *reinterpret_cast<u32x2_t*>(p + plane) = p1;
+    } else {
+        split3_pack4(v, p0, p1, p2);
+        *reinterpret_cast<u32x2_t*>(p) = p0;
+        *reinterpret_cast<u32x2_t*>(p + plane) = p1;
+        *reinterpret_cast<u32x2_t*>(p + 2 * plane) = p2;
+    }
+}
+// a producer's end: lanes that saw a saturated value set the sticky flag (range_flag: int in device memory, may be null)
+__device__ __forceinline__ void report_overflow(int* range_flag, bool ovf) {
+    if (range_flag && ovf) atomicOr(range_flag, 1);      // (exceptional: no need to elect one lane)
 }
 // wave64 all-reduce sum via DPP/shuffles
 __device__ __forceinline__ float wave_sum(float v) {

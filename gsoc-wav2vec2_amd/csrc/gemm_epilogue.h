@@ -18,11 +18,14 @@ using f32x16_t = __attribute__((ext_vector_type(16))) float;
 // (gelu_erf_fast: common.h)
 // C / C16 / R point at the wave sub-tile's first element (row 0, column 0 of the WTM x WTN block); any may be null.
 // bias points at the sub-tile's first column.  rows_left / cols_left = valid extent of the sub-tile.
-// c16_plane != 0: C16 receives the exact three-term bf16 split of the result (planes c16_plane elements apart; precision mode bf16x3).
+// c16_plane != 0: C16 receives the planes of the result, c16_plane elements apart: the exact three-term bf16 split (c16_fmt PF_BF16X3)
+// or the two fp16 terms of result x F16X2_ACT_SCALE (PF_F16X2; a saturated value sets *range_flag).
 template <int MT, int NTL, bool FAST_GELU>
 __device__ __forceinline__ void gemm_epilogue(const f32x16_t (&acc)[MT][NTL], float* __restrict__ C, uint16_t* __restrict__ C16,
                                               const float* __restrict__ R, const float* __restrict__ bias, int ldc,
-                                              int rows_left, int cols_left, int act, int li, int lh, int64_t c16_plane = 0) {
+                                              int rows_left, int cols_left, int act, int li, int lh, int64_t c16_plane = 0, int c16_fmt = 0,
+                                              int* range_flag = nullptr) {
+    bool ovf = false;
     const bool interior = rows_left >= MT * 32 && cols_left >= NTL * 32;
 #pragma unroll
     for (int nt = 0; nt < NTL; ++nt) {
@@ -64,7 +67,8 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16_t (&acc)[MT][NTL], fl
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         uint16_t* const d = C16 + off0 + ((r & 3) + 8 * (r >> 2)) * ldc;
-                        if (c16_plane) split3_one(v[r], d[0], d[c16_plane], d[2 * c16_plane]);
+                        if (c16_plane && c16_fmt == PF_F16X2) split2h_one(v[r], F16X2_ACT_SCALE, d[0], d[c16_plane], ovf);
+                        else if (c16_plane) split3_one(v[r], d[0], d[c16_plane], d[2 * c16_plane]);
                         else d[0] = (uint16_t)pack_bf16_rne(v[r], 0.0f);
                     }
                 }
@@ -78,7 +82,8 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16_t (&acc)[MT][NTL], fl
                         if (R) o += R[off];
                         if (C) C[off] = o;
                         if (C16) {
-                            if (c16_plane) split3_one(o, C16[off], C16[off + c16_plane], C16[off + 2 * c16_plane]);
+                            if (c16_plane && c16_fmt == PF_F16X2) split2h_one(o, F16X2_ACT_SCALE, C16[off], C16[off + c16_plane], ovf);
+                            else if (c16_plane) split3_one(o, C16[off], C16[off + c16_plane], C16[off + 2 * c16_plane]);
                             else C16[off] = (uint16_t)pack_bf16_rne(o, 0.0f);
                         }
                     }
@@ -86,6 +91,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16_t (&acc)[MT][NTL], fl
             }
         }
     }
+    report_overflow(range_flag, ovf);
 }
 
 #endif

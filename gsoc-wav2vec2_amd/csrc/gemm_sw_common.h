@@ -259,12 +259,14 @@ __device__ __forceinline__ void sw_epilogue_f32(const bool nt, const f32x16 (&ac
 #undef SW_F32_RES
 }
 
-// ---- three-plane epilogue (precision mode bf16x3: the consumer GEMM streams its activation as three bf16 planes whose sum is the
-// fp32 value EXACTLY -- gemm_split_sw.hip; that kernel applies the activation before it calls this).  acc + bias in place, then
-// plane p = bf16(rest), rest -= plane p (exact in fp32), each plane through the wave's LDS image like sw_epilogue_bf16.  An LDS pipe executes one wave's
+// ---- plane epilogue (precision modes bf16x3 / f16x2: the consumer GEMM streams its activation as three bf16 planes whose sum is the
+// fp32 value EXACTLY, or as the two fp16 terms of value x F16X2_ACT_SCALE -- gemm_split_sw.hip; that kernel applies the activation
+// before it calls this).  acc + bias in place, then plane p = round(rest), rest -= plane p (exact in fp32), each plane through the
+// wave's LDS image like sw_epilogue_bf16 (the transposing read moves 16-bit elements: fp16 and bf16 alike).  An LDS pipe executes one wave's
 // operations in order and the image is the wave's own, so a pass's writes cannot overtake the previous pass's reads.
+template <int FMT>
 __device__ __forceinline__ void sw_epilogue_planes(const bool nt, f32x16 (&acc)[4][2], uint16_t* __restrict__ C16, int64_t plane, const float* __restrict__ bias,
-                                                   int ldc, unsigned wbase, int lane) {
+                                                   int ldc, unsigned wbase, int lane, int* range_flag) {
     const int li = lane & 31, lh = lane >> 5;
     const unsigned pre_w = ((sw_cswz(li) ^ (unsigned)lh) << 3);
     if (bias) {
@@ -277,8 +279,22 @@ __device__ __forceinline__ void sw_epilogue_planes(const bool nt, f32x16 (&acc)[
                 for (int r = 0; r < 16; ++r) acc[mt][nt_][r] += bv;
         }
     }
+    if constexpr (FMT == PF_F16X2) {      // x S, saturated to fp16's range (a saturated value is wrong: reported through the sticky flag)
+        bool ovf = false;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+        for (int nt_ = 0; nt_ < 2; ++nt_)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float t = acc[mt][nt_][r] * F16X2_ACT_SCALE;
+                    ovf |= !(fabsf(t) <= F16X2_MAX);
+                    acc[mt][nt_][r] = __builtin_amdgcn_fmed3f(t, -F16X2_MAX, F16X2_MAX);
+                }
+        report_overflow(range_flag, ovf);
+    }
+#pragma unroll
+    for (int p = 0; p < plane_count(FMT); ++p) {
 #pragma unroll
         for (int nt_ = 0; nt_ < 2; ++nt_) {
             const unsigned colbase = wbase + (unsigned)(nt_ * 32 + li) * 256u;
@@ -287,16 +303,29 @@ __device__ __forceinline__ void sw_epilogue_planes(const bool nt, f32x16 (&acc)[
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     u32x2 w;
-                    w[0] = pack_bf16_rne(acc[mt][nt_][4 * gq], acc[mt][nt_][4 * gq + 1]);
-                    w[1] = pack_bf16_rne(acc[mt][nt_][4 * gq + 2], acc[mt][nt_][4 * gq + 3]);
-                    const unsigned a = colbase + ((unsigned)((mt * 8 + 2 * gq) << 3) ^ pre_w);
-                    asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(w) : "memory");
-                    if (p < 2) {
-                        acc[mt][nt_][4 * gq] -= __uint_as_float(w[0] << 16);
-                        acc[mt][nt_][4 * gq + 1] -= __uint_as_float(w[0] & 0xffff0000u);
-                        acc[mt][nt_][4 * gq + 2] -= __uint_as_float(w[1] << 16);
-                        acc[mt][nt_][4 * gq + 3] -= __uint_as_float(w[1] & 0xffff0000u);
+                    if constexpr (FMT == PF_F16X2) {
+                        const h2_t a = {(_Float16)acc[mt][nt_][4 * gq], (_Float16)acc[mt][nt_][4 * gq + 1]};
+                        const h2_t b = {(_Float16)acc[mt][nt_][4 * gq + 2], (_Float16)acc[mt][nt_][4 * gq + 3]};
+                        w[0] = __builtin_bit_cast(unsigned, a);
+                        w[1] = __builtin_bit_cast(unsigned, b);
+                        if (p == 0) {
+                            acc[mt][nt_][4 * gq] -= (float)a[0];
+                            acc[mt][nt_][4 * gq + 1] -= (float)a[1];
+                            acc[mt][nt_][4 * gq + 2] -= (float)b[0];
+                            acc[mt][nt_][4 * gq + 3] -= (float)b[1];
+                        }
+                    } else {
+                        w[0] = pack_bf16_rne(acc[mt][nt_][4 * gq], acc[mt][nt_][4 * gq + 1]);
+                        w[1] = pack_bf16_rne(acc[mt][nt_][4 * gq + 2], acc[mt][nt_][4 * gq + 3]);
+                        if (p < 2) {
+                            acc[mt][nt_][4 * gq] -= __uint_as_float(w[0] << 16);
+                            acc[mt][nt_][4 * gq + 1] -= __uint_as_float(w[0] & 0xffff0000u);
+                            acc[mt][nt_][4 * gq + 2] -= __uint_as_float(w[1] << 16);
+                            acc[mt][nt_][4 * gq + 3] -= __uint_as_float(w[1] & 0xffff0000u);
+                        }
                     }
+                    const unsigned a_ = colbase + ((unsigned)((mt * 8 + 2 * gq) << 3) ^ pre_w);
+                    asm volatile("ds_write_b64 %0, %1" ::"v"(a_), "v"(w) : "memory");
                 }
             }
         }

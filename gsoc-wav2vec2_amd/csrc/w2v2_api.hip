@@ -911,17 +911,20 @@ int w2v2_op_gemm_split(const float* A, int64_t lda, int64_t strideA, const float
 int w2v2_op_check_select_forms(uint64_t* mismatches, void* stream) {
     return launch_check_select_forms(reinterpret_cast<unsigned long long*>(mismatches), reinterpret_cast<hipStream_t>(stream));
 }
-int w2v2_op_split_planes(const float* x, uint16_t* planes, int64_t plane_stride, int64_t n, void* stream) {
-    return launch_split_planes(x, planes, plane_stride, n, reinterpret_cast<hipStream_t>(stream));
+int w2v2_op_split_planes(const float* x, uint16_t* planes, int64_t plane_stride, int64_t n, int32_t fmt, int32_t* range_flag, void* stream) {
+    W2V2_REQUIRE(fmt == PF_BF16X3 || fmt == PF_F16X2, "op_split_planes: unknown plane format %d", fmt);
+    return launch_split_planes(x, planes, plane_stride, n, fmt, range_flag, reinterpret_cast<hipStream_t>(stream));
 }
-int w2v2_op_split_weight(const float* B, uint16_t* images, int32_t K, int32_t N, void* stream) {
-    return launch_split_weight_sw(B, images, K, N, reinterpret_cast<hipStream_t>(stream));
+int w2v2_op_split_weight(const float* B, uint16_t* images, float* scale_ws, int32_t K, int32_t N, int32_t fmt, void* stream) {
+    W2V2_REQUIRE(fmt == PF_BF16X3 || fmt == PF_F16X2, "op_split_weight: unknown plane format %d", fmt);
+    return launch_split_weight_sw(B, images, K, N, fmt, scale_ws, reinterpret_cast<hipStream_t>(stream));
 }
-int w2v2_op_gemm_split_planes(const uint16_t* A16, int64_t planeA, int64_t lda, int64_t strideA, const uint16_t* Bimg, float* C,
-                              uint16_t* C16, int64_t planeC, int64_t ldc, int64_t strideC, const float* bias, const float* residual,
-                              int32_t M, int32_t N, int32_t K, int32_t nbatch, int32_t act, void* stream) {
-    return launch_gemm_split_sw(nullptr, A16, planeA, lda, strideA, Bimg, C, C16, planeC, ldc, strideC, bias, residual, M, N, K, nbatch, act,
-                                reinterpret_cast<hipStream_t>(stream));
+int w2v2_op_gemm_split_planes(int32_t fmt, const uint16_t* A16, int64_t planeA, int64_t lda, int64_t strideA, const uint16_t* Bimg,
+                              const float* out_scale, float* C, uint16_t* C16, int64_t planeC, int64_t ldc, int64_t strideC,
+                              const float* bias, const float* residual, int32_t M, int32_t N, int32_t K, int32_t nbatch, int32_t act,
+                              int32_t* range_flag, void* stream) {
+    return launch_gemm_split_sw(nullptr, fmt, A16, planeA, lda, strideA, Bimg, out_scale, C, C16, planeC, ldc, strideC, bias, residual, M, N, K,
+                                nbatch, act, range_flag, reinterpret_cast<hipStream_t>(stream));
 }
 int w2v2_op_gemm_bf16_at(const float* At, int64_t lda, int64_t strideA, const float* B, int64_t ldb, int64_t strideB,
                          float* C, int64_t ldc, int64_t strideC, int32_t M, int32_t N, int32_t K, int32_t nbatch, void* stream) {

@@ -100,9 +100,9 @@ PROTOTYPES = {
     "w2v2_crc32c_extend": (C.c_uint32, [C.c_uint32, _P, C.c_uint64]),
     "w2v2_op_weight_grad_bf16": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P]),
     "w2v2_op_check_select_forms": (C.c_int, [_P, _P]),
-    "w2v2_op_split_planes": (C.c_int, [_P, _P, _I64, _I64, _P]),
-    "w2v2_op_split_weight": (C.c_int, [_P, _P, _I32, _I32, _P]),
-    "w2v2_op_gemm_split_planes": (C.c_int, [_P, _I64, _I64, _I64, _P, _P, _P, _I64, _I64, _I64, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
+    "w2v2_op_split_planes": (C.c_int, [_P, _P, _I64, _I64, _I32, _P, _P]),
+    "w2v2_op_split_weight": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _P]),
+    "w2v2_op_gemm_split_planes": (C.c_int, [_I32, _P, _I64, _I64, _I64, _P, _P, _P, _P, _I64, _I64, _I64, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "w2v2_op_gemm_bf16_shadows": (C.c_int, [_P, _I64, _I64, _P, _P, _P, _I64, _I64, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "w2v2_op_gemm_bf16": (C.c_int, [_P, _I64, _I64, _P, _I64, _P, _I64, _I64, _P, _P, _I32, _I32, _I32, _I32, _I32, _P]),
     "w2v2_op_layer_norm": (C.c_int, [_P, _P, _P, _P, _I64, _I32, C.c_float, _I32, _P]),

@@ -306,21 +306,29 @@ int w2v2_op_gemm_split(const float* A_dev, int64_t lda, int64_t strideA, const f
                        const float* bias_dev, const float* residual_dev,
                        int32_t M, int32_t N, int32_t K, int32_t nbatch, int32_t act, void* stream);
 
-/* The same contraction with BOTH operands pre-split, the form the model's forward GEMMs run in precision mode bf16x3
- * (gemm_split_sw.hip: software-pipelined 128 x 256 tiles, operands HBM / L2 -> LDS by DMA):
- *   w2v2_op_split_planes   x (n fp32) -> three bf16 planes, plane p at planes + p * plane_stride: x = p0 + p1 + p2 exactly
- *                          (what the producing kernels of the model write next to / instead of their fp32 output);
- *   w2v2_op_split_weight   Bm (K, N) fp32 -> the kernel's weight images, 3 K N bf16 (done once per variable update);
- *   w2v2_op_gemm_split_planes   A as planes (rows lda elements apart, overlapping rows = strided Conv1D, batch stride strideA,
- *                          planes planeA elements apart), B as images; the result as fp32 C (+ residual) or -- C NULL -- as the
- *                          three planes of act(A B + bias) at C16 + p * planeC for the next GEMM.  N % 256 == 0, K % 64 == 0,
- *                          lda % 8 == 0, 16-byte aligned planes. */
-int w2v2_op_split_planes(const float* x_dev, uint16_t* planes_dev, int64_t plane_stride, int64_t n, void* stream);
-int w2v2_op_split_weight(const float* B_dev, uint16_t* images_dev, int32_t K, int32_t N, void* stream);
-int w2v2_op_gemm_split_planes(const uint16_t* A16_dev, int64_t planeA, int64_t lda, int64_t strideA, const uint16_t* B_images_dev,
+/* The same contraction with BOTH operands pre-split into 16-bit planes, the form the model's forward GEMMs run in precision modes
+ * bf16x3 and f16x2 (gemm_split_sw.hip: software-pipelined 128 x 256 tiles, operands HBM / L2 -> LDS by DMA).  fmt:
+ *   W2V2_PLANES_BF16X3  three bf16 planes, x = p0 + p1 + p2 exactly; six MFMA products per fp32 product;
+ *   W2V2_PLANES_F16X2   two fp16 planes of x * 2^e (activations: e = 4; a weight: e chosen from max |w|); three products.
+ *   w2v2_op_split_planes   x (n fp32) -> planes, plane p at planes + p * plane_stride (what the producing kernels of the model write
+ *                          next to / instead of their fp32 output);
+ *   w2v2_op_split_weight   Bm (K, N) fp32 -> the kernel's weight images, plane_count * K * N 16-bit elements (done once per variable
+ *                          update).  f16x2: scale_ws_dev = two device words, [0] work space, [1] receives the fp32 scale
+ *                          1 / (2^e_w * 2^4) that the GEMM must be given as out_scale_dev; bf16x3: NULL;
+ *   w2v2_op_gemm_split_planes   A as planes (rows lda elements apart, overlapping rows = strided Conv1D, batch stride strideA, planes
+ *                          planeA elements apart), B as images; the result as fp32 C (+ residual) or -- C NULL -- as the planes of
+ *                          act(A B + bias) at C16 + p * planeC for the next GEMM.  range_flag_dev (int, may be NULL): set to 1 when an
+ *                          f16x2 plane output saturates fp16 (|x| >= 4094).  N % 256 == 0, K % 64 == 0, lda % 8 == 0, 16-byte aligned planes. */
+#define W2V2_PLANES_BF16X3 0
+#define W2V2_PLANES_F16X2 1
+int w2v2_op_split_planes(const float* x_dev, uint16_t* planes_dev, int64_t plane_stride, int64_t n, int32_t fmt, int32_t* range_flag_dev,
+                         void* stream);
+int w2v2_op_split_weight(const float* B_dev, uint16_t* images_dev, float* scale_ws_dev, int32_t K, int32_t N, int32_t fmt, void* stream);
+int w2v2_op_gemm_split_planes(int32_t fmt, const uint16_t* A16_dev, int64_t planeA, int64_t lda, int64_t strideA,
+                              const uint16_t* B_images_dev, const float* out_scale_dev,
                               float* C_dev, uint16_t* C16_dev, int64_t planeC, int64_t ldc, int64_t strideC,
                               const float* bias_dev, const float* residual_dev,
-                              int32_t M, int32_t N, int32_t K, int32_t nbatch, int32_t act, void* stream);
+                              int32_t M, int32_t N, int32_t K, int32_t nbatch, int32_t act, int32_t* range_flag_dev, void* stream);
 
 /* Self-check of the branch-free GELU forms the bf16x3 GEMM epilogues use (csrc/common.h: erf_select, tanh_select): evaluates them
  * and the device library's erff / tanhf on all 2^32 float bit patterns; mismatches_dev[0] / [1] receive the number of patterns whose

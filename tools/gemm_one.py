@@ -17,13 +17,15 @@ C = torch.empty(nb * M * Nn, device=dev); bias = torch.randn(Nn, device=dev)
 st = N.current_stream()
 if planes:      # the plane-fed bf16x3 kernel (gemm_split_sw.hip): planes of A and weight images built once, outside the loop
     pA = torch.empty(3 * a_elems, dtype=torch.int16, device=dev); img = torch.empty(3 * K * Nn, dtype=torch.int16, device=dev)
-    N.check(lib.w2v2_op_split_planes(N.ptr(A), N.ptr(pA), a_elems, a_elems - a_elems % 4, st))
-    N.check(lib.w2v2_op_split_weight(N.ptr(Bm), N.ptr(img), K, Nn, st))
+    FMT = 1 if os.environ.get("SPLIT_FMT") == "f16x2" else 0
+    ws = torch.zeros(2, device=dev)
+    N.check(lib.w2v2_op_split_planes(N.ptr(A), N.ptr(pA), a_elems, a_elems - a_elems % 4, FMT, None, st))
+    N.check(lib.w2v2_op_split_weight(N.ptr(Bm), N.ptr(img), N.ptr(ws) if FMT else None, K, Nn, FMT, st))
     P = torch.empty(3 * nb * M * Nn, dtype=torch.int16, device=dev) if act or name == "conv1" else None
 for _ in range(iters):
     if planes:
-        N.check(lib.w2v2_op_gemm_split_planes(N.ptr(pA), a_elems, lda, sA, N.ptr(img), None if P is not None else N.ptr(C), N.ptr(P) if P is not None else None,
-                                              nb * M * Nn, Nn, M * Nn, N.ptr(bias), None, M, Nn, K, nb, act, st))
+        N.check(lib.w2v2_op_gemm_split_planes(FMT, N.ptr(pA), a_elems, lda, sA, N.ptr(img), N.ptr(ws[1:]) if FMT else None, None if P is not None else N.ptr(C),
+                                              N.ptr(P) if P is not None else None, nb * M * Nn, Nn, M * Nn, N.ptr(bias), None, M, Nn, K, nb, act, None, st))
         continue
     if split:
         N.check(lib.w2v2_op_gemm_split(N.ptr(A), lda, sA, N.ptr(Bm), N.ptr(C), Nn, M * Nn, N.ptr(bias), None, M, Nn, K, nb, act, st))

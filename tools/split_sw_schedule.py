@@ -12,19 +12,37 @@ The tables below mirror the kernel's `unit` / `term` lambdas; run after editing 
 """
 import sys
 
-SLOTS, IPT = 10, 9
-KIND = ["A2", "B0a", "B0b", "A1", "B1a", "B1b", "A0", "B2a", "B2b"]          # item j of a K tile
-# term -> (plane of A, plane of B)
-PROD = [(2, 0), (1, 0), (1, 1), (0, 1), (0, 0), (0, 2)]
-# term -> reads: (operand, j relative to the tile's item 0 (B: j of half a; half b = j + 1), register slot as function of PAR)
-READS = {0: [("A", 3, lambda par: par ^ 1)], 1: [("B", 4, lambda par: 1)], 2: [("A", 6, lambda par: par)], 3: [],
-         4: [("B", 7, lambda par: 1), ("A", 9, lambda par: par ^ 1)], 5: [("B", 10, lambda par: 0)]}
-REQ = {0: [11, 12], 1: [13], 2: [14, 15], 3: [16], 4: [], 5: [17, 18, 19]}
-VM_FULL = {0: 14, 1: 14, 2: 14, 3: None, 4: 14, 5: 10}
-VM_LAST = {0: 10, 1: 6, 2: 4, 3: None, 4: 0, 5: None}
+SLOTS = 10
+FORMATS = {
+    # bf16x3: nine items per K tile, six terms
+    "bf16x3": dict(
+        IPT=9, KIND=["A2", "B0a", "B0b", "A1", "B1a", "B1b", "A0", "B2a", "B2b"],
+        PROD=[(2, 0), (1, 0), (1, 1), (0, 1), (0, 0), (0, 2)],                  # term -> (plane of A, plane of B)
+        # term -> reads: (operand, j relative to the tile's item 0 (B: j of half a; half b = j + 1), register slot as function of PAR)
+        READS={0: [("A", 3, lambda par: par ^ 1)], 1: [("B", 4, lambda par: 1)], 2: [("A", 6, lambda par: par)], 3: [],
+               4: [("B", 7, lambda par: 1), ("A", 9, lambda par: par ^ 1)], 5: [("B", 10, lambda par: 0)]},
+        REQ={0: [11, 12], 1: [13], 2: [14, 15], 3: [16], 4: [], 5: [17, 18, 19]},
+        REQ_PENULT_MAX=17,                                                       # the penultimate tile requests items j <= this
+        VM={"full": {0: 14, 1: 14, 2: 14, 3: None, 4: 14, 5: 10}, "penult": {0: 14, 1: 14, 2: 14, 3: None, 4: 14, 5: 10},
+            "last": {0: 10, 1: 6, 2: 4, 3: None, 4: 0, 5: None}},
+        SA=lambda t, par: par if (t == 0 or t >= 3) else par ^ 1, SB=lambda t: 1 if t in (2, 3, 5) else 0,
+        PRO_A=(0, 2), PRO_ITEMS=10, PRO_EXTRA=10, PARITY=True),
+    # f16x2: six items per K tile, three terms, no parity
+    "f16x2": dict(
+        IPT=6, KIND=["A1", "B0a", "B0b", "A0", "B1a", "B1b"],
+        PROD=[(1, 0), (0, 0), (0, 1)],
+        READS={0: [("A", 3, lambda par: 1)], 1: [("B", 4, lambda par: 1), ("A", 6, lambda par: 0)], 2: [("B", 7, lambda par: 0)]},
+        REQ={0: [11, 12], 1: [13], 2: [14, 15, 16]},
+        REQ_PENULT_MAX=11,
+        VM={"full": {0: 14, 1: 12, 2: 10}, "penult": {0: 14, 1: 10, 2: 6}, "last": {0: 4, 1: 0, 2: None}},
+        SA=lambda t, par: 0 if t == 0 else 1, SB=lambda t: 1 if t == 2 else 0,
+        PRO_A=(0, 1), PRO_ITEMS=10, PRO_EXTRA=10, PARITY=False),
+}
 
 
-def simulate(nk, half=0):
+def simulate(nk, half=0, fmt="bf16x3"):
+    F = FORMATS[fmt]
+    IPT, KIND, PROD, READS, REQ = F["IPT"], F["KIND"], F["PROD"], F["READS"], F["REQ"]
     E = IPT * nk
     out = []                      # outstanding pieces of this wave, oldest first (item ids, two per item)
     landed = set()
@@ -60,25 +78,23 @@ def simulate(nk, half=0):
     regA, regB = {}, {}
     done = set()
     # prologue
-    for j in range(IPT):
+    for j in range(F["PRO_ITEMS"]):
         issue(j)
-    issue(IPT)
     wait(18); gterm[0] += 1
-    read(0); regA[0] = (0, 2)
+    read(0); regA[0] = F["PRO_A"]
     wait(14); gterm[0] += 1
-    issue(10)
+    issue(F["PRO_EXTRA"])
     read(1 + half); read(2 - half)          # (the other half is read by the other wave pair; both count as read for the slot logic)
     regB[0] = (0, 0)
     for kt in range(nk):
-        par = kt & 1
+        par = (kt & 1) if F["PARITY"] else 0
         mode = "last" if kt == nk - 1 else "penult" if kt == nk - 2 else "full"
         base = IPT * kt
-        for t in range(6):
-            wait((VM_LAST if mode == "last" else VM_FULL)[t])
+        for t in range(len(PROD)):
+            wait(F["VM"][mode][t])
             gterm[0] += 1
             pa, pb = PROD[t]
-            sa = par if (t == 0 or t >= 3) else par ^ 1
-            sb = 1 if t in (2, 3, 5) else 0
+            sa, sb = F["SA"](t, par), F["SB"](t)
             assert regA.get(sa) == (kt, pa), f"nk={nk} kt={kt} T{t}: A slot {sa} holds {regA.get(sa)}, wanted plane {pa}"
             assert regB.get(sb) == (kt, pb), f"nk={nk} kt={kt} T{t}: B slot {sb} holds {regB.get(sb)}, wanted plane {pb}"
             done.add((kt, pa, pb))
@@ -99,18 +115,19 @@ def simulate(nk, half=0):
                     assert slotf(par) != sb, "B read into the slot the term multiplies from"
             for j in REQ[t]:
                 item = base + j
-                if mode == "last" or (mode == "penult" and j >= 18):
+                if mode == "last" or (mode == "penult" and j > F["REQ_PENULT_MAX"]):
                     assert item >= E, f"nk={nk}: item {item} exists but is never requested"
                     continue
                 issue(item)
     assert len(issued) == E and not [x for x in out if x not in landed and False]
-    assert len(done) == 6 * nk
+    assert len(done) == len(PROD) * nk
     assert all(i in read_term for i in range(E)), "unread items"
     return True
 
 
 if __name__ == "__main__":
-    for nk in range(2, 200, 2):
-        for half in (0, 1):
-            simulate(nk, half)
-    print("split_sw schedule: ring, counted waits and register slots consistent for K = 64 .. 6336")
+    for fmt in FORMATS:
+        for nk in range(2, 200, 1 if fmt == "f16x2" else 2):
+            for half in (0, 1):
+                simulate(nk, half, fmt)
+        print(f"split_sw schedule ({fmt}): ring, counted waits and register slots consistent for K = 64 .. 6336")
