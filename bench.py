@@ -433,17 +433,23 @@ def add_clock(roof, clk):
         roof["frac_clock_adjusted"] = round(roof["achieved"] / adj, 4)
 
 
-FAMILY_OF = {"fp32": "gemm_f32", "bf16": "gemm_bf16", "bf16x3": "gemm_split"}
-PEAK_OF = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16x3": round(PEAK_BF16_MFMA_TFLOPS / 6, 1)}
+FAMILY_OF = {"fp32": "gemm_f32", "bf16": "gemm_bf16", "bf16x3": "gemm_split", "f16x2": "gemm_split"}
+PEAK_OF = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16x3": round(PEAK_BF16_MFMA_TFLOPS / 6, 1),
+           "f16x2": round(PEAK_BF16_MFMA_TFLOPS / 3, 1)}
 KERNEL_OF = {
     "fp32": "gemm_f32_dma_kernel (fp32 MFMA 32x32x2, LDS-DMA staged, 256x128x16 tiles for the well-filled shapes, 128x128x32 for the rest, 64x64 "
             "for underfilled last rounds: conv1-6 implicit GEMM + all Dense layers)",
     "bf16": "gemm_bf16 family (bf16 MFMA 32x32x16, operands from bf16 shadows by LDS-DMA: gemm_bf16_sw_kernel 128x256 software-pipelined "
             "for the large shapes, gemm_bf16_kernel 128x128 for the rest, gemm_bf16_tr_kernel for weight gradients: conv1-6 + all Dense)",
-    "bf16x3": "gemm_split_kernel (fp32 GEMM as 6 bf16 MFMA 32x32x16 products of exact 3-term operand splits; peak = bf16 dense peak / 6)",
+    "bf16x3": "gemm_split_sw_kernel<.., bf16x3> (fp32 GEMM as 6 bf16 MFMA 32x32x16 products of exact 3-term operand splits, both operands streamed as "
+              "planes written by their producers; peak = bf16 dense peak / 6)",
+    "f16x2": "gemm_split_sw_kernel<.., f16x2> (fp32-grade GEMM as 3 fp16 MFMA 32x32x16 products of 2-term operand splits; peak = fp16 dense peak / 3)",
 }
 DTYPE_OF = {"fp32": "f32", "bf16": "bf16 operands, f32 accumulate (Dense / Conv1D); f32 elsewhere",
-            "bf16x3": "f32 operands as exact 3 x bf16 sums, 6 bf16 MFMA products per f32 product, f32 accumulate (Dense / Conv1D); f32 elsewhere"}
+            "bf16x3": "f32 operands as exact 3 x bf16 sums, 6 bf16 MFMA products per f32 product, f32 accumulate (Dense / Conv1D); f32 elsewhere",
+            "f16x2": "f32 operands as 2 x fp16 sums (22 bits), 3 fp16 MFMA products per f32 product, f32 accumulate (Dense / Conv1D); f32 elsewhere"}
+ALT_NOTE = {"bf16x3": "bf16x3 (fp32 operands as exact 3 x bf16 sums, 6 bf16 MFMA products per fp32 product, fp32 accumulate)",
+            "f16x2": "f16x2 (fp32 operands as 2 x fp16 sums of x 2^e, 3 fp16 MFMA products per fp32 product, fp32 accumulate; |activation| < 4094)"}
 MATRIX_FAMILIES = ("gemm_f32", "gemm_bf16", "gemm_split", "pos_conv", "attention", "conv0_apply")
 
 
@@ -520,7 +526,7 @@ def run_leg(ctx, spec, model=None):
     model.profile(False)
     elapsed = D.max_over_ranks(elapsed, device=dev)            # the slowest rank defines the step
     res = {"elapsed": elapsed, "ms_per_step": 1e3 * elapsed / steps, "B": B, "L": L, "T": T, "cfg": cfg, "x": x, "amask": amask,
-           "family": family, "prof": prof if do_prof else {}, "gold_wave": gold_wave,
+           "family": family, "prof": prof if do_prof else {}, "gold_wave": gold_wave, "gold_logits": gold_logits,
            "kernel_launches_per_step": {k: v["kernels"] // steps for k, v in prof.items() if v["kernels"]},
            "op_calls_per_step": {k: v["issued"] // steps for k, v in prof.items() if v["issued"]}}
 
@@ -580,7 +586,7 @@ def run_leg(ctx, spec, model=None):
     if gold_logits is not None:
         # `out` is the output of the last TIMED-configuration forward (per-family instrumentation does not change results)
         err = float((out[:2].double().cpu() - torch.from_numpy(gold_logits).double()).abs().max())
-        bar = 1e-3 if precision in ("fp32", "bf16x3") else 0.15
+        bar = 1e-3 if precision in ("fp32", "bf16x3", "f16x2") else 0.15
         assert err < bar, f"rank {rank}: max |logits - HF fp64| = {err:.3e} exceeds {bar}"
         res["logit_err"] = D.max_over_ranks(err, device=dev)
     return res, model, out
@@ -655,7 +661,7 @@ def main():
     ap.add_argument("--model", choices=["base", "large-robust"], default="base",
                     help="base = wav2vec2-base (the headline); large-robust = 24L/1024d prenorm, LayerNorm convs, conv bias, "
                          "attention mask (BASELINE configs[3] / [4] shapes, e.g. --batch 16 --samples 480000)")
-    ap.add_argument("--precision", choices=["fp32", "bf16", "bf16x3"], default="fp32",
+    ap.add_argument("--precision", choices=["fp32", "bf16", "bf16x3", "f16x2"], default="fp32",
                     help="fp32 = the reference's arithmetic and the headline metric; bf16 = Dense / Conv1D operands rounded "
                          "to bf16 with fp32 accumulation (BASELINE configs[2]/[4] 'bf16 CTC fine-tune'), reported separately")
     ap.add_argument("--mode", choices=["forward", "train"], default="forward",
@@ -723,8 +729,8 @@ def main():
 
     # Beside the headline (never as it): the same workload in precision mode "bf16x3" -- fp32-level results from the bf16
     # matrix cores.  Single-process forward runs of the fp32 configuration only; timed after the headline.
-    def measure_bf16x3(ref_logits):
-        model.set_precision("bf16x3")
+    def measure_alt(prec, ref_logits):
+        model.set_precision(prec)
         try:
             for _ in range(max(1, args.warmup)):
                 out3 = model(x, attention_mask=amask)
@@ -743,25 +749,33 @@ def main():
                 gs = model.profile_read().get("gemm_split")
                 model.profile(False)
                 if gs and gs["ms"] > 0:
-                    ach, pk = gs["flops"] / (gs["ms"] * 1e-3) / 1e12, round(PEAK_BF16_MFMA_TFLOPS / 6, 1)
-                    roof = {"kernel": "gemm_split_kernel", "bound": "mfma", "achieved": round(ach, 2), "peak": pk, "unit": "TFLOP/s (fp32-equivalent)",
-                            "frac": round(ach / pk, 4), "launches": gs["launches"], "note": "peak = bf16 dense MFMA peak / 6 products"}
+                    ach, pk = gs["flops"] / (gs["ms"] * 1e-3) / 1e12, PEAK_OF[prec]
+                    roof = {"kernel": KERNEL_OF[prec], "bound": "mfma", "achieved": round(ach, 2), "peak": pk, "unit": "TFLOP/s (fp32-equivalent)",
+                            "frac": round(ach / pk, 4), "launches": gs["launches"], "ms_per_step": round(gs["ms"], 3),
+                            "note": "peak = nominal dense bf16 / fp16 MFMA peak / products per fp32 product; on real data the pipe itself sustains "
+                                    "0.68-0.76 of that nominal figure (power: profiles/r05_mfma_power_probe.txt)"}
                     # the clock this mode runs at (the bf16 matrix pipe draws more power than the fp32 one: the chip throttles)
                     add_clock(roof, clock_under_load(ctx, lambda: model(x, attention_mask=amask), max(2000, int(400 * 1e3 * e3 / args.steps))))
         finally:
             model.set_precision("fp32")
-        return {"precision": "bf16x3 (fp32 operands as exact 3 x bf16 sums, 6 bf16 MFMA products per fp32 product, fp32 accumulate)",
-                "value": round(B * L / SAMPLE_RATE * args.steps / e3, 2), "unit": "audio-seconds/s",
-                "ms_per_step": round(1e3 * e3 / args.steps, 3), "roofline": roof,
-                "max_abs_logit_diff_vs_fp32_path": float((out3 - ref_logits).abs().max()),
-                "note": "opt-in mode, not the headline; logit error vs the fp64 reference equals the fp32 path's (tests/test_model_gpu.py)"}
+        o = {"precision": ALT_NOTE[prec],
+             "value": round(B * L / SAMPLE_RATE * args.steps / e3, 2), "unit": "audio-seconds/s",
+             "ms_per_step": round(1e3 * e3 / args.steps, 3), "roofline": roof,
+             "max_abs_logit_diff_vs_fp32_path": float((out3 - ref_logits).abs().max()),
+             "note": "opt-in mode, not the headline; logit error vs the fp64 reference at the fp32 path's level (tests/test_model_gpu.py)"}
+        if gold_wave is not None and res.get("gold_logits") is not None:
+            o["max_abs_logit_err"] = float((out3[:2].double().cpu() - torch.from_numpy(res["gold_logits"]).double()).abs().max())
+        if prec == "f16x2":
+            o["range_overflow"] = bool(model.range_overflow())
+        return o
 
-    alt = None
+    alts = {}
     if world == 1 and args.mode == "forward" and args.precision == "fp32" and not args.no_alt:
-        try:                                                   # never let the side measurement cost the headline line
-            alt = measure_bf16x3(out)
-        except Exception as exc:                               # noqa: BLE001
-            alt = {"precision": "bf16x3", "error": repr(exc)}
+        for prec in ("bf16x3", "f16x2"):
+            try:                                               # never let the side measurement cost the headline line
+                alts[prec] = measure_alt(prec, out)
+            except Exception as exc:                           # noqa: BLE001
+                alts[prec] = {"precision": prec, "error": repr(exc)}
 
     line = None
     if rank == 0:
@@ -813,8 +827,8 @@ def main():
             line["logit_err_note"] = ("rows 0-1 of the timed batch = tests/golden/base_sample_padded.npz (sample.wav normalised + zero-padded to "
                                       f"{L}, and a noise row); max |logits - HF-PyTorch fp64 logits| over both rows, max over ranks; bar "
                                       + ("1e-3 (BASELINE.json; the reference's TF-vs-HF bar)" if args.precision != "bf16" else "0.15 (bf16 mode, self-declared)"))
-        if alt:
-            line["bf16x3"] = alt
+        for prec, alt in alts.items():
+            line[prec] = alt
         if "final_loss" in res:
             line["final_loss"] = res["final_loss"]
         if "allreduce" in res:

@@ -651,19 +651,20 @@ int launch_attention(Profiler* prof, const float* qkv, const int32_t* frame_len,
 }
 
 int launch_attention_x(Profiler* prof, const float* qkv, const uint16_t* qkv16, const int32_t* frame_len, float* ctx, int B, int T, int H,
-                       int heads, uint16_t* ctx16, hipStream_t s) {
+                       int heads, uint16_t* ctx16, hipStream_t s, const PlaneOut* planes) {
     W2V2_REQUIRE(B > 0 && T > 0 && heads > 0 && H % heads == 0, "attention: bad sizes");
     const int dh = H / heads;
     ProfScope ps(prof, FAM_ATTENTION, 4.0 * B * (double)heads * T * (double)T * dh,
                  4.0 * B * (double)T * 4.0 * H, s);
     if (gemm_get_precision() == 1 && attention_bf16_supported(dh))
         return launch_attention_fwd_bf16(qkv, qkv16, frame_len, ctx, ctx16, B, T, H, heads, nullptr, s);
-    W2V2_REQUIRE(qkv && ctx, "attention: null operand");
-    AttnArgs a{qkv, frame_len, ctx, B, T, H, heads, 1.0f / sqrtf((float)dh)};
+    W2V2_REQUIRE(qkv && (ctx || (planes && planes->p)), "attention: null operand");
     W2V2_REQUIRE(!ctx16, "attention: a bf16 shadow output needs the bf16 kernel (precision 1, head size 64)");
-    if (gemm_get_precision() == 2 && tune_int("W2V2_SPLIT_ATTN", 1) != 0 && attention_split_supported(dh) && H % 4 == 0 &&
+    if (gemm_get_precision() >= 2 && tune_int("W2V2_SPLIT_ATTN", 1) != 0 && attention_split_supported(dh) && H % 4 == 0 &&
         ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(ctx)) & 15) == 0)
-        return launch_attention_split(qkv, frame_len, ctx, B, T, H, heads, s);     // fp32-level results, bf16 matrix cores
+        return launch_attention_split(qkv, frame_len, ctx, B, T, H, heads, s, planes);     // fp32-level results, bf16 matrix cores
+    W2V2_REQUIRE(ctx && !(planes && planes->p), "attention: a plane output needs the split kernel (precision modes 2 / 3, head size 64)");
+    AttnArgs a{qkv, frame_len, ctx, B, T, H, heads, 1.0f / sqrtf((float)dh)};
     switch (dh) {
         case 32: return launch_attn<32>(a, s);
         case 64: return launch_attn<64>(a, s);

@@ -37,9 +37,10 @@ constexpr int STAGE = 6 * PLANE;        // K planes 0..2, then V^T planes 0..2
 struct AttnSplitArgs {
     const float* qkv;           // (B, T, 3H): q | k | v
     const int32_t* frame_len;   // (B) or null
-    float* ctx;                 // (B, T, H)
+    float* ctx;                 // (B, T, H), or null when only the planes are wanted
     int B, T, H, heads;
     float scale;
+    PlaneOut planes;            // optional planes of ctx for the out-projection GEMM (gemm_split_sw.hip)
 };
 
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
@@ -261,16 +262,20 @@ __global__ __launch_bounds__(NT, 2) void attention_split_kernel(AttnSplitArgs a)
 
     // ---- normalise and store: O^T rows are d = 32 dt + (r&3) + 8 (r>>2) + 4 lh, column = query ----
     const int q = q0 + li;
+    bool ovf = false;
     if (q < a.T) {
         const float inv = 1.0f / l_run;
-        float* op = a.ctx + ((int64_t)b * a.T + q) * a.H + head * DH + 4 * lh;
+        const int64_t off = ((int64_t)b * a.T + q) * a.H + head * DH + 4 * lh;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<f32x4*>(op + 32 * d + 8 * g) =
-                    f32x4{o[d][4 * g] * inv, o[d][4 * g + 1] * inv, o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv};
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {o[d][4 * g] * inv, o[d][4 * g + 1] * inv, o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv};
+                if (a.ctx) *reinterpret_cast<f32x4*>(a.ctx + off + 32 * d + 8 * g) = v;
+                if (a.planes.p) store_planes4(a.planes.p + off + 32 * d + 8 * g, a.planes.plane, a.planes.fmt, v, ovf);
+            }
     }
+    report_overflow(a.planes.range_flag, ovf);
 }
 
 }  // namespace
@@ -278,12 +283,14 @@ __global__ __launch_bounds__(NT, 2) void attention_split_kernel(AttnSplitArgs a)
 bool attention_split_supported(int head_dim) { return head_dim == DH; }
 
 int launch_attention_split(const float* qkv, const int32_t* frame_len, float* ctx, int B, int T, int H, int heads,
-                           hipStream_t s) {
-    W2V2_REQUIRE(qkv && ctx && B > 0 && T > 0 && heads > 0, "attention_split: bad argument");
+                           hipStream_t s, const PlaneOut* planes) {
+    const PlaneOut pl = planes ? *planes : PlaneOut{};
+    W2V2_REQUIRE(qkv && (ctx || pl.p) && B > 0 && T > 0 && heads > 0, "attention_split: bad argument");
+    W2V2_REQUIRE(!pl.p || (pl.plane % 4 == 0 && (reinterpret_cast<uintptr_t>(pl.p) & 7) == 0), "attention_split: unaligned planes");
     W2V2_REQUIRE(H / heads == DH && H % heads == 0, "attention_split: head size %d unsupported (64)", H / heads);
     W2V2_REQUIRE((H % 4) == 0 && (reinterpret_cast<uintptr_t>(qkv) & 15) == 0 && (reinterpret_cast<uintptr_t>(ctx) & 15) == 0,
                  "attention_split: unaligned buffers");
-    AttnSplitArgs a{qkv, frame_len, ctx, B, T, H, heads, 1.0f / sqrtf((float)DH)};
+    AttnSplitArgs a{qkv, frame_len, ctx, B, T, H, heads, 1.0f / sqrtf((float)DH), pl};
     constexpr size_t lds = 2 * STAGE;
     static std::atomic<bool> attr_set{false};   // (idempotent call; atomic so concurrent host threads agree on the flag)
     if (!attr_set) {

@@ -69,6 +69,13 @@ const char* family_name(int f);
 // bf16x3), or two fp16 planes of x S (precision mode f16x2; helpers further down)
 enum PlaneFmt { PF_BF16X3 = 0, PF_F16X2 = 1 };
 constexpr int plane_count(int fmt) { return fmt == PF_F16X2 ? 2 : 3; }
+// where a producing kernel leaves the planes of its output for the consumer GEMM (same element layout as the fp32 output; null p = none)
+struct PlaneOut {
+    uint16_t* p = nullptr;
+    int64_t plane = 0;         // elements between planes
+    int fmt = PF_BF16X3;
+    int* range_flag = nullptr; // f16x2: sticky overflow flag in device memory
+};
 
 // Kernel launches actually enqueued, per family (an op-level call may enqueue several kernels: main + tail tiles, a partial
 // and a final reduction ...).  Every launch in csrc/ goes through W2V2_LAUNCH; the family is the innermost live ProfScope's
@@ -226,7 +233,8 @@ int launch_layer_norm(Profiler* prof, const float* x, float* y, const float* gam
                       const float* beta, int64_t rows, int C, float eps, int act, hipStream_t s);
 
 int launch_layer_norm_x(Profiler* prof, const float* x, float* y, const float* gamma, const float* beta, int64_t rows,
-                        int C, float eps, int act, uint16_t* y16 /* optional bf16 shadow of y */, hipStream_t s);
+                        int C, float eps, int act, uint16_t* y16 /* optional bf16 shadow of y */, hipStream_t s,
+                        const PlaneOut* planes = nullptr /* optional planes of y (precision modes bf16x3 / f16x2; C % 4 == 0) */);
 
 int64_t conv0_ws_floats(int B, int64_t L, int K, int stride, int C);
 int launch_conv0(Profiler* prof, const float* wave, const float* kernel, const float* bias,
@@ -235,7 +243,8 @@ int launch_conv0(Profiler* prof, const float* wave, const float* kernel, const f
 
 int launch_conv0_x(Profiler* prof, const float* wave, const float* kernel, const float* bias,
                    const float* gamma, const float* beta, float* out, uint16_t* out16 /* optional bf16 shadow */, float* ws,
-                   int B, int64_t L, int K, int stride, int C, float eps, int norm_mode, int act, hipStream_t s);
+                   int B, int64_t L, int K, int stride, int C, float eps, int norm_mode, int act, hipStream_t s,
+                   const PlaneOut* planes = nullptr /* optional planes of the output (the K = 10, stride 5, C % 4 == 0 kernel only) */);
 // fp32 -> bf16 (nearest even): plain copy, and [K][N] -> [N][K] transpose (GEMM weight shadows)
 int launch_to_bf16(const float* x, uint16_t* y, int64_t n, hipStream_t s);
 // one 64 x 64 tile of one weight for the single-launch shadow refresh (shadow.hip): w (K, N) fp32 -> wt (N, K) bf16 and / or
@@ -280,11 +289,13 @@ int launch_qkv_pack(float* packed_w, float* packed_b, const float* const w[3], c
 int launch_qkv_unpack(const float* packed_w, const float* packed_b, float* const w[3], float* const b[3], int H, hipStream_t s);
 bool attention_bf16_supported(int head_size);   // attention_bf16.hip: head size 64
 bool attention_split_supported(int head_size);  // attention_split.hip (precision mode 2): head size 64
-int launch_attention_split(const float* qkv, const int32_t* frame_len, float* ctx, int B, int T, int H, int heads, hipStream_t s);
+int launch_attention_split(const float* qkv, const int32_t* frame_len, float* ctx, int B, int T, int H, int heads, hipStream_t s,
+                           const PlaneOut* planes = nullptr /* optional planes of ctx; ctx itself may then be null */);
 // qkv16: optional bf16 shadow of qkv (precision mode 1 with head size 64 reads ONLY it; qkv may then be null.  Without it that
 // kernel rounds qkv into scratch first).  ctx may be null when ctx16 is given.
 int launch_attention_x(Profiler* prof, const float* qkv, const uint16_t* qkv16, const int32_t* frame_len, float* ctx, int B, int T, int H,
-                       int heads, uint16_t* ctx16 /* optional bf16 shadow of ctx (bf16 kernel only) */, hipStream_t s);
+                       int heads, uint16_t* ctx16 /* optional bf16 shadow of ctx (bf16 kernel only) */, hipStream_t s,
+                       const PlaneOut* planes = nullptr /* optional planes of ctx (split kernel only: precision modes 2 / 3, head size 64) */);
 
 int launch_frame_lengths(Profiler* prof, const int32_t* mask, int32_t* frame_len, int B, int64_t L,
                          const int32_t* ks, const int32_t* ss, int nl, hipStream_t s);

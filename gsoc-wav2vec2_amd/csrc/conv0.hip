@@ -35,6 +35,7 @@ struct Conv0Args {
     const float* beta;
     float* out;            // (B, T0, C)
     uint16_t* out16;       // optional bf16 shadow of out (precision mode 1: layer 1's GEMM reads it)
+    PlaneOut planes;       // optional planes of out (precision modes bf16x3 / f16x2; conv0_apply4_kernel only)
     double* partial;       // (B, nchunks, 2, C)
     float* scale_shift;    // (B, 2, C)
     const double* ln_const;   // MODE 3 (LayerNorm over channels): LN_CONST doubles, see conv0_ln_const_kernel
@@ -230,6 +231,8 @@ __global__ __launch_bounds__(256) void conv0_apply4_kernel(Conv0Args a, int tpr 
     }
     float* __restrict__ orow = a.out ? a.out + ((int64_t)b * a.T0 + t0) * a.C + c : nullptr;
     uint16_t* __restrict__ orow16 = a.out16 ? a.out16 + ((int64_t)b * a.T0 + t0) * a.C + c : nullptr;
+    uint16_t* __restrict__ prow = a.planes.p ? a.planes.p + ((int64_t)b * a.T0 + t0) * a.C + c : nullptr;
+    bool ovf = false;
     for (int t = fp; t < nt; t += fpb) {
         const float* xp = xs + t * ST;
         f32x4_c0 y = bs;
@@ -274,7 +277,9 @@ __global__ __launch_bounds__(256) void conv0_apply4_kernel(Conv0Args a, int tpr 
             h[1] = pack_bf16_rne(y[2], y[3]);
             *reinterpret_cast<u32x2_c0*>(orow16 + (int64_t)t * a.C) = h;
         }
+        if (prow) store_planes4(prow + (int64_t)t * a.C, a.planes.plane, a.planes.fmt, y, ovf);
     }
+    report_overflow(a.planes.range_flag, ovf);
 }
 
 // (b, c): fp64 combine of chunk partials -> scale = rsqrt(var+eps)*gamma, shift = beta - mean*scale
@@ -425,17 +430,25 @@ int launch_conv0(Profiler* prof, const float* wave, const float* kernel, const f
 
 int launch_conv0_x(Profiler* prof, const float* wave, const float* kernel, const float* bias,
                    const float* gamma, const float* beta, float* out, uint16_t* out16, float* ws, int B, int64_t L,
-                   int K, int stride, int C, float eps, int norm_mode, int act, hipStream_t s) {
-    W2V2_REQUIRE(wave && kernel && (out || out16), "conv0: null operand");
+                   int K, int stride, int C, float eps, int norm_mode, int act, hipStream_t s, const PlaneOut* planes) {
+    const PlaneOut pl = planes ? *planes : PlaneOut{};
+    W2V2_REQUIRE(wave && kernel && (out || out16 || pl.p), "conv0: null operand");
+    // planes come out of the 16-byte-store kernel only (K = 10, stride 5, C / 4 lanes tiling the block, aligned operands); other
+    // geometries: write fp32 and split it (launch_split_planes)
+    W2V2_REQUIRE(!pl.p || (K == 10 && stride == 5 && C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0 && pl.plane % 4 == 0 &&
+                           (reinterpret_cast<uintptr_t>(pl.p) & 7) == 0 &&
+                           ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(kernel) | reinterpret_cast<uintptr_t>(bias) |
+                             reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0),
+                 "conv0: plane output needs the K = 10 / stride 5 geometry, C %% 4 == 0 and 16-byte aligned operands");
     W2V2_REQUIRE(B > 0 && C > 0 && K > 0 && K <= 32 && stride > 0 && L >= K,
                  "conv0: unsupported B=%d C=%d K=%d stride=%d L=%lld", B, C, K, stride, (long long)L);
     W2V2_REQUIRE(norm_mode >= 0 && norm_mode <= 2, "conv0: bad norm_mode %d", norm_mode);
     Conv0Args a;
-    a.wave = wave; a.kernel = kernel; a.bias = bias; a.gamma = gamma; a.beta = beta; a.out = out; a.out16 = out16;
+    a.wave = wave; a.kernel = kernel; a.bias = bias; a.gamma = gamma; a.beta = beta; a.out = out; a.out16 = out16; a.planes = pl;
     a.L = L; a.K = K; a.stride = stride; a.C = C; a.eps = eps; a.norm_mode = norm_mode; a.act = act;
     a.T0 = (int)(1 + (L - K) / stride);
     a.nchunks = conv0_nchunks(L, K, stride);
-    const double out_bytes = (out ? 4.0 : 0.0) * B * (double)a.T0 * C + (out16 ? 2.0 : 0.0) * B * (double)a.T0 * C, in_bytes = 4.0 * B * (double)L;
+    const double out_bytes = ((out ? 4.0 : 0.0) + (out16 ? 2.0 : 0.0) + (pl.p ? 2.0 * plane_count(pl.fmt) : 0.0)) * B * (double)a.T0 * C, in_bytes = 4.0 * B * (double)L;
     const double flops = 2.0 * B * (double)a.T0 * C * K;
     if (norm_mode == 1) {
         ProfScope ps(prof, FAM_CONV0_APPLY, flops, in_bytes + out_bytes, s);

@@ -24,8 +24,9 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict
                                                          uint16_t* __restrict__ y16,   // optional bf16 shadow of y
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta,
-                                                         int64_t rows, int C, float eps, int act) {
+                                                         int64_t rows, int C, float eps, int act, PlaneOut pl) {
     const int lane = threadIdx.x & 63;
+    bool ovf = false;
     const int64_t stride = (int64_t)gridDim.x * 4;
     int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict
                         if (c + e < C) hr[e] = (uint16_t)pack_bf16_rne(o[e], 0.f);
                 }
             }
+            if (pl.p) store_planes4(pl.p + row * C + c, pl.plane, pl.fmt, f32x4_t{o[0], o[1], o[2], o[3]}, ovf);      // (launcher: C % 4 == 0)
             if (!y) continue;       // bf16-only output: the consumer streams the shadow
             if (vec) {
                 *reinterpret_cast<float4*>(yr + c) = make_float4(o[0], o[1], o[2], o[3]);
@@ -111,6 +113,7 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict
 #pragma unroll
         for (int i = 0; i < NV; ++i) v[i] = nx[i];
     }
+    report_overflow(pl.range_flag, ovf);
 }
 
 
@@ -123,8 +126,9 @@ template <int NV, bool DROP>      // DROP = false: plain LayerNorm of `a` (res, 
 __global__ __launch_bounds__(256) void layer_norm_drop_kernel(const float* __restrict__ a, const float* __restrict__ res, float* __restrict__ t1,
                                                               float* __restrict__ y, uint16_t* __restrict__ y16, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, int64_t rows, int C, float eps, float p, uint64_t seed,
-                                                              uint32_t stream) {
+                                                              uint32_t stream, PlaneOut pl) {
     const int lane = threadIdx.x & 63;
+    bool ovf = false;
     const int64_t stride = (int64_t)gridDim.x * 4;
     int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -186,11 +190,13 @@ __global__ __launch_bounds__(256) void layer_norm_drop_kernel(const float* __res
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k] = v[i][k] * rstd * gv[i][k] + bv[i][k];
             if (y16) *reinterpret_cast<uint2*>(y16 + row * C + c) = make_uint2(pack_bf16_rne(o[0], o[1]), pack_bf16_rne(o[2], o[3]));
+            if (pl.p) store_planes4(pl.p + row * C + c, pl.plane, pl.fmt, o, ovf);
             if (y) *reinterpret_cast<ln_f32x4*>(y + row * C + c) = o;
         }
         if (!more) break;
         row = next;
     }
+    report_overflow(pl.range_flag, ovf);
 }
 
 }  // namespace
@@ -211,9 +217,9 @@ int launch_layer_norm_drop(Profiler* prof, const float* a, const float* res, flo
     // (two instances only: hipcc 7.2 crashes in its machine-copy-propagation pass on the <2> instance of this kernel, and the encoder widths
     //  this pass serves are 768 / 1024; narrower rows -- the tiny test configurations -- leave the upper lanes of the <4> instance idle)
     if (C <= 1024)
-        W2V2_LAUNCH((layer_norm_drop_kernel<4, true>), grid, block, 0, s, a, res, t1, y, y16, gamma, beta, rows, C, eps, p, seed, stream);
+        W2V2_LAUNCH((layer_norm_drop_kernel<4, true>), grid, block, 0, s, a, res, t1, y, y16, gamma, beta, rows, C, eps, p, seed, stream, PlaneOut{});
     else
-        W2V2_LAUNCH((layer_norm_drop_kernel<8, true>), grid, block, 0, s, a, res, t1, y, y16, gamma, beta, rows, C, eps, p, seed, stream);
+        W2V2_LAUNCH((layer_norm_drop_kernel<8, true>), grid, block, 0, s, a, res, t1, y, y16, gamma, beta, rows, C, eps, p, seed, stream, PlaneOut{});
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -224,8 +230,10 @@ int launch_layer_norm(Profiler* prof, const float* x, float* y, const float* gam
 }
 
 int launch_layer_norm_x(Profiler* prof, const float* x, float* y, const float* gamma, const float* beta, int64_t rows,
-                        int C, float eps, int act, uint16_t* y16, hipStream_t s) {
-    W2V2_REQUIRE(x && (y || y16) && gamma && beta, "layer_norm: null operand");
+                        int C, float eps, int act, uint16_t* y16, hipStream_t s, const PlaneOut* planes) {
+    const PlaneOut pl = planes ? *planes : PlaneOut{};
+    W2V2_REQUIRE(x && (y || y16 || pl.p) && gamma && beta, "layer_norm: null operand");
+    W2V2_REQUIRE(!pl.p || ((C & 3) == 0 && pl.plane % 4 == 0 && (reinterpret_cast<uintptr_t>(pl.p) & 7) == 0), "layer_norm: plane output needs C %% 4 == 0 and 8-byte aligned planes");
     W2V2_REQUIRE(rows > 0 && C > 0 && C <= 2048, "layer_norm: rows=%lld C=%d unsupported (C <= 2048)",
                  (long long)rows, C);
     // 4 blocks per CU (16 waves), each wave looping over rows
@@ -233,7 +241,7 @@ int launch_layer_norm_x(Profiler* prof, const float* x, float* y, const float* g
     static int cap = -1;
     if (cap < 0) cap = tune_int("W2V2_LN_BLOCKS", 256 * 4);      // 512 / 1024 / 2048 / 4096 blocks -> 1.14 / 1.06 / 1.10 / 1.26 ms for the 25 LayerNorms of a base forward
     dim3 grid((unsigned)(want < cap ? want : cap)), block(256);
-    ProfScope ps(prof, FAM_LAYERNORM, 8.0 * rows * C, (4.0 + (y ? 4.0 : 0.0) + (y16 ? 2.0 : 0.0)) * rows * C, s);
+    ProfScope ps(prof, FAM_LAYERNORM, 8.0 * rows * C, (4.0 + (y ? 4.0 : 0.0) + (y16 ? 2.0 : 0.0) + (pl.p ? 2.0 * plane_count(pl.fmt) : 0.0)) * rows * C, s);
     // Round 4: plain rows (no activation, C % 4 == 0, C > 512, 16-byte aligned) take the row loop of the fused dropout kernel, whose next
     // row is loaded into the registers just consumed: 6.2 TB/s measured there against 4.8 for layer_norm_kernel's copy-forward prefetch.
     // Same element arithmetic in the same order: bit-identical.
@@ -241,20 +249,20 @@ int launch_layer_norm_x(Profiler* prof, const float* x, float* y, const float* g
         ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0 &&
         (reinterpret_cast<uintptr_t>(y16) & 7) == 0) {
         if (C <= 1024)
-            W2V2_LAUNCH((layer_norm_drop_kernel<4, false>), grid, block, 0, s, x, nullptr, nullptr, y, y16, gamma, beta, rows, C, eps, 0.f, (uint64_t)0, 0u);
+            W2V2_LAUNCH((layer_norm_drop_kernel<4, false>), grid, block, 0, s, x, nullptr, nullptr, y, y16, gamma, beta, rows, C, eps, 0.f, (uint64_t)0, 0u, pl);
         else
-            W2V2_LAUNCH((layer_norm_drop_kernel<8, false>), grid, block, 0, s, x, nullptr, nullptr, y, y16, gamma, beta, rows, C, eps, 0.f, (uint64_t)0, 0u);
+            W2V2_LAUNCH((layer_norm_drop_kernel<8, false>), grid, block, 0, s, x, nullptr, nullptr, y, y16, gamma, beta, rows, C, eps, 0.f, (uint64_t)0, 0u, pl);
         W2V2_HIP_CHECK(hipGetLastError());
         return W2V2_OK;
     }
     if (C <= 256)
-        W2V2_LAUNCH(layer_norm_kernel<1>, grid, block, 0, s, x, y, y16, gamma, beta, rows, C, eps, act);
+        W2V2_LAUNCH(layer_norm_kernel<1>, grid, block, 0, s, x, y, y16, gamma, beta, rows, C, eps, act, pl);
     else if (C <= 512)
-        W2V2_LAUNCH(layer_norm_kernel<2>, grid, block, 0, s, x, y, y16, gamma, beta, rows, C, eps, act);
+        W2V2_LAUNCH(layer_norm_kernel<2>, grid, block, 0, s, x, y, y16, gamma, beta, rows, C, eps, act, pl);
     else if (C <= 1024)
-        W2V2_LAUNCH(layer_norm_kernel<4>, grid, block, 0, s, x, y, y16, gamma, beta, rows, C, eps, act);
+        W2V2_LAUNCH(layer_norm_kernel<4>, grid, block, 0, s, x, y, y16, gamma, beta, rows, C, eps, act, pl);
     else
-        W2V2_LAUNCH(layer_norm_kernel<8>, grid, block, 0, s, x, y, y16, gamma, beta, rows, C, eps, act);
+        W2V2_LAUNCH(layer_norm_kernel<8>, grid, block, 0, s, x, y, y16, gamma, beta, rows, C, eps, act, pl);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }

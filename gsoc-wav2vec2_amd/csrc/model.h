@@ -62,6 +62,20 @@ struct w2v2_model {
     struct SplitPlanes { uint16_t* p = nullptr; int64_t elems = 0; uint64_t epoch = 0; };
     std::unordered_map<const float*, SplitPlanes> w48;     // keyed by the fp32 matrix (a variable, or a transposed copy)
     uint64_t w48_epoch = 1;                                 // bumped whenever the variables change: entries re-split lazily
+    // precision modes 2 / 3 on the plane-fed GEMM (gemm_split_sw.hip; w2v2_api.hip::w2v2_ensure_planes): the planes of every GEMM
+    // operand, written by its producer (three bf16 planes or two fp16 planes per element: PlaneFmt), and the weights as that kernel's
+    // LDS images, built on first use and re-split lazily after the variables change (w48_epoch).  Stream order lets one buffer serve
+    // every layer: attention input | ctx | FFN input | FFN hidden.
+    struct PlaneBuf { uint16_t* p = nullptr; int64_t plane = 0; };
+    bool opt_planes = true;                                  // W2V2_OPT_SPLIT_PLANES
+    int pl_fmt = -1, pl_B = 0;
+    int64_t pl_L = 0;
+    std::vector<void*> pl_allocs;
+    std::vector<PlaneBuf> conv48;                            // conv-stack outputs 0 .. NC-2
+    PlaneBuf ln512_48, attn_in48, ctx48, ffn_in48, ffn48;
+    int* range_flag = nullptr;                               // sticky fp16 saturation flag (device)
+    struct SplitImages { uint16_t* img = nullptr; float* scale_ws = nullptr; int64_t elems = 0; uint64_t epoch = 0; };
+    std::unordered_map<const float*, SplitImages> wimg[2];   // [PlaneFmt], keyed by the fp32 matrix
     w2v2::Profiler* prof = nullptr;
     struct TrainState* train = nullptr;      // owned by w2v2_train.hip (null until the first training call)
 
@@ -85,6 +99,10 @@ int w2v2_ensure_workspace(w2v2_model* m, int B, int64_t L);
 int w2v2_split_planes(w2v2_model* m, const float* W, int K, int N, hipStream_t s, const uint16_t** planes);
 // whether GEMM (M, N, K) x nbatch with this A should take the split kernel in the model's current precision mode
 bool w2v2_use_split_gemm(const w2v2_model* m, const float* A, int64_t lda, int64_t strideA, int64_t ldb, int M, int N, int K, int nbatch);
+// precision modes 2 / 3 with W2V2_OPT_SPLIT_PLANES: the plane buffers of a (B, L) forward in the mode's format; the LDS images (and,
+// f16x2, the accumulator scale) of the (K, N) fp32 matrix W
+int w2v2_ensure_planes(w2v2_model* m, int B, int64_t L, int fmt);
+int w2v2_split_images(w2v2_model* m, const float* W, int K, int N, int fmt, hipStream_t s, const uint16_t** img, const float** out_scale);
 // implemented in w2v2_train.hip
 void w2v2_train_destroy(w2v2_model* m);
 void w2v2_train_invalidate(w2v2_model* m);

@@ -187,7 +187,18 @@ static void build_inventory(w2v2_model* m) {
     }
 }
 
+static void free_planes(w2v2_model* m) {
+    for (void* p : m->pl_allocs) (void)hipFree(p);
+    m->pl_allocs.clear();
+    m->conv48.clear();
+    m->ln512_48 = m->attn_in48 = m->ctx48 = m->ffn_in48 = m->ffn48 = w2v2_model::PlaneBuf{};
+    m->pl_fmt = -1;
+    m->pl_B = 0;
+    m->pl_L = 0;
+}
+
 static void free_workspace(w2v2_model* m) {
+    free_planes(m);
     for (void* p : m->allocs) (void)hipFree(p);
     m->allocs.clear();
     for (void* p : m->sh_allocs) (void)hipFree(p);
@@ -382,8 +393,64 @@ int w2v2_ensure_shadows(w2v2_model* m, int B, int T, hipStream_t s) {
     return W2V2_OK;
 }
 
+// ---- precision modes 2 / 3: operand planes (gemm_split_sw.hip) ----------------------------------------------------------------
+int w2v2_ensure_planes(w2v2_model* m, int B, int64_t L, int fmt) {
+    if (m->pl_fmt == fmt && m->pl_B == B && m->pl_L == L) return W2V2_OK;
+    free_planes(m);
+    const w2v2_config& c = m->cfg;
+    const int np = plane_count(fmt);
+    auto alloc = [&](w2v2_model::PlaneBuf& b, int64_t elems) -> int {
+        b.plane = (elems + 7) & ~(int64_t)7;                 // 16-byte aligned planes
+        void* p = nullptr;
+        W2V2_HIP_CHECK(hipMalloc(&p, (size_t)b.plane * np * sizeof(uint16_t)));
+        m->pl_allocs.push_back(p);
+        b.p = reinterpret_cast<uint16_t*>(p);
+        return W2V2_OK;
+    };
+    const int NC = c.num_conv_layers;
+    m->conv48.resize(NC > 1 ? NC - 1 : 0);
+    for (int i = 0; i + 1 < NC; ++i)
+        if (int e = alloc(m->conv48[i], (int64_t)B * m->conv_T[i] * c.filter_sizes[i])) return e;
+    const int64_t BT = (int64_t)B * m->conv_T[NC - 1], H = c.hidden_size;
+    if (int e = alloc(m->ln512_48, BT * c.filter_sizes[NC - 1])) return e;
+    if (int e = alloc(m->attn_in48, BT * H)) return e;
+    if (int e = alloc(m->ctx48, BT * H)) return e;
+    if (int e = alloc(m->ffn_in48, BT * H)) return e;
+    if (int e = alloc(m->ffn48, BT * c.intermediate_size)) return e;
+    if (!m->range_flag) {
+        W2V2_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m->range_flag), sizeof(int)));
+        W2V2_HIP_CHECK(hipMemset(m->range_flag, 0, sizeof(int)));
+    }
+    m->pl_fmt = fmt;
+    m->pl_B = B;
+    m->pl_L = L;
+    return W2V2_OK;
+}
+
+int w2v2_split_images(w2v2_model* m, const float* W, int K, int N, int fmt, hipStream_t s, const uint16_t** img, const float** out_scale) {
+    W2V2_REQUIRE(W && (fmt == PF_BF16X3 || fmt == PF_F16X2), "split_images: bad argument");
+    w2v2_model::SplitImages& e = m->wimg[fmt][W];
+    const int64_t elems = (int64_t)plane_count(fmt) * K * N;
+    if (!e.img || e.elems != elems) {
+        if (e.img) (void)hipFree(e.img);
+        e.img = nullptr;
+        W2V2_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e.img), (size_t)elems * sizeof(uint16_t)));
+        if (!e.scale_ws) W2V2_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e.scale_ws), 2 * sizeof(float)));
+        e.elems = elems;
+        e.epoch = 0;
+    }
+    if (e.epoch != m->w48_epoch) {
+        if (int err = launch_split_weight_sw(W, e.img, K, N, fmt, e.scale_ws, s)) return err;
+        e.epoch = m->w48_epoch;
+    }
+    *img = e.img;
+    *out_scale = fmt == PF_F16X2 ? e.scale_ws + 1 : nullptr;
+    return W2V2_OK;
+}
+
 bool w2v2_use_split_gemm(const w2v2_model* m, const float* A, int64_t lda, int64_t strideA, int64_t ldb, int M, int N, int K, int nbatch) {
-    if (m->precision != W2V2_PRECISION_BF16X3 || ldb != N || N % 256 != 0) return false;
+    // (precision mode 3 falls back to this six-product kernel for the shapes / call sites its plane-fed kernel does not serve)
+    if (m->precision < W2V2_PRECISION_BF16X3 || ldb != N || N % 256 != 0) return false;
     if (tune_int("W2V2_SPLIT_GEMM", 1) == 0) return false;      // (tools-only: tools/nll_drift_probe.py separates the GEMMs from the attention)
     // (below ~half a wave of 128 x 256 tiles the fp32 path's small tiles and split-K serve a single utterance better)
     const int64_t split_tiles = (int64_t)((M + 127) / 128) * (N / 256) * nbatch;
@@ -479,6 +546,12 @@ void w2v2_destroy(w2v2_model* m) {
     for (void* p : m->w16_allocs) (void)hipFree(p);
     for (auto& kv : m->w48)
         if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto& tab : m->wimg)
+        for (auto& kv : tab) {
+            if (kv.second.img) (void)hipFree(kv.second.img);
+            if (kv.second.scale_ws) (void)hipFree(kv.second.scale_ws);
+        }
+    if (m->range_flag) (void)hipFree(m->range_flag);
     if (m->pos_w16) (void)hipFree(m->pos_w16);
     if (m->shadow_jobs) (void)hipFree(m->shadow_jobs);
     profiler_destroy(m->prof);
@@ -587,7 +660,7 @@ int64_t w2v2_num_frames(const w2v2_model* m, int64_t n) {
 
 int w2v2_set_precision(w2v2_model* m, int32_t mode) {
     W2V2_REQUIRE(m, "set_precision: null model");
-    W2V2_REQUIRE(mode == W2V2_PRECISION_FP32 || mode == W2V2_PRECISION_BF16 || mode == W2V2_PRECISION_BF16X3, "set_precision: unknown mode %d", mode);
+    W2V2_REQUIRE(mode >= W2V2_PRECISION_FP32 && mode <= W2V2_PRECISION_F16X2, "set_precision: unknown mode %d", mode);
     m->precision = mode;
     return W2V2_OK;
 }
@@ -598,6 +671,7 @@ int w2v2_set_option(w2v2_model* m, int32_t option, int32_t value) {
     switch (option) {
         case W2V2_OPT_BF16_SHADOWS: m->opt_shadows = value != 0; return W2V2_OK;
         case W2V2_OPT_KEEP_ACTIVATIONS: m->opt_keep_acts = value != 0; return W2V2_OK;
+        case W2V2_OPT_SPLIT_PLANES: m->opt_planes = value != 0; return W2V2_OK;
         default: set_error("set_option: unknown option %d", option); return W2V2_EINVAL;
     }
 }
@@ -606,8 +680,22 @@ int w2v2_get_option(const w2v2_model* m, int32_t option) {
     switch (option) {
         case W2V2_OPT_BF16_SHADOWS: return m->opt_shadows ? 1 : 0;
         case W2V2_OPT_KEEP_ACTIVATIONS: return m->opt_keep_acts ? 1 : 0;
+        case W2V2_OPT_SPLIT_PLANES: return m->opt_planes ? 1 : 0;
         default: return W2V2_EINVAL;
     }
+}
+
+int w2v2_range_overflow(w2v2_model* m, int32_t* flag, void* stream) {
+    W2V2_REQUIRE(m && flag, "range_overflow: null argument");
+    *flag = 0;
+    if (!m->range_flag) return W2V2_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int v = 0;
+    W2V2_HIP_CHECK(hipMemcpyAsync(&v, m->range_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    W2V2_HIP_CHECK(hipStreamSynchronize(s));
+    if (v) W2V2_HIP_CHECK(hipMemsetAsync(m->range_flag, 0, sizeof(int), s));
+    *flag = v != 0;
+    return W2V2_OK;
 }
 
 int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const int32_t* mask,
@@ -646,56 +734,124 @@ int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const i
     auto W16 = [&](const float* w) -> const uint16_t* { return sh ? m->w16[w] : nullptr; };
     // Precision mode 2: fp32 operands, each an exact sum of three bf16 terms, six MFMA products (gemm_split.hip).  The
     // weight planes are built on first use; shapes the split kernel does not take (lm_head: N = 32) stay on the fp32 MFMA.
+    // Precision modes 2 / 3 with operand planes (W2V2_OPT_SPLIT_PLANES, default): every producer of a GEMM operand writes its planes
+    // -- three bf16 terms (bf16x3) or two fp16 terms (f16x2) per element -- and the GEMM streams them (gemm_split_sw.hip).  Whether a
+    // call site does is decided here from its shape, so that the producer knows: whole 256-column tiles, K % 64 == 0, 16-byte aligned
+    // rows, and enough tiles to fill the chip (below that the fp32 path's small tiles serve a single utterance better).
+    using PlaneBuf = w2v2_model::PlaneBuf;
+    const int NC = c.num_conv_layers;
+    const bool pm = m->precision >= W2V2_PRECISION_BF16X3 && m->opt_planes;
+    const int fmt = m->precision == W2V2_PRECISION_F16X2 ? PF_F16X2 : PF_BF16X3;
+    const bool keep = w2v2_keep_activations(m);
+    auto site = [&](int64_t M_, int N_, int K_, int nb, int64_t lda_, int64_t sA_) {
+        return pm && N_ % 256 == 0 && K_ % 64 == 0 && lda_ % 8 == 0 && sA_ % 8 == 0 && 128 * lda_ < (1 << 29) && ((M_ + 127) / 128) * (N_ / 256) * nb >= 128;
+    };
+    std::vector<char> cp(NC + 1, 0);             // cp[i]: conv layer i's GEMM streams the planes of conv output i - 1
+    for (int i = 1; i < NC; ++i)
+        cp[i] = site(m->conv_T[i], c.filter_sizes[i], c.kernal_sizes[i] * c.filter_sizes[i - 1], B, (int64_t)c.strides[i] * c.filter_sizes[i - 1],
+                     (int64_t)m->conv_T[i - 1] * c.filter_sizes[i - 1]) && c.filter_sizes[i - 1] % 4 == 0;
+    const int C512 = c.filter_sizes[NC - 1];
+    const bool p_proj = site(BT, H, C512, 1, C512, 0) && C512 % 4 == 0, p_qkv = site(BT, 3 * H, H, 1, H, 0) && H % 4 == 0, p_out = site(BT, H, H, 1, H, 0),
+               p_f1 = site(BT, F, H, 1, H, 0), p_f2 = site(BT, H, F, 1, F, 0) && F % 8 == 0;
+    bool any_planes = p_proj || p_qkv || p_out || p_f1 || p_f2;
+    for (int i = 1; i < NC; ++i) any_planes = any_planes || cp[i];
+    if (any_planes)
+        if (int e = w2v2_ensure_planes(m, B, L, fmt)) return e;
+    auto PO = [&](const PlaneBuf& b) {
+        PlaneOut o;
+        o.p = b.p; o.plane = b.plane; o.fmt = fmt; o.range_flag = m->range_flag;
+        return o;
+    };
+    // Apl: the planes of A (the call site was decided above), Cpl: where the planes of the result go, need_f32: the fp32 result is
+    // wanted as well (a tap under W2V2_OPT_KEEP_ACTIVATIONS) -- the plane epilogue writes one or the other, so it is then split off C.
     auto gemm = [&](const float* A, const uint16_t* A16, int64_t lda, int64_t strideA, const float* Bw, int64_t ldb, float* Cc,
                     uint16_t* C16, int64_t ldc, int64_t strideC, const float* bias, const float* res, int M, int N, int K,
-                    int nbatch, int act_) -> int {
+                    int nbatch, int act_, const PlaneBuf* Apl = nullptr, const PlaneBuf* Cpl = nullptr, bool need_f32 = true) -> int {
+        auto split_out = [&]() -> int {
+            W2V2_REQUIRE(Cc && ldc == N && (nbatch == 1 || strideC == (int64_t)M * N), "forward: plane output of a strided result");
+            return launch_split_planes(Cc, Cpl->p, Cpl->plane, (int64_t)nbatch * M * N, fmt, m->range_flag, s);
+        };
+        if (Apl) {
+            const uint16_t* img = nullptr;
+            const float* sc = nullptr;
+            if (int e = w2v2_split_images(m, Bw, K, N, fmt, s, &img, &sc)) return e;
+            const bool planes_only = Cpl && !need_f32;
+            if (int e = launch_gemm_split_sw(pf, fmt, Apl->p, Apl->plane, lda, strideA, img, sc, planes_only ? nullptr : Cc, planes_only ? Cpl->p : nullptr,
+                                             planes_only ? Cpl->plane : 0, ldc, strideC, bias, res, M, N, K, nbatch, act_, m->range_flag, s))
+                return e;
+            return (Cpl && !planes_only) ? split_out() : W2V2_OK;
+        }
+        int e;
         if (w2v2_use_split_gemm(m, A, lda, strideA, ldb, M, N, K, nbatch)) {
             const uint16_t* planes = nullptr;
-            if (int e = w2v2_split_planes(m, Bw, K, N, s, &planes)) return e;
-            return launch_gemm_split(pf, A, lda, strideA, planes, Cc, ldc, strideC, bias, res, M, N, K, nbatch, act_, s);
+            if (int e2 = w2v2_split_planes(m, Bw, K, N, s, &planes)) return e2;
+            e = launch_gemm_split(pf, A, lda, strideA, planes, Cc, ldc, strideC, bias, res, M, N, K, nbatch, act_, s);
+        } else if (!sh) {
+            e = launch_gemm(pf, A, lda, strideA, Bw, ldb, Cc, ldc, strideC, bias, res, M, N, K, nbatch, act_, s);
+        } else {
+            GemmShadows x;
+            x.A16 = A16; x.B16 = W16(Bw); x.C16 = C16; x.ldb16 = K;
+            e = launch_gemm_bf16_x(pf, A, lda, strideA, Bw, ldb, 0, Cc, ldc, strideC, bias, res, M, N, K, nbatch, act_, x, s);
         }
-        if (!sh) return launch_gemm(pf, A, lda, strideA, Bw, ldb, Cc, ldc, strideC, bias, res, M, N, K, nbatch, act_, s);
-        GemmShadows x;
-        x.A16 = A16; x.B16 = W16(Bw); x.C16 = C16; x.ldb16 = K;
-        return launch_gemm_bf16_x(pf, A, lda, strideA, Bw, ldb, 0, Cc, ldc, strideC, bias, res, M, N, K, nbatch, act_, x, s);
+        if (e) return e;
+        return Cpl ? split_out() : W2V2_OK;
     };
-    const int NC = c.num_conv_layers;
     const bool ffn_sh_only = sh && F % 64 == 0;      // the output dense can then always take the shadow (K = F)
 
     // ---- feature extractor (feature_extractor.py:54-59) ----
     // group-norm mode with shadows: conv0 .. conv(NC-2) feed only the next layer's GEMM; where that GEMM reads the bf16 shadow
     // the fp32 copy is not written at all (w2v2_conv_out_bf16_only)
     m->acts_skipped.clear();
+    // (planes: a conv output whose one reader streams its planes is written ONLY as planes, like the bf16-only outputs of mode 1)
+    auto planes_only_out = [&](int i) { return i + 1 < NC && cp[i + 1] && !keep; };
     for (int i = 0; i + 1 < NC; ++i)
-        if (w2v2_conv_out_bf16_only(m, i, sh) || w2v2_conv_ln_bf16_only(m, i, sh)) m->acts_skipped.push_back("conv" + std::to_string(i));
-    if (int e = launch_conv0_x(pf, wave, fe(0, "/conv/kernel"), c.conv_bias ? fe(0, "/conv/bias") : nullptr,
-                               fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"),
-                               (w2v2_conv_out_bf16_only(m, 0, sh) || w2v2_conv_ln_bf16_only(m, 0, sh)) ? nullptr : m->conv[0],
-                               sh ? m->conv16[0] : nullptr, m->conv0_ws, B, L, c.kernal_sizes[0], c.strides[0],
-                               c.filter_sizes[0], 1e-5f, layer_mode ? 2 : 0, act_ew, s))      // (layer mode: conv + LayerNorm + GELU in one pass)
-        return e;
+        if (w2v2_conv_out_bf16_only(m, i, sh) || w2v2_conv_ln_bf16_only(m, i, sh) || planes_only_out(i)) m->acts_skipped.push_back("conv" + std::to_string(i));
+    {
+        // the fused plane output needs conv0's 16-byte-store kernel (K = 10, stride 5); other geometries write fp32 and split it
+        const bool fused = NC > 1 && cp[1] && c.kernal_sizes[0] == 10 && c.strides[0] == 5 && 256 % (c.filter_sizes[0] / 4) == 0 && c.filter_sizes[0] / 4 <= 256;
+        const PlaneOut po = fused ? PO(m->conv48[0]) : PlaneOut{};
+        const bool f32_too = !(NC > 1 && cp[1]) || keep || !fused;
+        if (int e = launch_conv0_x(pf, wave, fe(0, "/conv/kernel"), c.conv_bias ? fe(0, "/conv/bias") : nullptr,
+                                   fe(0, "/layer_norm/gamma"), fe(0, "/layer_norm/beta"),
+                                   (w2v2_conv_out_bf16_only(m, 0, sh) || w2v2_conv_ln_bf16_only(m, 0, sh) || !f32_too) ? nullptr : m->conv[0],
+                                   sh ? m->conv16[0] : nullptr, m->conv0_ws, B, L, c.kernal_sizes[0], c.strides[0],
+                                   c.filter_sizes[0], 1e-5f, layer_mode ? 2 : 0, act_ew, s, fused ? &po : nullptr))      // (layer mode: conv + LayerNorm + GELU in one pass)
+            return e;
+        if (NC > 1 && cp[1] && !fused)
+            if (int e = launch_split_planes(m->conv[0], m->conv48[0].p, m->conv48[0].plane, (int64_t)B * m->conv_T[0] * c.filter_sizes[0], fmt, m->range_flag, s))
+                return e;
+    }
     for (int i = 1; i < NC; ++i) {
         const int cin = c.filter_sizes[i - 1], cout = c.filter_sizes[i];
         const int Tin = m->conv_T[i - 1], Tout = m->conv_T[i];
         uint16_t* o16 = (sh && i + 1 < NC) ? m->conv16[i] : nullptr;     // the last conv output feeds a LayerNorm
         // strided Conv1D == GEMM over an overlapping window view: lda = stride * C_in < K * C_in
+        // planes of this layer's output for the next layer's GEMM: from the GEMM epilogue (group-norm mode: bias + GELU there) or from
+        // the LayerNorm + GELU pass behind it (layer-norm mode: the GEMM output is that pass's fp32 input)
+        const bool out_pl = i + 1 < NC && cp[i + 1];
+        const PlaneBuf* opl = out_pl ? &m->conv48[i] : nullptr;
         if (int e = gemm(m->conv[i - 1], sh ? m->conv16[i - 1] : nullptr, (int64_t)c.strides[i] * cin, (int64_t)Tin * cin,
                          fe(i, "/conv/kernel"), cout, w2v2_conv_out_bf16_only(m, i, sh) ? nullptr : m->conv[i], layer_mode ? nullptr : o16, cout,
                          (int64_t)Tout * cout, c.conv_bias ? fe(i, "/conv/bias") : nullptr, nullptr, Tout, cout, c.kernal_sizes[i] * cin, B,
-                         layer_mode ? 0 : act))
+                         layer_mode ? 0 : act, cp[i] ? &m->conv48[i - 1] : nullptr, layer_mode ? nullptr : opl, keep))
             return e;
-        if (layer_mode)
-            if (int e = launch_layer_norm_x(pf, m->conv[i], w2v2_conv_ln_bf16_only(m, i, sh) ? nullptr : m->conv[i], fe(i, "/layer_norm/gamma"), fe(i, "/layer_norm/beta"),
-                                            (int64_t)B * Tout, cout, 1e-5f, act_ew, o16, s))
+        if (layer_mode) {
+            const PlaneOut po = out_pl ? PO(*opl) : PlaneOut{};
+            if (int e = launch_layer_norm_x(pf, m->conv[i], (w2v2_conv_ln_bf16_only(m, i, sh) || planes_only_out(i)) ? nullptr : m->conv[i], fe(i, "/layer_norm/gamma"),
+                                            fe(i, "/layer_norm/beta"), (int64_t)B * Tout, cout, 1e-5f, act_ew, o16, s, out_pl ? &po : nullptr))
                 return e;
+        }
     }
     // ---- feature projection (feature_extractor.py:92-95) ----
     const int C = c.filter_sizes[NC - 1];
-    if (int e = launch_layer_norm_x(pf, m->conv[NC - 1], m->ln512, m->P("feature_projection/layer_norm/gamma"),
-                                    m->P("feature_projection/layer_norm/beta"), BT, C, eps, 0, sh ? m->ln512_16 : nullptr, s))
-        return e;
+    {
+        const PlaneOut po = p_proj ? PO(m->ln512_48) : PlaneOut{};
+        if (int e = launch_layer_norm_x(pf, m->conv[NC - 1], (p_proj && !keep) ? nullptr : m->ln512, m->P("feature_projection/layer_norm/gamma"),
+                                        m->P("feature_projection/layer_norm/beta"), BT, C, eps, 0, sh ? m->ln512_16 : nullptr, s, p_proj ? &po : nullptr))
+            return e;
+    }
     if (int e = gemm(m->ln512, sh ? m->ln512_16 : nullptr, C, 0, m->P("feature_projection/projection/kernel"), H, m->proj, nullptr,
-                     H, 0, m->P("feature_projection/projection/bias"), nullptr, (int)BT, H, C, 1, 0))
+                     H, 0, m->P("feature_projection/projection/bias"), nullptr, (int)BT, H, C, 1, 0, p_proj ? &m->ln512_48 : nullptr))
         return e;
     // ---- encoder (encoder.py:251-276) ----
     const int32_t* flen = nullptr;
@@ -713,9 +869,11 @@ int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const i
                                        H, c.num_conv_pos_embeddings, c.num_conv_pos_embedding_groups, act, s)) {
         return e;
     }
+    const PlaneOut po_attn = p_qkv ? PO(m->attn_in48) : PlaneOut{}, po_ctx = p_out ? PO(m->ctx48) : PlaneOut{},
+                   po_ffn_in = p_f1 ? PO(m->ffn_in48) : PlaneOut{};
     if (!prenorm)
         if (int e = launch_layer_norm_x(pf, m->posout, m->hs[0], m->P("encoder/layer_norm/gamma"),
-                                        m->P("encoder/layer_norm/beta"), BT, H, eps, 0, sh ? m->hs16[0] : nullptr, s))
+                                        m->P("encoder/layer_norm/beta"), BT, H, eps, 0, sh ? m->hs16[0] : nullptr, s, p_qkv ? &po_attn : nullptr))
             return e;
     for (int i = 0; i < c.num_layers; ++i) {
         const std::string b = "encoder/layers/" + std::to_string(i);
@@ -723,51 +881,56 @@ int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const i
         const float* attn_in = x;
         const uint16_t* attn_in16 = sh ? m->hs16[i] : nullptr;       // postnorm: the previous LayerNorm wrote it
         if (prenorm) {
-            if (int e = launch_layer_norm_x(pf, x, m->t0, m->P(b + "/layer_norm/gamma"), m->P(b + "/layer_norm/beta"), BT, H, eps, 0,
-                                            sh ? m->t0_16 : nullptr, s))
+            if (int e = launch_layer_norm_x(pf, x, (p_qkv && !keep) ? nullptr : m->t0, m->P(b + "/layer_norm/gamma"), m->P(b + "/layer_norm/beta"), BT, H, eps, 0,
+                                            sh ? m->t0_16 : nullptr, s, p_qkv ? &po_attn : nullptr))
                 return e;
             attn_in = m->t0;
             attn_in16 = sh ? m->t0_16 : nullptr;
         }
         // the bf16 attention kernels read q | k | v only as bf16: the projection then writes just that shadow
         if (int e = gemm(attn_in, attn_in16, H, 0, m->qkv_w[i], 3 * H, attn16 ? nullptr : m->qkv, attn16 ? m->qkv16 : nullptr, 3 * H, 0, m->qkv_b[i],
-                         nullptr, (int)BT, 3 * H, H, 1, 0))
+                         nullptr, (int)BT, 3 * H, H, 1, 0, p_qkv ? &m->attn_in48 : nullptr))
             return e;
         // (the attention output's one reader is the out-projection GEMM; when that is certain to stream the bf16 shadow -- K = H a
         //  multiple of 64, rows 16-byte aligned: gemm_bf16.hip -- the fp32 copy is not written: 75 MB per layer at B = 32)
         const auto wo16 = m->w16.find(m->P(b + "/attention/out_proj/kernel"));
         const bool ctx16_only = attn16 && H % 64 == 0 && wo16 != m->w16.end() && wo16->second != nullptr;
-        if (int e = launch_attention_x(pf, attn16 ? nullptr : m->qkv, attn16 ? m->qkv16 : nullptr, flen, ctx16_only ? nullptr : m->ctx, B, T, H, c.num_heads,
-                                       attn16 ? m->ctx16 : nullptr, s))
+        // (planes: the split attention kernel writes the planes of ctx itself; any other attention kernel leaves fp32 to be split)
+        const bool ctx_fused = p_out && attention_split_supported(H / c.num_heads) && H % 4 == 0 && tune_int("W2V2_SPLIT_ATTN", 1) != 0;
+        if (int e = launch_attention_x(pf, attn16 ? nullptr : m->qkv, attn16 ? m->qkv16 : nullptr, flen, (ctx16_only || (ctx_fused && !keep)) ? nullptr : m->ctx, B, T, H,
+                                       c.num_heads, attn16 ? m->ctx16 : nullptr, s, ctx_fused ? &po_ctx : nullptr))
             return e;
+        if (p_out && !ctx_fused)
+            if (int e = launch_split_planes(m->ctx, m->ctx48.p, m->ctx48.plane, BT * H, fmt, m->range_flag, s)) return e;
         // out projection + residual (encoder.py:31,117-119)
         if (int e = gemm(m->ctx, attn16 ? m->ctx16 : nullptr, H, 0, m->P(b + "/attention/out_proj/kernel"), H, m->t1, nullptr, H, 0,
-                         m->P(b + "/attention/out_proj/bias"), x, (int)BT, H, H, 1, 0))
+                         m->P(b + "/attention/out_proj/bias"), x, (int)BT, H, H, 1, 0, p_out ? &m->ctx48 : nullptr))
             return e;
         const float* ffn_res = m->t1;
         if (!prenorm) {
             if (int e = launch_layer_norm_x(pf, m->t1, m->t2, m->P(b + "/layer_norm/gamma"), m->P(b + "/layer_norm/beta"), BT, H, eps, 0,
-                                            sh ? m->t2_16 : nullptr, s))
+                                            sh ? m->t2_16 : nullptr, s, p_f1 ? &po_ffn_in : nullptr))
                 return e;
             ffn_res = m->t2;
         } else {
-            if (int e = launch_layer_norm_x(pf, m->t1, m->t2, m->P(b + "/final_layer_norm/gamma"), m->P(b + "/final_layer_norm/beta"), BT, H,
-                                            eps, 0, sh ? m->t2_16 : nullptr, s))
+            if (int e = launch_layer_norm_x(pf, m->t1, (p_f1 && !keep) ? nullptr : m->t2, m->P(b + "/final_layer_norm/gamma"), m->P(b + "/final_layer_norm/beta"), BT, H,
+                                            eps, 0, sh ? m->t2_16 : nullptr, s, p_f1 ? &po_ffn_in : nullptr))
                 return e;
         }
         // the FFN intermediate has one consumer: with shadows only its bf16 form is written (302 MB of fp32 stores saved)
         if (int e = gemm(m->t2, sh ? m->t2_16 : nullptr, H, 0, m->P(b + "/feed_forward/intermediate_dense/kernel"), F,
                          ffn_sh_only ? nullptr : m->ffn, sh ? m->ffn16 : nullptr, F, 0, m->P(b + "/feed_forward/intermediate_dense/bias"),
-                         nullptr, (int)BT, F, H, 1, act))
+                         nullptr, (int)BT, F, H, 1, act, p_f1 ? &m->ffn_in48 : nullptr, p_f2 ? &m->ffn48 : nullptr, keep))
             return e;
         // output dense + residual; StochasticDepth at inference is a plain add (tensorflow_addons.py:386-390)
         float* dst = prenorm ? m->hs[i + 1] : m->t3;
         if (int e = gemm(m->ffn, sh ? m->ffn16 : nullptr, F, 0, m->P(b + "/feed_forward/output_dense/kernel"), H, dst, nullptr, H, 0,
-                         m->P(b + "/feed_forward/output_dense/bias"), ffn_res, (int)BT, H, F, 1, 0))
+                         m->P(b + "/feed_forward/output_dense/bias"), ffn_res, (int)BT, H, F, 1, 0, p_f2 ? &m->ffn48 : nullptr))
             return e;
-        if (!prenorm)
+        if (!prenorm)       // (its planes are the next layer's attention input)
             if (int e = launch_layer_norm_x(pf, m->t3, m->hs[i + 1], m->P(b + "/final_layer_norm/gamma"),
-                                            m->P(b + "/final_layer_norm/beta"), BT, H, eps, 0, sh ? m->hs16[i + 1] : nullptr, s))
+                                            m->P(b + "/final_layer_norm/beta"), BT, H, eps, 0, sh ? m->hs16[i + 1] : nullptr, s,
+                                            (p_qkv && i + 1 < c.num_layers) ? &po_attn : nullptr))
                 return e;
     }
     const uint16_t* head_in16 = sh && !prenorm ? m->hs16[c.num_layers] : nullptr;
@@ -873,7 +1036,7 @@ int w2v2_op_gemm(const float* A, int64_t lda, int64_t strideA, const float* B, i
                        reinterpret_cast<hipStream_t>(stream));
 }
 int w2v2_op_set_precision(int32_t mode) {
-    W2V2_REQUIRE(mode == W2V2_PRECISION_FP32 || mode == W2V2_PRECISION_BF16 || mode == W2V2_PRECISION_BF16X3, "op_set_precision: unknown mode %d", mode);
+    W2V2_REQUIRE(mode >= W2V2_PRECISION_FP32 && mode <= W2V2_PRECISION_F16X2, "op_set_precision: unknown mode %d", mode);
     gemm_set_precision(mode);
     return W2V2_OK;
 }

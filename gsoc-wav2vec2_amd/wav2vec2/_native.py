@@ -64,6 +64,7 @@ PROTOTYPES = {
     "w2v2_set_trainable_flags": (C.c_int, [_P, _P, _I32]),
     "w2v2_set_option": (C.c_int, [_P, _I32, _I32]),
     "w2v2_get_option": (C.c_int, [_P, _I32]),
+    "w2v2_range_overflow": (C.c_int, [_P, C.POINTER(_I32), _P]),
     "w2v2_train_forward": (C.c_int, [_P, _P, _I32, _I64, _P, _P, _P, C.c_float, C.c_uint64, _P, _P]),
     "w2v2_train_backward": (C.c_int, [_P, _P, _P]),
     "w2v2_grad_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_I64)]),

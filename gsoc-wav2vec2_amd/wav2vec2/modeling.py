@@ -328,7 +328,7 @@ class TFKerasModel(Layer):
         self._train_rng = np.random.RandomState(self._seed & 0xFFFFFFFF)
 
     # ---- arithmetic of the dense contractions --------------------------------
-    PRECISIONS = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "mixed_bfloat16": 1, "bf16x3": 2}
+    PRECISIONS = {"fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "mixed_bfloat16": 1, "bf16x3": 2, "f16x2": 3}
 
     def set_precision(self, precision):
         """"fp32" (default: the reference's arithmetic) or "bf16" (Conv1D layers 1..6 and every Dense take
@@ -336,17 +336,22 @@ class TFKerasModel(Layer):
         bf16 fine-tune configurations ask for; variables, activations and optimizer state stay fp32), or "bf16x3"
         (fp32 operands split exactly into three bf16 terms, six bf16 MFMA products per fp32 product, fp32
         accumulation -- fp32-level results at the bf16 matrix cores' rate; forward GEMMs and attention, and the
-        data-gradient GEMMs of the training step; csrc/gemm_split.hip, attention_split.hip)."""
+        data-gradient GEMMs of the training step; csrc/gemm_split.hip, gemm_split_sw.hip, attention_split.hip), or "f16x2"
+        (inference forward: every GEMM operand as TWO fp16 terms, three MFMA products per fp32 product -- half the matrix work
+        of "bf16x3" at a measured error at or below the fp32 kernel's; activations must stay below 4094 in magnitude, see
+        `range_overflow`)."""
         if precision not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(set(self.PRECISIONS))}, got {precision!r}")
         N.check(self._lib.w2v2_set_precision(self._handle, self.PRECISIONS[precision]), "w2v2_set_precision")
 
-    OPTIONS = {"bf16_shadows": 0, "keep_activations": 1}      # W2V2_OPT_* of include/w2v2.h
+    OPTIONS = {"bf16_shadows": 0, "keep_activations": 1, "split_planes": 2}      # W2V2_OPT_* of include/w2v2.h
 
     def set_option(self, name, value):
         """Per-model switches of the bf16 precision mode (include/w2v2.h: w2v2_set_option): "bf16_shadows" (default on; off =
         every GEMM rounds its fp32 operands itself, same bits, slower) and "keep_activations" (default off; on = stage outputs
-        that are normally written only as bf16 keep their fp32 copy so `activation(name)` can tap them)."""
+        that are normally written only as bf16 -- or, in "bf16x3" / "f16x2", only as operand planes -- keep their fp32 copy so
+        `activation(name)` can tap them); "split_planes" (default on; off = the "bf16x3" / "f16x2" forward GEMMs split fp32 rows
+        in registers instead of streaming planes written by their producers: the round-4 path, for A/B measurements)."""
         if name not in self.OPTIONS:
             raise KeyError(f"unknown option {name!r}; one of {sorted(self.OPTIONS)}")
         N.check(self._lib.w2v2_set_option(self._handle, self.OPTIONS[name], int(bool(value))), "w2v2_set_option")
@@ -356,7 +361,15 @@ class TFKerasModel(Layer):
 
     @property
     def precision(self):
-        return {0: "fp32", 1: "bf16", 2: "bf16x3"}[self._lib.w2v2_get_precision(self._handle)]
+        return {0: "fp32", 1: "bf16", 2: "bf16x3", 3: "f16x2"}[self._lib.w2v2_get_precision(self._handle)]
+
+    def range_overflow(self):
+        """precision "f16x2": True if a forward since the last call met an activation beyond fp16's scaled range (|x| >= 4094) --
+        its logits are then not fp32-grade; rerun in "bf16x3" or "fp32".  Clears the flag; synchronises the stream."""
+        import ctypes
+        flag = ctypes.c_int32(0)
+        N.check(self._lib.w2v2_range_overflow(self._handle, ctypes.byref(flag), N.current_stream()), "w2v2_range_overflow")
+        return bool(flag.value)
 
     # ---- persistence (reference modeling.py:22-27, 41-84) -------------------
     def _keras_layers(self, weights):

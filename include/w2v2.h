@@ -127,10 +127,20 @@ int64_t w2v2_num_frames(const w2v2_model* m, int64_t num_samples);
  *                        W2V2_PRECISION_FP32 -- logits within the same 1e-3 of the reference -- at the bf16 pipe's rate.
  *                        Attention (head size 64) takes the same route; shapes the split kernels do not take, the
  *                        positional conv, the weight-gradient GEMMs and the training attention stay on the fp32 MFMA.
+ *                        In the inference forward the producers of the GEMM operands (conv0, LayerNorm, the GEMM and attention
+ *                        epilogues) write the three planes themselves and the GEMMs stream them (gemm_split_sw.hip).
+ *   W2V2_PRECISION_F16X2   fp32-grade results from the fp16 matrix cores at HALF the MFMA work of BF16X3 (inference forward):
+ *                        an operand is the sum of TWO fp16 terms of x 2^e (22 significant bits; e = 4 for activations, chosen
+ *                        from max |w| for a weight), a product keeps a0 b0 + a0 b1 + a1 b0.  The error per product (~2^-22) is
+ *                        below what an fp32 running sum over K >= 64 products commits: measured GEMM error at or below the
+ *                        fp32 MFMA kernel's, logits within the same bar.  Domain: |activation| < 4094 (a larger value
+ *                        saturates and sets a sticky flag, w2v2_range_overflow).  GEMM shapes its kernel does not take, the
+ *                        attention core and the training step run as in BF16X3.
  * Everything else (conv0 + GroupNorm, LayerNorm, softmax, CTC) is fp32 in all modes. */
 #define W2V2_PRECISION_FP32 0
 #define W2V2_PRECISION_BF16 1
 #define W2V2_PRECISION_BF16X3 2
+#define W2V2_PRECISION_F16X2 3
 int w2v2_set_precision(w2v2_model* m, int32_t mode);
 int w2v2_get_precision(const w2v2_model* m);
 
@@ -139,11 +149,19 @@ int w2v2_get_precision(const w2v2_model* m);
  *                                          results bit for bit, slower; the parity tests flip it to prove exactly that.
  *   W2V2_OPT_KEEP_ACTIVATIONS (default 0)  1 = also write the fp32 copies of stage outputs whose only reader streams the bf16
  *                                          shadow, so w2v2_copy_activation can tap them (otherwise such a tap is an error).
+ *   W2V2_OPT_SPLIT_PLANES (default 1)      precision modes BF16X3 / F16X2: 0 = no operand planes written by the producers; the
+ *                                          forward GEMMs then load fp32 rows and split them in registers (gemm_split.hip, six
+ *                                          bf16 products in both modes) -- the round-4 path, kept for A/B measurements.
  * w2v2_get_option returns the value, or W2V2_EINVAL for an unknown option. */
 #define W2V2_OPT_BF16_SHADOWS 0
 #define W2V2_OPT_KEEP_ACTIVATIONS 1
+#define W2V2_OPT_SPLIT_PLANES 2
 int w2v2_set_option(w2v2_model* m, int32_t option, int32_t value);
 int w2v2_get_option(const w2v2_model* m, int32_t option);
+/* W2V2_PRECISION_F16X2: *flag = 1 if a forward since the last call met an activation outside fp16's range after scaling
+ * (|x| >= 4094: its planes were saturated, the logits of that forward are NOT fp32-grade -- rerun in BF16X3 or FP32); clears the
+ * flag.  Synchronises `stream`.  Always 0 in the other modes. */
+int w2v2_range_overflow(w2v2_model* m, int32_t* flag, void* stream);
 
 /* ---- the hot path --------------------------------------------------------
  * Replaces Wav2Vec2ForCTC.call / Wav2Vec2Model.call at training=False
