@@ -563,3 +563,38 @@ def test_counted_wait_kernels_have_no_scratch():
     bad = [(n, s) for n, s in zip(names, scratch) if "gemm_bf16_sw_kernel" in n and s != 0]
     assert sum("gemm_bf16_sw_kernel" in n for n in names) >= 7, names
     assert not bad, bad
+
+
+def test_split_sw_kernels_have_no_scratch_and_a_consistent_schedule():
+    """The same build gate for the plane-fed split GEMM (gemm_split_sw.hip: both plane formats x seven epilogue instances, all built on
+    counted vmcnt waits over a ten-slot LDS ring), plus the ring / register-slot schedule simulated for every K (tools/split_sw_schedule.py:
+    every item requested once and in order, no slot refilled before its reads retired behind a barrier, no item read before the counted
+    wait guarantees it landed, every term multiplying the planes it claims to)."""
+    import shutil
+    import subprocess
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("split_sw_schedule", os.path.join(root, "tools", "split_sw_schedule.py"))
+    sim = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sim)
+    for fmt in sim.FORMATS:
+        for nk in (2, 4, 6, 8, 16, 24, 48, 96, 128):
+            for half in (0, 1):
+                assert sim.simulate(nk, half, fmt)
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(root, "gsoc-wav2vec2_amd", "csrc", "gemm_split_sw.hip")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-c", src, "-o", os.devnull,
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    names, scratch = [], []
+    for line in r.stderr.splitlines():
+        if "Function Name:" in line:
+            names.append(line.split("Function Name:")[1].split("[")[0].strip())
+        elif "ScratchSize [bytes/lane]:" in line:
+            scratch.append(int(line.split("ScratchSize [bytes/lane]:")[1].split("[")[0].strip()))
+    assert names and len(names) == len(scratch)
+    assert sum("gemm_split_sw_kernel" in n for n in names) >= 14, names
+    bad = [(n, s) for n, s in zip(names, scratch) if "gemm_split_sw_kernel" in n and s != 0]
+    assert not bad, bad

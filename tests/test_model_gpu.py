@@ -175,22 +175,25 @@ def test_bf16_shadows_do_not_change_results(torch_mod, name):
     assert np.array_equal(m.activation(f"conv{len(cfg.kernal_sizes) - 1}"), res["1"][f"conv{len(cfg.kernal_sizes) - 1}"])
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("name", ["tiny_base", "base_sample_unpadded", "base_sample_padded", "robust_masked"])
-def test_bf16x3_precision_is_fp32_grade(torch_mod, name):
-    """Precision mode "bf16x3" (fp32 GEMMs evaluated as six bf16 MFMA products of exact three-term operand splits) must
-    meet the FP32 bar, not a bf16 one: the same 2e-4 against the HF fp64 logits as test_logits_match_golden, and an
-    error no worse than 1.5x the native fp32 path's on the same fixture."""
+def test_bf16x3_precision_is_fp32_grade(torch_mod, name, mode):
+    """Precision modes "bf16x3" (fp32 GEMMs evaluated as six bf16 MFMA products of exact three-term operand splits) and "f16x2"
+    (three fp16 products of two-term splits) must meet the FP32 bar, not a bf16 one: the same 2e-4 against the HF fp64 logits as
+    test_logits_match_golden, and an error no worse than 1.5x the native fp32 path's on the same fixture.  (These two-row fixtures
+    are below the tile count at which the forward streams operand planes: the GEMMs here are gemm_split.hip's in both modes;
+    test_plane_modes_at_full_batch covers the plane kernels.)"""
     g = H.golden(name)
     m, cfg = build(name)
     mask = g.get("attention_mask")
     mask = None if mask is None else mask.astype(np.int32)
     e32 = H.max_err(m(g["wave"], attention_mask=mask).numpy(), g["logits_f64"])
-    m.set_precision("bf16x3")
-    assert m.precision == "bf16x3"
+    m.set_precision(mode)
+    assert m.precision == mode
     got = m(g["wave"], attention_mask=mask).numpy()
     e3 = H.max_err(got, g["logits_f64"])
-    print(f"{name}: max|logits - HF fp64|  bf16x3 {e3:.3e}   fp32 {e32:.3e}")
-    report(f"{name}/bf16x3_logits_vs_hf_f64", e3)
+    print(f"{name}: max|logits - HF fp64|  {mode} {e3:.3e}   fp32 {e32:.3e}")
+    report(f"{name}/{mode}_logits_vs_hf_f64", e3)
     assert e3 < H.ATOL_AIM
     assert e3 < 1.5 * e32 + 2e-5
     prof_ok = m.activation("layer0")
@@ -246,7 +249,7 @@ def test_batch_rows_are_independent(torch_mod):
     assert np.array_equal(out[:2], both) and np.array_equal(out[8:], both)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16x2"])
 def test_ctc_loss_matches_golden(torch_mod, precision):
     """reference tests/test_wav2vec2.py:217-237: loss within 1e-3 of HF.  (bf16x3 is held to the fp32 bar.)"""
     import wav2vec2
@@ -381,21 +384,131 @@ def test_linearity_of_lm_head_at_full_size(torch_mod):
     assert np.array_equal(a[perm], b)
 
 
-def test_bf16x3_batch_rows_are_position_independent(torch_mod):
-    """The same bit-for-bit batch-permutation property in precision mode bf16x3 (every tile of the split GEMM sums K in
-    the same order, so a row's result does not depend on where it sits in the batch)."""
+@pytest.mark.parametrize("mode,B", [("bf16x3", 4), ("f16x2", 4), ("bf16x3", 12), ("f16x2", 12)])
+def test_bf16x3_batch_rows_are_position_independent(torch_mod, mode, B):
+    """The same bit-for-bit batch-permutation property in precision modes bf16x3 / f16x2 (every tile of the split GEMMs sums K in
+    the same order, so a row's result does not depend on where it sits in the batch); B = 12 streams operand planes."""
     m, cfg = build("base_sample_padded")
-    m.set_precision("bf16x3")
-    B, L = 4, 246000
+    m.set_precision(mode)
+    L = 246000
     x = V.hash_normal("full/wave3", B * L, 4).reshape(B, L)
     a = m(x).numpy()
-    perm = np.array([2, 0, 3, 1])
+    perm = np.array([2, 0, 3, 1] + list(range(B - 1, 3, -1)))
     b = m(x[perm]).numpy()
     assert np.isfinite(a).all()
     assert np.array_equal(a[perm], b)
 
 
-def test_bf16x3_ragged_shapes_at_base_width(torch_mod):
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
+def test_plane_modes_at_full_batch(torch_mod, mode):
+    """The plane-fed forward of precision modes bf16x3 / f16x2 (conv0, LayerNorm, attention and GEMM epilogues write the operand
+    planes, gemm_split_sw.hip streams them) at a batch where every GEMM takes it: eight copies of the two-row BASELINE-length fixture.
+    Logits at the fp32 bar against HF fp64 and no worse than 1.5x the fp32 path; copies bit-equal; a forward reproduces itself; the
+    round-4 route (W2V2_OPT_SPLIT_PLANES off: fp32 rows split in registers) agrees to fp32 noise; with W2V2_OPT_KEEP_ACTIVATIONS the
+    logits are bit-identical and the stage taps meet their bars, without it a conv tap that exists only as planes is an error."""
+    g = H.golden("base_sample_padded")
+    m, cfg = build("base_sample_padded")
+    copies = 8
+    wave = np.concatenate([g["wave"]] * copies, 0)
+    e32 = H.max_err(m(wave).numpy()[:2], g["logits_f64"])
+    m.set_precision(mode)
+    a = m(wave).numpy()
+    err = H.max_err(a[:2], g["logits_f64"])
+    print(f"full batch {mode}: max|logits - HF fp64| {err:.3e} (fp32 path {e32:.3e})")
+    report(f"base_sample_padded_x8/{mode}_planes_logits_vs_hf_f64", err)
+    assert np.isfinite(a).all() and err < H.ATOL_AIM and err < 1.5 * e32 + 2e-5
+    assert all(np.array_equal(a[:2], a[2 * k:2 * k + 2]) for k in range(1, copies))
+    assert np.array_equal(m(wave).numpy(), a)
+    assert m.range_overflow() is False
+    with pytest.raises(Exception):
+        m.activation("conv2")                                   # written only as planes in this forward
+    m.set_option("keep_activations", True)
+    assert np.array_equal(m(wave).numpy(), a)
+    for tap in ("conv0", "conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "encoder_in", "layer0"):
+        e = H.max_err(H.tap_view(tap, m.activation(tap)[:2], False), g[tap])
+        assert e < H.ATOL_AIM * max(1.0, float(np.abs(g[tap]).max())), f"{tap}: {e:.3e}"
+    m.set_option("keep_activations", False)
+    m.set_option("split_planes", False)
+    b = m(wave).numpy()
+    m.set_option("split_planes", True)
+    assert not np.array_equal(a, b) and H.max_err(a, b) < 1e-4
+    m.set_precision("fp32")
+    assert H.max_err(m(wave).numpy()[:2], g["logits_f64"]) == e32
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
+def test_plane_modes_large_robust(torch_mod, mode):
+    """The same on the large-robust architecture (LayerNorm extractor: its planes come from the LN + GELU pass; prenorm encoder; ragged
+    attention mask), four copies of the two-row HF fixture at 246000 samples."""
+    import wav2vec2
+    from wav2vec2.config import RobustWav2Vec2Config
+    cfg = RobustWav2Vec2Config()
+    g = H.golden("robust_full_246000")
+    wave = np.concatenate([g["wave"]] * 4, 0)
+    mask = np.concatenate([g["attention_mask"].astype(np.int32)] * 4, 0)
+    m = wav2vec2.Wav2Vec2ForCTC(cfg, input_shape=wave.shape)
+    m.set_weights(V.seeded_weights(cfg, seed=5))
+    m.set_precision(mode)
+    a = m(wave, attention_mask=mask).numpy()
+    err = H.max_err(a[:2], g["logits_f64"])
+    report(f"robust_full_246000_x4/{mode}_planes_logits_vs_hf_f64", err)
+    assert np.isfinite(a).all() and err < H.ATOL_AIM
+    assert all(np.array_equal(a[:2], a[2 * k:2 * k + 2]) for k in range(1, 4))
+    assert m.range_overflow() is False
+
+
+def test_f16x2_reports_values_beyond_its_range(torch_mod):
+    """f16x2 stores activations as fp16 terms of 16 x: |x| >= 4094 saturates.  A model whose FFN hidden activations are pushed past
+    that (a +1e4 bias on layer 0's intermediate dense) must say so through range_overflow(), stay finite, and clear the flag."""
+    g = H.golden("base_sample_padded")
+    m, cfg = build("base_sample_padded")
+    w = H.case_weights("base_sample_padded")
+    w["encoder/layers/0/feed_forward/intermediate_dense/bias"] = w["encoder/layers/0/feed_forward/intermediate_dense/bias"] + 1e4
+    m.set_weights(w)
+    m.set_precision("f16x2")
+    wave = np.concatenate([g["wave"]] * 8, 0)
+    out = m(wave).numpy()
+    assert np.isfinite(out).all()
+    assert m.range_overflow() is True
+    assert m.range_overflow() is False                          # reading clears it
+    m.set_precision("bf16x3")                                    # exact splits have no such domain
+    ref = m(wave).numpy()
+    assert m.range_overflow() is False and np.isfinite(ref).all()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "f16x2"])
+def test_ctc_nll_error_is_propagated_logit_error(torch_mod, precision):
+    """Why the 768-frame fixture's NLL sits 1e-3 .. 1e-2 from HF fp64 in every precision mode (and HF's own fp32 run 1.4e-3): row 0 is
+    46797 samples of speech padded with zeros to 246000, ~600 of its frames see identical values, so the fp32-level logit error there
+    (2-6e-5) is the SAME on every one of them and enters the loss ~600 times with one sign.  Checked here: (1) fed HF's fp64 logits the
+    CTC kernel itself is within 1e-4 of HF's fp64 loss; (2) the NLL error of the path under test equals, to first order, the kernel's own
+    gradient at the reference logits dotted with the path's logit error -- i.e. it is logit noise propagated through the loss, not a loss
+    error (tools/nll_drift_probe.py switches the split GEMMs / split attention on one at a time: the sign and size of the projection
+    change with every variant, there is no single biased stage)."""
+    import torch
+    import wav2vec2
+    g = H.golden("base_sample_padded")
+    m, cfg = build("base_sample_padded")
+    loss_fn = wav2vec2.CTCLoss(cfg, g["wave"].shape, division_factor=1)
+    gold = torch.from_numpy(g["logits_f64"].astype(np.float32)).cuda()
+    nll_gold, grad = loss_fn.per_sample(g["labels"], gold, with_grad=True)
+    kernel_err = float(np.abs(nll_gold.cpu().numpy() - g["ctc_nll_f64"]).max())
+    report("base_sample_padded/ctc_kernel_on_fp64_logits_abs_err", kernel_err)
+    assert kernel_err < 1e-4
+    m.set_precision(precision)
+    logits = m(g["wave"])
+    nll = loss_fn.per_sample(g["labels"], logits).cpu().numpy().astype(np.float64)
+    d = logits.double().cpu().numpy() - g["logits_f64"].astype(np.float64)
+    first_order = (grad.double().cpu().numpy() * d).sum(axis=(1, 2))
+    actual = nll - g["ctc_nll_f64"]
+    print(f"{precision}: nll error {actual}, first-order prediction {first_order}, max|dlogit| {np.abs(d).max():.2e}")
+    report(f"base_sample_padded/ctc_nll_first_order_residual_{precision}", float(np.abs(actual - first_order).max()))
+    assert np.abs(actual - first_order).max() < 3e-4 + 0.1 * np.abs(actual).max()
+    assert np.abs(d).max() < H.ATOL_AIM
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
+def test_bf16x3_ragged_shapes_at_base_width(torch_mod, mode):
     """bf16x3 at the real layer widths (so the split GEMM / attention kernels run, unlike on the tiny configs) with every M
     ragged: B = 3 rows of 20563 samples (T = 63: not a multiple of the 64-key attention tile or of the 128-row GEMM tile)
     and a ragged attention mask.  Against the fp32 path on the same input (which is itself pinned to the oracle)."""
@@ -408,7 +521,7 @@ def test_bf16x3_ragged_shapes_at_base_width(torch_mod):
     m = wav2vec2.Wav2Vec2ForCTC(cfg, input_shape=(3, L))
     m.set_weights(w)
     a = m(x, attention_mask=mask).numpy()
-    m.set_precision("bf16x3")
+    m.set_precision(mode)
     b = m(x, attention_mask=mask).numpy()
     assert np.isfinite(b).all() and not np.array_equal(a, b)
     assert H.max_err(a, b) < 1e-4
@@ -490,10 +603,11 @@ def test_large_robust_long_form_480000_vs_hf(torch_mod):
     for tap in ("conv6", "encoder_in", "layer0"):
         e = H.max_err(H.tap_view(tap, m.activation(tap), False), g[tap])
         assert e < H.ATOL_AIM * max(1.0, float(np.abs(g[tap]).max())), f"{tap}: {e:.3e}"
-    m.set_precision("bf16x3")
-    err3 = H.max_err(m(x, attention_mask=mask).numpy(), g["logits_f64"])
-    report("robust_long_480000/bf16x3_logits_vs_hf_f64", err3)
-    assert err3 < H.ATOL_AIM
+    for mode in ("bf16x3", "f16x2"):
+        m.set_precision(mode)
+        err3 = H.max_err(m(x, attention_mask=mask).numpy(), g["logits_f64"])
+        report(f"robust_long_480000/{mode}_logits_vs_hf_f64", err3)
+        assert err3 < H.ATOL_AIM
 
 
 def _greedy(logits):
@@ -610,7 +724,7 @@ def test_from_pretrained_hf_checkpoint_directory(torch_mod, tmp_path):
     assert np.array_equal(m2(g["wave"]).numpy(), want)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3", "f16x2"])
 def test_odd_vocab_and_length(torch_mod, precision):
     """A vocabulary that is not a multiple of 4 (guarded lm_head GEMM: no 16-byte columns) and an input length that
     leaves ragged frame counts at every conv layer, B = 3: the guarded paths inside the model, against the oracle."""
@@ -625,7 +739,7 @@ def test_odd_vocab_and_length(torch_mod, precision):
     m.set_precision(precision)
     got = m(x).numpy()
     assert got.shape == (3, cfg.num_frames(L), 29) and np.isfinite(got).all()
-    if precision in ("fp32", "bf16x3"):              # bf16x3 is held to the fp32 bar
+    if precision in ("fp32", "bf16x3", "f16x2"):     # the split modes are held to the fp32 bar
         ref = O.ctc_forward(cfg, w, x)
         assert H.max_err(got, ref) < H.ATOL_AIM
     else:
@@ -645,9 +759,10 @@ def test_models_release_device_memory(torch_mod):
 
     def cycle():
         m, cfg = build("base_sample_unpadded")
-        for prec in ("fp32", "bf16", "bf16x3"):
+        for prec in ("fp32", "bf16", "bf16x3", "f16x2"):
             m.set_precision(prec)
             m(g["wave"])
+        m(np.concatenate([g["wave"]] * 24, 0))          # (f16x2 at a batch that allocates the plane buffers and weight images)
         del m
         gc.collect()
         torch.cuda.synchronize()
@@ -751,9 +866,10 @@ def test_is_gelu_approx_model_level(torch_mod, kind):
     print(f"tiny_{kind} tanh-GELU: max|hip - oracle| = {err:.3e}; exact-vs-tanh gap {gap:.3e}")
     report(f"tiny_{kind}/gelu_approx_logits_vs_oracle", err)
     assert err < H.ATOL_AIM and gap > 20 * err
-    # the bf16x3 mode evaluates the same epilogue function
-    m.set_precision("bf16x3")
-    assert H.max_err(m(x, attention_mask=mask).numpy(), ref) < H.ATOL_AIM
+    # the split modes evaluate the same epilogue function
+    for mode in ("bf16x3", "f16x2"):
+        m.set_precision(mode)
+        assert H.max_err(m(x, attention_mask=mask).numpy(), ref) < H.ATOL_AIM
     m.set_precision("fp32")
 
 

@@ -338,6 +338,164 @@ def test_gemm_split_rejects_unsupported_shapes(env):
     assert lib.w2v2_op_gemm_split(N.ptr(A), 32, 0, N.ptr(B), N.ptr(out), 96, 0, None, None, 64, 96, 32, 1, 0, stream()) == -1   # N % 256
 
 
+# ---- the plane-fed split GEMM (csrc/gemm_split_sw.hip): precision modes bf16x3 / f16x2 of the inference forward ----
+PLANE_FMTS = {"bf16x3": (0, 3), "f16x2": (1, 2)}      # name -> (W2V2_PLANES_*, planes per element)
+F16X2_ACT_SCALE = 16.0
+
+
+def _planes_value(torch, p, n, fmt_name):
+    """(planes * n) int16 device tensor -> the fp64 values the planes stand for"""
+    if fmt_name == "f16x2":
+        return (p[:n].view(torch.float16).double() + p[n:2 * n].view(torch.float16).double()) / F16X2_ACT_SCALE
+    f = lambda q: (q.to(torch.int32) << 16).view(torch.float32).double()
+    return f(p[:n]) + f(p[n:2 * n]) + f(p[2 * n:3 * n])
+
+
+def _split_operands(lib, torch, dev, tA, tB, K, N_, fmt_name):
+    fmt, npl = PLANE_FMTS[fmt_name]
+    n = tA.numel()
+    pA = torch.empty(npl * n, dtype=torch.int16, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    N.check(lib.w2v2_op_split_planes(N.ptr(tA), N.ptr(pA), n, n, fmt, N.ptr(flag), stream()))
+    img = torch.empty(npl * K * N_, dtype=torch.int16, device=dev)
+    ws = torch.zeros(2, dtype=torch.float32, device=dev)
+    N.check(lib.w2v2_op_split_weight(N.ptr(tB), N.ptr(img), N.ptr(ws) if fmt else None, K, N_, fmt, stream()))
+    _KEEP.extend([pA, img, ws, flag])
+    return pA, img, (ws[1:] if fmt else None), flag
+
+
+@pytest.mark.parametrize("fmt_name", ["bf16x3", "f16x2"])
+def test_split_planes_represent_the_value(env, fmt_name):
+    """What the producers write: bf16x3 planes sum back to the fp32 value EXACTLY; f16x2 planes (two fp16 terms of 16 x) to 2^-21
+    relative (2^-28 absolute for tiny values: fp16 subnormals are kept), and a value beyond fp16's range sets the sticky flag."""
+    lib, torch, dev = env
+    x = np.concatenate([rnd("pl", (4096,), 3.0), rnd("pl2", (4096,), 1e-3), rnd("pl3", (1024,), 200.0), np.zeros(64, np.float32)]).astype(np.float32)
+    t = dev_t(torch, dev, x)
+    pA, _, _, flag = _split_operands(lib, torch, dev, t, dev_t(torch, dev, rnd("plw", (64, 256))), 64, 256, fmt_name)
+    v = _planes_value(torch, pA, x.size, fmt_name).cpu().numpy()
+    if fmt_name == "bf16x3":
+        assert np.array_equal(v, x.astype(np.float64))
+    else:
+        assert (np.abs(v - x) <= np.abs(x) * 2.0 ** -21 + 2.0 ** -28).all()
+        assert int(flag.item()) == 0
+        big = dev_t(torch, dev, np.array([1.0, 5000.0, -2.0, 3.0], np.float32))
+        p2 = torch.empty(8, dtype=torch.int16, device=dev)
+        N.check(lib.w2v2_op_split_planes(N.ptr(big), N.ptr(p2), 4, 4, 1, N.ptr(flag), stream()))
+        assert int(flag.item()) == 1 and bool(torch.isfinite(p2.view(torch.float16).float()).all())
+
+
+@pytest.mark.parametrize("fmt_name", ["bf16x3", "f16x2"])
+@pytest.mark.parametrize("M,N_,K,act,use_bias,use_res", [
+    (128, 256, 64, 0, False, False), (300, 256, 128, 1, True, False), (1000, 768, 192, 0, True, True), (1, 256, 64, 0, True, False),
+    (2048, 768, 3072, 0, True, True), (515, 2304, 768, 2, True, False), (2100, 512, 1536, 1, True, False)])
+def test_gemm_split_planes_is_fp32_grade(env, fmt_name, M, N_, K, act, use_bias, use_res):
+    """The plane-fed GEMM of precision modes bf16x3 (six bf16 products of exact three-term splits) and f16x2 (three fp16 products of
+    two-term splits): same bar as test_gemm_split_is_fp32_grade -- the fp32 tolerance against fp64 and an rms error no larger than
+    1.5x what the fp32 MFMA kernel commits on the same operands (measured 0.6-1.0x; f16x2 at K <= 128, where fp32 sums are still
+    short, up to 1.1x) -- for fp32 output with residual, and for the plane output the next GEMM streams."""
+    lib, torch, dev = env
+    fmt, npl = PLANE_FMTS[fmt_name]
+    A, B = rnd("Ap", (M, K)), rnd("Bp", (K, N_), 0.2)
+    bias = rnd("biasp", (N_,)) if use_bias else None
+    res = rnd("resp", (M, N_)) if use_res else None
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    if use_bias:
+        ref = ref + bias
+    if act:
+        ref = O.gelu(ref, approximate=(act == 2))
+    pre_res = ref
+    if use_res:
+        ref = ref + res
+    tA, tB = dev_t(torch, dev, A), dev_t(torch, dev, B)
+    tb = dev_t(torch, dev, bias) if use_bias else None
+    tr = dev_t(torch, dev, res) if use_res else None
+    pA, img, sc, flag = _split_operands(lib, torch, dev, tA, tB, K, N_, fmt_name)
+    out = torch.full((M, N_), float("nan"), device=dev)
+    nat = torch.full((M, N_), float("nan"), device=dev)
+    N.check(lib.w2v2_op_gemm_split_planes(fmt, N.ptr(pA), M * K, K, 0, N.ptr(img), N.ptr(sc) if fmt else None, N.ptr(out), None, 0, N_, 0,
+                                          N.ptr(tb), N.ptr(tr), M, N_, K, 1, act, N.ptr(flag), stream()))
+    N.check(lib.w2v2_op_gemm(N.ptr(tA), K, 0, N.ptr(tB), N_, N.ptr(nat), N_, 0, N.ptr(tb), N.ptr(tr), M, N_, K, 1, act, stream()))
+    got, native = out.cpu().numpy(), nat.cpu().numpy()
+    assert np.isfinite(got).all()
+    scale = max(1.0, np.abs(ref).max())
+    assert H.max_err(got, ref) < 2e-5 * scale
+    rms = lambda x, r: float(np.sqrt(np.mean((x - r) ** 2)))
+    assert rms(got, ref) <= 1.5 * rms(native, ref) + 2e-8, (rms(got, ref), rms(native, ref))
+    # the plane output (no residual in that form): bf16x3 planes ARE the fp32 result, f16x2 planes are it to 2^-21
+    P = torch.full((npl * M * N_,), 0x7fff, dtype=torch.int16, device=dev)
+    N.check(lib.w2v2_op_gemm_split_planes(fmt, N.ptr(pA), M * K, K, 0, N.ptr(img), N.ptr(sc) if fmt else None, None, N.ptr(P), M * N_, N_, 0,
+                                          N.ptr(tb), None, M, N_, K, 1, act, N.ptr(flag), stream()))
+    pv = _planes_value(torch, P, M * N_, fmt_name).cpu().numpy().reshape(M, N_)
+    if not use_res:
+        if fmt_name == "bf16x3":
+            assert np.array_equal(pv, got.astype(np.float64))
+        else:
+            assert (np.abs(pv - got) <= np.abs(got) * 2.0 ** -20 + 2.0 ** -27).all()
+    assert H.max_err(pv, pre_res) < 2e-5 * scale
+    assert int(flag.item()) == 0
+
+
+def test_gemm_split_planes_exact_on_three_term_operands(env):
+    """bf16x3 through the plane-fed kernel keeps the exactness of the split (24-bit integer operands, exactly representable sums)."""
+    lib, torch, dev = env
+    M, N_, K = 128, 256, 64
+    idx = np.arange(M * K, dtype=np.int64).reshape(M, K)
+    A = (((idx * 2654435761) % 4096) + 4096 * ((idx * 40503) % 4096)).astype(np.float32)
+    B = np.zeros((K, N_), np.float32)
+    B[np.arange(N_) % K, np.arange(N_)] = 1.0
+    B[(np.arange(N_) + 1) % K, np.arange(N_)] = -1.0
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    tA, tB = dev_t(torch, dev, A), dev_t(torch, dev, B)
+    pA, img, _, flag = _split_operands(lib, torch, dev, tA, tB, K, N_, "bf16x3")
+    out = torch.empty((M, N_), device=dev)
+    N.check(lib.w2v2_op_gemm_split_planes(0, N.ptr(pA), M * K, K, 0, N.ptr(img), None, N.ptr(out), None, 0, N_, 0, None, None, M, N_, K, 1, 0,
+                                          N.ptr(flag), stream()))
+    assert np.array_equal(out.cpu().numpy().astype(np.float64), ref)
+
+
+@pytest.mark.parametrize("fmt_name", ["bf16x3", "f16x2"])
+def test_strided_conv_as_overlapping_gemm_split_planes(env, fmt_name):
+    """Conv1D as a GEMM over overlapping plane rows, the batch in one launch, ragged last row tile, GELU, plane output."""
+    lib, torch, dev = env
+    fmt, npl = PLANE_FMTS[fmt_name]
+    Tin, Cin, Cout, k, s, B = 49199 // 16, 512, 512, 3, 2, 2
+    x, w = rnd("xp", (B, Tin, Cin)), rnd("wp", (k, Cin, Cout), 0.1)
+    bias = rnd("cbp", (Cout,))
+    ref = O.gelu(O.conv1d_valid(x.astype(np.float64), w.astype(np.float64), s, bias.astype(np.float64)))
+    Tout = 1 + (Tin - k) // s
+    tx, tw = dev_t(torch, dev, x), dev_t(torch, dev, w)
+    px, img, sc, flag = _split_operands(lib, torch, dev, tx, tw, k * Cin, Cout, fmt_name)
+    out = torch.empty((B, Tout, Cout), device=dev)
+    N.check(lib.w2v2_op_gemm_split_planes(fmt, N.ptr(px), x.size, s * Cin, Tin * Cin, N.ptr(img), N.ptr(sc) if fmt else None, N.ptr(out), None, 0, Cout,
+                                          Tout * Cout, N.ptr(dev_t(torch, dev, bias)), None, Tout, Cout, k * Cin, B, 1, N.ptr(flag), stream()))
+    assert H.max_err(out.cpu().numpy(), ref) < 2e-5 * max(1.0, np.abs(ref).max())
+    P = torch.empty(npl * B * Tout * Cout, dtype=torch.int16, device=dev)
+    N.check(lib.w2v2_op_gemm_split_planes(fmt, N.ptr(px), x.size, s * Cin, Tin * Cin, N.ptr(img), N.ptr(sc) if fmt else None, None, N.ptr(P), B * Tout * Cout,
+                                          Cout, Tout * Cout, N.ptr(dev_t(torch, dev, bias)), None, Tout, Cout, k * Cin, B, 1, N.ptr(flag), stream()))
+    pv = _planes_value(torch, P, B * Tout * Cout, fmt_name).cpu().numpy().reshape(B, Tout, Cout)
+    assert H.max_err(pv, ref) < 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_gemm_split_planes_rejects_unsupported_shapes(env):
+    lib, torch, dev = env
+    p = torch.zeros(3 * 64 * 96, dtype=torch.int16, device=dev)
+    out = torch.empty((64, 96), device=dev)
+    assert lib.w2v2_op_gemm_split_planes(0, N.ptr(p), 64 * 64, 64, 0, N.ptr(p), None, N.ptr(out), None, 0, 96, 0, None, None, 64, 96, 64, 1, 0, None, stream()) == -1   # N % 256
+    out2 = torch.empty((64, 256), device=dev)
+    assert lib.w2v2_op_gemm_split_planes(0, N.ptr(p), 64 * 32, 32, 0, N.ptr(p), None, N.ptr(out2), None, 0, 256, 0, None, None, 64, 256, 32, 1, 0, None, stream()) == -1   # K % 64
+    assert lib.w2v2_op_gemm_split_planes(1, N.ptr(p), 64 * 64, 64, 0, N.ptr(p), None, N.ptr(out2), None, 0, 256, 0, None, None, 64, 256, 64, 1, 0, None, stream()) == -1   # f16x2 without its scale
+    assert lib.w2v2_op_split_planes(N.ptr(out), N.ptr(p), 64 * 96, 64 * 96, 7, None, stream()) == -1                                                                       # unknown format
+
+
+def test_select_form_gelu_is_the_library_function(env):
+    """csrc/common.h: erf_select / tanh_select (the device library's erff / tanhf with both arms evaluated and the result selected:
+    no control flow around the split GEMM's 128 accumulators) return the library's bits for EVERY one of the 2^32 float patterns."""
+    lib, torch, dev = env
+    mm = torch.full((2,), -1, dtype=torch.int64, device=dev)
+    N.check(lib.w2v2_op_check_select_forms(N.ptr(mm), stream()))
+    assert mm.tolist() == [0, 0]
+
+
 @pytest.mark.parametrize("rows,Kin,Nout,per,S", [(512, 128, 256, 128, 4), (1499 * 2, 256, 128, 1024, 3), (23984, 128, 384, 12032, 2),
                                                  (65, 128, 128, 64, 2), (37, 128, 128, 64, 1)])
 def test_weight_grad_bf16_ragged_rows(env, rows, Kin, Nout, per, S):
