@@ -317,7 +317,9 @@ def _sha16(path):
         return None
 
 
-KERNEL_SOURCES = {"fp32": ("gemm_f32.hip", "gemm_epilogue.h"), "bf16": ("gemm_bf16.hip", "gemm_bf16_sw.hip", "gemm_epilogue.h")}
+KERNEL_SOURCES = {"fp32": ("gemm_f32.hip", "gemm_epilogue.h"), "bf16": ("gemm_bf16.hip", "gemm_bf16_sw.hip", "gemm_sw_common.h", "gemm_epilogue.h"),
+                  "bf16x3": ("gemm_split_sw.hip", "gemm_sw_common.h", "gemm_epilogue.h"), "f16x2": ("gemm_split_sw.hip", "gemm_sw_common.h", "gemm_epilogue.h")}
+FAMILY_KERNEL_TAG = {"fp32": "gemm_f32", "bf16": "gemm_bf16", "bf16x3": "gemm_split", "f16x2": "gemm_split"}     # substring of the family's kernel names
 
 
 def kernel_source_hash(precision):
@@ -333,34 +335,51 @@ def kernel_source_hash(precision):
     return h.hexdigest()[:16]
 
 
-def measured_traffic(precision="fp32", mode="forward"):
-    """HBM bytes per launch of the dominant GEMM family from the committed rocprofv3 --pmc summaries of this same command
-    (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction; tools/pmc_traffic.sh writes them together with the
-    round and the hash of the kernel sources they were measured on).  PMC counters cannot be collected from inside the run, so this
-    is a STORED figure: returned with its provenance, and refused (None, with the reason) when the kernel sources have changed
-    since it was measured -- a stale number is never printed as if it were current."""
-    out = {"bytes": None, "source": None}
+def traffic_key(model, precision, mode, L):
+    return f"{model}/{precision}/{mode}/{L}"
+
+
+def measured_traffic(model, precision, mode, L):
+    """HBM bytes PER STEP of the dominant GEMM family from the committed rocprofv3 --pmc summaries of this same command (separate
+    FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction; tools/pmc_traffic.sh writes profiles/hbm_traffic_configs.json with,
+    per configuration, the family's kernel launches per step, bytes per launch and the hash of the kernel sources they were measured
+    on).  PMC counters cannot be collected from inside the run, so this is a STORED figure: returned with its provenance, and refused
+    (None, with the reason) when the kernel sources have changed since it was measured -- a stale number is never printed as current."""
+    out = {"bytes_per_step": None, "bytes_per_launch": None, "kernel_launches_per_step": None, "source": None}
+    fn = "hbm_traffic_configs.json"
     try:
-        fn = "hbm_traffic_latest.json" if precision == "fp32" else "hbm_traffic_bf16.json"
         with open(os.path.join(ROOT, "profiles", fn)) as f:
             js = json.load(f)
-        meta = js.get("_meta", {})
+        e = js[traffic_key(model, precision, mode, L)]
         want = kernel_source_hash(precision)
-        if meta.get("kernel_source_sha16") != want:
-            out["source"] = (f"profiles/{fn} was measured on kernel sources {meta.get('kernel_source_sha16')} (round {meta.get('round')}); "
-                             f"the sources are now {want}: stale, not printed -- rerun tools/pmc_traffic.sh")
+        if e.get("kernel_source_sha16") != want:
+            out["source"] = (f"profiles/{fn} [{traffic_key(model, precision, mode, L)}] was measured on kernel sources {e.get('kernel_source_sha16')} "
+                             f"(round {e.get('round')}); the sources are now {want}: stale, not printed -- rerun tools/pmc_traffic.sh")
             return out
-        if precision == "fp32":
-            hits = [v for k, v in js.items() if "gemm_f32" in k and v.get("launches")]
-            n = sum(v["launches"] for v in hits)                    # launch-weighted mean over the family's kernels (256x128, 128x128, 64x64 tail tiles)
-            out["bytes"] = round(sum(v["launches"] * (v["fetch_corrected_bytes"] + v["write_bytes"]) for v in hits) / n)
-        else:
-            v = js[mode]
-            out["bytes"] = round(v["fetch_corrected_bytes_per_launch"] + v["write_bytes_per_launch"])
-        out["source"] = f"committed PMC profile profiles/{fn} (round {meta.get('round')}, kernel sources {want}); not measured in this run"
-    except (OSError, ValueError, KeyError) as exc:
+        n = e["kernel_launches_per_step"]
+        if not n:
+            raise ValueError("no launches of the family in the profile")
+        out["bytes_per_launch"] = round(e["fetch_corrected_bytes_per_launch"] + e["write_bytes_per_launch"])
+        out["kernel_launches_per_step"] = n
+        out["bytes_per_step"] = round(n * (e["fetch_corrected_bytes_per_launch"] + e["write_bytes_per_launch"]))
+        out["source"] = f"committed PMC profile profiles/{fn} (round {e.get('round')}, kernel sources {want}); not measured in this run"
+    except (OSError, ValueError, KeyError, ZeroDivisionError, TypeError) as exc:
         out["source"] = f"no usable PMC profile: {exc!r}"
     return out
+
+
+def add_traffic(roof, model, precision, mode, L):
+    """roofline.traffic* on ONE denominator: HBM bytes per step of the family (PMC, stored) beside the compulsory bytes per step (A + B + C
+    of every op-level call once), and their ratio."""
+    if roof is None:
+        return
+    tr = measured_traffic(model, precision, mode, L)
+    alg = roof.get("traffic_algorithmic_per_step")
+    roof["traffic"] = tr["bytes_per_launch"]
+    roof["traffic_unit"] = "HBM bytes per kernel launch of the family (rocprofv3 PMC FETCH_SIZE x 2 + WRITE_SIZE, separate passes)"
+    roof["traffic_per_step"] = tr["bytes_per_step"]
+    roof["traffic_over_algorithmic"] = round(tr["bytes_per_step"] / alg, 3) if tr["bytes_per_step"] and alg else None
+    roof["traffic_source"] = tr["source"]
 
 
 def self_launch(n):
@@ -433,6 +452,7 @@ def add_clock(roof, clk):
         roof["frac_clock_adjusted"] = round(roof["achieved"] / adj, 4)
 
 
+DEFAULT_BATCH = {"base": 32, "large-robust": 16}      # per-GPU batch of the BASELINE configurations (the PMC profiles are kept for these)
 FAMILY_OF = {"fp32": "gemm_f32", "bf16": "gemm_bf16", "bf16x3": "gemm_split", "f16x2": "gemm_split"}
 PEAK_OF = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16x3": round(PEAK_BF16_MFMA_TFLOPS / 6, 1),
            "f16x2": round(PEAK_BF16_MFMA_TFLOPS / 3, 1)}
@@ -525,6 +545,8 @@ def run_leg(ctx, spec, model=None):
     prof = model.profile_read()
     model.profile(False)
     elapsed = D.max_over_ranks(elapsed, device=dev)            # the slowest rank defines the step
+    timed_out = out                                            # (a training leg's loss is reported from the last TIMED step: the steps further
+                                                               #  down that skip the collective let the replicas' weights diverge)
     res = {"elapsed": elapsed, "ms_per_step": 1e3 * elapsed / steps, "B": B, "L": L, "T": T, "cfg": cfg, "x": x, "amask": amask,
            "family": family, "prof": prof if do_prof else {}, "gold_wave": gold_wave, "gold_logits": gold_logits,
            "kernel_launches_per_step": {k: v["kernels"] // steps for k, v in prof.items() if v["kernels"]},
@@ -546,6 +568,7 @@ def run_leg(ctx, spec, model=None):
                 step(all_reduce=False)
             barrier()
             e_no = D.max_over_ranks(time.perf_counter() - t1, device=dev)
+            overlap_was = trainer.overlap_all_reduce
             trainer.overlap_all_reduce = False                 # the collective alone: all buckets back to back on the calling stream
             trainer.all_reduce_gradients()
             barrier()
@@ -555,7 +578,7 @@ def run_leg(ctx, spec, model=None):
                 trainer.all_reduce_gradients()
             barrier()
             e_ar = D.max_over_ranks(time.perf_counter() - t2, device=dev) / reps
-            trainer.overlap_all_reduce = True
+            trainer.overlap_all_reduce = overlap_was
             ar.update({"ms_per_step_without_collective": round(1e3 * e_no / steps, 3),
                        "exposed_ms": round(1e3 * (elapsed - e_no) / steps, 3),
                        "standalone_ms": round(1e3 * e_ar, 3),
@@ -579,8 +602,8 @@ def run_leg(ctx, spec, model=None):
         # the probed window: 40 % of a step, started right after the step's enqueue (long enough to average over many kernels)
         res["clock"] = clock_under_load(ctx, lambda: step(all_reduce=False), max(2000, min(60000, int(400 * res["ms_per_step"]))))
     if mode == "train":
-        assert bool(torch.isfinite(out).all()), "training loss is not finite"
-        res["final_loss"] = round(float(out), 4)
+        assert bool(torch.isfinite(out).all()) and bool(torch.isfinite(timed_out).all()), "training loss is not finite"
+        res["final_loss"] = round(float(timed_out), 4)
     else:
         assert tuple(out.shape) == (B, T, cfg.vocab_size) and bool(torch.isfinite(out).all())
     if gold_logits is not None:
@@ -605,8 +628,9 @@ def roofline_of(res, spec, steps):
             "launches_note": "launches_per_step = op-level GEMM calls; kernel_launches_per_step = kernels enqueued for them (a call whose last "
                              "round of tiles is underfilled runs a main + a tail-tile kernel): the count a rocprofv3 kernel trace shows",
             "avg_launch_ms": round(gm["ms"] / max(1, gm["launches"]), 4),
-            "traffic_algorithmic": round(gm["bytes"] / max(1, gm["launches"])),
-            "traffic_algorithmic_note": "compulsory HBM bytes per op-level call (A + B + C once each), mean over the bracketed launches",
+            "traffic_algorithmic_per_step": round(gm["bytes"] / max(1, gm["launches"]) * (gm["issued"] // max(1, steps))),
+            "traffic_algorithmic_note": "compulsory HBM bytes per step of the family (A + B + C of every op-level call once; mean over the bracketed "
+                                        "launches x calls per step) -- the same denominator as traffic_per_step",
             "event_sampling": f"every {EVENT_STRIDE}th launch of the family bracketed ({gm['launches']} of {gm['issued']})"}
 
 
@@ -635,12 +659,70 @@ def side_object(ctx, spec, res, label):
            "unit": "audio-seconds/s", "dtype": DTYPE_OF[spec["precision"]], "roofline": roofline_of(res, spec, steps),
            "families": fam, "unattributed_ms": unattr, "kernel_launches_per_step": kernels,
            "matrix_tflops": round(flops_step * world / (res["ms_per_step"] * 1e-3) / 1e12, 2)}
+    if B == DEFAULT_BATCH.get(spec["model"]):
+        add_traffic(obj["roofline"], spec["model"], spec["precision"], spec["mode"], L)
     add_clock(obj["roofline"], res.get("clock"))
     if "final_loss" in res:
         obj["final_loss"] = res["final_loss"]
     if "allreduce" in res:
         obj["allreduce"] = res["allreduce"]
     return obj
+
+
+def measure_alt(ctx, model, x, amask, model_name, B, L, steps, warmup, prec, ref_logits, gold_logits, profile):
+    """Beside a fp32 forward leg (never as it): the same workload on the same model in an fp32-grade split mode -- "bf16x3" (six bf16 MFMA
+    products of exact three-term operand splits) or "f16x2" (three fp16 products of two-term splits), DESIGN.md 7.2 / 7.3.  Single-process,
+    timed after the leg; its own roofline (GEMM family, events on every launch of two extra untimed steps), families, clock, traffic."""
+    torch = ctx["torch"]
+    model.set_precision(prec)
+    try:
+        for _ in range(warmup):
+            out3 = model(x, attention_mask=amask)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            out3 = model(x, attention_mask=amask)
+        torch.cuda.synchronize()
+        e3 = time.perf_counter() - t1
+        ms_step = 1e3 * e3 / steps
+        roof, fam, unattr = None, None, None
+        if profile:
+            model.profile(True)
+            model.profile_reset()
+            for _ in range(2):
+                out3 = model(x, attention_mask=amask)
+            torch.cuda.synchronize()
+            pa = model.profile_read()
+            model.profile(False)
+            gs = pa.get("gemm_split")
+            fam = {k: {"ms_per_step": round(v["ms"] / 2, 3), "share": round(v["ms"] / 2 / ms_step, 4), "kernel_launches_per_step": v["kernels"] // 2,
+                       "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0,
+                       "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0.0} for k, v in pa.items() if v["launches"] > 0}
+            unattr = round(ms_step - sum(v["ms"] for v in pa.values()) / 2, 3)
+            if gs and gs["ms"] > 0:
+                ach, pk = gs["flops"] / (gs["ms"] * 1e-3) / 1e12, PEAK_OF[prec]
+                roof = {"kernel": KERNEL_OF[prec], "bound": "mfma", "achieved": round(ach, 2), "peak": pk, "unit": "TFLOP/s (fp32-equivalent)",
+                        "frac": round(ach / pk, 4), "launches_per_step": gs["issued"] // 2, "kernel_launches_per_step": gs["kernels"] // 2,
+                        "ms_per_step": round(gs["ms"] / 2, 3),
+                        "traffic_algorithmic_per_step": round(gs["bytes"] / 2),
+                        "peak_note": "peak = nominal dense bf16 / fp16 MFMA peak / products per fp32 product.  On real operands the matrix pipe itself "
+                                     "sustains 0.68-0.76 of the nominal figure at 1.67-1.85 GHz (power-limited: a register-only MFMA loop, "
+                                     "profiles/r05_mfma_power_probe.txt), which bounds frac for any kernel"}
+                if B == DEFAULT_BATCH.get(model_name):
+                    add_traffic(roof, model_name, prec, "forward", L)
+                # the clock this mode runs at (the bf16 / fp16 matrix pipe draws more power than the fp32 one: the chip throttles)
+                add_clock(roof, clock_under_load(ctx, lambda: model(x, attention_mask=amask), max(2000, int(400 * ms_step))))
+    finally:
+        model.set_precision("fp32")
+    o = {"precision": ALT_NOTE[prec], "value": round(B * L / SAMPLE_RATE * steps / e3, 2), "unit": "audio-seconds/s", "steps": steps,
+         "ms_per_step": round(ms_step, 3), "roofline": roof, "families": fam, "unattributed_ms": unattr,
+         "max_abs_logit_diff_vs_fp32_path": float((out3 - ref_logits).abs().max()),
+         "note": "opt-in mode, not the headline; logit error vs the fp64 reference at the fp32 path's level (tests/test_model_gpu.py)"}
+    if gold_logits is not None:
+        o["max_abs_logit_err"] = float((out3[:2].double().cpu() - torch.from_numpy(gold_logits).double()).abs().max())
+    if prec == "f16x2":
+        o["range_overflow"] = bool(model.range_overflow())
+    return o
 
 
 def main():
@@ -727,53 +809,12 @@ def main():
     elapsed, prof, logit_err, gold_wave = res["elapsed"], res["prof"], res.get("logit_err"), res["gold_wave"]
     gemm_family = res["family"]
 
-    # Beside the headline (never as it): the same workload in precision mode "bf16x3" -- fp32-level results from the bf16
-    # matrix cores.  Single-process forward runs of the fp32 configuration only; timed after the headline.
-    def measure_alt(prec, ref_logits):
-        model.set_precision(prec)
-        try:
-            for _ in range(max(1, args.warmup)):
-                out3 = model(x, attention_mask=amask)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                out3 = model(x, attention_mask=amask)
-            torch.cuda.synchronize()
-            e3 = time.perf_counter() - t1
-            roof = None
-            if not args.no_profile:                            # one extra, untimed forward with the family's launches bracketed by events
-                model.profile(True, families=["gemm_split"], stride=1)
-                model.profile_reset()
-                out3 = model(x, attention_mask=amask)
-                torch.cuda.synchronize()
-                gs = model.profile_read().get("gemm_split")
-                model.profile(False)
-                if gs and gs["ms"] > 0:
-                    ach, pk = gs["flops"] / (gs["ms"] * 1e-3) / 1e12, PEAK_OF[prec]
-                    roof = {"kernel": KERNEL_OF[prec], "bound": "mfma", "achieved": round(ach, 2), "peak": pk, "unit": "TFLOP/s (fp32-equivalent)",
-                            "frac": round(ach / pk, 4), "launches": gs["launches"], "ms_per_step": round(gs["ms"], 3),
-                            "note": "peak = nominal dense bf16 / fp16 MFMA peak / products per fp32 product; on real data the pipe itself sustains "
-                                    "0.68-0.76 of that nominal figure (power: profiles/r05_mfma_power_probe.txt)"}
-                    # the clock this mode runs at (the bf16 matrix pipe draws more power than the fp32 one: the chip throttles)
-                    add_clock(roof, clock_under_load(ctx, lambda: model(x, attention_mask=amask), max(2000, int(400 * 1e3 * e3 / args.steps))))
-        finally:
-            model.set_precision("fp32")
-        o = {"precision": ALT_NOTE[prec],
-             "value": round(B * L / SAMPLE_RATE * args.steps / e3, 2), "unit": "audio-seconds/s",
-             "ms_per_step": round(1e3 * e3 / args.steps, 3), "roofline": roof,
-             "max_abs_logit_diff_vs_fp32_path": float((out3 - ref_logits).abs().max()),
-             "note": "opt-in mode, not the headline; logit error vs the fp64 reference at the fp32 path's level (tests/test_model_gpu.py)"}
-        if gold_wave is not None and res.get("gold_logits") is not None:
-            o["max_abs_logit_err"] = float((out3[:2].double().cpu() - torch.from_numpy(res["gold_logits"]).double()).abs().max())
-        if prec == "f16x2":
-            o["range_overflow"] = bool(model.range_overflow())
-        return o
-
     alts = {}
     if world == 1 and args.mode == "forward" and args.precision == "fp32" and not args.no_alt:
         for prec in ("bf16x3", "f16x2"):
             try:                                               # never let the side measurement cost the headline line
-                alts[prec] = measure_alt(prec, out)
+                alts[prec] = measure_alt(ctx, model, x, amask, args.model, B, L, args.steps, max(1, args.warmup), prec, out, res.get("gold_logits"),
+                                         not args.no_profile)
             except Exception as exc:                           # noqa: BLE001
                 alts[prec] = {"precision": prec, "error": repr(exc)}
 
@@ -806,12 +847,10 @@ def main():
         }
         if prof:
             roof = roofline_of(res, spec, args.steps)
-            if (args.model, B, L) == ("base", 32, 246000) and args.precision in ("fp32", "bf16"):
-                tr = measured_traffic(args.precision, args.mode)
-                roof["traffic"], roof["traffic_source"] = tr["bytes"], tr["source"]
-            else:
-                roof["traffic"], roof["traffic_source"] = None, "no PMC profile is kept for this configuration"
-            roof["traffic_unit"] = "HBM bytes per kernel launch of the family (rocprofv3 PMC FETCH_SIZE x 2 + WRITE_SIZE, separate passes)"
+            if B == DEFAULT_BATCH.get(args.model):
+                add_traffic(roof, args.model, args.precision, args.mode, L)
+            elif roof is not None:
+                roof["traffic"], roof["traffic_source"] = None, "PMC profiles are kept for the BASELINE batch sizes only"
             add_clock(roof, res.get("clock"))
             line["roofline"] = roof
             fam, unattr, kernels, flops_step = families_of(res, world, args.steps)
@@ -838,16 +877,23 @@ def main():
     # training legs run the bucketed RCCL gradient all-reduce when N > 1).  Each leg is guarded: a failure is reported in its
     # object and never costs the headline line.
     headline_default = (args.model, args.precision, args.mode, args.batch, args.samples) == ("base", "fp32", "forward", 32, 246000)
+    if headline_default and not args.no_side and rank == 0:
+        try:                                                   # insurance: the headline as measured, on disk before anything else runs
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "bench_headline.json"), "w") as f:
+                json.dump(line, f)
+        except OSError:
+            pass
     if headline_default and not args.no_side:
         del model, out, x, amask, res
         gc.collect()
         k = max(1, args.side_shrink)
-        legs = [("configs2_train_bf16", {"model": "base", "precision": "bf16", "mode": "train", "B": 32 // k, "L": 246000, "steps": 5, "warmup": 2},
+        legs = [("configs2_train_bf16", {"model": "base", "precision": "bf16", "mode": "train", "B": 32 // k, "L": 246000, "steps": 10, "warmup": 2},
                  "BASELINE configs[2] per-GPU shard: wav2vec2-base CTC fine-tune step, bf16 contractions (conv stack frozen, dropout 0.1, "
                  "spec-augment, Adam, fp32 variables / optimizer state), 32 x 246000 per GPU (global batch 256 at 8 GPUs)"),
-                ("configs3_large_fwd_f32", {"model": "large-robust", "precision": "fp32", "mode": "forward", "B": 16 // k, "L": 246000, "steps": 5, "warmup": 2},
+                ("configs3_large_fwd_f32", {"model": "large-robust", "precision": "fp32", "mode": "forward", "B": 16 // k, "L": 246000, "steps": 10, "warmup": 2},
                  "BASELINE configs[3]: wav2vec2-large-robust (24L / 1024d, prenorm, LayerNorm convs, attention mask) fp32 forward, 16 x 246000 on 1 GPU"),
-                ("configs4_large_train_bf16", {"model": "large-robust", "precision": "bf16", "mode": "train", "B": 16 // k, "L": 480000, "steps": 3, "warmup": 1},
+                ("configs4_large_train_bf16", {"model": "large-robust", "precision": "bf16", "mode": "train", "B": 16 // k, "L": 480000, "steps": 10, "warmup": 2},
                  "BASELINE configs[4] per-GPU shard: large (24L / 1024d; xlsr-53 is run as the robust architecture, SURVEY 8d) bf16 CTC fine-tune "
                  "step, 16 x 480000 per GPU (global batch 128 at 8 GPUs)")]
         keep = None                                            # the large model is built once and serves configs[3] and [4]
@@ -858,11 +904,29 @@ def main():
                 reuse = keep if sp["model"] == "large-robust" else None
                 r, m2, o2 = run_leg(ctx, sp, model=reuse)
                 obj = side_object(ctx, sp, r, label) if rank == 0 else None
+                if name == "configs3_large_fwd_f32" and world == 1 and not args.no_alt:
+                    # the same forward in the two fp32-grade split modes (single process; each guarded like the leg itself)
+                    for prec in ("bf16x3", "f16x2"):
+                        try:
+                            obj[prec] = measure_alt(ctx, m2, r["x"], r["amask"], sp["model"], r["B"], r["L"], sp["steps"], sp["warmup"], prec, o2, None,
+                                                    sp["profile"])
+                        except Exception as exc:               # noqa: BLE001
+                            obj[prec] = {"precision": prec, "error": repr(exc)[:400]}
                 keep = m2 if sp["model"] == "large-robust" else None
                 del r, o2, m2
             except Exception as exc:                           # noqa: BLE001 -- reported, the headline still prints
                 obj = {"workload": label, "error": repr(exc)[:400]}
                 keep = None
+                failed = 1
+            else:
+                failed = 0
+            if world > 1:
+                # every rank learns whether ANY rank failed this leg (a failure all ranks share -- out of memory, an unsupported shape --
+                # reaches this point on all of them; one that hits a single rank inside a collective cannot be recovered from without
+                # aborting the group, which is why the headline line is also kept in gpurun_out/bench_headline.json before the legs)
+                if D.max_over_ranks(float(failed), device=dev) > 0 and not failed:
+                    obj = {"workload": label, "error": "another rank failed this leg"} if rank == 0 else None
+                    keep = None
             gc.collect()
             if rank == 0:
                 obj["leg_wall_s"] = round(time.perf_counter() - t_leg, 1)
