@@ -888,12 +888,13 @@ def main():
         del model, out, x, amask, res
         gc.collect()
         k = max(1, args.side_shrink)
-        legs = [("configs2_train_bf16", {"model": "base", "precision": "bf16", "mode": "train", "B": 32 // k, "L": 246000, "steps": 10, "warmup": 2},
+        side_steps, side_warm = (10, 2) if k == 1 else (3, 1)      # (the shrunken legs exist for the multi-process tests: keep them short)
+        legs = [("configs2_train_bf16", {"model": "base", "precision": "bf16", "mode": "train", "B": 32 // k, "L": 246000, "steps": side_steps, "warmup": side_warm},
                  "BASELINE configs[2] per-GPU shard: wav2vec2-base CTC fine-tune step, bf16 contractions (conv stack frozen, dropout 0.1, "
                  "spec-augment, Adam, fp32 variables / optimizer state), 32 x 246000 per GPU (global batch 256 at 8 GPUs)"),
-                ("configs3_large_fwd_f32", {"model": "large-robust", "precision": "fp32", "mode": "forward", "B": 16 // k, "L": 246000, "steps": 10, "warmup": 2},
+                ("configs3_large_fwd_f32", {"model": "large-robust", "precision": "fp32", "mode": "forward", "B": 16 // k, "L": 246000, "steps": side_steps, "warmup": side_warm},
                  "BASELINE configs[3]: wav2vec2-large-robust (24L / 1024d, prenorm, LayerNorm convs, attention mask) fp32 forward, 16 x 246000 on 1 GPU"),
-                ("configs4_large_train_bf16", {"model": "large-robust", "precision": "bf16", "mode": "train", "B": 16 // k, "L": 480000, "steps": 10, "warmup": 2},
+                ("configs4_large_train_bf16", {"model": "large-robust", "precision": "bf16", "mode": "train", "B": 16 // k, "L": 480000, "steps": side_steps, "warmup": side_warm},
                  "BASELINE configs[4] per-GPU shard: large (24L / 1024d; xlsr-53 is run as the robust architecture, SURVEY 8d) bf16 CTC fine-tune "
                  "step, 16 x 480000 per GPU (global batch 128 at 8 GPUs)")]
         keep = None                                            # the large model is built once and serves configs[3] and [4]

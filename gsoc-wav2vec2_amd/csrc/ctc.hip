@@ -42,8 +42,10 @@ __device__ __forceinline__ double lse3(double a, double b, double c) {
 struct CtcArgs {
     const float* logits;      // (B, T, V)
     const int32_t* labels;    // (B, U)
-    const int32_t* label_len;
-    const int32_t* logit_len;
+    const int32_t* label_len; // (B), or null: the reference's rule, count of labels != blank (losses.py:32-33)
+    const int32_t* logit_len; // (B), or null: every row takes uniform_len frames (losses.py:29-30)
+    int uniform_len;
+    float grad_scale;         // the gradient is multiplied by it (1 / division_factor, losses.py:45)
     float* nll;               // (B)
     float* grad;              // (B, T, V) or null
     double* alpha_ws;         // (B, T, S_max) when grad != null
@@ -71,9 +73,21 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_kernel(CtcArgs a) {
     __shared__ int bad_label;
 
     const int b = blockIdx.x, tid = threadIdx.x;
-    int U = a.label_len[b];
+    int U;
+    if (a.label_len) {
+        U = a.label_len[b];
+    } else {                                             // count of non-blank labels (block-wide, integer: order-independent)
+        __shared__ int cnt_sh;
+        if (tid == 0) cnt_sh = 0;
+        __syncthreads();
+        int c = 0;
+        for (int u = tid; u < a.U; u += CTC_THREADS) c += a.labels[(int64_t)b * a.U + u] != a.blank;
+        if (c) atomicAdd(&cnt_sh, c);
+        __syncthreads();
+        U = cnt_sh;
+    }
     U = U < 0 ? 0 : (U > a.U ? a.U : U);
-    int Tb = a.logit_len[b];
+    int Tb = a.logit_len ? a.logit_len[b] : a.uniform_len;
     Tb = Tb < 0 ? 0 : (Tb > a.T ? a.T : Tb);
     const int S = 2 * U + 1;
     const float* __restrict__ lg = a.logits + (int64_t)b * a.T * a.V;
@@ -192,9 +206,18 @@ __global__ __launch_bounds__(64) void ctc_grad_kernel(CtcArgs a) {
     // probability in [0, 1] and the terms of one entry sum to at most 1, so 2^61 leaves headroom in 64 bits
     unsigned long long* occ = reinterpret_cast<unsigned long long*>(raw);          // [V]
     const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    int U = a.label_len[b];
+    int U;
+    if (a.label_len) {
+        U = a.label_len[b];
+    } else {
+        int c = 0;
+        for (int u = tid; u < a.U; u += 64) c += a.labels[(int64_t)b * a.U + u] != a.blank;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+        U = c;
+    }
     U = U < 0 ? 0 : (U > a.U ? a.U : U);
-    int Tb = a.logit_len[b];
+    int Tb = a.logit_len ? a.logit_len[b] : a.uniform_len;
     Tb = Tb < 0 ? 0 : (Tb > a.T ? a.T : Tb);
     const int S = 2 * U + 1;
     float* __restrict__ gr = a.grad + ((int64_t)b * a.T + t) * a.V;
@@ -243,7 +266,17 @@ __global__ __launch_bounds__(64) void ctc_grad_kernel(CtcArgs a) {
         }
     }
     __syncthreads();
-    for (int v = tid; v < a.V; v += 64) gr[v] = (float)(exp((double)lg[v] - lse) - (double)occ[v] * (1.0 / FIX));
+    // (x grad_scale as a separate fp32 multiplication: the same bits as scaling the fp32 gradient afterwards, and exact for 1.0)
+    for (int v = tid; v < a.V; v += 64) gr[v] = (float)(exp((double)lg[v] - lse) - (double)occ[v] * (1.0 / FIX)) * a.grad_scale;
+}
+
+// loss_sum[0] = sum_b nll[b] * scale, added in row order by one lane (Keras Reduction.SUM of the per-sample losses / division_factor)
+__global__ void ctc_loss_sum_kernel(const float* __restrict__ nll, int B, float scale, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += nll[b] * scale;
+        out[0] = s;
+    }
 }
 
 struct LenArgs {
@@ -294,11 +327,18 @@ __global__ void frame_len_finish_kernel(int32_t* __restrict__ out, int B, LenArg
 int launch_ctc(Profiler* prof, const float* logits, int B, int T, int V, const int32_t* labels,
                int U, const int32_t* label_len, const int32_t* logit_len, int blank, float* nll,
                float* grad, hipStream_t s) {
-    W2V2_REQUIRE(logits && labels && label_len && logit_len && nll, "ctc: null operand");
+    W2V2_REQUIRE(label_len && logit_len, "ctc: null operand");
+    return launch_ctc_x(prof, logits, B, T, V, labels, U, label_len, logit_len, 0, blank, 1.0f, nll, grad, nullptr, s);
+}
+
+int launch_ctc_x(Profiler* prof, const float* logits, int B, int T, int V, const int32_t* labels, int U, const int32_t* label_len,
+                 const int32_t* logit_len, int uniform_len, int blank, float grad_scale, float* nll, float* grad, float* loss_sum, hipStream_t s) {
+    W2V2_REQUIRE(logits && labels && nll && (logit_len || uniform_len > 0), "ctc: null operand");
     W2V2_REQUIRE(B > 0 && T > 0 && V > 0 && U >= 0, "ctc: bad sizes");
     W2V2_REQUIRE(blank >= 0 && blank < V, "ctc: blank index %d outside vocabulary %d", blank, V);
     CtcArgs a;
     a.logits = logits; a.labels = labels; a.label_len = label_len; a.logit_len = logit_len;
+    a.uniform_len = uniform_len; a.grad_scale = grad_scale;
     a.nll = nll; a.grad = grad; a.B = B; a.T = T; a.V = V; a.U = U; a.blank = blank;
     a.S_max = 2 * U + 1;
     a.alpha_ws = a.beta_ws = a.lse_ws = nullptr;
@@ -327,6 +367,7 @@ int launch_ctc(Profiler* prof, const float* logits, int B, int T, int V, const i
     ProfScope ps(prof, FAM_CTC, 30.0 * B * (double)T * a.S_max, 4.0 * B * (double)T * V * (grad ? 2 : 1), s);
     W2V2_LAUNCH(ctc_kernel, dim3(B, grad ? 2 : 1), dim3(CTC_THREADS), lds, s, a);
     if (grad) W2V2_LAUNCH(ctc_grad_kernel, dim3(T, B), dim3(64), (size_t)V * sizeof(unsigned long long), s, a);
+    if (loss_sum) W2V2_LAUNCH(ctc_loss_sum_kernel, dim3(1), dim3(64), 0, s, nll, B, grad_scale, loss_sum);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }

@@ -958,6 +958,13 @@ int w2v2_ctc_loss(const float* logits, int32_t B, int32_t T, int32_t V, const in
                       reinterpret_cast<hipStream_t>(stream));
 }
 
+int w2v2_ctc_loss_fused(const float* logits, int32_t B, int32_t T, int32_t V, const int32_t* labels, int32_t U, int32_t logit_length_all,
+                        int32_t blank, float scale, float* nll, float* grad, float* loss_sum, void* stream) {
+    W2V2_REQUIRE(logit_length_all > 0, "ctc_loss_fused: logit_length_all must be positive");
+    return launch_ctc_x(w2v2::tl_step_prof, logits, B, T, V, labels, U, nullptr, nullptr, logit_length_all, blank, scale, nll, grad, loss_sum,
+                        reinterpret_cast<hipStream_t>(stream));
+}
+
 int w2v2_activation_info(const w2v2_model* m, const char* name, int64_t shape[3]) {
     W2V2_REQUIRE(m && name && shape, "activation_info: null argument");
     auto it = m->acts.find(name);

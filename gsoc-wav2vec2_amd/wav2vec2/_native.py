@@ -60,6 +60,7 @@ PROTOTYPES = {
     "w2v2_get_precision": (C.c_int, [_P]),
     "w2v2_forward": (C.c_int, [_P, _P, _I32, _I64, _P, _P, _P]),
     "w2v2_ctc_loss": (C.c_int, [_P, _I32, _I32, _I32, _P, _I32, _P, _P, _I32, _P, _P, _P]),
+    "w2v2_ctc_loss_fused": (C.c_int, [_P, _I32, _I32, _I32, _P, _I32, _I32, _I32, C.c_float, _P, _P, _P, _P]),
     "w2v2_set_trainable": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "w2v2_set_trainable_flags": (C.c_int, [_P, _P, _I32]),
     "w2v2_set_option": (C.c_int, [_P, _I32, _I32]),

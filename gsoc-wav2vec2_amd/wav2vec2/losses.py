@@ -53,20 +53,21 @@ class CTCLoss:
         logit_len = int(self._get_logit_length(int(self.model_input_shape[1])))
         if logit_len > T:
             raise ValueError(f"model_input_shape implies {logit_len} frames but logits have {T}")
-        logit_length = torch.full((B,), logit_len, device=dev, dtype=torch.int32)
-        label_length = (labels != self.pad_id).sum(dim=-1).to(torch.int32).contiguous()
         nll = torch.empty((B,), device=dev, dtype=torch.float32)
         grad = torch.empty_like(logits) if with_grad else None
+        total = torch.empty((1,), device=dev, dtype=torch.float32)
         lib = N.load()
-        N.check(lib.w2v2_ctc_loss(N.ptr(logits), B, T, V, N.ptr(labels), U, N.ptr(label_length),
-                                  N.ptr(logit_length), self.pad_id, N.ptr(nll), N.ptr(grad),
-                                  N.current_stream()), "w2v2_ctc_loss")
+        # label lengths (count of labels != pad_id), the uniform logit length, the 1 / division_factor scaling of the gradient and
+        # the SUM reduction are all evaluated by the native call: no framework kernel runs between the forward and the backward
+        N.check(lib.w2v2_ctc_loss_fused(N.ptr(logits), B, T, V, N.ptr(labels), U, logit_len, self.pad_id, 1.0 / float(self.division_factor),
+                                        N.ptr(nll), N.ptr(grad), N.ptr(total), N.current_stream()), "w2v2_ctc_loss_fused")
+        self.last_total = total[0]            # sum_b nll_b / division_factor (what `__call__` returns), a 0-d device tensor view
         if with_grad:
-            return nll, grad / self.division_factor
+            return nll, grad                  # grad already / division_factor
         return nll
 
     def __call__(self, labels, hidden_states):
-        nll = self.per_sample(labels, hidden_states)
-        return (nll / self.division_factor).sum()
+        self.per_sample(labels, hidden_states)
+        return self.last_total
 
     call = __call__

@@ -263,12 +263,13 @@ class Trainer:
         own gradients): a MEASUREMENT switch -- bench.py times the step with and without it to report the exposed
         communication time -- never the training semantics of the reference (main.py:156,192)."""
         logits = self.forward(batch, attention_mask)
-        nll, grad = self.loss.per_sample(labels, logits, with_grad=True)     # grad already / division_factor
+        _, grad = self.loss.per_sample(labels, logits, with_grad=True)       # grad already / division_factor
+        total = self.loss.last_total                                         # sum_b nll_b / division_factor, summed on the device
         self.backward(grad)
         if all_reduce:
             self.all_reduce_gradients()
         self.apply_gradients()
-        return (nll / self.loss.division_factor).sum()
+        return total
 
     def all_reduce_payload(self):
         """(bytes sent per step and replica, number of non-empty buckets, number of collectives) of `all_reduce_gradients`."""

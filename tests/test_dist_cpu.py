@@ -173,6 +173,42 @@ def test_two_rank_gradient_all_reduce_equals_unsharded(tmp_path, payload):
         assert err < 2e-2 * scale, (err, scale)                                 # two bf16 roundings of the payload
 
 
+def _payload_worker(rank, world, port, out_dir, n):
+    for p in (ROOT, os.path.join(ROOT, "gsoc-wav2vec2_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from wav2vec2 import dist as DD
+    from wav2vec2 import variables as V
+    torch.set_num_threads(1)
+    DD.init(backend="gloo")
+    g = torch.from_numpy(V.hash_normal(f"dist/payload{rank}", n, 3).astype(np.float32) * 1e-3)      # a rank's gradient shard contribution
+    for dtype, tag in ((None, "fp32"), (torch.bfloat16, "bf16")):
+        buf = g.clone()
+        DD.all_reduce_range(buf, 0, n, dtype, async_op=False)()
+        if rank == 0:
+            np.save(os.path.join(out_dir, f"sum_{tag}.npy"), buf.double().numpy())
+    torch.distributed.destroy_process_group()
+
+
+def test_eight_rank_bf16_payload_error_bound(tmp_path):
+    """Trainer(allreduce_dtype="bf16") at the world size of BASELINE configs[2] / [4]: the collective SUMs in bf16, so every partial sum of
+    the reduction is rounded again.  Eight gloo ranks, one million-element gradient each: the fp32 payload equals the fp64 sum to fp32
+    rounding; the bf16 payload stays within 2e-2 of max |sum| (worst element) and 8e-3 rms -- the figure dist.all_reduce_range documents
+    (the two-rank test above pins 2e-2 at two roundings; this is the eight-rank case the review asked for)."""
+    from wav2vec2 import variables as V
+    world, n = 8, 1 << 20
+    mp.spawn(_payload_worker, args=(world, _free_port(), str(tmp_path), n), nprocs=world, join=True)
+    want = sum(V.hash_normal(f"dist/payload{r}", n, 3).astype(np.float32).astype(np.float64) * np.float64(np.float32(1e-3)) for r in range(world))
+    f32, b16 = np.load(tmp_path / "sum_fp32.npy"), np.load(tmp_path / "sum_bf16.npy")
+    scale = np.abs(want).max()
+    assert np.abs(f32 - want).max() < 1e-6 * scale
+    err = np.abs(b16 - want)
+    print(f"8-rank bf16 payload: max err {err.max() / scale:.2e} of max |sum|, rms {np.sqrt((err ** 2).mean()) / np.sqrt((want ** 2).mean()):.2e}")
+    assert err.max() < 2e-2 * scale
+    assert np.sqrt((err ** 2).mean()) < 8e-3 * np.sqrt((want ** 2).mean())
+
+
 def test_bucket_layout_tiles_the_buffer():
     from wav2vec2 import variables as V
     for case in ("tiny_base", "base_sample_padded", "robust_masked"):

@@ -167,3 +167,29 @@ def test_bench_two_ranks_report_every_baseline_config_with_the_collective():
             assert ar["ms_per_step_without_collective"] > 0 and ar["standalone_ms"] > 0 and ar["busbw_GBps"] > 0
             assert np.isfinite(leg["final_loss"])
     assert js["configs2_train_bf16"]["allreduce"]["payload_bytes"] == 4 * (90195104 + 768)      # 360.8 MB fp32 for base
+
+
+def test_bench_four_ranks_over_gloo_keep_the_eight_gpu_path_warm():
+    """The same command at N = 4 (four processes on the one GPU, gloo): the world size is no longer a power-of-two pair, the large model's
+    26 gradient buckets and the base model's 14 are all-reduced among four ranks inside the timed steps, the loss divisor is 4 x the
+    per-rank batch.  No number of this run is quotable (one GPU, host-staged collectives) -- it exists so that the driver's first real
+    `--gpus 8` run cannot fail on plumbing."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+           "--side-shrink", "8", "--no-cpu-baseline", "--no-alt", "--no-profile"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    js = json.loads(lines[0])
+    assert js["n_gpus"] == 4 and js["comm"]["world_size"] == 4 and js["config"]["global_batch"] == 128 and js["scaling"] == "weak"
+    for key, buckets in (("configs2_train_bf16", 14), ("configs4_large_train_bf16", 26)):
+        leg = js[key]
+        assert "error" not in leg, leg
+        ar = leg["allreduce"]
+        assert leg["n_gpus"] == 4 and ar["world_size"] == 4 and ar["buckets"] == buckets and ar["collectives_per_step"] >= buckets
+        assert ar["standalone_ms"] > 0 and np.isfinite(leg["final_loss"])
+    assert "error" not in js["configs3_large_fwd_f32"] and js["configs3_large_fwd_f32"]["global_batch"] == 4 * 2

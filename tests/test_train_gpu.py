@@ -773,6 +773,42 @@ def test_configs2_full_batch_bf16_step(env):
     assert np.array_equal(two, runs[0][0][:2]), f"rows 0-1 of the full batch differ from the 2-row forward by {H.max_err(two, runs[0][0][:2]):.3e}"
 
 
+def test_configs4_full_batch_bf16_step(env):
+    """BASELINE configs[4] at its full per-GPU batch: large-robust (24 L / 1024 d, prenorm, LayerNorm convs, attention mask), bf16,
+    16 x 480000 (T = 1499: B T = 23984 rows, not a multiple of the 64-row K tile of the weight gradients), dropout 0.1 + spec-augment,
+    conv stack frozen.  The same oracle-free properties as configs[2]: finite loss and gradients, a bit-reproducible step (logits and the
+    whole flat gradient buffer), and rows 0-1 of the 16-row training forward equal to the 2-row training forward bit for bit -- the
+    slab routing of the ragged weight-gradient rows and the 128 x 256 tiles at this size are exercised under assertion, not only in
+    bench.py."""
+    import wav2vec2
+    B, L = 16, 480000
+    m, cfg, w = build("robust_masked", L)
+    m.set_precision("bf16")
+    T = cfg.num_frames(L)
+    assert T == 1499
+    x = V.hash_normal("configs4/wave", B * L, 13).reshape(B, L).astype(np.float32)
+    mask = np.ones((B, L), np.int32)
+    mask[1, -70000:] = 0
+    mask[5, -200001:] = 0
+    x = (x * mask).astype(np.float32)
+    labels = _ragged_labels(B, 256, 24, 200, 7)
+    loss_fn = wav2vec2.CTCLoss(cfg, x.shape, division_factor=B)
+    tr = wav2vec2.Trainer(m, loss_fn, dropout=0.1, apply_spec_augment=False, seed=2)
+    spec = compute_mask_indices((B, T), 0.05, 10, rng=np.random.RandomState(5))
+    runs = []
+    for _ in range(2):
+        logits = tr.forward(x, attention_mask=mask, spec_mask=spec, step_seed=43)
+        nll, dlog = loss_fn.per_sample(labels, logits, with_grad=True)
+        tr.backward(dlog)
+        runs.append((logits.cpu().numpy().copy(), tr.grad_buffer().cpu().numpy().copy(), nll.cpu().numpy().copy()))
+    assert np.isfinite(runs[0][0]).all() and np.isfinite(runs[0][1]).all() and np.isfinite(runs[0][2]).all()
+    assert np.abs(runs[0][1]).max() > 0
+    assert np.array_equal(runs[0][0], runs[1][0]), "logits differ between two identical steps"
+    assert np.array_equal(runs[0][1], runs[1][1]), f"{int((runs[0][1] != runs[1][1]).sum())} gradient elements differ"
+    two = tr.forward(x[:2], attention_mask=mask[:2], spec_mask=spec[:2], step_seed=43).cpu().numpy()
+    assert np.array_equal(two, runs[0][0][:2]), f"rows 0-1 of the full batch differ from the 2-row forward by {H.max_err(two, runs[0][0][:2]):.3e}"
+
+
 def test_new_trainer_is_a_fresh_optimizer(env):
     """The reference builds a new Adam for stage 2 (src/main.py:213,240): iteration 0 AND zero moments.  The moments live in
     the model's native state, so a second Trainer on a used model must reset them; `reset_optimizer=False` adopts them."""
