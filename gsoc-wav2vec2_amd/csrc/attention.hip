@@ -662,7 +662,8 @@ int launch_attention_x(Profiler* prof, const float* qkv, const uint16_t* qkv16, 
     W2V2_REQUIRE(!ctx16, "attention: a bf16 shadow output needs the bf16 kernel (precision 1, head size 64)");
     if (gemm_get_precision() >= 2 && tune_int("W2V2_SPLIT_ATTN", 1) != 0 && attention_split_supported(dh) && H % 4 == 0 &&
         ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(ctx)) & 15) == 0)
-        return launch_attention_split(qkv, frame_len, ctx, B, T, H, heads, s, planes);     // fp32-level results, bf16 matrix cores
+        return launch_attention_split(qkv, frame_len, ctx, B, T, H, heads, s, planes, gemm_get_precision() == W2V2_PRECISION_F16X2 ? PF_F16X2 : PF_BF16X3,
+                                      planes ? planes->range_flag : nullptr);     // fp32-level results, bf16 / fp16 matrix cores
     W2V2_REQUIRE(ctx && !(planes && planes->p), "attention: a plane output needs the split kernel (precision modes 2 / 3, head size 64)");
     AttnArgs a{qkv, frame_len, ctx, B, T, H, heads, 1.0f / sqrtf((float)dh)};
     switch (dh) {

@@ -746,7 +746,7 @@ int launch_attention_bwd_bf16(const float* qkv, const uint16_t* qkv16, const int
     W2V2_REQUIRE(((reinterpret_cast<uintptr_t>(ctx) | reinterpret_cast<uintptr_t>(ctx16)) & 15) == 0, "attention_bwd_bf16: unaligned ctx");
     W2V2_REQUIRE(dvec, "attention_bwd_bf16: null dvec");
     Attn16BwdArgs a{q16, frame_len, do16, dvec, ctx16, ctx16 ? nullptr : ctx, dqkv, dqkv16, colpart, B, T, H, heads, nqb, nqb * heads * B};
-    const bool bits = tr.keep_bits && tr.p > 0.f;
+    const bool bits = tr.keep_bits && (uint32_t)((double)tr.p * 65536.0) != 0u;      // = dropout_threshold(p) != 0: the forward's predicate for writing the words
     size_t lds_q = 2 * (2 * IMG + (bits ? NW * 64 * 4 : 0)), lds_kv = 2 * (2 * IMG + 2 * KT * 4 + (bits ? NW * 2 * (KT + 4) * 4 : 0));
     if (colpart) {
         if (lds_q < (size_t)COLSUM_LDS) lds_q = COLSUM_LDS;

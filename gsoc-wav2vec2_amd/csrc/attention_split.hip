@@ -13,6 +13,11 @@
 // Block = 8 waves x 32 queries; K and V^T live in LDS as three bf16 planes each (6 x 8 KiB per stage, two stages = 96 KiB,
 // one block per CU, two waves per SIMD).  The next tile is loaded to registers under the current tile's work, split
 // and stored after it.
+//
+// FMT = PF_F16X2 (precision mode f16x2): the same kernel with every operand as TWO fp16 terms and three products per contraction
+// (a1 b0 + a0 b1 + a0 b0) -- half the MFMAs, two planes per LDS image, a cheaper split.  Operands are scaled by powers of two into
+// fp16's comfortable range (q d^-0.5, k, v by F16X2_ACT_SCALE like every activation of the mode; the probabilities, which lie in
+// [0, 1], by 2^10) and the accumulators rescaled exactly; a value beyond the range saturates and sets the mode's sticky flag.
 #include "common.h"
 
 namespace w2v2 {
@@ -31,8 +36,10 @@ constexpr int KT = 64;      // keys per tile
 constexpr int NW = 8;       // waves per block, 32 queries each
 constexpr int NT = NW * 64;
 constexpr int ROWB = 128;   // bytes per LDS row: 64 bf16
-constexpr int PLANE = KT * ROWB;        // one bf16 plane of K (64 keys x 64 d) or of V^T (64 d x 64 keys): 8 KiB
-constexpr int STAGE = 6 * PLANE;        // K planes 0..2, then V^T planes 0..2
+constexpr int PLANE = KT * ROWB;        // one 16-bit plane of K (64 keys x 64 d) or of V^T (64 d x 64 keys): 8 KiB
+constexpr int stage_bytes(int fmt) { return 2 * plane_count(fmt) * PLANE; }      // K planes, then V^T planes
+constexpr float P_SCALE = 1024.0f;      // f16x2: probabilities x 2^10 before their split
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 
 struct AttnSplitArgs {
     const float* qkv;           // (B, T, 3H): q | k | v
@@ -41,9 +48,9 @@ struct AttnSplitArgs {
     int B, T, H, heads;
     float scale;
     PlaneOut planes;            // optional planes of ctx for the out-projection GEMM (gemm_split_sw.hip)
+    int* range_flag;            // f16x2: sticky saturation flag (may be null)
 };
 
-__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
 
 // two fp32 -> one dword per plane (lo = first value), exact three-term split
 struct Split3 { unsigned p0, p1, p2; };
@@ -61,6 +68,30 @@ __device__ __forceinline__ Split3 split2(float a, float b) {
 #define W2V2_SPLIT_INTO(x, y, v0, v1, v2) \
     do { const Split3 t_ = split2((x), (y)); (v0) = t_.p0; (v1) = t_.p1; (v2) = t_.p2; } while (0)
 
+// two fp32 (already scaled) -> one dword per plane of the format: bf16x3 exact three-term split | f16x2 two fp16 terms, saturating
+template <int FMT>
+__device__ __forceinline__ void split_pair(float a, float b, unsigned (&pl)[3], bool& ovf) {
+    if constexpr (FMT == PF_F16X2) {
+        ovf |= !(fabsf(a) <= F16X2_MAX) | !(fabsf(b) <= F16X2_MAX);
+        a = __builtin_amdgcn_fmed3f(a, -F16X2_MAX, F16X2_MAX);
+        b = __builtin_amdgcn_fmed3f(b, -F16X2_MAX, F16X2_MAX);
+        const h2_t h = {(_Float16)a, (_Float16)b};
+        pl[0] = __builtin_bit_cast(unsigned, h);
+        pl[1] = pack_f16_rne(a - (float)h[0], b - (float)h[1]);
+        pl[2] = 0u;
+    } else {
+        const Split3 t = split2(a, b);
+        pl[0] = t.p0; pl[1] = t.p1; pl[2] = t.p2;
+    }
+}
+template <int FMT>
+__device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
+    if constexpr (FMT == PF_F16X2)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 // exp(x), x <= 0, with the rounding of x * log2(e) compensated (see attention.hip::exp_compensated)
 __device__ __forceinline__ float exp_comp(float x) {
     constexpr float L2E_HI = 1.44269504088896340736f, L2E_LO = 1.925963033500822e-08f, LN2 = 0.69314718055994530942f;
@@ -74,11 +105,17 @@ __device__ __forceinline__ float exp_comp(float x) {
 __device__ __forceinline__ int swz_k(int row) { return ((row >> 1) & 7) ^ ((row >> 4) & 1); }
 __device__ __forceinline__ int swz_v(int d) { return (((d >> 1) & 7) << 1) ^ ((d >> 4) & 1); }
 
-// the six (first operand plane, second operand plane) pairs of order <= 2, smallest products first
-constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+// the (first operand plane, second operand plane) pairs of order <= 2, smallest products first: six for three planes, three for two
+template <int FMT> struct Terms;
+template <> struct Terms<PF_BF16X3> { static constexpr int N = 6; static constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0}; };
+template <> struct Terms<PF_F16X2> { static constexpr int N = 3; static constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0}; };
 
+template <int FMT>
 __global__ __launch_bounds__(NT, 2) void attention_split_kernel(AttnSplitArgs a) {
+    constexpr int NP = plane_count(FMT), STAGE = stage_bytes(FMT), NTERM = Terms<FMT>::N;
+    constexpr float OPS = FMT == PF_F16X2 ? F16X2_ACT_SCALE : 1.0f;       // scale of q d^-0.5, k, v before their split
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_as[];
+    bool ovf = false;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
@@ -88,18 +125,23 @@ __global__ __launch_bounds__(NT, 2) void attention_split_kernel(AttnSplitArgs a)
     const int flen = a.frame_len ? a.frame_len[b] : a.T;
 
     // ---- Q fragments (B operand of S^T), three planes: lane = (query li, half lh), d = 16 st + 8 lh .. + 7, pre-scaled ----
-    u32x4 qf[3][4];
+    u32x4 qf[NP][4];
     {
         const int qr = min(q0 + li, a.T - 1);
         const float* qp = base + (int64_t)qr * ld + 8 * lh;
+        const float qs = a.scale * OPS;
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(qp + 16 * st);
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(qp + 16 * st + 4);
-            W2V2_SPLIT_INTO(v0[0] * a.scale, v0[1] * a.scale, qf[0][st][0], qf[1][st][0], qf[2][st][0]);
-            W2V2_SPLIT_INTO(v0[2] * a.scale, v0[3] * a.scale, qf[0][st][1], qf[1][st][1], qf[2][st][1]);
-            W2V2_SPLIT_INTO(v1[0] * a.scale, v1[1] * a.scale, qf[0][st][2], qf[1][st][2], qf[2][st][2]);
-            W2V2_SPLIT_INTO(v1[2] * a.scale, v1[3] * a.scale, qf[0][st][3], qf[1][st][3], qf[2][st][3]);
+            const float e[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned pl[3];
+                split_pair<FMT>(e[2 * j] * qs, e[2 * j + 1] * qs, pl, ovf);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) qf[p][st][j] = pl[p];
+            }
         }
     }
 
@@ -126,24 +168,22 @@ __global__ __launch_bounds__(NT, 2) void attention_split_kernel(AttnSplitArgs a)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + i * NT, r = idx >> 4, sl = idx & 15;
-            u32x2 p0, p1, p2;
-            W2V2_SPLIT_INTO(rk[i][0], rk[i][1], p0[0], p1[0], p2[0]);
-            W2V2_SPLIT_INTO(rk[i][2], rk[i][3], p0[1], p1[1], p2[1]);
+            unsigned lo[3], hi[3];
+            split_pair<FMT>(rk[i][0] * OPS, rk[i][1] * OPS, lo, ovf);
+            split_pair<FMT>(rk[i][2] * OPS, rk[i][3] * OPS, hi, ovf);
             unsigned char* dst = S + r * ROWB + (((sl >> 1) ^ swz_k(r)) << 4) + (sl & 1) * 8;
-            *reinterpret_cast<u32x2*>(dst) = p0;
-            *reinterpret_cast<u32x2*>(dst + PLANE) = p1;
-            *reinterpret_cast<u32x2*>(dst + 2 * PLANE) = p2;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(dst + p * PLANE) = u32x2{lo[p], hi[p]};
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {                    // register transpose: column j of the patch = 4 consecutive keys
             const int d = 2 * v_dp + j;
-            u32x2 p0, p1, p2;
-            W2V2_SPLIT_INTO(rv[0][j], rv[1][j], p0[0], p1[0], p2[0]);
-            W2V2_SPLIT_INTO(rv[2][j], rv[3][j], p0[1], p1[1], p2[1]);
-            unsigned char* dst = S + 3 * PLANE + d * ROWB + ((v_c ^ swz_v(d)) << 3);
-            *reinterpret_cast<u32x2*>(dst) = p0;
-            *reinterpret_cast<u32x2*>(dst + PLANE) = p1;
-            *reinterpret_cast<u32x2*>(dst + 2 * PLANE) = p2;
+            unsigned lo[3], hi[3];
+            split_pair<FMT>(rv[0][j] * OPS, rv[1][j] * OPS, lo, ovf);
+            split_pair<FMT>(rv[2][j] * OPS, rv[3][j] * OPS, hi, ovf);
+            unsigned char* dst = S + NP * PLANE + d * ROWB + ((v_c ^ swz_v(d)) << 3);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x2*>(dst + p * PLANE) = u32x2{lo[p], hi[p]};
         }
     };
 
@@ -164,7 +204,7 @@ __global__ __launch_bounds__(NT, 2) void attention_split_kernel(AttnSplitArgs a)
         load_tile(tile + 1 < ntiles ? tile + 1 : tile);     // unconditional (the last one re-reads)
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char* Ks = smem_as + buf * STAGE;
-        const unsigned char* Vs = Ks + 3 * PLANE;
+        const unsigned char* Vs = Ks + NP * PLANE;
 
         // ---- S^T = K Q^T for two 32-key sub-tiles: 2 x 4 x 6 MFMAs, the two accumulators interleaved ----
         f32x16 s[2];
@@ -174,19 +214,25 @@ __global__ __launch_bounds__(NT, 2) void attention_split_kernel(AttnSplitArgs a)
             for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
-            u32x4 kf[2][3];
+            u32x4 kf[2][NP];
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
                 const int row = kt * 32 + li;
                 const unsigned char* kp = Ks + row * ROWB + (((2 * st + lh) ^ swz_k(row)) << 4);
 #pragma unroll
-                for (int p = 0; p < 3; ++p) kf[kt][p] = *reinterpret_cast<const u32x4*>(kp + p * PLANE);
+                for (int p = 0; p < NP; ++p) kf[kt][p] = *reinterpret_cast<const u32x4*>(kp + p * PLANE);
             }
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+            for (int t = 0; t < NTERM; ++t)
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
-                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(kf[kt][PA[t]]), as_bf16x8(qf[PB[t]][st]), s[kt], 0, 0, 0);
+                    s[kt] = mfma16<FMT>(kf[kt][Terms<FMT>::PA[t]], qf[Terms<FMT>::PB[t]][st], s[kt]);
+        }
+        if constexpr (FMT == PF_F16X2) {       // undo the operand scales (exact)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kt][r] *= 1.0f / (OPS * OPS);
         }
         // ---- mask + online softmax (lane owns query li; keys (r&3) + 8 (r>>2) + 4 lh) ----
         if (k0 + KT > min(flen, a.T)) {
@@ -233,27 +279,34 @@ __global__ __launch_bounds__(NT, 2) void attention_split_kernel(AttnSplitArgs a)
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                u32x4 pb[3];
+                u32x4 pb[NP];
+                constexpr float PS = FMT == PF_F16X2 ? P_SCALE : 1.0f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) W2V2_SPLIT_INTO(s[kt][8 * h + 2 * j], s[kt][8 * h + 2 * j + 1], pb[0][j], pb[1][j], pb[2][j]);
-                u32x4 vf[2][3];
+                for (int j = 0; j < 4; ++j) {
+                    unsigned pl[3];
+                    bool never = false;                   // (probabilities x 2^10 <= 1024: cannot saturate)
+                    split_pair<FMT>(s[kt][8 * h + 2 * j] * PS, s[kt][8 * h + 2 * j + 1] * PS, pl, never);
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) pb[p][j] = pl[p];
+                }
+                u32x4 vf[2][NP];
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
                     const int d = dt * 32 + li, sw = swz_v(d);
                     const unsigned char* row = Vs + d * ROWB;
                     const int oa = ((8 * kt + 4 * h + lh) ^ sw) << 3, ob = ((8 * kt + 4 * h + 2 + lh) ^ sw) << 3;
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) {
+                    for (int p = 0; p < NP; ++p) {
                         const u32x2 va = *reinterpret_cast<const u32x2*>(row + p * PLANE + oa);
                         const u32x2 vb = *reinterpret_cast<const u32x2*>(row + p * PLANE + ob);
                         vf[dt][p] = u32x4{va[0], va[1], vb[0], vb[1]};
                     }
                 }
 #pragma unroll
-                for (int t = 0; t < 6; ++t)
+                for (int t = 0; t < NTERM; ++t)
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt)
-                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vf[dt][PA[t]]), as_bf16x8(pb[PB[t]]), o[dt], 0, 0, 0);
+                        o[dt] = mfma16<FMT>(vf[dt][Terms<FMT>::PA[t]], pb[Terms<FMT>::PB[t]], o[dt]);
             }
         __builtin_amdgcn_sched_barrier(0);
         store_tile(buf ^ 1);        // the other stage was last read one iteration ago (barrier below closed it)
@@ -262,9 +315,10 @@ __global__ __launch_bounds__(NT, 2) void attention_split_kernel(AttnSplitArgs a)
 
     // ---- normalise and store: O^T rows are d = 32 dt + (r&3) + 8 (r>>2) + 4 lh, column = query ----
     const int q = q0 + li;
-    bool ovf = false;
+    report_overflow(a.range_flag, ovf);
+    ovf = false;
     if (q < a.T) {
-        const float inv = 1.0f / l_run;
+        const float inv = (1.0f / l_run) * (FMT == PF_F16X2 ? 1.0f / (P_SCALE * OPS) : 1.0f);      // (f16x2: O carries the scales of P and V)
         const int64_t off = ((int64_t)b * a.T + q) * a.H + head * DH + 4 * lh;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
@@ -283,23 +337,28 @@ __global__ __launch_bounds__(NT, 2) void attention_split_kernel(AttnSplitArgs a)
 bool attention_split_supported(int head_dim) { return head_dim == DH; }
 
 int launch_attention_split(const float* qkv, const int32_t* frame_len, float* ctx, int B, int T, int H, int heads,
-                           hipStream_t s, const PlaneOut* planes) {
+                           hipStream_t s, const PlaneOut* planes, int fmt, int* range_flag) {
     const PlaneOut pl = planes ? *planes : PlaneOut{};
     W2V2_REQUIRE(qkv && (ctx || pl.p) && B > 0 && T > 0 && heads > 0, "attention_split: bad argument");
     W2V2_REQUIRE(!pl.p || (pl.plane % 4 == 0 && (reinterpret_cast<uintptr_t>(pl.p) & 7) == 0), "attention_split: unaligned planes");
     W2V2_REQUIRE(H / heads == DH && H % heads == 0, "attention_split: head size %d unsupported (64)", H / heads);
     W2V2_REQUIRE((H % 4) == 0 && (reinterpret_cast<uintptr_t>(qkv) & 15) == 0 && (reinterpret_cast<uintptr_t>(ctx) & 15) == 0,
                  "attention_split: unaligned buffers");
-    AttnSplitArgs a{qkv, frame_len, ctx, B, T, H, heads, 1.0f / sqrtf((float)DH), pl};
-    constexpr size_t lds = 2 * STAGE;
+    W2V2_REQUIRE(fmt == PF_BF16X3 || fmt == PF_F16X2, "attention_split: unknown plane format %d", fmt);
+    AttnSplitArgs a{qkv, frame_len, ctx, B, T, H, heads, 1.0f / sqrtf((float)DH), pl, range_flag};
     static std::atomic<bool> attr_set{false};   // (idempotent call; atomic so concurrent host threads agree on the flag)
     if (!attr_set) {
-        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_split_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_split_kernel<PF_BF16X3>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * stage_bytes(PF_BF16X3)));
+        W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_split_kernel<PF_F16X2>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * stage_bytes(PF_F16X2)));
         attr_set = true;
     }
     dim3 grid((T + NW * 32 - 1) / (NW * 32), heads, B), block(NT);
-    W2V2_LAUNCH(attention_split_kernel, grid, block, lds, s, a);
+    if (fmt == PF_F16X2)
+        W2V2_LAUNCH(attention_split_kernel<PF_F16X2>, grid, block, 2 * stage_bytes(PF_F16X2), s, a);
+    else
+        W2V2_LAUNCH(attention_split_kernel<PF_BF16X3>, grid, block, 2 * stage_bytes(PF_BF16X3), s, a);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }

@@ -83,7 +83,6 @@ struct PlaneOut {
 extern thread_local int tl_launch_family;
 void note_kernel_launch();
 int64_t kernel_launches(int family);
-void kernel_launches_reset();
 #define W2V2_LAUNCH(...)                  \
     do {                                  \
         ::w2v2::note_kernel_launch();     \
@@ -100,6 +99,7 @@ void profiler_enable(Profiler*, bool on);
 void profiler_set_mask(Profiler*, unsigned family_mask);   // bit f = record family f; 0 = all
 void profiler_set_stride(Profiler*, int stride);           // every stride-th launch of a family gets the event pair
 int64_t profiler_seen(const Profiler*, int family);        // launches since the last reset, sampled or not
+int64_t profiler_kernel_launches(const Profiler*, int family);      // kernels enqueued (process-wide counter) since THIS profiler's last reset
 bool profiler_enabled(const Profiler*);
 void profiler_reset(Profiler*);
 // returns a token (>=0) to pass to profiler_end, or -1 when disabled
@@ -107,17 +107,20 @@ int profiler_begin(Profiler*, int family, double flops, double bytes, hipStream_
 void profiler_end(Profiler*, int token, hipStream_t s);
 int profiler_read(Profiler*, int family, int64_t* launches, double* ms, double* flops, double* bytes);
 
+// (a scope opened inside another one -- a launcher with its own scope called from a launcher that has one -- neither brackets its
+//  kernels again nor re-labels their launches: time and launch counts stay with the OUTER family, nothing is counted twice)
+extern thread_local int tl_prof_depth;
 struct ProfScope {
     Profiler* p;
     int tok;
     hipStream_t s;
     int outer_family;
     ProfScope(Profiler* p_, int family, double flops, double bytes, hipStream_t s_)
-        : p(p_), tok(p_ ? profiler_begin(p_, family, flops, bytes, s_) : -1), s(s_), outer_family(tl_launch_family) {
-        tl_launch_family = family;
+        : p(p_), tok((p_ && tl_prof_depth == 0) ? profiler_begin(p_, family, flops, bytes, s_) : -1), s(s_), outer_family(tl_launch_family) {
+        if (tl_prof_depth++ == 0) tl_launch_family = family;
     }
     ~ProfScope() {
-        tl_launch_family = outer_family;
+        if (--tl_prof_depth == 0) tl_launch_family = outer_family;
         if (tok >= 0) profiler_end(p, tok, s);
     }
 };
@@ -290,7 +293,9 @@ int launch_qkv_unpack(const float* packed_w, const float* packed_b, float* const
 bool attention_bf16_supported(int head_size);   // attention_bf16.hip: head size 64
 bool attention_split_supported(int head_size);  // attention_split.hip (precision mode 2): head size 64
 int launch_attention_split(const float* qkv, const int32_t* frame_len, float* ctx, int B, int T, int H, int heads, hipStream_t s,
-                           const PlaneOut* planes = nullptr /* optional planes of ctx; ctx itself may then be null */);
+                           const PlaneOut* planes = nullptr /* optional planes of ctx; ctx itself may then be null */,
+                           int fmt = PF_BF16X3 /* PF_F16X2: two fp16 terms / three products per contraction (precision mode 3) */,
+                           int* range_flag = nullptr /* f16x2: sticky flag for q / k / v beyond fp16's scaled range */);
 // qkv16: optional bf16 shadow of qkv (precision mode 1 with head size 64 reads ONLY it; qkv may then be null.  Without it that
 // kernel rounds qkv into scratch first).  ctx may be null when ctx16 is given.
 int launch_attention_x(Profiler* prof, const float* qkv, const uint16_t* qkv16, const int32_t* frame_len, float* ctx, int B, int T, int H,

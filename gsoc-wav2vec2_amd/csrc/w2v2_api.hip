@@ -41,6 +41,7 @@ const char* family_name(int f) {
 
 // ---- kernel-launch counters (common.h: W2V2_LAUNCH) ---------------------------
 thread_local int tl_launch_family = FAM_MISC;
+thread_local int tl_prof_depth = 0;
 thread_local Profiler* tl_step_prof = nullptr;
 static std::atomic<int64_t> g_kernel_launches[FAM_COUNT];
 void note_kernel_launch() {
@@ -49,9 +50,6 @@ void note_kernel_launch() {
 }
 int64_t kernel_launches(int family) {
     return (family >= 0 && family < FAM_COUNT) ? g_kernel_launches[family].load(std::memory_order_relaxed) : 0;
-}
-void kernel_launches_reset() {
-    for (auto& n : g_kernel_launches) n.store(0, std::memory_order_relaxed);
 }
 
 // ---- profiler ---------------------------------------------------------------
@@ -65,6 +63,8 @@ struct Profiler {
     unsigned mask = 0xFFFFFFFFu;    // families that get an event pair
     int stride = 1;                 // of a family's launches, every stride-th gets the pair (w2v2_profile_sampling)
     int64_t seen[32] = {0};         // launches of each family since the last reset, sampled or not
+    int64_t launch_base[32] = {0};  // the process-wide kernel-launch counters at the last reset (a reset never clears them: another model,
+                                    // or another thread's, keeps counting from its own base)
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> pool;   // recycled events
 };
@@ -76,7 +76,10 @@ void profiler_reset(Profiler* p) {
     }
     p->recs.clear();
     for (auto& n : p->seen) n = 0;
-    kernel_launches_reset();
+    for (int f = 0; f < FAM_COUNT; ++f) p->launch_base[f] = kernel_launches(f);
+}
+int64_t profiler_kernel_launches(const Profiler* p, int family) {
+    return (p && family >= 0 && family < FAM_COUNT) ? kernel_launches(family) - p->launch_base[family] : 0;
 }
 void profiler_destroy(Profiler* p) {
     if (!p) return;
@@ -897,8 +900,10 @@ int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const i
         const bool ctx16_only = attn16 && H % 64 == 0 && wo16 != m->w16.end() && wo16->second != nullptr;
         // (planes: the split attention kernel writes the planes of ctx itself; any other attention kernel leaves fp32 to be split)
         const bool ctx_fused = p_out && attention_split_supported(H / c.num_heads) && H % 4 == 0 && tune_int("W2V2_SPLIT_ATTN", 1) != 0;
+        PlaneOut po_flag;                                    // (no planes wanted: the split attention still reports f16x2 saturation)
+        po_flag.range_flag = m->range_flag;
         if (int e = launch_attention_x(pf, attn16 ? nullptr : m->qkv, attn16 ? m->qkv16 : nullptr, flen, (ctx16_only || (ctx_fused && !keep)) ? nullptr : m->ctx, B, T, H,
-                                       c.num_heads, attn16 ? m->ctx16 : nullptr, s, ctx_fused ? &po_ctx : nullptr))
+                                       c.num_heads, attn16 ? m->ctx16 : nullptr, s, ctx_fused ? &po_ctx : (pm ? &po_flag : nullptr)))
             return e;
         if (p_out && !ctx_fused)
             if (int e = launch_split_planes(m->ctx, m->ctx48.p, m->ctx48.plane, BT * H, fmt, m->range_flag, s)) return e;
@@ -1026,7 +1031,7 @@ int w2v2_profile_read(w2v2_model* m, int index, const char** name, int64_t* laun
 int w2v2_profile_kernel_launches(w2v2_model* m, int index, int64_t* launches) {
     W2V2_REQUIRE(m && launches, "profile_kernel_launches: null argument");
     W2V2_REQUIRE(index >= 0 && index < FAM_COUNT, "profile_kernel_launches: bad family index %d", index);
-    *launches = kernel_launches(index);
+    *launches = profiler_kernel_launches(m->prof, index);
     return W2V2_OK;
 }
 int w2v2_profile_reset(w2v2_model* m) {

@@ -495,6 +495,9 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
                        uint64_t seed, float* logits_out, void* stream) {
     W2V2_REQUIRE(m && wave && logits_out, "train_forward: null argument");
     W2V2_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "train_forward: dropout %f outside [0, 1)", dropout_p);
+    // (the keep decisions compare 16 hash bits with floor(p 2^16): a positive p below that resolution would scale by 1 / (1 - p) in
+    //  some kernels and not drop at all in others -- one predicate everywhere: every accepted p > 0 has a non-zero threshold)
+    W2V2_REQUIRE(dropout_p == 0.f || dropout_p >= 1.0f / 65536.0f, "train_forward: dropout %g is below the 2^-16 resolution of the keep decisions", dropout_p);
     if (!m->finalized) {
         set_error("train_forward: call w2v2_finalize after setting the variables");
         return W2V2_ESTATE;
@@ -663,7 +666,11 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
         // postnorm: t2 = LN1(t1) feeds the FFN and is its residual; prenorm: t2 = LN2(t1) feeds the FFN, t1 is the residual
         const char* ln_a = prenorm ? "/final_layer_norm" : "/layer_norm";
         // (round 4: dropout + residual + LayerNorm as one pass over the row -- t1 is written once and not read back)
-        if (H % 4 == 0 && tune_int("W2V2_LN_DROP", 1) != 0) {
+        // (the fused pass takes rows of up to 2048 channels, a multiple of 4, 16-byte aligned: anything else falls back to the two kernels)
+        if (H % 4 == 0 && H <= 2048 && tune_int("W2V2_LN_DROP", 1) != 0 &&
+            ((reinterpret_cast<uintptr_t>(m->t0) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(l.t1) | reinterpret_cast<uintptr_t>(l.t2) |
+              reinterpret_cast<uintptr_t>(m->P(b + ln_a + "/gamma")) | reinterpret_cast<uintptr_t>(m->P(b + ln_a + "/beta"))) & 15) == 0 &&
+            (reinterpret_cast<uintptr_t>(S16(l.t2_16)) & 7) == 0) {
             if (int e = launch_layer_norm_drop(pf, m->t0, x, l.t1, l.t2, S16(l.t2_16), m->P(b + ln_a + "/gamma"), m->P(b + ln_a + "/beta"), BT, H, eps, p,
                                                seed, layer_stream(i, 1), s))
                 return e;

@@ -815,11 +815,11 @@ def test_attention_bf16(env, bf16_ops, B, T, Hh, heads, flen):
     assert err.max() < 2e-2 and err.mean() < 2e-3
 
 
-@pytest.fixture
-def bf16x3_ops(env):
-    """Per-kernel calls in W2V2_PRECISION_BF16X3 for the duration of one test."""
+@pytest.fixture(params=[2, 3], ids=["bf16x3", "f16x2"])
+def bf16x3_ops(env, request):
+    """Per-kernel calls in W2V2_PRECISION_BF16X3 / W2V2_PRECISION_F16X2 for the duration of one test."""
     lib = env[0]
-    N.check(lib.w2v2_op_set_precision(2))
+    N.check(lib.w2v2_op_set_precision(request.param))
     yield
     N.check(lib.w2v2_op_set_precision(0))
 
@@ -827,9 +827,9 @@ def bf16x3_ops(env):
 @pytest.mark.parametrize("B,T,Hh,heads,flen", [(1, 145, 768, 12, None), (2, 768, 128, 2, None), (2, 200, 128, 2, [200, 61]),
                                                 (1, 97, 64, 1, [0]), (2, 64, 64, 1, None), (1, 33, 128, 2, None), (1, 300, 64, 1, [257])])
 def test_attention_split_is_fp32_grade(env, bf16x3_ops, B, T, Hh, heads, flen):
-    """Precision mode bf16x3's attention (csrc/attention_split.hip, head size 64): q d^-0.5, k, v and the probabilities as
-    exact three-term bf16 sums, six MFMA products per fp32 product.  Same fp64 formula and the SAME 2e-5 bound as the fp32
-    kernel's test_attention, plus: no worse than 1.5x the fp32 kernel's error on the same input."""
+    """The attention of precision modes bf16x3 / f16x2 (csrc/attention_split.hip, head size 64): q d^-0.5, k, v and the probabilities
+    as exact three-term bf16 sums with six MFMA products per fp32 product, or as two-term fp16 sums with three.  Same fp64 formula
+    and the SAME 2e-5 bound as the fp32 kernel's test_attention, plus: no worse than 1.5x the fp32 kernel's error on the same input."""
     lib, torch, dev = env
     d = Hh // heads
     assert d == 64
