@@ -330,6 +330,206 @@ __global__ __launch_bounds__(NW * 64, 3) void attention_bf16_kernel(Attn16Args a
 }
 
 
+// ---- Round 5: the same forward, software-pipelined inside a wave (default; W2V2_ATTN16_PIPE = 0 in the tools-only build restores the
+// kernel above for A/B runs).  Why: PMC of the kernel above (profiles/r04_attention_bf16_pmc.md) shows 456 VALU instructions per 64-key
+// tile against 16 MFMAs -- VALU-bound 3.5 : 1 -- yet the VALU pipe only 41 % busy: within a wave the S MFMAs wait for the tile barrier
+// and their LDS reads, the softmax waits for the S MFMAs, every PV MFMA for its own transposing reads, and the four waves of a block
+// walk those phases in lock step.  Here a wave works on 32-key SUB-tiles and always has the NEXT sub-tile's four S MFMAs (and their
+// fragment reads) in flight under the softmax arithmetic of the current one:
+//     even step:   [ S(tile j, keys 32..63) -> sb   ||  softmax(sa) ]   rescale O   [ PV(sa) ]
+//     odd step:    barrier, DMA of tile j + 2       [ S(tile j + 1, keys 0..31) -> sa  ||  softmax(sb) ]   rescale O   [ PV(sb) ]
+// The online softmax runs per sub-tile (running max / sum updated every 32 keys); O is rescaled only when some lane's maximum moved
+// (a wave-uniform test: after the first tiles it almost never does).  K / V images sit in a three-slot ring: the odd step reads the
+// next tile while the current tile's V is still needed, and the one barrier per tile both publishes tile j + 1 and frees tile j - 1's
+// slot for the DMA of tile j + 2.  Same bf16 operands, fp32 scores / exponentials / sums as above; the probabilities are rounded to bf16
+// relative to a running maximum that is updated twice per tile instead of once, so the two kernels agree to bf16 rounding noise, not bit
+// for bit (the backward recomputes P from the saved log-sum-exp either way).
+template <bool TRAIN, bool DROP>
+__global__ __launch_bounds__(NW * 64, 3) void attention_bf16_pipe_kernel(Attn16Args a, AttnTrain tr) {
+    constexpr int STAGE = 2 * IMG;           // K image, V image
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_a16[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int work = xcd_work(blockIdx.x, a.nwork);
+    const int bh = work / a.nqb, qb = work - bh * a.nqb;
+    const int b = bh / a.heads, head = bh - b * a.heads;
+    const int q0 = (qb * NW + wave) * 32;
+    const int ld = 3 * a.H;
+    const uint16_t* __restrict__ base = a.qkv16 + (int64_t)b * a.T * ld + head * DH;
+    const int flen = a.frame_len ? a.frame_len[b] : a.T;
+    const int ntiles = (a.T + KT - 1) / KT;
+
+    TrOff tro;
+    tro.init(lane);
+    // (TileDma's addressing with the lane constants rebuilt per tile: two registers live across the loop instead of four)
+    const int dma_r0 = 16 * wave + (lane >> 3), dma_l7 = lane & 7;
+    auto issue = [&](int tile, int slot) {          // (tile clamped: past the end the last tile is fetched again, never used)
+        unsigned char* S = smem_a16 + slot * STAGE + (2 * wave) * 1024;
+        const int row0 = min(tile, ntiles - 1) * KT;
+        const int a0 = min(row0 + dma_r0, a.T - 1) * ld + 8 * (dma_l7 ^ swz(dma_r0));
+        const int a1 = min(row0 + dma_r0 + 8, a.T - 1) * ld + 8 * (dma_l7 ^ swz(dma_r0 + 8));
+#pragma unroll
+        for (int kv = 0; kv < 2; ++kv) {
+            const uint16_t* src = base + (1 + kv) * a.H;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + a0),
+                                             (__attribute__((address_space(3))) void*)(S + kv * IMG), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + a1),
+                                             (__attribute__((address_space(3))) void*)(S + kv * IMG + 1024), 16, 0, 0);
+        }
+    };
+    issue(0, 0);
+    issue(1, 1);
+
+    u32x4 qf[4];
+    load_col_frags(qf, base + min(q0 + li, a.T - 1) * ld + 8 * lh);
+
+    f32x16 o[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const uint32_t drop_key = DROP ? dropout_key(tr.seed, tr.stream) : 0u, drop_thr = DROP ? dropout_threshold(tr.p) : 0u;
+    const uint32_t thr1s_pk = dropout_thr1s_pk(drop_thr);
+    const uint32_t drop_row = (uint32_t)(((uint64_t)bh * a.T + (uint64_t)min(q0 + li, a.T - 1)) * attention_drop_stride(a.T));
+    constexpr bool drop = DROP;            // (a template parameter: as a run-time branch inside the loop the two PV paths kept O in
+                                           //  different registers and the loop paid 16 v_mov_b64 + an MFMA drain per sub-tile to merge them)
+    const int xr = swz(li);
+    const int kend = min(flen, a.T);
+    const uint32_t keep_lane = (uint32_t)(lh * a.nqb * NW * 32 + q0 + li);
+
+    // S^T of one 32-key sub-tile: four MFMAs over d
+    auto scores = [&](f32x16& s, const unsigned char* Ks, int kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, kt * 32 + li, xr, st, lh), as_bf16x8(qf[st]), s, 0, 0, 0);
+    };
+    // key-padding mask / tile padding on a sub-tile that touches the valid-length or T boundary (wave-uniform test by the caller)
+    auto mask = [&](f32x16& s, int k0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float v = s[r];
+            v = key >= flen ? v + MASK_BIAS : v;
+            s[r] = key >= a.T ? -INFINITY : v;
+        }
+    };
+    // online softmax of one sub-tile: s -> un-normalised probabilities relative to the new running maximum; returns the factor the
+    // accumulated O and sum carry from the old maximum (1 when it did not move)
+    auto softmax = [&](f32x16& s) -> float {
+        float mx = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * C2);       // exp2(-inf) = 0 on the first sub-tile
+        const float mc = -m_new * C2;
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(s[r], C2, mc));
+            s[r] = p;
+            rs += p;
+        }
+        rs += __shfl_xor(rs, 32, 64);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+        return alpha;
+    };
+    auto rescale = [&](float alpha) {
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0ull) {      // (wave-uniform: some lane's running maximum moved)
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        }
+    };
+    // O^T += V^T P^T for one sub-tile (packed pairs, dropout on the packed pairs: see the kernel above)
+    auto pv = [&](f32x16& s, const unsigned char* Vs, int kt, uint32_t pm0, uint32_t& bits) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            u32x4 pw;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 8 * h + 2 * j;
+                pw[j] = pack_bf16(s[r], s[r + 1]);
+                if (DROP) {
+                    const uint32_t cpair = (uint32_t)(kt * 16 + ((r & 3) >> 1) + 4 * (r >> 2));
+                    const uint32_t km = dropout_keep_mask_pk(dropout_word_premul(drop_key, pm0 + cpair * DROPOUT_FIB), thr1s_pk);
+                    pw[j] &= km;
+                    bits |= km & ((1u << (8 * kt + (r >> 1))) | (1u << (16 + 8 * kt + (r >> 1))));
+                }
+            }
+            const bf16x8 pb = as_bf16x8(pw);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Vs, tro, kt, h, dt), pb, o[dt], 0, 0, 0);
+        }
+    };
+
+    f32x16 sa, sb;
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          // tile 0 (tile 1's four pieces may still fly)
+    __syncthreads();
+    scores(sa, smem_a16, 0);
+    int slot = 0;                                              // ring slot of tile j
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int k0 = tile * KT;
+        const unsigned char* Ks = smem_a16 + slot * STAGE;
+        const unsigned char* Vs = Ks + IMG;
+        const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
+        const uint32_t pm0 = (((drop_row + (uint32_t)k0) >> 1) + 2u * (uint32_t)lh) * DROPOUT_FIB;
+        uint32_t bits = 0;
+        // ---- even step: keys k0 .. k0 + 31
+        if (k0 + 32 > kend) mask(sa, k0);
+        scores(sb, Ks, 1);
+        const float al0 = softmax(sa);
+        rescale(al0);
+        __builtin_amdgcn_sched_barrier(0);
+        pv(sa, Vs, 0, pm0, bits);
+        // ---- odd step: keys k0 + 32 .. k0 + 63.  Tile j + 1 has landed (this wave's pieces: vmcnt(0); everyone's: the barrier), and every
+        // wave is done with tile j - 1, whose slot takes the DMA of tile j + 2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        issue(tile + 2, slot2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k0 + 64 > kend) mask(sb, k0 + 32);
+        scores(sa, smem_a16 + slot1 * STAGE, 0);
+        const float al1 = softmax(sb);
+        rescale(al1);
+        __builtin_amdgcn_sched_barrier(0);
+        pv(sb, Vs, 1, pm0, bits);
+        if (drop && tr.keep_bits) (tr.keep_bits + keep_word(bh, tile, 0, a.nqb))[keep_lane] = bits;     // (uniform base + 32-bit lane offset)
+        slot = slot1;
+    }
+
+    const int q = q0 + li;
+    if (TRAIN && q < a.T && lh == 0) tr.lse[(int64_t)bh * a.T + q] = m_run * SCALE + logf(l_run);
+    if (q < a.T) {
+        const float inv = (drop ? 1.0f / (1.0f - tr.p) : 1.0f) / l_run;
+        const int64_t o0 = ((int64_t)b * a.T + q) * a.H + head * DH + 4 * lh;
+        if (a.ctx) {
+            float* op = a.ctx + o0;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(op + 32 * d + 8 * g) =
+                        f32x4{o[d][4 * g] * inv, o[d][4 * g + 1] * inv, o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv};
+        }
+        if (a.ctx16) {
+            uint16_t* hp = a.ctx16 + o0;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<u32x2*>(hp + 32 * d + 8 * g) =
+                        u32x2{pack_bf16(o[d][4 * g] * inv, o[d][4 * g + 1] * inv), pack_bf16(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv)};
+        }
+    }
+}
+
 // ======================================================================================
 // Backward (see attention.hip for the math).  Same ownership as the fp32 kernels -- a wave owns 32 queries
 // (dQ) or 32 keys (dK, dV) whose [col][d] fragments sit in registers as B operands, the other side streams
@@ -717,12 +917,22 @@ int launch_attention_fwd_bf16(const float* qkv, const uint16_t* qkv16, const int
                  "attention_bf16: unaligned operand");
     const int nqb = (T + NW * 32 - 1) / (NW * 32);
     Attn16Args a{q16, frame_len, ctx, ctx16, B, T, H, heads, nqb, nqb * heads * B};
-    const size_t lds = 2 * 2 * IMG;
     dim3 grid(a.nwork), block(NW * 64);
-    if (tr)
-        W2V2_LAUNCH(attention_bf16_kernel<true>, grid, block, lds, s, a, *tr);
-    else
-        W2V2_LAUNCH(attention_bf16_kernel<false>, grid, block, lds, s, a, AttnTrain{0.f, 0, 0, nullptr});
+    if (tune_int("W2V2_ATTN16_PIPE", 1) != 0) {          // the software-pipelined forward (three-slot K / V ring: 48 KiB)
+        const size_t lds = 3 * 2 * IMG;
+        if (tr && (uint32_t)((double)tr->p * 65536.0) != 0u)          // (dropout_threshold(p) on the host)
+            W2V2_LAUNCH((attention_bf16_pipe_kernel<true, true>), grid, block, lds, s, a, *tr);
+        else if (tr)
+            W2V2_LAUNCH((attention_bf16_pipe_kernel<true, false>), grid, block, lds, s, a, *tr);
+        else
+            W2V2_LAUNCH((attention_bf16_pipe_kernel<false, false>), grid, block, lds, s, a, AttnTrain{0.f, 0, 0, nullptr});
+    } else {
+        const size_t lds = 2 * 2 * IMG;
+        if (tr)
+            W2V2_LAUNCH(attention_bf16_kernel<true>, grid, block, lds, s, a, *tr);
+        else
+            W2V2_LAUNCH(attention_bf16_kernel<false>, grid, block, lds, s, a, AttnTrain{0.f, 0, 0, nullptr});
+    }
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }

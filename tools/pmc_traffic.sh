@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/pmc_traffic; mkdir -p $O; round=${1:-0}; ONLY=${ONLY:-}
 cd /tmp
 B="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-alt --no-side"
-run() { tag=$1; shift; timeout 500 rocprofv3 "$@" --output-format csv -d $O/raw_$tag -- $B ${EXTRA:-} > $O/raw_$tag.log 2>&1 || echo "pass $tag failed: $(tail -2 $O/raw_$tag.log)"; }
+run() { local tag=$1; shift; timeout 500 rocprofv3 "$@" --output-format csv -d $O/raw_$tag -- $B ${EXTRA:-} > $O/raw_$tag.log 2>&1 || echo "pass $tag failed: $(tail -2 $O/raw_$tag.log)"; }
 # tag | bench arguments   (every BASELINE configuration and the two split modes of the forward legs: profiles/hbm_traffic_configs.json)
 CONFIGS="f32|
 b16f|--precision bf16
