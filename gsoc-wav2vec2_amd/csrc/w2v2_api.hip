@@ -675,6 +675,7 @@ int w2v2_set_option(w2v2_model* m, int32_t option, int32_t value) {
         case W2V2_OPT_BF16_SHADOWS: m->opt_shadows = value != 0; return W2V2_OK;
         case W2V2_OPT_KEEP_ACTIVATIONS: m->opt_keep_acts = value != 0; return W2V2_OK;
         case W2V2_OPT_SPLIT_PLANES: m->opt_planes = value != 0; return W2V2_OK;
+        case W2V2_OPT_WGRAD_STREAM: m->opt_wgrad_stream = value != 0; return W2V2_OK;
         default: set_error("set_option: unknown option %d", option); return W2V2_EINVAL;
     }
 }
@@ -684,6 +685,7 @@ int w2v2_get_option(const w2v2_model* m, int32_t option) {
         case W2V2_OPT_BF16_SHADOWS: return m->opt_shadows ? 1 : 0;
         case W2V2_OPT_KEEP_ACTIVATIONS: return m->opt_keep_acts ? 1 : 0;
         case W2V2_OPT_SPLIT_PLANES: return m->opt_planes ? 1 : 0;
+        case W2V2_OPT_WGRAD_STREAM: return m->opt_wgrad_stream ? 1 : 0;
         default: return W2V2_EINVAL;
     }
 }

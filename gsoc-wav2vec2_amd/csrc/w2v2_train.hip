@@ -77,6 +77,20 @@ struct TrainState {
     // gradient buckets for overlapping the data-parallel all-reduce with the backward: completion order
     //   0 = lm_head, 1 .. N = encoder layers N-1 .. 0, N+1 = everything in front of layer 0 in the flat buffer
     std::vector<hipEvent_t> bucket_ev;
+    // Weight-gradient side stream (round 5, W2V2_OPT_WGRAD_STREAM, default OFF).  dW = X^T dY is off the backward's critical path --
+    // only the optimizer (and the bucket's all-reduce) reads it -- so the encoder layers' four weight-gradient GEMMs (+ their slab
+    // folds) can be enqueued on a second, lower-priority stream, to fill what the critical path leaves idle: the underfilled last
+    // round of every N = 768 data-gradient GEMM (576 tiles on 512 block slots), the matrix pipe under the VALU-bound attention
+    // backward, the HBM-bound element-wise passes.  MEASURED (profiles/r05_ab_wgrad_stream.txt): the kernels do overlap -- every
+    // family's event brackets stretch -- and the step time does not move (33.38 vs 33.39 ms base, 97.7 vs 98.0 large-robust): the
+    // chip is a shared-throughput machine here (clock 1.98 GHz under the bf16 GEMMs: power; HBM under the element-wise passes), not a
+    // slot-limited one.  Kept as an option because the all-reduce overlap of an 8-GPU job may still want the earlier buckets; off by
+    // default.  Ordering is by events only: `wg_fork` (main -> side: the dY the GEMM reads is complete), `wg_join[site]` (side -> main,
+    // waited for right before the main stream next overwrites that site's dY), and the bucket events are recorded on the side stream
+    // after it has also waited for the main stream's position.  Same kernels, same operands: results are bit-identical to one stream.
+    hipStream_t wg_stream = nullptr;
+    hipEvent_t wg_fork = nullptr, wg_main = nullptr, wg_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* red_ws_side = nullptr;     // the side stream's own reduction scratch (red_ws belongs to the main stream's kernels)
 };
 
 static int t_alloc(TrainState* t, float** out, int64_t floats) {
@@ -108,6 +122,9 @@ void w2v2_train_destroy(w2v2_model* m) {
     if (m->train->adam_chunks) (void)hipFree(m->train->adam_chunks);
     if (m->train->pos_w16_t) (void)hipFree(m->train->pos_w16_t);
     for (hipEvent_t ev : m->train->bucket_ev) (void)hipEventDestroy(ev);
+    if (m->train->wg_stream) (void)hipStreamDestroy(m->train->wg_stream);
+    for (hipEvent_t ev : {m->train->wg_fork, m->train->wg_main, m->train->wg_join[0], m->train->wg_join[1], m->train->wg_join[2], m->train->wg_join[3]})
+        if (ev) (void)hipEventDestroy(ev);
     delete m->train;
     m->train = nullptr;
 }
@@ -237,6 +254,7 @@ static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
     const int64_t lw = ln_bwd_ws_floats(BT, (int)(H > C ? H : C));
     if (lw > rw) rw = lw;
     if (int e = t_alloc(t, &t->red_ws, rw + 16)) return e;
+    if (int e = t_alloc(t, &t->red_ws_side, rw + 16)) return e;
     if (int e = t_alloc(t, &t->dvec, (int64_t)B * c.num_heads * T)) return e;
     t->attn_colpart = nullptr;
     if (attention_bf16_supported((int)(H / c.num_heads)))
@@ -318,8 +336,10 @@ static bool is_trainable(w2v2_model* m, const std::string& name) {
 // dy16_zero_row: the caller keeps row M of dY16 all-zero (TrainState's dY shadows are allocated that way) -- a row count that is not a
 // multiple of 64 can then take the 128 x 256 kernel's ragged form instead of the 128 x 128 kernel
 static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, int Kin, int Nout, float* dW,
-                       float* db, hipStream_t s, const uint16_t* A16 = nullptr, const uint16_t* dY16 = nullptr, bool dy16_zero_row = false) {
+                       float* db, hipStream_t s, const uint16_t* A16 = nullptr, const uint16_t* dY16 = nullptr, bool dy16_zero_row = false,
+                       float* red_ws = nullptr) {
     TrainState* t = m->train;
+    if (!red_ws) red_ws = t->red_ws;       // (the side stream passes its own: TrainState::red_ws_side)
     bool fused_bias = false;
     if (dW) {
         // dW (Kin, Nout) = A^T dY over the M = B T rows: few output tiles and a very long K, so the rows are cut into S slabs
@@ -367,7 +387,7 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
                     if (int e = launch_colsum(t->slabs, dW, S, Kin * Nout, t->slabs + (int64_t)S * Kin * Nout, 0, s)) return e;
                 if (db) {
                     W2V2_REQUIRE(dY, "weight_grad: the bias gradient needs the fp32 dY");
-                    if (int e = launch_colsum(dY, db, M, Nout, t->red_ws, 0, s)) return e;
+                    if (int e = launch_colsum(dY, db, M, Nout, red_ws, 0, s)) return e;
                 }
                 return W2V2_OK;
             }
@@ -391,7 +411,7 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
                 if (int e = launch_colsum(t->slabs, dW, S, Kin * Nout, t->slabs + (int64_t)S * Kin * Nout, 0, s)) return e;
             if (db) {
                 W2V2_REQUIRE(dY, "weight_grad: the bias gradient needs the fp32 dY");
-                if (int e = launch_colsum(dY, db, M, Nout, t->red_ws, 0, s)) return e;
+                if (int e = launch_colsum(dY, db, M, Nout, red_ws, 0, s)) return e;
             }
             return W2V2_OK;
         }
@@ -446,13 +466,13 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
         if (fused_bias) {
             // per-slab column sums of dY are in cs_ws (S, Nout); the leftover rows add one more row, then one small fold
             if (R)
-                if (int e = launch_colsum(dY + (int64_t)Mq * Nout, t->cs_ws + (int64_t)S * Nout, R, Nout, t->red_ws, 0, s)) return e;
-            if (int e = launch_colsum(t->cs_ws, db, nslabs, Nout, t->red_ws, 0, s)) return e;
+                if (int e = launch_colsum(dY + (int64_t)Mq * Nout, t->cs_ws + (int64_t)S * Nout, R, Nout, red_ws, 0, s)) return e;
+            if (int e = launch_colsum(t->cs_ws, db, nslabs, Nout, red_ws, 0, s)) return e;
         }
     }
     if (db && !fused_bias) {
         W2V2_REQUIRE(dY, "weight_grad: the bias gradient needs the fp32 dY");
-        if (int e = launch_colsum(dY, db, M, Nout, t->red_ws, 0, s)) return e;
+        if (int e = launch_colsum(dY, db, M, Nout, red_ws, 0, s)) return e;
     }
     return W2V2_OK;
 }
@@ -819,8 +839,48 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         W2V2_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         t->bucket_ev.push_back(ev);
     }
-    // bucket k's slice of the flat buffer is final once this is recorded (w2v2_train_bucket_wait)
+    // ---- weight-gradient side stream (TrainState::wg_stream): the bf16 shadow path only -- there every dY a weight gradient reads is a
+    // shadow with a known next writer (the wait points below); the other paths keep one stream.
+    // (tools-only build: W2V2_WGRAD_STREAM = 0 / 1 overrides the option for A/B runs)
+    const int wg_knob = tune_int("W2V2_WGRAD_STREAM", -1);
+    const bool side_on = shb && t->x16_valid && t->x16_attn && t->attn_colpart && (wg_knob < 0 ? m->opt_wgrad_stream : wg_knob != 0);
+    if (side_on && !t->wg_stream) {
+        int lo = 0, hi = 0;
+        W2V2_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));           // (lo = the numerically largest = least urgent)
+        W2V2_HIP_CHECK(hipStreamCreateWithPriority(&t->wg_stream, hipStreamNonBlocking, lo));
+        W2V2_HIP_CHECK(hipEventCreateWithFlags(&t->wg_fork, hipEventDisableTiming));
+        W2V2_HIP_CHECK(hipEventCreateWithFlags(&t->wg_main, hipEventDisableTiming));
+        for (int k = 0; k < 4; ++k) W2V2_HIP_CHECK(hipEventCreateWithFlags(&t->wg_join[k], hipEventDisableTiming));
+    }
+    bool wg_pending[4] = {false, false, false, false};
+    bool wg_used = false;
+    // side(site, f): run f(stream, reduction scratch) -- a weight gradient -- behind everything the main stream has enqueued so far
+    auto side = [&](int site, auto&& f) -> int {
+        if (!side_on) return f(s, t->red_ws);
+        W2V2_HIP_CHECK(hipEventRecord(t->wg_fork, s));
+        W2V2_HIP_CHECK(hipStreamWaitEvent(t->wg_stream, t->wg_fork, 0));
+        if (int e = f(t->wg_stream, t->red_ws_side)) return e;
+        W2V2_HIP_CHECK(hipEventRecord(t->wg_join[site], t->wg_stream));
+        wg_pending[site] = wg_used = true;
+        return W2V2_OK;
+    };
+    // the main stream is about to overwrite what site's weight gradient reads
+    auto side_wait = [&](int site) -> int {
+        if (wg_pending[site]) {
+            W2V2_HIP_CHECK(hipStreamWaitEvent(s, t->wg_join[site], 0));
+            wg_pending[site] = false;
+        }
+        return W2V2_OK;
+    };
+    // bucket k's slice of the flat buffer is final once this is recorded (w2v2_train_bucket_wait): with the side stream in use the
+    // event goes THERE, after the side stream has caught up with the main stream's position (LayerNorm / bias gradients come from it)
     auto bucket_done = [&](int k) -> int {
+        if (wg_used) {
+            W2V2_HIP_CHECK(hipEventRecord(t->wg_main, s));
+            W2V2_HIP_CHECK(hipStreamWaitEvent(t->wg_stream, t->wg_main, 0));
+            W2V2_HIP_CHECK(hipEventRecord(t->bucket_ev[k], t->wg_stream));
+            return W2V2_OK;
+        }
         W2V2_HIP_CHECK(hipEventRecord(t->bucket_ev[k], s));
         return W2V2_OK;
     };
@@ -856,12 +916,12 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     auto dqkv16_only = [&](int i, const uint16_t* attn_in16) {
         return xs && s16q && t->x16_attn && t->attn_colpart && attn_in16 && H % 128 == 0 && dx_shadowed(m->qkv_w[i]);
     };
-    auto qkv_weight_grad = [&](const std::string& b, const float* attn_in, const uint16_t* attn_in16, bool only16) -> int {
+    auto qkv_weight_grad = [&](const std::string& b, const float* attn_in, const uint16_t* attn_in16, bool only16, hipStream_t s, float* rws) -> int {
         // packed q|k|v projection: dW (H, 3H) -> the three (H, H) kernels, db (3H) -> the three biases
         float* dWqkv = t->dwqkv;
         float* dbqkv = dWqkv + (int64_t)3 * H * H;
         if (int e = weight_grad(m, attn_in, only16 ? nullptr : t->g3h, (int)BT, H, 3 * H, dWqkv, only16 ? nullptr : dbqkv, s,
-                                (xs && s16q) ? attn_in16 : nullptr, s16q, s16q != nullptr))
+                                (xs && s16q) ? attn_in16 : nullptr, s16q, s16q != nullptr, rws))
             return e;
         if (only16)
             if (int e = launch_colsum_fold(t->attn_colpart, dbqkv, attention_colpart_rows(B, T), 3 * H, s)) return e;
@@ -930,23 +990,29 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         const LnDropTail do_drop{p, seed, layer_stream(i, 1)};
         if (l.keep != 0.f) {
             W2V2_REQUIRE(!f16 || dh16, "train_backward: no bf16 shadow of the layer's output gradient");
-            if (int e = weight_grad(m, f16 ? nullptr : l.gd, dh, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
-                                    G(b + "/feed_forward/output_dense/bias"), s, (xs && dh16) ? l.gd16 : nullptr, dh16, dh16 != nullptr && dh16 == s16h))
+            if (int e = side(0, [&](hipStream_t st, float* rws) {
+                    return weight_grad(m, f16 ? nullptr : l.gd, dh, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
+                                       G(b + "/feed_forward/output_dense/bias"), st, (xs && dh16) ? l.gd16 : nullptr, dh16, dh16 != nullptr && dh16 == s16h, rws);
+                }))
                 return e;
             bool b1_done = false;
             float* const gb1 = G(b + "/feed_forward/intermediate_dense/bias");
             // (f16: du is needed only as bf16 -- both consumers stream the shadow -- unless its fp32 column sums are still to be taken)
             const bool du16_only = f16 && (!gb1 || shb) && dx_shadowed(m->P(b + "/feed_forward/intermediate_dense/kernel"));
             float* const du = du16_only ? nullptr : t->gf;
+            if (int e = side_wait(1)) return e;              // (du / its shadow: read by the layer above's up-projection weight gradient)
             if (int e = ffn_hidden_grad(i, l, b, dh, dh16, du16_only, gb1, &b1_done)) return e;
-            if (int e = weight_grad(m, l.t2, du, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
-                                    b1_done ? nullptr : gb1, s, xs ? l.t2_16 : nullptr, s16f, s16f != nullptr))
+            if (int e = side(1, [&](hipStream_t st, float* rws) {
+                    return weight_grad(m, l.t2, du, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
+                                       b1_done ? nullptr : gb1, st, xs ? l.t2_16 : nullptr, s16f, s16f != nullptr, rws);
+                }))
                 return e;
             if (int e = gemm_dx(du, s16f, F, l.W1T, m->P(b + "/feed_forward/intermediate_dense/kernel"), tmp, H, nullptr, (int)BT, H, F, s)) return e;
             float* dg2 = G(b + "/final_layer_norm/gamma");
             float* db2 = G(b + "/final_layer_norm/beta");
             // dt1 = dh (residual) + LN2-backward(tmp), one pass (+ d_o's shadow and column sums where nothing reads d_o in fp32;
-            // dh16 in s16h is dead by now)
+            // dh16 in s16h is dead by now -- once the down-projection's weight gradient has read it)
+            if (int e = side_wait(0)) return e;
             if (int e = launch_ln_bwd_x(l.t1, m->P(b + "/final_layer_norm/gamma"), tmp, dt1, do_tail ? s16h : nullptr, dg2 ? dg2 : t->dummy,
                                         db2 ? db2 : t->dummy + H, BT, H, eps, t->red_ws, s, do_tail ? (gbo ? gbo : t->dummy + 2 * H) : nullptr, dh,
                                         do_tail ? &do_drop : nullptr))
@@ -968,20 +1034,31 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         if (int e = gemm_dx(do16_only ? nullptr : d_o, s16h, H, l.WoT, m->P(b + "/attention/out_proj/kernel"), c16 ? nullptr : dctx, H, nullptr, (int)BT, H, H, s, dctx16)) return e;
         AttnTrain tr{p, seed, layer_stream(i, 0), l.lse, t->x16_attn ? l.keep_bits : nullptr};
         const bool q16 = dqkv16_only(i, l.a16);
+        auto out_weight_grad = [&](hipStream_t st, float* rws) {
+            return weight_grad(m, t->ctx16_only ? nullptr : l.ctx, do16_only ? nullptr : d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), bo_done ? nullptr : gbo, st,
+                               (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h, s16h != nullptr, rws);
+        };
+        // (side stream: the out-projection's weight gradient goes out BEFORE the attention backward, to run under it)
+        if (side_on)
+            if (int e = side(2, out_weight_grad)) return e;
+        if (int e = side_wait(3)) return e;                  // (dqkv / its shadow / the column partials: the layer above's q|k|v weight gradient)
         if (int e = launch_attention_bwd(pf, t->x16_attn ? nullptr : l.qkv, flen, c16 ? nullptr : l.ctx, c16 ? nullptr : dctx, q16 ? nullptr : t->g3h, t->dvec, B, T, H, c.num_heads, tr,
                                          s, s16q, t->x16_attn ? l.qkv16 : nullptr, dctx16, q16 ? t->attn_colpart : nullptr, c16 ? l.ctx16 : nullptr))
             return e;
-        // (the out-projection's weight gradient runs here, not before its data gradient: the attention backward has just read O, so
+        // (one stream: the out-projection's weight gradient runs here, not before its data gradient: the attention backward has just read O, so
         //  the GEMM finds it in the Infinity Cache instead of streaming it from HBM cold; d_o / its shadow are untouched until below)
-        if (int e = weight_grad(m, t->ctx16_only ? nullptr : l.ctx, do16_only ? nullptr : d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), bo_done ? nullptr : gbo, s,
-                                (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h, s16h != nullptr))
-            return e;
-        if (int e = qkv_weight_grad(b, l.a, l.a16, q16)) return e;
+        if (!side_on)
+            if (int e = out_weight_grad(s, t->red_ws)) return e;
+        if (int e = side(3, [&](hipStream_t st, float* rws) { return qkv_weight_grad(b, l.a, l.a16, q16, st, rws); })) return e;
+        if (!do16_only)
+            if (int e = side_wait(2)) return e;              // (d_o in fp32 lives in tmp)
         if (int e = gemm_dx(q16 ? nullptr : t->g3h, s16q, 3 * H, l.WqkvT, m->qkv_w[i], tmp, H, nullptr, (int)BT, H, 3 * H, s)) return e;
         float* dg1 = G(b + "/layer_norm/gamma");
         float* db1 = G(b + "/layer_norm/beta");
         // dh = dt1 (residual) + LN1-backward(tmp), one pass (+ the shadow the next iteration's down-projection GEMMs stream)
         dh16_valid = s16h && H % 4 == 0 && (reinterpret_cast<uintptr_t>(dt1) & 15) == 0;
+        if (int e = side_wait(2)) return e;                  // (d_o's shadow in s16h: the out-projection's weight gradient)
+        if (int e = side_wait(0)) return e;                  // (dh in fp32, when the down-projection's weight gradient read that)
         if (int e = launch_ln_bwd_x(x, m->P(b + "/layer_norm/gamma"), tmp, dh, dh16_valid ? s16h : nullptr, dg1 ? dg1 : t->dummy,
                                     db1 ? db1 : t->dummy + H, BT, H, eps, t->red_ws, s, nullptr, dt1))
             return e;
@@ -997,15 +1074,18 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         float* db2 = G(b + "/final_layer_norm/beta");
         // (dt3 is the dY of the FFN down-projection: its column sums are that layer's bias gradient)
         float* const gb2 = (shb && l.keep != 0.f) ? G(b + "/feed_forward/output_dense/bias") : nullptr;
+        if (int e = side_wait(2)) return e;                  // (tmp / s16h still hold the d_o the layer above's out-projection weight gradient reads)
         if (int e = launch_ln_bwd_x(l.t3, m->P(b + "/final_layer_norm/gamma"), dh, dt3, (l.keep != 0.f && H % 4 == 0) ? s16h : nullptr,
                                     dg2 ? dg2 : t->dummy, db2 ? db2 : t->dummy + H, BT, H, eps, t->red_ws, s, gb2))
             return e;
         float* dt2 = tmp2;
         if (l.keep != 0.f) {
             // t3 = t2 + f,  f = gd W2 + b2
-            if (int e = weight_grad(m, f16 ? nullptr : l.gd, dt3, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
-                                    gb2 ? nullptr : G(b + "/feed_forward/output_dense/bias"), s, xs ? l.gd16 : nullptr, H % 4 == 0 ? s16h : nullptr,
-                                    s16h != nullptr))
+            if (int e = side(0, [&](hipStream_t st, float* rws) {
+                    return weight_grad(m, f16 ? nullptr : l.gd, dt3, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
+                                       gb2 ? nullptr : G(b + "/feed_forward/output_dense/bias"), st, xs ? l.gd16 : nullptr, H % 4 == 0 ? s16h : nullptr,
+                                       s16h != nullptr, rws);
+                }))
                 return e;
             // du = dgd * keep/(1-p) * GELU'(u)   (+ its column sums = the up-projection's bias gradient)
             bool b1_done = false;
@@ -1013,9 +1093,12 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
             // (f16: du is needed only as bf16 -- both consumers stream the shadow, the column sums come from the producer)
             const bool du16_only = f16 && (!gb1 || shb) && dx_shadowed(m->P(b + "/feed_forward/intermediate_dense/kernel"));
             float* const du = du16_only ? nullptr : t->gf;
+            if (int e = side_wait(1)) return e;              // (du / its shadow: read by the layer above's up-projection weight gradient)
             if (int e = ffn_hidden_grad(i, l, b, dt3, H % 4 == 0 ? s16h : nullptr, du16_only, gb1, &b1_done)) return e;
-            if (int e = weight_grad(m, l.t2, du, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
-                                    b1_done ? nullptr : gb1, s, xs ? l.t2_16 : nullptr, s16f, s16f != nullptr))
+            if (int e = side(1, [&](hipStream_t st, float* rws) {
+                    return weight_grad(m, l.t2, du, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
+                                       b1_done ? nullptr : gb1, st, xs ? l.t2_16 : nullptr, s16f, s16f != nullptr, rws);
+                }))
                 return e;
             // dt2 = du W1^T + dt3 (the residual branch)
             if (int e = gemm_dx(du, s16f, F, l.W1T, m->P(b + "/feed_forward/intermediate_dense/kernel"), dt2, H, dt3, (int)BT, H, F, s)) return e;
@@ -1035,6 +1118,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         const bool do16_only = xs && t->x16_attn && s16h && H % 128 == 0 && (BT * H) % 4 == 0 && dx_shadowed(m->P(b + "/attention/out_proj/kernel"));
         const bool do_tail = do16_only && shb && fuse_do_tail;
         const LnDropTail do_drop{p, seed, layer_stream(i, 1)};
+        if (int e = side_wait(0)) return e;                  // (dt3 in tmp / s16h: the down-projection's weight gradient; d_o goes there next)
         if (int e = launch_ln_bwd_x(l.t1, m->P(b + "/layer_norm/gamma"), dt2, dt1, do_tail ? s16h : nullptr, dg1 ? dg1 : t->dummy,
                                     db1 ? db1 : t->dummy + H, BT, H, eps, t->red_ws, s, do_tail ? (gbo ? gbo : t->dummy + 2 * H) : nullptr, nullptr,
                                     do_tail ? &do_drop : nullptr))
@@ -1051,17 +1135,27 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         AttnTrain tr{p, seed, layer_stream(i, 0), l.lse, t->x16_attn ? l.keep_bits : nullptr};
         const uint16_t* const hs16_i = m->hs16.size() > (size_t)i ? m->hs16[i] : nullptr;
         const bool q16 = dqkv16_only(i, hs16_i);
+        auto out_weight_grad = [&](hipStream_t st, float* rws) {
+            return weight_grad(m, t->ctx16_only ? nullptr : l.ctx, do16_only ? nullptr : d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), bo_done ? nullptr : gbo, st,
+                               (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h, s16h != nullptr, rws);
+        };
+        // (side stream: the out-projection's weight gradient goes out BEFORE the attention backward, to run under it)
+        if (side_on)
+            if (int e = side(2, out_weight_grad)) return e;
+        if (int e = side_wait(3)) return e;                  // (dqkv / its shadow / the column partials: the layer above's q|k|v weight gradient)
         if (int e = launch_attention_bwd(pf, t->x16_attn ? nullptr : l.qkv, flen, c16 ? nullptr : l.ctx, c16 ? nullptr : dctx, q16 ? nullptr : t->g3h, t->dvec, B, T, H, c.num_heads, tr,
                                          s, s16q, t->x16_attn ? l.qkv16 : nullptr, dctx16, q16 ? t->attn_colpart : nullptr, c16 ? l.ctx16 : nullptr))
             return e;
-        if (int e = weight_grad(m, t->ctx16_only ? nullptr : l.ctx, do16_only ? nullptr : d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), bo_done ? nullptr : gbo, s,
-                                (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h, s16h != nullptr))
-            return e;
-        if (int e = qkv_weight_grad(b, m->hs[i], hs16_i, q16)) return e;
+        if (!side_on)
+            if (int e = out_weight_grad(s, t->red_ws)) return e;
+        if (int e = side(3, [&](hipStream_t st, float* rws) { return qkv_weight_grad(b, m->hs[i], hs16_i, q16, st, rws); })) return e;
         // dx = dqkv Wqkv^T + dt1 (residual)
         if (int e = gemm_dx(q16 ? nullptr : t->g3h, s16q, 3 * H, l.WqkvT, m->qkv_w[i], dh, H, dt1, (int)BT, H, 3 * H, s)) return e;
         if (int e = bucket_done(c.num_layers - i)) return e;
     }
+    // (the scratch the layers' gradients flowed through is reused from here on, and the last weight gradient below shares the slabs)
+    for (int k = 0; k < 4; ++k)
+        if (int e = side_wait(k)) return e;
     // ---- encoder input: postnorm hs[0] = dropout(LN(posout));  prenorm hs0 = dropout(posout) ----
     float* dpos = tmp2;
     if (prenorm) {

@@ -152,10 +152,16 @@ int w2v2_get_precision(const w2v2_model* m);
  *   W2V2_OPT_SPLIT_PLANES (default 1)      precision modes BF16X3 / F16X2: 0 = no operand planes written by the producers; the
  *                                          forward GEMMs then load fp32 rows and split them in registers (gemm_split.hip, six
  *                                          bf16 products in both modes) -- the round-4 path, kept for A/B measurements.
+ *   W2V2_OPT_WGRAD_STREAM (default 0)      bf16 training backward: 1 = the encoder layers' weight-gradient GEMMs run on a second,
+ *                                          lower-priority HIP stream owned by the model, ordered against the caller's stream by
+ *                                          events only (w2v2_train_backward returns with the caller's stream waiting for all of it;
+ *                                          bucket events then come from that stream).  Same results bit for bit; measured neutral
+ *                                          on one GPU, hence off.
  * w2v2_get_option returns the value, or W2V2_EINVAL for an unknown option. */
 #define W2V2_OPT_BF16_SHADOWS 0
 #define W2V2_OPT_KEEP_ACTIVATIONS 1
 #define W2V2_OPT_SPLIT_PLANES 2
+#define W2V2_OPT_WGRAD_STREAM 3
 int w2v2_set_option(w2v2_model* m, int32_t option, int32_t value);
 int w2v2_get_option(const w2v2_model* m, int32_t option);
 /* W2V2_PRECISION_F16X2: *flag = 1 if a forward since the last call met an activation outside fp16's range after scaling

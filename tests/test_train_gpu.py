@@ -344,6 +344,40 @@ def test_gradients_match_autograd_base_dims(env):
     print("worst relative gradient error (base dims)", worst)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,L,B", [("base_sample_padded", 61520, 2), ("tiny_robust", 4000, 2)])
+def test_weight_gradient_side_stream_is_bit_identical(env, case, L, B):
+    """Model option "wgrad_stream" (W2V2_OPT_WGRAD_STREAM): the encoder layers' weight-gradient GEMMs on the model's second HIP stream,
+    ordered by events.  Same kernels on the same operands: the WHOLE flat gradient buffer is bit-identical to the one-stream backward,
+    five backward passes in a row (a missing wait would let the main stream overwrite a dY a weight gradient is still reading), for the
+    postnorm (base) and the prenorm (robust) layer loop."""
+    import wav2vec2
+    _, torch, dev = env
+    labels = np.tile(np.array([[5, 9, 9, 11, 0, 0]], np.int32), (B, 1))
+    x = V.hash_normal("train/wave_side", B * L, 8).reshape(B, L)
+    m, cfg, w = build(case, L)
+    m.set_precision("bf16")
+    assert m.get_option("wgrad_stream") is False            # (measured neutral on one GPU: off by default)
+    loss_fn = wav2vec2.CTCLoss(cfg, x.shape, division_factor=B)
+    tr = wav2vec2.Trainer(m, loss_fn, dropout=0.1, apply_spec_augment=False, seed=1)
+    ref = None
+    for flag, reps in ((False, 1), (True, 5), (False, 1)):
+        m.set_option("wgrad_stream", flag)
+        for _ in range(reps):
+            logits = tr.forward(x, step_seed=7)
+            nll, dlog = loss_fn.per_sample(labels, logits, with_grad=True)
+            tr.backward(dlog)
+            g = tr.grad_buffer().clone()
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(g).all())
+            if ref is None:
+                ref = g
+                assert float(ref.abs().max()) > 0
+            else:
+                assert torch.equal(g, ref), (flag, int((g != ref).sum()))
+    m.set_option("wgrad_stream", False)
+
+
 @pytest.mark.parametrize("L,frames", [(20560, 64), (24080, 75)])
 def test_bf16_precision_training_step(env, L, frames):
     """bf16 fine-tune arithmetic (BASELINE configs 3 / 5): training-mode logits equal the torch oracle with
