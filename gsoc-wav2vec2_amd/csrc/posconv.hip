@@ -79,7 +79,28 @@ __global__ __launch_bounds__(256) void pos_conv_kernel(PosArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ln = lane & 15, lk = lane >> 4;
-    const int t0 = blockIdx.x * PBM, g = blockIdx.y, b = blockIdx.z;
+    // Block -> (frame block, group, sample), XCD-aware (round 5): hardware hands consecutive block ids to the eight XCDs in turn, each
+    // with its own 4 MiB L2.  A block streams its group's 128 tap tiles (K cg^2 floats: 1.18 MB at cg = 48, 2.1 MB at cg = 64) from L2;
+    // with the groups spread over all XCDs every L2 saw all 16 groups' 19 - 34 MB and the taps came from the Infinity Cache again and
+    // again (FETCH_SIZE 1.50 GB per launch for 95 MB of operands).  Here XCD x owns groups [x groups / 8, (x + 1) groups / 8): two
+    // groups' taps stay resident in its L2, and the frame blocks of one (sample, group) -- which share half their input slab --
+    // follow each other on it.
+    int t0, g, b;
+    {
+        const int tb = (a.T + PBM - 1) / PBM;
+        const int bid = blockIdx.x;
+        if (a.groups % 8 == 0) {
+            const int gpx = a.groups >> 3, xcd = bid & 7, idx = bid >> 3;
+            const int tblk = idx % tb, r = idx / tb;
+            t0 = tblk * PBM;
+            g = xcd * gpx + r % gpx;
+            b = r / gpx;
+        } else {
+            t0 = (bid % tb) * PBM;
+            g = (bid / tb) % a.groups;
+            b = bid / (tb * a.groups);
+        }
+    }
     const int pad = a.pad_left;
     const int rows = PBM + a.K - 1;
     float* Xs = smem;                           // rows x XS
@@ -185,7 +206,7 @@ int launch_pos(const PosArgs& a, hipStream_t s) {
         attr_set = true;
     }
     W2V2_REQUIRE(lds <= 160 * 1024, "pos_conv: K=%d needs %zu B of LDS (> 160 KiB)", a.K, lds);
-    dim3 grid((a.T + PBM - 1) / PBM, a.groups, a.B), block(256);
+    dim3 grid((unsigned)(((a.T + PBM - 1) / PBM) * a.groups * a.B)), block(256);
     W2V2_LAUNCH(pos_conv_kernel<CG>, grid, block, lds, s, a);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
