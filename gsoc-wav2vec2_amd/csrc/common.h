@@ -289,6 +289,7 @@ int stream_scratch(int slot, hipStream_t s, size_t bytes, void** out);
 int stream_scratch_release();       // frees the calling device's scratch buffers
 // one layer's q | k | v projections <-> the packed (H, 3H) kernel and (3H) bias (shadow.hip); unpack skips null targets
 int launch_qkv_pack(float* packed_w, float* packed_b, const float* const w[3], const float* const b[3], int H, hipStream_t s);
+int launch_qkv_pack_layers(float* const* packed_w, float* const* packed_b, const float* const* w, const float* const* b, int layers, int H, hipStream_t s);
 int launch_qkv_unpack(const float* packed_w, const float* packed_b, float* const w[3], float* const b[3], int H, hipStream_t s);
 bool attention_bf16_supported(int head_size);   // attention_bf16.hip: head size 64
 bool attention_split_supported(int head_size);  // attention_split.hip (precision mode 2): head size 64

@@ -69,6 +69,7 @@ struct w2v2_model {
     struct PlaneBuf { uint16_t* p = nullptr; int64_t plane = 0; };
     bool opt_planes = true;                                  // W2V2_OPT_SPLIT_PLANES
     bool opt_wgrad_stream = false;                           // W2V2_OPT_WGRAD_STREAM
+    bool opt_defer_folds = true;                             // W2V2_OPT_DEFER_FOLDS
     int pl_fmt = -1, pl_B = 0;
     int64_t pl_L = 0;
     std::vector<void*> pl_allocs;

@@ -93,7 +93,52 @@ __global__ __launch_bounds__(256) void qkv_pack_kernel(QkvPtrs a) {
         }
 }
 
+// the same packing for up to QKV_MULTI layers in one launch (blockIdx.z = layer): the per-step refresh after the optimizer (w2v2_finalize)
+constexpr int QKV_MULTI = 24;
+struct QkvPtrsMulti {
+    QkvPtrs l[QKV_MULTI];
+};
+__global__ __launch_bounds__(256) void qkv_pack_multi_kernel(QkvPtrsMulti t) {
+    const QkvPtrs& a = t.l[blockIdx.z];
+    const int j = blockIdx.y, H = a.H, hv = H >> 2;
+    const float* w = a.w[j];
+    const int64_t n4 = (int64_t)H * hv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / hv, c = (i % hv) * 4;
+        *reinterpret_cast<float4*>(a.packed_w + r * 3 * H + (int64_t)j * H + c) = *reinterpret_cast<const float4*>(w + r * H + c);
+    }
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < H; i += 256) a.packed_b[j * H + i] = a.b[j][i];
+}
+
 }  // namespace
+
+// layers' q | k | v kernels and biases -> packed (H, 3H) / (3H), QKV_MULTI layers per launch.  w / b: 3 pointers per layer.
+int launch_qkv_pack_layers(float* const* packed_w, float* const* packed_b, const float* const* w, const float* const* b, int layers, int H, hipStream_t s) {
+    W2V2_REQUIRE(packed_w && packed_b && w && b && layers > 0 && H > 0 && H % 4 == 0, "qkv_pack_layers: bad argument");
+    const int blocks = (int)(((int64_t)H * H / 4 + 255) / 256);
+    for (int l0 = 0; l0 < layers; l0 += QKV_MULTI) {
+        const int n = layers - l0 < QKV_MULTI ? layers - l0 : QKV_MULTI;
+        QkvPtrsMulti t;
+        uintptr_t bits = 0;
+        for (int i = 0; i < n; ++i) {
+            QkvPtrs& a = t.l[i];
+            a.packed_w = packed_w[l0 + i]; a.packed_b = packed_b[l0 + i]; a.H = H;
+            bits |= reinterpret_cast<uintptr_t>(a.packed_w);
+            for (int j = 0; j < 3; ++j) {
+                a.w[j] = const_cast<float*>(w[3 * (l0 + i) + j]);
+                a.b[j] = const_cast<float*>(b[3 * (l0 + i) + j]);
+                W2V2_REQUIRE(a.w[j] && a.b[j] && a.packed_w && a.packed_b, "qkv_pack_layers: null source");
+                bits |= reinterpret_cast<uintptr_t>(a.w[j]);
+            }
+        }
+        for (int i = n; i < QKV_MULTI; ++i) t.l[i] = t.l[0];
+        W2V2_REQUIRE((bits & 15) == 0, "qkv_pack_layers: unaligned buffer");
+        W2V2_LAUNCH(qkv_pack_multi_kernel, dim3(blocks < 64 ? blocks : 64, 3, n), dim3(256), 0, s, t);
+    }
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
 
 static int launch_qkv(bool pack, float* packed_w, float* packed_b, float* const w[3], float* const b[3], int H, hipStream_t s) {
     W2V2_REQUIRE(packed_w && packed_b && H > 0 && H % 4 == 0, "qkv_pack: bad argument");

@@ -147,7 +147,8 @@ int launch_dropout_bwd(const float* u, const float* dy, float* dx, int64_t n, in
 int launch_dropout_bwd_x(const float* u, const float* dy, float* dx, uint16_t* dx16 /* optional bf16 shadow */, int64_t n, int act,
                          float p, uint64_t seed, uint32_t stream_id, hipStream_t s, const EwBf16& in = EwBf16{});
 int launch_dropout_bwd_colsum(const float* u, const float* dy, float* dx, uint16_t* dx16, float* colsum, int64_t rows, int cols,
-                              int act, float p, uint64_t seed, uint32_t stream_id, float* ws, hipStream_t s, const EwBf16& in = EwBf16{});
+                              int act, float p, uint64_t seed, uint32_t stream_id, float* ws, hipStream_t s, const EwBf16& in = EwBf16{},
+                              struct FoldBatch* defer = nullptr /* the fold of ws joins this batch (ws then stays live until its flush) */);
 // t1 = dropout(a) + res and y (/ y16) = LayerNorm(t1) in one pass (layernorm.hip); bit-identical to launch_dropout_fwd + launch_layer_norm_x
 int launch_layer_norm_drop(Profiler* prof, const float* a, const float* res, float* t1, float* y, uint16_t* y16 /* optional bf16 shadow */,
                            const float* gamma, const float* beta, int64_t rows, int C, float eps, float p, uint64_t seed, uint32_t stream,
@@ -157,6 +158,39 @@ int64_t colsum_ws_floats(int64_t rows, int cols);
 int64_t dropout_bwd_colsum_ws_floats(int64_t rows, int cols);      // scratch of launch_dropout_bwd_colsum
 int launch_colsum(const float* x, float* out, int64_t rows, int cols, float* ws, int accumulate, hipStream_t s);
 int launch_colsum_fold(const float* partial, float* out, int nrows, int cols, hipStream_t s);   // rows are per-block partial sums
+// Deferred folds (round 5).  Every producer of a gradient leaves partial rows (split-K slabs of a weight gradient, per-block column sums
+// of a LayerNorm / dropout / attention backward) that a small fold kernel turned into the final fp32 gradient right behind it: nine
+// launches of 8-15 us per encoder layer, each with a grid too small to fill the chip.  Nothing inside the layer reads those gradients,
+// so the folds of one layer are collected in a FoldBatch and run as ONE launch over a job table (the kernel argument itself) in front of
+// the layer's bucket event.  A job keeps the summation order of the kernel it replaces (TALL = colsum_final_kernel<true>: sequential
+// fp64 over the partial rows; WIDE = colsum_final_wide_kernel: 8 row lanes x 4 loads in flight), so results are bit-identical to the
+// separate launches (tests/test_train_gpu.py::test_deferred_folds_do_not_change_results).  The producers' partial buffers must stay
+// untouched until flush(): each deferred site has its own scratch (TrainState::site_slabs / site_ws).
+struct FoldJob {
+    const float* partial;
+    float* out[3];        // WIDE: one target per column group.  TALL with unpack > 0: the three (unpack, unpack) kernels of a packed (unpack, 3 unpack) matrix
+    int64_t ld;           // floats between partial rows
+    int nchunks, cols;    // partial rows; columns (per group)
+    int kind;             // 0 = TALL, 1 = WIDE
+    int groups;           // WIDE: column groups sharing the partial rows (group g reads partial + g cols)
+    int unpack;           // TALL: 0, or H of the packed q|k|v kernel
+    int block0;           // first block of the job in the launch
+};
+constexpr int FOLD_MAX_JOBS = 12;
+struct FoldTable {
+    FoldJob j[FOLD_MAX_JOBS];
+    int n;
+};
+struct FoldBatch {
+    FoldTable tab;
+    int nblocks = 0;
+    double bytes = 0.0;
+    FoldBatch() { tab.n = 0; }
+    // false: the job does not fit the table or the 16-byte path (the caller then runs the separate fold as before)
+    bool add_tall(const float* partial, int nchunks, int64_t cols, float* out, int unpack = 0, float* out1 = nullptr, float* out2 = nullptr);
+    bool add_wide(const float* partial, int nchunks, int cols, int64_t ld, int groups, float* out0, float* out1 = nullptr, float* out2 = nullptr);
+    int flush(hipStream_t s);
+};
 int64_t ln_bwd_ws_floats(int64_t rows, int C);
 int launch_ln_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma,
                   float* dbeta, int64_t rows, int C, float eps, float* ws, hipStream_t s);
@@ -170,7 +204,8 @@ int launch_ln_bwd_x(const float* x, const float* gamma, const float* dy, float* 
                     float* dgamma, float* dbeta, int64_t rows, int C, float eps, float* ws, hipStream_t s,
                     float* dxsum = nullptr /* optional: column sums of dx (C floats) */,
                     const float* residual = nullptr /* optional: dx = LN-backward(dy) + residual */,
-                    const struct LnDropTail* tail = nullptr /* optional: dx16 / dxsum take dropout-backward(dx) instead of dx */);
+                    const struct LnDropTail* tail = nullptr /* optional: dx16 / dxsum take dropout-backward(dx) instead of dx */,
+                    struct FoldBatch* defer = nullptr /* the fold of ws joins this batch (ws then stays live until its flush) */);
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1, float b2,
                 float eps, hipStream_t s);
 int launch_spec_aug_fwd(const float* x, const uint8_t* mask, const float* embed, float* y, int64_t rows, int H, hipStream_t s);

@@ -352,6 +352,64 @@ __global__ __launch_bounds__(256) void colsum_final_wide_kernel(const float* __r
     }
 }
 
+// The deferred folds of one encoder layer in one launch (train.h: FoldBatch).  A block finds its job by a wave-uniform scan of the
+// table (at most FOLD_MAX_JOBS entries, in the kernel-argument segment) and then runs the body of the kernel the job replaces, with the
+// same per-column summation order.
+__global__ __launch_bounds__(256) void fold_multi_kernel(const FoldTable tab) {
+    __shared__ double red[8][33];
+    int ji = 0;
+    while (ji + 1 < tab.n && (int)blockIdx.x >= tab.j[ji + 1].block0) ++ji;
+    const FoldJob& J = tab.j[ji];
+    const int b = (int)blockIdx.x - J.block0;
+    const float* __restrict__ partial = J.partial;
+    const int nchunks = J.nchunks, cols = J.cols;
+    const int64_t ld = J.ld;
+    if (J.kind == 0) {      // colsum_final_kernel<true>
+        const int c = (b * EW_THREADS + (int)threadIdx.x) * 4;
+        if (c >= cols) return;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        for (int k = 0; k < nchunks; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(partial + (int64_t)k * ld + c);
+            a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+        }
+        const float4 o = make_float4((float)a0, (float)a1, (float)a2, (float)a3);
+        const int H = J.unpack;
+        if (H) {            // column c of the packed (H, 3H) matrix = row c / 3H, kernel (c % 3H) / H, column c % H  (H % 4 == 0: a float4 stays in one kernel)
+            const int row = c / (3 * H), rem = c - row * 3 * H, which = rem / H;
+            float* dst = which == 0 ? J.out[0] : (which == 1 ? J.out[1] : J.out[2]);
+            *reinterpret_cast<float4*>(dst + (int64_t)row * H + (rem - which * H)) = o;
+        } else {
+            *reinterpret_cast<float4*>(J.out[0] + c) = o;
+        }
+        return;
+    }
+    // colsum_final_wide_kernel: blockIdx = (column block, group)
+    const int colblocks = (cols + 31) / 32;
+    const int g = b / colblocks, bx = b - g * colblocks;
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int c = bx * 32 + cx;
+    partial += (int64_t)g * cols;
+    float* out = g == 0 ? J.out[0] : (g == 1 ? J.out[1] : J.out[2]);
+    double acc = 0.0;
+    if (c < cols) {
+        int k = ry;
+        for (; k + 24 < nchunks; k += 32) {
+            const float v0 = partial[(int64_t)k * ld + c], v1 = partial[(int64_t)(k + 8) * ld + c];
+            const float v2 = partial[(int64_t)(k + 16) * ld + c], v3 = partial[(int64_t)(k + 24) * ld + c];
+            acc += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+        }
+        for (; k < nchunks; k += 8) acc += (double)partial[(int64_t)k * ld + c];
+    }
+    red[ry][cx] = acc;
+    __syncthreads();
+    if (ry == 0 && c < cols) {
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += red[j][cx];
+        out[c] = (float)t;
+    }
+}
+
 // LayerNorm backward.  One wave per row (grid-stride); per-lane dgamma / dbeta partials live in
 // registers across the rows a wave visits, are combined across the block's 4 waves through LDS and
 // written as partial[block][2][C]; colsum_final reduces them.
@@ -672,6 +730,44 @@ int launch_colsum_fold(const float* partial, float* out, int nrows, int cols, hi
     return W2V2_OK;
 }
 
+bool FoldBatch::add_tall(const float* partial, int nchunks, int64_t cols, float* out, int unpack, float* out1, float* out2) {
+    if (tab.n >= FOLD_MAX_JOBS || !partial || !out || nchunks <= 0 || cols <= 0 || cols > 0x7FFFFFF0 || (cols & 3) != 0) return false;
+    uintptr_t al = reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(out);
+    if (unpack) {
+        if (!out1 || !out2 || (unpack & 3) != 0 || cols != (int64_t)3 * unpack * unpack) return false;
+        al |= reinterpret_cast<uintptr_t>(out1) | reinterpret_cast<uintptr_t>(out2);
+    }
+    if (al & 15) return false;
+    FoldJob& J = tab.j[tab.n++];
+    J.partial = partial; J.out[0] = out; J.out[1] = out1; J.out[2] = out2;
+    J.ld = cols; J.nchunks = nchunks; J.cols = (int)cols; J.kind = 0; J.groups = 1; J.unpack = unpack; J.block0 = nblocks;
+    nblocks += (int)((cols + 4 * EW_THREADS - 1) / (4 * EW_THREADS));
+    bytes += 4.0 * (nchunks + 1.0) * (double)cols;
+    return true;
+}
+
+bool FoldBatch::add_wide(const float* partial, int nchunks, int cols, int64_t ld, int groups, float* out0, float* out1, float* out2) {
+    if (tab.n >= FOLD_MAX_JOBS || !partial || nchunks <= 0 || cols <= 0 || groups < 1 || groups > 3) return false;
+    if (!out0 || (groups > 1 && !out1) || (groups > 2 && !out2)) return false;
+    FoldJob& J = tab.j[tab.n++];
+    J.partial = partial; J.out[0] = out0; J.out[1] = out1; J.out[2] = out2;
+    J.ld = ld; J.nchunks = nchunks; J.cols = cols; J.kind = 1; J.groups = groups; J.unpack = 0; J.block0 = nblocks;
+    nblocks += ((cols + 31) / 32) * groups;
+    bytes += 4.0 * (nchunks + 1.0) * (double)cols * groups;
+    return true;
+}
+
+int FoldBatch::flush(hipStream_t s) {
+    if (tab.n == 0) return W2V2_OK;
+    {
+        ProfScope ps(tl_step_prof, FAM_REDUCE, 0.0, bytes, s);
+        W2V2_LAUNCH(fold_multi_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, tab);
+    }
+    tab.n = 0; nblocks = 0; bytes = 0.0;
+    W2V2_HIP_CHECK(hipGetLastError());
+    return W2V2_OK;
+}
+
 int launch_colsum(const float* x, float* out, int64_t rows, int cols, float* ws, int accumulate, hipStream_t s) {
     W2V2_REQUIRE(x && out && rows > 0 && cols > 0, "colsum: bad argument");
     ProfScope ps(tl_step_prof, FAM_REDUCE, 0.0, 4.0 * (rows + 1.0) * cols, s);
@@ -703,7 +799,7 @@ int launch_colsum(const float* x, float* out, int64_t rows, int cols, float* ws,
 // layer dx is the output gradient of).  ws: dropout_bwd_colsum_ws_floats(rows, cols) floats.  Falls back to the two separate passes when
 // the tensors do not allow 16-byte accesses.
 int launch_dropout_bwd_colsum(const float* u, const float* dy, float* dx, uint16_t* dx16, float* colsum, int64_t rows, int cols,
-                              int act, float p, uint64_t seed, uint32_t stream_id, float* ws, hipStream_t s, const EwBf16& in) {
+                              int act, float p, uint64_t seed, uint32_t stream_id, float* ws, hipStream_t s, const EwBf16& in, FoldBatch* defer) {
     W2V2_REQUIRE((dy || in.b16) && (dx || dx16) && colsum && ws && rows > 0 && cols > 0 && p >= 0.f && p < 1.f && (act == 0 || u || in.a16),
                  "dropout_bwd_colsum: bad argument");
     ProfScope ps(tl_step_prof, FAM_DROPOUT, 0.0,
@@ -727,7 +823,8 @@ int launch_dropout_bwd_colsum(const float* u, const float* dy, float* dx, uint16
     const int nchunks = (int)((rows + chunk - 1) / chunk);
     W2V2_LAUNCH(dropout_bwd_colsum_kernel, dim3(colblocks, nchunks), dim3(256), 0, s, u, dy, dx, dx16, ws, rows, cols,
                        chunk, act, p, seed, stream_id, in.a16, in.b16, in.round_in);
-    W2V2_LAUNCH(colsum_final_wide_kernel, dim3((cols + 31) / 32), dim3(256), 0, s, ws, colsum, nchunks, cols, (int64_t)cols, 0);
+    if (!(defer && defer->add_wide(ws, nchunks, cols, (int64_t)cols, 1, colsum)))
+        W2V2_LAUNCH(colsum_final_wide_kernel, dim3((cols + 31) / 32), dim3(256), 0, s, ws, colsum, nchunks, cols, (int64_t)cols, 0);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }
@@ -742,12 +839,12 @@ int64_t ln_bwd_ws_floats(int64_t rows, int C) { return (int64_t)ln_bwd_blocks(ro
 
 int launch_ln_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma,
                   float* dbeta, int64_t rows, int C, float eps, float* ws, hipStream_t s) {
-    return launch_ln_bwd_x(x, gamma, dy, dx, nullptr, dgamma, dbeta, rows, C, eps, ws, s, nullptr, nullptr, nullptr);
+    return launch_ln_bwd_x(x, gamma, dy, dx, nullptr, dgamma, dbeta, rows, C, eps, ws, s, nullptr, nullptr, nullptr, nullptr);
 }
 
 int launch_ln_bwd_x(const float* x, const float* gamma, const float* dy, float* dx, uint16_t* dx16, float* dgamma,
                     float* dbeta, int64_t rows, int C, float eps, float* ws, hipStream_t s, float* dxsum, const float* residual,
-                    const LnDropTail* tail) {
+                    const LnDropTail* tail, FoldBatch* defer) {
     W2V2_REQUIRE(!tail || (dx16 && dxsum && tail->p >= 0.f && tail->p < 1.f), "ln_bwd: the dropout tail needs its bf16 output and a column-sum target");
     W2V2_REQUIRE(x && gamma && dy && dx && dgamma && dbeta && ws, "ln_bwd: null operand");
     W2V2_REQUIRE(!residual || (C & 3) != 0 || (reinterpret_cast<uintptr_t>(residual) & 15) == 0, "ln_bwd: unaligned residual");
@@ -773,7 +870,8 @@ int launch_ln_bwd_x(const float* x, const float* gamma, const float* dy, float* 
     else if (C <= 512) go(std::integral_constant<int, 2>{});
     else go(std::integral_constant<int, 4>{});
     // partial is (nb, ng C): dgamma = column sums of its first C columns, dbeta of the next C [, the sums of dx of the last C]
-    W2V2_LAUNCH(colsum_final_wide_kernel, dim3((C + 31) / 32, ng), dim3(256), 0, s, ws, dgamma, nb, C, (int64_t)ng * C, 0, dbeta, dxsum);
+    if (!(defer && defer->add_wide(ws, nb, C, (int64_t)ng * C, ng, dgamma, dbeta, dxsum)))
+        W2V2_LAUNCH(colsum_final_wide_kernel, dim3((C + 31) / 32, ng), dim3(256), 0, s, ws, dgamma, nb, C, (int64_t)ng * C, 0, dbeta, dxsum);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }

@@ -626,7 +626,19 @@ int w2v2_finalize(w2v2_model* m, void* stream) {
             W2V2_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&m->qkv_b[i]), (size_t)3 * H * sizeof(float)));
         }
     }
-    for (int i = 0; i < c.num_layers; ++i) {
+    if (H % 4 == 0 && c.num_layers > 0) {       // all layers in one launch (24 per launch): this runs after every optimizer step
+        std::vector<const float*> wl(3 * (size_t)c.num_layers), bl(3 * (size_t)c.num_layers);
+        for (int i = 0; i < c.num_layers; ++i) {
+            const std::string b = "encoder/layers/" + std::to_string(i) + "/attention/";
+            const char* names[3] = {"q_proj", "k_proj", "v_proj"};
+            for (int j = 0; j < 3; ++j) {
+                wl[3 * i + j] = m->P(b + names[j] + "/kernel");
+                bl[3 * i + j] = m->P(b + names[j] + "/bias");
+            }
+        }
+        if (int e = launch_qkv_pack_layers(m->qkv_w.data(), m->qkv_b.data(), wl.data(), bl.data(), c.num_layers, H, s)) return e;
+    }
+    for (int i = 0; i < c.num_layers && H % 4 != 0; ++i) {
         const std::string b = "encoder/layers/" + std::to_string(i) + "/attention/";
         const char* names[3] = {"q_proj", "k_proj", "v_proj"};
         const float* wj[3];
@@ -635,9 +647,7 @@ int w2v2_finalize(w2v2_model* m, void* stream) {
             wj[j] = m->P(b + names[j] + "/kernel");
             bj[j] = m->P(b + names[j] + "/bias");
         }
-        if (H % 4 == 0) {
-            if (int e = launch_qkv_pack(m->qkv_w[i], m->qkv_b[i], wj, bj, H, s)) return e;
-        } else {
+        {
             for (int j = 0; j < 3; ++j) {
                 W2V2_HIP_CHECK(hipMemcpy2DAsync(m->qkv_w[i] + j * H, (size_t)3 * H * sizeof(float), wj[j], (size_t)H * sizeof(float),
                                                 (size_t)H * sizeof(float), (size_t)H, hipMemcpyDeviceToDevice, s));
@@ -676,6 +686,7 @@ int w2v2_set_option(w2v2_model* m, int32_t option, int32_t value) {
         case W2V2_OPT_KEEP_ACTIVATIONS: m->opt_keep_acts = value != 0; return W2V2_OK;
         case W2V2_OPT_SPLIT_PLANES: m->opt_planes = value != 0; return W2V2_OK;
         case W2V2_OPT_WGRAD_STREAM: m->opt_wgrad_stream = value != 0; return W2V2_OK;
+        case W2V2_OPT_DEFER_FOLDS: m->opt_defer_folds = value != 0; return W2V2_OK;
         default: set_error("set_option: unknown option %d", option); return W2V2_EINVAL;
     }
 }
@@ -686,6 +697,7 @@ int w2v2_get_option(const w2v2_model* m, int32_t option) {
         case W2V2_OPT_KEEP_ACTIVATIONS: return m->opt_keep_acts ? 1 : 0;
         case W2V2_OPT_SPLIT_PLANES: return m->opt_planes ? 1 : 0;
         case W2V2_OPT_WGRAD_STREAM: return m->opt_wgrad_stream ? 1 : 0;
+        case W2V2_OPT_DEFER_FOLDS: return m->opt_defer_folds ? 1 : 0;
         default: return W2V2_EINVAL;
     }
 }

@@ -36,6 +36,8 @@ struct LayerSave {
 struct TrainState {
     int B = 0, T = 0;
     int64_t L = 0;
+    int lean = 0;                       // LEAN_* set the shape-dependent buffers were built with (ensure_train_ws)
+    int64_t alloc_bytes = 0;            // bytes behind `allocs`
     std::vector<void*> allocs;          // shape-dependent buffers: rebuilt when (B, L) changes
     std::vector<void*> persist;         // shape-independent buffers (gradients, Adam moments, transposed kernels, slab scratch):
                                         // allocated once -- their addresses key the bf16x3 plane cache (w2v2_model::w48)
@@ -91,12 +93,27 @@ struct TrainState {
     hipStream_t wg_stream = nullptr;
     hipEvent_t wg_fork = nullptr, wg_main = nullptr, wg_join[4] = {nullptr, nullptr, nullptr, nullptr};
     float* red_ws_side = nullptr;     // the side stream's own reduction scratch (red_ws belongs to the main stream's kernels)
+    // Deferred folds (train.h: FoldBatch): the partial rows of a layer's gradients live until the layer's one fold launch, so each
+    // deferred producer has its own scratch -- split-K slabs of the four weight gradients (0 = FFN down, 1 = FFN up, 2 = out-projection,
+    // 3 = q|k|v; 33 x the kernel's size each: ~0.9 GB for base, 1.7 GB for large) and the per-block column sums of LayerNorm 2 / the FFN
+    // dropout backward / LayerNorm 1 (site_ws).  The attention backward's column partials already have theirs (attn_colpart).
+    float* site_slabs[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* site_ws[3] = {nullptr, nullptr, nullptr};
+};
+
+// where a weight gradient puts its split-K slabs and who folds them
+struct WgSite {
+    float* slabs = nullptr;           // own slab scratch (TrainState::site_slabs[k]); null: the shared TrainState::slabs
+    FoldBatch* defer = nullptr;       // the slab fold joins this batch instead of running behind the GEMM
+    float* unpack3[3] = {nullptr, nullptr, nullptr};      // q|k|v: the fold writes the three (H, H) kernels straight from the packed (H, 3H) slabs
+    int unpackH = 0;
 };
 
 static int t_alloc(TrainState* t, float** out, int64_t floats) {
     void* p = nullptr;
     W2V2_HIP_CHECK(hipMalloc(&p, (size_t)(floats > 0 ? floats : 1) * sizeof(float)));
     t->allocs.push_back(p);
+    t->alloc_bytes += (floats > 0 ? floats : 1) * (int64_t)sizeof(float);
     *out = reinterpret_cast<float*>(p);
     return W2V2_OK;
 }
@@ -112,6 +129,7 @@ static int p_alloc(TrainState* t, float** out, int64_t floats) {
 static void t_free(TrainState* t) {
     for (void* p : t->allocs) (void)hipFree(p);
     t->allocs.clear();
+    t->alloc_bytes = 0;
 }
 
 void w2v2_train_destroy(w2v2_model* m) {
@@ -182,6 +200,11 @@ static int ensure_persistent(w2v2_model* m) {
         }
         t->slab_floats = 33 * (F * H > 3 * H * H ? F * H : 3 * H * H);      // 32 split-K slabs + the reduction scratch
         if (int e = p_alloc(t, &t->slabs, t->slab_floats)) return e;
+        {
+            const int64_t site_elems[4] = {F * H, H * F, H * H, 3 * H * H};
+            for (int k = 0; k < 4; ++k)
+                if (int e = p_alloc(t, &t->site_slabs[k], 33 * site_elems[k])) return e;
+        }
         t->cs_floats = 34 * (F > 3 * H ? F : 3 * H);
         if (int e = p_alloc(t, &t->cs_ws, t->cs_floats)) return e;
         if (int e = p_alloc(t, &t->dwqkv, 3 * H * H + 3 * H)) return e;
@@ -191,9 +214,14 @@ static int ensure_persistent(w2v2_model* m) {
     return W2V2_OK;
 }
 
-static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
+// `lean`: which per-layer fp32 activations the coming forward will NOT write (precision mode 1 on the shadow paths keeps q|k|v, the
+// attention output and the FFN hidden activation only as bf16, and u as bf16 in half of its buffer): they are not allocated -- 0.75 GB
+// per layer at 32 x 246000, 9 GB for base and 24 GB for large at 16 x 480000 (rounds 2-4 allocated them regardless).  A forward that
+// needs a different set (the precision or the shadow option changed on the same shapes) rebuilds the workspace.
+enum : int { LEAN_QKV = 1, LEAN_CTX = 2, LEAN_GD = 4, LEAN_U_HALF = 8 };
+static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T, int lean) {
     TrainState* t = get_state(m);
-    if (t->B == B && t->L == L && t->B > 0) return W2V2_OK;
+    if (t->B == B && t->L == L && t->B > 0 && t->lean == lean) return W2V2_OK;
     if (int e = ensure_persistent(m)) return e;
     const w2v2_config& c = m->cfg;
     const int64_t H = c.hidden_size, F = c.intermediate_size, BT = (int64_t)B * T;
@@ -214,13 +242,17 @@ static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
     if (int e = t_alloc(t, &sm, (BT + 15) / 4 + 4)) return e;
     t->spec_mask = reinterpret_cast<uint8_t*>(sm);
     for (auto& l : t->layers) {
-        if (int e = t_alloc(t, &l.qkv, BT * 3 * H)) return e;
-        if (int e = t_alloc(t, &l.ctx, BT * H)) return e;
+        l.qkv = l.ctx = l.gd = nullptr;
+        if (!(lean & LEAN_QKV))
+            if (int e = t_alloc(t, &l.qkv, BT * 3 * H)) return e;
+        if (!(lean & LEAN_CTX))
+            if (int e = t_alloc(t, &l.ctx, BT * H)) return e;
         if (int e = t_alloc(t, &l.lse, (int64_t)B * c.num_heads * T)) return e;
         if (int e = t_alloc(t, &l.t1, BT * H)) return e;
         if (int e = t_alloc(t, &l.t2, BT * H)) return e;
-        if (int e = t_alloc(t, &l.u, BT * F)) return e;
-        if (int e = t_alloc(t, &l.gd, BT * F)) return e;
+        if (int e = t_alloc(t, &l.u, (lean & LEAN_U_HALF) ? (BT * F + 1) / 2 + 4 : BT * F)) return e;
+        if (!(lean & LEAN_GD))
+            if (int e = t_alloc(t, &l.gd, BT * F)) return e;
         if (int e = t_alloc(t, &l.t3, BT * H)) return e;
         l.a = nullptr;
         if (c.attention_norm_type == 1)
@@ -255,6 +287,8 @@ static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
     if (lw > rw) rw = lw;
     if (int e = t_alloc(t, &t->red_ws, rw + 16)) return e;
     if (int e = t_alloc(t, &t->red_ws_side, rw + 16)) return e;
+    for (int k = 0; k < 3; ++k)
+        if (int e = t_alloc(t, &t->site_ws[k], rw + 16)) return e;
     if (int e = t_alloc(t, &t->dvec, (int64_t)B * c.num_heads * T)) return e;
     t->attn_colpart = nullptr;
     if (attention_bf16_supported((int)(H / c.num_heads)))
@@ -276,6 +310,7 @@ static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T) {
     t->B = B;
     t->L = L;
     t->T = T;
+    t->lean = lean;
     return W2V2_OK;
 }
 
@@ -337,10 +372,29 @@ static bool is_trainable(w2v2_model* m, const std::string& name) {
 // multiple of 64 can then take the 128 x 256 kernel's ragged form instead of the 128 x 128 kernel
 static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, int Kin, int Nout, float* dW,
                        float* db, hipStream_t s, const uint16_t* A16 = nullptr, const uint16_t* dY16 = nullptr, bool dy16_zero_row = false,
-                       float* red_ws = nullptr) {
+                       float* red_ws = nullptr, const WgSite* site = nullptr) {
     TrainState* t = m->train;
     if (!red_ws) red_ws = t->red_ws;       // (the side stream passes its own: TrainState::red_ws_side)
     bool fused_bias = false;
+    // slab scratch: the shared one, or this site's own (33 Kin Nout floats: S <= 32 slabs; the deferred fold needs no partial scratch
+    // behind them).  The slab-count rule below keeps using TrainState::slab_floats either way, so S does not depend on the site.
+    float* const slabs = (site && site->slabs) ? site->slabs : t->slabs;
+    FoldBatch* const defer = (site && site->slabs) ? site->defer : nullptr;
+    const bool unpack = site && site->unpackH > 0;
+    // dW = sum of `nrows` slabs: behind the GEMM, or as a job of the layer's fold launch.  (`unpack`: even a single slab goes through the
+    // fold, which scatters the packed matrix into the three kernels)
+    auto fold_slabs = [&](int nrows) -> int {
+        if (defer && (unpack ? defer->add_tall(slabs, nrows, (int64_t)Kin * Nout, site->unpack3[0], site->unpackH, site->unpack3[1], site->unpack3[2])
+                             : defer->add_tall(slabs, nrows, (int64_t)Kin * Nout, dW)))
+            return W2V2_OK;
+        if (unpack) {           // behind the GEMM, but still one launch for the sum and the scatter into the three kernels
+            FoldBatch one;
+            W2V2_REQUIRE(one.add_tall(slabs, nrows, (int64_t)Kin * Nout, site->unpack3[0], site->unpackH, site->unpack3[1], site->unpack3[2]),
+                         "weight_grad: the unpacking fold does not fit this shape");
+            return one.flush(s);
+        }
+        return launch_colsum(slabs, dW, nrows, Kin * Nout, slabs + (int64_t)nrows * Kin * Nout, 0, s);
+    };
     if (dW) {
         // dW (Kin, Nout) = A^T dY over the M = B T rows: few output tiles and a very long K, so the rows are cut into S slabs
         // (one GEMM batch each) that a column sum folds.  precision mode 1 stages A^T from X directly (the bf16 GEMM's B path
@@ -380,11 +434,11 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
                 GemmShadows x;
                 x.transA = true; x.A16 = A16; x.B16p = dY16; x.kextra = (int)(units_all % S);
                 if (M % kq != 0) { x.validK = M; x.b_zero_row = true; }
-                if (int e = launch_gemm_bf16_x(m->prof, nullptr, Kin, (int64_t)Kp * Kin, nullptr, Nout, (int64_t)Kp * Nout, S == 1 ? dW : t->slabs, Nout,
+                if (int e = launch_gemm_bf16_x(m->prof, nullptr, Kin, (int64_t)Kp * Kin, nullptr, Nout, (int64_t)Kp * Nout, (S == 1 && !unpack) ? dW : slabs, Nout,
                                                (int64_t)Kin * Nout, nullptr, nullptr, Kin, Nout, Kp, S, 0, x, s))
                     return e;
-                if (S > 1)
-                    if (int e = launch_colsum(t->slabs, dW, S, Kin * Nout, t->slabs + (int64_t)S * Kin * Nout, 0, s)) return e;
+                if (S > 1 || unpack)
+                    if (int e = fold_slabs(S)) return e;
                 if (db) {
                     W2V2_REQUIRE(dY, "weight_grad: the bias gradient needs the fp32 dY");
                     if (int e = launch_colsum(dY, db, M, Nout, red_ws, 0, s)) return e;
@@ -404,11 +458,11 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
             W2V2_REQUIRE(S == 1 || (int64_t)(S + 1) * Kin * Nout <= t->slab_floats, "weight_grad: slab scratch too small");
             GemmShadows x;
             x.transA = true; x.A16 = A16; x.B16p = dY16; x.validK = M;
-            if (int e = launch_gemm_bf16_x(m->prof, nullptr, Kin, (int64_t)Kp * Kin, nullptr, Nout, (int64_t)Kp * Nout, S == 1 ? dW : t->slabs, Nout,
+            if (int e = launch_gemm_bf16_x(m->prof, nullptr, Kin, (int64_t)Kp * Kin, nullptr, Nout, (int64_t)Kp * Nout, (S == 1 && !unpack) ? dW : slabs, Nout,
                                            (int64_t)Kin * Nout, nullptr, nullptr, Kin, Nout, Kp, S, 0, x, s))
                 return e;
-            if (S > 1)
-                if (int e = launch_colsum(t->slabs, dW, S, Kin * Nout, t->slabs + (int64_t)S * Kin * Nout, 0, s)) return e;
+            if (S > 1 || unpack)
+                if (int e = fold_slabs(S)) return e;
             if (db) {
                 W2V2_REQUIRE(dY, "weight_grad: the bias gradient needs the fp32 dY");
                 if (int e = launch_colsum(dY, db, M, Nout, red_ws, 0, s)) return e;
@@ -429,7 +483,7 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
         const int Mq = (int)(units * kq), R = M - Mq;
         const int nslabs = S + (R ? 1 : 0);
         W2V2_REQUIRE(nslabs == 1 || (int64_t)(nslabs + 1) * Kin * Nout <= t->slab_floats, "weight_grad: slab scratch too small");
-        float* dst = nslabs == 1 ? dW : t->slabs;
+        float* dst = (nslabs == 1 && !unpack) ? dW : slabs;
         const int Kp = S ? Mq / S : 0;
         if (S) {
             if (direct) {
@@ -461,8 +515,8 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
                 return e;
         }
         // sum the slabs (rows = nslabs, cols = Kin * Nout); the one-chunk partial scratch lives behind the slabs
-        if (nslabs > 1)
-            if (int e = launch_colsum(t->slabs, dW, nslabs, Kin * Nout, t->slabs + (int64_t)nslabs * Kin * Nout, 0, s)) return e;
+        if (nslabs > 1 || unpack)
+            if (int e = fold_slabs(nslabs)) return e;
         if (fused_bias) {
             // per-slab column sums of dY are in cs_ws (S, Nout); the leftover rows add one more row, then one small fold
             if (R)
@@ -530,11 +584,33 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (int e = w2v2_ensure_workspace(m, B, L)) return e;
     const int T = (int)Tll;
-    if (int e = ensure_train_ws(m, B, L, T)) return e;
-    TrainState* t = m->train;
-    Profiler* pf = m->prof;
     const int H = c.hidden_size, F = c.intermediate_size;
     const int64_t BT = (int64_t)B * T;
+    // Precision mode 1: the same bf16 shadows as the inference forward (w2v2_api.hip).  Every producer of a forward GEMM
+    // operand -- conv0, GEMM epilogues, LayerNorm, dropout, attention -- also writes the nearest-even bf16 copy, so the
+    // forward GEMMs stream 2-byte operands by LDS-DMA instead of converting fp32 in registers.  The shadow buffers are
+    // transient scratch (the backward works from the saved fp32 activations); results are bit-identical either way.
+    const bool sh = m->precision == 1 && w2v2_shadows_enabled(m);
+    if (sh)       // (also refreshes the bf16 weight shadows after an optimizer step: m->w16_valid, which the decisions below read)
+        if (int e = w2v2_ensure_shadows(m, B, T, s)) return e;
+    const bool attn16 = sh && attention_bf16_supported(H / c.num_heads);
+    // FFN hidden activations as bf16 only: needs the shadow paths on both sides (forward GEMM by LDS-DMA, weight gradient in
+    // the transposing-read form, whole 128-tiles) and the plain bf16 copies of the FFN kernels for the data gradients
+    const bool ffn16_only = sh && m->w16_valid && F % 128 == 0 && H % 128 == 0 && (BT * F) % 4 == 0 && !m->w16p.empty();
+    // Precision mode 1 keeps the FFN pre-activation u = t2 W1 + b1 as bf16 (what a mixed_bfloat16 Dense hands to its activation): on
+    // the shadow path the up-projection writes ONLY the bf16 copy (its bf16 epilogue; 302 MB of fp32 stores per layer gone at B = 32)
+    // and GELU + dropout, GELU' in the backward read that; the shadow-free path of the mode rounds the fp32 u on the way into the
+    // same kernels, so both paths agree bit for bit.
+    const bool u16_only = ffn16_only && tune_int("W2V2_U16", 1) != 0;
+    // The attention output O: its readers are the out-projection GEMM and that GEMM's weight gradient (both stream the bf16 shadow)
+    // and D = rowsum(dO o O) of the attention backward, which is defined on the bf16 values -- no fp32 copy is written.
+    const bool ctx16_only = ffn16_only && attn16 && tune_int("W2V2_CTX16", 1) != 0;
+    // (tools-only build: W2V2_LEAN_WS = 0 allocates everything, as rounds 2-4 did, for A/B runs)
+    const int lean = tune_int("W2V2_LEAN_WS", 1) == 0 ? 0
+                     : (attn16 ? LEAN_QKV : 0) | (ctx16_only ? LEAN_CTX : 0) | (ffn16_only ? LEAN_GD : 0) | (u16_only ? LEAN_U_HALF : 0);
+    if (int e = ensure_train_ws(m, B, L, T, lean)) return e;
+    TrainState* t = m->train;
+    Profiler* pf = m->prof;
     const int act = c.is_gelu_approx ? 2 : 1;
     // element-wise kernels in precision mode 1 evaluate exact GELU / GELU' through the 5-term erf the bf16 GEMM epilogue uses (act 3)
     const int act_ew = (act == 1 && m->precision == 1) ? 3 : act;
@@ -544,14 +620,6 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
     t->seed = seed;
     auto fe = [&](int i, const char* leaf) { return m->P("feature_extractor/conv_layers/" + std::to_string(i) + leaf); };
 
-    // Precision mode 1: the same bf16 shadows as the inference forward (w2v2_api.hip).  Every producer of a forward GEMM
-    // operand -- conv0, GEMM epilogues, LayerNorm, dropout, attention -- also writes the nearest-even bf16 copy, so the
-    // forward GEMMs stream 2-byte operands by LDS-DMA instead of converting fp32 in registers.  The shadow buffers are
-    // transient scratch (the backward works from the saved fp32 activations); results are bit-identical either way.
-    const bool sh = m->precision == 1 && w2v2_shadows_enabled(m);
-    if (sh)
-        if (int e = w2v2_ensure_shadows(m, B, T, s)) return e;
-    const bool attn16 = sh && attention_bf16_supported(H / c.num_heads);
     auto gemm = [&](const float* A, const uint16_t* A16, int64_t lda, int64_t strideA, const float* Bw, int64_t ldb, float* Cc,
                     uint16_t* C16, int64_t ldc, int64_t strideC, const float* bias, const float* res, int M, int N, int K,
                     int nbatch, int act_) -> int {
@@ -641,21 +709,10 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
         // postnorm: layer 0's q|k|v GEMM reads this tensor -> shadow
         if (int e = launch_dropout_fwd_x(pre, nullptr, h0, (sh && !prenorm) ? m->hs16[0] : nullptr, BT * H, 0, p, seed, DS_ENCODER_IN, s)) return e;
     }
-    // FFN hidden activations as bf16 only: needs the shadow paths on both sides (forward GEMM by LDS-DMA, weight gradient in
-    // the transposing-read form, whole 128-tiles) and the plain bf16 copies of the FFN kernels for the data gradients
-    const bool ffn16_only = sh && m->w16_valid && F % 128 == 0 && H % 128 == 0 && (BT * F) % 4 == 0 && !m->w16p.empty();
-    t->ffn16_only = ffn16_only;
-    // Precision mode 1 keeps the FFN pre-activation u = t2 W1 + b1 as bf16 (what a mixed_bfloat16 Dense hands to its activation): on
-    // the shadow path the up-projection writes ONLY the bf16 copy (its bf16 epilogue; 302 MB of fp32 stores per layer gone at B = 32)
-    // and GELU + dropout, GELU' in the backward read that; the shadow-free path of the mode rounds the fp32 u on the way into the
-    // same kernels, so both paths agree bit for bit.
-    const bool u16_only = ffn16_only && tune_int("W2V2_U16", 1) != 0;
+    t->ffn16_only = ffn16_only;       // (decided in front of the workspace, which leaves out the fp32 buffers these modes never write)
     t->u16_only = u16_only;
-    const int u_round = m->precision == 1 ? 1 : 0;
-    // The attention output O: its readers are the out-projection GEMM and that GEMM's weight gradient (both stream the bf16 shadow)
-    // and D = rowsum(dO o O) of the attention backward, which is defined on the bf16 values -- no fp32 copy is written.
-    const bool ctx16_only = ffn16_only && attn16 && tune_int("W2V2_CTX16", 1) != 0;
     t->ctx16_only = ctx16_only;
+    const int u_round = m->precision == 1 ? 1 : 0;
     for (int i = 0; i < c.num_layers; ++i) {
         const std::string b = "encoder/layers/" + std::to_string(i);
         LayerSave& l = t->layers[i];
@@ -822,12 +879,17 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     // With the shadows on, the weight-gradient GEMMs take the LDS-DMA / transposing-read kernel, which has no fp32 dY in
     // registers to sum for the bias gradient: the PRODUCER of each dY leaves its column sums instead (dropout backward,
     // LayerNorm backward), and weight_grad is called without a bias target.  `bias_from_producer` says that happened.
+    // Deferred folds of the encoder layers (train.h: FoldBatch; W2V2_OPT_DEFER_FOLDS): `fb` is set below, once the side-stream decision is known
+    FoldBatch fold;
+    FoldBatch* fb = nullptr;
     auto dropout_bwd_bias = [&](const float* u, const float* dy, float* dx, uint16_t* dx16, int64_t rows, int cols, int act_, uint32_t stream_id,
-                                float* bias_grad, bool* bias_done, const EwBf16& in = EwBf16{}) -> int {
+                                float* bias_grad, bool* bias_done, const EwBf16& in = EwBf16{}, bool deferrable = false) -> int {
         *bias_done = false;
         if (shb && bias_grad) {
             *bias_done = true;
-            return launch_dropout_bwd_colsum(u, dy, dx, dx16, bias_grad, rows, cols, act_, p, seed, stream_id, t->red_ws, s, in);
+            const bool d = deferrable && fb;        // (the FFN site: its partial rows live in site_ws[1] until the layer's fold launch)
+            return launch_dropout_bwd_colsum(u, dy, dx, dx16, bias_grad, rows, cols, act_, p, seed, stream_id, d ? t->site_ws[1] : t->red_ws, s, in,
+                                             d ? fb : nullptr);
         }
         return launch_dropout_bwd_x(u, dy, dx, dx16, rows * cols, act_, p, seed, stream_id, s, in);
     };
@@ -852,6 +914,18 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         W2V2_HIP_CHECK(hipEventCreateWithFlags(&t->wg_main, hipEventDisableTiming));
         for (int k = 0; k < 4; ++k) W2V2_HIP_CHECK(hipEventCreateWithFlags(&t->wg_join[k], hipEventDisableTiming));
     }
+    // (the side stream keeps the folds behind their GEMMs: its weight gradients run ahead of / behind the main stream's position)
+    // (tools-only build: W2V2_DEFER_FOLDS = 0 none, 1 the column-sum folds only -- slab sums behind their GEMMs --, 2 everything.
+    //  One box, arms interleaved, profiles/r05_ab_defer_folds.txt: base step 33.80 / 33.55 / 33.50 ms, large-robust 98.38 / 97.94 / 97.74)
+    const int defer_mode = (!side_on && m->opt_defer_folds) ? tune_int("W2V2_DEFER_FOLDS", 2) : 0;
+    if (defer_mode != 0) fb = &fold;
+    auto wg_site = [&](int k) {
+        WgSite w;
+        if (defer_mode == 2) { w.slabs = t->site_slabs[k]; w.defer = fb; }
+        return w;
+    };
+    float* const ln2_ws = fb ? t->site_ws[0] : t->red_ws;
+    float* const ln1_ws = fb ? t->site_ws[2] : t->red_ws;
     bool wg_pending[4] = {false, false, false, false};
     bool wg_used = false;
     // side(site, f): run f(stream, reduction scratch) -- a weight gradient -- behind everything the main stream has enqueued so far
@@ -920,21 +994,34 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         // packed q|k|v projection: dW (H, 3H) -> the three (H, H) kernels, db (3H) -> the three biases
         float* dWqkv = t->dwqkv;
         float* dbqkv = dWqkv + (int64_t)3 * H * H;
+        const char* names[3] = {"q_proj", "k_proj", "v_proj"};
+        float* gw3[3];
+        float* gb3[3];
+        bool all6 = true;
+        for (int j = 0; j < 3; ++j) {
+            gw3[j] = G(b + "/attention/" + names[j] + "/kernel");
+            gb3[j] = G(b + "/attention/" + names[j] + "/bias");
+            all6 = all6 && gw3[j] && gb3[j];
+        }
+        if (fb && only16 && all6 && H % 4 == 0 && fold.tab.n + 2 <= FOLD_MAX_JOBS) {
+            // deferred: the layer's fold launch sums the (H, 3H) slabs straight into the three (H, H) kernels and the attention backward's
+            // column partials into the three biases (group g of the wide job = columns [g H, (g + 1) H) of the 3H-wide partial rows)
+            WgSite site = wg_site(3);
+            site.unpackH = H;
+            for (int j = 0; j < 3; ++j) site.unpack3[j] = gw3[j];
+            if (int e = weight_grad(m, attn_in, nullptr, (int)BT, H, 3 * H, dWqkv, nullptr, s, (xs && s16q) ? attn_in16 : nullptr, s16q, s16q != nullptr,
+                                    rws, &site))
+                return e;
+            W2V2_REQUIRE(fb->add_wide(t->attn_colpart, attention_colpart_rows(B, T), H, (int64_t)3 * H, 3, gb3[0], gb3[1], gb3[2]),
+                         "train_backward: fold table full");
+            return W2V2_OK;
+        }
         if (int e = weight_grad(m, attn_in, only16 ? nullptr : t->g3h, (int)BT, H, 3 * H, dWqkv, only16 ? nullptr : dbqkv, s,
                                 (xs && s16q) ? attn_in16 : nullptr, s16q, s16q != nullptr, rws))
             return e;
         if (only16)
             if (int e = launch_colsum_fold(t->attn_colpart, dbqkv, attention_colpart_rows(B, T), 3 * H, s)) return e;
-        const char* names[3] = {"q_proj", "k_proj", "v_proj"};
-        if (H % 4 == 0) {
-            float* gw3[3];
-            float* gb3[3];
-            for (int j = 0; j < 3; ++j) {
-                gw3[j] = G(b + "/attention/" + names[j] + "/kernel");
-                gb3[j] = G(b + "/attention/" + names[j] + "/bias");
-            }
-            return launch_qkv_unpack(dWqkv, dbqkv, gw3, gb3, H, s);
-        }
+        if (H % 4 == 0) return launch_qkv_unpack(dWqkv, dbqkv, gw3, gb3, H, s);
         for (int j = 0; j < 3; ++j) {
             float* gw = G(b + "/attention/" + names[j] + "/kernel");
             float* gb = G(b + "/attention/" + names[j] + "/bias");
@@ -961,10 +1048,10 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
             W2V2_REQUIRE(s16f && dx_shadowed(W2), "train_backward: the forward kept u as bf16 only, which needs the shadow path for the down-projection's data gradient");
             if (int e = gemm_dx(dy, dy16, H, l.W2T, W2, nullptr, F, nullptr, (int)BT, F, H, s, s16f)) return e;
             in.a16 = reinterpret_cast<const uint16_t*>(l.u); in.b16 = s16f;
-            return dropout_bwd_bias(nullptr, nullptr, du16_only ? nullptr : t->gf, s16f, BT, F, act_ew, layer_stream(i, 2), gb1, b1_done, in);
+            return dropout_bwd_bias(nullptr, nullptr, du16_only ? nullptr : t->gf, s16f, BT, F, act_ew, layer_stream(i, 2), gb1, b1_done, in, true);
         }
         if (int e = gemm_dx(dy, dy16, H, l.W2T, W2, t->gf, F, nullptr, (int)BT, F, H, s)) return e;
-        return dropout_bwd_bias(l.u, t->gf, du16_only ? nullptr : t->gf, s16f, BT, F, act_ew, layer_stream(i, 2), gb1, b1_done, in);
+        return dropout_bwd_bias(l.u, t->gf, du16_only ? nullptr : t->gf, s16f, BT, F, act_ew, layer_stream(i, 2), gb1, b1_done, in, true);
     };
     const bool fuse_do_tail = !tune_int("W2V2_NO_DO_TAIL", 0);
     bool dh16_valid = false;
@@ -977,6 +1064,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         // prenorm layer (encoder.py:111-134):  t1 = x + drop(attn(LN1(x)));  out = t1 + keep * FFN(LN2(t1))
         const std::string b = "encoder/layers/" + std::to_string(i);
         LayerSave& l = t->layers[i];
+        const WgSite ws0 = wg_site(0), ws1 = wg_site(1), ws2 = wg_site(2);
         const float* x = i == 0 ? t->hs0 : m->hs[i];
         float* dt1 = tmp3;
         // dh's bf16 shadow (written by the previous iteration's closing axpby into s16h, which is free again by then)
@@ -992,7 +1080,8 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
             W2V2_REQUIRE(!f16 || dh16, "train_backward: no bf16 shadow of the layer's output gradient");
             if (int e = side(0, [&](hipStream_t st, float* rws) {
                     return weight_grad(m, f16 ? nullptr : l.gd, dh, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
-                                       G(b + "/feed_forward/output_dense/bias"), st, (xs && dh16) ? l.gd16 : nullptr, dh16, dh16 != nullptr && dh16 == s16h, rws);
+                                       G(b + "/feed_forward/output_dense/bias"), st, (xs && dh16) ? l.gd16 : nullptr, dh16, dh16 != nullptr && dh16 == s16h, rws,
+                                       &ws0);
                 }))
                 return e;
             bool b1_done = false;
@@ -1004,7 +1093,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
             if (int e = ffn_hidden_grad(i, l, b, dh, dh16, du16_only, gb1, &b1_done)) return e;
             if (int e = side(1, [&](hipStream_t st, float* rws) {
                     return weight_grad(m, l.t2, du, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
-                                       b1_done ? nullptr : gb1, st, xs ? l.t2_16 : nullptr, s16f, s16f != nullptr, rws);
+                                       b1_done ? nullptr : gb1, st, xs ? l.t2_16 : nullptr, s16f, s16f != nullptr, rws, &ws1);
                 }))
                 return e;
             if (int e = gemm_dx(du, s16f, F, l.W1T, m->P(b + "/feed_forward/intermediate_dense/kernel"), tmp, H, nullptr, (int)BT, H, F, s)) return e;
@@ -1014,8 +1103,8 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
             // dh16 in s16h is dead by now -- once the down-projection's weight gradient has read it)
             if (int e = side_wait(0)) return e;
             if (int e = launch_ln_bwd_x(l.t1, m->P(b + "/final_layer_norm/gamma"), tmp, dt1, do_tail ? s16h : nullptr, dg2 ? dg2 : t->dummy,
-                                        db2 ? db2 : t->dummy + H, BT, H, eps, t->red_ws, s, do_tail ? (gbo ? gbo : t->dummy + 2 * H) : nullptr, dh,
-                                        do_tail ? &do_drop : nullptr))
+                                        db2 ? db2 : t->dummy + H, BT, H, eps, ln2_ws, s, do_tail ? (gbo ? gbo : t->dummy + 2 * H) : nullptr, dh,
+                                        do_tail ? &do_drop : nullptr, fb))
                 return e;
             bo_done = do_tail && gbo;
         } else {
@@ -1036,7 +1125,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         const bool q16 = dqkv16_only(i, l.a16);
         auto out_weight_grad = [&](hipStream_t st, float* rws) {
             return weight_grad(m, t->ctx16_only ? nullptr : l.ctx, do16_only ? nullptr : d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), bo_done ? nullptr : gbo, st,
-                               (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h, s16h != nullptr, rws);
+                               (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h, s16h != nullptr, rws, &ws2);
         };
         // (side stream: the out-projection's weight gradient goes out BEFORE the attention backward, to run under it)
         if (side_on)
@@ -1060,14 +1149,16 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         if (int e = side_wait(2)) return e;                  // (d_o's shadow in s16h: the out-projection's weight gradient)
         if (int e = side_wait(0)) return e;                  // (dh in fp32, when the down-projection's weight gradient read that)
         if (int e = launch_ln_bwd_x(x, m->P(b + "/layer_norm/gamma"), tmp, dh, dh16_valid ? s16h : nullptr, dg1 ? dg1 : t->dummy,
-                                    db1 ? db1 : t->dummy + H, BT, H, eps, t->red_ws, s, nullptr, dt1))
+                                    db1 ? db1 : t->dummy + H, BT, H, eps, ln1_ws, s, nullptr, dt1, nullptr, fb))
             return e;
+        if (int e = fold.flush(s)) return e;                 // (the layer's deferred folds: its gradients are final behind this launch)
         if (int e = bucket_done(c.num_layers - i)) return e;
     }
 
     for (int i = c.num_layers - 1; i >= 0 && !prenorm; --i) {
         const std::string b = "encoder/layers/" + std::to_string(i);
         LayerSave& l = t->layers[i];
+        const WgSite ws0 = wg_site(0), ws1 = wg_site(1), ws2 = wg_site(2);
         // hs[i+1] = LN(t3)
         float* dt3 = tmp;
         float* dg2 = G(b + "/final_layer_norm/gamma");
@@ -1076,7 +1167,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         float* const gb2 = (shb && l.keep != 0.f) ? G(b + "/feed_forward/output_dense/bias") : nullptr;
         if (int e = side_wait(2)) return e;                  // (tmp / s16h still hold the d_o the layer above's out-projection weight gradient reads)
         if (int e = launch_ln_bwd_x(l.t3, m->P(b + "/final_layer_norm/gamma"), dh, dt3, (l.keep != 0.f && H % 4 == 0) ? s16h : nullptr,
-                                    dg2 ? dg2 : t->dummy, db2 ? db2 : t->dummy + H, BT, H, eps, t->red_ws, s, gb2))
+                                    dg2 ? dg2 : t->dummy, db2 ? db2 : t->dummy + H, BT, H, eps, ln2_ws, s, gb2, nullptr, nullptr, fb))
             return e;
         float* dt2 = tmp2;
         if (l.keep != 0.f) {
@@ -1084,7 +1175,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
             if (int e = side(0, [&](hipStream_t st, float* rws) {
                     return weight_grad(m, f16 ? nullptr : l.gd, dt3, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
                                        gb2 ? nullptr : G(b + "/feed_forward/output_dense/bias"), st, xs ? l.gd16 : nullptr, H % 4 == 0 ? s16h : nullptr,
-                                       s16h != nullptr, rws);
+                                       s16h != nullptr, rws, &ws0);
                 }))
                 return e;
             // du = dgd * keep/(1-p) * GELU'(u)   (+ its column sums = the up-projection's bias gradient)
@@ -1097,7 +1188,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
             if (int e = ffn_hidden_grad(i, l, b, dt3, H % 4 == 0 ? s16h : nullptr, du16_only, gb1, &b1_done)) return e;
             if (int e = side(1, [&](hipStream_t st, float* rws) {
                     return weight_grad(m, l.t2, du, (int)BT, H, F, G(b + "/feed_forward/intermediate_dense/kernel"),
-                                       b1_done ? nullptr : gb1, st, xs ? l.t2_16 : nullptr, s16f, s16f != nullptr, rws);
+                                       b1_done ? nullptr : gb1, st, xs ? l.t2_16 : nullptr, s16f, s16f != nullptr, rws, &ws1);
                 }))
                 return e;
             // dt2 = du W1^T + dt3 (the residual branch)
@@ -1120,8 +1211,8 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         const LnDropTail do_drop{p, seed, layer_stream(i, 1)};
         if (int e = side_wait(0)) return e;                  // (dt3 in tmp / s16h: the down-projection's weight gradient; d_o goes there next)
         if (int e = launch_ln_bwd_x(l.t1, m->P(b + "/layer_norm/gamma"), dt2, dt1, do_tail ? s16h : nullptr, dg1 ? dg1 : t->dummy,
-                                    db1 ? db1 : t->dummy + H, BT, H, eps, t->red_ws, s, do_tail ? (gbo ? gbo : t->dummy + 2 * H) : nullptr, nullptr,
-                                    do_tail ? &do_drop : nullptr))
+                                    db1 ? db1 : t->dummy + H, BT, H, eps, ln1_ws, s, do_tail ? (gbo ? gbo : t->dummy + 2 * H) : nullptr, nullptr,
+                                    do_tail ? &do_drop : nullptr, fb))
             return e;
         bo_done = do_tail && gbo;
         if (!do_tail)
@@ -1137,7 +1228,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         const bool q16 = dqkv16_only(i, hs16_i);
         auto out_weight_grad = [&](hipStream_t st, float* rws) {
             return weight_grad(m, t->ctx16_only ? nullptr : l.ctx, do16_only ? nullptr : d_o, (int)BT, H, H, G(b + "/attention/out_proj/kernel"), bo_done ? nullptr : gbo, st,
-                               (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h, s16h != nullptr, rws);
+                               (xs && t->x16_attn) ? l.ctx16 : nullptr, s16h, s16h != nullptr, rws, &ws2);
         };
         // (side stream: the out-projection's weight gradient goes out BEFORE the attention backward, to run under it)
         if (side_on)
@@ -1151,6 +1242,7 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         if (int e = side(3, [&](hipStream_t st, float* rws) { return qkv_weight_grad(b, m->hs[i], hs16_i, q16, st, rws); })) return e;
         // dx = dqkv Wqkv^T + dt1 (residual)
         if (int e = gemm_dx(q16 ? nullptr : t->g3h, s16q, 3 * H, l.WqkvT, m->qkv_w[i], dh, H, dt1, (int)BT, H, 3 * H, s)) return e;
+        if (int e = fold.flush(s)) return e;                 // (the layer's deferred folds: its gradients are final behind this launch)
         if (int e = bucket_done(c.num_layers - i)) return e;
     }
     // (the scratch the layers' gradients flowed through is reused from here on, and the last weight gradient below shares the slabs)
@@ -1253,6 +1345,17 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
 /* Gradient buckets: slices of the flat buffer in the order the backward completes them.  Data-parallel callers enqueue
  * one all-reduce per bucket on a communication stream that waits (w2v2_train_bucket_wait) for that bucket only, so the
  * collectives of the upper layers run under the backward of the lower ones. */
+int w2v2_train_storage(const w2v2_model* m, int32_t* mask, int64_t* workspace_bytes) {
+    W2V2_REQUIRE(m && mask && workspace_bytes, "train_storage: null argument");
+    const TrainState* t = m->train;
+    *mask = 0;
+    *workspace_bytes = t ? t->alloc_bytes : 0;
+    if (t && t->B > 0)
+        *mask = (t->x16_attn ? W2V2_TRAIN_BF16_QKV : 0) | (t->ctx16_only ? W2V2_TRAIN_BF16_CTX : 0) | (t->ffn16_only ? W2V2_TRAIN_BF16_FFN : 0) |
+                (t->u16_only ? W2V2_TRAIN_BF16_U : 0);
+    return W2V2_OK;
+}
+
 int w2v2_train_num_buckets(const w2v2_model* m) { return m ? m->cfg.num_layers + 2 : W2V2_EINVAL; }
 
 int w2v2_train_bucket(w2v2_model* m, int32_t k, int64_t* offset, int64_t* numel) {

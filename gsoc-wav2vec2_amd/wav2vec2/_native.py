@@ -76,6 +76,7 @@ PROTOTYPES = {
     "w2v2_train_bucket_wait": (C.c_int, [_P, _I32, _P]),
     "w2v2_grad_slot": (C.c_int, [_P, C.c_char_p, C.POINTER(_I64), C.POINTER(_I64)]),
     "w2v2_get_grad": (C.c_int, [_P, C.c_char_p, _P, _I64, _P]),
+    "w2v2_train_storage": (C.c_int, [_P, C.POINTER(_I32), C.POINTER(_I64)]),
     "w2v2_adam_step": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, _I64, _P]),
     "w2v2_ln_bwd_ws_floats": (_I64, [_I64, _I32]),
     "w2v2_op_layer_norm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I32, C.c_float, _P, _P]),

@@ -344,7 +344,7 @@ class TFKerasModel(Layer):
             raise ValueError(f"precision must be one of {sorted(set(self.PRECISIONS))}, got {precision!r}")
         N.check(self._lib.w2v2_set_precision(self._handle, self.PRECISIONS[precision]), "w2v2_set_precision")
 
-    OPTIONS = {"bf16_shadows": 0, "keep_activations": 1, "split_planes": 2, "wgrad_stream": 3}      # W2V2_OPT_* of include/w2v2.h
+    OPTIONS = {"bf16_shadows": 0, "keep_activations": 1, "split_planes": 2, "wgrad_stream": 3, "defer_folds": 4}      # W2V2_OPT_* of include/w2v2.h
 
     def set_option(self, name, value):
         """Per-model switches of the bf16 precision mode (include/w2v2.h: w2v2_set_option): "bf16_shadows" (default on; off =
@@ -352,7 +352,9 @@ class TFKerasModel(Layer):
         that are normally written only as bf16 -- or, in "bf16x3" / "f16x2", only as operand planes -- keep their fp32 copy so
         `activation(name)` can tap them); "wgrad_stream" (default off; bf16 training backward: the layers' weight-gradient GEMMs run on a second HIP stream
         of the model, same bits); "split_planes" (default on; off = the "bf16x3" / "f16x2" forward GEMMs split fp32 rows
-        in registers instead of streaming planes written by their producers: the round-4 path, for A/B measurements)."""
+        in registers instead of streaming planes written by their producers: the round-4 path, for A/B measurements);
+        "defer_folds" (default on; training backward: the nine small reductions that finish an encoder layer's gradients run as one
+        launch in front of the layer's bucket event; off = one launch behind each producer, same bits)."""
         if name not in self.OPTIONS:
             raise KeyError(f"unknown option {name!r}; one of {sorted(self.OPTIONS)}")
         N.check(self._lib.w2v2_set_option(self._handle, self.OPTIONS[name], int(bool(value))), "w2v2_set_option")

@@ -157,11 +157,17 @@ int w2v2_get_precision(const w2v2_model* m);
  *                                          events only (w2v2_train_backward returns with the caller's stream waiting for all of it;
  *                                          bucket events then come from that stream).  Same results bit for bit; measured neutral
  *                                          on one GPU, hence off.
+ *   W2V2_OPT_DEFER_FOLDS (default 1)       training backward: the small reductions that finish an encoder layer's gradients (split-K
+ *                                          slab sums of the four weight gradients, the q|k|v unpack, the LayerNorm / dropout /
+ *                                          attention column-sum folds: nine launches per layer) run as ONE launch in front of the
+ *                                          layer's bucket event.  Same summation order, same bits; 0 = one launch behind each
+ *                                          producer (the round-4 behaviour, kept for the bit-identity test and A/B timing).
  * w2v2_get_option returns the value, or W2V2_EINVAL for an unknown option. */
 #define W2V2_OPT_BF16_SHADOWS 0
 #define W2V2_OPT_KEEP_ACTIVATIONS 1
 #define W2V2_OPT_SPLIT_PLANES 2
 #define W2V2_OPT_WGRAD_STREAM 3
+#define W2V2_OPT_DEFER_FOLDS 4
 int w2v2_set_option(w2v2_model* m, int32_t option, int32_t value);
 int w2v2_get_option(const w2v2_model* m, int32_t option);
 /* W2V2_PRECISION_F16X2: *flag = 1 if a forward since the last call met an activation outside fp16's range after scaling
@@ -250,6 +256,15 @@ int w2v2_adam_buffers(w2v2_model* m, float** m_dev, float** v_dev, int64_t* nume
  * (a new Trainer, or a checkpoint without moments) calls this. */
 int w2v2_adam_reset(w2v2_model* m, void* stream);
 int w2v2_get_grad(w2v2_model* m, const char* name, float* host_dst, int64_t numel, void* stream);
+/* Which per-layer activations the LAST training forward kept only as bf16 (precision mode BF16 on the shadow paths; their fp32 buffers
+ * are then not allocated at all), and the bytes of shape-dependent training workspace currently allocated.  Introspection for the tests:
+ * a step that silently fell back to the fp32 activations (twice the element-wise traffic) must not pass unnoticed.
+ *   *mask: bit 0 = q|k|v, bit 1 = attention output, bit 2 = FFN hidden activation, bit 3 = FFN pre-activation u (bf16 in half a buffer) */
+#define W2V2_TRAIN_BF16_QKV 1
+#define W2V2_TRAIN_BF16_CTX 2
+#define W2V2_TRAIN_BF16_FFN 4
+#define W2V2_TRAIN_BF16_U 8
+int w2v2_train_storage(const w2v2_model* m, int32_t* mask, int64_t* workspace_bytes);
 int w2v2_adam_step(w2v2_model* m, float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
 
 /* ---- introspection (parity tests, profiling) -----------------------------

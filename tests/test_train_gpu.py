@@ -378,6 +378,79 @@ def test_weight_gradient_side_stream_is_bit_identical(env, case, L, B):
     m.set_option("wgrad_stream", False)
 
 
+@pytest.mark.gpu
+def test_bf16_step_keeps_the_bf16_only_activation_path_after_an_optimizer_step(env):
+    """The bf16 fine-tune step keeps q|k|v, the attention output, the FFN hidden activation and its pre-activation only as bf16 and does
+    not even allocate their fp32 buffers (w2v2_train_storage).  That decision reads the bf16 weight shadows' validity, which every
+    optimizer step resets -- so it must be taken AFTER the forward has refreshed them: a step that silently fell back to the fp32
+    activations is numerically fine and twice as slow in the element-wise kernels (this happened once: caught by the bench, not by a test).
+    Also: the workspace really shrinks, and a precision switch on the same shapes rebuilds it."""
+    import wav2vec2
+    _, torch, dev = env
+    B, L = 2, 61520
+    m, cfg, w = build("base_sample_padded", L)
+    x = V.hash_normal("train/wave_lean", B * L, 8).reshape(B, L)
+    labels = np.tile(np.array([[5, 9, 9, 11, 0, 0]], np.int32), (B, 1))
+    m.set_precision("bf16")
+    m.freeze_feature_extractor()
+    tr = wav2vec2.Trainer(m, wav2vec2.CTCLoss(cfg, x.shape, division_factor=B), dropout=0.1, seed=1)
+    for _ in range(3):                       # the 2nd and 3rd forward follow an optimizer step
+        assert np.isfinite(float(tr.step(x, labels)))
+        names, lean_bytes = tr.activation_storage()
+        assert names == {"qkv", "ctx", "ffn", "u"}, names
+    m.set_precision("fp32")
+    assert np.isfinite(float(tr.step(x, labels)))
+    names, full_bytes = tr.activation_storage()
+    assert names == set(), names
+    T, H, F, N = cfg.num_frames(L), cfg.hidden_size, cfg.intermediate_size, cfg.num_layers
+    saved = N * B * T * (3 * H + H + F + F // 2) * 4          # q|k|v, ctx, gd and half of u per layer, fp32
+    # (the bf16 step also owns ~40 MB of positional-conv kernel-gradient scratch the fp32 step does not allocate: hence 0.6, not 1.0)
+    assert full_bytes - lean_bytes >= 0.6 * saved, (full_bytes, lean_bytes, saved)
+    m.set_precision("bf16")
+    assert np.isfinite(float(tr.step(x, labels)))
+    assert tr.activation_storage()[0] == {"qkv", "ctx", "ffn", "u"}
+    m.set_precision("fp32")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("case,L,B", [("base_sample_padded", 61520, 2), ("tiny_robust", 4000, 2), ("base_sample_padded", 24080, 3)])
+def test_deferred_folds_do_not_change_results(env, case, L, B, precision):
+    """Model option "defer_folds" (W2V2_OPT_DEFER_FOLDS, default on): the nine small reductions that finish an encoder layer's gradients
+    (split-K slab sums of the four weight gradients with the q|k|v unpack, LayerNorm / dropout / attention column-sum folds) run as ONE
+    launch over a job table in front of the layer's bucket event.  Each job keeps the summation order of the kernel it replaces, so the
+    WHOLE flat gradient buffer must be bit-identical to the one-launch-per-producer backward -- postnorm (base) and prenorm (robust)
+    loops, whole and ragged row counts (B T = 3 x 75 = 225), both precisions, three passes in a row (a partial buffer recycled before
+    its fold ran would show up as a changed gradient), and with a stochastic-depth drop of one layer (fewer jobs in that layer's table)."""
+    import wav2vec2
+    _, torch, dev = env
+    labels = np.tile(np.array([[5, 9, 9, 11, 0, 0]], np.int32), (B, 1))
+    x = V.hash_normal("train/wave_fold", B * L, 8).reshape(B, L)
+    m, cfg, w = build(case, L)
+    m.set_precision(precision)
+    assert m.get_option("defer_folds") is True
+    loss_fn = wav2vec2.CTCLoss(cfg, x.shape, division_factor=B)
+    tr = wav2vec2.Trainer(m, loss_fn, dropout=0.1, apply_spec_augment=False, seed=1)
+    for sd_keep in (None, [1.0] + [0.0] + [1.0] * (cfg.num_layers - 2)):
+        ref = None
+        for flag, reps in ((False, 1), (True, 3), (False, 1)):
+            m.set_option("defer_folds", flag)
+            for _ in range(reps):
+                logits = tr.forward(x, step_seed=7, sd_keep=sd_keep)
+                nll, dlog = loss_fn.per_sample(labels, logits, with_grad=True)
+                tr.backward(dlog)
+                g = tr.grad_buffer().clone()
+                torch.cuda.synchronize()
+                assert bool(torch.isfinite(g).all())
+                if ref is None:
+                    ref = g
+                    assert float(ref.abs().max()) > 0
+                else:
+                    assert torch.equal(g, ref), (flag, sd_keep is not None, int((g != ref).sum()))
+    m.set_option("defer_folds", True)
+    m.set_precision("fp32")
+
+
 @pytest.mark.parametrize("L,frames", [(20560, 64), (24080, 75)])
 def test_bf16_precision_training_step(env, L, frames):
     """bf16 fine-tune arithmetic (BASELINE configs 3 / 5): training-mode logits equal the torch oracle with

@@ -84,8 +84,41 @@ def pmc(fetch_dir, write_dir, dst):
     print("\n".join(out))
 
 
+def gaps(src, dst, steps):
+    """Device-side idle time between consecutive kernels of the trace (rocprofv3 --kernel-trace): the launch gaps a hipGraph could
+    at best remove.  `steps` = benchmark steps in the trace (warm-up included); the first step is dropped (allocation, first-use)."""
+    trace = list(csv.DictReader(open(find(src, "_kernel_trace.csv"))))
+    ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in trace)
+    ev = [e for e in ev if e[2].startswith("w2v2::") or e[2].startswith("__amd_rocclr")]
+    # step boundaries: the optimizer launch closes a training step; a forward-only trace is cut evenly
+    closers = [i for i, e in enumerate(ev) if "adam_multi_kernel" in e[2]]
+    if len(closers) >= 2:
+        lo, hi = closers[0] + 1, closers[-1] + 1            # whole steps between the first and the last optimizer launch
+        nsteps = len(closers) - 1
+    else:
+        per = len(ev) // max(1, steps)
+        lo, hi, nsteps = per, per * steps, steps - 1
+    seg = ev[lo:hi]
+    busy = sum(e[1] - e[0] for e in seg)
+    g = [max(0, seg[i + 1][0] - seg[i][1]) for i in range(len(seg) - 1)]
+    span = seg[-1][1] - seg[0][0]
+    g_sorted = sorted(g)
+    def pct(q): return g_sorted[min(len(g_sorted) - 1, int(q * len(g_sorted)))] / 1e3
+    big = sorted(((g[i], seg[i][2], seg[i + 1][2]) for i in range(len(g))), reverse=True)[:8]
+    out = [f"# device-side launch gaps ({nsteps} steps, {len(seg)} kernel launches, from the rocprofv3 kernel trace)", "",
+           f"* launches per step: {len(seg) / nsteps:.0f}",
+           f"* span per step: {span / nsteps / 1e6:.3f} ms; kernels busy: {busy / nsteps / 1e6:.3f} ms; idle between kernels: {sum(g) / nsteps / 1e6:.3f} ms",
+           f"* gap per launch: median {pct(0.5):.2f} us, p90 {pct(0.9):.2f} us, p99 {pct(0.99):.2f} us, mean {sum(g) / len(g) / 1e3:.2f} us",
+           "", "| largest gaps (us) | after | before |", "|---|---|---|"]
+    out += [f"| {a / 1e3:.1f} | `{b}` | `{c}` |" for a, b, c in big]
+    open(dst, "w").write("\n".join(out) + "\n")
+    print("\n".join(out[:6]))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "gaps":
+        gaps(sys.argv[2], sys.argv[3], int(sys.argv[4]))
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])
