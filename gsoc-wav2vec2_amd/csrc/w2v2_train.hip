@@ -974,6 +974,8 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     }
     float *dh = t->gh[0], *tmp = t->gh[1], *tmp2 = t->gh[2], *tmp3 = t->gh[3];
     const bool prenorm = c.attention_norm_type == 1;
+    float* head_b2 = nullptr;      // prenorm: the encoder LayerNorm's backward already summed dh's columns into the top layer's b2 gradient
+    bool head_dh16 = false;        // ... and wrote dh's bf16 shadow
     if (int e = launch_gemm(pf, dlogits, V, 0, t->WlmT, H, tmp, H, 0, nullptr, nullptr, (int)BT, H, V, 1, 0, s)) return e;
     if (!prenorm) {
         if (int e = launch_dropout_bwd(nullptr, tmp, dh, BT * H, 0, p, seed, DS_HEAD, s)) return e;
@@ -981,9 +983,15 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         if (int e = launch_dropout_bwd(nullptr, tmp, tmp2, BT * H, 0, p, seed, DS_HEAD, s)) return e;
         float* dg = G("encoder/layer_norm/gamma");
         float* db = G("encoder/layer_norm/beta");
-        if (int e = launch_ln_bwd(m->hs[c.num_layers], m->P("encoder/layer_norm/gamma"), tmp2, dh, dg ? dg : t->dummy,
-                                  db ? db : t->dummy + H, BT, H, eps, t->red_ws, s))
+        // (round 5: this pass also leaves dh's bf16 shadow -- a separate rounding kernel before -- and, on the shadow path, the column
+        //  sums of dh = the top layer's down-projection bias gradient: see `b2_done` in the prenorm loop)
+        const bool top16 = s16h && (BT * H) % 4 == 0 && (reinterpret_cast<uintptr_t>(dh) & 15) == 0;
+        head_b2 = (shb && tune_int("W2V2_B2_FROM_LN", 1) != 0 && c.num_layers > 0 && t->layers[c.num_layers - 1].keep != 0.f)
+                      ? G("encoder/layers/" + std::to_string(c.num_layers - 1) + "/feed_forward/output_dense/bias") : nullptr;
+        if (int e = launch_ln_bwd_x(m->hs[c.num_layers], m->P("encoder/layer_norm/gamma"), tmp2, dh, top16 ? s16h : nullptr, dg ? dg : t->dummy,
+                                    db ? db : t->dummy + H, BT, H, eps, t->red_ws, s, head_b2))
             return e;
+        head_dh16 = top16;
     }
 
     // dqkv only as bf16 (+ per-block column sums for the bias gradient) when all three of its readers can do without the fp32 copy
@@ -1054,8 +1062,12 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         return dropout_bwd_bias(l.u, t->gf, du16_only ? nullptr : t->gf, s16f, BT, F, act_ew, layer_stream(i, 2), gb1, b1_done, in, true);
     };
     const bool fuse_do_tail = !tune_int("W2V2_NO_DO_TAIL", 0);
-    bool dh16_valid = false;
-    if (prenorm && s16h && (BT * H) % 4 == 0 && (reinterpret_cast<uintptr_t>(dh) & 15) == 0) {
+    bool dh16_valid = head_dh16;
+    // b2_done: the kernel that produced dh (the encoder LayerNorm's backward for the top layer, the LayerNorm-1 backward of layer i + 1
+    // below) also left its column sums -- dh is the dY of this layer's down-projection, so they are its bias gradient -- and the
+    // weight gradient needs no separate pass over the fp32 dh (two launches and a 98 MB read per layer at 16 x 480000)
+    bool b2_done = head_b2 != nullptr;
+    if (prenorm && !dh16_valid && s16h && (BT * H) % 4 == 0 && (reinterpret_cast<uintptr_t>(dh) & 15) == 0) {
         // the last layer's output gradient arrives in fp32 only: round it once so that its down-projection GEMMs stream shadows too
         if (int e = launch_to_bf16(dh, s16h, BT * H, s)) return e;
         dh16_valid = true;
@@ -1080,8 +1092,8 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
             W2V2_REQUIRE(!f16 || dh16, "train_backward: no bf16 shadow of the layer's output gradient");
             if (int e = side(0, [&](hipStream_t st, float* rws) {
                     return weight_grad(m, f16 ? nullptr : l.gd, dh, (int)BT, F, H, G(b + "/feed_forward/output_dense/kernel"),
-                                       G(b + "/feed_forward/output_dense/bias"), st, (xs && dh16) ? l.gd16 : nullptr, dh16, dh16 != nullptr && dh16 == s16h, rws,
-                                       &ws0);
+                                       b2_done ? nullptr : G(b + "/feed_forward/output_dense/bias"), st, (xs && dh16) ? l.gd16 : nullptr, dh16,
+                                       dh16 != nullptr && dh16 == s16h, rws, &ws0);
                 }))
                 return e;
             bool b1_done = false;
@@ -1148,9 +1160,13 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         dh16_valid = s16h && H % 4 == 0 && (reinterpret_cast<uintptr_t>(dt1) & 15) == 0;
         if (int e = side_wait(2)) return e;                  // (d_o's shadow in s16h: the out-projection's weight gradient)
         if (int e = side_wait(0)) return e;                  // (dh in fp32, when the down-projection's weight gradient read that)
+        // (+ the column sums of dh: the down-projection bias gradient of layer i - 1, unless stochastic depth dropped that layer's FFN)
+        float* const next_b2 = (shb && tune_int("W2V2_B2_FROM_LN", 1) != 0 && i > 0 && t->layers[i - 1].keep != 0.f)
+                                   ? G("encoder/layers/" + std::to_string(i - 1) + "/feed_forward/output_dense/bias") : nullptr;
         if (int e = launch_ln_bwd_x(x, m->P(b + "/layer_norm/gamma"), tmp, dh, dh16_valid ? s16h : nullptr, dg1 ? dg1 : t->dummy,
-                                    db1 ? db1 : t->dummy + H, BT, H, eps, ln1_ws, s, nullptr, dt1, nullptr, fb))
+                                    db1 ? db1 : t->dummy + H, BT, H, eps, ln1_ws, s, next_b2, dt1, nullptr, fb))
             return e;
+        b2_done = next_b2 != nullptr;
         if (int e = fold.flush(s)) return e;                 // (the layer's deferred folds: its gradients are final behind this launch)
         if (int e = bucket_done(c.num_layers - i)) return e;
     }

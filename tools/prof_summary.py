@@ -111,6 +111,14 @@ def gaps(src, dst, steps):
            f"* gap per launch: median {pct(0.5):.2f} us, p90 {pct(0.9):.2f} us, p99 {pct(0.99):.2f} us, mean {sum(g) / len(g) / 1e3:.2f} us",
            "", "| largest gaps (us) | after | before |", "|---|---|---|"]
     out += [f"| {a / 1e3:.1f} | `{b}` | `{c}` |" for a, b, c in big]
+    # runtime fill / copy kernels (hipMemsetAsync, hipMemcpyAsync): which launches they sit between
+    ctx = defaultdict(int)
+    for i, e in enumerate(seg):
+        if e[2].startswith("__amd_rocclr"):
+            ctx[(e[2], seg[i - 1][2] if i else "-", seg[i + 1][2] if i + 1 < len(seg) else "-")] += 1
+    if ctx:
+        out += ["", "| runtime kernel | after | before | per step |", "|---|---|---|---|"]
+        out += [f"| `{k[0]}` | `{k[1]}` | `{k[2]}` | {v / nsteps:.1f} |" for k, v in sorted(ctx.items(), key=lambda kv: -kv[1])[:16]]
     open(dst, "w").write("\n".join(out) + "\n")
     print("\n".join(out[:6]))
 
