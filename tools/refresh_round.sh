@@ -13,6 +13,7 @@ python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.
 S="--no-cpu-baseline --no-side"
 python bench.py --precision bf16 $S > $O/bench_bf16_n1.json 2>/dev/null
 python bench.py --precision bf16x3 $S > $O/bench_bf16x3_n1.json 2>/dev/null
+python bench.py --precision f16x2 $S > $O/bench_f16x2_n1.json 2>/dev/null
 python bench.py --mode train --precision bf16 $S > $O/bench_bf16_train_n1.json 2>/dev/null
 python bench.py --mode train $S > $O/bench_train_n1.json 2>/dev/null
 python bench.py --mode train --precision bf16 --model large-robust --batch 16 --samples 480000 $S --steps 8 --warmup 3 > $O/bench_large_robust_bf16_train_n1.json 2>/dev/null
