@@ -720,10 +720,10 @@ __global__ __launch_bounds__(256, 3) void attention_bf16_bwd_dq_kernel(Attn16Bwd
 }
 
 // ---- dK, dV: block = 4 waves x 32 keys; streams 64-query tiles of Q and dO (+ lse, D as two 64-float rows) ----
-// (MINW: waves per SIMD the register allocation is held to.  2 = 228 VGPRs, no scratch: the shipping instance; the tools-only build
-//  also carries MINW = 3 -- 168 VGPRs, 37 spilled -- for the occupancy A/B recorded in DESIGN.md 7.1)
-template <bool BITS, int MINW = 2>
-__global__ __launch_bounds__(256, MINW) void attention_bf16_bwd_dkv_kernel(Attn16BwdArgs a, AttnTrain tr) {
+// (two waves per SIMD: 228 VGPRs, no scratch.  Held to three -- 168 VGPRs, 37 of them spilled inside the tile loop -- the kernel is 1.6 x
+//  slower: attention 5.32 -> 6.99 ms per step on base, 24.2 -> 32.6 on large-robust, profiles/r05_ab_attention_dkv_3waves.txt)
+template <bool BITS>
+__global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16BwdArgs a, AttnTrain tr) {
     constexpr int WROW = KT + 4;      // keep words per (wave, lh) row, padded: the two rows a lane group reads land on different banks
     constexpr int STAGE = 2 * IMG + 2 * KT * 4 + (BITS ? NW * 2 * WROW * 4 : 0);      // Q, dO images; lse, D; per wave: 2 rows of keep words
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_a16[];
@@ -967,13 +967,6 @@ int launch_attention_bwd_bf16(const float* qkv, const uint16_t* qkv16, const int
     dim3 grid(a.nwork), block(256);
     if (bits) {
         W2V2_LAUNCH(attention_bf16_bwd_dq_kernel<true>, grid, block, lds_q, s, a, tr);
-#ifdef W2V2_TUNING
-        if (tune_int("W2V2_DKV_WAVES", 2) == 3) {
-            W2V2_LAUNCH((attention_bf16_bwd_dkv_kernel<true, 3>), grid, block, lds_kv, s, a, tr);
-            W2V2_HIP_CHECK(hipGetLastError());
-            return W2V2_OK;
-        }
-#endif
         W2V2_LAUNCH(attention_bf16_bwd_dkv_kernel<true>, grid, block, lds_kv, s, a, tr);
     } else {
         W2V2_LAUNCH(attention_bf16_bwd_dq_kernel<false>, grid, block, lds_q, s, a, tr);
