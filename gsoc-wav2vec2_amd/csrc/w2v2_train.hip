@@ -75,6 +75,7 @@ struct TrainState {
     bool ffn16_only = false;                      // the last forward wrote dropout(GELU(u)) only as bf16 (no fp32 l.gd)
     bool ctx16_only = false;                      // ... and the attention output only as bf16 (no fp32 l.ctx: the backward reads O and dO as bf16)
     bool u16_only = false;                        // ... and the FFN pre-activation u only as bf16 (in the first half of l.u's storage)
+    bool ln16_only = false;                       // ... and (prenorm) the two in-layer LayerNorm outputs a, t2 only as bf16
     bool x16_valid = false, x16_attn = false;     // the last forward wrote the per-layer bf16 shadows (/ ctx16 from the bf16 attention)
     // gradient buckets for overlapping the data-parallel all-reduce with the backward: completion order
     //   0 = lm_head, 1 .. N = encoder layers N-1 .. 0, N+1 = everything in front of layer 0 in the flat buffer
@@ -218,7 +219,10 @@ static int ensure_persistent(w2v2_model* m) {
 // attention output and the FFN hidden activation only as bf16, and u as bf16 in half of its buffer): they are not allocated -- 0.75 GB
 // per layer at 32 x 246000, 9 GB for base and 24 GB for large at 16 x 480000 (rounds 2-4 allocated them regardless).  A forward that
 // needs a different set (the precision or the shadow option changed on the same shapes) rebuilds the workspace.
-enum : int { LEAN_QKV = 1, LEAN_CTX = 2, LEAN_GD = 4, LEAN_U_HALF = 8 };
+// LEAN_LN (prenorm only): the outputs of the two LayerNorms inside a layer feed nothing but GEMMs -- q|k|v / the FFN up-projection and their
+// weight gradients, which all stream the bf16 shadow -- so their fp32 copies (a, t2) are neither written nor allocated.  (Postnorm: t2 is
+// also the FFN's residual and stays fp32.)
+enum : int { LEAN_QKV = 1, LEAN_CTX = 2, LEAN_GD = 4, LEAN_U_HALF = 8, LEAN_LN = 16 };
 static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T, int lean) {
     TrainState* t = get_state(m);
     if (t->B == B && t->L == L && t->B > 0 && t->lean == lean) return W2V2_OK;
@@ -249,13 +253,15 @@ static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T, int lean) {
             if (int e = t_alloc(t, &l.ctx, BT * H)) return e;
         if (int e = t_alloc(t, &l.lse, (int64_t)B * c.num_heads * T)) return e;
         if (int e = t_alloc(t, &l.t1, BT * H)) return e;
-        if (int e = t_alloc(t, &l.t2, BT * H)) return e;
+        l.t2 = nullptr;
+        if (!(lean & LEAN_LN))
+            if (int e = t_alloc(t, &l.t2, BT * H)) return e;
         if (int e = t_alloc(t, &l.u, (lean & LEAN_U_HALF) ? (BT * F + 1) / 2 + 4 : BT * F)) return e;
         if (!(lean & LEAN_GD))
             if (int e = t_alloc(t, &l.gd, BT * F)) return e;
         if (int e = t_alloc(t, &l.t3, BT * H)) return e;
         l.a = nullptr;
-        if (c.attention_norm_type == 1)
+        if (c.attention_norm_type == 1 && !(lean & LEAN_LN))
             if (int e = t_alloc(t, &l.a, BT * H)) return e;
     }
     {
@@ -605,9 +611,13 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
     // The attention output O: its readers are the out-projection GEMM and that GEMM's weight gradient (both stream the bf16 shadow)
     // and D = rowsum(dO o O) of the attention backward, which is defined on the bf16 values -- no fp32 copy is written.
     const bool ctx16_only = ffn16_only && attn16 && tune_int("W2V2_CTX16", 1) != 0;
+    // Prenorm: a = LN1(x) and t2 = LN2(t1) are read only by GEMMs that stream their shadows (forward GEMM by LDS-DMA, weight gradient in the
+    // transposing-read form: the same conditions as above): written only as bf16 (196 MB of fp32 stores per layer gone at 16 x 480000)
+    const bool ln16_only = c.attention_norm_type == 1 && ffn16_only && attn16 && tune_int("W2V2_LN16", 1) != 0;
     // (tools-only build: W2V2_LEAN_WS = 0 allocates everything, as rounds 2-4 did, for A/B runs)
     const int lean = tune_int("W2V2_LEAN_WS", 1) == 0 ? 0
-                     : (attn16 ? LEAN_QKV : 0) | (ctx16_only ? LEAN_CTX : 0) | (ffn16_only ? LEAN_GD : 0) | (u16_only ? LEAN_U_HALF : 0);
+                     : (attn16 ? LEAN_QKV : 0) | (ctx16_only ? LEAN_CTX : 0) | (ffn16_only ? LEAN_GD : 0) | (u16_only ? LEAN_U_HALF : 0) |
+                       (ln16_only ? LEAN_LN : 0);
     if (int e = ensure_train_ws(m, B, L, T, lean)) return e;
     TrainState* t = m->train;
     Profiler* pf = m->prof;
@@ -712,6 +722,7 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
     t->ffn16_only = ffn16_only;       // (decided in front of the workspace, which leaves out the fp32 buffers these modes never write)
     t->u16_only = u16_only;
     t->ctx16_only = ctx16_only;
+    t->ln16_only = ln16_only;
     const int u_round = m->precision == 1 ? 1 : 0;
     for (int i = 0; i < c.num_layers; ++i) {
         const std::string b = "encoder/layers/" + std::to_string(i);
@@ -721,10 +732,10 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
         const float* attn_in = x;
         const uint16_t* attn_in16 = (sh && !prenorm) ? m->hs16[i] : nullptr;   // postnorm: written by the producer of hs[i]
         if (prenorm) {     // x + drop(attn(LN(x)))   (encoder.py:114-119)
-            if (int e = launch_layer_norm_x(pf, x, l.a, m->P(b + "/layer_norm/gamma"), m->P(b + "/layer_norm/beta"), BT, H, eps, 0,
+            if (int e = launch_layer_norm_x(pf, x, ln16_only ? nullptr : l.a, m->P(b + "/layer_norm/gamma"), m->P(b + "/layer_norm/beta"), BT, H, eps, 0,
                                             S16(l.a16), s))
                 return e;
-            attn_in = l.a;
+            attn_in = ln16_only ? nullptr : l.a;
             attn_in16 = S16(l.a16);
         }
         // the bf16 attention kernels (forward and backward) read q | k | v only as bf16: the projection then writes just that shadow
@@ -748,12 +759,12 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
             ((reinterpret_cast<uintptr_t>(m->t0) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(l.t1) | reinterpret_cast<uintptr_t>(l.t2) |
               reinterpret_cast<uintptr_t>(m->P(b + ln_a + "/gamma")) | reinterpret_cast<uintptr_t>(m->P(b + ln_a + "/beta"))) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(S16(l.t2_16)) & 7) == 0) {
-            if (int e = launch_layer_norm_drop(pf, m->t0, x, l.t1, l.t2, S16(l.t2_16), m->P(b + ln_a + "/gamma"), m->P(b + ln_a + "/beta"), BT, H, eps, p,
+            if (int e = launch_layer_norm_drop(pf, m->t0, x, l.t1, ln16_only ? nullptr : l.t2, S16(l.t2_16), m->P(b + ln_a + "/gamma"), m->P(b + ln_a + "/beta"), BT, H, eps, p,
                                                seed, layer_stream(i, 1), s))
                 return e;
         } else {
             if (int e = launch_dropout_fwd(m->t0, x, l.t1, BT * H, 0, p, seed, layer_stream(i, 1), s)) return e;
-            if (int e = launch_layer_norm_x(pf, l.t1, l.t2, m->P(b + ln_a + "/gamma"), m->P(b + ln_a + "/beta"), BT, H, eps, 0, S16(l.t2_16), s)) return e;
+            if (int e = launch_layer_norm_x(pf, l.t1, ln16_only ? nullptr : l.t2, m->P(b + ln_a + "/gamma"), m->P(b + ln_a + "/beta"), BT, H, eps, 0, S16(l.t2_16), s)) return e;
         }
         const float* ffn_res = prenorm ? l.t1 : l.t2;
         float* ffn_out = prenorm ? m->hs[i + 1] : l.t3;
@@ -761,7 +772,7 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
             // u = t2 W1 + b1;  gd = dropout(GELU(u));  out = res + keep * (gd W2 + b2)   (encoder.py:127-130)
             // (ffn16_only: every reader of gd -- the next GEMM, and the down-projection's weight gradient -- streams the bf16 shadow)
             uint16_t* const u16 = u16_only ? reinterpret_cast<uint16_t*>(l.u) : nullptr;
-            if (int e = gemm(l.t2, S16(l.t2_16), H, 0, m->P(b + "/feed_forward/intermediate_dense/kernel"), F, u16_only ? nullptr : l.u, u16, F, 0,
+            if (int e = gemm(ln16_only ? nullptr : l.t2, S16(l.t2_16), H, 0, m->P(b + "/feed_forward/intermediate_dense/kernel"), F, u16_only ? nullptr : l.u, u16, F, 0,
                              m->P(b + "/feed_forward/intermediate_dense/bias"), nullptr, (int)BT, F, H, 1, 0))
                 return e;
             EwBf16 uin;
@@ -1368,7 +1379,7 @@ int w2v2_train_storage(const w2v2_model* m, int32_t* mask, int64_t* workspace_by
     *workspace_bytes = t ? t->alloc_bytes : 0;
     if (t && t->B > 0)
         *mask = (t->x16_attn ? W2V2_TRAIN_BF16_QKV : 0) | (t->ctx16_only ? W2V2_TRAIN_BF16_CTX : 0) | (t->ffn16_only ? W2V2_TRAIN_BF16_FFN : 0) |
-                (t->u16_only ? W2V2_TRAIN_BF16_U : 0);
+                (t->u16_only ? W2V2_TRAIN_BF16_U : 0) | (t->ln16_only ? W2V2_TRAIN_BF16_LN : 0);
     return W2V2_OK;
 }
 

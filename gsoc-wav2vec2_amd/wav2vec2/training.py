@@ -272,12 +272,12 @@ class Trainer:
         return total
 
     def activation_storage(self):
-        """(set of per-layer activations the last training forward kept ONLY as bf16 -- "qkv", "ctx", "ffn", "u" --, bytes of
+        """(set of per-layer activations the last training forward kept ONLY as bf16 -- "qkv", "ctx", "ffn", "u", and for prenorm models "ln" --, bytes of
         shape-dependent training workspace allocated).  In precision "bf16" with shadows all four are bf16-only and their fp32 buffers do
         not exist; anything else after an optimizer step means the step fell back to the fp32 activations (include/w2v2.h: w2v2_train_storage)."""
         mask, nbytes = C.c_int32(), C.c_int64()
         N.check(self.model._lib.w2v2_train_storage(self.model._handle, C.byref(mask), C.byref(nbytes)), "w2v2_train_storage")
-        names = {n for bit, n in ((1, "qkv"), (2, "ctx"), (4, "ffn"), (8, "u")) if mask.value & bit}
+        names = {n for bit, n in ((1, "qkv"), (2, "ctx"), (4, "ffn"), (8, "u"), (16, "ln")) if mask.value & bit}
         return names, nbytes.value
 
     def all_reduce_payload(self):

@@ -259,11 +259,13 @@ int w2v2_get_grad(w2v2_model* m, const char* name, float* host_dst, int64_t nume
 /* Which per-layer activations the LAST training forward kept only as bf16 (precision mode BF16 on the shadow paths; their fp32 buffers
  * are then not allocated at all), and the bytes of shape-dependent training workspace currently allocated.  Introspection for the tests:
  * a step that silently fell back to the fp32 activations (twice the element-wise traffic) must not pass unnoticed.
- *   *mask: bit 0 = q|k|v, bit 1 = attention output, bit 2 = FFN hidden activation, bit 3 = FFN pre-activation u (bf16 in half a buffer) */
+ *   *mask: bit 0 = q|k|v, bit 1 = attention output, bit 2 = FFN hidden activation, bit 3 = FFN pre-activation u (bf16 in half a buffer),
+ *          bit 4 = (prenorm) the in-layer LayerNorm outputs */
 #define W2V2_TRAIN_BF16_QKV 1
 #define W2V2_TRAIN_BF16_CTX 2
 #define W2V2_TRAIN_BF16_FFN 4
 #define W2V2_TRAIN_BF16_U 8
+#define W2V2_TRAIN_BF16_LN 16   /* prenorm only: the outputs of the two LayerNorms inside a layer (they feed GEMMs only) */
 int w2v2_train_storage(const w2v2_model* m, int32_t* mask, int64_t* workspace_bytes);
 int w2v2_adam_step(w2v2_model* m, float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
 

@@ -823,6 +823,8 @@ def test_bf16_fine_tune_step_at_full_length(env, case, L, frames):
     logits = tr.forward(x, attention_mask=mask, spec_mask=spec, step_seed=42)
     nll, dlog = loss_fn.per_sample(labels, logits, with_grad=True)
     tr.backward(dlog)
+    # the step really ran on the bf16-only activations (prenorm: the in-layer LayerNorm outputs too), whose fp32 buffers do not exist
+    assert tr.activation_storage()[0] == ({"qkv", "ctx", "ffn", "u", "ln"} if cfg.is_robust else {"qkv", "ctx", "ffn", "u"})
     t0 = time.time()
     with H.oracle_operands("bf16"):
         loss, ref_nll, ref_logits, ref_grads = TT.loss_and_grads(cfg, w, x, labels, attention_mask=mask, p=0.1, seed=42,
