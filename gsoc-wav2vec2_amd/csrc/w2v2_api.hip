@@ -897,8 +897,15 @@ int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const i
         const float* x = m->hs[i];
         const float* attn_in = x;
         const uint16_t* attn_in16 = sh ? m->hs16[i] : nullptr;       // postnorm: the previous LayerNorm wrote it
+        // (prenorm, bf16 shadows: the two in-layer LayerNorm outputs feed one GEMM each; when that GEMM is certain to stream the shadow -- K = H a
+        //  multiple of 64 and a weight shadow, as for the attention output below -- the fp32 copy is not written: 2 x 98 MB per layer at 16 x 480000)
+        auto shadow_certain = [&](const float* w) {
+            const auto it = m->w16.find(w);
+            return sh && !keep && H % 64 == 0 && it != m->w16.end() && it->second != nullptr;
+        };
         if (prenorm) {
-            if (int e = launch_layer_norm_x(pf, x, (p_qkv && !keep) ? nullptr : m->t0, m->P(b + "/layer_norm/gamma"), m->P(b + "/layer_norm/beta"), BT, H, eps, 0,
+            const bool a16_only = shadow_certain(m->qkv_w[i]);
+            if (int e = launch_layer_norm_x(pf, x, ((p_qkv && !keep) || a16_only) ? nullptr : m->t0, m->P(b + "/layer_norm/gamma"), m->P(b + "/layer_norm/beta"), BT, H, eps, 0,
                                             sh ? m->t0_16 : nullptr, s, p_qkv ? &po_attn : nullptr))
                 return e;
             attn_in = m->t0;
@@ -932,7 +939,8 @@ int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const i
                 return e;
             ffn_res = m->t2;
         } else {
-            if (int e = launch_layer_norm_x(pf, m->t1, (p_f1 && !keep) ? nullptr : m->t2, m->P(b + "/final_layer_norm/gamma"), m->P(b + "/final_layer_norm/beta"), BT, H,
+            const bool t2_16_only = shadow_certain(m->P(b + "/feed_forward/intermediate_dense/kernel"));
+            if (int e = launch_layer_norm_x(pf, m->t1, ((p_f1 && !keep) || t2_16_only) ? nullptr : m->t2, m->P(b + "/final_layer_norm/gamma"), m->P(b + "/final_layer_norm/beta"), BT, H,
                                             eps, 0, sh ? m->t2_16 : nullptr, s, p_f1 ? &po_ffn_in : nullptr))
                 return e;
         }
