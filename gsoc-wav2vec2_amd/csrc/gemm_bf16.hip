@@ -768,14 +768,17 @@ namespace {
 
 // Which shadow-fed shapes take the 128 x 256 software-pipelined kernel (measured at B = 32, profiles/r03_gemm_bf16_study.md: it wins
 // 8-25 % on every model shape with N K >= 768 x 1024 and on the batched conv layers, and loses 5-10 % on the two smaller Dense
-// shapes): whole 256-column tiles, at least 256 of them (half of the chip's 512 block slots), a weight of >= 768 Ki elements or a batch.  GemmShadows::force_kernel overrides
+// shapes): whole 256-column tiles, at least 256 of them (half of the chip's 512 block slots), a weight of >= 576 Ki elements (round 3: 768 Ki) or a batch.  GemmShadows::force_kernel overrides
 // (1 = never, 2 = whenever the operands allow it: the op-level parity tests compare the two kernels bit for bit).
 bool use_sw_kernel(const GemmShadows& x, int M, int N, int K, int64_t lda, int64_t ldb16, int64_t strideA, int nbatch) {
     if (x.zmod != 0 || x.force_kernel == 1 || !gemm_bf16_sw_ok(M, N, K, lda, ldb16, strideA)) return false;
     if (x.force_kernel == 2) return true;
     if (tune_int("W2V2_GEMM16_SW", 1) == 0) return false;
     const int64_t tiles = (int64_t)((M + 127) / 128) * (N / 256) * nbatch;
-    return tiles >= 256 && ((int64_t)N * K >= 768 * 1024 || nbatch > 1);      // (768 x 768 and 768 x 512 tie or lose: 527 vs 571, 553 vs 623 TF)
+    // (round 5: the threshold moved from N K >= 768 x 1024 to 768 x 768 -- with the leaner fp32 epilogue of this round the out-projection and
+    //  its data gradient, 25 launches per step on the 128 x 128 kernel at MFMA busy 0.23, are faster here too: fine-tune step 32.95 -> 32.32 ms,
+    //  forward 11.30 -> 11.24 ms same-box, profiles/r05_ab_sw_768x768.txt; W2V2_SW_MIN_K in the tools-only build)
+    return tiles >= 256 && ((int64_t)N * K >= (int64_t)768 * tune_int("W2V2_SW_MIN_K", 768) || nbatch > 1);      // 
 }
 
 int forced_cfg16() {
