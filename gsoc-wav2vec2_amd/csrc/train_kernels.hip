@@ -95,6 +95,44 @@ __global__ void dropout_fwd_kernel(const float* __restrict__ x, const float* __r
     }
 }
 
+// The FFN's GELU + dropout on bf16-only tensors (u16 -> gd16; precision mode 1), eight elements per lane: 16-byte loads and stores instead of
+// the general kernel's 8-byte ones on this path (a wave covers 1 KiB per access).  Same element arithmetic, pairing and hash indices as
+// dropout_fwd_kernel<true>: bit-identical results.
+__device__ __forceinline__ void unpack8_bf16(const uint4& w, float (&v)[8]) {
+    v[0] = __uint_as_float(w.x << 16); v[1] = __uint_as_float(w.x & 0xFFFF0000u);
+    v[2] = __uint_as_float(w.y << 16); v[3] = __uint_as_float(w.y & 0xFFFF0000u);
+    v[4] = __uint_as_float(w.z << 16); v[5] = __uint_as_float(w.z & 0xFFFF0000u);
+    v[6] = __uint_as_float(w.w << 16); v[7] = __uint_as_float(w.w & 0xFFFF0000u);
+}
+__global__ void dropout_fwd_bf16x8_kernel(const uint16_t* __restrict__ x16, uint16_t* __restrict__ y16, int64_t n8, int act, float p, uint64_t seed,
+                                          uint32_t stream) {
+    const float inv = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    const uint32_t key = dropout_key(seed, stream), thr = dropout_threshold(p);
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n8; i += (int64_t)gridDim.x * EW_THREADS) {
+        float xv[8], v[8];
+        unpack8_bf16(reinterpret_cast<const uint4*>(x16)[i], xv);
+        if (act == 3) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const f32x2_t a = gelu_erf_fast2(f32x2_t{xv[e], xv[e + 1]});
+                v[e] = a[0]; v[e + 1] = a[1];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = apply_act(xv[e], act);
+        }
+        if (p > 0.f) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const uint32_t w = dropout_word(key, ((uint32_t)(8 * i) >> 1) + (e >> 1));
+                v[e] = dropout_keep_lo(w, thr) ? v[e] * inv : 0.0f;
+                v[e + 1] = dropout_keep_hi(w, thr) ? v[e + 1] * inv : 0.0f;
+            }
+        }
+        reinterpret_cast<uint4*>(y16)[i] = make_uint4(pack_bf16_rne(v[0], v[1]), pack_bf16_rne(v[2], v[3]), pack_bf16_rne(v[4], v[5]), pack_bf16_rne(v[6], v[7]));
+    }
+}
+
 // dx = dy * keep/(1-p) * act'(u)
 // (dy16 may be dx16: every element is read once, then written, by the same lane)
 template <bool VEC>
@@ -192,6 +230,68 @@ __global__ __launch_bounds__(256) void dropout_bwd_colsum_kernel(const float* __
         *reinterpret_cast<float4*>(partial + (int64_t)blockIdx.y * cols + c) =
             make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z),
                         (p0.w + p1.w) + (p2.w + p3.w));
+    }
+}
+
+// dropout_bwd_colsum_kernel on bf16-only tensors (u16, dy16 -> dx16, in place or not), eight columns per lane: 16-byte accesses; a block is
+// 32 column groups (256 columns) x 8 row lanes.  Same element arithmetic and hash indices; the column sums add the rows in a different
+// order than the four-column kernel (fp32 summation order only).
+__global__ __launch_bounds__(256) void dropout_bwd_colsum_bf16x8_kernel(const uint16_t* __restrict__ u16, const uint16_t* dy16, uint16_t* dx16,
+                                                                        float* __restrict__ partial, int64_t rows, int cols, int rows_per_chunk,
+                                                                        int act, float p, uint64_t seed, uint32_t stream) {
+    __shared__ float red[8][32][9];
+    const float inv = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    const uint32_t key = dropout_key(seed, stream), thr = dropout_threshold(p);
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int c = (blockIdx.x * 32 + cx) * 8;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (c < cols) {
+        for (int64_t r = r0 + ry; r < r1; r += 8) {
+            const int64_t i = r * cols + c;                       // a multiple of 8
+            float g[8];
+            unpack8_bf16(*reinterpret_cast<const uint4*>(dy16 + i), g);
+            if (p > 0.f) {
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const uint32_t w = dropout_word(key, ((uint32_t)i >> 1) + (e >> 1));
+                    g[e] = dropout_keep_lo(w, thr) ? g[e] * inv : 0.0f;
+                    g[e + 1] = dropout_keep_hi(w, thr) ? g[e + 1] * inv : 0.0f;
+                }
+            }
+            if (act) {
+                float uv[8];
+                unpack8_bf16(*reinterpret_cast<const uint4*>(u16 + i), uv);
+                if (act == 3) {
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const f32x2_t d = gelu_grad_fast2(f32x2_t{uv[e], uv[e + 1]});
+                        g[e] *= d[0]; g[e + 1] *= d[1];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) g[e] *= gelu_grad(uv[e], act);
+                }
+            }
+            *reinterpret_cast<uint4*>(dx16 + i) = make_uint4(pack_bf16_rne(g[0], g[1]), pack_bf16_rne(g[2], g[3]), pack_bf16_rne(g[4], g[5]), pack_bf16_rne(g[6], g[7]));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += g[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[ry][cx][e] = acc[e];
+    __syncthreads();
+    {   // 256 threads fold the 8 row lanes of the block's 256 columns: thread = one column
+        const int col = threadIdx.x, gx = col >> 3, ge = col & 7;
+        if (blockIdx.x * 256 + col < cols) {
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t += red[j][gx][ge];
+            partial[(int64_t)blockIdx.y * cols + blockIdx.x * 256 + col] = t;
+        }
     }
 }
 
@@ -664,7 +764,12 @@ int launch_dropout_fwd_x(const float* x, const float* res, float* y, uint16_t* y
     ProfScope ps(tl_step_prof, FAM_DROPOUT, 0.0, (double)n * ((x ? 4.0 : 2.0) + (res ? 4.0 : 0.0) + (y ? 4.0 : 0.0) + (y16 ? 2.0 : 0.0)), s);
     const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res)) & 15) == 0 &&
                      ((reinterpret_cast<uintptr_t>(y16) | reinterpret_cast<uintptr_t>(in.a16)) & 7) == 0;
-    if (vec)
+    // bf16 in, bf16 out, nothing else (the FFN's GELU + dropout in precision mode 1): eight elements per lane
+    const bool x8 = in.a16 && !res && !y && y16 && (n & 7) == 0 && ((reinterpret_cast<uintptr_t>(y16) | reinterpret_cast<uintptr_t>(in.a16)) & 15) == 0 &&
+                    tune_int("W2V2_EW_X8", 1) != 0;
+    if (x8)
+        W2V2_LAUNCH(dropout_fwd_bf16x8_kernel, dim3(ew_grid(n >> 3)), dim3(EW_THREADS), 0, s, in.a16, y16, n >> 3, act, p, seed, stream_id);
+    else if (vec)
         W2V2_LAUNCH(dropout_fwd_kernel<true>, dim3(ew_grid(n >> 2)), dim3(EW_THREADS), 0, s, x, res, y, y16, n, act, p, seed, stream_id, in.a16,
                            in.round_in);
     else
@@ -821,8 +926,15 @@ int launch_dropout_bwd_colsum(const float* u, const float* dy, float* dx, uint16
     const int colblocks = (cols + 255) / 256;
     while (chunk > 16 && (rows + chunk - 1) / chunk * colblocks < target) chunk >>= 1;
     const int nchunks = (int)((rows + chunk - 1) / chunk);
-    W2V2_LAUNCH(dropout_bwd_colsum_kernel, dim3(colblocks, nchunks), dim3(256), 0, s, u, dy, dx, dx16, ws, rows, cols,
-                       chunk, act, p, seed, stream_id, in.a16, in.b16, in.round_in);
+    // bf16 operands only (u16, dy16 -> dx16): eight columns per lane
+    const bool x8 = !dx && dx16 && in.b16 && (!act || in.a16) && (cols & 7) == 0 && tune_int("W2V2_EW_X8", 1) != 0 &&
+                    ((reinterpret_cast<uintptr_t>(dx16) | reinterpret_cast<uintptr_t>(in.a16) | reinterpret_cast<uintptr_t>(in.b16)) & 15) == 0;
+    if (x8)
+        W2V2_LAUNCH(dropout_bwd_colsum_bf16x8_kernel, dim3(colblocks, nchunks), dim3(256), 0, s, in.a16, in.b16, dx16, ws, rows, cols, chunk, act, p, seed,
+                           stream_id);
+    else
+        W2V2_LAUNCH(dropout_bwd_colsum_kernel, dim3(colblocks, nchunks), dim3(256), 0, s, u, dy, dx, dx16, ws, rows, cols,
+                           chunk, act, p, seed, stream_id, in.a16, in.b16, in.round_in);
     if (!(defer && defer->add_wide(ws, nchunks, cols, (int64_t)cols, 1, colsum)))
         W2V2_LAUNCH(colsum_final_wide_kernel, dim3((cols + 31) / 32), dim3(256), 0, s, ws, colsum, nchunks, cols, (int64_t)cols, 0);
     W2V2_HIP_CHECK(hipGetLastError());
