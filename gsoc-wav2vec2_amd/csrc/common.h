@@ -185,6 +185,11 @@ struct GemmShadows {
     int64_t strideB16 = 0, strideC2 = 0, strideBias = 0;
     int64_t strideB2 = 0;        // fp32 B with a two-level batch: B advances with zo * strideB2 + zi * strideB
     bool overlapA = false;       // transposed A whose rows overlap (lda < M): the packed positional-conv input
+    // SRC 7 (fp32 transposed A) only: the K dimension is a concatenation of segments of `kseg` rows (a multiple of 64) that lie segA (A) /
+    // segB (B) elements apart -- the positional-conv kernel gradient contracts over the frames of SEVERAL samples in one accumulator
+    // (segment = sample) instead of writing one slab per sample.  kseg = 0: contiguous K.
+    int kseg = 0;
+    int64_t segA = 0, segB = 0;
     // transposed-A form only: also write the column sums of B over each batch's K rows to colsum[z * strideCS + n]
     // (dW = X^T dY has the bias gradient 1^T dY for free: dY is in registers while it is staged)
     float* colsum = nullptr;

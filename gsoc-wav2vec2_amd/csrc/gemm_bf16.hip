@@ -59,6 +59,8 @@ struct Gemm16Args {
     // (the bias gradient: B = dY is already in registers while it is staged, so the sums cost 8 adds per patch column)
     float* colsum;
     int64_t strideCS;
+    int kseg;              // SRC 7: K as segments of kseg rows, segA / segB elements apart (GemmShadows::kseg); 0 = contiguous
+    int64_t segA, segB;
     int64_t validK;        // tr form: rows of the K dimension that exist, over all batches (batch z owns [z K, (z + 1) K)); rows beyond
                            // read as zero, so neither the row count nor its split into slabs has to be a multiple of the K tile
 #ifdef W2V2_TUNING
@@ -216,6 +218,13 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
 
     auto load_tile = [&](int kt) {
         const int k0 = kt * BK;
+        // element offsets of K row k0 in A^T / B (SRC 7 may walk a segmented K: a tile never straddles a segment, kseg % BK == 0)
+        int64_t ka = (int64_t)k0 * g.lda, kb = (int64_t)k0 * g.ldb;
+        if (AT && g.kseg) {
+            const int seg = k0 / g.kseg, kin = k0 - seg * g.kseg;
+            ka = (int64_t)seg * g.segA + (int64_t)kin * g.lda;
+            kb = (int64_t)seg * g.segB + (int64_t)kin * g.ldb;
+        }
         if constexpr (A16) {
 #pragma unroll
             for (int i = 0; i < NA16; ++i) ra16[i] = *reinterpret_cast<const u32x4*>(a16_src[i] + k0);
@@ -228,7 +237,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
 #pragma unroll
             for (int i = 0; i < NAT; ++i)
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) rat[i][kk] = *reinterpret_cast<const f32x4*>(A + at_off[i] + (int64_t)(k0 + kk) * g.lda);
+                for (int kk = 0; kk < 8; ++kk) rat[i][kk] = *reinterpret_cast<const f32x4*>(A + at_off[i] + ka + (int64_t)kk * g.lda);
         }
 #pragma unroll
         for (int i = 0; i < ((A16 || AT) ? 0 : NA); ++i) {
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(WM* WN * 64, MINB) void gemm_bf16_kernel(Gemm16Args
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
                 if constexpr (FAST) {
-                    rb[i][kk] = *reinterpret_cast<const bvec*>(Bm + b_off[i] + (int64_t)(k0 + kk) * g.ldb);
+                    rb[i][kk] = *reinterpret_cast<const bvec*>(Bm + b_off[i] + kb + (int64_t)kk * g.ldb);
                 } else {
                     const int idx = tid + i * NT;
                     const int k = k0 + (idx / NQ) * 8 + kk, col = n0 + PN * (idx % NQ);
@@ -810,6 +819,9 @@ int launch_gemm_bf16_x(Profiler* prof, const float* A, int64_t lda, int64_t stri
     g.zmod = x.zmod; g.strideB16 = x.strideB16; g.strideC2 = x.strideC2; g.strideBias = x.strideBias; g.strideB2 = x.strideB2;
     g.colsum = x.transA ? x.colsum : nullptr; g.strideCS = x.strideCS;
     g.B16p = x.B16p;
+    g.kseg = x.kseg; g.segA = x.segA; g.segB = x.segB;
+    W2V2_REQUIRE(x.kseg == 0 || (x.transA && !x.A16 && !x.B16p && A && B && x.kseg % BK == 0 && K % x.kseg == 0 && !x.colsum),
+                 "gemm_bf16: a segmented K (kseg) is for the fp32 transposed-A form, whole segments of a multiple of 64 rows");
     g.validK = x.validK > 0 ? x.validK : (int64_t)K * nbatch;
     W2V2_REQUIRE(x.validK == 0 || (x.transA && x.A16 && x.B16p && x.validK > (int64_t)K * (nbatch - 1) + 64 * x.kextra &&
                                    x.validK <= (int64_t)K * nbatch + 64 * x.kextra),

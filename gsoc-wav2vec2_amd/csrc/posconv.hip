@@ -604,6 +604,31 @@ int launch_pos_conv_dw_bf16(Profiler* prof, const float* xz, const float* dc, fl
     gx.strideB2 = (int64_t)Tk * H;
     gx.strideC2 = (int64_t)groups * K * cg * cg;
     const int M = K * cg;
+    // Round 5: the contraction runs over the frames of SEVERAL samples in one accumulator (GemmShadows::kseg: K = segments of Tk rows, one per
+    // sample) instead of one (K cg, og) slab per sample -- 604 MB of slabs written and folded per step at B = 32, and a K of 768 rows per
+    // block, most of its time prologue and epilogue.  Slab h of S takes the samples b = h, h + S, h + 2S, ... (so that batch z = h G + g still
+    // finds its first operands at z strideA / zo strideB2 + zi strideB), S in {1, 2, 4} chosen to fill whole rounds of the 512 block slots:
+    // base 48 tiles x 16 groups x S = 2 -> 1536 blocks, large 64 x 16 x 1 -> 1024.  The sum over a slab's samples is taken in the MFMA
+    // accumulators in sample order (deterministic); S = 1 writes the gradient itself.
+    if (tune_int("W2V2_POS_DW_KCAT", 1) != 0) {
+        const int64_t tiles = (int64_t)((M + 127) / 128) * groups;
+        int S = 1;
+        double best = 1e30;
+        for (int cand : {1, 2, 4}) {
+            if (B % cand) continue;
+            const int64_t blocks = tiles * cand;
+            const double waste = (double)((blocks + 511) / 512 * 512) / (double)blocks;
+            if (waste < best - 1e-9) { best = waste; S = cand; }
+        }
+        gx.kseg = Tk;
+        gx.segA = (int64_t)S * groups * Tp * cg;
+        gx.segB = (int64_t)S * Tk * H;
+        float* dst = S == 1 ? dwg : slabs;
+        if (int e = launch_gemm_bf16_x(nullptr, pack32, cg, (int64_t)Tp * cg, dc, H, cg, dst, cg, (int64_t)K * cg * cg, nullptr, nullptr, M, cg,
+                                       (B / S) * Tk, S * groups, 0, gx, s))
+            return e;
+        return S == 1 ? W2V2_OK : launch_colsum(slabs, dwg, S, (int)((int64_t)groups * K * cg * cg), red_ws, 0, s);
+    }
     // A^T: element (m = f, k = t) of batch z = b G + g at pack32[z Tp cg + t cg + f]; B (k = t, n) at dc[b Tk H + t H + g og + n]
     if (int e = launch_gemm_bf16_x(nullptr, pack32, cg, (int64_t)Tp * cg, dc, H, cg, slabs, cg, (int64_t)K * cg * cg, nullptr, nullptr, M, cg, Tk,
                                    B * groups, 0, gx, s))
