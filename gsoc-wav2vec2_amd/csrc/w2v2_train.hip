@@ -1308,7 +1308,10 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
             const int Tk = (T + 63) / 64 * 64;
             if (!t->pos_pack32) {
                 if (int e = t_alloc(t, &t->pos_pack32, (int64_t)B * (Tk + K - 1) * H)) return e;
-                if (int e = t_alloc(t, &t->pos_dw_slabs, (int64_t)B * K * cg * H)) return e;
+                // (one (K cg, og) slab per group and per SLAB of samples: at most four since the samples are concatenated along K -- posconv.hip;
+                //  the one-slab-per-sample form of the tools-only build keeps B of them)
+                const int nslab = tune_int("W2V2_POS_DW_KCAT", 1) != 0 ? (B < 4 ? B : 4) : B;
+                if (int e = t_alloc(t, &t->pos_dw_slabs, (int64_t)nslab * K * cg * H)) return e;
                 if (Tk != T)
                     if (int e = t_alloc(t, &t->pos_dc_pad, (int64_t)B * Tk * H)) return e;
             }
