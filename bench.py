@@ -725,6 +725,117 @@ def measure_alt(ctx, model, x, amask, model_name, B, L, steps, warmup, prec, ref
     return o
 
 
+COMPACT_LIMIT = 4096              # the driver keeps 8 KB of stdout; the line it parses must stay far below that
+ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "clock_mhz_under_load",
+             "frac_clock_adjusted")
+
+
+def _compact_roofline(roof, full=True):
+    """The roofline object without prose: numbers + a short kernel name."""
+    if not roof:
+        return None
+    out = {k: roof[k] for k in ROOF_KEYS if k in roof}
+    if "kernel" in out:
+        out["kernel"] = out["kernel"].split(" (")[0][:48]
+    if not full:
+        out = {k: out[k] for k in ("achieved", "frac", "traffic_over_algorithmic") if k in out}
+    return out
+
+
+def _compact_side(obj):
+    """A side configuration on the stdout line: one flat object {ms_per_step, value, frac, ...}."""
+    if not isinstance(obj, dict):
+        return None
+    if "error" in obj:
+        return {"error": str(obj["error"])[:120]}
+    out = {"ms_per_step": obj.get("ms_per_step"), "value": obj.get("value")}
+    roof = obj.get("roofline") or {}
+    for k_out, k_in in (("frac", "frac"), ("achieved", "achieved"), ("traffic_over_algorithmic", "traffic_over_algorithmic")):
+        if roof.get(k_in) is not None:
+            out[k_out] = roof[k_in]
+    ar = obj.get("allreduce") or {}
+    for k in ("exposed_ms", "standalone_ms", "busbw_GBps", "payload_bytes", "collectives_per_step"):
+        if ar.get(k) is not None:
+            out.setdefault("allreduce", {})[k] = ar[k]
+    for prec in ("bf16x3", "f16x2"):
+        alt = obj.get(prec)
+        if isinstance(alt, dict) and "ms_per_step" in alt:
+            out[prec] = {"ms_per_step": alt["ms_per_step"], "value": alt["value"], "frac": (alt.get("roofline") or {}).get("frac")}
+    return out
+
+
+def compact_line(full):
+    """The ONE stdout line the driver parses: the contract keys, the roofline and cpu_baseline objects as
+    numbers only and one flat triple per side configuration -- no prose.  The complete object (notes, per-family tables, provenance of
+    every figure) goes to gpurun_out/bench_full.json and to stderr.  Always < COMPACT_LIMIT bytes: optional keys are dropped, in a fixed
+    order, until it is (tests/test_host_cpu.py pins that on the stored round-5 object)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "data",
+            "max_abs_logit_err", "gpu_over_cpu", "forward_tflops", "final_loss", "bench_wall_s")
+    line = {k: full[k] for k in keep if k in full}
+    line["dtype"] = str(full.get("dtype", "")).split(" ")[0].rstrip(",") or None
+    comm = full.get("comm") or {}
+    line["comm"] = {k: comm[k] for k in ("backend", "world_size", "rccl_version", "launcher") if k in comm}
+    cfgo = dict(full.get("config") or {})
+    if "workload" in cfgo:
+        cfgo["workload"] = str(cfgo["workload"])[:120]
+    line["config"] = cfgo
+    if "roofline" in full:
+        line["roofline"] = _compact_roofline(full["roofline"])
+    cb = full.get("cpu_baseline")
+    if cb:
+        c = {k: cb[k] for k in ("value", "unit", "cores", "kind", "cpu_model") if k in cb}
+        legs = {}
+        for name, leg in (cb.get("legs") or {}).items():
+            if "audio_s_per_s_best" in leg:
+                legs[name] = {"best": leg["audio_s_per_s_best"], "median": leg["audio_s_per_s_median"]}
+            elif "audio_s_per_s" in leg:
+                legs[name] = {"best": leg["audio_s_per_s"], "workers": leg.get("workers")}
+        if legs:
+            c["legs"] = legs
+            meds = [v["median"] for v in legs.values() if "median" in v]
+            if meds:
+                c["value_median"] = max(meds)
+        c["sample"] = str(cb.get("sample", ""))[:160]
+        line["cpu_baseline"] = c
+    if "allreduce" in full:
+        line["allreduce"] = {k: full["allreduce"][k] for k in ("payload_bytes", "buckets", "collectives_per_step", "payload_dtype", "backend",
+                                                                 "world_size", "exposed_ms", "standalone_ms", "busbw_GBps", "engine")
+                             if k in full["allreduce"]}
+    for prec in ("bf16x3", "f16x2"):
+        alt = full.get(prec)
+        if isinstance(alt, dict) and "ms_per_step" in alt:
+            line[prec] = {"ms_per_step": alt["ms_per_step"], "value": alt["value"], "frac": (alt.get("roofline") or {}).get("frac"),
+                          "max_abs_logit_err": alt.get("max_abs_logit_err")}
+    for name in ("configs2_train_bf16", "configs3_large_fwd_f32", "configs4_large_train_bf16"):
+        if name in full:
+            line[name] = _compact_side(full[name])
+    if "full_object" in full:
+        line["full_object"] = full["full_object"]
+    # a hard guarantee, not a hope: shed optional keys until the line fits
+    for victim in ("f16x2", "bf16x3", "forward_tflops", "comm", "configs3_large_fwd_f32", "configs4_large_train_bf16", "configs2_train_bf16",
+                   "allreduce", "full_object"):
+        if len(json.dumps(line)) < COMPACT_LIMIT:
+            break
+        line.pop(victim, None)
+    return line
+
+
+def emit(full):
+    """Full object -> gpurun_out/bench_full.json + stderr; compact line -> stdout (the last line, the only one on stdout)."""
+    path = os.path.join(ROOT, "gpurun_out", "bench_full.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(full, f)
+        full["full_object"] = "gpurun_out/bench_full.json (also on stderr)"
+    except OSError:
+        full["full_object"] = "stderr"
+    print("BENCH_FULL " + json.dumps(full), file=sys.stderr, flush=True)
+    out = json.dumps(compact_line(full))
+    assert len(out) < COMPACT_LIMIT, len(out)
+    print(out, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -945,7 +1056,7 @@ def main():
                 line["cpu_baseline"] = {"value": None, "unit": "audio-seconds/s", "cores": 0, "kind": "port",
                                         "sample": f"CPU baseline failed: {exc!r}"}
         line["bench_wall_s"] = round(time.perf_counter() - t_start, 1)
-        print(json.dumps(line), flush=True)
+        emit(line)
     if dist.is_initialized():
         dist.destroy_process_group()
 

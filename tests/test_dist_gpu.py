@@ -134,6 +134,20 @@ def test_two_ranks_on_one_gpu_drive_the_real_trainer(tmp_path, payload, overlap)
         assert np.array_equal(got[0]["w:" + n], got[1]["w:" + n]), n
 
 
+def _bench_objects(r):
+    """bench.py's contract: stdout carries ONE compact JSON line (< 4 KB: the driver keeps 8 KB of stdout and parses the last line),
+    the complete object is on stderr behind the tag BENCH_FULL (and in gpurun_out/bench_full.json)."""
+    import json
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    assert r.stdout.rstrip().splitlines()[-1] == lines[0]
+    assert len(lines[0]) < 4096, len(lines[0])
+    compact = json.loads(lines[0])
+    fulls = [ln for ln in r.stderr.splitlines() if ln.startswith("BENCH_FULL ")]
+    assert len(fulls) == 1
+    return compact, json.loads(fulls[0][len("BENCH_FULL "):])
+
+
 def test_bench_two_ranks_report_every_baseline_config_with_the_collective():
     """The one command the driver runs, at N = 2: `bench.py --gpus 2` self-launches two ranks under torch.distributed.run and its
     single JSON line must carry, beside the headline, BASELINE configs[2] / [3] / [4] -- the two training legs with the bucketed
@@ -149,9 +163,11 @@ def test_bench_two_ranks_report_every_baseline_config_with_the_collective():
            "--side-shrink", "8", "--no-cpu-baseline", "--no-alt"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    js = json.loads(lines[0])
+    compact, js = _bench_objects(r)
+    assert compact["n_gpus"] == 2 and compact["comm"]["backend"] == "gloo" and compact["roofline"]["frac"] > 0
+    for key in ("configs2_train_bf16", "configs4_large_train_bf16"):          # the compact line carries the measured collective
+        assert compact[key]["ms_per_step"] > 0 and compact[key]["frac"] > 0 and "exposed_ms" in compact[key]["allreduce"], compact[key]
+    assert compact["configs3_large_fwd_f32"]["value"] > 0
     assert js["n_gpus"] == 2 and js["comm"]["backend"] == "gloo" and js["comm"]["world_size"] == 2
     assert js["config"]["global_batch"] == 64 and js["roofline"]["frac"] > 0
     for key, train in (("configs2_train_bf16", True), ("configs3_large_fwd_f32", False), ("configs4_large_train_bf16", True)):
@@ -182,9 +198,8 @@ def test_bench_four_ranks_over_gloo_keep_the_eight_gpu_path_warm():
            "--side-shrink", "8", "--no-cpu-baseline", "--no-alt", "--no-profile"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    js = json.loads(lines[0])
+    compact, js = _bench_objects(r)
+    assert compact["n_gpus"] == 4 and compact["configs2_train_bf16"]["allreduce"]["standalone_ms"] > 0
     assert js["n_gpus"] == 4 and js["comm"]["world_size"] == 4 and js["config"]["global_batch"] == 128 and js["scaling"] == "weak"
     for key, buckets in (("configs2_train_bf16", 14), ("configs4_large_train_bf16", 26)):
         leg = js[key]

@@ -598,3 +598,43 @@ def test_split_sw_kernels_have_no_scratch_and_a_consistent_schedule():
     assert sum("gemm_split_sw_kernel" in n for n in names) >= 14, names
     bad = [(n, s) for n, s in zip(names, scratch) if "gemm_split_sw_kernel" in n and s != 0]
     assert not bad, bad
+
+
+def test_bench_stdout_line_is_compact_and_parseable():
+    """the driver keeps 8 KB of stdout and parses the last line, and round 5's 27 KB line came back `parsed: null`.
+    bench.compact_line() turns the complete object into the ONE stdout line: the contract keys, `roofline` / `cpu_baseline` as numbers
+    and a flat triple per side configuration, always < 4096 bytes.  Checked on the stored complete objects of round 5 (the
+    headline with every side leg, and the two training lines) and on a worst case whose strings are all oversized."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test3", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for name in ("r05_bench_n1.json", "r05_bench_n1_launched.json", "r05_bench_bf16_train_n1.json", "r05_bench_large_robust_bf16_train_n1.json"):
+        with open(os.path.join(root, "profiles", name)) as f:
+            full = json.loads(f.read().strip().splitlines()[-1])
+        line = json.dumps(bench.compact_line(full))
+        assert len(line) < bench.COMPACT_LIMIT == 4096, (name, len(line))
+        js = json.loads(line)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+            assert k in js, (name, k)
+        assert js["value"] == full["value"] and js["ms_per_step"] == full["ms_per_step"] and js["config"]["workload"]
+        assert js["roofline"]["frac"] == full["roofline"]["frac"] and js["roofline"]["bound"] == "mfma" and js["roofline"]["peak"] > 0
+        assert not any(k.endswith("_note") or k in ("clock_method", "traffic_unit", "op") for k in js["roofline"])
+        if "cpu_baseline" in full:
+            cb = js["cpu_baseline"]
+            assert cb["value"] == full["cpu_baseline"]["value"] and cb["cores"] and cb["kind"] == "port" and cb["sample"]
+            assert cb["legs"]["B=1"]["median"] <= cb["legs"]["B=1"]["best"] and cb["value_median"] <= cb["value"]
+        for side in ("configs2_train_bf16", "configs3_large_fwd_f32", "configs4_large_train_bf16"):
+            if side in full:
+                assert js[side]["ms_per_step"] == full[side]["ms_per_step"] and js[side]["frac"] == full[side]["roofline"]["frac"]
+    # worst case: every string blown up, every optional object present -> still under the limit, contract keys intact
+    full["config"]["workload"] = "w" * 5000
+    full["roofline"]["kernel"] = "k" * 5000
+    full["cpu_baseline"] = {"value": 1.0, "unit": "audio-seconds/s", "cores": 16, "kind": "port", "sample": "s" * 5000, "cpu_model": "m" * 40,
+                            "legs": {"B=1": {"audio_s_per_s_best": 2.0, "audio_s_per_s_median": 1.0}}}
+    for side in ("configs2_train_bf16", "configs3_large_fwd_f32", "configs4_large_train_bf16"):
+        full[side] = {"error": "e" * 5000}
+    line = json.dumps(bench.compact_line(full))
+    assert len(line) < 4096 and json.loads(line)["roofline"]["frac"] and json.loads(line)["cpu_baseline"]["value"] == 1.0
