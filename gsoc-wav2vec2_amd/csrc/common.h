@@ -44,6 +44,40 @@ int tune_int(const char* name, int dflt);      // getenv + atoi, read on every c
 constexpr int tune_int(const char*, int dflt) { return dflt; }
 #endif
 
+// ---- tile order of the large-tile GEMM kernels inside an XCD's run of tiles (round 6) ----
+// Every GEMM kernel hands each XCD (blockIdx % 8) one contiguous run of the linear tile order, so that tiles in flight together on
+// an XCD share operand panels in ITS L2 (4 MB).  With the linear order row-major (N fastest), the ~64 tiles an XCD has in flight are
+// 64 / tiles_n rows x ALL tiles_n columns: on the wide shapes (N = 3072 / 4096: 12 - 32 column tiles) that is 2 - 5 row panels of A
+// beside the WHOLE of B, streamed through L2 again for every such set -- PMC (profiles/hbm_traffic_configs.json, round 5): the bf16
+// q|k|v / FFN-up kernels of the large model fetched 577 MB per launch for 57 MB of operands, the fp32 256 x 128 instances 960 MB.
+// Grouped order: the run walks groups of `gm` tile rows, column-major inside a group; gm is the number of A row panels
+// (BM x K elements each) that fit a 3.25-MB share of the L2, so a group's A panels stay resident while B streams past them ONCE per
+// group instead of once per 64 tiles; the tiles in flight form a gm x (64 / gm) patch.  gm = 0 keeps the linear order (narrow N, the
+// weight-gradient form with its own shorter-dimension-fastest rule).  Bijective for any tile count (the last group is shorter).
+__device__ __forceinline__ void grouped_tile(int t, int tiles_m, int tiles_n, int gm, int& tm, int& tn) {
+    const int per = gm * tiles_n, grp = t / per, first = grp * gm;
+    const int rows = min(gm, tiles_m - first), tl = t - grp * per;
+    tn = tl / rows;
+    tm = first + (tl - tn * rows);
+}
+// host side: group height for a launch (0 = linear order).  a_panel_bytes = BM x K x element size; inflight = tiles an XCD runs at once
+inline int tile_group_rows(int tiles_m, int tiles_n, int64_t a_panel_bytes, int inflight) {
+    const int forced = tune_int("W2V2_TILE_GROUP", -1);
+    if (forced >= 0) return forced > tiles_m ? tiles_m : forced;
+    if (tiles_m < tiles_n || tiles_n < 6) return 0;      // narrow outputs: inflight / tiles_n rows x all columns is already the patch
+    int64_t gm = (int64_t)3407872 / (a_panel_bytes > 0 ? a_panel_bytes : 1);      // 3.25 MB of the 4-MB L2 for the resident A panels
+    const int need = (inflight + tiles_n - 1) / tiles_n;      // never fewer rows than the linear order has in flight
+    if (gm < need) gm = need;
+    if (gm < 2) gm = 2;
+    // an XCD's run covers tiles_m / 8 rows: split them into equal groups no taller than that (B streams past once per group)
+    const int rows_xcd = (tiles_m + 7) / 8;
+    if (gm < rows_xcd) {
+        const int ngroups = (int)((rows_xcd + gm - 1) / gm);
+        gm = (rows_xcd + ngroups - 1) / ngroups;
+    }
+    return (int)(gm > tiles_m ? tiles_m : gm);
+}
+
 // ---- kernel families (one row each in profiles/ and in the roofline) ------
 enum Family {
     FAM_CONV0_STATS = 0,   // conv0 recompute + per-(sample,channel) sum/sumsq   (HBM: wave read)

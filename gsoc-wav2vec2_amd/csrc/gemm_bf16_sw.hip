@@ -42,6 +42,8 @@ struct GemmSWArgs {
                                // from A's last existing row (finite) and from B's row just past the end, which the caller keeps all-zero
     int M, N, K, act;
     int tiles_m, tiles_n;
+    int gm = 0;                // grouped tile order: rows per group (common.h::grouped_tile); 0 = linear order
+    int stagger = 0;           // shader cycles the SECOND block of every CU's first pair waits before its first tile (0 = none): see the kernel
 #ifdef W2V2_TUNING
     unsigned long long* trace;
     int abl;
@@ -93,7 +95,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_sw_kernel(GemmSWArgs g) {
         bid = lin - z * nwg;
     }
     const bool m_fast = g.tiles_m < g.tiles_n;
-    const int tm = m_fast ? bid % g.tiles_m : bid / g.tiles_n, tn = m_fast ? bid / g.tiles_m : bid % g.tiles_n;
+    int tm = m_fast ? bid % g.tiles_m : bid / g.tiles_n, tn = m_fast ? bid / g.tiles_m : bid % g.tiles_n;
+    if (!TR && g.gm > 0) grouped_tile(bid, g.tiles_m, g.tiles_n, g.gm, tm, tn);      // wide outputs: gm x (64 / gm) patches in flight (common.h)
     const int m0 = tm * SW_BM, n0 = tn * SW_BN;
     const int zk = TR ? (z < g.kextra ? z : g.kextra) : 0;                  // K tiles the earlier (longer) slabs pushed this one back by
     const int nk = g.K / SW_BK + ((TR && z < g.kextra) ? 1 : 0);
@@ -304,6 +307,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_sw_kernel(GemmSWArgs g) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    // ---- phase stagger (round 6).  All 512 blocks of the first wave start together, run their K loops together -- two blocks of a
+    // CU sharing its matrix pipe, 2009 cycles per K tile each against 1420 alone (profiles/r03_gemm_bf16_sw_phase_trace_v2.txt) --
+    // and reach their epilogues together: the whole chip then stores at once (the 11 - 22 k-cycle epilogues of that trace are that
+    // burst, not the 3 k cycles the instructions need) while every matrix pipe idles, and the lock step survives from tile to
+    // tile.  The blocks dispatched second onto each CU (linear ids 256 .. 511 of the first wave) therefore start half a tile period
+    // late: while one block of a CU stores, the other has the pipe to itself, and the chip sees two half-size store bursts.
+    if (!TR && g.stagger > 0 && (int)blockIdx.z == 0 && (int)blockIdx.x >= 256 && (int)blockIdx.x < 512) {
+        const long long t0 = clock64();
+        while (clock64() - t0 < (long long)g.stagger) __builtin_amdgcn_s_sleep(32);
+    }
     // ---- prologue: ten items in flight; then the two read-only "phases" in front of K tile 0 (A_0, then B_0)
     issue(IC<0>{}, 0, 0); issue(IC<1>{}, 0, 1); issue(IC<2>{}, 0, 2); issue(IC<3>{}, 0, 3); issue(IC<4>{}, 0, 4); issue(IC<5>{}, 0, 5);
     issue(IC<0>{}, 1, 6); issue(IC<1>{}, 1, 7); issue(IC<2>{}, 1, 8); issue(IC<3>{}, 1, 9);
@@ -446,6 +459,11 @@ int launch_gemm_bf16_sw(const uint16_t* A16, int64_t lda, int64_t strideA, const
     g.M = M; g.N = N; g.K = K; g.act = act;
     g.tiles_m = (M + SW_BM - 1) / SW_BM;
     g.tiles_n = N / SW_BN;
+    {   // half a tile period: (entry + epilogue ~ 12 k cycles + K tiles x 2048 shared-pipe cycles) / 2, when every slot gets 2+ tiles
+        const int pct = tune_int("W2V2_SW_STAGGER_PCT", 0);
+        g.stagger = (pct > 0 && nbatch == 1 && g.tiles_m * g.tiles_n >= 1024) ? (int)((12000 + (int64_t)(K / SW_BK) * 2048) * pct / 100) : 0;
+    }
+    g.gm = nbatch == 1 ? tile_group_rows(g.tiles_m, g.tiles_n, (int64_t)SW_BM * K * 2, 64) : 0;      // (2 blocks x 32 CUs in flight per XCD)
     // which epilogue: bf16-only and fp32 outputs go through LDS when the strides allow 16-byte row pieces
     // (they issue 16-byte stores to C / C16 and 16-byte residual loads at z * strideC + row * ldc + 4 | 8 j: the bases and the batch
     //  stride must keep that alignment too, else the register epilogue -- ek 0, element-wise accesses -- takes the tile)

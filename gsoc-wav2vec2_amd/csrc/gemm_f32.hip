@@ -45,6 +45,7 @@ struct GemmArgs {
     int64_t lda, ldb, ldc, strideA, strideB, strideC;
     int M, N, K, act;
     int tiles_m, tiles_n;
+    int gm = 0;      // grouped tile order of the LDS-DMA kernel: rows per group (common.h::grouped_tile); 0 = linear order
 };
 
 __device__ __forceinline__ float ld_a(const float* A, const GemmArgs& g, int row, int k) {
@@ -244,7 +245,8 @@ __global__ __launch_bounds__(WM* WN * 64, MINW) void gemm_f32_dma_kernel(GemmArg
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
+    int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
+    if (g.gm > 0) grouped_tile(bid, g.tiles_m, g.tiles_n, g.gm, tm, tn);      // wide outputs: gm x (inflight / gm) patches per XCD (common.h)
     const int m0 = tm * BM, n0 = tn * BN;
     const int z = blockIdx.z;
     const float* __restrict__ A = g.A + (int64_t)z * g.strideA;
@@ -348,6 +350,9 @@ int launch_dma(GemmArgs& g, int nbatch, hipStream_t s) {
     g.tiles_n = (g.N + BN - 1) / BN;
     dim3 grid(g.tiles_m * g.tiles_n, 1, nbatch), block(WM * WN * 64);
     const size_t lds = 2 * (BM * BKT + BKT * BN) * sizeof(float);
+    // tiles an XCD has in flight: 32 CUs x the blocks of this instance a CU holds (LDS-bound; at least MINW / waves-per-SIMD)
+    const int per_cu = (int)(160 * 1024 / lds) < 1 ? 1 : (int)(160 * 1024 / lds) > 4 ? 4 : (int)(160 * 1024 / lds);
+    g.gm = nbatch == 1 ? tile_group_rows(g.tiles_m, g.tiles_n, (int64_t)BM * g.K * 4, 32 * per_cu) : 0;
     static std::atomic<bool> attr_set{false};   // (idempotent call; atomic so concurrent host threads agree on the flag)
     if (!attr_set && lds > 64 * 1024) {
         W2V2_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_dma_kernel<WM, WN, MINW, BKT, BM, BN>),

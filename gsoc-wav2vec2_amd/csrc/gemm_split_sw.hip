@@ -65,6 +65,7 @@ struct SplitSWArgs {
     int64_t lda, ldc, strideA, strideC;
     int M, N, K, act;
     int tiles_m, tiles_n;
+    int gm = 0;                // grouped tile order: rows per group (common.h::grouped_tile); 0 = linear order
 };
 
 enum { SS_FULL = 0, SS_PENULT = 1, SS_LAST = 2 };
@@ -106,8 +107,10 @@ __global__ __launch_bounds__(256, 2) void gemm_split_sw_kernel(SplitSWArgs g) {
     // (integer division runs on the VALU: readfirstlane brings the block-uniform tile coordinates back into SGPRs -- per-lane copies
     //  of them and of the offsets derived from them would have to be parked in scratch across the K loop)
     z = __builtin_amdgcn_readfirstlane(z);
-    const int tm = __builtin_amdgcn_readfirstlane(m_fast ? bid % g.tiles_m : bid / g.tiles_n);
-    const int tn = __builtin_amdgcn_readfirstlane(m_fast ? bid / g.tiles_m : bid % g.tiles_n);
+    int tm_ = m_fast ? bid % g.tiles_m : bid / g.tiles_n, tn_ = m_fast ? bid / g.tiles_m : bid % g.tiles_n;
+    if (g.gm > 0) grouped_tile(bid, g.tiles_m, g.tiles_n, g.gm, tm_, tn_);      // wide outputs: gm x (64 / gm) patches in flight (common.h)
+    const int tm = __builtin_amdgcn_readfirstlane(tm_);
+    const int tn = __builtin_amdgcn_readfirstlane(tn_);
     const int m0 = tm * SS_BM, n0 = tn * SS_BN;
     const int nk = g.K / SS_BK;                                     // even, >= 2
 
@@ -547,6 +550,7 @@ int launch_gemm_split_sw(Profiler* prof, int fmt, const uint16_t* A16, int64_t p
     g.M = M; g.N = N; g.K = K; g.act = act;
     g.tiles_m = (M + SS_BM - 1) / SS_BM;
     g.tiles_n = N / SS_BN;
+    g.gm = nbatch == 1 ? tile_group_rows(g.tiles_m, g.tiles_n, (int64_t)SS_BM * K * 2 * plane_count(fmt), 64) : 0;      // (A row panel: all its planes)
     const double np = plane_count(fmt);
     ProfScope ps(prof, FAM_GEMM_SPLIT, 2.0 * M * (double)N * K * nbatch,
                  nbatch * ((double)M * K * 2.0 * np + (double)M * N * (C ? 4.0 : 2.0 * np)) + 2.0 * np * (double)K * N, s);

@@ -638,3 +638,24 @@ def test_bench_stdout_line_is_compact_and_parseable():
         full[side] = {"error": "e" * 5000}
     line = json.dumps(bench.compact_line(full))
     assert len(line) < 4096 and json.loads(line)["roofline"]["frac"] and json.loads(line)["cpu_baseline"]["value"] == 1.0
+
+
+def test_grouped_tile_order_is_a_bijection():
+    """csrc/common.h::grouped_tile (round 6: the order in which an XCD's run walks the output tiles of the wide GEMMs -- groups of gm
+    tile rows, column-major inside a group).  The same integer arithmetic restated here must visit every tile exactly once for any
+    tile counts and group height (the last group is shorter), and consecutive indices inside a group must stay within gm rows."""
+    def grouped_tile(t, tiles_m, tiles_n, gm):
+        per = gm * tiles_n
+        grp = t // per
+        first = grp * gm
+        rows = min(gm, tiles_m - first)
+        tl = t - grp * per
+        tn = tl // rows
+        return first + (tl - tn * rows), tn
+
+    for tiles_m, tiles_n, gm in ((188, 16, 10), (192, 12, 12), (48, 32, 2), (11, 6, 11), (11, 6, 4), (7, 9, 3), (1, 6, 1), (17, 8, 16)):
+        seen = [grouped_tile(t, tiles_m, tiles_n, gm) for t in range(tiles_m * tiles_n)]
+        assert sorted(seen) == [(m, n) for m in range(tiles_m) for n in range(tiles_n)], (tiles_m, tiles_n, gm)
+        for t in range(0, tiles_m * tiles_n - 64, 37):       # any 64 tiles in flight span at most two groups' rows
+            rows = {m for m, _ in seen[t:t + 64]}
+            assert max(rows) - min(rows) < 2 * gm + 64 // tiles_n + 1

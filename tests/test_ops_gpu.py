@@ -58,6 +58,8 @@ def stream():
     (64, 2304, 64, 0, True, False),      # packed qkv-like wide N
     (130, 100, 50, 2, True, True),       # K not a multiple of 32 -> guarded path
     (77, 30, 19, 1, True, False),        # nothing aligned
+    (1100, 896, 64, 0, True, True),      # 9 x 7 tiles of 128 x 128: the grouped tile order (common.h::grouped_tile), ragged last group
+    (2300, 1664, 48, 1, True, False),    # 9 x 13 tiles of 256 x 128 / 18 x 13 of 128 x 128: groups of several rows, ragged rows and columns
 ])
 def test_gemm_matches_numpy(env, M, N_, K, act, use_bias, use_res):
     lib, torch, dev = env
@@ -174,6 +176,8 @@ def _bf16_bits(torch, t):
     (1000, 2304, 768, 2, True, False, True, True),       # tanh GELU, both outputs
     (640, 768, 3072, 0, True, True, True, True),         # long K
     (130, 256, 256, 1, True, False, False, True),
+    (1300, 1536, 192, 0, True, True, True, True),        # 11 x 6 tiles: the grouped tile order (common.h::grouped_tile) with a short last group
+    (2050, 2048, 256, 1, True, False, False, True),      # 17 x 8 tiles, ragged last row tile, bf16-only output
     (8192 + 128, 768, 768, 0, True, True, True, True)])  # 25-MB outputs: tile pointers whose low word has bit 31 set (a sign-extended
                                                          # scalar base of the residual prefetch faulted from M = 8192 on)
 def test_gemm_bf16_shadow_kernels_agree_bit_for_bit(env, M, N_, K, act, use_bias, use_res, f32_out, b16_out):
@@ -387,7 +391,8 @@ def test_split_planes_represent_the_value(env, fmt_name):
 @pytest.mark.parametrize("fmt_name", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("M,N_,K,act,use_bias,use_res", [
     (128, 256, 64, 0, False, False), (300, 256, 128, 1, True, False), (1000, 768, 192, 0, True, True), (1, 256, 64, 0, True, False),
-    (2048, 768, 3072, 0, True, True), (515, 2304, 768, 2, True, False), (2100, 512, 1536, 1, True, False)])
+    (2048, 768, 3072, 0, True, True), (515, 2304, 768, 2, True, False), (2100, 512, 1536, 1, True, False),
+    (1300, 1536, 128, 0, True, True)])      # 11 x 6 tiles: the grouped tile order (common.h::grouped_tile) with a short last group
 def test_gemm_split_planes_is_fp32_grade(env, fmt_name, M, N_, K, act, use_bias, use_res):
     """The plane-fed GEMM of precision modes bf16x3 (six bf16 products of exact three-term splits) and f16x2 (three fp16 products of
     two-term splits): same bar as test_gemm_split_is_fp32_grade -- the fp32 tolerance against fp64 and an rms error no larger than

@@ -7,9 +7,9 @@ out=$O/abl_$tag.txt; echo "# A = $A, B = $B, bench.py $*" > $out
 for rep in $(seq 1 $reps); do
   for arm in A B; do
     lib=$A; [ $arm = B ] && lib=$B
-    line=$(W2V2_NATIVE_LIB=$R/$lib python $R/bench.py "$@" --no-cpu-baseline --no-side --no-alt 2>/dev/null | python -c "
+    line=$(W2V2_NATIVE_LIB=$R/$lib python $R/bench.py "$@" --no-cpu-baseline --no-side --no-alt 2>/dev/null >/dev/null; python -c "
 import sys,json
-d=json.loads(sys.stdin.read()); f=d.get('families',{})
+d=json.load(open('$R/gpurun_out/bench_full.json')); f=d.get('families',{})      # (stdout carries the compact line only: the complete object is in the file)
 print(d['ms_per_step'], d['roofline']['achieved'], ' '.join(f'{k}={v[\"ms_per_step\"]}' for k,v in f.items()))")
     echo "$arm rep $rep: $line" >> $out
   done
