@@ -43,7 +43,6 @@ struct GemmSWArgs {
     int M, N, K, act;
     int tiles_m, tiles_n;
     int gm = 0;                // grouped tile order: rows per group (common.h::grouped_tile); 0 = linear order
-    int stagger = 0;           // shader cycles the SECOND block of every CU's first pair waits before its first tile (0 = none): see the kernel
 #ifdef W2V2_TUNING
     unsigned long long* trace;
     int abl;
@@ -307,16 +306,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_sw_kernel(GemmSWArgs g) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    // ---- phase stagger (round 6).  All 512 blocks of the first wave start together, run their K loops together -- two blocks of a
-    // CU sharing its matrix pipe, 2009 cycles per K tile each against 1420 alone (profiles/r03_gemm_bf16_sw_phase_trace_v2.txt) --
-    // and reach their epilogues together: the whole chip then stores at once (the 11 - 22 k-cycle epilogues of that trace are that
-    // burst, not the 3 k cycles the instructions need) while every matrix pipe idles, and the lock step survives from tile to
-    // tile.  The blocks dispatched second onto each CU (linear ids 256 .. 511 of the first wave) therefore start half a tile period
-    // late: while one block of a CU stores, the other has the pipe to itself, and the chip sees two half-size store bursts.
-    if (!TR && g.stagger > 0 && (int)blockIdx.z == 0 && (int)blockIdx.x >= 256 && (int)blockIdx.x < 512) {
-        const long long t0 = clock64();
-        while (clock64() - t0 < (long long)g.stagger) __builtin_amdgcn_s_sleep(32);
-    }
+    // (Round 6, measured dead end: starting the second block of every CU's first pair half a tile period late -- so that one block of a CU
+    //  stores while the other has the matrix pipe, and the chip sees two half-size store bursts instead of one -- changed nothing:
+    //  base fine-tune step 31.75 - 31.86 ms without, 31.54 - 32.10 ms with 25 / 50 / 75 % of a period; large 93.4 - 93.9 vs 93.5 - 93.9,
+    //  profiles/r06_ab_gemm_stagger_*.txt.  The blocks do not stay in lock step long enough for it to matter.)
     // ---- prologue: ten items in flight; then the two read-only "phases" in front of K tile 0 (A_0, then B_0)
     issue(IC<0>{}, 0, 0); issue(IC<1>{}, 0, 1); issue(IC<2>{}, 0, 2); issue(IC<3>{}, 0, 3); issue(IC<4>{}, 0, 4); issue(IC<5>{}, 0, 5);
     issue(IC<0>{}, 1, 6); issue(IC<1>{}, 1, 7); issue(IC<2>{}, 1, 8); issue(IC<3>{}, 1, 9);
@@ -459,10 +452,6 @@ int launch_gemm_bf16_sw(const uint16_t* A16, int64_t lda, int64_t strideA, const
     g.M = M; g.N = N; g.K = K; g.act = act;
     g.tiles_m = (M + SW_BM - 1) / SW_BM;
     g.tiles_n = N / SW_BN;
-    {   // half a tile period: (entry + epilogue ~ 12 k cycles + K tiles x 2048 shared-pipe cycles) / 2, when every slot gets 2+ tiles
-        const int pct = tune_int("W2V2_SW_STAGGER_PCT", 0);
-        g.stagger = (pct > 0 && nbatch == 1 && g.tiles_m * g.tiles_n >= 1024) ? (int)((12000 + (int64_t)(K / SW_BK) * 2048) * pct / 100) : 0;
-    }
     g.gm = nbatch == 1 ? tile_group_rows(g.tiles_m, g.tiles_n, (int64_t)SW_BM * K * 2, 64) : 0;      // (2 blocks x 32 CUs in flight per XCD)
     // which epilogue: bf16-only and fp32 outputs go through LDS when the strides allow 16-byte row pieces
     // (they issue 16-byte stores to C / C16 and 16-byte residual loads at z * strideC + row * ldc + 4 | 8 j: the bases and the batch

@@ -533,10 +533,15 @@ def _load_names(attrs, key):
     return out
 
 
+TOP_LEVEL_GROUP = "top_level_model_weights"      # Keras >= 2.6: the model's own weights; a group that `layer_names` does not list
+
+
 def save_keras_weights(path, layers, keras_version="2.5.0", backend="tensorflow"):
-    """``layers``: [(layer_name, [(weight_name, array), ...]), ...] in ``model.layers`` order."""
+    """``layers``: [(layer_name, [(weight_name, array), ...]), ...] in ``model.layers`` order.  A group named
+    ``top_level_model_weights`` is written like any other but left out of ``layer_names`` (Keras' convention for weights no layer
+    owns: Keras 2.5's by-position loader never sees it, newer loaders and this package's read it)."""
     w = Writer(path)
-    _save_names(w, w.root, "layer_names", [name for name, _ in layers])
+    _save_names(w, w.root, "layer_names", [name for name, _ in layers if name != TOP_LEVEL_GROUP])
     w.set_attr(w.root, "backend", np.array(backend.encode("utf-8")))
     w.set_attr(w.root, "keras_version", np.array(keras_version.encode("utf-8")))
     for layer_name, weights in layers:
@@ -561,6 +566,8 @@ def load_keras_weights(path):
         for p, ds in root.visit_datasets().items():
             out[p] = ds.read()
         return out
+    if TOP_LEVEL_GROUP in root.members() and TOP_LEVEL_GROUP not in layer_names:
+        layer_names = layer_names + [TOP_LEVEL_GROUP]
     for layer in layer_names:
         g = root[layer]
         for wn in _load_names(g.attrs, "weight_names"):

@@ -132,29 +132,6 @@ def read_hf_state_dict(save_dir):
     return {k: v.detach().cpu().numpy() for k, v in sd.items()}
 
 
-def keras_layer_groups(model, weights, with_lm_head):
-    """Keras HDF5 grouping for the backbone-only model `Wav2Vec2Model`: one group per top-level layer (the 7 conv layers,
-    the feature projection, the encoder).  `masked_spec_embed` is a weight of the model itself, not of a sub-layer; it is
-    stored in a group named after the model.  (Loading is by variable name, so the grouping is not load-bearing here.)"""
-    groups, order = {}, []
-
-    def add(group, local, arr):
-        if group not in groups:
-            groups[group] = []
-            order.append(group)
-        groups[group].append((V.tf_variable_name(local, with_lm_head), arr))
-
-    for local, arr in weights.items():
-        parts = local.split("/")
-        if local.startswith("feature_extractor/conv_layers/"):
-            add("/".join(parts[:3]), local, arr)
-        elif parts[0] in ("feature_projection", "encoder", "lm_head"):
-            add(parts[0], local, arr)
-        else:
-            add("wav2vec2", local, arr)
-    return [(g, groups[g]) for g in order]
-
-
 def convert_hf_checkpoint(hf_dir, save_dir, with_lm_head=True):
     """The job of the reference's src/convert_torch_to_tf.py without TensorFlow and without a GPU: read a
     HuggingFace-PyTorch checkpoint directory, apply the HF -> TF name / layout map (file:12-44,110-117) and write
@@ -164,13 +141,7 @@ def convert_hf_checkpoint(hf_dir, save_dir, with_lm_head=True):
     weights = V.from_hf_state_dict(read_hf_state_dict(hf_dir), config, with_lm_head=with_lm_head)
     config.save_pretrained(save_dir)
     from . import h5lite
-    named = [(V.tf_variable_name(n, with_lm_head), a) for n, a in weights.items()]
-    if with_lm_head:
-        layers = [("wav2vec2", [(n, a) for n, a in named if "/lm_head/" not in n]), ("dropout", []),
-                  ("lm_head", [(n, a) for n, a in named if "/lm_head/" in n])]
-    else:
-        layers = keras_layer_groups(None, weights, False)
-    h5lite.save_keras_weights(os.path.join(save_dir, "tf_model.h5"), layers)
+    h5lite.save_keras_weights(os.path.join(save_dir, "tf_model.h5"), V.keras_layers(config, weights, with_lm_head))
     return config
 
 
@@ -376,14 +347,10 @@ class TFKerasModel(Layer):
 
     # ---- persistence (reference modeling.py:22-27, 41-84) -------------------
     def _keras_layers(self, weights):
-        """[(layer_name, [(TF variable name, array)])] in the order of the reference model's `.layers` -- the grouping Keras'
-        HDF5 weight format uses (one group per top-level layer)."""
-        named = [(V.tf_variable_name(n, self._prefix_with_head), a) for n, a in weights.items()]
-        if not self._with_lm_head:
-            # Wav2Vec2Model: masked_spec_embed is the model's own weight; sub-layers follow in tracking order
-            return keras_layer_groups(self, weights, self._prefix_with_head)
-        head = [(n, a) for n, a in named if "/lm_head/" in n]
-        return [("wav2vec2", [(n, a) for n, a in named if "/lm_head/" not in n]), ("dropout", []), ("lm_head", head)]
+        """[(layer_name, [(TF variable name, array)])]: groups in the order of the reference model's `.layers`, weights inside a
+        group in the order Keras lists them (wav2vec2/variables.py::keras_weight_order) -- what `load_weights` of a Keras-layout
+        HDF5 file zips against, position by position."""
+        return V.keras_layers(self.config, weights, self._prefix_with_head)
 
     def save_weights(self, path):
         """Keras' rule (`Model.save_weights`): a path ending in `.h5` / `.hdf5` / `.keras` is a Keras-layout HDF5 weight file,

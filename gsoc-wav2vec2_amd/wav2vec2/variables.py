@@ -73,6 +73,67 @@ def variable_specs(config, with_lm_head=True):
     return specs
 
 
+def keras_weight_order(config, with_lm_head=True):
+    """Local variable names in the order Keras (TF 2.5, the reference's version) lists the model's weights -- the order of the
+    ``weight_names`` attribute of each HDF5 group, which is what ``load_weights`` of a ``tf_model.h5`` zips against (by position
+    inside a top-level layer, NOT by name).  Derived from the reference's constructors by Keras' rules, no TF run (none exists
+    here):
+
+    * a ``Layer`` lists its OWN weights (``add_weight`` order) and then its tracked sub-layers in ATTRIBUTE-ASSIGNMENT order
+      (``__init__`` order, not call order); list attributes are tracked in list order.  Assignment order in the reference:
+      ``FeatureExtractorLayer``: conv_layer, layer_norm (feature_extractor.py:31-50) -- ``Conv1D`` kernel then bias,
+      ``GroupNormalization`` / ``LayerNormalization`` gamma then beta; ``FeatureProjection``: layer_norm, projection (:86-91);
+      ``Wav2Vec2Encoder``: pos_conv_embed, layer_norm, dropout, layers[i] (encoder.py:232-250); ``TransformerLayer``: attention
+      (q, k, v, projection: :15-18), dropout, layer_norm, intermediate, attn_output, final_layer_norm, stochastic_depth (:96-108).
+      This is the order ``variable_specs`` already uses, with two exceptions:
+    * ``Conv1DWithWeightNorm.build`` (tensorflow_addons.py:23-36) first runs ``Conv1D.build`` (kernel, bias), then REPLACES the
+      attribute ``kernel`` by a new ``tf.Variable(name="weight_v")`` -- Keras' ``__setattr__`` drops the replaced variable from
+      the layer's weight list and appends the new one -- and only then adds ``weight_g``: bias, weight_v, weight_g.
+    * ``Wav2Vec2Model`` is a ``tf.keras.Model``: ``Model.trainable_weights`` walks the tracked sub-objects FIRST and appends the
+      model's own ``_trainable_weights`` (``masked_spec_embed``, modeling.py:161-167) LAST.  [from the Keras 2.4 / 2.5 sources as
+      remembered: unverified here; loading in this package is by name, so this affects only files carried back to the reference]
+
+    The count pins the derivation to the reference's own output: 213 names for the base CTC model
+    (notebooks/wav2vec2_onnx.ipynb:125, "Total number of loaded variables: 213" -- a 214th, the orphaned ``kernel`` of the
+    positional conv, would appear if the replaced variable stayed listed)."""
+    specs = variable_specs(config, with_lm_head)
+    body = [n for n in specs if n != "masked_spec_embed" and not n.startswith("lm_head/")]
+    pc = "encoder/pos_conv_embed/conv/"
+    i = body.index(pc + "bias")
+    assert body[i:i + 3] == [pc + "bias", pc + "weight_g", pc + "weight_v"]
+    body[i:i + 3] = [pc + "bias", pc + "weight_v", pc + "weight_g"]
+    order = body + ["masked_spec_embed"]
+    if with_lm_head:
+        order += ["lm_head/kernel", "lm_head/bias"]
+    assert sorted(order) == sorted(specs)
+    return order
+
+
+def keras_layers(config, weights, with_lm_head):
+    """``[(group, [(TF variable name, array)])]`` of the Keras HDF5 weight file of one model, groups in ``model.layers`` order and
+    weights inside a group in ``keras_weight_order``.  ``Wav2Vec2ForCTC.layers`` = [wav2vec2, dropout, lm_head]
+    (modeling.py:227-229); ``Wav2Vec2Model.layers`` = the 7 conv layers, feature_projection, encoder -- its own weight
+    ``masked_spec_embed`` belongs to no layer: Keras 2.5 leaves it out of the file, Keras >= 2.6 stores such weights in the group
+    ``top_level_model_weights`` (not listed in ``layer_names``); it is written there, and read back from there by this package."""
+    order = keras_weight_order(config, with_lm_head)
+    named = lambda n: (tf_variable_name(n, with_lm_head), weights[n])
+    if with_lm_head:
+        return [("wav2vec2", [named(n) for n in order if not n.startswith("lm_head/")]), ("dropout", []),
+                ("lm_head", [named(n) for n in order if n.startswith("lm_head/")])]
+    groups, seq = {}, []
+    for n in order:
+        parts = n.split("/")
+        g = "/".join(parts[:3]) if n.startswith("feature_extractor/conv_layers/") else parts[0] if len(parts) > 1 else TOP_LEVEL_GROUP
+        if g not in groups:
+            groups[g] = []
+            seq.append(g)
+        groups[g].append(named(n))
+    return [(g, groups[g]) for g in seq]
+
+
+TOP_LEVEL_GROUP = "top_level_model_weights"      # Keras >= 2.6: weights of the model itself (no layer owns them)
+
+
 def tf_variable_name(local_name, with_lm_head=True):
     """Full TF variable name as the reference's converter spells it
     (convert_torch_to_tf.py:24-35,38-44)."""

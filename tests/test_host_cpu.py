@@ -659,3 +659,65 @@ def test_grouped_tile_order_is_a_bijection():
         for t in range(0, tiles_m * tiles_n - 64, 37):       # any 64 tiles in flight span at most two groups' rows
             rows = {m for m, _ in seen[t:t + 64]}
             assert max(rows) - min(rows) < 2 * gm + 64 // tiles_n + 1
+
+
+def test_keras_weight_order_of_tf_model_h5(tmp_path):
+    """`tf_model.h5` is loaded by the reference with Keras' `load_weights`, which zips the file's `weight_names`
+    against the layer's weights BY POSITION -- so the order inside each HDF5 group must be the order Keras creates / lists them
+    (variables.py::keras_weight_order, derived from the reference's constructors: modeling.py:158-167,227-233;
+    feature_extractor.py:31-50,86-91; encoder.py:15-20,96-108,168-175,232-245; tensorflow_addons.py:23-46).  Pinned here: 213 names
+    for the base CTC model (the count the reference itself prints, notebooks/wav2vec2_onnx.ipynb:125), the landmarks of the
+    order, and that the file written by save_pretrained carries exactly that order and still loads (by name) to the same weights."""
+    from wav2vec2 import h5lite, variables as V
+    from wav2vec2.config import RobustWav2Vec2Config, Wav2Vec2Config
+    cfg = Wav2Vec2Config()
+    order = V.keras_weight_order(cfg, with_lm_head=True)
+    assert len(order) == 213 and len(set(order)) == 213 and sorted(order) == sorted(V.variable_specs(cfg, True))
+    # sub-layers in attribute-assignment order: conv stack, projection, encoder; the model's own weight after them; the head last
+    assert order[0] == "feature_extractor/conv_layers/0/conv/kernel"
+    assert order[1:3] == ["feature_extractor/conv_layers/0/layer_norm/gamma", "feature_extractor/conv_layers/0/layer_norm/beta"]
+    assert order[3] == "feature_extractor/conv_layers/1/conv/kernel" and order[8] == "feature_extractor/conv_layers/6/conv/kernel"
+    assert order[9:13] == ["feature_projection/layer_norm/gamma", "feature_projection/layer_norm/beta",
+                           "feature_projection/projection/kernel", "feature_projection/projection/bias"]
+    # Conv1DWithWeightNorm.build: Conv1D's kernel is replaced by weight_v (appended after the bias), then weight_g is added
+    assert order[13:16] == ["encoder/pos_conv_embed/conv/bias", "encoder/pos_conv_embed/conv/weight_v", "encoder/pos_conv_embed/conv/weight_g"]
+    assert order[16:18] == ["encoder/layer_norm/gamma", "encoder/layer_norm/beta"]
+    l0 = [n[len("encoder/layers/0/"):] for n in order[18:34]]
+    assert l0 == ["attention/q_proj/kernel", "attention/q_proj/bias", "attention/k_proj/kernel", "attention/k_proj/bias",
+                  "attention/v_proj/kernel", "attention/v_proj/bias", "attention/out_proj/kernel", "attention/out_proj/bias",
+                  "layer_norm/gamma", "layer_norm/beta", "feed_forward/intermediate_dense/kernel", "feed_forward/intermediate_dense/bias",
+                  "feed_forward/output_dense/kernel", "feed_forward/output_dense/bias", "final_layer_norm/gamma", "final_layer_norm/beta"]
+    assert order[18 + 16 * 12] == "masked_spec_embed" and order[-2:] == ["lm_head/kernel", "lm_head/bias"]
+    # robust: conv bias + a LayerNorm on every conv layer -> 7 * 4 conv-stack names; 24 layers
+    rorder = V.keras_weight_order(RobustWav2Vec2Config(), True)
+    assert rorder[:4] == [f"feature_extractor/conv_layers/0/{s}" for s in ("conv/kernel", "conv/bias", "layer_norm/gamma", "layer_norm/beta")]
+    assert len(rorder) == 1 + 28 + 4 + 3 + 2 + 24 * 16 + 2
+
+    # the file: tiny model, CTC form -- groups [wav2vec2, dropout, lm_head], weight_names in Keras order, `:0` suffixes, full prefix
+    tiny = Wav2Vec2Config(hidden_size=32, num_heads=2, num_layers=2, intermediate_size=64, filter_sizes=[16] * 7,
+                          num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4)
+    w = V.seeded_weights(tiny, seed=3)
+    path = str(tmp_path / "tf_model.h5")
+    h5lite.save_keras_weights(path, V.keras_layers(tiny, w, True))
+    f = h5lite.File(path)
+    assert h5lite._load_names(f.root.attrs, "layer_names") == ["wav2vec2", "dropout", "lm_head"]
+    names = h5lite._load_names(f.root["wav2vec2"].attrs, "weight_names")
+    want = [V.tf_variable_name(n, True) for n in V.keras_weight_order(tiny, True) if not n.startswith("lm_head/")]
+    assert names == want and names[-1] == "wav2vec2-ctc/wav2vec2/masked_spec_embed:0"
+    assert h5lite._load_names(f.root["lm_head"].attrs, "weight_names") == ["wav2vec2-ctc/lm_head/kernel:0", "wav2vec2-ctc/lm_head/bias:0"]
+    got = h5lite.load_keras_weights(path)
+    assert set(got) == {V.tf_variable_name(n, True) for n in w}
+    assert all(np.array_equal(got[V.tf_variable_name(n, True)], a) for n, a in w.items())
+
+    # backbone form: one group per layer of `Wav2Vec2Model.layers`; masked_spec_embed (no layer owns it) in `top_level_model_weights`,
+    # which `layer_names` does not list (Keras 2.5's by-position loader counts 9 layers with weights in file and model alike)
+    wb = V.seeded_weights(tiny, seed=3, with_lm_head=False)
+    pathb = str(tmp_path / "backbone.h5")
+    h5lite.save_keras_weights(pathb, V.keras_layers(tiny, wb, False))
+    fb = h5lite.File(pathb)
+    assert h5lite._load_names(fb.root.attrs, "layer_names") == [f"feature_extractor/conv_layers/{i}" for i in range(7)] + ["feature_projection", "encoder"]
+    assert h5lite._load_names(fb.root["top_level_model_weights"].attrs, "weight_names") == ["wav2vec2/masked_spec_embed:0"]
+    enc = h5lite._load_names(fb.root["encoder"].attrs, "weight_names")
+    assert enc[:3] == ["wav2vec2/encoder/pos_conv_embed/conv/bias:0", "wav2vec2/encoder/pos_conv_embed/conv/weight_v:0", "wav2vec2/encoder/pos_conv_embed/conv/weight_g:0"]
+    gotb = h5lite.load_keras_weights(pathb)
+    assert set(gotb) == {V.tf_variable_name(n, False) for n in wb} and np.array_equal(gotb["wav2vec2/masked_spec_embed:0"], wb["masked_spec_embed"])
