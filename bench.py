@@ -518,7 +518,8 @@ def run_leg(ctx, spec, model=None):
     if mode == "train":
         labels_dev = torch.from_numpy(make_labels(B, rank)).to(dev)
         model.freeze_feature_extractor()                      # stage 2 of the reference (main.py:234-237)
-        trainer = W.Trainer(model, W.CTCLoss(cfg, (B, L), division_factor=world * B), learning_rate=1e-4, seed=rank)
+        trainer = W.Trainer(model, W.CTCLoss(cfg, (B, L), division_factor=world * B), learning_rate=1e-4, seed=rank,
+                            collective=ctx.get("collective", "torch"))
 
         def step(all_reduce=True):
             return trainer.step(x, labels_dev, attention_mask=amask, all_reduce=all_reduce)
@@ -558,7 +559,9 @@ def run_leg(ctx, spec, model=None):
         ar = {"payload_bytes": payload, "buckets": buckets, "collectives_per_step": colls, "payload_dtype": trainer.allreduce_dtype,
               "op": "SUM all-reduce of the trainable slots of the flat gradient buffer, one per bucket (lm_head, encoder layers N-1 .. 0, front) "
                     "on a communication stream behind that bucket's completion event, under the rest of the backward (Trainer.all_reduce_gradients)",
-              "backend": ctx["comm"]["backend"], "world_size": world}
+              "backend": ctx["comm"]["backend"], "world_size": world,
+              "engine": {"torch": "torch.distributed all_reduce per run (RCCL)", "native": "library: ncclAllReduce per bucket on its own stream (csrc/comm.hip)",
+                         "native-rs": "library: ncclReduceScatter + ncclAllGather per bucket on its own stream (csrc/comm.hip)"}[trainer.collective]}
         if world > 1:
             for _ in range(1):
                 step(all_reduce=False)
@@ -860,6 +863,9 @@ def main():
     ap.add_argument("--mode", choices=["forward", "train"], default="forward",
                     help="forward = BASELINE configs[1] (the headline metric); train = one CTC fine-tune step "
                          "(BASELINE configs[2] shape, fp32: forward + CTC + backward + gradient all-reduce + Adam)")
+    ap.add_argument("--collective", choices=["torch", "native", "native-rs"], default=os.environ.get("W2V2_BENCH_COLLECTIVE", "torch"),
+                    help="engine of the gradient SUM in the training legs: torch.distributed (default), or the library's own RCCL communicator "
+                         "(include/w2v2.h w2v2_allreduce_bucket): native = ncclAllReduce, native-rs = ncclReduceScatter + ncclAllGather; needs --backend nccl")
     ap.add_argument("--backend", default=os.environ.get("W2V2_BENCH_BACKEND", "nccl"),
                     help="process-group backend: nccl (= RCCL, the default and the only one a result may be quoted on); gloo exists so the "
                          "N > 1 code path can be exercised by two processes on ONE GPU, which RCCL refuses (tests/test_dist_gpu.py)")
@@ -911,7 +917,9 @@ def main():
         os.dup2(saved_fd, 1)
         os.close(saved_fd)
     comm = D.describe()                           # what the process group itself reports (echoed in the JSON line)
-    ctx = {"torch": torch, "D": D, "W": wav2vec2, "dev": dev, "world": world, "rank": rank, "comm": comm}
+    if args.collective != "torch" and world > 1 and args.backend != "nccl":
+        raise SystemExit("--collective native needs one GPU per rank (RCCL): use it with --backend nccl")
+    ctx = {"torch": torch, "D": D, "W": wav2vec2, "dev": dev, "world": world, "rank": rank, "comm": comm, "collective": args.collective}
 
     spec = {"model": args.model, "precision": args.precision, "mode": args.mode, "B": args.batch, "L": args.samples,
             "steps": args.steps, "warmup": args.warmup, "profile": not args.no_profile}

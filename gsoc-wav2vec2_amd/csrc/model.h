@@ -80,6 +80,7 @@ struct w2v2_model {
     std::unordered_map<const float*, SplitImages> wimg[2];   // [PlaneFmt], keyed by the fp32 matrix
     w2v2::Profiler* prof = nullptr;
     struct TrainState* train = nullptr;      // owned by w2v2_train.hip (null until the first training call)
+    struct Comm* comm = nullptr;             // owned by comm.hip: the native RCCL communicator (null until w2v2_comm_init)
 
     float* P(const std::string& n) const {
         auto it = index.find(n);
@@ -108,3 +109,7 @@ int w2v2_split_images(w2v2_model* m, const float* W, int K, int N, int fmt, hipS
 // implemented in w2v2_train.hip
 void w2v2_train_destroy(w2v2_model* m);
 void w2v2_train_invalidate(w2v2_model* m);
+// the contiguous runs of TRAINABLE slots (offset, numel; 16-byte aligned slots merge) inside gradient bucket k, and the flat buffer
+int w2v2_train_trainable_runs(w2v2_model* m, int k, std::vector<std::pair<int64_t, int64_t>>* runs, float** grads);
+// implemented in comm.hip
+void w2v2_comm_free(w2v2_model* m);

@@ -539,6 +539,7 @@ int w2v2_create(const w2v2_config* cfg, w2v2_model** out) {
 
 void w2v2_destroy(w2v2_model* m) {
     if (!m) return;
+    w2v2_comm_free(m);
     w2v2_train_destroy(m);
     free_workspace(m);
     for (auto& p : m->params)

@@ -1545,3 +1545,27 @@ int w2v2_op_dropout(const float* x, const float* residual, float* y, int64_t n, 
 }
 
 }  // extern "C"
+
+// What a data-parallel SUM all-reduce of bucket k has to send (comm.hip; the host-side mirror is wav2vec2/dist.py::trainable_ranges):
+// the runs of trainable slots, adjacent slots merged (a slot is its variable rounded up to 4 floats; the padding rides along, it is
+// zero on every rank).  Frozen slots -- the conv stack in stage 2 (main.py:234-237), everything but lm_head in stage 1 -- stay home.
+int w2v2_train_trainable_runs(w2v2_model* m, int k, std::vector<std::pair<int64_t, int64_t>>* runs, float** grads) {
+    W2V2_REQUIRE(m && runs, "trainable_runs: null argument");
+    int64_t lo = 0, n = 0;
+    if (int e = w2v2_train_bucket(m, k, &lo, &n)) return e;
+    if (int e = ensure_persistent(m)) return e;
+    TrainState* t = m->train;
+    const int64_t hi = lo + n;
+    runs->clear();
+    for (size_t i = 0; i < m->params.size(); ++i) {
+        const int64_t off = t->goff[i];
+        if (off < lo || off >= hi || !t->trainable[i]) continue;
+        int64_t end = off + ((m->params[i].numel + 3) & ~(int64_t)3);
+        if (end > hi) end = hi;
+        if (!runs->empty() && runs->back().first + runs->back().second == off) runs->back().second = end - runs->back().first;
+        else runs->emplace_back(off, end - off);
+    }
+    if (grads) *grads = t->grads;
+    return W2V2_OK;
+}
+

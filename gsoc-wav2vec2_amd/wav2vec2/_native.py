@@ -75,6 +75,14 @@ PROTOTYPES = {
     "w2v2_train_bucket": (C.c_int, [_P, _I32, C.POINTER(_I64), C.POINTER(_I64)]),
     "w2v2_train_bucket_wait": (C.c_int, [_P, _I32, _P]),
     "w2v2_grad_slot": (C.c_int, [_P, C.c_char_p, C.POINTER(_I64), C.POINTER(_I64)]),
+    "w2v2_comm_unique_id": (C.c_int, [_P, _I32]),
+    "w2v2_comm_init": (C.c_int, [_P, _P, _I32, _I32, _I32]),
+    "w2v2_comm_info": (C.c_int, [_P, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
+    "w2v2_comm_destroy": (C.c_int, [_P]),
+    "w2v2_allreduce_num_runs": (C.c_int, [_P, _I32, C.POINTER(_I32)]),
+    "w2v2_allreduce_run": (C.c_int, [_P, _I32, _I32, C.POINTER(_I64), C.POINTER(_I64)]),
+    "w2v2_allreduce_bucket": (C.c_int, [_P, _I32, _I32]),
+    "w2v2_allreduce_finish": (C.c_int, [_P, _P, C.POINTER(_I64)]),
     "w2v2_get_grad": (C.c_int, [_P, C.c_char_p, _P, _I64, _P]),
     "w2v2_train_storage": (C.c_int, [_P, C.POINTER(_I32), C.POINTER(_I64)]),
     "w2v2_adam_step": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, _I64, _P]),

@@ -48,6 +48,56 @@ def describe():
     return out
 
 
+COMM_ID_BYTES = 128          # include/w2v2.h: W2V2_COMM_ID_BYTES = sizeof(ncclUniqueId)
+
+
+def native_comm_init(model, rank=None, world=None, unique_id=None):
+    """Give `model` the library's own RCCL communicator (include/w2v2.h: w2v2_comm_init; csrc/comm.hip) -- the engine behind
+    `Trainer(..., collective="native")`.  Rank 0 draws the rendezvous id (w2v2_comm_unique_id) and the other ranks receive its 128
+    bytes: over the default torch.distributed group when one exists (any backend -- it carries bytes, not gradients), or from
+    `unique_id` when the host has its own channel (the torch-free stub of INTEGRATION.md section 3 passes it through a file).
+    Returns (rank, world)."""
+    import ctypes as C
+
+    from . import _native as N
+    if rank is None or world is None:
+        world, rank, _ = env_world()
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                world, rank = dist.get_world_size(), dist.get_rank()
+        except ImportError:
+            pass
+    lib = model._lib
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    if unique_id is not None:
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError(f"unique_id must be {COMM_ID_BYTES} bytes")
+        C.memmove(buf, bytes(unique_id), COMM_ID_BYTES)
+    else:
+        if rank == 0:
+            N.check(lib.w2v2_comm_unique_id(buf, COMM_ID_BYTES), "w2v2_comm_unique_id")
+        if world > 1:
+            import torch.distributed as dist
+            if not (dist.is_available() and dist.is_initialized()):
+                raise RuntimeError("native_comm_init: world > 1 needs a channel for the rendezvous id: pass unique_id, or initialise torch.distributed")
+            box = [bytes(buf) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            C.memmove(buf, box[0], COMM_ID_BYTES)
+    N.check(lib.w2v2_comm_init(model._handle, buf, COMM_ID_BYTES, int(rank), int(world)), "w2v2_comm_init")
+    return rank, world
+
+
+def native_comm_info(model):
+    """(rank, world, RCCL version code) of the model's native communicator; world 0 = none."""
+    import ctypes as C
+
+    from . import _native as N
+    r, w, v = C.c_int32(), C.c_int32(), C.c_int32()
+    N.check(model._lib.w2v2_comm_info(model._handle, C.byref(r), C.byref(w), C.byref(v)), "w2v2_comm_info")
+    return r.value, w.value, v.value
+
+
 def shard_bounds(total_rows, world, rank):
     """Contiguous [lo, hi) slice of a global batch for `rank`; the first total % world ranks take one
     extra row (the reference keeps a fixed 32 rows per replica, src/main.py:41,156)."""

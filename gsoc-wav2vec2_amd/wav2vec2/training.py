@@ -56,11 +56,18 @@ class Trainer:
     `allreduce_dtype`: "fp32" (default) or "bf16" -- the gradient payload of the data-parallel all-reduce."""
 
     def __init__(self, model, loss, learning_rate=1e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-7, seed=0,
-                 dropout=None, apply_spec_augment=None, overlap_all_reduce=True, reset_optimizer=True, allreduce_dtype="fp32"):
+                 dropout=None, apply_spec_augment=None, overlap_all_reduce=True, reset_optimizer=True, allreduce_dtype="fp32",
+                 collective="torch"):
         if not getattr(model, "_with_lm_head", False):
             raise ValueError("Trainer needs a Wav2Vec2ForCTC model")
         if allreduce_dtype not in ("fp32", "bf16"):
             raise ValueError("allreduce_dtype must be 'fp32' or 'bf16'")
+        if collective not in ("torch", "native", "native-rs"):
+            raise ValueError("collective must be 'torch', 'native' or 'native-rs'")
+        if collective != "torch" and allreduce_dtype != "fp32":
+            raise ValueError("the native collective reduces the fp32 gradient buffer in place: allreduce_dtype must be 'fp32'")
+        self.collective = collective      # engine of the gradient SUM: torch.distributed, or the library's own RCCL communicator
+                                          # (include/w2v2.h w2v2_allreduce_bucket; "native-rs" = reduce-scatter + all-gather)
         self.model, self.loss = model, loss
         self.learning_rate, self.beta_1, self.beta_2, self.epsilon = learning_rate, beta_1, beta_2, epsilon
         cfg = model.config
@@ -162,6 +169,8 @@ class Trainer:
         enough for the ring to run at link speed over xGMI, small enough that only the last one is exposed.  Only trainable
         slots travel (`reduce_ranges`); `allreduce_dtype="bf16"` halves the payload.
         `overlap_all_reduce=False` (constructor) issues the same ranges after the whole backward on the calling stream."""
+        if self.collective != "torch":
+            return self._all_reduce_native(force)
         import torch
         import torch.distributed as dist
         active = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)
@@ -196,6 +205,39 @@ class Trainer:
             for f in finishers:
                 f()               # (a compressed payload is copied back on the communication stream)
         torch.cuda.current_stream().wait_stream(cs)      # the optimizer step next waits for the collectives
+
+    def _all_reduce_native(self, force=False):
+        """The same protocol issued by the library (csrc/comm.hip): per bucket, its communication stream waits for that bucket's
+        event and SUMs the bucket's trainable runs in place over RCCL; the calling stream then waits for the communication stream.
+        The communicator is created on first use (wav2vec2/dist.py::native_comm_init)."""
+        m = self.model
+        _, world, _ = D.native_comm_info(m)
+        if world == 0:
+            _, world = D.native_comm_init(m)
+        if world <= 1 and not force:
+            return
+        algo = 1 if self.collective == "native-rs" else 0
+        nb = m._lib.w2v2_train_num_buckets(m._handle)
+        for k in range(nb):
+            N.check(m._lib.w2v2_allreduce_bucket(m._handle, k, algo), "w2v2_allreduce_bucket")
+        sent = C.c_int64()
+        N.check(m._lib.w2v2_allreduce_finish(m._handle, N.current_stream(), C.byref(sent)), "w2v2_allreduce_finish")
+        self._native_bytes_last = sent.value
+
+    def native_reduce_ranges(self):
+        """Per bucket the (offset, numel) runs the NATIVE collective sends (w2v2_allreduce_run): must equal `reduce_ranges()`."""
+        m = self.model
+        out = []
+        for k in range(m._lib.w2v2_train_num_buckets(m._handle)):
+            cnt = C.c_int32()
+            N.check(m._lib.w2v2_allreduce_num_runs(m._handle, k, C.byref(cnt)), "w2v2_allreduce_num_runs")
+            runs = []
+            for i in range(cnt.value):
+                off, n = C.c_int64(), C.c_int64()
+                N.check(m._lib.w2v2_allreduce_run(m._handle, k, i, C.byref(off), C.byref(n)), "w2v2_allreduce_run")
+                runs.append((off.value, n.value))
+            out.append(runs)
+        return out
 
     def apply_gradients(self):
         m = self.model

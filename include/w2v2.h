@@ -248,6 +248,34 @@ int w2v2_train_bucket_wait(w2v2_model* m, int32_t k, void* stream);
 /* Slot [offset, offset + numel) of one variable in the flat gradient / Adam buffers (inventory order, 16-byte aligned slots):
  * lets the caller send only the trainable runs of a bucket (the reference's payload excludes the frozen conv stack). */
 int w2v2_grad_slot(w2v2_model* m, const char* name, int64_t* offset, int64_t* numel);
+
+/* ---- native data-parallel collective (RCCL over xGMI; gsoc-wav2vec2_amd/csrc/comm.hip) ------------------------------------------
+ * The gradient SUM of the reference's MirroredStrategy step (src/main.py:148-156,192: one replica per device; :198-200: the loss is
+ * divided by the GLOBAL batch, so the cross-replica SUM of the gradients is the global-mean gradient) issued by the library itself:
+ * one process per GPU, one communicator per model.  RCCL is bound at run time (dlopen librccl.so.1; a copy the process already holds
+ * is reused), so hosts without it only lose these entry points (W2V2_ESTATE with the reason in w2v2_last_error).
+ *   w2v2_comm_unique_id    rank 0 draws the rendezvous id (W2V2_COMM_ID_BYTES bytes) and hands it to the other ranks by any channel
+ *                          the host has (a file, MPI, a TCP store: bytes, not a torch type);
+ *   w2v2_comm_init         every rank: ncclCommInitRank on the CURRENT device + the library's own high-priority communication stream;
+ *   w2v2_allreduce_bucket  in-place SUM of gradient bucket k's TRAINABLE runs (frozen slots are zero on every rank and stay home:
+ *                          90,195,104 + 768 elements = 360.8 MB for wav2vec2-base in stage 2) on the communication stream,
+ *                          which first waits for that bucket's completion event of the last enqueued backward -- and for nothing
+ *                          else: call it for k = 0 .. w2v2_train_num_buckets - 1 right after w2v2_train_backward and the upper layers'
+ *                          collectives run under the lower layers' backward.  algo 0 = ncclAllReduce; 1 = ncclReduceScatter +
+ *                          ncclAllGather over the run's world-divisible body (+ an all-reduce of the < world-element tail);
+ *   w2v2_allreduce_finish  `stream` (the optimizer's) waits for everything enqueued on the communication stream; *payload_bytes
+ *                          (may be NULL) = bytes reduced since the previous finish;
+ *   w2v2_allreduce_num_runs / _run   the (offset, numel) runs a bucket sends (tests; equal to wav2vec2/dist.py::trainable_ranges).
+ * Not thread-safe; every rank must make the same calls in the same order (RCCL's rule). */
+#define W2V2_COMM_ID_BYTES 128
+int w2v2_comm_unique_id(uint8_t* id_out, int32_t nbytes);
+int w2v2_comm_init(w2v2_model* m, const uint8_t* unique_id, int32_t nbytes, int32_t rank, int32_t world);
+int w2v2_comm_info(const w2v2_model* m, int32_t* rank, int32_t* world, int32_t* rccl_version);
+int w2v2_comm_destroy(w2v2_model* m);
+int w2v2_allreduce_num_runs(w2v2_model* m, int32_t k, int32_t* count);
+int w2v2_allreduce_run(w2v2_model* m, int32_t k, int32_t i, int64_t* offset, int64_t* numel);
+int w2v2_allreduce_bucket(w2v2_model* m, int32_t k, int32_t algo);
+int w2v2_allreduce_finish(w2v2_model* m, void* stream, int64_t* payload_bytes);
 /* Adam's moment buffers (device, flat, same layout as the gradient buffer): what a training checkpoint must carry besides
  * the variables and the step count (the reference's ModelCheckpoint writes a TF checkpoint, training_utils.py:38-45). */
 int w2v2_adam_buffers(w2v2_model* m, float** m_dev, float** v_dev, int64_t* numel);

@@ -185,26 +185,83 @@ def test_bench_two_ranks_report_every_baseline_config_with_the_collective():
     assert js["configs2_train_bf16"]["allreduce"]["payload_bytes"] == 4 * (90195104 + 768)      # 360.8 MB fp32 for base
 
 
-def test_bench_four_ranks_over_gloo_keep_the_eight_gpu_path_warm():
-    """The same command at N = 4 (four processes on the one GPU, gloo): the world size is no longer a power-of-two pair, the large model's
-    26 gradient buckets and the base model's 14 are all-reduced among four ranks inside the timed steps, the loss divisor is 4 x the
-    per-rank batch.  No number of this run is quotable (one GPU, host-staged collectives) -- it exists so that the driver's first real
-    `--gpus 8` run cannot fail on plumbing."""
-    import json
+def test_bench_eight_ranks_over_gloo_is_the_drivers_command():
+    """The driver's own 8-GPU command line (`bench.py --gpus 8`) with eight processes on the one GPU over gloo:
+    the world size the scaling run uses, the large model's 26 gradient buckets and the base model's 14 all-reduced among eight ranks
+    inside the timed steps, the loss divisor 8 x the per-rank batch -- and the ONE compact stdout line must carry, per training
+    leg, the measured collective (`allreduce.exposed_ms`, `standalone_ms`, `busbw_GBps`).  No number of this run is quotable (one GPU,
+    host-staged collectives) -- it exists so that the driver's first real `--gpus 8` run cannot fail on plumbing or on parsing."""
     import subprocess
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None), env.pop("RANK", None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--backend", "gloo", "--steps", "2", "--warmup", "1",
-           "--side-shrink", "8", "--no-cpu-baseline", "--no-alt", "--no-profile"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+           "--side-shrink", "16", "--no-cpu-baseline", "--no-alt", "--no-profile"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=2400, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     compact, js = _bench_objects(r)
-    assert compact["n_gpus"] == 4 and compact["configs2_train_bf16"]["allreduce"]["standalone_ms"] > 0
-    assert js["n_gpus"] == 4 and js["comm"]["world_size"] == 4 and js["config"]["global_batch"] == 128 and js["scaling"] == "weak"
+    assert compact["n_gpus"] == 8 and compact["config"]["global_batch"] == 256 and compact["scaling"] == "weak" and compact["value"] > 0
+    for key in ("configs2_train_bf16", "configs4_large_train_bf16"):
+        ar = compact[key]["allreduce"]
+        assert "exposed_ms" in ar and ar["standalone_ms"] > 0 and ar["busbw_GBps"] > 0, compact[key]
+    assert js["n_gpus"] == 8 and js["comm"]["world_size"] == 8 and js["config"]["global_batch"] == 256 and js["scaling"] == "weak"
     for key, buckets in (("configs2_train_bf16", 14), ("configs4_large_train_bf16", 26)):
         leg = js[key]
         assert "error" not in leg, leg
         ar = leg["allreduce"]
-        assert leg["n_gpus"] == 4 and ar["world_size"] == 4 and ar["buckets"] == buckets and ar["collectives_per_step"] >= buckets
-        assert ar["standalone_ms"] > 0 and np.isfinite(leg["final_loss"])
-    assert "error" not in js["configs3_large_fwd_f32"] and js["configs3_large_fwd_f32"]["global_batch"] == 4 * 2
+        assert leg["n_gpus"] == 8 and ar["world_size"] == 8 and ar["buckets"] == buckets and ar["collectives_per_step"] >= buckets
+        assert ar["standalone_ms"] > 0 and np.isfinite(leg["final_loss"]) and ar["engine"].startswith("torch.distributed")
+    assert "error" not in js["configs3_large_fwd_f32"] and js["configs3_large_fwd_f32"]["global_batch"] == 8 * 1
+
+
+# ---------------------------------------------------------------- the library's own RCCL collective (csrc/comm.hip) ----------
+@pytest.mark.parametrize("collective", ["native", "native-rs"])
+def test_native_collective_world_of_one(collective):
+    """the C ABI's own data-parallel collective (w2v2_comm_init / w2v2_allreduce_bucket / w2v2_allreduce_finish,
+    RCCL bound at run time).  One GPU here, so a world of ONE rank: what can be pinned is everything but the wire --
+      * the communicator comes up (w2v2_comm_unique_id -> ncclCommInitRank) with the library's own communication stream;
+      * the runs it sends per bucket are EXACTLY the host-side ranges of the torch engine (Trainer.reduce_ranges: frozen conv
+        stack excluded, adjacent trainable slots merged), in both training stages of the reference (main.py:210,234-237);
+      * a forced all-reduce over every bucket waits for the bucket events of the backward enqueued right before it, runs through
+        RCCL (both algorithms) and leaves the gradients bit-identical (SUM over one replica); the reported payload is the
+        reference's 4 bytes x trainable elements; the optimizer step behind it equals the torch-engine step bit for bit."""
+    import torch
+    from wav2vec2 import _native as N
+    from wav2vec2 import dist as D
+    x = _wave()
+    m_ref, tr_ref = _make_trainer(2, "fp32", True)
+    loss_ref = float(tr_ref.step(x, LABELS))
+    m, tr = _make_trainer(2, "fp32", True)
+    tr.collective = collective
+    assert D.native_comm_info(m)[1] == 0                            # no communicator yet
+    assert D.native_comm_init(m) == (0, 1)
+    r, w, ver = D.native_comm_info(m)
+    assert (r, w) == (0, 1) and ver >= 20000                        # RCCL reports NCCL-style version codes (2.26.6 -> 22606)
+    logits = tr.forward(x)
+    nll, grad = tr.loss.per_sample(LABELS, logits, with_grad=True)
+    tr.backward(grad)
+    torch.cuda.synchronize()
+    local = tr.grad_buffer().clone()
+    assert tr.native_reduce_ranges() == tr.reduce_ranges()
+    n_tr = sum(n for runs in tr.reduce_ranges() for _, n in runs)
+    tr.backward(grad)                                               # enqueue the backward again ...
+    tr.all_reduce_gradients(force=True)                             # ... and the library's per-bucket collectives right behind it
+    torch.cuda.synchronize()
+    assert torch.equal(tr.grad_buffer(), local) and tr._native_bytes_last == 4 * n_tr
+    tr.apply_gradients()
+    torch.cuda.synchronize()
+    assert abs(float(nll.sum()) - loss_ref) <= 1e-6 * abs(loss_ref)
+    for n in CHECK:
+        assert np.array_equal(m.get_weights()[n], m_ref.get_weights()[n]), n
+    # stage 1 of the reference: only lm_head trains -> one run, in bucket 0
+    m.layers[0].trainable = False
+    tr._ranges_cache = {}
+    logits = tr.forward(x)
+    nll, grad = tr.loss.per_sample(LABELS, logits, with_grad=True)
+    tr.backward(grad)
+    assert tr.native_reduce_ranges() == tr.reduce_ranges()
+    assert [len(r) for r in tr.native_reduce_ranges()] == [1] + [0] * (len(tr.reduce_ranges()) - 1)
+    tr.all_reduce_gradients(force=True)
+    torch.cuda.synchronize()
+    # a destroyed communicator refuses loudly
+    N.check(m._lib.w2v2_comm_destroy(m._handle), "w2v2_comm_destroy")
+    assert m._lib.w2v2_allreduce_bucket(m._handle, 0, 0) != 0 and b"no communicator" in m._lib.w2v2_last_error()
