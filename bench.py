@@ -585,8 +585,8 @@ def run_leg(ctx, spec, model=None):
             ar.update({"ms_per_step_without_collective": round(1e3 * e_no / steps, 3),
                        "exposed_ms": round(1e3 * (elapsed - e_no) / steps, 3),
                        "standalone_ms": round(1e3 * e_ar, 3),
-                       "busbw_GBps": round(payload * 2 * (world - 1) / world / e_ar / 1e9, 1),
-                       "algbw_GBps": round(payload / e_ar / 1e9, 1),
+                       "busbw_GBps": round(payload * 2 * (world - 1) / world / e_ar / 1e9, 3),
+                       "algbw_GBps": round(payload / e_ar / 1e9, 3),
                        "busbw_note": "payload x 2 (N - 1) / N / standalone time (ring all-reduce convention); xGMI: 7 links x ~153 GB/s per GPU"})
         else:
             ar["note"] = "one rank: no collective is issued (SUM over one replica is the identity); the N > 1 lines carry exposed_ms / busbw"
@@ -853,6 +853,8 @@ def main():
                     help="skip the other BASELINE configurations measured beside the headline (configs[2] bf16 fine-tune step, configs[3] "
                          "large-robust fp32 forward, configs[4] large bf16 fine-tune step at 480000 samples)")
     ap.add_argument("--side-shrink", type=int, default=1, help="(tests) divide the side legs' per-GPU batch by this factor")
+    ap.add_argument("--side-legs", default="configs2_train_bf16,configs3_large_fwd_f32,configs4_large_train_bf16",
+                    help="(tests) comma-separated subset of the side legs to run")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--model", choices=["base", "large-robust"], default="base",
                     help="base = wav2vec2-base (the headline); large-robust = 24L/1024d prenorm, LayerNorm convs, conv bias, "
@@ -1017,6 +1019,11 @@ def main():
                  "BASELINE configs[4] per-GPU shard: large (24L / 1024d; xlsr-53 is run as the robust architecture, SURVEY 8d) bf16 CTC fine-tune "
                  "step, 16 x 480000 per GPU (global batch 128 at 8 GPUs)")]
         keep = None                                            # the large model is built once and serves configs[3] and [4]
+        wanted = {n.strip() for n in args.side_legs.split(",") if n.strip()}
+        unknown = wanted - {n for n, _, _ in legs}
+        if unknown:
+            raise SystemExit(f"--side-legs: unknown leg(s) {sorted(unknown)}")
+        legs = [leg for leg in legs if leg[0] in wanted]
         for name, sp, label in legs:
             sp["profile"] = not args.no_profile
             t_leg = time.perf_counter()

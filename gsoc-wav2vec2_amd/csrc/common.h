@@ -349,10 +349,10 @@ int launch_ctc(Profiler* prof, const float* logits, int B, int T, int V, const i
                int U, const int32_t* label_len, const int32_t* logit_len, int blank, float* nll,
                float* grad, hipStream_t s);
 // ... with the reference's conventions evaluated on the device (losses.py:29-45): label_len null = count of labels != blank,
-// logit_len null = uniform_len frames for every row, the gradient x grad_scale (1 / division_factor), loss_sum (optional device
-// scalar) = sum_b nll[b] x grad_scale.  One call, no host-side tensor arithmetic around it.
+// logit_len null = uniform_len frames for every row, the gradient / grad_div (division_factor), loss_sum (optional device
+// scalar) = sum_b nll[b] / grad_div.  One call, no host-side tensor arithmetic around it.
 int launch_ctc_x(Profiler* prof, const float* logits, int B, int T, int V, const int32_t* labels, int U, const int32_t* label_len,
-                 const int32_t* logit_len, int uniform_len, int blank, float grad_scale, float* nll, float* grad, float* loss_sum, hipStream_t s);
+                 const int32_t* logit_len, int uniform_len, int blank, float grad_div, float* nll, float* grad, float* loss_sum, hipStream_t s);
 
 // ---- device helpers ---------------------------------------------------------
 #ifdef __HIPCC__

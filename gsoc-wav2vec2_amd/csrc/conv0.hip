@@ -451,6 +451,7 @@ int launch_conv0_x(Profiler* prof, const float* wave, const float* kernel, const
     const double out_bytes = ((out ? 4.0 : 0.0) + (out16 ? 2.0 : 0.0) + (pl.p ? 2.0 * plane_count(pl.fmt) : 0.0)) * B * (double)a.T0 * C, in_bytes = 4.0 * B * (double)L;
     const double flops = 2.0 * B * (double)a.T0 * C * K;
     if (norm_mode == 1) {
+        W2V2_REQUIRE(!pl.p || (reinterpret_cast<uintptr_t>(out16) & 7) == 0, "conv0: plane output needs an 8-byte aligned bf16 output");
         ProfScope ps(prof, FAM_CONV0_APPLY, flops, in_bytes + out_bytes, s);
         launch_mode<2>(a, B, s);
         W2V2_HIP_CHECK(hipGetLastError());
@@ -464,7 +465,7 @@ int launch_conv0_x(Profiler* prof, const float* wave, const float* kernel, const
                               reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0 &&
                             (reinterpret_cast<uintptr_t>(out16) & 7) == 0;
         if (!vec_ok) {          // other geometries: the plain conv, then the LayerNorm kernel in place
-            W2V2_REQUIRE(out, "conv0: this geometry needs the fp32 output buffer for its LayerNorm pass");
+            W2V2_REQUIRE(out && !pl.p, "conv0: this geometry needs the fp32 output buffer for its LayerNorm pass (and cannot write planes)");
             a.out16 = nullptr;
             {
                 ProfScope ps(prof, FAM_CONV0_APPLY, flops, in_bytes + 4.0 * B * (double)a.T0 * C, s);
@@ -506,6 +507,10 @@ int launch_conv0_x(Profiler* prof, const float* wave, const float* kernel, const
             W2V2_LAUNCH(conv0_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, B);
         }
     }
+    // (the plane output exists only in the 16-byte-store kernel, and launch_mode<1> also tests the alignment of the
+    //  scale / shift table and of the bf16 output before it picks that kernel -- the generic kernel would leave the planes unwritten)
+    W2V2_REQUIRE(!pl.p || ((reinterpret_cast<uintptr_t>(a.scale_shift) & 15) == 0 && (reinterpret_cast<uintptr_t>(out16) & 7) == 0),
+                 "conv0: plane output needs a 16-byte aligned workspace and an 8-byte aligned bf16 output");
     {
         ProfScope ps(prof, FAM_CONV0_APPLY, flops, in_bytes + out_bytes, s);
         launch_mode<1>(a, B, s);

@@ -45,7 +45,7 @@ struct CtcArgs {
     const int32_t* label_len; // (B), or null: the reference's rule, count of labels != blank (losses.py:32-33)
     const int32_t* logit_len; // (B), or null: every row takes uniform_len frames (losses.py:29-30)
     int uniform_len;
-    float grad_scale;         // the gradient is multiplied by it (1 / division_factor, losses.py:45)
+    float grad_div;           // the gradient is divided by it (division_factor, losses.py:45: `loss / division_factor`; TF's RealDiv gradient is g / y)
     float* nll;               // (B)
     float* grad;              // (B, T, V) or null
     double* alpha_ws;         // (B, T, S_max) when grad != null
@@ -266,15 +266,15 @@ __global__ __launch_bounds__(64) void ctc_grad_kernel(CtcArgs a) {
         }
     }
     __syncthreads();
-    // (x grad_scale as a separate fp32 multiplication: the same bits as scaling the fp32 gradient afterwards, and exact for 1.0)
-    for (int v = tid; v < a.V; v += 64) gr[v] = (float)(exp((double)lg[v] - lse) - (double)occ[v] * (1.0 / FIX)) * a.grad_scale;
+    // (/ grad_div as a separate fp32 division: the same bits as dividing the fp32 gradient afterwards, and exact for 1.0)
+    for (int v = tid; v < a.V; v += 64) gr[v] = (float)(exp((double)lg[v] - lse) - (double)occ[v] * (1.0 / FIX)) / a.grad_div;
 }
 
-// loss_sum[0] = sum_b nll[b] * scale, added in row order by one lane (Keras Reduction.SUM of the per-sample losses / division_factor)
-__global__ void ctc_loss_sum_kernel(const float* __restrict__ nll, int B, float scale, float* __restrict__ out) {
+// loss_sum[0] = sum_b nll[b] / div, added in row order by one lane (Keras Reduction.SUM of the per-sample losses / division_factor)
+__global__ void ctc_loss_sum_kernel(const float* __restrict__ nll, int B, float div, float* __restrict__ out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         float s = 0.f;
-        for (int b = 0; b < B; ++b) s += nll[b] * scale;
+        for (int b = 0; b < B; ++b) s += nll[b] / div;
         out[0] = s;
     }
 }
@@ -332,13 +332,13 @@ int launch_ctc(Profiler* prof, const float* logits, int B, int T, int V, const i
 }
 
 int launch_ctc_x(Profiler* prof, const float* logits, int B, int T, int V, const int32_t* labels, int U, const int32_t* label_len,
-                 const int32_t* logit_len, int uniform_len, int blank, float grad_scale, float* nll, float* grad, float* loss_sum, hipStream_t s) {
+                 const int32_t* logit_len, int uniform_len, int blank, float grad_div, float* nll, float* grad, float* loss_sum, hipStream_t s) {
     W2V2_REQUIRE(logits && labels && nll && (logit_len || uniform_len > 0), "ctc: null operand");
     W2V2_REQUIRE(B > 0 && T > 0 && V > 0 && U >= 0, "ctc: bad sizes");
     W2V2_REQUIRE(blank >= 0 && blank < V, "ctc: blank index %d outside vocabulary %d", blank, V);
     CtcArgs a;
     a.logits = logits; a.labels = labels; a.label_len = label_len; a.logit_len = logit_len;
-    a.uniform_len = uniform_len; a.grad_scale = grad_scale;
+    a.uniform_len = uniform_len; a.grad_div = grad_div;
     a.nll = nll; a.grad = grad; a.B = B; a.T = T; a.V = V; a.U = U; a.blank = blank;
     a.S_max = 2 * U + 1;
     a.alpha_ws = a.beta_ws = a.lse_ws = nullptr;
@@ -367,7 +367,7 @@ int launch_ctc_x(Profiler* prof, const float* logits, int B, int T, int V, const
     ProfScope ps(prof, FAM_CTC, 30.0 * B * (double)T * a.S_max, 4.0 * B * (double)T * V * (grad ? 2 : 1), s);
     W2V2_LAUNCH(ctc_kernel, dim3(B, grad ? 2 : 1), dim3(CTC_THREADS), lds, s, a);
     if (grad) W2V2_LAUNCH(ctc_grad_kernel, dim3(T, B), dim3(64), (size_t)V * sizeof(unsigned long long), s, a);
-    if (loss_sum) W2V2_LAUNCH(ctc_loss_sum_kernel, dim3(1), dim3(64), 0, s, nll, B, grad_scale, loss_sum);
+    if (loss_sum) W2V2_LAUNCH(ctc_loss_sum_kernel, dim3(1), dim3(64), 0, s, nll, B, grad_div, loss_sum);
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }

@@ -822,11 +822,20 @@ int w2v2_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, const i
     m->acts_skipped.clear();
     // (planes: a conv output whose one reader streams its planes is written ONLY as planes, like the bf16-only outputs of mode 1)
     auto planes_only_out = [&](int i) { return i + 1 < NC && cp[i + 1] && !keep; };
+    // the fused plane output needs conv0's 16-byte-store kernel (K = 10, stride 5); other geometries write fp32 and split it
+    const bool fused = NC > 1 && cp[1] && c.kernal_sizes[0] == 10 && c.strides[0] == 5 && 256 % (c.filter_sizes[0] / 4) == 0 && c.filter_sizes[0] / 4 <= 256;
+    // "convI" is not readable back exactly when the code below hands its producer a null fp32 destination (this used to be a
+    // second, looser predicate): conv0 fused into planes; a plane-fed GEMM whose output also goes out as planes only; a LayerNorm-mode
+    // layer whose LN + GELU pass writes bf16 / planes only (conv[i] then holds the pre-norm values); the bf16-only outputs of mode 1
+    auto f32_skipped = [&](int i) {
+        if (w2v2_conv_out_bf16_only(m, i, sh) || w2v2_conv_ln_bf16_only(m, i, sh)) return true;
+        if (i == 0) return NC > 1 && cp[1] && !keep && fused;
+        if (layer_mode) return planes_only_out(i);
+        return cp[i] && i + 1 < NC && cp[i + 1] && !keep;
+    };
     for (int i = 0; i + 1 < NC; ++i)
-        if (w2v2_conv_out_bf16_only(m, i, sh) || w2v2_conv_ln_bf16_only(m, i, sh) || planes_only_out(i)) m->acts_skipped.push_back("conv" + std::to_string(i));
+        if (f32_skipped(i)) m->acts_skipped.push_back("conv" + std::to_string(i));
     {
-        // the fused plane output needs conv0's 16-byte-store kernel (K = 10, stride 5); other geometries write fp32 and split it
-        const bool fused = NC > 1 && cp[1] && c.kernal_sizes[0] == 10 && c.strides[0] == 5 && 256 % (c.filter_sizes[0] / 4) == 0 && c.filter_sizes[0] / 4 <= 256;
         const PlaneOut po = fused ? PO(m->conv48[0]) : PlaneOut{};
         const bool f32_too = !(NC > 1 && cp[1]) || keep || !fused;
         if (int e = launch_conv0_x(pf, wave, fe(0, "/conv/kernel"), c.conv_bias ? fe(0, "/conv/bias") : nullptr,
@@ -987,9 +996,10 @@ int w2v2_ctc_loss(const float* logits, int32_t B, int32_t T, int32_t V, const in
 }
 
 int w2v2_ctc_loss_fused(const float* logits, int32_t B, int32_t T, int32_t V, const int32_t* labels, int32_t U, int32_t logit_length_all,
-                        int32_t blank, float scale, float* nll, float* grad, float* loss_sum, void* stream) {
+                        int32_t blank, float division_factor, float* nll, float* grad, float* loss_sum, void* stream) {
     W2V2_REQUIRE(logit_length_all > 0, "ctc_loss_fused: logit_length_all must be positive");
-    return launch_ctc_x(w2v2::tl_step_prof, logits, B, T, V, labels, U, nullptr, nullptr, logit_length_all, blank, scale, nll, grad, loss_sum,
+    W2V2_REQUIRE(division_factor > 0.f, "ctc_loss_fused: division_factor must be positive");
+    return launch_ctc_x(w2v2::tl_step_prof, logits, B, T, V, labels, U, nullptr, nullptr, logit_length_all, blank, division_factor, nll, grad, loss_sum,
                         reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -99,12 +99,23 @@ struct TrainState {
     // 3 = q|k|v; 33 x the kernel's size each: ~0.9 GB for base, 1.7 GB for large) and the per-block column sums of LayerNorm 2 / the FFN
     // dropout backward / LayerNorm 1 (site_ws).  The attention backward's column partials already have theirs (attn_colpart).
     float* site_slabs[4] = {nullptr, nullptr, nullptr, nullptr};
+    int64_t site_slab_floats[4] = {0, 0, 0, 0};
     float* site_ws[3] = {nullptr, nullptr, nullptr};
+    int64_t red_ws_floats = 0;        // size of red_ws (and of each of red_ws_side / site_ws[k] once they exist)
 };
+
+// Slabs a weight gradient of `elems` = Kin x Nout elements can be cut into: weight_grad's rule is tiles x S <= 512 blocks for the bf16
+// kernels (tiles of at most 128 x 256) and <= 2048 for the fp32 one (128 x 128), S <= 32 -- plus one slab of fold scratch.  (Round 5
+// allocated 33 slabs for every site whatever its shape: 0.93 GB for base, 1.66 GB for large, where this rule gives 0.50 / 0.59 GB.)
+static int64_t site_slab_count(int64_t elems) {
+    const int64_t s = ((int64_t)2048 * 16384 + elems - 1) / elems;
+    return (s < 32 ? s : 32) + 1;
+}
 
 // where a weight gradient puts its split-K slabs and who folds them
 struct WgSite {
     float* slabs = nullptr;           // own slab scratch (TrainState::site_slabs[k]); null: the shared TrainState::slabs
+    int64_t slab_floats = 0;          // its size
     FoldBatch* defer = nullptr;       // the slab fold joins this batch instead of running behind the GEMM
     float* unpack3[3] = {nullptr, nullptr, nullptr};      // q|k|v: the fold writes the three (H, H) kernels straight from the packed (H, 3H) slabs
     int unpackH = 0;
@@ -201,16 +212,33 @@ static int ensure_persistent(w2v2_model* m) {
         }
         t->slab_floats = 33 * (F * H > 3 * H * H ? F * H : 3 * H * H);      // 32 split-K slabs + the reduction scratch
         if (int e = p_alloc(t, &t->slabs, t->slab_floats)) return e;
-        {
-            const int64_t site_elems[4] = {F * H, H * F, H * H, 3 * H * H};
-            for (int k = 0; k < 4; ++k)
-                if (int e = p_alloc(t, &t->site_slabs[k], 33 * site_elems[k])) return e;
-        }
+        // (the per-site slab scratches of the deferred folds are allocated by the first backward that defers: ensure_site_scratch)
         t->cs_floats = 34 * (F > 3 * H ? F : 3 * H);
         if (int e = p_alloc(t, &t->cs_ws, t->cs_floats)) return e;
         if (int e = p_alloc(t, &t->dwqkv, 3 * H * H + 3 * H)) return e;
         if (int e = p_alloc(t, &t->dummy, 2 * (H + C + F))) return e;       // sink for gradients of frozen LN params
         t->transposes_fresh = false;
+    }
+    return W2V2_OK;
+}
+
+// Scratch that only some backward configurations use, allocated the first time one of them runs (it used to be allocated
+// for every model -- fp32 training, W2V2_OPT_DEFER_FOLDS = 0 and the side-stream mode included): the side stream's reduction scratch,
+// the deferred folds' per-site partial rows (shape-dependent: freed with the workspace) and per-site split-K slabs (persistent).
+static int ensure_site_scratch(w2v2_model* m, bool side, bool defer_cols, bool defer_slabs) {
+    TrainState* t = m->train;
+    if (side && !t->red_ws_side)
+        if (int e = t_alloc(t, &t->red_ws_side, t->red_ws_floats)) return e;
+    if (defer_cols && !t->site_ws[0])
+        for (int k = 0; k < 3; ++k)
+            if (int e = t_alloc(t, &t->site_ws[k], t->red_ws_floats)) return e;
+    if (defer_slabs && !t->site_slabs[0]) {
+        const int64_t H = m->cfg.hidden_size, F = m->cfg.intermediate_size;
+        const int64_t site_elems[4] = {F * H, H * F, H * H, 3 * H * H};
+        for (int k = 0; k < 4; ++k) {
+            t->site_slab_floats[k] = site_slab_count(site_elems[k]) * site_elems[k];
+            if (int e = p_alloc(t, &t->site_slabs[k], t->site_slab_floats[k])) return e;
+        }
     }
     return W2V2_OK;
 }
@@ -292,9 +320,9 @@ static int ensure_train_ws(w2v2_model* m, int B, int64_t L, int T, int lean) {
     const int64_t lw = ln_bwd_ws_floats(BT, (int)(H > C ? H : C));
     if (lw > rw) rw = lw;
     if (int e = t_alloc(t, &t->red_ws, rw + 16)) return e;
-    if (int e = t_alloc(t, &t->red_ws_side, rw + 16)) return e;
-    for (int k = 0; k < 3; ++k)
-        if (int e = t_alloc(t, &t->site_ws[k], rw + 16)) return e;
+    t->red_ws_side = nullptr;                    // (the side stream's scratch and the deferred folds' per-site scratch: allocated by the
+    t->site_ws[0] = t->site_ws[1] = t->site_ws[2] = nullptr;      //  first backward that uses them -- ensure_site_scratch)
+    t->red_ws_floats = rw + 16;
     if (int e = t_alloc(t, &t->dvec, (int64_t)B * c.num_heads * T)) return e;
     t->attn_colpart = nullptr;
     if (attention_bf16_supported((int)(H / c.num_heads)))
@@ -421,6 +449,9 @@ static int weight_grad(w2v2_model* m, const float* A, const float* dY, int M, in
         const int64_t max_blocks = direct ? dwb : 2048;
         int cap = 32;                                                   // most slabs worth having / that fit the scratch
         while (cap > 1 && (tiles * cap > max_blocks || (int64_t)(cap + 2) * Kin * Nout > t->slab_floats)) --cap;
+        // (a site's own scratch is sized for the most slabs the line above can give its shape -- site_slab_count; should that bound ever
+        //  be wrong the count shrinks to what fits instead of writing past the end: correct, though no longer the shared scratch's count)
+        while (cap > 1 && site && site->slabs && (int64_t)(cap + 1) * Kin * Nout > site->slab_floats) --cap;
         // S must divide the number of kq-row units; if M / kq has no useful divisor (a prime, say), give up to 15 more
         // units to the leftover slab until one appears
         // both bf16 shadows and whole 128 x 128 tiles: the LDS-DMA + transposing-read kernel; it has no fp32 dY in registers,
@@ -574,6 +605,9 @@ int w2v2_train_forward(w2v2_model* m, const float* wave, int32_t B, int64_t L, c
                        const uint8_t* spec_mask_host, const float* sd_keep_host, float dropout_p,
                        uint64_t seed, float* logits_out, void* stream) {
     W2V2_REQUIRE(m && wave && logits_out, "train_forward: null argument");
+    // ("f16x2" is an inference mode -- its range contract |activation| < 4094 is not watched by the training kernels, and
+    //  the step would silently run the six-product bf16x3 path instead)
+    W2V2_REQUIRE(m->precision != 3, "train_forward: precision f16x2 is an inference-forward mode; train in fp32, bf16 or bf16x3");
     W2V2_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "train_forward: dropout %f outside [0, 1)", dropout_p);
     // (the keep decisions compare 16 hash bits with floor(p 2^16): a positive p below that resolution would scale by 1 / (1 - p) in
     //  some kernels and not drop at all in others -- one predicate everywhere: every accepted p > 0 has a non-zero threshold)
@@ -930,9 +964,10 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
     //  One box, arms interleaved, profiles/r05_ab_defer_folds.txt: base step 33.80 / 33.55 / 33.50 ms, large-robust 98.38 / 97.94 / 97.74)
     const int defer_mode = (!side_on && m->opt_defer_folds) ? tune_int("W2V2_DEFER_FOLDS", 2) : 0;
     if (defer_mode != 0) fb = &fold;
+    if (int e = ensure_site_scratch(m, side_on, defer_mode != 0, defer_mode == 2)) return e;
     auto wg_site = [&](int k) {
         WgSite w;
-        if (defer_mode == 2) { w.slabs = t->site_slabs[k]; w.defer = fb; }
+        if (defer_mode == 2) { w.slabs = t->site_slabs[k]; w.slab_floats = t->site_slab_floats[k]; w.defer = fb; }
         return w;
     };
     float* const ln2_ws = fb ? t->site_ws[0] : t->red_ws;

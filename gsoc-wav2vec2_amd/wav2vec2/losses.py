@@ -29,8 +29,9 @@ class CTCLoss:
             input_length = 1 + (input_length - kernal_size) // stride
         return input_length
 
-    def per_sample(self, labels, logits, with_grad=False):
-        """Per-sample NLL (B,) [and d sum(nll) / d logits]; torch CUDA tensors."""
+    def per_sample(self, labels, logits, with_grad=False, with_total=False):
+        """Per-sample NLL (B,) [and d sum(nll) / d logits] [and the scalar the reference's `call` returns: sum_b nll_b / division_factor];
+        torch CUDA tensors."""
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("CTCLoss (MI355X build) needs a HIP device; there is no CPU fallback")
@@ -57,17 +58,19 @@ class CTCLoss:
         grad = torch.empty_like(logits) if with_grad else None
         total = torch.empty((1,), device=dev, dtype=torch.float32)
         lib = N.load()
-        # label lengths (count of labels != pad_id), the uniform logit length, the 1 / division_factor scaling of the gradient and
+        # label lengths (count of labels != pad_id), the uniform logit length, the division of loss and gradient by division_factor and
         # the SUM reduction are all evaluated by the native call: no framework kernel runs between the forward and the backward
-        N.check(lib.w2v2_ctc_loss_fused(N.ptr(logits), B, T, V, N.ptr(labels), U, logit_len, self.pad_id, 1.0 / float(self.division_factor),
+        N.check(lib.w2v2_ctc_loss_fused(N.ptr(logits), B, T, V, N.ptr(labels), U, logit_len, self.pad_id, float(self.division_factor),
                                         N.ptr(nll), N.ptr(grad), N.ptr(total), N.current_stream()), "w2v2_ctc_loss_fused")
-        self.last_total = total[0]            # sum_b nll_b / division_factor (what `__call__` returns), a 0-d device tensor view
+        self.last_total = total[0]            # sum_b nll_b / division_factor, a 0-d device tensor view (kept for callers that read the
+                                              # attribute; `total()` and `__call__` do not depend on it: two interleaved calls stay correct)
+        if with_total:
+            return (nll, grad, total[0]) if with_grad else (nll, total[0])
         if with_grad:
             return nll, grad                  # grad already / division_factor
         return nll
 
     def __call__(self, labels, hidden_states):
-        self.per_sample(labels, hidden_states)
-        return self.last_total
+        return self.per_sample(labels, hidden_states, with_total=True)[1]
 
     call = __call__

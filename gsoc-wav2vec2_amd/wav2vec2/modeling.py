@@ -309,8 +309,12 @@ class TFKerasModel(Layer):
         accumulation -- fp32-level results at the bf16 matrix cores' rate; forward GEMMs and attention, and the
         data-gradient GEMMs of the training step; csrc/gemm_split.hip, gemm_split_sw.hip, attention_split.hip), or "f16x2"
         (inference forward: every GEMM operand as TWO fp16 terms, three MFMA products per fp32 product -- half the matrix work
-        of "bf16x3" at a measured error at or below the fp32 kernel's; activations must stay below 4094 in magnitude, see
-        `range_overflow`)."""
+        of "bf16x3" at a measured error at or below the fp32 kernel's).
+
+        CONTRACT of "f16x2": activations must stay below 4094 in magnitude.  A forward that meets a larger one saturates it, sets a
+        sticky device flag and STILL RETURNS logits -- they are then not fp32-grade.  `model(x)` does not read the flag (that would
+        synchronise every forward); a caller that cannot bound its activations must poll `range_overflow()` after the forwards
+        it cares about and rerun those in "bf16x3" / "fp32".  Training in "f16x2" is refused (w2v2_train_forward)."""
         if precision not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(set(self.PRECISIONS))}, got {precision!r}")
         N.check(self._lib.w2v2_set_precision(self._handle, self.PRECISIONS[precision]), "w2v2_set_precision")

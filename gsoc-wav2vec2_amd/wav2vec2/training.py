@@ -305,8 +305,8 @@ class Trainer:
         own gradients): a MEASUREMENT switch -- bench.py times the step with and without it to report the exposed
         communication time -- never the training semantics of the reference (main.py:156,192)."""
         logits = self.forward(batch, attention_mask)
-        _, grad = self.loss.per_sample(labels, logits, with_grad=True)       # grad already / division_factor
-        total = self.loss.last_total                                         # sum_b nll_b / division_factor, summed on the device
+        _, grad, total = self.loss.per_sample(labels, logits, with_grad=True, with_total=True)    # grad already / division_factor;
+                                                                             # total = sum_b nll_b / division_factor, summed on the device
         self.backward(grad)
         if all_reduce:
             self.all_reduce_gradients()

@@ -203,10 +203,11 @@ int w2v2_ctc_loss(const float* logits_dev, int32_t B, int32_t T, int32_t V,
 /* The same with CTCLoss.call's conventions evaluated on the device, so that the caller issues no tensor arithmetic around the call
  * (the training step: no framework kernels between the forward and the backward; capturable):
  *   label_length = count of labels != blank per row (losses.py:32-33); logit_length = logit_length_all for every row (losses.py:29-30:
- *   the full frame count); grad_logits_dev = d(sum_b nll_b) / d logits x scale (scale = 1 / division_factor, losses.py:45);
- *   loss_sum_dev (optional device scalar) = sum_b nll_b x scale, added in row order (Keras Reduction.SUM, losses.py:6). */
+ *   the full frame count); grad_logits_dev = d(sum_b nll_b) / d logits / division_factor (losses.py:45: a DIVISION, as the reference
+ *   computes it -- multiplying by a rounded reciprocal differs by an ulp for factors that are not powers of two);
+ *   loss_sum_dev (optional device scalar) = sum_b (nll_b / division_factor), added in row order (Keras Reduction.SUM, losses.py:6). */
 int w2v2_ctc_loss_fused(const float* logits_dev, int32_t B, int32_t T, int32_t V, const int32_t* labels_dev, int32_t U,
-                        int32_t logit_length_all, int32_t blank, float scale, float* nll_dev, float* grad_logits_dev,
+                        int32_t logit_length_all, int32_t blank, float division_factor, float* nll_dev, float* grad_logits_dev,
                         float* loss_sum_dev, void* stream);
 
 /* ---- the training step (reference src/main.py:136-259) --------

@@ -187,30 +187,31 @@ def test_bench_two_ranks_report_every_baseline_config_with_the_collective():
 
 def test_bench_eight_ranks_over_gloo_is_the_drivers_command():
     """The driver's own 8-GPU command line (`bench.py --gpus 8`) with eight processes on the one GPU over gloo:
-    the world size the scaling run uses, the large model's 26 gradient buckets and the base model's 14 all-reduced among eight ranks
-    inside the timed steps, the loss divisor 8 x the per-rank batch -- and the ONE compact stdout line must carry, per training
-    leg, the measured collective (`allreduce.exposed_ms`, `standalone_ms`, `busbw_GBps`).  No number of this run is quotable (one GPU,
-    host-staged collectives) -- it exists so that the driver's first real `--gpus 8` run cannot fail on plumbing or on parsing."""
+    the world size the scaling run uses, the base model's 14 gradient buckets all-reduced among eight ranks inside the timed steps,
+    the loss divisor 8 x the per-rank batch -- and the ONE compact stdout line must carry the measured collective of the training
+    leg (`allreduce.exposed_ms`, `standalone_ms`, `busbw_GBps`).  Only configs[2] runs as a side leg here (`--side-legs`): gloo stages
+    every all-reduce through host memory, and the large model's 1.25-GB payload among eight processes takes minutes per step (the
+    two-rank test above runs all three legs).  No number of this run is quotable (one GPU, host-staged collectives) -- it exists so
+    that the driver's first real `--gpus 8` run cannot fail on plumbing or on parsing."""
     import subprocess
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None), env.pop("RANK", None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--steps", "2", "--warmup", "1",
-           "--side-shrink", "16", "--no-cpu-baseline", "--no-alt", "--no-profile"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=2400, env=env, cwd=ROOT)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--steps", "1", "--warmup", "1",
+           "--side-shrink", "16", "--side-legs", "configs2_train_bf16", "--no-cpu-baseline", "--no-alt", "--no-profile"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     compact, js = _bench_objects(r)
     assert compact["n_gpus"] == 8 and compact["config"]["global_batch"] == 256 and compact["scaling"] == "weak" and compact["value"] > 0
-    for key in ("configs2_train_bf16", "configs4_large_train_bf16"):
-        ar = compact[key]["allreduce"]
-        assert "exposed_ms" in ar and ar["standalone_ms"] > 0 and ar["busbw_GBps"] > 0, compact[key]
+    ar = compact["configs2_train_bf16"]["allreduce"]
+    assert "exposed_ms" in ar and ar["standalone_ms"] > 0 and ar["busbw_GBps"] > 0, compact["configs2_train_bf16"]
+    assert "configs3_large_fwd_f32" not in compact and "configs4_large_train_bf16" not in compact
     assert js["n_gpus"] == 8 and js["comm"]["world_size"] == 8 and js["config"]["global_batch"] == 256 and js["scaling"] == "weak"
-    for key, buckets in (("configs2_train_bf16", 14), ("configs4_large_train_bf16", 26)):
-        leg = js[key]
-        assert "error" not in leg, leg
-        ar = leg["allreduce"]
-        assert leg["n_gpus"] == 8 and ar["world_size"] == 8 and ar["buckets"] == buckets and ar["collectives_per_step"] >= buckets
-        assert ar["standalone_ms"] > 0 and np.isfinite(leg["final_loss"]) and ar["engine"].startswith("torch.distributed")
-    assert "error" not in js["configs3_large_fwd_f32"] and js["configs3_large_fwd_f32"]["global_batch"] == 8 * 1
+    leg = js["configs2_train_bf16"]
+    assert "error" not in leg, leg
+    ar = leg["allreduce"]
+    assert leg["n_gpus"] == 8 and leg["global_batch"] == 8 * 2 and ar["world_size"] == 8 and ar["buckets"] == 14 and ar["collectives_per_step"] >= 14
+    assert ar["standalone_ms"] > 0 and np.isfinite(leg["final_loss"]) and ar["engine"].startswith("torch.distributed")
+    assert ar["payload_bytes"] == 4 * (90195104 + 768)
 
 
 # ---------------------------------------------------------------- the library's own RCCL collective (csrc/comm.hip) ----------
