@@ -81,9 +81,10 @@ def test_logits_match_golden(torch_mod, name):
 # the BASELINE-size fixture): conv stack 4.3e-2, out-projection 3.5e-2, FFN up 3.4e-2, FFN down 2.9e-2, attention core 2.7e-2,
 # q|k|v 2.4e-2, lm_head 1.8e-2, projection 1.2e-2 -- independent contributions that add up (root-sum-square 8.2e-2) to the 7.8e-2 ... 8.4e-2
 # the oracle itself shows with everything rounded.  No single stage pays for it: the figure is the mode's definition.
-# Bars = 1.5 x the measured values of rounds 2-3 (max |logits - HF fp64|, max |logits - rounded-operand oracle|):
-BF16_LOGIT_BARS = {"tiny_base": (0.105, 0.042), "tiny_robust": (0.088, 0.063), "base_sample_unpadded": (0.109, 0.066),
-                   "robust_masked": (0.067, 0.042), "base_sample_padded": (0.155, 0.10)}      # measured padded: 0.084 ... 0.103 vs HF fp64
+# Bars: EXTERNAL only (round 6; before: a table of "1.5 x what rounds 2-3 measured").  tests/golden/hf_bf16_autocast.json holds, per fixture,
+# how far PyTorch's own bf16 rendering of the same HF model (torch.autocast(bfloat16), tests/golden/make_autocast_golden.py) lands from the
+# committed HF fp64 logits: 0.090 ... 0.141.  The HIP bf16 mode must be no further from HF fp64 than that, and no further from the
+# rounded-operand oracle (a second bf16 rendering of the same model) than that either.
 
 
 with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hf_bf16_autocast.json")) as _f:
@@ -109,11 +110,10 @@ def test_bf16_precision_logits(torch_mod, name):
     report(f"{name}/bf16_logits_vs_rounded_oracle", err)
     report(f"{name}/bf16_logits_vs_hf_f64", cost)
     assert np.isfinite(got).all()
-    bar_hf, bar_oracle = BF16_LOGIT_BARS[name]
-    assert err < bar_oracle and cost < bar_hf, (err, cost)
     # External pin (tests/golden/make_autocast_golden.py): PyTorch's own "this model in bf16" -- the fixture's HF model under
     # torch.autocast(bfloat16) -- moves the same logits by 0.090 ... 0.141 from HF fp64; the HIP bf16 mode must not err more than that.
     hf_autocast = HF_BF16_AUTOCAST[name]["autocast_bf16_max_abs_err"]
+    assert err <= hf_autocast, (err, hf_autocast)
     print(f"{name}: HF autocast(bf16) errs {hf_autocast:.3e} from HF fp64; this mode {cost:.3e} ({cost / hf_autocast:.2f} x)")
     report(f"{name}/bf16_logits_over_hf_autocast", cost / hf_autocast)
     assert cost <= hf_autocast, (cost, hf_autocast)
@@ -670,7 +670,7 @@ def test_bf16_mode_keeps_the_decoded_output(torch_mod):
     # Measured (round 4): 2.0e-2 on row 0 (909.8 -> 892.0 over 768 frames, i.e. a mean shift of 0.023 per frame log-probability),
     # 6.4e-3 on row 1.  The 2e-3 asked for in the round-3 review is not what this mode delivers on random-init weights, where every
     # frame's posterior is nearly flat and the NLL is a sum of 768 log-probabilities each carrying the mode's ~0.03 logit error with a
-    # common sign; the bar is 1.5 x the measurement, like the mode's other bars (BF16_LOGIT_BARS).
+    # common sign; the bar is 1.5 x the measurement (the reference states no bf16 tolerance; SURVEY 7, hard part 3).
     assert rel <= 3e-2
 
 

@@ -475,7 +475,7 @@ def test_bf16_precision_training_step(env, L, frames):
         loss, ref_nll, ref_logits, ref_grads = TT.loss_and_grads(cfg, w, x, labels, p=0.1, seed=42, spec_mask=spec, division_factor=2)
     err = H.max_err(logits.cpu().numpy(), ref_logits)
     print("bf16 training logits vs rounded-operand oracle", err)
-    assert err < 0.06                      # bf16-sized bar = 1.5 x measured (0.038-0.040), see tests/test_model_gpu.py::BF16_LOGIT_BARS
+    assert err < 0.06                      # bf16-sized bar: half of what HF's own torch.autocast(bf16) costs the tiny fixture (0.12, tests/golden/hf_bf16_autocast.json); measured 0.038-0.040
     assert np.allclose(nll.cpu().numpy(), ref_nll, rtol=2e-2)
     worst = grads_close(tr, ref_grads, rtol=5e-2)          # measured 2.6e-2 / 3.4e-2 of max|g|
     print("worst relative gradient error (bf16 operands)", worst)
