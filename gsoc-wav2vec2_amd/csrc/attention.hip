@@ -212,7 +212,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs a, AttnTrai
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const uint32_t col = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    s[kt][r] = dropout_keep32(drop_key, cbase + col, drop_thr) ? s[kt][r] : 0.f;
+                    s[kt][r] = dropout_keep32(drop_key, cbase + attention_drop_col(col), drop_thr) ? s[kt][r] : 0.f;
                 }
         }
 #pragma unroll
@@ -439,12 +439,12 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(AttnBwdArgs a, At
                     s[r] = key < a.T ? sv : -INFINITY;       // exp2(-inf) = 0: a padding key contributes nothing
                 }
             }
-            const uint32_t cbase = (uint32_t)rowbase + (uint32_t)(k0 + kt * 32 + 4 * lh);
+            const uint32_t cbase = (uint32_t)rowbase + (uint32_t)(k0 + kt * 32 + 8 * lh);      // attention_drop_col of the lane's keys: 16 a + 8 lh + 4 b + c
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float pv = exp_compensated(s[r] - lse);
                 float g = dp[r];
-                if (tr.p > 0.f) g = dropout_keep32(drop_key, cbase + (uint32_t)((r & 3) + 8 * (r >> 2)), drop_thr) ? g : 0.f;
+                if (tr.p > 0.f) g = dropout_keep32(drop_key, cbase + (uint32_t)((r & 3) + 4 * ((r >> 2) & 1) + 16 * (r >> 3)), drop_thr) ? g : 0.f;
                 s[r] = pv * fmaf(g, inv, -dv);
             }
             // dQ^T[d][q] += sum_key K[key][d] dS^T[key][q]
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(AttnBwdArgs a, A
     }
     const float inv = tr.p > 0.f ? 1.0f / (1.0f - tr.p) : 1.0f;
     const int64_t bh = (int64_t)b * a.heads + head;
-    const uint32_t drop_col = (uint32_t)((uint64_t)bh * a.T * attention_drop_stride(a.T)) + (uint32_t)kr;
+    const uint32_t drop_col = (uint32_t)((uint64_t)bh * a.T * attention_drop_stride(a.T)) + attention_drop_col((uint32_t)kr);
 
     f32x16 dk[DT], dvv[DT];
 #pragma unroll

@@ -155,195 +155,31 @@ __device__ __forceinline__ void load_col_frags(u32x4 (&f)[4], const uint16_t* p)
     for (int st = 0; st < 4; ++st) f[st] = *reinterpret_cast<const u32x4*>(p + 16 * st);
 }
 
-template <bool TRAIN>
-__global__ __launch_bounds__(NW * 64, 3) void attention_bf16_kernel(Attn16Args a, AttnTrain tr) {
-    constexpr int STAGE = 2 * IMG;           // K image, V image
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_a16[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    const int work = xcd_work(blockIdx.x, a.nwork);
-    const int bh = work / a.nqb, qb = work - bh * a.nqb;
-    const int b = bh / a.heads, head = bh - b * a.heads;
-    const int q0 = (qb * NW + wave) * 32;
-    const int ld = 3 * a.H;
-    const uint16_t* __restrict__ base = a.qkv16 + (int64_t)b * a.T * ld + head * DH;
-    const int flen = a.frame_len ? a.frame_len[b] : a.T;
-
-    TileDma dma;
-    dma.init(wave, lane);
-    TrOff tro;
-    tro.init(lane);
-    auto issue = [&](int tile, int buf) {
-        unsigned char* S = smem_a16 + buf * STAGE;
-        dma.issue(base + a.H, ld, tile * KT, a.T, S, wave);
-        dma.issue(base + 2 * a.H, ld, tile * KT, a.T, S + IMG, wave);
-    };
-    issue(0, 0);
-
-    // ---- Q fragments (B operand of S^T): lane = (query li, half lh), d = 16 st + 8 lh .. + 7 ----
-    u32x4 qf[4];
-    load_col_frags(qf, base + min(q0 + li, a.T - 1) * ld + 8 * lh);
-
-    f32x16 o[2];
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;     // running max (of the UNSCALED scores) and sum
-    // dropout hash inputs hoisted out of the tile loop: element index = ((b h + head) T + q) T + key, modulo 2^32
-    const uint32_t drop_key = TRAIN ? dropout_key(tr.seed, tr.stream) : 0u, drop_thr = TRAIN ? dropout_threshold(tr.p) : 0u;
-    const uint32_t thr1s_pk = dropout_thr1s_pk(drop_thr);
-    const uint32_t drop_row = (uint32_t)(((uint64_t)bh * a.T + (uint64_t)min(q0 + li, a.T - 1)) * attention_drop_stride(a.T));
-    const int xr = swz(li);                   // swizzle of this lane's fragment rows (sub * 32 + li: the sub-tile does not change it)
-
-    const int ntiles = (a.T + KT - 1) / KT;
-    __syncthreads();                          // (carries the vmcnt(0) that retires the DMA)
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const int k0 = tile * KT, buf = tile & 1;
-        issue(min(tile + 1, ntiles - 1), buf ^ 1);      // unconditional: see attention.hip (a branch here costs the DMA / compute overlap)
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned char* Ks = smem_a16 + buf * STAGE;
-        const unsigned char* Vs = Ks + IMG;
-
-        // ---- S^T = K Q^T for two 32-key sub-tiles: 8 MFMAs ----
-        f32x16 s[2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-#pragma unroll
-            for (int st = 0; st < 4; ++st)
-                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, kt * 32 + li, xr, st, lh), as_bf16x8(qf[st]), s[kt], 0, 0, 0);
-        }
-        // ---- mask + online softmax (lane owns query li; keys (r&3) + 8 (r>>2) + 4 lh) ----
-        // masking only on tiles that touch the valid-length / T boundary (wave-uniform branch), exp as one FMA-class op + v_exp_f32
-        if (k0 + KT > min(flen, a.T)) {
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    float v = s[kt][r];
-                    v = key >= flen ? v + MASK_BIAS : v;
-                    v = key >= a.T ? -INFINITY : v;           // tile padding: not a key at all
-                    s[kt][r] = v;
-                }
-        }
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * C2);   // exp2(-inf) = 0 on the first tile
-        // exponent = s C2 - m C2 as ONE fused multiply-add (round 4; before: (s - m) * C2, two instructions per score).  The product
-        // s C2 is exact inside the FMA; what is rounded is m C2, once per row: a relative error of 2^-24 |m C2| in every probability
-        // of the row -- 1e-6 at |m| = 100, against the 2^-9 the bf16 rounding of P commits next -- and the SAME factor in the row sum,
-        // so it cancels in the normalised output.  (A fully masked row, |m C2| = 1.4e4, would see 1e-3: such a row has no valid key
-        // and its output is discarded by the caller's mask.)
-        const float mc = -m_new * C2;
-        float rs = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], C2, mc));
-                s[kt][r] = p;
-                rs += p;
-            }
-        rs += __shfl_xor(rs, 32, 64);
-        l_run = l_run * alpha + rs;
-        m_run = m_new;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-
-        // ---- O^T += V^T P^T: 8 MFMAs; B = the packed accumulator registers, A = transposing reads of the V image ----
-        // Attention-probability dropout (encoder.py:42-44) is applied to the PACKED pairs: registers (2j, 2j + 1) of a sub-tile are keys
-        // (2i, 2i + 1) of an even-strided row = the two halves of one hash word = one packed bf16 pair, so a word's two decisions
-        // (train.h::dropout_keep_mask_pk: two packed 16-bit instructions) mask the pair with one AND and enter the keep word with one
-        // AND-OR.  (Round 3 masked the fp32 values one by one: extract, subtract, shift, AND, AND-OR per ELEMENT -- with the hash 60 % of
-        // this VALU-bound loop.)  The row sum above uses the un-dropped p; 1 / (1 - p) is applied once, with the final normalisation.
-        // cbase = drop_row + k0 is even (even row stride, k0 a multiple of 64), so pair = (cbase + col) / 2 = (cbase / 2 + 2 lh) + a
-        // compile-time constant: one multiply per tile, an add per hash word
-        const uint32_t pm0 = (((drop_row + (uint32_t)k0) >> 1) + 2u * (uint32_t)lh) * DROPOUT_FIB;
-        uint32_t bits = 0;
-        auto pv = [&](auto dropping) {          // (two instances chosen by ONE wave-uniform branch per tile: a test inside the loops became 16 branches)
-            constexpr bool DROP = decltype(dropping)::value;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    u32x4 pw;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int r = 8 * h + 2 * j;              // registers r, r + 1: keys 2i, 2i + 1
-                        pw[j] = pack_bf16(s[kt][r], s[kt][r + 1]);
-                        if (DROP) {
-                            const uint32_t cpair = (uint32_t)(kt * 16 + ((r & 3) >> 1) + 4 * (r >> 2));      // (col - 4 lh) / 2
-                            const uint32_t km = dropout_keep_mask_pk(dropout_word_premul(drop_key, pm0 + cpair * DROPOUT_FIB), thr1s_pk);
-                            pw[j] &= km;
-                            bits |= km & ((1u << (8 * kt + (r >> 1))) | (1u << (16 + 8 * kt + (r >> 1))));
-                        }
-                    }
-                    const bf16x8 pb = as_bf16x8(pw);
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt)
-                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols(Vs, tro, kt, h, dt), pb, o[dt], 0, 0, 0);
-                }
-        };
-        const bool drop = TRAIN && drop_thr != 0u;
-        if (drop) pv(std::true_type{});
-        else pv(std::false_type{});
-        if (drop && tr.keep_bits) tr.keep_bits[keep_word(bh, tile, lh, a.nqb) + q0 + li] = bits;
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();        // everyone is done with `buf`; the DMA into the other stage has landed
-    }
-
-    // ---- normalise and store: O^T rows are d = 32 dt + (r&3) + 8 (r>>2) + 4 lh, column = query ----
-    const int q = q0 + li;
-    if (TRAIN && q < a.T && lh == 0) tr.lse[(int64_t)bh * a.T + q] = m_run * SCALE + logf(l_run);
-    if (q < a.T) {
-        const float inv = ((TRAIN && drop_thr != 0u) ? 1.0f / (1.0f - tr.p) : 1.0f) / l_run;
-        const int64_t o0 = ((int64_t)b * a.T + q) * a.H + head * DH + 4 * lh;
-        if (a.ctx) {
-            float* op = a.ctx + o0;
-#pragma unroll
-            for (int d = 0; d < 2; ++d)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<f32x4*>(op + 32 * d + 8 * g) =
-                        f32x4{o[d][4 * g] * inv, o[d][4 * g + 1] * inv, o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv};
-        }
-        if (a.ctx16) {      // bf16 shadow for the out-projection GEMM
-            uint16_t* hp = a.ctx16 + o0;
-#pragma unroll
-            for (int d = 0; d < 2; ++d)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<u32x2*>(hp + 32 * d + 8 * g) =
-                        u32x2{pack_bf16(o[d][4 * g] * inv, o[d][4 * g + 1] * inv), pack_bf16(o[d][4 * g + 2] * inv, o[d][4 * g + 3] * inv)};
-        }
-    }
-}
-
-
-// ---- Round 5: the same forward, software-pipelined inside a wave (default; W2V2_ATTN16_PIPE = 0 in the tools-only build restores the
-// kernel above for A/B runs).  Why: PMC of the kernel above (profiles/r04_attention_bf16_pmc.md) shows 456 VALU instructions per 64-key
-// tile against 16 MFMAs -- VALU-bound 3.5 : 1 -- yet the VALU pipe only 41 % busy: within a wave the S MFMAs wait for the tile barrier
-// and their LDS reads, the softmax waits for the S MFMAs, every PV MFMA for its own transposing reads, and the four waves of a block
-// walk those phases in lock step.  Here a wave works on 32-key SUB-tiles and always has the NEXT sub-tile's four S MFMAs (and their
-// fragment reads) in flight under the softmax arithmetic of the current one:
+// ---- The forward, software-pipelined inside a wave (round 5; the plain two-stage kernel it replaced -- one barrier per 64-key tile, S
+// MFMAs, softmax, PV MFMAs in sequence -- was removed in round 6, A/B in profiles/r05_ab_attention_pipe.txt).  Why: PMC of the plain kernel
+// (profiles/r04_attention_bf16_pmc.md) showed 456 VALU instructions per 64-key tile against 16 MFMAs -- VALU-bound 3.5 : 1 -- yet the VALU
+// pipe only 41 % busy: within a wave the S MFMAs wait for the tile barrier and their LDS reads, the softmax waits for the S MFMAs, every
+// PV MFMA for its own transposing reads, and the four waves of a block walk those phases in lock step.  Here a wave works on 32-key
+// SUB-tiles and always has the NEXT sub-tile's four S MFMAs (and their fragment reads) in flight under the softmax arithmetic of the
+// current one:
 //     even step:   [ S(tile j, keys 32..63) -> sb   ||  softmax(sa) ]   rescale O   [ PV(sa) ]
 //     odd step:    barrier, DMA of tile j + 2       [ S(tile j + 1, keys 0..31) -> sa  ||  softmax(sb) ]   rescale O   [ PV(sb) ]
 // The online softmax runs per sub-tile (running max / sum updated every 32 keys); O is rescaled only when some lane's maximum moved
 // (a wave-uniform test: after the first tiles it almost never does).  K / V images sit in a three-slot ring: the odd step reads the
 // next tile while the current tile's V is still needed, and the one barrier per tile both publishes tile j + 1 and frees tile j - 1's
 // slot for the DMA of tile j + 2.  Same bf16 operands, fp32 scores / exponentials / sums as above; the probabilities are rounded to bf16
-// relative to a running maximum that is updated twice per tile instead of once, so the two kernels agree to bf16 rounding noise, not bit
-// for bit (the backward recomputes P from the saved log-sum-exp either way).
+// relative to a running maximum that is updated every 32 keys.
+// exp as one FMA-class op + v_exp_f32: exponent = s C2 - m C2 as ONE fused multiply-add (round 4; before: (s - m) * C2).  The product s C2 is
+// exact inside the FMA; what is rounded is m C2, once per row: a relative error of 2^-24 |m C2| in every probability of the row -- 1e-6 at
+// |m| = 100, against the 2^-9 the bf16 rounding of P commits next -- and the SAME factor in the row sum, so it cancels in the normalised
+// output.  (A fully masked row, |m C2| = 1.4e4, would see 1e-3: such a row has no valid key and its output is discarded by the caller's mask.)
+// Attention-probability dropout (encoder.py:42-44) is applied to the PACKED pairs: registers (2j, 2j + 1) of a sub-tile are the two halves
+// of one hash word = one packed bf16 pair, so a word's two decisions (train.h::dropout_keep_mask_pk: two packed 16-bit instructions) mask
+// the pair with one AND and enter the keep word with one bit-field insert; registers 8h .. 8h + 7 are one OCT of the hash (train.h: one
+// mixer round and two 64-bit products for eight decisions; round 5 paid a full two-multiply mixer per pair, 60 % of this VALU-bound loop).
+// The row sum uses the un-dropped p; 1 / (1 - p) is applied once, with the final normalisation.  What the forward saves for the backward
+// kernels below is  lse2 = -(m C2 + log2 l)  -- minus the log-sum-exp in the exponent's own units, so that P = exp2(S C2 + lse2) is one
+// fused multiply-add and one v_exp_f32 there.
 template <bool TRAIN, bool DROP>
 __global__ __launch_bounds__(NW * 64, 3) void attention_bf16_pipe_kernel(Attn16Args a, AttnTrain tr) {
     constexpr int STAGE = 2 * IMG;           // K image, V image
@@ -446,20 +282,30 @@ __global__ __launch_bounds__(NW * 64, 3) void attention_bf16_pipe_kernel(Attn16A
                 for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
         }
     };
-    // O^T += V^T P^T for one sub-tile (packed pairs, dropout on the packed pairs: see the kernel above)
-    auto pv = [&](f32x16& s, const unsigned char* Vs, int kt, uint32_t pm0, uint32_t& bits) {
+    // O^T += V^T P^T for one sub-tile (packed pairs, dropout on the packed pairs).  pm0 = the lane's first oct of the tile, pre-multiplied
+    auto pv = [&](f32x16& s, const unsigned char* Vs, auto ktc, uint32_t pm0, uint32_t& bits) {
+        constexpr int kt = decltype(ktc)::value;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             u32x4 pw;
+            uint32_t w[4] = {0u, 0u, 0u, 0u};
+            if (DROP) {       // registers 8 h .. 8 h + 7 = columns 16 h + 8 lh + 0 .. 7 of the sub-tile = oct 4 kt + 2 h (+ lh, in pm0)
+                const uint32_t x = dropout_oct_x(drop_key, pm0 + (uint32_t)(4 * kt + 2 * h) * DROPOUT_FIB);
+                dropout_oct_words<0>(x, w[0], w[1]);
+                dropout_oct_words<1>(x, w[2], w[3]);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r = 8 * h + 2 * j;
                 pw[j] = pack_bf16(s[r], s[r + 1]);
                 if (DROP) {
-                    const uint32_t cpair = (uint32_t)(kt * 16 + ((r & 3) >> 1) + 4 * (r >> 2));
-                    const uint32_t km = dropout_keep_mask_pk(dropout_word_premul(drop_key, pm0 + cpair * DROPOUT_FIB), thr1s_pk);
+                    const uint32_t km = dropout_keep_mask_pk(w[j], thr1s_pk);
                     pw[j] &= km;
-                    bits |= km & ((1u << (8 * kt + (r >> 1))) | (1u << (16 + 8 * kt + (r >> 1))));
+                    constexpr uint32_t one = 1u;
+                    const uint32_t sel = (one << (8 * kt + (r >> 1))) | (one << (16 + 8 * kt + (r >> 1)));      // keep_bit(kt, r), keep_bit(kt, r + 1)
+                    // bits = (km & sel) | (bits & ~sel) as ONE bit-field insert with the selector in a scalar register (the compiler's own
+                    // choice: 16 v_and with literal selectors + 8 v_or3 at the end of the tile, with all 16 masks live until then)
+                    asm("v_bfi_b32 %0, %1, %2, %0" : "+v"(bits) : "s"(sel), "v"(km));
                 }
             }
             const bf16x8 pb = as_bf16x8(pw);
@@ -479,7 +325,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attention_bf16_pipe_kernel(Attn16A
         const unsigned char* Ks = smem_a16 + slot * STAGE;
         const unsigned char* Vs = Ks + IMG;
         const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
-        const uint32_t pm0 = (((drop_row + (uint32_t)k0) >> 1) + 2u * (uint32_t)lh) * DROPOUT_FIB;
+        const uint32_t pm0 = (((drop_row + (uint32_t)k0) >> 3) + (uint32_t)lh) * DROPOUT_FIB;      // (drop_row: a multiple of 16; k0: of 64)
         uint32_t bits = 0;
         // ---- even step: keys k0 .. k0 + 31
         if (k0 + 32 > kend) mask(sa, k0);
@@ -487,7 +333,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attention_bf16_pipe_kernel(Attn16A
         const float al0 = softmax(sa);
         rescale(al0);
         __builtin_amdgcn_sched_barrier(0);
-        pv(sa, Vs, 0, pm0, bits);
+        pv(sa, Vs, std::integral_constant<int, 0>{}, pm0, bits);
         // ---- odd step: keys k0 + 32 .. k0 + 63.  Tile j + 1 has landed (this wave's pieces: vmcnt(0); everyone's: the barrier), and every
         // wave is done with tile j - 1, whose slot takes the DMA of tile j + 2
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -499,13 +345,13 @@ __global__ __launch_bounds__(NW * 64, 3) void attention_bf16_pipe_kernel(Attn16A
         const float al1 = softmax(sb);
         rescale(al1);
         __builtin_amdgcn_sched_barrier(0);
-        pv(sb, Vs, 1, pm0, bits);
+        pv(sb, Vs, std::integral_constant<int, 1>{}, pm0, bits);
         if (drop && tr.keep_bits) (tr.keep_bits + keep_word(bh, tile, 0, a.nqb))[keep_lane] = bits;     // (uniform base + 32-bit lane offset)
         slot = slot1;
     }
 
     const int q = q0 + li;
-    if (TRAIN && q < a.T && lh == 0) tr.lse[(int64_t)bh * a.T + q] = m_run * SCALE + logf(l_run);
+    if (TRAIN && q < a.T && lh == 0) tr.lse[(int64_t)bh * a.T + q] = -fmaf(m_run, C2, __builtin_amdgcn_logf(l_run));      // lse2 (v_log_f32 = log2)
     if (q < a.T) {
         const float inv = (drop ? 1.0f / (1.0f - tr.p) : 1.0f) / l_run;
         const int64_t o0 = ((int64_t)b * a.T + q) * a.H + head * DH + 4 * lh;
@@ -611,7 +457,7 @@ __global__ __launch_bounds__(256, 3) void attention_bf16_bwd_dq_kernel(Attn16Bwd
     load_col_frags(qf, base + qr * ld + 8 * lh);
     load_col_frags(dof, a.do16 + ((int64_t)b * a.T + qr) * a.H + head * DH + 8 * lh);
     const int64_t sidx = (int64_t)bh * a.T + qr;
-    const float nlse = -tr.lse[sidx] * LOG2E;
+    const float nlse = tr.lse[sidx];          // lse2 = -(m C2 + log2 l), the forward's form
     float dv;
     if (a.o16 || a.o32) {         // D = sum_d dO O of this query: each lane half takes its 32 d; bf16 values (dO: the fragments just loaded), fp32 sums
         const int64_t r0 = ((int64_t)b * a.T + qr) * a.H + head * DH + 8 * lh;
@@ -672,7 +518,7 @@ __global__ __launch_bounds__(256, 3) void attention_bf16_bwd_dq_kernel(Attn16Bwd
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, row, xr, st, lh), as_bf16x8(qf[st]), s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vs, row, xr, st, lh), as_bf16x8(dof[st]), dp, 0, 0, 0);
             }
-            // dS^T = P^T * (dP^T * keep/(1-p) - D);  P = exp(scale S - lse) = exp2(S C2 - lse log2e)
+            // dS^T = P^T * (dP^T * keep/(1-p) - D);  P = exp(scale S - lse) = exp2(S C2 + lse2)
             if (k0 + KT > min(flen, a.T)) {         // boundary tiles only (wave-uniform)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -682,13 +528,13 @@ __global__ __launch_bounds__(256, 3) void attention_bf16_bwd_dq_kernel(Attn16Bwd
                     s[r] = key < a.T ? sv : -INFINITY;       // exp2(-inf) = 0: a padding key contributes nothing
                 }
             }
-            const uint32_t cbase = (uint32_t)rowbase + (uint32_t)(k0 + kt * 32 + 4 * lh);
+            const uint32_t cbase = (uint32_t)rowbase + (uint32_t)(k0 + kt * 32 + 8 * lh);      // attention_drop_col of the lane's keys: 16 a + 8 lh + 4 b + c
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], C2, nlse));
                 float g = dp[r];
                 if (BITS) g = keep_f32(g, bits, keep_bit(kt, r));
-                else if (drop_thr != 0u) g = dropout_keep32(drop_key, cbase + (uint32_t)((r & 3) + 8 * (r >> 2)), drop_thr) ? g : 0.f;
+                else if (drop_thr != 0u) g = dropout_keep32(drop_key, cbase + (uint32_t)((r & 3) + 4 * ((r >> 2) & 1) + 16 * (r >> 3)), drop_thr) ? g : 0.f;
                 s[r] = pv * fmaf(g, inv, -dv);
             }
             // dQ^T[d][q] += sum_key K^T[d][key] dS^T[key][q]
@@ -748,7 +594,6 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
     const int Tq = a.nqb * NW * 32;
     const uint32_t* __restrict__ kbits = BITS ? tr.keep_bits + keep_word(bh, c0 / KT, 0, a.nqb) : nullptr;
     const int kb_half = (li >> 2) & 1, kb_bit = keep_bit((c0 >> 5) & 1, (li & 3) + 4 * (li >> 3));
-    const int kb_shift = 31 - kb_bit;       // (word << kb_shift) >> 31 = all ones where this lane's key was kept
 
     TileDma dma;
     dma.init(wave, lane);
@@ -777,7 +622,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
     load_col_frags(kf, base + kr * ld + a.H + 8 * lh);
     load_col_frags(vf, base + kr * ld + 2 * a.H + 8 * lh);
     const float inv = drop_thr != 0u ? 1.0f / (1.0f - tr.p) : 1.0f;
-    const uint32_t drop_col = (uint32_t)((uint64_t)bh * a.T * attention_drop_stride(a.T)) + (uint32_t)kr;
+    const uint32_t drop_col = (uint32_t)((uint64_t)bh * a.T * attention_drop_stride(a.T)) + attention_drop_col((uint32_t)kr);
     const int xr = swz(li);
 
     f32x16 dk[2], dvv[2];
@@ -794,7 +639,7 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char* Qs = smem_a16 + buf * STAGE;
         const unsigned char* Os = Qs + IMG;
-        const float* Ls = reinterpret_cast<const float*>(Qs + 2 * IMG);      // [0, KT): lse, [KT, 2KT): D
+        const float* Ls = reinterpret_cast<const float*>(Qs + 2 * IMG);      // [0, KT): lse2, [KT, 2KT): D
         const uint32_t* Ws = reinterpret_cast<const uint32_t*>(Qs + 2 * IMG + 2 * KT * 4) + (2 * wave + kb_half) * WROW;
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
@@ -811,10 +656,13 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
             // (columns of keys >= T are clamped duplicates whose results are never stored, so only the QUERY bound
             // needs masking, and only on the last tile)
             uint32_t didx = drop_col + (uint32_t)(t0 + qt * 32 + 4 * lh) * attention_drop_stride(a.T);   // ((bh T + q) T + key) mod 2^32
+            // P[q][key] = exp2(S C2 + lse2[q] (+ the key's mask bias)): one fused multiply-add per score where no key of the wave is masked
+            if (c0 + 32 <= flen) {          // (wave-uniform)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ql = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                s[r] = __builtin_amdgcn_exp2f(fmaf(Ls[ql], -LOG2E, fmaf(s[r], C2, kmask)));      // P[q][key]
+                for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], C2, Ls[qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh]));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], C2, kmask) + Ls[qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh]);
             }
             if (t0 + KT > a.T) {          // the last tile only (wave-uniform): query rows past T contribute nothing
 #pragma unroll
@@ -825,8 +673,8 @@ __global__ __launch_bounds__(256, 2) void attention_bf16_bwd_dkv_kernel(Attn16Bw
                 const int ql = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const float pv = s[r];
                 float g = dp[r], pd = pv;             // (Pd's factor 1 / (1 - p) multiplies dV once, at the end -- as the forward does with O)
-                if (BITS) {             // one arithmetic shift turns this lane's bit of the row's keep word into a mask for both values
-                    const uint32_t km = (uint32_t)((int32_t)(Ws[ql] << kb_shift) >> 31);
+                if (BITS) {             // one signed 1-bit field extract (v_bfe_i32) turns this lane's bit of the row's keep word into a mask for both values
+                    const uint32_t km = (uint32_t)__builtin_amdgcn_sbfe((int)Ws[ql], (unsigned)kb_bit, 1u);
                     g = __uint_as_float(__float_as_uint(g) & km);
                     pd = __uint_as_float(__float_as_uint(pd) & km);
                 } else if (drop_thr != 0u) {
@@ -911,7 +759,7 @@ int launch_attention_fwd_bf16(const float* qkv, const uint16_t* qkv16, const int
     W2V2_REQUIRE(ctx || ctx16, "attention_bf16: no output");
     W2V2_REQUIRE((int64_t)T * 3 * H < (1ll << 31), "attention_bf16: T x 3H too large for 32-bit row offsets");
     // (the forward steps the hash's pair index inside a key tile by addition: equal to "(index mod 2^32) >> 1" while no index wraps)
-    W2V2_REQUIRE(!tr || tr->p <= 0.f || (int64_t)B * heads * T * (T + (T & 1)) < (1ll << 32),
+    W2V2_REQUIRE(!tr || tr->p <= 0.f || (int64_t)B * heads * T * ((T + 15) & ~15) < (1ll << 32),
                  "attention_bf16: dropout over 2^32 or more attention probabilities is not supported");
     const uint16_t* q16 = nullptr;
     if (int e = shadow_or_scratch(qkv, qkv16, (int64_t)B * T * 3 * H, SCRATCH_QKV16, s, &q16)) return e;
@@ -920,21 +768,13 @@ int launch_attention_fwd_bf16(const float* qkv, const uint16_t* qkv16, const int
     const int nqb = (T + NW * 32 - 1) / (NW * 32);
     Attn16Args a{q16, frame_len, ctx, ctx16, B, T, H, heads, nqb, nqb * heads * B};
     dim3 grid(a.nwork), block(NW * 64);
-    if (tune_int("W2V2_ATTN16_PIPE", 1) != 0) {          // the software-pipelined forward (three-slot K / V ring: 48 KiB)
-        const size_t lds = 3 * 2 * IMG;
-        if (tr && (uint32_t)((double)tr->p * 65536.0) != 0u)          // (dropout_threshold(p) on the host)
-            W2V2_LAUNCH((attention_bf16_pipe_kernel<true, true>), grid, block, lds, s, a, *tr);
-        else if (tr)
-            W2V2_LAUNCH((attention_bf16_pipe_kernel<true, false>), grid, block, lds, s, a, *tr);
-        else
-            W2V2_LAUNCH((attention_bf16_pipe_kernel<false, false>), grid, block, lds, s, a, AttnTrain{0.f, 0, 0, nullptr});
-    } else {
-        const size_t lds = 2 * 2 * IMG;
-        if (tr)
-            W2V2_LAUNCH(attention_bf16_kernel<true>, grid, block, lds, s, a, *tr);
-        else
-            W2V2_LAUNCH(attention_bf16_kernel<false>, grid, block, lds, s, a, AttnTrain{0.f, 0, 0, nullptr});
-    }
+    const size_t lds = 3 * 2 * IMG;          // three-slot K / V ring: 48 KiB
+    if (tr && (uint32_t)((double)tr->p * 65536.0) != 0u)          // (dropout_threshold(p) on the host)
+        W2V2_LAUNCH((attention_bf16_pipe_kernel<true, true>), grid, block, lds, s, a, *tr);
+    else if (tr)
+        W2V2_LAUNCH((attention_bf16_pipe_kernel<true, false>), grid, block, lds, s, a, *tr);
+    else
+        W2V2_LAUNCH((attention_bf16_pipe_kernel<false, false>), grid, block, lds, s, a, AttnTrain{0.f, 0, 0, nullptr});
     W2V2_HIP_CHECK(hipGetLastError());
     return W2V2_OK;
 }

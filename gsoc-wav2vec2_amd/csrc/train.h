@@ -15,21 +15,25 @@ enum DropStream : uint32_t {
 };
 
 #ifdef __HIPCC__
-// keep(seed, stream, idx, p): counter-based hash, 32-bit arithmetic only (the attention forward evaluates it once per
-// score; the first version used 64-bit splitmix per element, ~40 VALU ops; one lowbias32 per element ~16; now one per PAIR):
-//   k    = low 32 bits of splitmix64(seed ^ stream * GOLD)                    -- loop-invariant
-//   w    = lowbias32(lo32(idx >> 1) * 0x9E3779B1 ^ k)   (Fibonacci pre-multiply spreads the sequential counter, then a
-//                                               bijective multiply-xorshift mixer; lagged mask correlations < 1e-3)
-//   keep = (idx odd ? w >> 16 : w & 0xFFFF) >= floor(p * 2^16)       -- the two 16-bit halves decide elements 2j and 2j + 1
-// The mixer (two 32-bit multiplies at ~1.8 plain ops each, three xorshifts) is the expensive part, so one hash word serves two
-// elements; p is realised to 2^-16 (0.1 -> 0.1000061).  The index enters modulo 2^32 (a pattern repeats after 8.6e9
-// elements of one tensor).  Attention probabilities index their (B heads T, T) matrix with the row stride rounded up to
-// even (attention_drop_stride), so that a pair never straddles two query rows.  Same integer function as
-// wav2vec2/variables.py::dropout_keep / attention_keep.
-__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
-    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-    return x;
-}
+// keep(seed, stream, idx, p): counter-based hash, 32-bit arithmetic only.  History of its cost in the one place that is bound by it (the
+// bf16 attention forward evaluates it once per score): 64-bit splitmix per element, ~40 VALU ops; one lowbias32 per element, ~16; one
+// per PAIR (round 3); round 6: one mixer ROUND per OCT of eight consecutive elements, finished by two 32 x 32 -> 64-bit products that
+// yield four words = eight 16-bit decisions (2.25 plain ops per decision against 4.8: VERDICT r05 item 2):
+//   k        = low 32 bits of splitmix64(seed ^ stream * GOLD)                          -- loop-invariant
+//   x        = round1(lo32(idx >> 3) * 0x9E3779B1 ^ k),  round1(x): x ^= x >> 16; x *= 0x7feb352d; x ^= x >> 15   (lowbias32's first half)
+//   (lo, hi) = x * 0x846ca68b  (words 0, 1)   |   x * 0xC2B2AE35  (words 2, 3)           -- the full 64-bit products
+//   word 2j  = lo ^ (lo >> 16)               (= lowbias32's second half for j = 0)
+//   word 2j+1 = hi + (lo << 16)              (hi alone is not uniform -- it is < the multiplier; its sum with the product's low half is)
+//   keep     = ((idx odd ? w >> 16 : w & 0xFFFF) ^ 0x8000) >= floor(p * 2^16),  w = word (idx >> 1) & 3 of oct idx >> 3
+// p is realised to 2^-16 (0.1 -> 0.1000061).  Measured on 6-12 M decisions per key (six keys, tools/dropout_hash_stats.py: the tests the
+// pair hash passed): keep-rate error < 2e-4, lag / column / diagonal / in-oct pair correlations at the sampling noise (< 1e-3; < 4e-3 for
+// the maximum over the 28 in-oct pairs), 16-bit halves uniform (chi-square, 255 dof: 280-300).  The index enters modulo 2^32 (a pattern
+// repeats after 4.3e9 elements of one tensor).  Attention probabilities index their (B heads T, T) matrix with the row stride rounded up
+// to a multiple of 16 and bits 2 and 3 of the key index exchanged (attention_drop_stride / attention_drop_col): an oct is then the eight
+// scores a lane of the forward holds in accumulator registers 8a .. 8a + 7.  Same integer function as
+// wav2vec2/variables.py::dropout_hash / attention_keep.
+constexpr uint32_t DROPOUT_FIB = 0x9E3779B1u;
+constexpr uint32_t DROPOUT_M1 = 0x7feb352du, DROPOUT_M2 = 0x846ca68bu, DROPOUT_M3 = 0xC2B2AE35u;
 __device__ __forceinline__ uint32_t dropout_key(uint64_t seed, uint32_t stream) {
     uint64_t z = (seed ^ ((uint64_t)stream * 0x9E3779B97F4A7C15ULL)) + 0x9E3779B97F4A7C15ULL;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
@@ -39,12 +43,28 @@ __device__ __forceinline__ uint32_t dropout_key(uint64_t seed, uint32_t stream) 
 __device__ __forceinline__ uint32_t dropout_threshold(float p) {      // 16-bit threshold
     return (uint32_t)((double)p * 65536.0);
 }
+// the shared round of an oct, from the pre-multiplied oct index (oct * 0x9E3779B1 mod 2^32: callers whose oct indices are `base + small
+// constant` pay the multiply once per base and an add per oct -- products distribute over the sum modulo 2^32)
+__device__ __forceinline__ uint32_t dropout_oct_x(uint32_t key, uint32_t oct_times_fib) {
+    uint32_t x = oct_times_fib ^ key;
+    x ^= x >> 16; x *= DROPOUT_M1; x ^= x >> 15;
+    return x;
+}
+// words 2 H and 2 H + 1 of the oct (elements 4 H .. 4 H + 3): one 64-bit product
+template <int H>
+__device__ __forceinline__ void dropout_oct_words(uint32_t x, uint32_t& w_even, uint32_t& w_odd) {
+    const uint64_t prod = (uint64_t)x * (uint64_t)(H ? DROPOUT_M3 : DROPOUT_M2);
+    const uint32_t lo = (uint32_t)prod, hi = (uint32_t)(prod >> 32);
+    w_even = lo ^ (lo >> 16);
+    w_odd = hi + (lo << 16);
+}
 // the hash word of element pair (2 pair, 2 pair + 1): low half decides the even element, high half the odd one
-__device__ __forceinline__ uint32_t dropout_word(uint32_t key, uint32_t pair) { return lowbias32(pair * 0x9E3779B1u ^ key); }
-// the same word from the pre-multiplied pair index (pair * 0x9E3779B1 mod 2^32): callers whose pair indices are `base + small
-// constant` pay the multiply once per base and an add per word (products distribute over the sum modulo 2^32)
-constexpr uint32_t DROPOUT_FIB = 0x9E3779B1u;
-__device__ __forceinline__ uint32_t dropout_word_premul(uint32_t key, uint32_t pair_times_fib) { return lowbias32(pair_times_fib ^ key); }
+__device__ __forceinline__ uint32_t dropout_word(uint32_t key, uint32_t pair) {
+    const uint32_t x = dropout_oct_x(key, (pair >> 2) * DROPOUT_FIB);
+    const uint64_t prod = (uint64_t)x * (uint64_t)((pair & 2u) ? DROPOUT_M3 : DROPOUT_M2);
+    const uint32_t lo = (uint32_t)prod, hi = (uint32_t)(prod >> 32);
+    return (pair & 1u) ? hi + (lo << 16) : lo ^ (lo >> 16);
+}
 // The decision reads a 16-bit half as a SIGNED number: keep  <=>  int16(half) >= thr - 2^15  <=>  (half ^ 0x8000) >= thr  (round 4;
 // before: half >= thr -- the same probability, the top bit of the uniform half flipped).  In this form the decisions of BOTH halves of a
 // word come out of two packed 16-bit instructions (dropout_keep_mask_pk below), which is what the bf16 attention forward -- VALU-bound,
@@ -70,8 +90,11 @@ __device__ __forceinline__ uint32_t dropout_keep_mask_pk(uint32_t w, uint32_t th
     d = d >> 15;
     return __builtin_bit_cast(uint32_t, d);
 }
-// row stride of the attention-probability index space: T rounded up to even
-__device__ __forceinline__ uint32_t attention_drop_stride(int T) { return (uint32_t)(T + (T & 1)); }
+// index space of the attention probabilities: row stride = T rounded up to a multiple of 16, and inside a row key k sits at column
+// attention_drop_col(k) = k with bits 2 and 3 exchanged (see the header of this section: a lane of the bf16 forward holds keys
+// 16 a + 8 b + 4 lh + c in register 8 a + 4 b + c, so its registers 8 a .. 8 a + 7 are the consecutive columns 16 a + 8 lh + 0 .. 7 = one oct)
+__device__ __forceinline__ uint32_t attention_drop_stride(int T) { return (uint32_t)((T + 15) & ~15); }
+__device__ __forceinline__ uint32_t attention_drop_col(uint32_t k) { return (k & ~12u) | ((k & 4u) << 1) | ((k & 8u) >> 1); }
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t stream, uint64_t idx, float p) {
     return dropout_keep32(dropout_key(seed, stream), (uint32_t)idx, dropout_threshold(p));
 }

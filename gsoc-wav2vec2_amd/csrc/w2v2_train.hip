@@ -49,6 +49,8 @@ struct TrainState {
     bool pos_w16_t_fresh = false;
     uint8_t* spec_mask = nullptr;       // (B*T) device copy, or null when not applied
     bool have_spec = false, have_mask = false;
+    uint64_t trainable_sig = 0;           // signature of `trainable` at the last backward (0: none yet -> the buffer is cleared)
+    bool grads_need_clear = false;
     float p = 0.f;
     uint64_t seed = 0;
     // gradient / optimizer state: flat, inventory order
@@ -938,7 +940,29 @@ int w2v2_train_backward(w2v2_model* m, const float* dlogits, void* stream) {
         }
         return launch_dropout_bwd_x(u, dy, dx, dx16, rows * cols, act_, p, seed, stream_id, s, in);
     };
-    W2V2_HIP_CHECK(hipMemsetAsync(t->grads, 0, (size_t)t->gtotal * 4, s));
+    // Gradient buffer at the start of a backward.  Rounds 1-5 zeroed all of it every step (360 MB / 1.25 GB: the runtime's fill kernels,
+    // 0.23 / 0.8 ms per step and the only framework kernels left in it).  Every producer below STORES its gradient (no accumulation
+    // into the buffer: folds, column sums and GEMM epilogues overwrite), so a slot needs zeros only if nothing will write it this time:
+    //   * slots of variables that are not trainable, and the 16-byte padding between slots: zero since allocation, never written;
+    //   * masked_spec_embed when this step has no spec-augment mask;
+    //   * everything, conservatively, when the trainable set changed since the last backward (a slot that was written before keeps
+    //     its last gradient) or when stochastic depth dropped a layer (its branch's gradients are not computed: zeros).
+    // tests/test_train_gpu.py poisons the buffer with NaN before its gradient checks: a trainable slot nobody wrote shows up there.
+    {
+        uint64_t sig = 1469598103934665603ull;
+        for (size_t i = 0; i < t->trainable.size(); ++i) sig = (sig ^ (uint64_t)(t->trainable[i] ? 0x9E : 0x3C)) * 1099511628211ull;
+        bool dropped = false;
+        for (int i = 0; i < c.num_layers; ++i) dropped = dropped || t->layers[i].keep == 0.f;
+        if (sig != t->trainable_sig || dropped || t->grads_need_clear) {
+            W2V2_HIP_CHECK(hipMemsetAsync(t->grads, 0, (size_t)t->gtotal * 4, s));
+            t->trainable_sig = sig;
+            t->grads_need_clear = dropped;        // (the step after a dropped layer starts from zeros as well: its slots hold nothing new)
+        } else if (!t->have_spec) {
+            auto it = m->index.find("masked_spec_embed");
+            if (it != m->index.end() && t->trainable[it->second])
+                W2V2_HIP_CHECK(hipMemsetAsync(t->grads + t->goff[it->second], 0, (size_t)m->params[it->second].numel * 4, s));
+        }
+    }
     if (int e = refresh_transposes(m, s)) return e;
     const int nbuckets = c.num_layers + 2;
     while ((int)t->bucket_ev.size() < nbuckets) {

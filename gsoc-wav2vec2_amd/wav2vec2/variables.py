@@ -306,28 +306,27 @@ def layer_stream(layer, site):
     return DS_LAYER_BASE + 4 * layer + site
 
 
-def _lowbias32(x):
-    with np.errstate(over="ignore"):
-        x = x ^ (x >> np.uint32(16))
-        x = x * np.uint32(0x7FEB352D)
-        x = x ^ (x >> np.uint32(15))
-        x = x * np.uint32(0x846CA68B)
-        x = x ^ (x >> np.uint32(16))
-    return x
-
-
 def dropout_hash(seed, stream, n, start=0):
-    """16-bit hash value per element index, identical to csrc/train.h (integer arithmetic only): elements 2j and 2j + 1 share
-    one lowbias32 word over ((j mod 2^31) * 0x9E3779B1) xor a per-(seed, stream) key -- the low half belongs to the even
-    element, the high half to the odd one."""
+    """16-bit hash value per element index, identical to csrc/train.h (integer arithmetic only).  The eight elements of an OCT
+    (index >> 3) share one mixer round x of ((oct mod 2^32) * 0x9E3779B1) xor a per-(seed, stream) key; the 64-bit products
+    x * 0x846ca68b (elements 0-3) and x * 0xC2B2AE35 (elements 4-7) give two words each -- lo ^ (lo >> 16) and hi + (lo << 16) --
+    whose low half belongs to the even element and high half to the odd one."""
     key0 = np.array([(int(seed) ^ ((int(stream) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF],
                     dtype=np.uint64)
     key = np.uint32(int(_splitmix64(key0)[0]) & 0xFFFFFFFF)
     idx = np.arange(start, start + n, dtype=np.uint64)
     lo = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    u16, u15 = np.uint32(16), np.uint32(15)
     with np.errstate(over="ignore"):
-        w = _lowbias32(((lo >> np.uint32(1)) * np.uint32(0x9E3779B1)) ^ key)
-    return np.where((lo & np.uint32(1)) != 0, w >> np.uint32(16), w & np.uint32(0xFFFF)).astype(np.uint32)
+        x = ((lo >> np.uint32(3)) * np.uint32(0x9E3779B1)) ^ key
+        x = x ^ (x >> u16)
+        x = x * np.uint32(0x7FEB352D)
+        x = x ^ (x >> u15)
+        mult = np.where((lo & np.uint32(4)) != 0, np.uint64(0xC2B2AE35), np.uint64(0x846CA68B))
+        prod = x.astype(np.uint64) * mult
+        plo, phi = (prod & np.uint64(0xFFFFFFFF)).astype(np.uint32), (prod >> np.uint64(32)).astype(np.uint32)
+        w = np.where((lo & np.uint32(2)) != 0, phi + (plo << u16), plo ^ (plo >> u16))
+    return np.where((lo & np.uint32(1)) != 0, w >> u16, w & np.uint32(0xFFFF)).astype(np.uint32)
 
 
 def dropout_keep(seed, stream, n, p):
@@ -339,7 +338,10 @@ def dropout_keep(seed, stream, n, p):
 
 
 def attention_keep(seed, stream, rows, T, p):
-    """Keep mask of the attention probabilities, (rows, T) with rows = B * heads * T queries: the element index space has the
-    row stride T rounded up to even, so that a hash word never straddles two query rows (csrc/train.h::attention_drop_stride)."""
-    T2 = T + (T & 1)
-    return dropout_keep(seed, stream, rows * T2, p).reshape(rows, T2)[:, :T]
+    """Keep mask of the attention probabilities, (rows, T) with rows = B * heads * T queries: the element index space has the row
+    stride T rounded up to a multiple of 16 and, inside a row, key k at column k with bits 2 and 3 exchanged
+    (csrc/train.h::attention_drop_stride / attention_drop_col: a hash oct is then what one lane of the forward kernel holds)."""
+    T2 = (T + 15) & ~15
+    k = np.arange(T)
+    col = (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1)
+    return dropout_keep(seed, stream, rows * T2, p).reshape(rows, T2)[:, col]

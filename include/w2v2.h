@@ -502,8 +502,11 @@ int w2v2_op_layer_norm_bwd(const float* x_dev, const float* gamma_dev, const flo
                            float* dgamma_dev, float* dbeta_dev, int64_t rows, int32_t C, float eps,
                            float* ws_dev, void* stream);
 
-/* Attention with dropout on the probabilities (encoder.py:42-44) + saved log-sum-exp (B, heads, T),
- * and its backward: dqkv (B, T, 3H) from dctx (B, T, H).  dvec_ws: (B, heads, T) scratch. */
+/* Attention with dropout on the probabilities (encoder.py:42-44) + the saved row statistic (B, heads, T),
+ * and its backward: dqkv (B, T, 3H) from dctx (B, T, H).  dvec_ws: (B, heads, T) scratch.
+ * lse_dev is what the forward leaves for the backward of the SAME precision mode: the natural log-sum-exp of the (masked, scaled)
+ * scores under W2V2_PRECISION_FP32; minus the log2-sum-exp2 (= -lse * log2 e, the kernels' own exponent units: P = exp2(S c + lse2)
+ * is then one fused multiply-add and one v_exp_f32 per score in the backward) under W2V2_PRECISION_BF16. */
 int w2v2_op_attention_train(const float* qkv_dev, const int32_t* frame_len_dev, float* ctx_dev, float* lse_dev,
                             int32_t B, int32_t T, int32_t H, int32_t num_heads, float dropout_p,
                             uint64_t seed, uint32_t stream_id, void* stream);

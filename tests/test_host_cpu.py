@@ -188,6 +188,22 @@ def test_dropout_hash_statistics():
     assert abs(keep.mean() - 0.9) < 0.005
     assert not np.array_equal(keep, V.dropout_keep(12345, V.layer_stream(3, 1), 200000, 0.1))
     assert np.array_equal(keep, V.dropout_keep(12345, V.layer_stream(3, 0), 200000, 0.1))
+    # the oct hash (round 6: eight decisions share one mixer round, csrc/train.h): the decisions inside an oct, at short lags and
+    # between rows must be as uncorrelated as independent draws are (tools/dropout_hash_stats.py is the long form of this test)
+    n = 1 << 21
+    k = V.dropout_keep(99, V.layer_stream(0, 2), n, 0.1).astype(np.float64)
+    k -= k.mean()
+    v, q = k.var(), k.reshape(-1, 8)
+    sd_oct, sd = 1.0 / np.sqrt(n / 8), 1.0 / np.sqrt(n)
+    assert max(abs((q[:, a] * q[:, b]).mean() / v) for a in range(8) for b in range(a + 1, 8)) < 4.5 * sd_oct
+    assert max(abs((k[:-l] * k[l:]).mean() / v) for l in (1, 2, 3, 4, 7, 8, 9, 16, 768, 3072)) < 4.5 * sd
+    h = V.dropout_hash(99, V.layer_stream(0, 2), n)
+    for byte in (h >> 8, h & 0xFF):             # both bytes of the 16-bit value uniform: chi-square, 255 degrees of freedom (mean 255, sd 22.6)
+        assert (((np.bincount(byte.astype(np.int64), minlength=256) - n / 256) ** 2) / (n / 256)).sum() < 255 + 5 * 22.6
+    # attention index space: stride 16-aligned, bits 2 / 3 of the key exchanged -- every (query, key) still gets its own decision
+    a = V.attention_keep(5, 16, 64, 21, 0.1)
+    raw = V.dropout_keep(5, 16, 64 * 32, 0.1).reshape(64, 32)
+    assert a.shape == (64, 21) and np.array_equal(a[:, 4:8], raw[:, 8:12]) and np.array_equal(a[:, 8:12], raw[:, 4:8]) and np.array_equal(a[:, 16:20], raw[:, 16:20]) and np.array_equal(a[:, 20], raw[:, 24])
 
 
 # ---- HuggingFace checkpoint directories (what src/convert_torch_to_tf.py converts) ------------

@@ -57,7 +57,7 @@ def test_dropout_hash_matches_host(env, n, p, stream):
     ref = np.where(keep, x / np.float32(1 - p), 0).astype(np.float32) + res
     assert np.allclose(y.cpu().numpy(), ref, atol=1e-6)
     if p > 0:
-        assert abs(keep.mean() - (1 - p)) < 0.02
+        assert abs(keep.mean() - (1 - p)) < 4.0 * np.sqrt(p * (1 - p) / n)       # four standard deviations of the sample mean
 
 
 @pytest.mark.parametrize("rows,Cn,p", [(37, 768, 0.1), (3001, 1024, 0.1), (9, 64, 0.5), (130, 768, 0.0), (5000, 1280, 0.1)])
@@ -196,7 +196,7 @@ def test_attention_train_forward_backward_bf16(env, B, T, Hh, heads, p, flen):
     finally:
         N.check(lib.w2v2_op_set_precision(0))
     e_ctx = H.max_err(ctx.cpu().numpy(), ctx_ref.detach().numpy())
-    e_lse = H.max_err(lse.cpu().numpy(), lse_ref)
+    e_lse = H.max_err(-lse.cpu().numpy() * np.log(2.0), lse_ref)       # (the bf16 kernels save -log2-sum-exp2: include/w2v2.h)
     print(f"bf16 attention train: ctx err {e_ctx:.3e}, lse err {e_lse:.3e}")
     assert e_ctx < 1e-2 and e_lse < 1e-4          # scores are fp32 sums of exact products: lse is tight
     got, ref = dqkv.cpu().numpy(), qt.grad.numpy()
@@ -277,6 +277,66 @@ def test_training_forward_without_randomness_equals_inference(env):
     a = tr.forward(g["wave"]).cpu().numpy()
     b = m(g["wave"]).numpy()
     assert np.allclose(a, b, atol=2e-6)
+
+
+@pytest.mark.parametrize("case,precision", [("tiny_base", "fp32"), ("tiny_base", "bf16"), ("tiny_robust", "bf16"), ("tiny_robust", "fp32")])
+def test_backward_overwrites_every_trainable_gradient(env, case, precision):
+    """The backward no longer zero-fills the whole gradient buffer (round 6: 0.23 / 0.8 ms of runtime fill kernels per step): every
+    producer stores its gradient, and only the slots nothing writes are cleared (csrc/w2v2_train.hip, at the top of the backward).
+    Pinned here by poisoning the buffer with NaN between two backward passes of the same step: the second must reproduce the first
+    bit for bit in every trainable variable -- with and without a spec-augment mask (masked_spec_embed is written only with one),
+    with a layer dropped by stochastic depth (that step and the one after take the full clear), and across a change of the
+    trainable set (stage 1 <-> stage 2 of the reference, main.py:210,234-237)."""
+    import torch
+    import wav2vec2
+    g = H.golden(case)
+    m, cfg, w = build(case, 4000)
+    m.freeze_feature_extractor()
+    m.set_precision(precision)
+    loss_fn = wav2vec2.CTCLoss(cfg, g["wave"].shape, division_factor=2)
+    tr = wav2vec2.Trainer(m, loss_fn, dropout=0.1, apply_spec_augment=False, seed=3)
+    mask = g.get("attention_mask")
+    mask = None if mask is None else mask.astype(np.int32)
+    T = cfg.num_frames(g["wave"].shape[1])
+    spec = compute_mask_indices((2, T), 0.3, 2, rng=np.random.RandomState(1))
+    names = [n for n in V.variable_specs(cfg) if "feature_extractor" not in n]
+    labels = np.array([[5, 9, 9, 11, 0, 0], [7, 6, 0, 0, 0, 0]], np.int32)
+
+    def grads():
+        torch.cuda.synchronize()
+        return {n: tr.gradient(n).copy() for n in names}
+
+    def check(tag, only=None, **fw):
+        logits = tr.forward(g["wave"], mask, step_seed=11, **fw)
+        _, dlog = loss_fn.per_sample(labels, logits, with_grad=True)
+        tr.backward(dlog)
+        first = grads()
+        tr.grad_buffer().fill_(float("nan"))
+        tr.backward(dlog)
+        second = grads()
+        for n in (only or names):
+            assert np.isfinite(second[n]).all(), f"{tag}: {n} was not written by the backward"
+            assert np.array_equal(first[n], second[n]), f"{tag}: {n}"
+        return first
+
+    try:
+        a = check("spec mask", spec_mask=spec)
+        assert np.any(a["masked_spec_embed"])
+        b = check("no spec mask")
+        assert not np.any(b["masked_spec_embed"])                     # cleared, not left over from the step before
+        sd = np.ones(cfg.num_layers, np.float32)
+        sd[-1] = 0.0
+        c = check("dropped layer", sd_keep=sd)
+        last = f"encoder/layers/{cfg.num_layers - 1}/feed_forward/intermediate_dense/kernel"
+        assert not np.any(c[last]) and np.any(b[last])
+        d = check("after a dropped layer")
+        assert np.any(d[last])
+        m.layers[0].trainable = False                                 # stage 1: only lm_head trains
+        tr._ranges_cache = {}
+        e = check("stage 1", only=["lm_head/kernel", "lm_head/bias"])
+        assert np.any(e["lm_head/kernel"]) and not np.any(e[last])    # the frozen variables' slots read zero, not the last stage-2 gradient
+    finally:
+        m.set_precision("fp32")
 
 
 @pytest.mark.parametrize("p,use_spec,use_sd", [(0.0, False, False), (0.1, True, True)])
