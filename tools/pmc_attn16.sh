@@ -3,7 +3,8 @@
 # and the shader clock (GRBM_GUI_ACTIVE / 8 / duration needs the kernel-trace pass).  -> gpurun_out/pmc_attn16.md
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; cd /tmp
-CMD="python $R/tools/fwd_families.py --precision bf16 --mode train --batch 8 --steps 1"
+export BATCH=${BATCH:-8}
+CMD="python $R/tools/fwd_families.py --precision bf16 --mode train --batch $BATCH --steps 1"
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC" "SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU" "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY"; do
   timeout 300 rocprofv3 --pmc $set --output-format csv -d $O/pmca_$i -- $CMD > $O/pmca_$i.log 2>&1 || echo "set $i failed: $(tail -1 $O/pmca_$i.log)"
@@ -25,7 +26,8 @@ for f in glob.glob(f"{O}/pmca_trace/**/*_kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if "attention_bf16" in r["Kernel_Name"]:
             d = dur[kind(r["Kernel_Name"])]; d[0] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"]); d[1] += 1
-lines = ["# bf16 attention kernels, training step at B = 8 x 246000 (T = 768, 12 heads): PMC per launch (one counter set per pass)", ""]
+import os
+lines = [f"# bf16 attention kernels, training step at B = {os.environ.get('BATCH', '8')} x 246000 (T = 768, 12 heads): PMC per launch (one counter set per pass)", ""]
 for k in ("fwd", "dq", "dkv"):
     c = {n: v[0] / max(v[1], 1) for n, v in acc[k].items()}
     us = dur[k][0] / max(dur[k][1], 1) / 1e3

@@ -32,10 +32,24 @@ def find(d, suffix):
     return hits[0]
 
 
+def provenance():
+    """One header line for every committed summary: the commit the snapshot was taken from (HEAD_REV, exported by
+    the caller on the build machine -- the GPU box has no .git) and the sha256 over ALL kernel sources, computed where the profile ran."""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(root, "gsoc-wav2vec2_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "gsoc-wav2vec2_amd", "csrc", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return (f"_provenance: git HEAD {os.environ.get('HEAD_REV', 'unknown (HEAD_REV not exported)')}; sha256 over csrc/*.hip + *.h ({len(files)} files) "
+            f"{h.hexdigest()[:16]}; command: {os.environ.get('PROF_CMD', 'n/a')}_")
+
+
 def stats(src, dst):
     rows = list(csv.DictReader(open(find(src, "_kernel_stats.csv"))))
     trace = list(csv.DictReader(open(find(src, "_kernel_trace.csv"))))
-    out = ["| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
+    out = [provenance(), "", "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
     for r in rows:
         if float(r["Percentage"]) < 0.01:
             continue

@@ -14,16 +14,16 @@ def load(name):
     return json.loads(lines[-1]) if lines else None
 
 
-ROWS = [("bench_n1.json", "base fp32 forward 32x246000 (headline, BASELINE configs[1]; the driver's command)"),
-        ("bench_n1_launched.json", "the same under torch.distributed.run with one rank (RCCL group of 1)"),
-        ("bench_f16x2_n1.json", "base f16x2 forward 32x246000 (opt-in, fp32-grade)"),
-        ("bench_bf16x3_n1.json", "base bf16x3 forward 32x246000 (opt-in, fp32-grade)"),
-        ("bench_bf16_n1.json", "base bf16 forward 32x246000"),
-        ("bench_train_n1.json", "base fp32 CTC fine-tune step 32x246000"),
-        ("bench_bf16_train_n1.json", "base bf16 CTC fine-tune step 32x246000 (configs[2] per GPU)"),
-        ("bench_large_robust_fwd_n1.json", "large-robust fp32 forward 16x246000 (configs[3])"),
-        ("bench_large_robust_bf16_n1.json", "large-robust bf16 forward 16x480000"),
-        ("bench_large_robust_bf16_train_n1.json", "large-robust bf16 fine-tune step 16x480000 (configs[4] per GPU)")]
+ROWS = [("bench_n1_full.json", "base fp32 forward 32x246000 (headline, BASELINE configs[1]; the driver's command)"),
+        ("bench_n1_launched_full.json", "the same under torch.distributed.run with one rank (RCCL group of 1)"),
+        ("bench_f16x2_n1_full.json", "base f16x2 forward 32x246000 (opt-in, fp32-grade)"),
+        ("bench_bf16x3_n1_full.json", "base bf16x3 forward 32x246000 (opt-in, fp32-grade)"),
+        ("bench_bf16_n1_full.json", "base bf16 forward 32x246000"),
+        ("bench_train_n1_full.json", "base fp32 CTC fine-tune step 32x246000"),
+        ("bench_bf16_train_n1_full.json", "base bf16 CTC fine-tune step 32x246000 (configs[2] per GPU)"),
+        ("bench_large_robust_fwd_n1_full.json", "large-robust fp32 forward 16x246000 (configs[3])"),
+        ("bench_large_robust_bf16_n1_full.json", "large-robust bf16 forward 16x480000"),
+        ("bench_large_robust_bf16_train_n1_full.json", "large-robust bf16 fine-tune step 16x480000 (configs[4] per GPU)")]
 print("| workload | ms / step | audio-s / s | dominant GEMM family: TF, frac of nominal peak | shader clock under load | frac at that clock | launches / step | max abs logit err vs HF fp64 |")
 print("|---|---|---|---|---|---|---|---|")
 for fn, label in ROWS:
@@ -35,7 +35,7 @@ for fn, label in ROWS:
     print(f"| {label} | {d['ms_per_step']} | {d['value']:.0f} | {r.get('achieved')} TF of {r.get('peak')} = {r.get('frac')} | "
           f"{r.get('clock_mhz_under_load')} MHz | {r.get('frac_clock_adjusted')} | {d.get('kernel_launches_per_step', '-')} | "
           f"{('%.1e' % err) if isinstance(err, (int, float)) else '-'} |")
-d = load("bench_n1.json")
+d = load("bench_n1_full.json")
 if d:
     print("\nThe driver's line also carries, measured by the same process right after the headline:\n")
     print("| object | ms / step | audio-s / s | family frac (nominal / at clock) | clock MHz | kernel launches / step | unattributed ms | traffic / compulsory per step |")
