@@ -674,7 +674,7 @@ def side_object(ctx, spec, res, label):
 
 def measure_alt(ctx, model, x, amask, model_name, B, L, steps, warmup, prec, ref_logits, gold_logits, profile):
     """Beside a fp32 forward leg (never as it): the same workload on the same model in an fp32-grade split mode -- "bf16x3" (six bf16 MFMA
-    products of exact three-term operand splits) or "f16x2" (three fp16 products of two-term splits), DESIGN.md 7.2 / 7.3.  Single-process,
+    products of exact three-term operand splits) or "f16x2" (three fp16 products of two-term splits), DESIGN.md section 5 (history: profiles/history.md 7.2, 7.3).  Single-process,
     timed after the leg; its own roofline (GEMM family, events on every launch of two extra untimed steps), families, clock, traffic."""
     torch = ctx["torch"]
     model.set_precision(prec)

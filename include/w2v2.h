@@ -156,7 +156,7 @@ int w2v2_get_precision(const w2v2_model* m);
  *                                          lower-priority HIP stream owned by the model, ordered against the caller's stream by
  *                                          events only (w2v2_train_backward returns with the caller's stream waiting for all of it;
  *                                          bucket events then come from that stream).  Same results bit for bit; measured neutral
- *                                          on one GPU, hence off.
+ *                                          on one GPU (profiles/history.md 7.1), hence off.
  *   W2V2_OPT_DEFER_FOLDS (default 1)       training backward: the small reductions that finish an encoder layer's gradients (split-K
  *                                          slab sums of the four weight gradients, the q|k|v unpack, the LayerNorm / dropout /
  *                                          attention column-sum folds: nine launches per layer) run as ONE launch in front of the
