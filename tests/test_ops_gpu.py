@@ -936,6 +936,42 @@ def test_ctc_loss_and_grad(env, B, T, Vv, U):
     assert np.array_equal(nll2.cpu().numpy(), got)
 
 
+@pytest.mark.parametrize("T,U,boost", [(768, 200, 25.0), (1499, 256, 40.0), (300, 100, -30.0)])
+def test_ctc_blank_dominated_logits_need_more_than_fp64_range(env, T, U, boost):
+    """The recursion runs on probabilities with a binary exponent per state pair (csrc/ctc.hip, round 6), not in log space.  What log
+    space gave for free is range: with a blank-dominated model (early CTC training) the all-blank prefix outweighs the best label path
+    by e^(U x boost) -- e^5000 at U = 200, boost 25: far beyond fp64 -- so a scheme with ONE scale per frame would flush every useful
+    state to zero and report inf.  NLL against the log-space fp64 oracle, gradient against torch autograd; boost < 0 is the opposite
+    corner (blank nearly impossible, the path forced through the labels)."""
+    lib, torch, dev = env
+    B, Vv = 2, 32
+    rng = np.random.default_rng(T + U)
+    logits = rng.normal(size=(B, T, Vv)).astype(np.float32) * 2
+    logits[:, :, 0] += np.float32(boost)
+    labels = rng.integers(1, Vv, size=(B, U)).astype(np.int32)
+    lab_len = np.array([U, U // 2], np.int32)
+    labels[1, lab_len[1]:] = 0
+    log_len = np.array([T, T - 5], np.int32)
+    ref = O.ctc_nll(logits, labels, lab_len, log_len, blank=0)
+    assert np.isfinite(ref).all() and (boost < 0 or ref[0] > 700.0)        # (the premise: the loss is outside exp()'s fp64 range)
+    tl = dev_t(torch, dev, logits)
+    nll = torch.empty((B,), device=dev)
+    grad = torch.full((B, T, Vv), float("nan"), device=dev)
+    N.check(lib.w2v2_ctc_loss(N.ptr(tl), B, T, Vv, N.ptr(dev_t(torch, dev, labels)), U, N.ptr(dev_t(torch, dev, lab_len)),
+                              N.ptr(dev_t(torch, dev, log_len)), 0, N.ptr(nll), N.ptr(grad), stream()))
+    got = nll.cpu().numpy()
+    assert np.allclose(got, ref, rtol=2e-6, atol=1e-3), (got, ref)
+    lt = torch.from_numpy(logits).double().requires_grad_(True)
+    lp = torch.log_softmax(lt, -1).transpose(0, 1)
+    flat = torch.cat([torch.from_numpy(labels[b, :lab_len[b]].astype(np.int64)) for b in range(B)])
+    loss = torch.nn.functional.ctc_loss(lp, flat, torch.from_numpy(log_len.astype(np.int64)), torch.from_numpy(lab_len.astype(np.int64)),
+                                        blank=0, reduction="sum")
+    loss.backward()
+    g = grad.cpu().numpy()
+    assert np.isfinite(g).all()
+    assert H.max_err(g, lt.grad.numpy()) < 1e-5
+
+
 def test_ctc_infeasible_is_inf(env):
     lib, torch, dev = env
     logits = np.zeros((1, 2, 5), np.float32)
