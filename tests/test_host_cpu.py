@@ -627,7 +627,8 @@ def test_bench_stdout_line_is_compact_and_parseable():
     spec = importlib.util.spec_from_file_location("bench_under_test3", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    for name in ("r05_bench_n1.json", "r05_bench_n1_launched.json", "r05_bench_bf16_train_n1.json", "r05_bench_large_robust_bf16_train_n1.json"):
+    for name in ("r05_bench_n1.json", "r05_bench_n1_launched.json", "r05_bench_bf16_train_n1.json", "r05_bench_large_robust_bf16_train_n1.json",
+                 "r06_bench_n1.json", "r06_bench_n1_launched.json", "r06_bench_bf16_train_n1.json", "r06_bench_large_robust_bf16_train_n1.json"):
         with open(os.path.join(root, "profiles", name)) as f:
             full = json.loads(f.read().strip().splitlines()[-1])
         line = json.dumps(bench.compact_line(full))
@@ -645,6 +646,10 @@ def test_bench_stdout_line_is_compact_and_parseable():
         for side in ("configs2_train_bf16", "configs3_large_fwd_f32", "configs4_large_train_bf16"):
             if side in full:
                 assert js[side]["ms_per_step"] == full[side]["ms_per_step"] and js[side]["frac"] == full[side]["roofline"]["frac"]
+    # the line the driver itself would have read in round 6, byte for byte as bench.py printed it on the GPU box
+    with open(os.path.join(root, "profiles", "r06_bench_n1_compact_line.json")) as f:
+        printed = f.read().strip().splitlines()[-1]
+    assert len(printed) < 4096 and json.loads(printed)["roofline"]["frac"] > 0.75 and json.loads(printed)["cpu_baseline"]["kind"] == "port"
     # worst case: every string blown up, every optional object present -> still under the limit, contract keys intact
     full["config"]["workload"] = "w" * 5000
     full["roofline"]["kernel"] = "k" * 5000
