@@ -28,8 +28,6 @@
 // against ~1e-7 per step of the fp32 exp / log on differences above).  Inputs that break it: a frame in which a needed label has
 // softmax probability below e^-745 (fp64 exp flushes to 0), or CTC_NORM consecutive frames whose needed labels all sit below
 // 1e-77: that path is dropped where log space would have charged it its > 700 nats.
-#include <mutex>
-
 #include "common.h"
 
 namespace w2v2 {
@@ -126,8 +124,6 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_kernel(CtcArgs a) {
     U = U < 0 ? 0 : (U > a.U ? a.U : U);
     int Tb = a.logit_len ? a.logit_len[b] : a.uniform_len;
     Tb = Tb < 0 ? 0 : (Tb > a.T ? a.T : Tb);
-    const float* __restrict__ lg = a.logits + (int64_t)b * a.T * a.V;
-
     // A label outside [0, V) (a vocabulary / config mismatch, a -1 pad) would index the frame's probabilities out of bounds:
     // the sample's loss becomes NaN instead (its gradient rows are zeros), and the state uses the blank in its place.
     for (int u = tid; u <= a.U; u += CTC_THREADS) {
@@ -150,7 +146,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_kernel(CtcArgs a) {
     }
     const double* __restrict__ yg = a.y_ws + (int64_t)b * a.T * a.V;      // this sample's softmax rows
     // the neighbour's value at this thread's exponent; if the neighbour sits 2^600 above, the thread adopts ITS exponent (own states: below any rounding)
-    auto align = [&](double nb, int Enb, double& ev, double& od, int& E) -> int {
+    auto align = [&](int Enb, double& ev, double& od, int& E) -> int {
         int d = Enb - E;
         if (d > 600) {
             ev = od = 0.0;
@@ -199,7 +195,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_kernel(CtcArgs a) {
             lds_barrier();
             const double pm1 = in_range ? xv[((t - 1) & 1) * XS + k] : 0.0;         // alpha_{t-1}(2k - 1) ...
             const int Ep = in_range ? xe[((t - 1) & 1) * ES + k] : CTC_NOEXP;       // ... and its exponent
-            const double p = ldexp(pm1, align(pm1, Ep, ev, od, E));
+            const double p = ldexp(pm1, align(Ep, ev, od, E));
             const double n_ev = has_even ? (ev + p) * yb : 0.0;
             od = has_odd ? (od + ev + (skip ? p : 0.0)) * yl : 0.0;
             ev = n_ev;
@@ -278,7 +274,7 @@ __global__ __launch_bounds__(CTC_THREADS) void ctc_kernel(CtcArgs a) {
             const int rb = ((t + 1) & 1);
             const double nb_ev = in_range ? xv[rb * XS + 2 * (k + 1)] : 0.0, nb_od = in_range ? xv[rb * XS + 2 * (k + 1) + 1] : 0.0;   // beta_{t+1}(2k + 2), (2k + 3)
             const int Enb = in_range ? xe[rb * ES + k + 1] : CTC_NOEXP;
-            const int d = align(nb_ev, Enb, ev, od, E);
+            const int d = align(Enb, ev, od, E);
             const double n0 = ldexp(nb_ev, d), n1 = ldexp(nb_od, d);
             const double n_ev = has_even ? (ev + od) * yb : 0.0;
             od = has_odd ? (od + n0 + (skip ? n1 : 0.0)) * yl : 0.0;
@@ -473,13 +469,7 @@ int launch_ctc_x(Profiler* prof, const float* logits, int B, int T, int V, const
     }
     const size_t lds = (size_t)(4 * (U + 3)) * sizeof(double) + (size_t)(((2 * (U + 3) + 3) & ~3) + ((U + 1 + 3) & ~3)) * sizeof(int) + 16;
     W2V2_REQUIRE(U + 1 <= CTC_THREADS, "ctc: %d labels per row; this build holds one state pair per thread, up to %d", U, CTC_THREADS - 1);
-    W2V2_REQUIRE(lds <= 60 * 1024, "ctc: U=%d needs %zu B of LDS", U, lds);
-    static std::once_flag attr_once;                       // (several host threads may each drive their own model)
-    hipError_t attr_err = hipSuccess;
-    std::call_once(attr_once, [&] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(ctc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    });
-    W2V2_HIP_CHECK(attr_err);
+    W2V2_REQUIRE(lds <= 60 * 1024, "ctc: U=%d needs %zu B of LDS", U, lds);          // (under the 64 KiB a kernel gets without opting in)
     ProfScope ps(prof, FAM_CTC, 30.0 * B * (double)T * (2 * U + 1), 4.0 * B * (double)T * V * (grad ? 2 : 1), s);
     W2V2_LAUNCH(ctc_softmax_kernel, dim3((unsigned)(((int64_t)B * T + 3) / 4)), dim3(256), 0, s, a);
     W2V2_LAUNCH(ctc_kernel, dim3(B, grad ? 2 : 1), dim3(CTC_THREADS), lds, s, a);
